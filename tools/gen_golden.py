@@ -1,0 +1,388 @@
+"""Generate tests/golden/*.npz by RUNNING the real reference (dev container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+
+Imports /root/reference through tools/refshim.py, pins the qconfig to
+get_default_qat_qconfig('qnnpack', version=0) and dumps inputs-by-seed / outputs as small fixtures.
+Fixtures hold DATA only (seeds, shapes, expected outputs); no reference source travels.
+Inputs are regenerated on the consumer side with oracle.frost_oracle.synth(shape, seed).
+"""
+import os
+import sys
+import warnings
+import zlib
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import numpy as np
+import torch
+
+import refshim
+from oracle.frost_oracle import synth, synth_state, float_to_qat_key, sample_big
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+META = dict(torch_version=torch.__version__, qconfig="qnnpack", qconfig_version=0,
+            threads=torch.get_num_threads(), mkldnn=bool(torch.backends.mkldnn.enabled))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrs):
+    arrs = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    for k, v in META.items():
+        arrs["meta_" + k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KB, {len(arrs)} arrays")
+
+
+def crc(a):
+    return np.uint32(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def fq_idx(y, mod):
+    s, zp = float(mod.scale[0]), int(mod.zero_point[0])
+    return torch.round(y.detach() / s + zp).to(torch.int16)
+
+
+def sd_np(sd, prefix=""):
+    """Non-parameter state only (BN stats, observer scalars): weights are regenerated from seeds."""
+    return {prefix + k.replace(".", "/"): v.detach().cpu().numpy().copy() for k, v in sd.items()
+            if not (k.endswith(".weight") or k.endswith(".bias"))}
+
+
+def load_synth(m, seed0):
+    """Fill a FLOAT module with synth_state values; returns (keys, shapes) for the fixture."""
+    sd = m.state_dict()
+    keys = list(sd.keys())
+    shapes = [tuple(v.shape) for v in sd.values()]
+    m.load_state_dict(synth_state(keys, shapes, seed0))
+    return np.array(keys), np.array([list(s) + [0] * (4 - len(s)) for s in shapes]), np.array([len(s) for s in shapes])
+
+
+def grad_pack(g):
+    g = g.detach().double().numpy()
+    return np.concatenate([[g.sum(), np.abs(g).sum(), np.sqrt((g * g).sum())], sample_big(g)]).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------ G1
+def g1_fake_quant():
+    edge = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 254.5, 255.5, 256.4, -0.4, -0.6, 300.0], requires_grad=True)
+    y = torch.fake_quantize_per_tensor_affine(edge, 1.0, 0, 0, 255)
+    y.sum().backward()
+    out = dict(edge_x=edge, edge_y=y, edge_mask=edge.grad)
+    cases = [("act", 0.0371, 121, 0, 255, 11), ("wgt", 0.00527, 0, -128, 127, 12), ("act0", 0.0213, 0, 0, 255, 13)]
+    for name, s, zp, qmin, qmax, seed in cases:
+        x = T(synth((4099,), seed) * (3.0 if name != "wgt" else 0.5)).requires_grad_(True)
+        g = T(synth((4099,), seed + 100))
+        y = torch.fake_quantize_per_tensor_affine(x, torch.tensor(s), torch.tensor(zp, dtype=torch.int32), qmin, qmax)
+        y.backward(g)
+        out.update({f"{name}_qp": np.array([s, zp, qmin, qmax, seed], dtype=np.float64),
+                    f"{name}_y": y, f"{name}_dx": x.grad})
+    save("g1_fake_quant", **out)
+
+
+# ------------------------------------------------------------------------------------------ G2
+def g2_observer():
+    from torch.ao.quantization import get_default_qat_qconfig
+    out = {}
+    for ver in (0, 1):
+        qc = get_default_qat_qconfig("qnnpack", version=ver)
+        for name, ctor, scale in (("act", qc.activation, 2.5), ("wgt", qc.weight, 0.3)):
+            m = ctor()
+            m.train()
+            rows = []
+            for step in range(3):
+                x = T(synth((3, 8, 5, 5), 200 + step) * scale * (1 + 0.3 * step) + (0.4 if name == "act" else 0.0))
+                y = m(x)
+                ap = m.activation_post_process if hasattr(m, "activation_post_process") else m
+                rows.append([float(ap.min_val), float(ap.max_val), float(m.scale.reshape(-1)[0]),
+                             float(m.zero_point.reshape(-1)[0])])
+                out[f"v{ver}_{name}_y{step}"] = y
+            out[f"v{ver}_{name}_traj"] = np.array(rows, dtype=np.float32)
+            out[f"v{ver}_{name}_inscale"] = np.float32(scale)
+    save("g2_observer", **out)
+
+
+# ------------------------------------------------------------------------------------------ G3
+def g3_layers():
+    ref, _ = refshim.load_frostnet()
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    specs = [  # name, kind, cin, cout, k, s, groups, H
+        ("stem", "cbr", 3, 32, 3, 2, 1, 16),
+        ("pw16_96", "cbr", 16, 96, 1, 1, 1, 12),
+        ("dw3s2_96", "cbr", 96, 96, 3, 2, 96, 12),
+        ("dw5s2_144", "cbr", 144, 144, 5, 2, 144, 10),
+        ("dw5s1_624", "cbr", 624, 624, 5, 1, 624, 6),
+        ("pw624_96_lin", "cb", 624, 96, 1, 1, 1, 6),
+        ("pw288_1728", "cbr", 288, 1728, 1, 1, 1, 3),
+        ("pw1728_320_lin", "cb", 1728, 320, 1, 1, 1, 3),
+    ]
+    for i, (name, kind, cin, cout, k, s, groups, H) in enumerate(specs):
+        cls = ref.ConvBNReLU if kind == "cbr" else ref.ConvBN
+        m = cls(cin, cout, k, s, (k - 1) // 2, 1, groups)
+        keys, shapes, ndims = load_synth(m, 3000 + 20 * i)
+        m.train()
+        m.fuse_model()
+        m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+        prepare_qat(m, inplace=True)
+        fused = m.conv[0]
+        # teacher-forced input: an already fake-quantised activation (uint8 index * scale)
+        in_scale, in_zp = 0.0231, (0 if i % 2 == 0 else 117)
+        xi = np.clip(np.round(synth((2, cin, H, H), 360 + i) * 40 + 128 + (0 if in_zp else -60)), 0, 255)
+        x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+        outs = {}
+        for step in range(2):  # two steps so the EMA branch of both observers is hit
+            x.grad = None
+            m.zero_grad()
+            y = m(x)
+            g = T(synth(tuple(y.shape), 370 + i + 50 * step))
+            y.backward(g)
+            outs[f"s{step}_yidx"] = fq_idx(y, fused.activation_post_process).to(torch.uint8)
+            outs[f"s{step}_dx"] = x.grad.clone()
+            outs[f"s{step}_dw"] = grad_pack(fused.weight.grad)
+            outs[f"s{step}_dgamma"] = fused.bn.weight.grad.clone()
+            outs[f"s{step}_dbeta"] = fused.bn.bias.grad.clone()
+            outs.update(sd_np(m.state_dict(), f"s{step}_sd/"))
+        save(f"g3_{name}", spec=np.array([cin, cout, k, s, groups, H, 2, 360 + i, 370 + i, int(kind == "cbr"),
+                                          3000 + 20 * i]),
+             in_qp=np.array([in_scale, in_zp]), x_idx=xi.astype(np.uint8), init_keys=keys, init_shapes=shapes,
+             init_ndims=ndims, **outs)
+
+
+# ------------------------------------------------------------------------------------------ G4
+def g4_blocks():
+    ref, _ = refshim.load_frostnet()
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    specs = [  # name, cin, cout, k, s, e, r, H
+        ("dw_e1", 32, 16, 3, 1, 1, 1, 8),
+        ("mb", 16, 24, 3, 2, 6, 4, 8),
+        ("cas_res", 80, 80, 5, 1, 3, 4, 6),
+        ("cas_nores", 80, 96, 5, 1, 6, 4, 6),
+        ("cas_s2", 40, 80, 5, 2, 6, 4, 8),
+    ]
+    for i, (name, cin, cout, k, s, e, r, H) in enumerate(specs):
+        for quantized in (True, False):
+            m = ref.CascadePreExBottleneck(cin, cout, quantized=quantized, kernel_size=k, stride=s, expand_ratio=e,
+                                           reduce_factor=r)
+            keys, shapes, ndims = load_synth(m, 4000 + 100 * i)
+            m.train()
+            if quantized:
+                for mod in m.modules():
+                    if type(mod) in (ref.ConvBNReLU, ref.ConvBN):
+                        mod.fuse_model()
+                m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+                prepare_qat(m, inplace=True)
+            if quantized:
+                in_scale, in_zp = 0.0187, 109
+                xi = np.clip(np.round(synth((2, cin, H, H), 460 + i) * 45 + 120), 0, 255).astype(np.uint8)
+                x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+            else:
+                xi = np.zeros(1)
+                x = T(synth((2, cin, H, H), 460 + i)).requires_grad_(True)
+            outs = {}
+            for step in range(2):
+                x.grad = None
+                m.zero_grad()
+                y = m(x)
+                g = T(synth(tuple(y.shape), 470 + i + 50 * step))
+                y.backward(g)
+                outs[f"s{step}_y"] = y.detach().clone()
+                outs[f"s{step}_dx"] = x.grad.clone()
+                for pn, p in m.named_parameters():
+                    outs[f"s{step}_grad/" + pn.replace(".", "/")] = grad_pack(p.grad)
+                outs.update(sd_np(m.state_dict(), f"s{step}_sd/"))
+            tag = "q" if quantized else "f"
+            save(f"g4_{name}_{tag}", spec=np.array([cin, cout, k, s, e, r, H, 2, 460 + i, 470 + i, 4000 + 100 * i]),
+                 in_qp=np.array([0.0187, 109]) if quantized else np.zeros(2), x_idx=xi,
+                 init_keys=keys, init_shapes=shapes, init_ndims=ndims, **outs)
+
+
+# ------------------------------------------------------------------------------------------ G5
+def _pgrads(net):
+    ps = list(net.named_parameters())
+    return dict(grad_norms=np.array([float(p.grad.double().norm()) for _, p in ps]),
+                grad_sums=np.array([float(p.grad.double().sum()) for _, p in ps]),
+                param_names=np.array([n for n, _ in ps]))
+
+
+def g5_wholenet():
+    _, reg = refshim.load_frostnet()
+    out = {}
+    # kaiming-init parity of the module itself (M9): same seed -> same weights
+    torch.manual_seed(1882)
+    net = reg["frostnet_small_1_0"](drop_rate=0.0)
+    out["init1882_small_conv1_crc"] = crc(net.state_dict()["conv1.conv.0.weight"].numpy())
+    out["init1882_small_cls_crc"] = crc(net.state_dict()["classifier.2.weight"].numpy())
+    # FP32 eval logits, Small B=1 @224 (config c1) and Large B=2 @224 (c2 reference); synth weights
+    for mode, B, seed in (("small", 1, 500), ("large", 2, 501)):
+        net = reg[f"frostnet_{mode}_1_0"](drop_rate=0.0)
+        load_synth(net, 5000)
+        net.eval()
+        x = T(synth((B, 3, 224, 224), seed))
+        with torch.no_grad():
+            y = net(x)
+        out[f"fp32_eval_{mode}_logits"] = y
+        out[f"fp32_eval_{mode}_spec"] = np.array([B, 224, seed, 5000])
+    save("g5_fp32_eval", **out)
+
+    # FP32 train-mode fwd+bwd, Large B=2 @64
+    net = reg["frostnet_large_1_0"](drop_rate=0.0)
+    load_synth(net, 5000)
+    net.train()
+    x = T(synth((2, 3, 64, 64), 510))
+    tgt = torch.tensor([3, 997])
+    y = net(x)
+    loss = torch.nn.functional.cross_entropy(y, tgt)
+    loss.backward()
+    save("g5_fp32_train", spec=np.array([2, 64, 510, 5000]), target=tgt, logits=y, loss=loss, **_pgrads(net),
+         rm_last=net.last_layer.conv[1].running_mean, rv_last=net.last_layer.conv[1].running_var,
+         grad_stem=net.conv1.conv[0].weight.grad, grad_cls_b=net.classifier[2].bias.grad)
+
+    # QAT: Large B=2 @64. two train fwd+bwd steps (first-call observers, then EMA), then eval logits.
+    net = reg["frostnet_quant_large_1_0"](drop_rate=0.0)
+    load_synth(net, 5000)
+    refshim.qat_prepare(net, version=0)
+    out = dict(spec=np.array([2, 64, 520, 5000]), target=tgt)
+    for step in range(2):
+        net.zero_grad()
+        x = T(synth((2, 3, 64, 64), 520 + step))
+        y = net(x)
+        loss = torch.nn.functional.cross_entropy(y, tgt)
+        loss.backward()
+        out[f"s{step}_logits"] = y
+        out[f"s{step}_loss"] = loss
+        for k_, v in _pgrads(net).items():
+            out[f"s{step}_{k_}"] = v
+        sd = net.state_dict()
+        keys = [k for k in sd if k.endswith("scale") or k.endswith("zero_point") or k.endswith("min_val")
+                or k.endswith("max_val")]
+        out[f"s{step}_qkeys"] = np.array(keys)
+        out[f"s{step}_qvals"] = np.array([float(sd[k].reshape(-1)[0]) for k in keys], dtype=np.float64)
+    net.eval()
+    with torch.no_grad():
+        ye = net(T(synth((2, 3, 64, 64), 529)))
+    out["eval_logits"] = ye
+    save("g5_qat_large", **out)
+
+
+# ------------------------------------------------------------------------------------------ G6
+def g6_optimizers():
+    opt = refshim.load_optimizer()
+    n = 53
+    out = {}
+    confs = {
+        "QSGD": (opt.QSGD, dict(lr=5e-3, momentum=0.9, weight_decay=1e-5, nesterov=True, clip_by=1e-3, toss_coin=True,
+                                noise_decay=1e-2)),
+        "QSGD_plain": (opt.QSGD, dict(lr=1e-2, momentum=0.9, weight_decay=0.0, nesterov=False, clip_by=0.0,
+                                      toss_coin=False, noise_decay=5e-2)),
+        "QRMS": (opt.QRMSprop, dict(lr=1e-3, alpha=0.9, momentum=0.9, eps=1e-8, weight_decay=1e-5, clip_by=1e-3,
+                                    toss_coin=True, noise_decay=1e-2)),
+        "QAdam": (opt.QAdam, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=False, clip_by=1e-3,
+                                  toss_coin=True, noise_decay=1e-2)),
+        "QAdam_ams": (opt.QAdam, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=True,
+                                      clip_by=1e-3, toss_coin=True, noise_decay=1e-2)),
+        "QAdamW": (opt.QAdamW, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False,
+                                    clip_by=1e-3, toss_coin=True, noise_decay=1e-2)),
+    }
+    real_laplace, real_random_ = np.random.laplace, torch.Tensor.random_
+    for name, (cls, kw) in confs.items():
+        p = torch.nn.Parameter(T(synth((n,), 600)) * 0.1)
+        o = cls([p], **kw)
+        traj_p, noises, coins = [], [], []
+        for step in range(6):  # 3 warm-up + 3 boost
+            if step == 3:
+                o.is_warmup = False
+            p.grad = T(synth((n,), 610 + step)) * 0.01
+            nz = np.abs(synth((n,), 620 + step)) * 1.3 + 0.01   # injected Laplace draw (sign irrelevant: abs)
+            cn = (synth((n,), 630 + step, "uniform") > 0).astype(np.float32)
+            np.random.laplace = lambda a, b, size, _nz=nz: _nz.astype(np.float64).reshape(tuple(size))
+
+            def fake_random_(self, *a, _cn=cn, **k):
+                return self.copy_(T(_cn).reshape(self.shape))
+            torch.Tensor.random_ = fake_random_
+            try:
+                o.step()
+            finally:
+                np.random.laplace, torch.Tensor.random_ = real_laplace, real_random_
+            traj_p.append(p.detach().clone().numpy())
+            noises.append(nz)
+            coins.append(cn)
+        st = o.state[p]
+        out[f"{name}_p"] = np.stack(traj_p)
+        out[f"{name}_noise"] = np.stack(noises)
+        out[f"{name}_coin"] = np.stack(coins)
+        for k_, v in st.items():
+            out[f"{name}_state_{k_}"] = v if isinstance(v, torch.Tensor) else np.asarray(v)
+        out[f"{name}_gfinal"] = p.grad.clone()      # reference mutates p.grad in place
+    save("g6_optimizers", n=n, **out)
+
+
+# ------------------------------------------------------------------------------------------ G7
+def g7_scalars():
+    helpers = refshim.load_helpers()
+    _, reg = refshim.load_frostnet()
+
+    class A:
+        pass
+    a = A()
+    a.anneal, a.epochs, a.warmup_epochs, a.warmup_lr, a.lr, a.restart_epochs = False, 400, 5, 0.0, 5e-3, 100
+
+    class FakeOpt:
+        param_groups = [dict(lr=0.0)]
+    pts = [(0, 0), (0, 1), (0, 2), (2, 7), (5, 0), (100, 3), (399, 9)]
+    lrs = [helpers.adjust_learning_rate_cosine(FakeOpt(), ep, it, 10, a) for ep, it in pts]
+    out = dict(lr_points=np.array(pts), lr_values=np.array(lrs, dtype=np.float64))
+    for mode in ("large", "base", "small"):
+        for wm, tag in ((1.0, "1_0"), (0.5, "0_5"), (1.25, "1_25")):
+            net = reg[f"frostnet_quant_{mode}_{tag}"](drop_rate=0.0)
+            names = [n for n, _ in net.named_parameters()]
+            shapes = [tuple(p.shape) for _, p in net.named_parameters()]
+            out[f"{mode}_{tag}_param_names"] = np.array(names)
+            out[f"{mode}_{tag}_param_numel"] = np.array([int(np.prod(s)) for s in shapes])
+            out[f"{mode}_{tag}_param_shape4"] = np.array([list(s) + [0] * (4 - len(s)) for s in shapes])
+            out[f"{mode}_{tag}_float_keys"] = np.array(list(net.state_dict().keys()))
+            if tag == "1_0":
+                refshim.qat_prepare(net, version=0)
+                out[f"{mode}_{tag}_qat_keys"] = np.array(list(net.state_dict().keys()))
+    # param-group element counts, Large (train.py:129-137)
+    net = reg["frostnet_quant_large_1_0"]()
+    dw = sum(p.numel() for p in net.parameters() if p.dim() == 4 and p.shape[1] == 1)
+    dense = sum(p.numel() for p in net.parameters() if p.dim() == 4 and p.shape[1] != 1)
+    other = sum(p.numel() for p in net.parameters() if p.dim() != 4)
+    out["large_group_counts"] = np.array([dw, dense, other])
+    save("g7_scalars", **out)
+
+
+# ------------------------------------------------------------------------------------------ G8
+def g8_features():
+    feat = refshim.load_features()
+    net = feat.FrostNet(mode="large", width_mult=1.0)
+    load_synth(net, 5000)
+    net.eval()
+    x = T(synth((1, 3, 128, 128), 800))
+    with torch.no_grad():
+        fs = net(x)
+    out = dict(spec=np.array([1, 128, 800, 5000]))
+    for i, f in enumerate(fs):
+        out[f"f{i}_shape"] = np.array(f.shape)
+        out[f"f{i}_sum"] = np.float64(f.double().sum())
+        out[f"f{i}_abssum"] = np.float64(f.double().abs().sum())
+        out[f"f{i}_crop"] = f[0, :8, :4, :4].clone()
+    out["keys"] = np.array(list(net.state_dict().keys()))
+    save("g8_features", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
+               g7=g7_scalars, g8=g8_features)
+    for w in which:
+        fns[w]()
