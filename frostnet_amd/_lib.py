@@ -1,0 +1,114 @@
+"""ctypes binding of libfrost_hip.so (include/frost_hip.h).  The product path: there is NO CPU fallback --
+if the library is missing or a call fails this raises."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrost_hip.so")
+_lib = None
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_FLAGS, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 7, 8
+COEF_ROWS = 8
+STATS_BYTES_PER_CH = 24
+
+
+class FrostWDesc(C.Structure):
+    _fields_ = [("w", P), ("gamma", P), ("rvar", P), ("qrec", P), ("wq_pack", P), ("wsum", P), ("minmax2", P),
+                ("wt_pack", P), ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32), ("kind", C.c_int32),
+                ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
+
+
+class FrostOptTensor(C.Structure):
+    _fields_ = [("p", P), ("g", P), ("exp_min", P), ("exp_max", P), ("coin", P), ("buf0", P), ("buf1", P), ("buf2", P),
+                ("n", C.c_int64), ("weight_decay", F), ("lr", F), ("first_step", C.c_int32), ("pad", C.c_int32)]
+
+
+class FrostOptHyper(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("boost", C.c_int32), ("toss_coin", C.c_int32), ("nesterov", C.c_int32),
+                ("amsgrad", C.c_int32), ("centered", C.c_int32), ("beta", F), ("momentum", F), ("dampening", F),
+                ("alpha", F), ("eps", F), ("beta1", F), ("beta2", F), ("clip_by", F), ("bc_beta", F),
+                ("noise_scale", F), ("bc1", F), ("bc2", F), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+_PROTOS = {
+    "frost_abi_version": [],
+    "frost_minmax_f32": [P, L, P, P],
+    "frost_fill_minmax": [P, I, P],
+    "frost_minmax_input": [P, I, I, I, I, L, L, L, L, P, P],
+    "frost_observer_update": [P, P, I, I, I, P],
+    "frost_quantize_input": [P, I, I, I, I, L, L, L, L, P, P, I, P],
+    "frost_fake_quant_f32": [P, L, P, I, I, P, P, P],
+    "frost_fake_quant_bwd_f32": [P, P, L, P, P],
+    "frost_dequant_act": [P, L, P, P, P],
+    "frost_weight_prep": [P, I, I, I, I, P],
+    "frost_stats_init_table": [P, P, P, I, P],
+    "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
+    "frost_dw_conv_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P],
+    "frost_stem_conv_fwd": [P, P, P, P, I, I, I, I, I, P, P, P, I, P, P],
+    "frost_conv_finalize": [P, L, I, P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "frost_cat_observe": [P, P, P, I, P],
+    "frost_cat_requant": [P, P, I, P, P, I, L, P, P, P],
+    "frost_add_minmax": [P, P, P, P, L, P, P],
+    "frost_add_requant": [P, P, P, P, L, P, P, P],
+    "frost_avgpool": [P, P, I, I, I, P, P, P],
+    "frost_classifier_fwd": [P, P, P, P, I, I, I, P, P],
+    "frost_pw_conv_bwd": [P, P, P, P, P, P, L, I, I, I, P, P, I, P, P, P, I, P],
+    "frost_pw_wgrad": [P, P, P, L, I, I, P, P],
+    "frost_dw_conv_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
+    "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
+    "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
+    "frost_stem_conv_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
+    "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
+    "frost_save_sigma": [P, P, I, P],
+    "frost_mask_logits": [P, P, P, L, P, P],
+    "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],
+    "frost_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
+    "frost_head_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "frost_gradboost_step": [P, I, L, P, P, P, P, P],
+}
+SYMBOLS = sorted(list(_PROTOS) + ["frost_last_error"])
+
+
+def load_library():
+    """Load (once) and return the ctypes handle. Raises if the shared library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python __graft_entry__.py` (build()) first. "
+                           "frostnet_amd has no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.frost_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    lib = load_library()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.frost_last_error().decode()}")
+
+
+def struct_to_tensor(arr, device):
+    """ctypes array/struct -> uint8 device tensor (descriptor tables live in device memory)."""
+    raw = bytes(memoryview(arr).cast("B"))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)

@@ -1,0 +1,114 @@
+// Shared device/host helpers for libfrost_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/frost_hip.h"
+
+#define FROST_BN_EPS 1e-5f
+#define FROST_BN_MOM 0.1f
+#define FROST_OBS_C 0.01f
+#define FROST_F32_EPS 1.1920928955078125e-07f
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+extern "C" void frost_set_error(const char* msg);
+int frost_check_launch(const char* what);
+
+#define FROST_REQUIRE(cond, msg) \
+  do { if (!(cond)) { frost_set_error(msg); return 1; } } while (0)
+
+__host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- qrecord access ---------------------------------------------------------------------------------------
+struct QP { float scale, inv; int zp; };
+__device__ __forceinline__ QP load_qp(const float* q) {
+  QP r; r.scale = q[FROST_Q_SCALE]; r.zp = __float_as_int(q[FROST_Q_ZP]); r.inv = 1.0f / r.scale; return r;
+}
+// fake-quantise to the uint8 index (torch fake_quantize_per_tensor_affine): q = clamp(rint(x*inv)+zp, lo, hi)
+__device__ __forceinline__ int fq_index(float x, float inv, int zp, int lo, int hi, bool* inrange = nullptr) {
+  float qf = rintf(x * inv) + (float)zp;   // same fp32 op order as aten: zp + nearbyint(x*inv)
+  if (inrange) *inrange = (qf >= (float)lo) && (qf <= (float)hi);
+  qf = fminf(fmaxf(qf, (float)lo), (float)hi);
+  return (int)qf;
+}
+
+// ---- bf16 ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// ---- ordered float atomics ---------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.0f) atomicMin((int*)addr, __float_as_int(v));
+  else atomicMax((unsigned int*)addr, __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// observer EMA + qparams, shared by every finalize-type kernel (Appendix B of SURVEY.md).
+// cur_lo/cur_hi: min/max of the current tensor. Writes all qrecord fields. One thread.
+__device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi, int symmetric, int rule127,
+                                           int observe) {
+  float mn = q[FROST_Q_MIN], mx = q[FROST_Q_MAX];
+  if (observe) {
+    if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = cur_lo; mx = cur_hi; }
+    else { mn = mn + FROST_OBS_C * (cur_lo - mn); mx = mx + FROST_OBS_C * (cur_hi - mx); }
+    q[FROST_Q_MIN] = mn; q[FROST_Q_MAX] = mx;
+    float scale; int zp = 0;
+    if (mx < mn) { scale = 1.0f; zp = 0; }
+    else {
+      float mn_neg = fminf(mn, 0.0f), mx_pos = fmaxf(mx, 0.0f);
+      if (symmetric) {
+        if (rule127) scale = fmaxf(-mn_neg / 128.0f, mx_pos / 127.0f);
+        else scale = fmaxf(-mn_neg, mx_pos) / 127.5f;
+        scale = fmaxf(scale, FROST_F32_EPS);
+      } else {
+        scale = (mx_pos - mn_neg) / 255.0f;
+        scale = fmaxf(scale, FROST_F32_EPS);
+        zp = 0 - (int)rintf(mn_neg / scale);
+        zp = min(max(zp, 0), 255);
+      }
+    }
+    q[FROST_Q_SCALE] = scale; q[FROST_Q_ZP] = __int_as_float(zp);
+  }
+  float scale = q[FROST_Q_SCALE]; int zp = __float_as_int(q[FROST_Q_ZP]);
+  float inv = 1.0f / scale;
+  q[FROST_Q_INV] = inv;
+  int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : 255;
+  int ilo = fq_index(cur_lo, inv, zp, lo, hi), ihi = fq_index(cur_hi, inv, zp, lo, hi);
+  q[FROST_Q_FQMIN] = (float)(ilo - zp) * scale;
+  q[FROST_Q_FQMAX] = (float)(ihi - zp) * scale;
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

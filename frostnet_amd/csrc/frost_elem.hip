@@ -1,0 +1,481 @@
+// Element-wise, observer, weight-prep, finalize, cat/add and head kernels (HBM-bound byte/float work).
+#include "frost_common.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[256] = "";
+extern "C" void frost_set_error(const char* msg) { strncpy(g_err, msg, sizeof(g_err) - 1); }
+extern "C" const char* frost_last_error(void) { return g_err; }
+extern "C" int frost_abi_version(void) { return FROST_ABI_VERSION; }
+int frost_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -(int)e;
+  }
+  return 0;
+}
+
+static inline int grid_for(int64_t n, int per_block, int cap = 4096) {
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+// ------------------------------------------------------------------------------------------------ min/max
+__global__ void k_fill_minmax(float* out2, int count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) { out2[2 * i] = INFINITY; out2[2 * i + 1] = -INFINITY; }
+}
+extern "C" int frost_fill_minmax(float* out2, int count, void* stream) {
+  hipLaunchKernelGGL(k_fill_minmax, dim3((count + 255) / 256), dim3(256), 0, as_stream(stream), out2, count);
+  return frost_check_launch("fill_minmax");
+}
+
+__device__ __forceinline__ void block_minmax_commit(float lo, float hi, float* out2) {
+  __shared__ float slo[4], shi[4];
+  lo = wave_min(lo); hi = wave_max(hi);
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { slo[w] = lo; shi[w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
+    atomic_min_f32(out2, lo); atomic_max_f32(out2 + 1, hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_f32(const float* __restrict__ x, int64_t n, float* out2) {
+  float lo = INFINITY, hi = -INFINITY;
+  int64_t n4 = n >> 2;
+  const float4* x4 = (const float4*)x;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 v = x4[i];
+    lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+    hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = x[(n4 << 2) + threadIdx.x]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+  block_minmax_commit(lo, hi, out2);
+}
+extern "C" int frost_minmax_f32(const float* x, int64_t n, float* out2, void* stream) {
+  FROST_REQUIRE(((uintptr_t)x & 15) == 0, "minmax: x must be 16B aligned");
+  hipLaunchKernelGGL(k_minmax_f32, dim3(grid_for(n, 1024, 2048)), dim3(256), 0, as_stream(stream), x, n, out2);
+  return frost_check_launch("minmax_f32");
+}
+
+__global__ void k_observer_update(float* q, const float* cur2, int symmetric, int rule127, int observe) {
+  if (threadIdx.x == 0) observer_update_dev(q, cur2[0], cur2[1], symmetric, rule127, observe);
+}
+extern "C" int frost_observer_update(float* qrec, const float* cur2, int symmetric, int rule127, int observe,
+                                     void* stream) {
+  hipLaunchKernelGGL(k_observer_update, dim3(1), dim3(64), 0, as_stream(stream), qrec, cur2, symmetric, rule127, observe);
+  return frost_check_launch("observer_update");
+}
+
+// ------------------------------------------------------------------------------------------------ input quant
+__global__ __launch_bounds__(256) void k_quantize_input(const float* __restrict__ x, int n, int c, int h, int w,
+                                                        int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                                        const float* __restrict__ qrec, int8_t* __restrict__ out, int cpad) {
+  QP q = load_qp(qrec);
+  int64_t npix = (int64_t)n * h * w;
+  for (int64_t p = blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    int xw = (int)(p % w); int64_t t = p / w; int yh = (int)(t % h); int in = (int)(t / h);
+    const float* px = x + in * sn + yh * sh + xw * sw;
+    uint32_t packed = 0;
+    for (int ch = 0; ch < cpad; ++ch) {
+      int idx = q.zp;
+      if (ch < c) idx = fq_index(px[ch * sc], q.inv, q.zp, 0, 255);
+      packed |= ((uint32_t)((idx - 128) & 255)) << (8 * (ch & 3));
+      if ((ch & 3) == 3) { *(uint32_t*)(out + p * cpad + ch - 3) = packed; packed = 0; }
+    }
+  }
+}
+extern "C" int frost_quantize_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                    int64_t sw, const float* qrec, int8_t* out, int cpad, void* stream) {
+  FROST_REQUIRE(cpad % 4 == 0 && cpad >= c, "quantize_input: cpad must be a multiple of 4 and >= c");
+  hipLaunchKernelGGL(k_quantize_input, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0, as_stream(stream), x, n,
+                     c, h, w, sn, sc, sh, sw, qrec, out, cpad);
+  return frost_check_launch("quantize_input");
+}
+
+// strided min/max of the logical (N,C,H,W) fp32 input (the QuantStub observer)
+__global__ __launch_bounds__(256) void k_minmax_strided(const float* __restrict__ x, int n, int c, int h, int w,
+                                                        int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* out2) {
+  float lo = INFINITY, hi = -INFINITY;
+  int64_t tot = (int64_t)n * c * h * w;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    // iterate in memory-friendly order for both NCHW-contiguous and channels_last: decode as (n, h, w, c) if sc==1
+    int64_t t = i; float v;
+    if (sc == 1) { int ch = (int)(t % c); t /= c; int xw = (int)(t % w); t /= w; int yh = (int)(t % h); int in = (int)(t / h);
+      v = x[in * sn + ch * sc + yh * sh + xw * sw]; }
+    else { int xw = (int)(t % w); t /= w; int yh = (int)(t % h); t /= h; int ch = (int)(t % c); int in = (int)(t / c);
+      v = x[in * sn + ch * sc + yh * sh + xw * sw]; }
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  block_minmax_commit(lo, hi, out2);
+}
+extern "C" int frost_minmax_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                  int64_t sw, float* out2, void* stream) {
+  hipLaunchKernelGGL(k_minmax_strided, dim3(grid_for((int64_t)n * c * h * w, 1024, 2048)), dim3(256), 0,
+                     as_stream(stream), x, n, c, h, w, sn, sc, sh, sw, out2);
+  return frost_check_launch("minmax_input");
+}
+
+// ------------------------------------------------------------------------------------------------ generic FQ
+__global__ __launch_bounds__(256) void k_fake_quant_f32(const float* __restrict__ x, int64_t n, const float* qrec, int qmin,
+                                                        int qmax, float* __restrict__ y, uint8_t* __restrict__ mask) {
+  QP q = load_qp(qrec);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    bool in; int idx = fq_index(x[i], q.inv, q.zp, qmin, qmax, &in);
+    y[i] = (float)(idx - q.zp) * q.scale;
+    if (mask) mask[i] = in ? 1 : 0;
+  }
+}
+extern "C" int frost_fake_quant_f32(const float* x, int64_t n, const float* qrec, int qmin, int qmax, float* y,
+                                    uint8_t* mask, void* stream) {
+  hipLaunchKernelGGL(k_fake_quant_f32, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), x, n, qrec, qmin, qmax, y, mask);
+  return frost_check_launch("fake_quant_f32");
+}
+__global__ __launch_bounds__(256) void k_fake_quant_bwd_f32(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                            int64_t n, float* __restrict__ dx) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = mask[i] ? dy[i] : 0.0f;
+}
+extern "C" int frost_fake_quant_bwd_f32(const float* dy, const uint8_t* mask, int64_t n, float* dx, void* stream) {
+  hipLaunchKernelGGL(k_fake_quant_bwd_f32, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), dy, mask, n, dx);
+  return frost_check_launch("fake_quant_bwd_f32");
+}
+__global__ __launch_bounds__(256) void k_dequant_act(const int8_t* __restrict__ qv, int64_t n, const float* qrec, float* __restrict__ y) {
+  QP q = load_qp(qrec);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (float)((int)qv[i] + 128 - q.zp) * q.scale;
+}
+extern "C" int frost_dequant_act(const int8_t* qv, int64_t n, const float* qrec, float* y, void* stream) {
+  hipLaunchKernelGGL(k_dequant_act, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), qv, n, qrec, y);
+  return frost_check_launch("dequant_act");
+}
+
+// ------------------------------------------------------------------------------------------------ weight prep
+__device__ __forceinline__ float w_scaled(const FrostWDesc& d, int co, int rest) {
+  float wv = d.w[(int64_t)co * d.cin_g * d.kk + rest];
+  if (d.gamma) { float sf = d.gamma[co] / sqrtf(d.rvar[co] + FROST_BN_EPS); wv = wv * sf; }
+  return wv;
+}
+__global__ __launch_bounds__(256) void k_wprep_minmax(const FrostWDesc* descs) {
+  const FrostWDesc d = descs[blockIdx.y];
+  int per = d.cin_g * d.kk; int64_t tot = (int64_t)d.cout * per;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int co = (int)(i / per);
+    float v = w_scaled(d, co, (int)(i - (int64_t)co * per));
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  block_minmax_commit(lo, hi, d.minmax2);
+}
+__global__ void k_wprep_observe(const FrostWDesc* descs, int nlayers, int rule127, int observe) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlayers) return;
+  const FrostWDesc d = descs[i];
+  observer_update_dev(d.qrec, d.minmax2[0], d.minmax2[1], 1, rule127, observe);
+  d.minmax2[0] = INFINITY; d.minmax2[1] = -INFINITY;
+}
+__device__ __forceinline__ int wq_at(const FrostWDesc& d, float inv, int co, int rest) {
+  return fq_index(w_scaled(d, co, rest), inv, 0, -128, 127);
+}
+// pack kernel: one thread per packed dword
+__global__ __launch_bounds__(256) void k_wprep_pack(const FrostWDesc* descs) {
+  const FrostWDesc d = descs[blockIdx.y];
+  float inv = 1.0f / d.qrec[FROST_Q_SCALE];
+  if (d.kind == 0) {            // pointwise: [ct][ks][lane][16B]; also bf16 transposed pack [cit][kb][lane][8]
+    int CT = d.cpad / 16, KS = d.kpad / 64;
+    int64_t ndw = (int64_t)CT * KS * 64 * 4;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < ndw; i += (int64_t)gridDim.x * 256) {
+      int dwi = (int)(i & 3); int lane = (int)((i >> 2) & 63); int64_t t = i >> 8; int ks = (int)(t % KS); int ct = (int)(t / KS);
+      int co = ct * 16 + (lane & 15); int k0 = ks * 64 + (lane >> 4) * 16 + dwi * 4;
+      uint32_t packed = 0;
+      for (int e = 0; e < 4; ++e) {
+        int k = k0 + e; int v = 0;
+        if (co < d.cout && k < d.cin_g) v = wq_at(d, inv, co, k);
+        packed |= ((uint32_t)(v & 255)) << (8 * e);
+      }
+      ((uint32_t*)d.wq_pack)[i] = packed;
+    }
+    if (d.wt_pack) {
+      int cinp = round_up(d.cin_g, 16); int CIT = cinp / 16, KB = d.cpad / 32 + ((d.cpad % 32) ? 1 : 0);
+      int64_t nel = (int64_t)CIT * KB * 64 * 8;
+      for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < nel; i += (int64_t)gridDim.x * 256) {
+        int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); int64_t t = i >> 9; int kb = (int)(t % KB); int cit = (int)(t / KB);
+        int ci = cit * 16 + (lane & 15); int g = lane >> 4;
+        int co = kb * 32 + 8 * g + e;
+        float v = 0.0f;
+        if (co < d.cout && ci < d.cin_g) v = (float)wq_at(d, inv, co, ci);
+        d.wt_pack[i] = f2bf(v);
+      }
+    }
+  } else if (d.kind == 1) {     // depthwise: [tap][cpad]
+    int64_t nb = (int64_t)d.kk * d.cpad;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
+      int c = (int)(i % d.cpad), tap = (int)(i / d.cpad);
+      d.wq_pack[i] = (int8_t)((c < d.cout) ? wq_at(d, inv, c, tap) : 0);
+    }
+  } else if (d.kind == 2) {     // stem (VALU direct conv): [t = tap*cin_g + c][cpad]
+    int64_t nb = (int64_t)d.kk * d.cin_g * d.cpad;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
+      int co = (int)(i % d.cpad); int t = (int)(i / d.cpad); int tap = t / d.cin_g, c = t % d.cin_g;
+      d.wq_pack[i] = (int8_t)((co < d.cout) ? wq_at(d, inv, co, c * d.kk + tap) : 0);
+    }
+  } else {                      // classifier: plain [cout][cin]
+    int64_t nb = (int64_t)d.cout * d.cin_g;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
+      int co = (int)(i / d.cin_g);
+      d.wq_pack[i] = (int8_t)wq_at(d, inv, co, (int)(i - (int64_t)co * d.cin_g));
+    }
+  }
+}
+// wsum: one wave per output channel
+__global__ __launch_bounds__(256) void k_wprep_wsum(const FrostWDesc* descs) {
+  const FrostWDesc d = descs[blockIdx.y];
+  if (!d.wsum) return;
+  float inv = 1.0f / d.qrec[FROST_Q_SCALE];
+  int per = d.cin_g * d.kk;
+  for (int co = blockIdx.x * 4 + (threadIdx.x >> 6); co < d.cpad; co += gridDim.x * 4) {
+    int s = 0;
+    if (co < d.cout) for (int r = threadIdx.x & 63; r < per; r += 64) s += wq_at(d, inv, co, r);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) d.wsum[co] = s;
+  }
+}
+extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe,
+                                 void* stream) {
+  hipStream_t s = as_stream(stream);
+  int gx = grid_for(max_elems, 1024, 64);
+  if (observe) hipLaunchKernelGGL(k_wprep_minmax, dim3(gx, nlayers), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(k_wprep_observe, dim3((nlayers + 63) / 64), dim3(64), 0, s, descs, nlayers, rule127, observe);
+  hipLaunchKernelGGL(k_wprep_pack, dim3(gx, nlayers), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(k_wprep_wsum, dim3(32, nlayers), dim3(256), 0, s, descs);
+  return frost_check_launch("weight_prep");
+}
+
+// ------------------------------------------------------------------------------------------------ stats init
+__global__ __launch_bounds__(256) void k_stats_init(uint8_t* base, const int32_t* cpads, const int64_t* offs) {
+  int l = blockIdx.y; int cp = cpads[l];
+  int64_t* s1 = (int64_t*)(base + offs[l]); uint64_t* s2 = (uint64_t*)(s1 + cp);
+  int32_t* mn = (int32_t*)(s2 + cp); int32_t* mx = mn + cp;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < cp; c += gridDim.x * 256) { s1[c] = 0; s2[c] = 0; mn[c] = INT32_MAX; mx[c] = INT32_MIN; }
+}
+extern "C" int frost_stats_init_table(void* stats, const int32_t* cpads, const int64_t* offs, int nlayers, void* stream) {
+  hipLaunchKernelGGL(k_stats_init, dim3(8, nlayers), dim3(256), 0, as_stream(stream), (uint8_t*)stats, cpads, offs);
+  return frost_check_launch("stats_init");
+}
+
+// ------------------------------------------------------------------------------------------------ finalize
+// One block. Turns integer stats into BN coefficients, running-stat updates, and the activation qrecord.
+__global__ __launch_bounds__(256) void k_conv_finalize(const uint8_t* stats, int64_t count, int cout, int cpad,
+                                                       const float* qx, const float* qw, const float* gamma,
+                                                       const float* beta, float* rmean, float* rvar, int64_t* nbt,
+                                                       int training, int relu, int observe, int have_stats, float* coef, float* qy) {
+  const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
+  const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
+  float sx = qx[FROST_Q_SCALE], sw = qw[FROST_Q_SCALE];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int c = threadIdx.x; c < cpad; c += 256) {
+    float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
+    if (c < cout) {
+      float sigr = sqrtf(rvar[c] + FROST_BN_EPS);
+      float sf = gamma[c] / sigr;
+      double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha
+      double mean_acc, mu, v;
+      if (training) {
+        mean_acc = (double)s1[c] / (double)count;
+        double var_acc = (double)s2[c] / (double)count - mean_acc * mean_acc;
+        if (var_acc < 0) var_acc = 0;
+        mu = mean_acc * alpha; v = var_acc * alpha * alpha;
+        double unb = (count > 1) ? v * (double)count / (double)(count - 1) : v;
+        rmean[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rmean[c] + (double)FROST_BN_MOM * mu);
+        rvar[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rvar[c] + (double)FROST_BN_MOM * unb);
+      } else {
+        mu = (double)rmean[c]; v = (double)rvar[c]; mean_acc = mu / alpha;
+      }
+      double invstd = 1.0 / sqrt(v + (double)FROST_BN_EPS);
+      double a = (double)gamma[c] * invstd * alpha;
+      A = (float)a; B = (float)((double)beta[c] - a * mean_acc);
+      M = (float)mean_acc; R = (float)(alpha * invstd);
+      K1 = (float)(invstd * (double)sigr);                         // gamma*invstd/sf
+      VF = (float)(v / (v + (double)FROST_BN_EPS));
+      if (have_stats) {
+        float ya = fmaf(A, (float)mnp[c], B), yb = fmaf(A, (float)mxp[c], B);
+        if (relu) { ya = fmaxf(ya, 0.0f); yb = fmaxf(yb, 0.0f); }
+        lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
+      }
+    }
+    coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
+    coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
+    coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
+  }
+  __shared__ float slo[4], shi[4];
+  lo = wave_min(lo); hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
+    if (training && nbt) *nbt += 1;
+    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe);
+    else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
+  }
+}
+extern "C" int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
+                                   const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
+                                   int training, int relu, int observe, float* coef, float* qrec_y, void* stream) {
+  int cpad = round_up(cout, 16);
+  hipLaunchKernelGGL(k_conv_finalize, dim3(1), dim3(256), 0, as_stream(stream), (const uint8_t*)stats, count, cout, cpad,
+                     qrec_x, qrec_w, gamma, beta, rmean, rvar, nbt, training, relu, observe, stats ? 1 : 0, coef, qrec_y);
+  return frost_check_launch("conv_finalize");
+}
+
+// ------------------------------------------------------------------------------------------------ cat
+__global__ void k_cat_observe(const float* qa, const float* qb, float* qy, int observe) {
+  if (threadIdx.x == 0)
+    observer_update_dev(qy, fminf(qa[FROST_Q_FQMIN], qb[FROST_Q_FQMIN]), fmaxf(qa[FROST_Q_FQMAX], qb[FROST_Q_FQMAX]), 0, 0, observe);
+}
+extern "C" int frost_cat_observe(const float* qrec_a, const float* qrec_b, float* qrec_y, int observe, void* stream) {
+  hipLaunchKernelGGL(k_cat_observe, dim3(1), dim3(64), 0, as_stream(stream), qrec_a, qrec_b, qrec_y, observe);
+  return frost_check_launch("cat_observe");
+}
+// requantise through two 256-entry LUTs held in LDS; y[p] = [lutA[a[p][:ca]], lutB[b[p][:cb]]]
+__global__ __launch_bounds__(256) void k_cat_requant(const int8_t* __restrict__ a, const float* qa, int ca,
+                                                     const int8_t* __restrict__ b, const float* qb, int cb, int64_t npix,
+                                                     const float* qy, int8_t* __restrict__ y) {
+  __shared__ uint8_t lut[2][256];
+  {
+    QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+    int i = threadIdx.x;   // i = stored byte as unsigned; offset-binary index q = (int8)i + 128
+    int q = (int)(int8_t)i + 128;
+    float va = (float)(q - A.zp) * A.scale, vb = (float)(q - B.zp) * B.scale;
+    lut[0][i] = (uint8_t)((fq_index(va, Y.inv, Y.zp, 0, 255) - 128) & 255);
+    lut[1][i] = (uint8_t)((fq_index(vb, Y.inv, Y.zp, 0, 255) - 128) & 255);
+  }
+  __syncthreads();
+  int cy = ca + cb; int dpp = cy >> 2;           // dwords per pixel (channels multiple of 4)
+  int64_t ndw = npix * dpp;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < ndw; i += (int64_t)gridDim.x * 256) {
+    int64_t p = i / dpp; int c0 = (int)(i - p * dpp) * 4;
+    uint32_t src; const uint8_t* l;
+    if (c0 < ca) { src = *(const uint32_t*)(a + p * ca + c0); l = lut[0]; }
+    else { src = *(const uint32_t*)(b + p * cb + (c0 - ca)); l = lut[1]; }
+    uint32_t o = (uint32_t)l[src & 255] | ((uint32_t)l[(src >> 8) & 255] << 8) | ((uint32_t)l[(src >> 16) & 255] << 16) |
+                 ((uint32_t)l[src >> 24] << 24);
+    *(uint32_t*)(y + i * 4) = o;
+  }
+}
+extern "C" int frost_cat_requant(const int8_t* a, const float* qrec_a, int ca, const int8_t* b, const float* qrec_b,
+                                 int cb, int64_t npix, const float* qrec_y, int8_t* y, void* stream) {
+  FROST_REQUIRE(ca % 4 == 0 && cb % 4 == 0, "cat: channel counts must be multiples of 4");
+  hipLaunchKernelGGL(k_cat_requant, dim3(grid_for(npix * ((ca + cb) / 4), 1024, 4096)), dim3(256), 0, as_stream(stream),
+                     a, qrec_a, ca, b, qrec_b, cb, npix, qrec_y, y);
+  return frost_check_launch("cat_requant");
+}
+
+// ------------------------------------------------------------------------------------------------ add
+__device__ __forceinline__ float add_val(int ba, int bb, const QP& A, const QP& B) {
+  return (float)(ba + 128 - A.zp) * A.scale + (float)(bb + 128 - B.zp) * B.scale;
+}
+__global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,
+                                                    const float* qb, int64_t n, float* out2) {
+  QP A = load_qp(qa), B = load_qp(qb);
+  float lo = INFINITY, hi = -INFINITY;
+  int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    uint32_t va = ((const uint32_t*)a)[i], vb = ((const uint32_t*)b)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = add_val((int)(int8_t)(va >> (8 * e)), (int)(int8_t)(vb >> (8 * e)), A, B);
+      lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+  }
+  block_minmax_commit(lo, hi, out2);
+}
+extern "C" int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                                float* minmax2, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
+  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 4096, 2048)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, minmax2);
+  return frost_check_launch("add_minmax");
+}
+__global__ __launch_bounds__(256) void k_add_requant(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,
+                                                     const float* qb, int64_t n, const float* qy, int8_t* __restrict__ y) {
+  QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+  int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    uint32_t va = ((const uint32_t*)a)[i], vb = ((const uint32_t*)b)[i], o = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = add_val((int)(int8_t)(va >> (8 * e)), (int)(int8_t)(vb >> (8 * e)), A, B);
+      o |= ((uint32_t)((fq_index(v, Y.inv, Y.zp, 0, 255) - 128) & 255)) << (8 * e);
+    }
+    ((uint32_t*)y)[i] = o;
+  }
+}
+extern "C" int frost_add_requant(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                                 const float* qrec_y, int8_t* y, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
+  hipLaunchKernelGGL(k_add_requant, dim3(grid_for(n, 4096, 4096)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, qrec_y, y);
+  return frost_check_launch("add_requant");
+}
+
+// ------------------------------------------------------------------------------------------------ head
+// avg-pool over hw positions of an offset-binary activation -> fp32 [n][c]  (x mask if given)
+__global__ __launch_bounds__(256) void k_avgpool(const int8_t* __restrict__ x, const float* qx, int n, int hw, int c,
+                                                 const float* __restrict__ drop, float* __restrict__ y) {
+  QP X = load_qp(qx);
+  int64_t tot = (int64_t)n * c;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int ch = (int)(i % c); int64_t in = i / c;
+    const int8_t* p = x + in * hw * c + ch;
+    float s = 0.0f;   // torch mean(): fp32 sum of the dequantised values, then / hw
+    for (int t = 0; t < hw; ++t) s += (float)((int)p[(int64_t)t * c] + 128 - X.zp) * X.scale;
+    float v = s / (float)hw;
+    if (drop) v *= drop[i];
+    y[i] = v;
+  }
+}
+extern "C" int frost_avgpool(const int8_t* x, const float* qrec_x, int n, int hw, int c, const float* drop_mask, float* y,
+                             void* stream) {
+  hipLaunchKernelGGL(k_avgpool, dim3(grid_for((int64_t)n * c, 256)), dim3(256), 0, as_stream(stream), x, qrec_x, n, hw, c, drop_mask, y);
+  return frost_check_launch("avgpool");
+}
+// classifier GEMM: y[n][o] = s_w * sum_k x[n][k]*wq[o][k] + bias[o]; 64x64 tile, fp32 VALU through LDS
+__global__ __launch_bounds__(256) void k_classifier_fwd(const float* __restrict__ x, const int8_t* __restrict__ wq,
+                                                        const float* qw, const float* __restrict__ bias, int n, int cin,
+                                                        int nclass, float* __restrict__ y) {
+  __shared__ float xs[64][33]; __shared__ float ws[64][33];
+  int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < cin; k0 += 32) {
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      int r = i >> 5, k = i & 31;
+      xs[r][k] = (r0 + r < n && k0 + k < cin) ? x[(int64_t)(r0 + r) * cin + k0 + k] : 0.0f;
+      ws[r][k] = (c0 + r < nclass && k0 + k < cin) ? (float)wq[(int64_t)(c0 + r) * cin + k0 + k] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = xs[ty * 4 + i][k]; b[i] = ws[tx * 4 + i][k]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float sw = qw[FROST_Q_SCALE];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+    int r = r0 + ty * 4 + i, c = c0 + tx * 4 + j;
+    if (r < n && c < nclass) y[(int64_t)r * nclass + c] = acc[i][j] * sw + bias[c];
+  }
+}
+extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
+                                    int cin, int nclass, float* y, void* stream) {
+  hipLaunchKernelGGL(k_classifier_fwd, dim3((nclass + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x, wq,
+                     qrec_w, bias, n, cin, nclass, y);
+  return frost_check_launch("classifier_fwd");
+}

@@ -1,0 +1,203 @@
+// Classifier head backward, cat/add backward, and the BN-fold weight-gradient finalize (SURVEY H-5).
+#include "frost_common.h"
+
+// ---------------------------------------------------------------------------------------------- small GEMM
+// C[M][N] (+)= alpha * sum_k A(m,k) * B(k,n);  A(m,k) = a[m*ars + k*acs], B(k,n) = b[k*brs + n*bcs]
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
+                                               int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
+                                               float alpha, float* __restrict__ c, int accumulate) {
+  __shared__ float as[32][65]; __shared__ float bs[32][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      int r, k;
+      if (acs == 1) { k = i & 31; r = i >> 5; } else { r = i & 63; k = i >> 6; }
+      as[k][r] = (m0 + r < M && k0 + k < K) ? (float)a[(int64_t)(m0 + r) * ars + (int64_t)(k0 + k) * acs] : 0.0f;
+      if (brs == 1) { k = i & 31; r = i >> 5; } else { r = i & 63; k = i >> 6; }
+      bs[k][r] = (n0 + r < N && k0 + k < K) ? (float)b[(int64_t)(k0 + k) * brs + (int64_t)(n0 + r) * bcs] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = as[k][ty * 4 + i]; bv[i] = bs[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const float al = alpha * (alpha_ptr ? *alpha_ptr : 1.0f);
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+    int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+    if (m < M && n < N) { float v = acc[i][j] * al; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int n, int m, float* __restrict__ out) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= m) return;
+  float s = 0.0f;
+  for (int r = 0; r < n; ++r) s += g[(int64_t)r * m + c];
+  out[c] = s;
+}
+// gx[n][hw][c] = dpool[n][c] * drop[n][c] / hw   (bf16)
+__global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ dpool, const float* __restrict__ drop, int n, int hw,
+                                                  int c, uint16_t* __restrict__ gx) {
+  int64_t tot = (int64_t)n * hw * c;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    int ch = (int)(i % c); int64_t in = i / ((int64_t)hw * c);
+    float v = dpool[in * c + ch]; if (drop) v *= drop[in * c + ch];
+    gx[i] = f2bf(v / (float)hw);
+  }
+}
+// replaces: autograd of [avgpool -> dropout -> nnqat.Conv2d] (frostnet.py:295-299). dlogits already STE-masked.
+// dwq[nclass][cin] = dlogits^T . pooled ; dbias = colsum(dlogits); gx = (dlogits . wq * s_w) * drop / hw
+extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, const int8_t* wq, const float* qrec_w,
+                              int n, int cin, int nclass, int hw, const float* drop_mask, float* dwq, float* dbias,
+                              uint16_t* gx, float* scratch_dpool, void* stream) {
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (nclass + 63) / 64), dim3(256), 0, s, dlogits_masked,
+                     (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, dwq, 0);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
+  hipLaunchKernelGGL((k_sgemm<float, int8_t>), dim3((cin + 63) / 64, (n + 63) / 64), dim3(256), 0, s, dlogits_masked,
+                     (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass, qrec_w + FROST_Q_SCALE, 1.0f,
+                     scratch_dpool, 0);
+  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
+  return frost_check_launch("head_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------- cat / add bwd
+__device__ __forceinline__ void acc_store4(uint16_t* dst, const float* v, int accumulate) {
+  float o[4] = {v[0], v[1], v[2], v[3]};
+  if (accumulate) { uint2 t = *(const uint2*)dst; o[0] += bf2f(t.x & 0xffff); o[1] += bf2f(t.x >> 16); o[2] += bf2f(t.y & 0xffff); o[3] += bf2f(t.y >> 16); }
+  uint2 w; w.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16); w.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+  *(uint2*)dst = w;
+}
+__global__ __launch_bounds__(256) void k_cat_bwd(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa, int ca,
+                                                 const int8_t* __restrict__ b, const float* qb, int cb, int64_t npix, const float* qy,
+                                                 uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ gb, int acc_b) {
+  __shared__ uint8_t ok[2][256];
+  {
+    QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+    int i = threadIdx.x; int q = (int)(int8_t)i + 128; bool ia, ib;
+    fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, 255, &ia);
+    fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, 255, &ib);
+    ok[0][i] = ia; ok[1][i] = ib;
+  }
+  __syncthreads();
+  const int cy = ca + cb, dpp = cy >> 2; const int64_t ndw = npix * dpp;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < ndw; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / dpp; const int c0 = (int)(i - p * dpp) * 4;
+    const uint2 gv = *(const uint2*)(gy + p * cy + c0);
+    float g[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
+    if (c0 < ca) {
+      const uint32_t src = *(const uint32_t*)(a + p * ca + c0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (!ok[0][(src >> (8 * r)) & 255]) g[r] = 0.0f;
+      acc_store4(ga + p * ca + c0, g, acc_a);
+    } else {
+      const int cc = c0 - ca; const uint32_t src = *(const uint32_t*)(b + p * cb + cc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (!ok[1][(src >> (8 * r)) & 255]) g[r] = 0.0f;
+      acc_store4(gb + p * cb + cc, g, acc_b);
+    }
+  }
+}
+extern "C" int frost_cat_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, int ca, const int8_t* b,
+                             const float* qrec_b, int cb, int64_t npix, const float* qrec_y, uint16_t* ga, int acc_a,
+                             uint16_t* gb, int acc_b, void* stream) {
+  int64_t ndw = npix * ((ca + cb) / 4); int64_t grid = (ndw + 1023) / 1024; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_cat_bwd, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, ca, b, qrec_b, cb, npix, qrec_y, ga, acc_a, gb, acc_b);
+  return frost_check_launch("cat_bwd");
+}
+__global__ __launch_bounds__(256) void k_add_bwd(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa,
+                                                 const int8_t* __restrict__ b, const float* qb, int64_t n4, const float* qy,
+                                                 uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ gb, int acc_b) {
+  QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t va = ((const uint32_t*)a)[i], vb = ((const uint32_t*)b)[i];
+    const uint2 gv = *(const uint2*)(gy + i * 4);
+    float g[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = (float)((int)(int8_t)(va >> (8 * r)) + 128 - A.zp) * A.scale + (float)((int)(int8_t)(vb >> (8 * r)) + 128 - B.zp) * B.scale;
+      bool inr; fq_index(v, Y.inv, Y.zp, 0, 255, &inr);
+      if (!inr) g[r] = 0.0f;
+    }
+    acc_store4(ga + i * 4, g, acc_a);
+    acc_store4(gb + i * 4, g, acc_b);
+  }
+}
+extern "C" int frost_add_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b,
+                             int64_t n, const float* qrec_y, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream) {
+  int64_t n4 = n / 4; int64_t grid = (n4 + 1023) / 1024; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_add_bwd, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, b, qrec_b, n4, qrec_y, ga, acc_a, gb, acc_b);
+  return frost_check_launch("add_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------- weight-grad finalize
+// dwq = dL/d(fake-quantised scaled weight), [cout][cin_g*kk] fp32.  One wave per output channel.
+//   mask = [-128 <= rint(W*sf/s_w) <= 127];  dW = dwq*mask*sf;  dgamma = S2*vfrac + sum(dwq*mask*W)/sigma_r;  dbeta = S1
+__global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ dwq, const float* __restrict__ w,
+                                                        const float* gamma, const float* rvar_saved_sigma, const float* qw,
+                                                        const float* coef, int cout, int per, int cpad, float* __restrict__ dw,
+                                                        float* dgamma, float* dbeta, int accumulate) {
+  const float inv = 1.0f / qw[FROST_Q_SCALE];
+  const int lane = threadIdx.x & 63;
+  for (int co = blockIdx.x * 4 + (threadIdx.x >> 6); co < cout; co += gridDim.x * 4) {
+    float sf = 1.0f, sigr = 1.0f;
+    if (gamma) { sigr = rvar_saved_sigma[co]; sf = gamma[co] / sigr; }
+    float dot = 0.0f;
+    for (int r = lane; r < per; r += 64) {
+      const int64_t idx = (int64_t)co * per + r;
+      const float wv = w[idx]; bool inr; fq_index(wv * sf, inv, 0, -128, 127, &inr);
+      const float g = inr ? dwq[idx] : 0.0f;
+      float o = g * sf; if (accumulate) o += dw[idx];
+      dw[idx] = o; dot += g * wv;
+    }
+    dot = wave_sum(dot);
+    if (lane == 0 && gamma) {
+      float dg = coef[FROST_COEF_S2 * cpad + co] * coef[FROST_COEF_VFRAC * cpad + co] + dot / sigr;
+      float db = coef[FROST_COEF_S1 * cpad + co];
+      if (accumulate) { dg += dgamma[co]; db += dbeta[co]; }
+      dgamma[co] = dg; dbeta[co] = db;
+    }
+  }
+}
+// sigma_r[c] = sqrt(running_var + eps) must be the value used in THIS step's forward (saved before the update).
+extern "C" int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,
+                                          const float* qrec_w, const float* coef, int cout, int cin_g, int kk, int cpad,
+                                          float* dw, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  int grid = (cout + 3) / 4; if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid), dim3(256), 0, as_stream(stream), dwq, w, gamma, sigma_r, qrec_w, coef, cout,
+                     cin_g * kk, cpad, dw, dgamma, dbeta, accumulate);
+  return frost_check_launch("weight_grad_finalize");
+}
+// save sigma_r = sqrt(rv+eps) for a list of layers BEFORE the forward updates running_var (one launch)
+__global__ void k_save_sigma(const FrostWDesc* descs, float* const* outs) {
+  const FrostWDesc d = descs[blockIdx.y];
+  if (!d.rvar) return;
+  float* o = outs[blockIdx.y];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < d.cout; c += gridDim.x * 256) o[c] = sqrtf(d.rvar[c] + FROST_BN_EPS);
+}
+extern "C" int frost_save_sigma(const FrostWDesc* descs, float* const* outs, int nlayers, void* stream) {
+  hipLaunchKernelGGL(k_save_sigma, dim3(8, nlayers), dim3(256), 0, as_stream(stream), descs, outs);
+  return frost_check_launch("save_sigma");
+}
+// logits fake-quant backward mask applied to dlogits:  g *= [0 <= rint(raw*inv)+zp <= 255]
+__global__ __launch_bounds__(256) void k_mask_logits(const float* __restrict__ g, const float* __restrict__ raw, const float* qy, int64_t n, float* __restrict__ out) {
+  QP Y = load_qp(qy);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { bool inr; fq_index(raw[i], Y.inv, Y.zp, 0, 255, &inr); out[i] = inr ? g[i] : 0.0f; }
+}
+extern "C" int frost_mask_logits(const float* g, const float* raw, const float* qrec_y, int64_t n, float* out, void* stream) {
+  int64_t grid = (n + 255) / 256; if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(k_mask_logits, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), g, raw, qrec_y, n, out);
+  return frost_check_launch("mask_logits");
+}

@@ -1,0 +1,367 @@
+"""Host-side executor of the MI355X FrostNet QAT path: owns the device arenas (qrecords, packed weights, integer
+statistics, BN coefficients), sequences the C-ABI kernels of libfrost_hip.so on the current HIP stream and keeps a
+tape so the backward pass replays the layers in reverse.  No host synchronisation anywhere: every scalar the
+reference keeps in Python/torch buffers (observer min/max, scale, zero-point, BN running stats) lives in device
+memory and is produced and consumed by kernels, so a whole fwd+bwd+optimizer step can be captured in a hipGraph.
+
+Mirrors, per call, the reference module graph: frostnet.py:14-145 (ConvBNReLU / ConvBN / CascadePreExBottleneck),
+torch nniqat.ConvBn(ReLU)2d._forward_approximate and FakeQuantize."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr, stream
+
+SLACK = 256  # bytes of slack after every activation buffer (the MFMA K-tail may over-read, weights there are 0)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class Act:
+    """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad")
+
+    def __init__(self, buf, n, h, w, c, q):
+        self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
+        self.grad = None
+        self.needs_grad = True
+
+    @property
+    def npix(self):
+        return self.n * self.h * self.w
+
+    @property
+    def numel(self):
+        return self.npix * self.c
+
+    def dequant(self):
+        """fp32 NCHW tensor of the fake-quantised values (tests / feature taps)."""
+        out = torch.empty(self.numel, dtype=torch.float32, device=self.buf.device)
+        call("frost_dequant_act", ptr(self.buf), self.numel, ptr(self.q), ptr(out), stream())
+        return out.view(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2)
+
+    def indices(self):
+        """uint8 index tensor, NCHW."""
+        v = self.buf[: self.numel].view(self.n, self.h, self.w, self.c).to(torch.int16) + 128
+        return v.permute(0, 3, 1, 2).to(torch.uint8)
+
+
+class QArena:
+    """All fake-quantize sites of a model: [nsites, 8] fp32 on device (layout FROST_Q_* in include/frost_hip.h)."""
+
+    def __init__(self, nsites, device):
+        self.t = torch.zeros(nsites, L.Q_STRIDE, dtype=torch.float32, device=device)
+        self.reset()
+        self.next = 0
+
+    def reset(self):
+        self.t[:, L.Q_MIN] = float("inf")
+        self.t[:, L.Q_MAX] = float("-inf")
+        self.t[:, L.Q_SCALE] = 1.0
+        self.t[:, L.Q_INV] = 1.0
+        self.t[:, L.Q_ZP] = 0.0
+        self.t[:, L.Q_FQMIN] = 0.0
+        self.t[:, L.Q_FQMAX] = 0.0
+
+    def alloc(self):
+        i = self.next
+        self.next += 1
+        return self.t[i]
+
+    @staticmethod
+    def set_qparams(rec, scale, zp):
+        rec[L.Q_SCALE] = float(scale)
+        rec[L.Q_INV] = 1.0 / float(scale)
+        rec.view(torch.int32)[L.Q_ZP] = int(zp)
+
+    @staticmethod
+    def get(rec):
+        r = rec.detach().cpu()
+        return dict(min_val=float(r[L.Q_MIN]), max_val=float(r[L.Q_MAX]), scale=float(r[L.Q_SCALE]),
+                    zero_point=int(r.view(torch.int32)[L.Q_ZP]), fq_min=float(r[L.Q_FQMIN]), fq_max=float(r[L.Q_FQMAX]))
+
+
+class ConvLayer:
+    """Device state of one ConvBN(ReLU) (kind pw / dw / stem) or of the classifier conv (kind cls)."""
+    KIND_ID = {"pw": 0, "dw": 1, "stem": 2, "cls": 3}
+
+    def __init__(self, name, kind, w, gamma, beta, rmean, rvar, nbt, bias, k, stride, relu, qw, qy):
+        self.name, self.kind, self.k, self.stride, self.relu = name, kind, k, stride, relu
+        self.w, self.gamma, self.beta, self.rmean, self.rvar, self.nbt, self.bias = w, gamma, beta, rmean, rvar, nbt, bias
+        self.cout, self.cin_g = w.shape[0], w.shape[1]
+        self.kk = k * k
+        self.cpad = round_up(self.cout, 16)
+        self.qw, self.qy = qw, qy
+        dev = w.device
+        if kind == "pw":
+            self.kpad = round_up(self.cin_g, 64)
+            nb = (self.cpad // 16) * (self.kpad // 64) * 1024
+            cit, kb = round_up(self.cin_g, 16) // 16, (self.cpad + 31) // 32
+            self.wt_pack = torch.zeros(cit * kb * 64 * 8, dtype=torch.int16, device=dev)
+        elif kind == "dw":
+            self.kpad, nb, self.wt_pack = 0, self.kk * self.cpad, None
+        elif kind == "stem":
+            self.kpad, nb, self.wt_pack = 0, self.kk * self.cin_g * self.cpad, None
+        else:
+            self.kpad, nb, self.wt_pack = 0, self.cout * self.cin_g, None
+        self.wq_pack = torch.zeros(nb + 64, dtype=torch.int8, device=dev)
+        self.wsum = torch.zeros(self.cpad, dtype=torch.int32, device=dev)
+        self.minmax2 = torch.tensor([float("inf"), float("-inf")], dtype=torch.float32, device=dev)
+        self.coef = torch.zeros(L.COEF_ROWS, self.cpad, dtype=torch.float32, device=dev)
+        self.sigma = torch.ones(self.cout, dtype=torch.float32, device=dev)
+        self.stats = None       # view into the engine's stats arena
+        self.dwq = None         # fp32 scratch for dL/d(fake-quantised weight)
+
+    def desc(self):
+        d = L.FrostWDesc()
+        d.w, d.gamma, d.rvar = self.w.data_ptr(), (self.gamma.data_ptr() if self.gamma is not None else None), \
+            (self.rvar.data_ptr() if self.rvar is not None else None)
+        d.qrec, d.wq_pack, d.wsum, d.minmax2 = self.qw.data_ptr(), self.wq_pack.data_ptr(), self.wsum.data_ptr(), \
+            self.minmax2.data_ptr()
+        d.wt_pack = self.wt_pack.data_ptr() if self.wt_pack is not None else None
+        d.cout, d.cin_g, d.kk, d.kind = self.cout, self.cin_g, self.kk, self.KIND_ID[self.kind]
+        d.cpad, d.kpad = self.cpad, self.kpad
+        return d
+
+
+class Engine:
+    def __init__(self, device, rule127=False):
+        self.device = torch.device(device)
+        self.rule127 = 1 if rule127 else 0
+        self.layers = []
+        self.tape = []
+        self._table = None
+
+    # ------------------------------------------------------------------------------------------ plan
+    def add_layer(self, layer):
+        self.layers.append(layer)
+        self._table = None
+        return layer
+
+    def _ensure_tables(self):
+        if self._table is not None:
+            return
+        n = len(self.layers)
+        arr = (L.FrostWDesc * n)()
+        for i, l in enumerate(self.layers):
+            arr[i] = l.desc()
+        self._table = L.struct_to_tensor(arr, self.device)
+        self._max_elems = max(l.w.numel() for l in self.layers)
+        offs, total = [], 0
+        for l in self.layers:
+            offs.append(total)
+            total += l.cpad * L.STATS_BYTES_PER_CH
+        self._stats = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        for l, o in zip(self.layers, offs):
+            l.stats = self._stats[o: o + l.cpad * L.STATS_BYTES_PER_CH]
+        self._cpads = torch.tensor([l.cpad for l in self.layers], dtype=torch.int32, device=self.device)
+        self._offs = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        ptrs = (C.c_void_p * n)(*[l.sigma.data_ptr() for l in self.layers])
+        self._sigma_ptrs = L.struct_to_tensor(ptrs, self.device)
+
+    def begin_step(self, observe=True):
+        """Per-step prologue: BN-fold + weight fake-quant + packing for every layer (3 launches), sigma_r snapshot,
+        integer-stat reset.  Must run before the first conv of a forward pass (uses running_var BEFORE its update)."""
+        self._ensure_tables()
+        n = len(self.layers)
+        call("frost_save_sigma", ptr(self._table), ptr(self._sigma_ptrs), n, stream())
+        call("frost_weight_prep", ptr(self._table), n, self._max_elems, self.rule127, 1 if observe else 0, stream())
+        call("frost_stats_init_table", ptr(self._stats), ptr(self._cpads), ptr(self._offs), n, stream())
+        self.tape = []
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def new_act(self, n, h, w, c, q):
+        buf = torch.empty(n * h * w * c + SLACK, dtype=torch.int8, device=self.device)
+        return Act(buf, n, h, w, c, q)
+
+    def act_from_indices(self, idx_nchw, q):
+        """Test helper: uint8 NCHW indices -> Act."""
+        n, c, h, w = idx_nchw.shape
+        a = self.new_act(n, h, w, c, q)
+        v = (idx_nchw.to(self.device).permute(0, 2, 3, 1).contiguous().to(torch.int16) - 128).to(torch.int8)
+        a.buf[: a.numel].copy_(v.view(-1))
+        return a
+
+    @staticmethod
+    def _grad_slot(a):
+        """bf16 gradient buffer of an Act: returns (tensor, accumulate_flag)."""
+        if a.grad is None:
+            a.grad = torch.empty(a.numel + 64, dtype=torch.int16, device=a.buf.device)
+            return a.grad, 0
+        return a.grad, 1
+
+    # ------------------------------------------------------------------------------------------ forward ops
+    def quantize_input(self, x, q, observe=True):
+        """QuantStub (frostnet.py:319-320): observer + fake-quantise of the fp32 image; accepts NCHW or channels_last."""
+        n, c, h, w = x.shape
+        sn, sc, sh, sw = x.stride()
+        if observe:
+            mm = torch.tensor([float("inf"), float("-inf")], dtype=torch.float32, device=self.device) \
+                if not hasattr(self, "_in_mm") else self._in_mm
+            self._in_mm = mm
+            call("frost_fill_minmax", ptr(mm), 1, stream())
+            call("frost_minmax_input", ptr(x), n, c, h, w, sn, sc, sh, sw, ptr(mm), stream())
+            call("frost_observer_update", ptr(q), ptr(mm), 0, 0, 1, stream())
+        cpad = round_up(c, 4)
+        a = self.new_act(n, h, w, cpad, q)
+        call("frost_quantize_input", ptr(x), n, c, h, w, sn, sc, sh, sw, ptr(q), ptr(a.buf), cpad, stream())
+        a.needs_grad = False
+        return a
+
+    def _conv_launch(self, l, x, mode, y):
+        st = ptr(l.stats)
+        if l.kind == "pw":
+            call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
+                 ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+        elif l.kind == "dw":
+            call("frost_dw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, x.c, l.k,
+                 l.stride, mode, st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+        else:
+            call("frost_stem_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout, mode,
+                 st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+
+    def conv(self, l, x, training=True, observe=True):
+        """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute)."""
+        pad = (l.k - 1) // 2
+        ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
+        y = self.new_act(x.n, ho, wo, l.cout, l.qy)
+        need_stats = training or observe
+        if need_stats:
+            self._conv_launch(l, x, 0, None)
+        call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
+             ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
+             1 if observe else 0, ptr(l.coef), ptr(l.qy), stream())
+        self._conv_launch(l, x, 1, y)
+        self.tape.append(("conv", l, x, y))
+        return y
+
+    def cat(self, a, b, q, observe=True):
+        """FloatFunctional.cat + its FakeQuantize (frostnet.py:129)."""
+        call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
+        y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
+        call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream())
+        self.tape.append(("cat", a, b, y))
+        return y
+
+    def add(self, a, b, q, observe=True):
+        """FloatFunctional.add + its FakeQuantize (frostnet.py:142)."""
+        if not hasattr(self, "_add_mm"):
+            self._add_mm = torch.empty(2, dtype=torch.float32, device=self.device)
+        if observe:
+            call("frost_fill_minmax", ptr(self._add_mm), 1, stream())
+            call("frost_add_minmax", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), stream())
+            call("frost_observer_update", ptr(q), ptr(self._add_mm), 0, 0, 1, stream())
+        y = self.new_act(a.n, a.h, a.w, a.c, q)
+        call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream())
+        self.tape.append(("add", a, b, y))
+        return y
+
+    def head(self, l, x, drop_mask=None, observe=True):
+        """AdaptiveAvgPool2d(1) -> Dropout -> nnqat.Conv2d(1280,nclass,1) + activation FQ (frostnet.py:295-299)."""
+        n, c = x.n, x.c
+        pooled = torch.empty(n, c, dtype=torch.float32, device=self.device)
+        call("frost_avgpool", ptr(x.buf), ptr(x.q), n, x.h * x.w, c, ptr(drop_mask), ptr(pooled), stream())
+        raw = torch.empty(n, l.cout, dtype=torch.float32, device=self.device)
+        call("frost_classifier_fwd", ptr(pooled), ptr(l.wq_pack), ptr(l.qw), ptr(l.bias), n, c, l.cout, ptr(raw), stream())
+        if observe:
+            if not hasattr(self, "_head_mm"):
+                self._head_mm = torch.empty(2, dtype=torch.float32, device=self.device)
+            call("frost_fill_minmax", ptr(self._head_mm), 1, stream())
+            call("frost_minmax_f32", ptr(raw), raw.numel(), ptr(self._head_mm), stream())
+            call("frost_observer_update", ptr(l.qy), ptr(self._head_mm), 0, 0, 1, stream())
+        logits = torch.empty_like(raw)
+        call("frost_fake_quant_f32", ptr(raw), raw.numel(), ptr(l.qy), 0, 255, ptr(logits), None, stream())
+        self.tape.append(("head", l, x, pooled, raw, drop_mask))
+        return logits
+
+    # ------------------------------------------------------------------------------------------ backward
+    def backward(self, dlogits=None, out_grads=None):
+        """Replay the tape in reverse. dlogits: fp32 [n, nclass] gradient of the loss w.r.t. the logits.
+        Parameter gradients are written (=, not +=) into l.w.grad / l.gamma.grad / l.beta.grad / l.bias.grad."""
+        for entry in reversed(self.tape):
+            kind = entry[0]
+            if kind == "head":
+                _, l, x, pooled, raw, drop = entry
+                g = torch.empty_like(raw)
+                call("frost_mask_logits", ptr(dlogits.contiguous()), ptr(raw), ptr(l.qy), raw.numel(), ptr(g), stream())
+                dwq = torch.empty(l.cout, l.cin_g, dtype=torch.float32, device=self.device)
+                gx, _ = self._grad_slot(x)
+                dpool = torch.empty_like(pooled)
+                self._ensure_grad(l)
+                call("frost_head_bwd", ptr(g), ptr(pooled), ptr(l.wq_pack), ptr(l.qw), x.n, x.c, l.cout, x.h * x.w,
+                     ptr(drop), ptr(dwq), ptr(l.bias.grad), ptr(gx), ptr(dpool), stream())
+                call("frost_weight_grad_finalize", ptr(dwq), ptr(l.w), None, None, ptr(l.qw), ptr(l.coef), l.cout,
+                     l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0, stream())
+            elif kind == "conv":
+                _, l, x, y = entry
+                self._conv_backward(l, x, y)
+            elif kind == "cat":
+                _, a, b, y = entry
+                ga, fa = self._grad_slot(a)
+                gb, fb = self._grad_slot(b)
+                call("frost_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q),
+                     ptr(ga), fa, ptr(gb), fb, stream())
+                y.grad = None
+            elif kind == "add":
+                _, a, b, y = entry
+                ga, fa = self._grad_slot(a)
+                gb, fb = self._grad_slot(b)
+                call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
+                     fa, ptr(gb), fb, stream())
+                y.grad = None
+        self.tape = []
+
+    @staticmethod
+    def _ensure_grad(l):
+        for p in (l.w, l.gamma, l.beta, l.bias):
+            if p is not None and p.grad is None:
+                p.grad = torch.zeros_like(p)
+
+    def _conv_backward(self, l, x, y):
+        self._ensure_grad(l)
+        gout = y.grad
+        if l.dwq is None:
+            l.dwq = torch.empty(l.w.numel(), dtype=torch.float32, device=self.device)
+        l.dwq.zero_()
+        dc = torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
+        s = stream()
+        if l.kind == "pw":
+            args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout)
+            call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s)
+            call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s)
+            if x.needs_grad:
+                gx, acc = self._grad_slot(x)
+                call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s)
+            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), s)
+        elif l.kind == "dw":
+            args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
+            call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s)
+            call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s)
+            if x.needs_grad:
+                gx, acc = self._grad_slot(x)
+                call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s)
+            call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s)
+        else:
+            args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout)
+            call("frost_stem_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s)
+            call("frost_stem_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(l.dwq), s)
+        call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
+             l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
+        y.grad = None
+
+
+def grad_to_float(g, n, h, w, c):
+    """bf16 gradient buffer -> fp32 NCHW (tests)."""
+    return g[: n * h * w * c].view(torch.bfloat16).float().view(n, h, w, c).permute(0, 3, 1, 2)
+
+
+def float_to_grad(t_nchw):
+    """fp32 NCHW -> bf16 NHWC buffer with slack (tests)."""
+    v = t_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).view(torch.int16).reshape(-1)
+    out = torch.zeros(v.numel() + 64, dtype=torch.int16, device=t_nchw.device)
+    out[: v.numel()] = v
+    return out

@@ -1,0 +1,262 @@
+"""FrostNet classifier -- the reference's nn.Module surface (frostnet.py:14-451) over the MI355X HIP engine.
+
+Same classes, constructor signatures, attribute names and state_dict keys as the reference (`ConvBNReLU`, `ConvBN`,
+`CascadePreExBottleneck`, `FrostNet`, 30 `frostnet[_quant]_{large,base,small}_{1_25,1_0,0_75,0_5,0_35}` factories), so
+`Classification/train.py`-style drivers, reference checkpoints and `torch.quantization.prepare_qat` work unchanged.
+
+The module tree holds stock torch modules (that is what defines the state_dict layout).  Execution:
+  * tensors on the HIP device + model switched to QAT (`fuse_model()` + `prepare_qat`) -> the hand-written gfx950
+    path (frostnet_amd.engine / libfrost_hip.so); missing library => RuntimeError, never a silent eager fallback;
+  * tensors on the CPU -> the stock module graph, i.e. the reference's own definition (config c1 plumbing only).
+"""
+import torch
+import torch.nn as nn
+
+try:  # soft dependency, exactly what frostnet.py:4-5 needs
+    from timm.models.registry import register_model
+except Exception:  # pragma: no cover
+    def register_model(fn):
+        MODEL_REGISTRY[fn.__name__] = fn
+        return fn
+
+MODEL_REGISTRY = {}
+
+
+def _fuse(seq, names):
+    """frostnet.py:28,60 call torch.quantization.fuse_modules; torch>=1.11 split the train-mode variant out."""
+    import torch.ao.quantization as aoq
+    if seq.training:
+        aoq.fuse_modules_qat(seq, names, inplace=True)
+    else:
+        aoq.fuse_modules(seq, names, inplace=True)
+
+
+class ConvBNReLU(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
+        super(ConvBNReLU, self).__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                            bias=False),
+                                  nn.BatchNorm2d(out_channels), nn.ReLU(False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+    def fuse_model(self):
+        _fuse(self.conv, ['0', '1', '2'])
+
+
+class ConvBN(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
+        super(ConvBN, self).__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                            bias=False),
+                                  nn.BatchNorm2d(out_channels))
+
+    def forward(self, x):
+        return self.conv(x)
+
+    def fuse_model(self):
+        _fuse(self.conv, ['0', '1'])
+
+
+def _make_divisible(v, divisor=8, min_value=None):
+    """frostnet.py:62-79."""
+    if min_value is None:
+        min_value = divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+class CascadePreExBottleneck(nn.Module):
+    """The Frost bottleneck (frostnet.py:81-145)."""
+
+    def __init__(self, in_channels, out_channels, quantized=False, kernel_size=3, stride=1, dilation=1, expand_ratio=6,
+                 reduce_factor=4, block_type='CAS'):
+        super(CascadePreExBottleneck, self).__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.expand_ratio = expand_ratio
+        self.quantized = quantized
+        if in_channels // reduce_factor < 8:
+            block_type = 'MB'
+        self.block_type = block_type
+        r_channels = _make_divisible(in_channels // reduce_factor)
+        self.reduction = not (stride == 1 and in_channels == out_channels)
+        if self.expand_ratio == 1:
+            self.squeeze_conv = None
+            self.conv1 = None
+            n_channels = in_channels
+        else:
+            if block_type == 'CAS':
+                self.squeeze_conv = ConvBNReLU(in_channels, r_channels, 1)
+                n_channels = r_channels + in_channels
+            else:
+                n_channels = in_channels
+            self.conv1 = ConvBNReLU(n_channels, n_channels * expand_ratio, 1)
+        # NB: dilation is accepted and ignored, exactly like the reference (frostnet.py:116-118)
+        self.conv2 = ConvBNReLU(n_channels * expand_ratio, n_channels * expand_ratio, kernel_size, stride,
+                                (kernel_size - 1) // 2, 1, groups=n_channels * expand_ratio)
+        self.reduce_conv = ConvBN(n_channels * expand_ratio, out_channels, 1)
+        if self.quantized:
+            self.skip_add = nn.quantized.FloatFunctional()
+            self.quant_cat = nn.quantized.FloatFunctional()
+
+    def forward(self, x):
+        if not self.expand_ratio == 1:
+            if self.block_type == 'CAS':
+                squeezed = self.squeeze_conv(x)
+                out = self.quant_cat.cat([squeezed, x], 1) if self.quantized else torch.cat([squeezed, x], 1)
+            else:
+                out = x
+            out = self.conv1(out)
+        else:
+            out = x
+        out = self.conv2(out)
+        out = self.reduce_conv(out)
+        if not self.reduction:
+            out = self.skip_add.add(x, out) if self.quantized else torch.add(x, out)
+        return out
+
+
+# stage tables, rows = [kernel_size, c, e, r, s]  (frostnet.py:156-269)
+_SETTINGS = {
+    'large': ([[3, 16, 1, 1, 1], [3, 24, 6, 4, 2], [3, 24, 3, 4, 1]],
+              [[5, 40, 6, 4, 2], [3, 40, 3, 4, 1]],
+              [[5, 80, 6, 4, 2], [5, 80, 3, 4, 1], [5, 80, 3, 4, 1], [5, 96, 6, 4, 1], [5, 96, 3, 4, 1], [3, 96, 3, 4, 1],
+               [3, 96, 3, 4, 1]],
+              [[5, 192, 6, 2, 2], [5, 192, 6, 4, 1], [5, 192, 6, 4, 1], [5, 192, 3, 4, 1], [5, 192, 3, 4, 1]],
+              [[5, 320, 6, 2, 1]]),
+    'base': ([[3, 16, 1, 1, 1], [5, 24, 6, 4, 2], [3, 24, 3, 4, 1]],
+             [[5, 40, 3, 4, 2], [5, 40, 3, 4, 1]],
+             [[5, 80, 3, 4, 2], [3, 80, 3, 4, 1], [5, 96, 3, 2, 1], [3, 96, 3, 4, 1], [5, 96, 3, 4, 1], [5, 96, 3, 4, 1]],
+             [[5, 192, 6, 2, 2], [5, 192, 3, 2, 1], [5, 192, 3, 2, 1], [5, 192, 3, 2, 1]],
+             [[5, 320, 6, 2, 1]]),
+    'small': ([[3, 16, 1, 1, 1], [5, 24, 3, 4, 2], [3, 24, 3, 4, 1]],
+              [[5, 40, 3, 4, 2]],
+              [[5, 80, 3, 4, 2], [5, 80, 3, 4, 1], [3, 80, 3, 4, 1], [5, 96, 3, 2, 1], [5, 96, 3, 4, 1], [5, 96, 3, 4, 1]],
+              [[5, 192, 6, 4, 2], [5, 192, 6, 4, 1], [5, 192, 6, 4, 1]],
+              [[5, 320, 6, 2, 1]]),
+}
+
+
+class _FrostBase(nn.Module):
+    def _make_layer(self, block, block_setting, width_mult, dilation=1):
+        layers = list()
+        for k, c, e, r, s in block_setting:
+            out_channels = _make_divisible(int(c * width_mult))
+            layers.append(block(self.in_channels, out_channels, quantized=self.quantized, kernel_size=k, stride=s,
+                                dilation=dilation, expand_ratio=e, reduce_factor=r))
+            self.in_channels = out_channels
+        return nn.Sequential(*layers)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def fuse_model(self):
+        for m in self.modules():
+            if type(m) in [ConvBNReLU, ConvBN]:
+                m.fuse_model()
+
+    # ---- HIP execution --------------------------------------------------------------------------------
+    def _is_qat_prepared(self):
+        return hasattr(self.conv1.conv[0], "weight_fake_quant")
+
+    def hip_runner(self):
+        """The device executor bound to this module tree (built lazily, rebuilt if parameters were moved)."""
+        from .runner import FrostRunner
+        r = self.__dict__.get("_hip_runner")
+        if r is None or not r.still_valid():
+            r = FrostRunner(self)
+            self.__dict__["_hip_runner"] = r
+        return r
+
+
+class FrostNet(_FrostBase):
+    def __init__(self, nclass=1000, mode='large', width_mult=1.0, quantized=False, bottleneck=CascadePreExBottleneck,
+                 drop_rate=0.2, dilated=False, **kwargs):
+        super(FrostNet, self).__init__()
+        self.quantized = quantized
+        if mode not in _SETTINGS:
+            raise ValueError('Unknown mode.')
+        l1, l2, l3, l4, l5 = _SETTINGS[mode]
+        self.in_channels = _make_divisible(int(32 * min(1.0, width_mult)))
+        self.conv1 = ConvBNReLU(3, self.in_channels, 3, 2, 1)
+        self.layer1 = self._make_layer(bottleneck, l1, width_mult, 1)
+        self.layer2 = self._make_layer(bottleneck, l2, width_mult, 1)
+        self.layer3 = self._make_layer(bottleneck, l3, width_mult, 1)
+        dilation = 2 if dilated else 1          # no effect, like the reference
+        self.layer4 = self._make_layer(bottleneck, l4, width_mult, dilation)
+        self.layer5 = self._make_layer(bottleneck, l5, width_mult, dilation)
+        last_in_channels = self.in_channels
+        self.last_layer = ConvBNReLU(last_in_channels, 1280, 1)
+        self.classifier = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Dropout(drop_rate), nn.Conv2d(1280, nclass, 1))
+        self.mode = mode
+        self._init_weights()
+        if self.quantized:
+            self.quant = torch.quantization.QuantStub()
+            self.dequant = torch.quantization.DeQuantStub()
+
+    def forward(self, x):
+        if x.is_cuda:
+            return self.hip_runner().forward(x)
+        if self.quantized:
+            x = self.quant(x)
+        x = self.conv1(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        x = self.layer4(x)
+        x = self.layer5(x)
+        x = self.last_layer(x)
+        x = self.classifier(x)
+        if self.quantized:
+            x = self.dequant(x)
+        return x.view(x.size(0), x.size(1))
+
+
+def _factory(mode, width, quantized):
+    def fn(**kwargs):
+        return FrostNet(nclass=1000, mode=mode, width_mult=width, quantized=quantized, bottleneck=CascadePreExBottleneck,
+                        **kwargs)
+    return fn
+
+
+for _q in (True, False):
+    for _mode in ('large', 'base', 'small'):
+        for _wm, _tag in ((1.25, '1_25'), (1.0, '1_0'), (0.75, '0_75'), (0.5, '0_5'), (0.35, '0_35')):
+            _name = f"frostnet_{'quant_' if _q else ''}{_mode}_{_tag}"
+            _fn = _factory(_mode, _wm, _q)
+            _fn.__name__ = _name
+            _fn.__qualname__ = _name
+            globals()[_name] = register_model(_fn)
+            MODEL_REGISTRY.setdefault(_name, globals()[_name])
+
+
+def create_model(name, pretrained=False, **kwargs):
+    """timm-style entry point: `num_classes`/`pretrained` are accepted and ignored like the reference."""
+    return MODEL_REGISTRY[name](**kwargs)
+
+
+def qat_prepare(model, version=0, backend="qnnpack"):
+    """Classification/train.py:166-173: fuse -> qconfig -> prepare_qat, parameters keep their identity."""
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    model.train()
+    model.fuse_model()
+    model.qconfig = get_default_qat_qconfig(backend, version=version)
+    prepare_qat(model, inplace=True)
+    return model

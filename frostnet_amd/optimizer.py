@@ -1,0 +1,285 @@
+"""GradBoost optimizers on MI355X -- same surface as the reference `optimizer.py` (get_optimizer :6-48, QSGD :51-206,
+QRMSprop :208-359, QAdam :361-512, QAdamW :514-667): constructor kwargs, the public `is_warmup` flag (StatAssist ->
+GradBoost hand-off, Classification/train.py:162-164), `step(closure)` and the per-parameter state keys
+(`step, restart_step, exp_min, exp_max, coin_toss, momentum_buffer | square_avg, grad_avg | exp_avg, exp_avg_sq,
+max_exp_avg_sq`) so checkpoints interchange.
+
+What differs, by design: the reference loops in Python over one param group per tensor, issuing ~15 tiny torch kernels
+plus a host `np.random.laplace` draw and an H2D copy per tensor; here ONE multi-tensor HIP launch
+(`frost_gradboost_step`) updates every tensor, with |Laplace| noise and the coin drawn on-device from Philox.  All
+step-varying scalars (lr, bias corrections, noise scale, Philox offset) live in device memory, so the launch can be
+captured in a hipGraph.  `inject(noise, coin)` feeds recorded draws for bit-parity tests.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from . import _lib as L
+from ._lib import call, ptr, stream
+
+_KIND = {"QSGD": 0, "QRMS": 1, "QAdam": 2, "QAdamW": 3}
+_T_STRIDE = C.sizeof(L.FrostOptTensor) // 4      # table row, in 4-byte words
+_T_WD, _T_LR, _T_FIRST = 18, 19, 20
+
+
+def get_optimizer(optim, params_set, args):
+    """optimizer.py:6-48 -- same names, same fixed hyper-parameters."""
+    if optim == "SGD":
+        return torch.optim.SGD(params_set, args.learning_rate, momentum=0.9, weight_decay=args.weight_decay,
+                               nesterov=args.nesterov)
+    if optim == "RMS":
+        return torch.optim.RMSprop(params_set, args.learning_rate, alpha=0.9, momentum=0.9, eps=1e-8,
+                                   weight_decay=args.weight_decay)
+    if optim == "Adam":
+        return torch.optim.Adam(params_set, args.learning_rate, betas=(0.9, 0.999), eps=1e-08,
+                                weight_decay=args.weight_decay)
+    if optim == "AdamW":
+        return torch.optim.AdamW(params_set, args.learning_rate, betas=(0.9, 0.999), eps=1e-08,
+                                 weight_decay=args.weight_decay, amsgrad=args.amsgrad)
+    if optim == "QSGD":
+        return QSGD(params_set, args.learning_rate, momentum=0.9, weight_decay=args.weight_decay, nesterov=args.nesterov,
+                    clip_by=args.clip_by, toss_coin=args.toss_coin, noise_decay=args.noise_decay)
+    if optim == "QRMS":
+        return QRMSprop(params_set, args.learning_rate, alpha=0.9, momentum=0.9, eps=1e-8, weight_decay=args.weight_decay,
+                        clip_by=args.clip_by, toss_coin=args.toss_coin, noise_decay=args.noise_decay)
+    if optim == "QAdam":
+        return QAdam(params_set, args.learning_rate, betas=(0.9, 0.999), eps=1e-08, weight_decay=args.weight_decay,
+                     amsgrad=args.amsgrad, clip_by=args.clip_by, toss_coin=args.toss_coin, noise_decay=args.noise_decay)
+    if optim == "QAdamW":
+        return QAdamW(params_set, args.learning_rate, betas=(0.9, 0.999), eps=1e-08, weight_decay=args.weight_decay,
+                      amsgrad=args.amsgrad, clip_by=args.clip_by, toss_coin=args.toss_coin, noise_decay=args.noise_decay)
+    raise ValueError(f"unknown optimizer {optim}")
+
+
+class _GradBoost(Optimizer):
+    KIND = None
+    STATE = ()          # (state key, table slot) for buf0..buf2
+
+    def __init__(self, params, defaults, seed=1882):
+        self.is_warmup = True
+        self._seed = seed
+        self._offset = 0
+        self._inject = None
+        self._plan = None
+        super().__init__(params, defaults)
+
+    # ---- parity hook: recorded |Laplace| draws and coins, concatenated in parameter order
+    def inject(self, noise, coin):
+        self._inject = (noise.contiguous().float(), coin.contiguous().float())
+
+    def _state_keys(self, group):
+        raise NotImplementedError
+
+    def _init_state(self, p, group):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["restart_step"] = 0
+            for k in self._state_keys(group):
+                st[k] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _hyper(self, group):
+        raise NotImplementedError
+
+    def _build_plan(self):
+        """Device table of every (param, state) pointer; rebuilt only when the set of tensors with grads changes."""
+        items = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("frostnet_amd GradBoost optimizers run on the HIP device only (no CPU fallback)")
+                items.append((p, group))
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in items)
+        if self._plan is not None and self._plan["sig"] == sig:
+            return self._plan
+        arr = (L.FrostOptTensor * len(items))()
+        prefix, tot = [], 0
+        for i, (p, group) in enumerate(items):
+            st = self._init_state(p, group)
+            t = arr[i]
+            t.p, t.g = p.data_ptr(), p.grad.data_ptr()
+            t.exp_min, t.exp_max = st["exp_min"].data_ptr(), st["exp_max"].data_ptr()
+            t.coin = st["coin_toss"].data_ptr() if "coin_toss" in st else None
+            for key, slot in self.STATE:
+                if key in st:
+                    setattr(t, slot, st[key].data_ptr())
+            t.n = p.numel()
+            t.weight_decay, t.lr, t.first_step = group["weight_decay"], group["lr"], 0
+            prefix.append(tot)
+            tot += p.numel()
+        dev = items[0][0].device
+        table = L.struct_to_tensor(arr, dev)
+        self._plan = dict(sig=sig, items=items, table=table, words=table.view(torch.int32).view(len(items), _T_STRIDE),
+                          prefix=torch.tensor(prefix, dtype=torch.int64, device=dev),
+                          hyper=torch.zeros(C.sizeof(L.FrostOptHyper), dtype=torch.uint8, device=dev),
+                          max_n=max(p.numel() for p, _ in items), total=tot,
+                          lr_host=None, wd_host=None)
+        return self._plan
+
+    def prepare_step(self):
+        """Host side of a step: advance counters, refresh the device-resident scalars (lr, bias corrections, noise
+        scale, Philox offset).  Everything the kernel reads afterwards is in device memory."""
+        plan = self._build_plan()
+        items = plan["items"]
+        boost = not self.is_warmup
+        steps = set()
+        for p, group in items:
+            st = self.state[p]
+            st["step"] += 1
+            if boost:
+                st["restart_step"] += 1
+            steps.add((st["step"], st["restart_step"]))
+        if len(steps) != 1:
+            raise RuntimeError("GradBoost multi-tensor step requires all tensors to share the same step count")
+        step, rstep = steps.pop()
+        group0 = items[0][1]
+        h = self._hyper(group0, step, rstep, boost)
+        h.seed, h.offset = self._seed, self._offset
+        self._offset += 1
+        plan["hyper"].copy_(torch.frombuffer(bytearray(bytes(memoryview(h).cast("B"))), dtype=torch.uint8), non_blocking=False)
+        lrs = [g["lr"] for _, g in items]
+        wds = [g["weight_decay"] for _, g in items]
+        if plan["lr_host"] != lrs:
+            plan["words"][:, _T_LR] = torch.tensor(lrs, dtype=torch.float32).view(torch.int32).to(plan["words"].device)
+            plan["lr_host"] = lrs
+        if plan["wd_host"] != wds:
+            plan["words"][:, _T_WD] = torch.tensor(wds, dtype=torch.float32).view(torch.int32).to(plan["words"].device)
+            plan["wd_host"] = wds
+        first = 1 if (self._needs_first_flag(group0) and step == 1) else 0
+        if plan.get("first") != first:
+            plan["words"][:, _T_FIRST] = first
+            plan["first"] = first
+        return plan
+
+    def _needs_first_flag(self, group):
+        return False
+
+    def launch(self, plan=None):
+        plan = plan or self._plan
+        noise = coin = None
+        if self._inject is not None:
+            noise, coin = self._inject
+            self._inject = None
+        call("frost_gradboost_step", ptr(plan["table"]), len(plan["items"]), plan["max_n"], ptr(plan["hyper"]),
+             ptr(noise), ptr(coin), ptr(plan["prefix"]), stream())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.launch(self.prepare_step())
+        return loss
+
+    def _base_hyper(self, group, step, rstep, boost, beta):
+        h = L.FrostOptHyper()
+        h.kind, h.boost = _KIND[self.KIND], 1 if boost else 0
+        h.toss_coin = 1 if group["toss_coin"] else 0
+        h.beta = beta
+        h.clip_by = group["clip_by"]
+        h.bc_beta = 1 - beta ** step
+        h.noise_scale = (1 - group["noise_decay"]) ** rstep
+        return h
+
+
+class QSGD(_GradBoost):
+    """optimizer.py:51-206."""
+    KIND = "QSGD"
+    STATE = (("momentum_buffer", "buf0"),)
+
+    def __init__(self, params, lr, momentum=0, dampening=0, weight_decay=0, nesterov=False, beta=0.9, eps=1e-8,
+                 clip_by=1e-3, toss_coin=True, noise_decay=1e-2):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if momentum < 0.0:
+            raise ValueError("Invalid momentum value: {}".format(momentum))
+        if weight_decay < 0.0:
+            raise ValueError("Invalid weight_decay value: {}".format(weight_decay))
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov, beta=beta, eps=eps, clip_by=clip_by, toss_coin=toss_coin,
+                                      noise_decay=noise_decay))
+
+    def _state_keys(self, group):
+        return ["exp_min", "exp_max"] + (["coin_toss"] if group["toss_coin"] else []) + \
+            (["momentum_buffer"] if group["momentum"] != 0 else [])
+
+    def _needs_first_flag(self, group):
+        return group["momentum"] != 0
+
+    def _hyper(self, group, step, rstep, boost):
+        h = self._base_hyper(group, step, rstep, boost, group["beta"])
+        h.momentum, h.dampening, h.nesterov = group["momentum"], group["dampening"], 1 if group["nesterov"] else 0
+        return h
+
+
+class QRMSprop(_GradBoost):
+    """optimizer.py:208-359."""
+    KIND = "QRMS"
+    STATE = (("momentum_buffer", "buf0"), ("square_avg", "buf1"), ("grad_avg", "buf2"))
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False, beta=0.9,
+                 clip_by=1e-3, toss_coin=True, noise_decay=1e-2):
+        for name, v in (("learning rate", lr), ("epsilon value", eps), ("momentum value", momentum),
+                        ("weight_decay value", weight_decay), ("alpha value", alpha)):
+            if not 0.0 <= v:
+                raise ValueError("Invalid {}: {}".format(name, v))
+        super().__init__(params, dict(lr=lr, momentum=momentum, alpha=alpha, eps=eps, centered=centered,
+                                      weight_decay=weight_decay, beta=beta, clip_by=clip_by, toss_coin=toss_coin,
+                                      noise_decay=noise_decay))
+
+    def _state_keys(self, group):
+        return ["square_avg"] + (["momentum_buffer"] if group["momentum"] > 0 else []) + \
+            (["grad_avg"] if group["centered"] else []) + ["exp_min", "exp_max"] + (["coin_toss"] if group["toss_coin"] else [])
+
+    def _hyper(self, group, step, rstep, boost):
+        h = self._base_hyper(group, step, rstep, boost, group["beta"])
+        h.momentum, h.alpha, h.eps, h.centered = group["momentum"], group["alpha"], group["eps"], 1 if group["centered"] else 0
+        return h
+
+
+class QAdam(_GradBoost):
+    """optimizer.py:361-512."""
+    KIND = "QAdam"
+    STATE = (("exp_avg", "buf0"), ("exp_avg_sq", "buf1"), ("max_exp_avg_sq", "buf2"))
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, clip_by=1e-3,
+                 toss_coin=True, noise_decay=1e-2):
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {}".format(eps))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
+                                      clip_by=clip_by, toss_coin=toss_coin, noise_decay=noise_decay))
+
+    def _state_keys(self, group):
+        return ["exp_avg", "exp_avg_sq", "exp_min", "exp_max"] + (["coin_toss"] if group["toss_coin"] else []) + \
+            (["max_exp_avg_sq"] if group["amsgrad"] else [])
+
+    def _hyper(self, group, step, rstep, boost):
+        b1, b2 = group["betas"]
+        h = self._base_hyper(group, step, rstep, boost, b1)
+        h.beta1, h.beta2, h.eps, h.amsgrad = b1, b2, group["eps"], 1 if group["amsgrad"] else 0
+        h.bc1, h.bc2 = 1 - b1 ** step, math.sqrt(1 - b2 ** step)
+        return h
+
+
+class QAdamW(QAdam):
+    """optimizer.py:514-667 (decoupled weight decay)."""
+    KIND = "QAdamW"
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, clip_by=1e-3,
+                 toss_coin=True, noise_decay=1e-2):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad,
+                         clip_by=clip_by, toss_coin=toss_coin, noise_decay=noise_decay)

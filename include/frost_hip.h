@@ -1,0 +1,199 @@
+/* libfrost_hip.so -- C ABI of the MI355X-native FrostNet QAT hot path.
+ *
+ * The reference (clovaai/frostnet) has NO FFI: its hot path is torch eager-mode QAT modules composed in
+ * Python (frostnet.py:14-145, optimizer.py:121-667, Classification/train.py:166-173).  This header is the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md): every entry replaces one stage of the
+ * torch module graph the reference executes, cited per function as `replaces:`.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.  All pointers are DEVICE pointers owned by
+ *    the caller.  Every call is asynchronous on `stream` (a hipStream_t passed as void*) and never syncs.
+ *  - return 0 on success, >0 = argument error, <0 = -(hipError_t).  Nothing aborts or throws.
+ *  - Activations: NHWC, one signed byte per element holding (q - 128), q = the reference's quint8 index
+ *    ("offset-binary index").  Channel counts are multiples of 4 (FrostNet: multiples of 8).
+ *    Activation buffers must be allocated with >= 64 bytes of slack after the last element.
+ *  - qrecord: 8 floats per fake-quantize site (FROST_Q_*): observer min/max, scale, zero_point(int bits),
+ *    fake-quantised tensor min/max, 1/scale.  torch's module buffers are views into these records.
+ *  - gradients of activations: bf16, NHWC.  Parameter gradients: fp32.
+ */
+#ifndef FROST_HIP_H
+#define FROST_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FROST_ABI_VERSION 1
+
+/* qrecord field indices (floats) */
+#define FROST_Q_MIN 0
+#define FROST_Q_MAX 1
+#define FROST_Q_SCALE 2
+#define FROST_Q_ZP 3      /* int32 bits */
+#define FROST_Q_FQMIN 4
+#define FROST_Q_FQMAX 5
+#define FROST_Q_INV 6
+#define FROST_Q_FLAGS 7   /* int32 bits: bit0 observer_enabled(default 1 when 0 written as 0x0?) see frost_qrecord_init */
+#define FROST_Q_STRIDE 8
+
+/* per-conv-layer coefficient rows (floats, each row `cpad` long; cpad = round_up(cout,16)) */
+#define FROST_COEF_A 0      /* y = fma(A, acc, B)                                   */
+#define FROST_COEF_B 1
+#define FROST_COEF_M 2      /* xhat = (acc - M) * R                                 */
+#define FROST_COEF_R 3
+#define FROST_COEF_K1 4     /* dc = K1 * (gy - S1/n - xhat*S2/n)                    */
+#define FROST_COEF_S1 5     /* sum gy      (written by the backward reduce pass)    */
+#define FROST_COEF_S2 6     /* sum gy*xhat                                          */
+#define FROST_COEF_VFRAC 7  /* v/(v+eps): d(gamma) = S2*VFRAC + fold term           */
+#define FROST_COEF_ROWS 8
+
+/* stats scratch per conv layer: 24 bytes per (padded) channel: int64 sum, uint64 sumsq, int32 min, int32 max,
+ * laid out SoA: [cpad] i64 | [cpad] u64 | [cpad] i32 | [cpad] i32 */
+#define FROST_STATS_BYTES_PER_CH 24
+
+int frost_abi_version(void);
+const char* frost_last_error(void);
+
+/* ---- element-wise / observer -------------------------------------------------------------------------- */
+/* replaces: MovingAverageMinMaxObserver.forward's torch.aminmax (torch/ao/quantization/observer.py:668-683)
+ * out2[0]=min, out2[1]=max (must be pre-set to +inf/-inf by frost_fill_minmax) */
+int frost_minmax_f32(const float* x, int64_t n, float* out2, void* stream);
+int frost_fill_minmax(float* out2, int count, void* stream);
+/* min/max of the logical (N,C,H,W) fp32 input with arbitrary element strides (the QuantStub observer) */
+int frost_minmax_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                       float* out2, void* stream);
+/* replaces: observer EMA + _calculate_qparams (observer.py:349-427) for ONE site.
+ * cur2 = {min,max} of the current tensor (raw floats).  symmetric: 0 = quint8 affine 0..255, 1 = qint8 -128..127.
+ * rule127: 0 = '/127.5' (qconfig version 0), 1 = max(-min/128,max/127) (version 1). fqmin/max are derived from cur2. */
+int frost_observer_update(float* qrec, const float* cur2, int symmetric, int rule127, int observe, void* stream);
+/* replaces: QuantStub's FakeQuantize on the input image (frostnet.py:319-320).  x: fp32 with arbitrary
+ * strides (elements) for logical (N,C,H,W); out: NHWC int8 with C padded to cpad (pad lanes = zero-point). */
+int frost_quantize_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         const float* qrec, int8_t* out, int cpad, void* stream);
+/* generic fake-quant fwd / STE bwd on fp32 (torch.fake_quantize_per_tensor_affine, fake_quantize.py:242-259) */
+int frost_fake_quant_f32(const float* x, int64_t n, const float* qrec, int qmin, int qmax, float* y, uint8_t* mask,
+                         void* stream);
+int frost_fake_quant_bwd_f32(const float* dy, const uint8_t* mask, int64_t n, float* dx, void* stream);
+/* dequantise an activation (offset-binary int8 NHWC) to fp32 (for taps / tests) */
+int frost_dequant_act(const int8_t* q, int64_t n, const float* qrec, float* y, void* stream);
+
+/* ---- weights: BN-fold + weight fake-quant + MFMA packing --------------------------------------------- */
+/* replaces: ConvBn2d._forward_approximate lines 135-143 (scale_factor, weight_fake_quant) for a LIST of layers
+ * in three launches.  Descriptor table lives in device memory (see FrostWDesc). */
+typedef struct FrostWDesc {
+  const float* w;        /* OIHW fp32 [cout][cin_g][k][k]                                    */
+  const float* gamma;    /* bn.weight  (NULL for the classifier: no fold)                   */
+  const float* rvar;     /* bn.running_var (value BEFORE this step's update)               */
+  float* qrec;           /* weight fake-quant qrecord                                       */
+  int8_t* wq_pack;       /* packed int8 weights, layout by `kind`                           */
+  int32_t* wsum;         /* [cpad] sum_k wq                                                 */
+  float* minmax2;        /* scratch {min,max}                                               */
+  uint16_t* wt_pack;     /* bf16 transposed pack for dgrad (pw only, may be NULL)           */
+  int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem(3x3 dense cin<=4), 3 classifier */
+  int32_t cpad, kpad, reserved0, reserved1;
+} FrostWDesc;
+int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe, void* stream);
+
+/* ---- conv stats / finalize / emit ---------------------------------------------------------------------- */
+/* reset the per-layer integer stats scratch (sum=0,sumsq=0,min=INT_MAX,max=INT_MIN); cpads/offs are device arrays */
+int frost_stats_init_table(void* stats, const int32_t* cpads, const int64_t* offs, int nlayers, void* stream);
+/* replaces: F.conv2d of a 1x1 conv on fake-quantised operands (conv_fused.py:152) -- int8 MFMA.
+ * mode 0: accumulate per-channel stats only.  mode 1: emit y=fq(relu?(A*acc+B)) as offset-binary int8. */
+int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix,
+                      int cin, int cout, int mode, void* stats, const float* coef, const float* qrec_y, int relu,
+                      int8_t* y, void* stream);
+/* replaces: depthwise k x k conv (groups=C) on fake-quantised operands.  x NHWC [n,h,w,c]. */
+int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
+                      int w, int c, int k, int stride, int mode, void* stats, const float* coef, const float* qrec_y,
+                      int relu, int8_t* y, void* stream);
+/* replaces: stem 3x3 s2 conv 3->cout (frostnet.py:277); x NHWC with cpad_in=4 */
+int frost_stem_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
+                        int w, int cout, int mode, void* stats, const float* coef, const float* qrec_y, int relu,
+                        int8_t* y, void* stream);
+/* replaces: conv/scale_factor, BatchNorm2d (train: batch stats + running-stat update; eval: running stats),
+ * the activation observer + qparams (conv_fused.py:153-157, fake_quantize.py:229-240).  One launch per layer. */
+int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
+                        const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
+                        int relu, int observe, float* coef, float* qrec_y, void* stream);
+
+/* ---- cat / add ------------------------------------------------------------------------------------------ */
+/* replaces: FloatFunctional.cat + its FakeQuantize (frostnet.py:129) */
+int frost_cat_observe(const float* qrec_a, const float* qrec_b, float* qrec_y, int observe, void* stream);
+int frost_cat_requant(const int8_t* a, const float* qrec_a, int ca, const int8_t* b, const float* qrec_b, int cb,
+                      int64_t npix, const float* qrec_y, int8_t* y, void* stream);
+/* replaces: FloatFunctional.add + its FakeQuantize (frostnet.py:142): pass 0 = min/max of a+b, pass 1 = emit */
+int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                     float* minmax2, void* stream);
+int frost_add_requant(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                      const float* qrec_y, int8_t* y, void* stream);
+
+/* ---- head: avg-pool + dropout + classifier (frostnet.py:295-299) -------------------------------------- */
+int frost_avgpool(const int8_t* x, const float* qrec_x, int n, int hw, int c, const float* drop_mask, float* y,
+                  void* stream);
+/* y[n][nclass] = x[n][cin] . wq^T * s_w + bias  (fp32, weights int8 fake-quantised) */
+int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n, int cin,
+                         int nclass, float* y, void* stream);
+
+/* ---- backward ------------------------------------------------------------------------------------------- */
+/* pass 0: S1=sum gy, S2=sum gy*xhat (into coef rows S1,S2); pass 1: write dc (bf16 [npix][cout]) and
+ * dx (bf16 [npix][cin], beta=accumulate flag) */
+int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                      const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout, int pass,
+                      float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, uint16_t* dx,
+                      int accumulate, void* stream);
+/* dWq[cout][cin] += sum_p dc[p][cout] * (x[p][cin]-zp) * s_x  (fp32 accumulate into dwq, must be zeroed) */
+int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int64_t npix, int cin, int cout,
+                   float* dwq, void* stream);
+int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                      const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
+                      const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream);
+int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c, int k,
+                   int stride, uint16_t* dx, int accumulate, void* stream);
+int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
+                   int stride, float* dwq, void* stream);
+int frost_stem_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
+                        int w, int cout, int pass, float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                        float* dwq, void* stream);
+/* fold-path: dW = dWq*mask*sf ; dgamma = S2*vfrac + sum(dWq*mask*W)/sigma_r ; dbeta = S1  (SURVEY H-5) */
+/* sigma_r[c] = sqrt(running_var+eps) as used by THIS step's forward (frost_save_sigma runs before the update) */
+int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,
+                               const float* qrec_w, const float* coef, int cout, int cin_g, int kk, int cpad,
+                               float* dw, float* dgamma, float* dbeta, int accumulate, void* stream);
+int frost_save_sigma(const FrostWDesc* descs, float* const* outs, int nlayers, void* stream);
+/* STE mask of the logits' activation fake-quant: out = g * [0 <= rint(raw/s)+zp <= 255] */
+int frost_mask_logits(const float* g, const float* raw, const float* qrec_y, int64_t n, float* out, void* stream);
+int frost_cat_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, int ca, const int8_t* b,
+                  const float* qrec_b, int cb, int64_t npix, const float* qrec_y, uint16_t* ga, int acc_a,
+                  uint16_t* gb, int acc_b, void* stream);
+int frost_add_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b,
+                  int64_t n, const float* qrec_y, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream);
+int frost_head_bwd(const float* dlogits_masked, const float* pooled, const int8_t* wq, const float* qrec_w, int n,
+                   int cin, int nclass, int hw, const float* drop_mask, float* dwq, float* dbias, uint16_t* gx,
+                   float* scratch_dpool, void* stream);
+
+/* ---- GradBoost optimizers (optimizer.py:121-206, 264-359, 411-512, 564-667) ------------------------- */
+typedef struct FrostOptTensor {
+  float* p; float* g; float* exp_min; float* exp_max; float* coin; float* buf0; float* buf1; float* buf2;
+  int64_t n; float weight_decay; float lr; int32_t first_step; int32_t pad;
+} FrostOptTensor;
+typedef struct FrostOptHyper {
+  int32_t kind;            /* 0 QSGD, 1 QRMS, 2 QAdam, 3 QAdamW */
+  int32_t boost;           /* !is_warmup */
+  int32_t toss_coin, nesterov, amsgrad, centered;
+  float beta, momentum, dampening, alpha, eps, beta1, beta2, clip_by;
+  float bc_beta;           /* 1 - beta^step            */
+  float noise_scale;       /* (1-noise_decay)^restart_step */
+  float bc1, bc2;          /* Adam: bc1 = 1-beta1^t ; bc2 = sqrt(1-beta2^t) (already square-rooted) */
+  uint64_t seed, offset;   /* Philox stream when noise/coin are not injected */
+} FrostOptHyper;
+/* noise/coin: optional injected tensors (concatenated in table order) for parity tests; NULL = on-device Philox */
+/* table, hyper, prefix (int64 element offset of each tensor in the noise/coin/Philox index space) are DEVICE
+ * memory so a captured hipGraph picks up new lr / bias corrections / offsets without re-capture. */
+int frost_gradboost_step(const FrostOptTensor* table, int ntensors, int64_t max_n, const FrostOptHyper* hyper,
+                         const float* noise, const float* coin, const int64_t* prefix, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
