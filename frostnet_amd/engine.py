@@ -210,6 +210,8 @@ class Engine:
         a = self.new_act(n, h, w, cpad, q)
         call("frost_quantize_input", ptr(x), n, c, h, w, sn, sc, sh, sw, ptr(q), ptr(a.buf), cpad, stream())
         a.needs_grad = False
+        if getattr(self, "trace", None) is not None:
+            self.trace.append(("input", a))
         return a
 
     def _conv_launch(self, l, x, mode, y):
@@ -236,6 +238,8 @@ class Engine:
              ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
              1 if observe else 0, ptr(l.coef), ptr(l.qy), stream())
         self._conv_launch(l, x, 1, y)
+        if getattr(self, "trace", None) is not None:
+            self.trace.append((l.name, y))
         self.tape.append(("conv", l, x, y))
         return y
 
@@ -244,6 +248,8 @@ class Engine:
         call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
         y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
         call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream())
+        if getattr(self, "trace", None) is not None:
+            self.trace.append(("cat", y))
         self.tape.append(("cat", a, b, y))
         return y
 
@@ -257,6 +263,8 @@ class Engine:
             call("frost_observer_update", ptr(q), ptr(self._add_mm), 0, 0, 1, stream())
         y = self.new_act(a.n, a.h, a.w, a.c, q)
         call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream())
+        if getattr(self, "trace", None) is not None:
+            self.trace.append(("add", y))
         self.tape.append(("add", a, b, y))
         return y
 

@@ -1,0 +1,199 @@
+"""Binds a QAT-prepared FrostNet module tree to the HIP engine.
+
+The module tree (stock torch / torch.ao modules, reference state_dict layout -- SURVEY.md Appendix C) stays the owner
+of every Parameter; its observer / fake-quant buffers (`scale`, `zero_point`, `min_val`, `max_val`) are re-pointed at
+rows of the engine's qrecord arena, so `state_dict()` / `load_state_dict()` keep working while the kernels update
+those scalars on-device.  Parameter gradients live in ONE flat fp32 arena (views assigned to `p.grad`), which is what
+the multi-tensor optimizer and the data-parallel all-reduce operate on.
+"""
+import torch
+
+from . import _lib as L
+from .engine import ConvLayer, Engine, QArena
+
+
+class _QATFunction(torch.autograd.Function):
+    """autograd boundary: image -> logits.  backward() runs the hand-written backward pass, which writes the parameter
+    gradients straight into the gradient arena (p.grad views) -- nothing is returned through autograd."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, runner):
+        ctx.runner = runner
+        return runner._forward_impl(x, record=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.runner._backward_impl(dlogits)
+        return None, None, None
+
+
+def _is_fused_fq(fq):
+    return type(fq).__name__ == "FusedMovingAvgObsFakeQuantize"
+
+
+class FrostRunner:
+    def __init__(self, model):
+        L.load_library()   # raises if the HIP library is missing: no CPU fallback on the device path
+        self.model = model
+        if not model._is_qat_prepared():
+            raise NotImplementedError(
+                "frostnet_amd: the HIP path implements the fake-quantised (QAT) FrostNet; call fuse_model() + "
+                "torch.quantization.prepare_qat (or frostnet_amd.qat_prepare) before moving activations to the GPU. "
+                "The float (StatAssist warm-up) graph runs on the CPU path only in this round.")
+        params = list(model.parameters())
+        self.device = params[0].device
+        self.E = Engine(self.device)
+        self._sig = tuple(p.data_ptr() for p in params) + tuple(b.data_ptr() for b in model.buffers())
+        self._build()
+
+    @classmethod
+    def for_block(cls, block):
+        """Bind a single QAT-prepared CascadePreExBottleneck (teacher-forced block tests)."""
+        L.load_library()
+        r = cls.__new__(cls)
+        r.model, r.device = block, next(block.parameters()).device
+        r.E, r.qa, r.rule127, r.observe = Engine(r.device), QArena(32, r.device), False, True
+        r.block = r._bind_block("B", block)
+        r.E.rule127 = 1 if r.rule127 else 0
+        r._params = list(block.parameters())
+        r.grad_arena = torch.zeros(sum(p.numel() for p in r._params), dtype=torch.float32, device=r.device)
+        r._grad_views, off = [], 0
+        for p in r._params:
+            r._grad_views.append(r.grad_arena[off: off + p.numel()].view_as(p))
+            off += p.numel()
+        return r
+
+    def still_valid(self):
+        m = self.model
+        sig = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())
+        return sig == self._sig
+
+    # ------------------------------------------------------------------------------------------ binding
+    def _bind_fq(self, fq, rec):
+        """Copy the module's current observer/qparam values into the qrecord, then alias the buffers onto it."""
+        obs = fq.activation_post_process
+        with torch.no_grad():
+            rec[L.Q_MIN] = obs.min_val.reshape(-1)[0].float() if obs.min_val.numel() else float("inf")
+            rec[L.Q_MAX] = obs.max_val.reshape(-1)[0].float() if obs.max_val.numel() else float("-inf")
+            rec[L.Q_SCALE] = fq.scale.reshape(-1)[0].float()
+            rec[L.Q_INV] = 1.0 / fq.scale.reshape(-1)[0].float()
+            rec.view(torch.int32)[L.Q_ZP] = fq.zero_point.reshape(-1)[0].to(torch.int32)
+        fq._buffers["scale"] = rec[L.Q_SCALE:L.Q_SCALE + 1]
+        fq._buffers["zero_point"] = rec.view(torch.int32)[L.Q_ZP:L.Q_ZP + 1]
+        obs._buffers["min_val"] = rec[L.Q_MIN]
+        obs._buffers["max_val"] = rec[L.Q_MAX]
+        return rec
+
+    def _conv_layer(self, name, blk, kind):
+        m = blk.conv[0]   # nniqat.ConvBnReLU2d / ConvBn2d
+        relu = type(m).__name__ == "ConvBnReLU2d"
+        qw = self._bind_fq(m.weight_fake_quant, self.qa.alloc())
+        qy = self._bind_fq(m.activation_post_process, self.qa.alloc())
+        self.rule127 = self.rule127 or _is_fused_fq(m.weight_fake_quant)
+        l = ConvLayer(name, kind, m.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var,
+                      m.bn.num_batches_tracked, None, m.kernel_size[0], m.stride[0], relu, qw, qy)
+        return self.E.add_layer(l)
+
+    def _bind_block(self, pre, b):
+        d = dict(mod=b, squeeze=None, conv1=None, q_cat=None, q_add=None)
+        if b.expand_ratio != 1:
+            if b.block_type == "CAS":
+                d["squeeze"] = self._conv_layer(pre + ".squeeze_conv", b.squeeze_conv, "pw")
+                d["q_cat"] = self._bind_fq(b.quant_cat.activation_post_process, self.qa.alloc())
+            d["conv1"] = self._conv_layer(pre + ".conv1", b.conv1, "pw")
+        d["conv2"] = self._conv_layer(pre + ".conv2", b.conv2, "dw")
+        d["reduce"] = self._conv_layer(pre + ".reduce_conv", b.reduce_conv, "pw")
+        if not b.reduction:
+            d["q_add"] = self._bind_fq(b.skip_add.activation_post_process, self.qa.alloc())
+        return d
+
+    def block_forward(self, d, inp, training, obs):
+        """CascadePreExBottleneck.forward (frostnet.py:124-145) on the engine."""
+        E = self.E
+        out = inp
+        if d["conv1"] is not None:
+            if d["squeeze"] is not None:
+                sq = E.conv(d["squeeze"], inp, training, obs)
+                out = E.cat(sq, inp, d["q_cat"], obs)
+            out = E.conv(d["conv1"], out, training, obs)
+        out = E.conv(d["conv2"], out, training, obs)
+        out = E.conv(d["reduce"], out, training, obs)
+        if d["q_add"] is not None:
+            out = E.add(inp, out, d["q_add"], obs)
+        return out
+
+    def _build(self):
+        m = self.model
+        blocks = [b for layer in (m.layer1, m.layer2, m.layer3, m.layer4, m.layer5) for b in layer]
+        nsites = 1 + 2 * (2 + 4 * len(blocks)) + 2 * len(blocks) + 2 + 8
+        self.qa = QArena(nsites, self.device)
+        self.rule127 = False
+        self.q_in = self._bind_fq(m.quant.activation_post_process, self.qa.alloc())
+        self.stem = self._conv_layer("conv1", m.conv1, "stem")
+        self.blocks = []
+        for lname in ("layer1", "layer2", "layer3", "layer4", "layer5"):
+            for bi, b in enumerate(getattr(m, lname)):
+                self.blocks.append(self._bind_block(f"{lname}.{bi}", b))
+        self.last = self._conv_layer("last_layer", m.last_layer, "pw") if hasattr(m, "last_layer") else None
+        self.cls = None
+        if hasattr(m, "classifier"):
+            c = m.classifier[2]
+            qw = self._bind_fq(c.weight_fake_quant, self.qa.alloc())
+            qy = self._bind_fq(c.activation_post_process, self.qa.alloc())
+            self.cls = self.E.add_layer(ConvLayer("classifier.2", "cls", c.weight, None, None, None, None, None, c.bias,
+                                                  1, 1, False, qw, qy))
+            self.drop_rate = float(m.classifier[1].p)
+        self.E.rule127 = 1 if self.rule127 else 0
+        self.observe = True
+        # buffers were re-pointed: refresh the validity signature
+        self._sig = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())
+        # flat gradient arena, parameter order = model.parameters() (the reference's registration order)
+        params = list(m.parameters())
+        self.grad_arena = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
+        self._grad_views, off = [], 0
+        for p in params:
+            self._grad_views.append(self.grad_arena[off: off + p.numel()].view_as(p))
+            off += p.numel()
+        self._params = params
+
+    def bind_grads(self):
+        for p, v in zip(self._params, self._grad_views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    # ------------------------------------------------------------------------------------------ execution
+    def forward(self, x):
+        training = self.model.training
+        if training and torch.is_grad_enabled():
+            return _QATFunction.apply(self._params[0], x, self)
+        return self._forward_impl(x, record=False)
+
+    def _trunk(self, x, training):
+        E, obs = self.E, self.observe
+        E.begin_step(observe=obs)
+        a = E.quantize_input(x, self.q_in, observe=obs)
+        a = E.conv(self.stem, a, training, obs)
+        feats = []
+        for d in self.blocks:
+            a = self.block_forward(d, a, training, obs)
+            feats.append(a)
+        return a, feats
+
+    def _forward_impl(self, x, record):
+        training = self.model.training
+        if x.dtype != torch.float32:
+            x = x.float()
+        a, _ = self._trunk(x, training)
+        a = self.E.conv(self.last, a, training, self.observe)
+        drop = None
+        if training and self.drop_rate > 0.0:
+            keep = 1.0 - self.drop_rate
+            drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device).bernoulli_(keep).div_(keep)
+        logits = self.E.head(self.cls, a, drop, self.observe)
+        if not record:
+            self.E.tape = []
+        return logits
+
+    def _backward_impl(self, dlogits):
+        self.bind_grads()
+        self.E.backward(dlogits)
