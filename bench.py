@@ -1,0 +1,211 @@
+"""Headline benchmark: images/sec, FrostNet-Large 224x224 QAT forward+backward (+GradBoost step) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one synthetic batch: fake-quantised forward (int8 MFMA / LDS depthwise),
+hand-written backward, GradBoost-SGD multi-tensor update; for N>1 plus the bucketed RCCL gradient all-reduce
+overlapped with backward.  Per-GPU batch is fixed (weak scaling).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per image, FrostNet-Large w=1.0 @224, int8 activations + bf16 gradients
+ALGO_BYTES_PER_IMG = 45_593_016
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def cpu_baseline(batch=8, res=224):
+    """Reference-path stand-in timed on the host cores: the CPU oracle (restated torch eager QAT graph, kind 'port')."""
+    from oracle import frost_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.net_cfg("large", 1.0)
+    P, B = O.make_state(O.float_state_spec(cfg), 5000, True)
+    qs = O.QState(B)
+    x = torch.from_numpy(O.synth((batch, 3, res, res), 77))
+    tgt = torch.randint(0, 1000, (batch,))
+    hp = dict(lr=5e-3, momentum=0.9, weight_decay=1e-5, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+    states = {k: {} for k in P}
+    t0 = time.time()
+    y = O.frostnet_forward(P, qs, cfg, x, True, True)
+    torch.nn.functional.cross_entropy(y, tgt).backward()
+    with torch.no_grad():
+        for k, p in P.items():
+            g = p.grad
+            O.gradboost_step("QSGD", p, g, states[k], dict(hp, weight_decay=O.param_group_rule(tuple(p.shape), 1e-5)),
+                             boost=True, noise=torch.empty_like(p).exponential_(), coin=torch.randint(0, 2, p.shape).float())
+    dt = time.time() - t0
+    return dict(value=batch / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 step, batch {batch} @ {res}x{res}, FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU "
+                       f"kernels via oracle/frost_oracle.py, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE.json config 3: 512)")
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--mode", default="large")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as ge
+    if local_rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    import frostnet_amd
+    from frostnet_amd import _lib as L
+    from frostnet_amd import frostnet as F
+    from frostnet_amd.optimizer import QSGD
+    from frostnet_amd.parallel import broadcast_model
+
+    torch.manual_seed(1882)                       # Classification/train.py:38-39
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{args.mode}_1_0"]()     # drop_rate 0.2 active, as in training
+    F.qat_prepare(model, version=0)
+    model.to(dev).train()
+    broadcast_model(model)
+    wd = 1e-5                                     # Classification/setting/train.json:5-21
+    groups = [{"params": [p], "weight_decay": (0.0 if p.shape[1] == 1 else wd) if p.dim() == 4 else wd * 0.01}
+              for p in model.parameters()]
+    opt = QSGD(groups, lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2, weight_decay=wd)
+    opt.is_warmup = False                         # StatAssist epoch done -> GradBoost noise on (train.py:162-164)
+    runner = model.hip_runner()
+    sync = runner.enable_data_parallel(nbuckets=4) if world > 1 else None
+
+    g = torch.Generator(device=dev).manual_seed(1882 + rank)
+    x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    tgt = torch.randint(0, 1000, (args.batch,), device=dev, generator=g)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def fwd_bwd():
+        loss = crit(model(x), tgt)
+        loss.backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        return loss
+
+    for _ in range(max(1, min(args.warmup, 3))):      # first steps build tables / state before any capture
+        eager_step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                plan = opt.prepare_step()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    static_loss = fwd_bwd()
+                    opt.launch(plan)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            opt.prepare_step()
+            graph.replay()
+        else:
+            eager_step()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel HIP-event timing on the launch stream (eager pass: events cannot be read out of a replayed graph)
+        L.PROFILER = L.Profiler()
+        eager_step()
+        summ = L.PROFILER.summary()
+        dom = max(summ, key=lambda k: summ[k]["total_ms"])
+        L.PROFILER = L.Profiler(only=dom)
+        for _ in range(3):
+            eager_step()
+        s2 = L.PROFILER.summary()[dom]
+        L.PROFILER = None
+        achieved = s2["bytes_per_launch"] / (s2["avg_ms"] * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        avg_launch_ms=round(s2["avg_ms"], 4), launches_per_step=s2["launches"] // 3,
+                        algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),
+                        whole_step=dict(achieved=round(value / world * ALGO_BYTES_PER_IMG / 1e9, 1), unit="GB/s",
+                                        frac=round(value / world * ALGO_BYTES_PER_IMG / 1e9 / HBM_PEAK_GBS, 4),
+                                        algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG),
+                        breakdown_ms={k: round(v["total_ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cpu = cpu_baseline()
+            except Exception as e:  # pragma: no cover
+                cpu = dict(value=None, error=str(e))
+        out = dict(metric="images/sec FrostNet-Large 224x224 QAT fwd+bwd", value=round(value, 2), unit="images/sec",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
+                   config=dict(workload=f"FrostNet-{args.mode.capitalize()} int8 fake-quant QAT fwd+bwd + GradBoost-SGD step "
+                                        f"(noise on; StatAssist FP epoch is a one-off before it), batch={args.batch}/GPU, "
+                                        f"{args.res}x{args.res} NHWC, qnnpack qconfig v0 (per-tensor)",
+                               per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
+                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype="bf16"),
+                   roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,9 +101,39 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def call(name, *args):
+class Profiler:
+    """Per-launch HIP-event timing on the launch stream (bench.py's roofline leg). `only`: restrict to one label."""
+
+    def __init__(self, only=None):
+        self.only = only
+        self.records = []      # (label, algorithmic_bytes, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for label, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(label, [0, 0.0, 0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1)
+            a[2] += nbytes
+        return {k: dict(launches=v[0], total_ms=v[1], avg_ms=v[1] / v[0], bytes_per_launch=v[2] / v[0]) for k, v in agg.items()}
+
+
+PROFILER = None
+
+
+def call(name, *args, prof=None):
+    """Launch one C-ABI entry on the current stream. prof=(label, algorithmic_bytes) tags it for the Profiler."""
     lib = load_library()
-    rc = getattr(lib, name)(*args)
+    p = PROFILER
+    if p is not None and prof is not None and (p.only is None or p.only == prof[0]):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        p.records.append((prof[0], prof[1], e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (rc={rc}): {lib.frost_last_error().decode()}")
 

@@ -135,6 +135,7 @@ class Engine:
         self.layers = []
         self.tape = []
         self._table = None
+        self.on_layer_grads = None     # callback(layer) after a layer's parameter gradients are final (DP overlap)
 
     # ------------------------------------------------------------------------------------------ plan
     def add_layer(self, layer):
@@ -169,7 +170,8 @@ class Engine:
         self._ensure_tables()
         n = len(self.layers)
         call("frost_save_sigma", ptr(self._table), ptr(self._sigma_ptrs), n, stream())
-        call("frost_weight_prep", ptr(self._table), n, self._max_elems, self.rule127, 1 if observe else 0, stream())
+        call("frost_weight_prep", ptr(self._table), n, self._max_elems, self.rule127, 1 if observe else 0, stream(),
+             prof=("weight_prep", sum(4 * l.w.numel() + l.wq_pack.numel() for l in self.layers)))
         call("frost_stats_init_table", ptr(self._stats), ptr(self._cpads), ptr(self._offs), n, stream())
         self.tape = []
 
@@ -215,16 +217,21 @@ class Engine:
         return a
 
     def _conv_launch(self, l, x, mode, y):
+        """mode 0 = stats pass (reads x), mode 1 = emit pass (reads x, writes y).  Algorithmic bytes of a launch =
+        the activation bytes it must move at 1 B/element (+ the packed weights once)."""
         st = ptr(l.stats)
+        nb = x.numel + l.wq_pack.numel() + (y.numel if y is not None else 0)
+        tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)
         if l.kind == "pw":
             call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
-                 ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+                 ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
         elif l.kind == "dw":
             call("frost_dw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, x.c, l.k,
-                 l.stride, mode, st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+                 l.stride, mode, st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(),
+                 prof=tag)
         else:
             call("frost_stem_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout, mode,
-                 st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream())
+                 st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
 
     def conv(self, l, x, training=True, observe=True):
         """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute)."""
@@ -247,7 +254,8 @@ class Engine:
         """FloatFunctional.cat + its FakeQuantize (frostnet.py:129)."""
         call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
         y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
-        call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream())
+        call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream(),
+             prof=("cat_fwd", 2 * y.numel))
         if getattr(self, "trace", None) is not None:
             self.trace.append(("cat", y))
         self.tape.append(("cat", a, b, y))
@@ -259,10 +267,12 @@ class Engine:
             self._add_mm = torch.empty(2, dtype=torch.float32, device=self.device)
         if observe:
             call("frost_fill_minmax", ptr(self._add_mm), 1, stream())
-            call("frost_add_minmax", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), stream())
+            call("frost_add_minmax", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), stream(),
+                 prof=("add_fwd_minmax", 2 * a.numel))
             call("frost_observer_update", ptr(q), ptr(self._add_mm), 0, 0, 1, stream())
         y = self.new_act(a.n, a.h, a.w, a.c, q)
-        call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream())
+        call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream(),
+             prof=("add_fwd_emit", 3 * a.numel))
         if getattr(self, "trace", None) is not None:
             self.trace.append(("add", y))
         self.tape.append(("add", a, b, y))
@@ -304,22 +314,26 @@ class Engine:
                      ptr(drop), ptr(dwq), ptr(l.bias.grad), ptr(gx), ptr(dpool), stream())
                 call("frost_weight_grad_finalize", ptr(dwq), ptr(l.w), None, None, ptr(l.qw), ptr(l.coef), l.cout,
                      l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0, stream())
+                if self.on_layer_grads is not None:
+                    self.on_layer_grads(l)
             elif kind == "conv":
                 _, l, x, y = entry
                 self._conv_backward(l, x, y)
+                if self.on_layer_grads is not None:
+                    self.on_layer_grads(l)
             elif kind == "cat":
                 _, a, b, y = entry
                 ga, fa = self._grad_slot(a)
                 gb, fb = self._grad_slot(b)
                 call("frost_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q),
-                     ptr(ga), fa, ptr(gb), fb, stream())
+                     ptr(ga), fa, ptr(gb), fb, stream(), prof=("cat_bwd", 5 * y.numel))
                 y.grad = None
             elif kind == "add":
                 _, a, b, y = entry
                 ga, fa = self._grad_slot(a)
                 gb, fb = self._grad_slot(b)
                 call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
-                     fa, ptr(gb), fb, stream())
+                     fa, ptr(gb), fb, stream(), prof=("add_bwd", 8 * a.numel))
                 y.grad = None
         self.tape = []
 
@@ -339,20 +353,29 @@ class Engine:
         s = stream()
         if l.kind == "pw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout)
-            call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s)
-            call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s)
+            # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
+            call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
+                 prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+            call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
+                 prof=("pw_bwd_dc", x.numel + 4 * y.numel))
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
-                call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s)
-            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), s)
+                call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s,
+                     prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
+            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), s,
+                 prof=("pw_wgrad", 2 * y.numel + x.numel))
         elif l.kind == "dw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
-            call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s)
-            call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s)
+            call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
+                 prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
+            call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
+                 prof=("dw_bwd_dc", x.numel + 4 * y.numel))
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
-                call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s)
-            call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s)
+                call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s,
+                     prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
+            call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
+                 prof=("dw_wgrad", 2 * y.numel + x.numel))
         else:
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout)
             call("frost_stem_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s)

@@ -156,6 +156,17 @@ class FrostRunner:
             off += p.numel()
         self._params = params
 
+    def enable_data_parallel(self, nbuckets=4, group=None):
+        """Attach the bucketed, backward-overlapped gradient all-reduce (frostnet_amd.parallel.GradSync)."""
+        from .parallel import GradSync
+        offs, off = {}, 0
+        for p in self._params:
+            offs[p.data_ptr()] = off
+            off += p.numel()
+        self.grad_sync = GradSync(self.grad_arena, list(offs.values()), nbuckets, group)
+        self.E.on_layer_grads = lambda l: self.grad_sync.ready(offs[l.w.data_ptr()])
+        return self.grad_sync
+
     def bind_grads(self):
         for p, v in zip(self._params, self._grad_views):
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
