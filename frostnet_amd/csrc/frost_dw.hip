@@ -27,112 +27,128 @@ __device__ __forceinline__ void unpack4s(uint32_t v, float* f) {  // signed int8
   f[0] = (float)(int8_t)(v & 255u); f[1] = (float)(int8_t)((v >> 8) & 255u); f[2] = (float)(int8_t)((v >> 16) & 255u); f[3] = (float)(int8_t)(v >> 24);
 }
 
+// v2: 512 threads = 32 channel pairs x 16 output columns; each thread owns 2 channels x 1 column x 8 rows.
+// ~110 VGPRs -> 2 workgroups (16 waves) per CU, so one workgroup's halo staging overlaps the other's FMAs.
+// Staging loads are issued as one batch (fixed trip count) before a single wait.
+__device__ __forceinline__ void unpack2(uint32_t v, float* f) {    // two offset-binary bytes -> unsigned index floats
+  v ^= 0x8080u;
+  f[0] = (float)(v & 255u); f[1] = (float)((v >> 8) & 255u);
+}
+template <int K, int S>
+__device__ __forceinline__ void dw_stage_tile(const int8_t* __restrict__ x, uint8_t* smem, int tid, int img, int iy0, int ix0,
+                                              int cb, int h, int w, int c, uint32_t zfill) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int NU = (IH * IW * 8 + 511) / 512;
+  uint2 v[NU];
+#pragma unroll
+  for (int jn = 0; jn < NU; ++jn) {
+    const int u = tid + jn * 512;
+    const int c8 = u & 7; const int pix = u >> 3; const int iy = pix / IW, ix = pix - iy * IW;
+    const int gy = iy0 + iy, gx = ix0 + ix; const int cc = cb * CB + c8 * 8;
+    v[jn] = make_uint2(zfill, zfill);
+    if (u < IH * IW * 8 && gy >= 0 && gy < h && gx >= 0 && gx < w && cc < c)
+      v[jn] = *(const uint2*)(x + (((int64_t)img * h + gy) * w + gx) * c + cc);
+  }
+#pragma unroll
+  for (int jn = 0; jn < NU; ++jn) {
+    const int u = tid + jn * 512;
+    if (u < IH * IW * 8) *(uint2*)(smem + u * 8) = v[jn];
+  }
+}
+
 template <int K, int S, int MODE>
-__global__ __launch_bounds__(256) void k_dw(const DwP p) {
+__global__ __launch_bounds__(512, ((K == 3 && (S == 1 || MODE < 2)) ? 4 : 2)) void k_dw(const DwP p) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ double red_d[4][16][8]; __shared__ float red_f[4][16][8];
+  __shared__ double red_d[8][32][4]; __shared__ float red_f[8][32][4];
   const int tid = threadIdx.x;
-  const int cq = tid & 15, ox = tid >> 4;
+  const int cp = tid & 31, ox = tid >> 5;
   const int cb = blockIdx.x % p.ncb, grp = blockIdx.x / p.ncb;
-  const int c0 = cb * CB + cq * 4;
+  const int c0 = cb * CB + cp * 2;
   const bool chok = c0 < p.c;
   const int zp = __float_as_int(p.qx[FROST_Q_ZP]);
   const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
 
-  // hoisted weights (floats) and per-channel constants
-  float wf[K * K][4];
+  float wf[K * K][2];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
-    uint32_t v = chok ? *(const uint32_t*)(p.wq + t * p.cpad + c0) : 0u;
-    unpack4s(v, wf[t]);
+    const uint32_t v = chok ? (uint32_t)*(const uint16_t*)(p.wq + t * p.cpad + c0) : 0u;
+    wf[t][0] = (float)(int8_t)(v & 255u); wf[t][1] = (float)(int8_t)(v >> 8);
   }
-  float corr[4] = {0, 0, 0, 0};
-  if (chok) { int4 ws = *(const int4*)(p.wsum + c0); corr[0] = (float)(zp * ws.x); corr[1] = (float)(zp * ws.y); corr[2] = (float)(zp * ws.z); corr[3] = (float)(zp * ws.w); }
-  float A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0}, Mv[4] = {0, 0, 0, 0}, Rv[4] = {0, 0, 0, 0}, K1[4] = {0, 0, 0, 0}, S1[4] = {0, 0, 0, 0}, S2[4] = {0, 0, 0, 0};
+  float corr[2] = {0, 0};
+  if (chok) { corr[0] = (float)(zp * p.wsum[c0]); corr[1] = (float)(zp * p.wsum[c0 + 1]); }
   float y_inv = 1.0f; int y_zp = 0;
-  if (MODE != D_STATS) {
-    y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zp = __float_as_int(p.qy[FROST_Q_ZP]);
-    if (chok) {
+  if (MODE != D_STATS) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zp = __float_as_int(p.qy[FROST_Q_ZP]); }
+  double st1[2] = {0, 0}, st2[2] = {0, 0}; float smn[2] = {INFINITY, INFINITY}, smx[2] = {-INFINITY, -INFINITY};
+  float r1[2] = {0, 0}, r2[2] = {0, 0};
+
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
+    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
+    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+    __syncthreads();
+    dw_stage_tile<K, S>(p.x, smem, tid, img, oy0 * S - p.pad, ox0 * S - p.pad, cb, p.h, p.w, p.c, zfill);
+    __syncthreads();
+    float acc[TH][2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+    for (int o = 0; o < TH; ++o) { acc[o][0] = 0; acc[o][1] = 0; }
+#pragma unroll
+    for (int iy = 0; iy < IH; ++iy) {
+      float xf[K][2];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) unpack2(*(const uint16_t*)(smem + (iy * IW + ox * S + kx) * CB + cp * 2), xf[kx]);
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        if ((iy - ky) >= 0 && ((iy - ky) % S) == 0 && (iy - ky) / S < TH) {
+          const int o = (iy - ky) / S;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            acc[o][0] = fmaf(xf[kx][0], wf[ky * K + kx][0], acc[o][0]);
+            acc[o][1] = fmaf(xf[kx][1], wf[ky * K + kx][1], acc[o][1]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the LDS look-ahead to one row: register pressure, not latency, binds here
+    }
+    float A[2] = {0, 0}, B[2] = {0, 0}, Mv[2] = {0, 0}, Rv[2] = {0, 0}, K1[2] = {0, 0}, S1[2] = {0, 0}, S2[2] = {0, 0};
+    if (MODE != D_STATS && chok) {      // (re)loaded per tile from L1/L2: keeps them out of the main loop's live set
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
         A[r] = p.coef[FROST_COEF_A * p.cpad + c0 + r]; B[r] = p.coef[FROST_COEF_B * p.cpad + c0 + r];
-        Mv[r] = p.coef[FROST_COEF_M * p.cpad + c0 + r]; Rv[r] = p.coef[FROST_COEF_R * p.cpad + c0 + r];
+        if (MODE != D_EMIT) { Mv[r] = p.coef[FROST_COEF_M * p.cpad + c0 + r]; Rv[r] = p.coef[FROST_COEF_R * p.cpad + c0 + r]; }
         if (MODE == D_BDC) {
           K1[r] = p.coef[FROST_COEF_K1 * p.cpad + c0 + r];
           S1[r] = p.coef[FROST_COEF_S1 * p.cpad + c0 + r] * p.inv_count; S2[r] = p.coef[FROST_COEF_S2 * p.cpad + c0 + r] * p.inv_count;
         }
       }
     }
-  }
-  double st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0}; float smn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, smx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
-
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
-  for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
-    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
-    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
-    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
-    __syncthreads();
-    // stage halo tile: [IH][IW][64B], 8-byte units
-    for (int u = tid; u < IH * IW * 8; u += 256) {
-      const int c8 = u & 7; const int pix = u >> 3; const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix; const int cc = cb * CB + c8 * 8;
-      uint2 v = make_uint2(zfill, zfill);
-      if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w && cc < p.c)
-        v = *(const uint2*)(p.x + (((int64_t)img * p.h + gy) * p.w + gx) * p.c + cc);
-      *(uint2*)(smem + pix * CB + c8 * 8) = v;
-    }
-    __syncthreads();
-    float acc[TH][4];
-#pragma unroll
-    for (int o = 0; o < TH; ++o) { acc[o][0] = 0; acc[o][1] = 0; acc[o][2] = 0; acc[o][3] = 0; }
-#pragma unroll
-    for (int iy = 0; iy < IH; ++iy) {
-      float xf[K][4];
-#pragma unroll
-      for (int kx = 0; kx < K; ++kx) unpack4(*(const uint32_t*)(smem + (iy * IW + ox * S + kx) * CB + cq * 4), xf[kx]);
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        if ((iy - ky) >= 0 && ((iy - ky) % S) == 0 && (iy - ky) / S < TH) {
-          const int o = (iy - ky) / S;
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[o][r] = fmaf(xf[kx][r], wf[ky * K + kx][r], acc[o][r]);
-        }
-      }
-    }
-    // epilogue
 #pragma unroll
     for (int o = 0; o < TH; ++o) {
       const int oy = oy0 + o, oxx = ox0 + ox;
       const bool valid = chok && oy < p.ho && oxx < p.wo;
       const int64_t opix = ((int64_t)img * p.ho + oy) * p.wo + oxx;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[o][r] - corr[r];
+      const float v[2] = {acc[o][0] - corr[0], acc[o][1] - corr[1]};
       if (MODE == D_STATS) {
         if (valid) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { st1[r] += (double)v[r]; st2[r] += (double)v[r] * (double)v[r]; smn[r] = fminf(smn[r], v[r]); smx[r] = fmaxf(smx[r], v[r]); }
+          for (int r = 0; r < 2; ++r) { st1[r] += (double)v[r]; st2[r] += (double)v[r] * (double)v[r]; smn[r] = fminf(smn[r], v[r]); smx[r] = fmaxf(smx[r], v[r]); }
         }
       } else if (MODE == D_EMIT) {
         uint32_t packed = 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 2; ++r) {
           float yv = fmaf(A[r], v[r], B[r]);
           if (p.relu) yv = fmaxf(yv, 0.0f);
           packed |= ((uint32_t)((fq_index(yv, y_inv, y_zp, 0, 255) - 128) & 255)) << (8 * r);
         }
-        if (valid) *(uint32_t*)(p.y + opix * p.c + c0) = packed;
+        if (valid) *(uint16_t*)(p.y + opix * p.c + c0) = (uint16_t)packed;
       } else {
-        uint2 gv = make_uint2(0, 0);
-        if (valid) gv = *(const uint2*)(p.gout + opix * p.c + c0);
-        const float gq[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
-        float dcv[4];
+        uint32_t gv = 0;
+        if (valid) gv = *(const uint32_t*)(p.gout + opix * p.c + c0);
+        const float gq[2] = {bf2f(gv & 0xffff), bf2f(gv >> 16)};
+        float dcv[2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 2; ++r) {
           float yv = fmaf(A[r], v[r], B[r]);
           bool alive = true;
           if (p.relu) { alive = yv > 0.0f; yv = fmaxf(yv, 0.0f); }
@@ -142,38 +158,33 @@ __global__ __launch_bounds__(256) void k_dw(const DwP p) {
           if (MODE == D_BRED) { r1[r] += gyv; r2[r] += gyv * xhat; }
           else dcv[r] = K1[r] * (gyv - S1[r] - xhat * S2[r]);
         }
-        if (MODE == D_BDC && valid) {
-          uint2 ov; ov.x = (uint32_t)f2bf(dcv[0]) | ((uint32_t)f2bf(dcv[1]) << 16); ov.y = (uint32_t)f2bf(dcv[2]) | ((uint32_t)f2bf(dcv[3]) << 16);
-          *(uint2*)(p.dc + opix * p.c + c0) = ov;
-        }
+        if (MODE == D_BDC && valid) *(uint32_t*)(p.dc + opix * p.c + c0) = (uint32_t)f2bf(dcv[0]) | ((uint32_t)f2bf(dcv[1]) << 16);
       }
     }
   }
 
-  // cross-thread reduction over the 16 threads (ox) that share a channel quad: lanes g=(ox&3), waves (ox>>2)
+  // reduce over the 16 threads (ox) that share a channel pair: lane bit 5 (ox&1) and the 8 waves (ox>>1)
   if (MODE == D_STATS || MODE == D_BRED) {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 2; ++r) {
       if (MODE == D_STATS) {
         double a = st1[r], b = st2[r]; float c = smn[r], d = smx[r];
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c = fminf(c, __shfl_xor(c, o)); d = fmaxf(d, __shfl_xor(d, o)); }
-        if (lane < 16) { red_d[wv][lane][r] = a; red_d[wv][lane][4 + r] = b; red_f[wv][lane][r] = c; red_f[wv][lane][4 + r] = d; }
+        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32); c = fminf(c, __shfl_xor(c, 32)); d = fmaxf(d, __shfl_xor(d, 32));
+        if (lane < 32) { red_d[wv][lane][r] = a; red_d[wv][lane][2 + r] = b; red_f[wv][lane][r] = c; red_f[wv][lane][2 + r] = d; }
       } else {
         float a = r1[r], b = r2[r];
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        if (lane < 16) { red_f[wv][lane][r] = a; red_f[wv][lane][4 + r] = b; }
+        a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+        if (lane < 32) { red_f[wv][lane][r] = a; red_f[wv][lane][2 + r] = b; }
       }
     }
     __syncthreads();
     if (tid < 64) {
-      const int q = tid >> 2, r = tid & 3; const int ch = cb * CB + q * 4 + r;
+      const int q = tid >> 1, r = tid & 1; const int ch = cb * CB + q * 2 + r;
       if (ch < p.c) {
         if (MODE == D_STATS) {
           double a = 0, b = 0; float c = INFINITY, d = -INFINITY;
-          for (int wv2 = 0; wv2 < 4; ++wv2) { a += red_d[wv2][q][r]; b += red_d[wv2][q][4 + r]; c = fminf(c, red_f[wv2][q][r]); d = fmaxf(d, red_f[wv2][q][4 + r]); }
+          for (int w2 = 0; w2 < 8; ++w2) { a += red_d[w2][q][r]; b += red_d[w2][q][2 + r]; c = fminf(c, red_f[w2][q][r]); d = fmaxf(d, red_f[w2][q][2 + r]); }
           int64_t* g_s1 = (int64_t*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
           int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
           if (c <= d) {
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(256) void k_dw(const DwP p) {
           }
         } else {
           float a = 0, b = 0;
-          for (int wv2 = 0; wv2 < 4; ++wv2) { a += red_f[wv2][q][r]; b += red_f[wv2][q][4 + r]; }
+          for (int w2 = 0; w2 < 8; ++w2) { a += red_f[w2][q][r]; b += red_f[w2][q][2 + r]; }
           atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch, b);
         }
       }
@@ -195,9 +206,9 @@ template <int K, int S, int MODE>
 static int launch_dw(DwP& p, hipStream_t s) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   size_t lds = (size_t)IH * IW * CB;
-  int64_t want = 1024 / p.ncb; if (want < 1) want = 1;
+  int64_t want = 1536 / p.ncb; if (want < 1) want = 1;
   p.ngroups = (int)(p.ntiles < want ? p.ntiles : want);
-  hipLaunchKernelGGL((k_dw<K, S, MODE>), dim3(p.ncb * p.ngroups), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_dw<K, S, MODE>), dim3(p.ncb * p.ngroups), dim3(512), lds, s, p);
   return frost_check_launch("dw");
 }
 template <int MODE>
@@ -233,97 +244,206 @@ extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int
   return pass == 0 ? dispatch_dw<D_BRED>(p, k, stride, as_stream(stream)) : dispatch_dw<D_BDC>(p, k, stride, as_stream(stream));
 }
 
-// ---- depthwise dgrad: dx[n][iy][ix][c] (+)= s_w * sum_taps dc[n][oy][ox][c] * wq[ky][kx][c]  (gather form)
-__global__ __launch_bounds__(256) void k_dw_dgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ wq, const float* qw,
-                                                  int n, int h, int w, int c, int cpad, int k, int stride, int ho, int wo,
-                                                  uint16_t* __restrict__ dx, int accumulate) {
-  const int pad = (k - 1) / 2; const float sw = qw[FROST_Q_SCALE];
-  const int cq_n = c >> 2; const int64_t tot = (int64_t)n * h * w * cq_n;
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    const int cq = (int)(i % cq_n); int64_t t = i / cq_n; const int ix = (int)(t % w); t /= w; const int iy = (int)(t % h); const int img = (int)(t / h);
-    const int c0 = cq * 4;
-    float a[4] = {0, 0, 0, 0};
-    for (int ky = 0; ky < k; ++ky) {
-      const int ty = iy + pad - ky; if (ty < 0 || (ty % stride) != 0) continue; const int oy = ty / stride; if (oy >= ho) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int tx = ix + pad - kx; if (tx < 0 || (tx % stride) != 0) continue; const int ox = tx / stride; if (ox >= wo) continue;
-        const uint2 gv = *(const uint2*)(dc + (((int64_t)img * ho + oy) * wo + ox) * c + c0);
-        float wv[4]; unpack4s(*(const uint32_t*)(wq + (ky * k + kx) * cpad + c0), wv);
-        a[0] = fmaf(bf2f(gv.x & 0xffff), wv[0], a[0]); a[1] = fmaf(bf2f(gv.x >> 16), wv[1], a[1]);
-        a[2] = fmaf(bf2f(gv.y & 0xffff), wv[2], a[2]); a[3] = fmaf(bf2f(gv.y >> 16), wv[3], a[3]);
+// ---- depthwise dgrad: dx[n][iy][ix][c] (+)= s_w * sum_{ky,kx} dc[n][(iy+pad-ky)/s][(ix+pad-kx)/s][c] * wq[ky][kx][c]
+// (taps with a non-integer source index contribute nothing).  LDS-tiled: the bf16 dc halo of an 8x16 dx tile is
+// staged once, every thread owns 2 channels x 1 column x 8 rows.  For stride 2 a wave handles columns of ONE
+// parity (w and w+8), so which kx taps exist is wave-uniform and every tap test folds at compile time.
+__host__ __device__ constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+template <int K, int S, int PAR>
+__device__ __forceinline__ void dw_dgrad_tile(const uint8_t* smem, const float (*wf)[2], int cp, int m, float (*acc)[2]) {
+  constexpr int PAD = (K - 1) / 2;
+  constexpr int LO = fdiv(-PAD, S);
+  constexpr int DW = (TW - 1 + PAD) / S - LO + 1;
+#pragma unroll
+  for (int r = 0; r < TH; ++r) {
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      if (((r + PAD - ky) % S + S) % S != 0) continue;
+      const int rr = fdiv(r + PAD - ky, S) - LO;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        if (((PAR + PAD - kx) % S + S) % S != 0) continue;
+        const int cc = fdiv(PAR + PAD - kx, S) - LO;           // + m (runtime)
+        const uint32_t v = *(const uint32_t*)(smem + ((rr * DW + cc + m) * CB + cp * 2) * 2);
+        acc[r][0] = fmaf(bf2f(v & 0xffff), wf[ky * K + kx][0], acc[r][0]);
+        acc[r][1] = fmaf(bf2f(v >> 16), wf[ky * K + kx][1], acc[r][1]);
       }
     }
-    uint16_t* dst = dx + (((int64_t)img * h + iy) * w + ix) * c + c0;
-    float v[4] = {a[0] * sw, a[1] * sw, a[2] * sw, a[3] * sw};
-    if (accumulate) { uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
-    uint2 o; o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    *(uint2*)dst = o;
   }
+}
+template <int K, int S>
+__global__ __launch_bounds__(512, 2) void k_dw_dgrad2(const uint16_t* __restrict__ dc, const int8_t* __restrict__ wq, const float* qw,
+                                                      int n, int h, int w, int c, int cpad, int ho, int wo, uint16_t* __restrict__ dx,
+                                                      int accumulate, int ncb, int ngroups, int tiles_x, int tiles_y) {
+  constexpr int PAD = (K - 1) / 2;
+  constexpr int LO = fdiv(-PAD, S);
+  constexpr int DH = (TH - 1 + PAD) / S - LO + 1, DW = (TW - 1 + PAD) / S - LO + 1;
+  constexpr int NU = (DH * DW * 8 + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int cp = tid & 31;
+  const int wv = tid >> 6, hi = (tid >> 5) & 1;
+  const int ox = (S == 2) ? (wv + 8 * hi) : (tid >> 5);          // S=2: a wave owns columns {w, w+8} (same parity)
+  const int cb = blockIdx.x % ncb, grp = blockIdx.x / ncb;
+  const int c0 = cb * CB + cp * 2;
+  const bool chok = c0 < c;
+  const float sw = qw[FROST_Q_SCALE];
+  float wf[K * K][2];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    const uint32_t v = chok ? (uint32_t)*(const uint16_t*)(wq + t * cpad + c0) : 0u;
+    wf[t][0] = (float)(int8_t)(v & 255u); wf[t][1] = (float)(int8_t)(v >> 8);
+  }
+  const int tiles_per_img = tiles_x * tiles_y; const int64_t ntiles = (int64_t)n * tiles_per_img;
+  for (int64_t tile = grp; tile < ntiles; tile += ngroups) {
+    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
+    const int iy0 = (tr / tiles_x) * TH, ix0 = (tr % tiles_x) * TW;
+    const int oy_lo = iy0 / S + LO, ox_lo = ix0 / S + LO;
+    __syncthreads();
+    {
+      uint4 v[NU];
+#pragma unroll
+      for (int jn = 0; jn < NU; ++jn) {
+        const int u = tid + jn * 512; const int c8 = u & 7; const int pix = u >> 3; const int ry = pix / DW, rx = pix - ry * DW;
+        const int oy = oy_lo + ry, oxx = ox_lo + rx; const int cc = cb * CB + c8 * 8;
+        v[jn] = make_uint4(0, 0, 0, 0);
+        if (u < DH * DW * 8 && oy >= 0 && oy < ho && oxx >= 0 && oxx < wo && cc < c)
+          v[jn] = *(const uint4*)(dc + (((int64_t)img * ho + oy) * wo + oxx) * c + cc);
+      }
+#pragma unroll
+      for (int jn = 0; jn < NU; ++jn) { const int u = tid + jn * 512; if (u < DH * DW * 8) *(uint4*)(smem + u * 16) = v[jn]; }
+    }
+    __syncthreads();
+    float acc[TH][2];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) { acc[r][0] = 0; acc[r][1] = 0; }
+    if (S == 1) dw_dgrad_tile<K, S, 0>(smem, wf, cp, ox, acc);
+    else if ((wv & 1) == 0) dw_dgrad_tile<K, S, 0>(smem, wf, cp, ox >> 1, acc);
+    else dw_dgrad_tile<K, S, 1>(smem, wf, cp, ox >> 1, acc);
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int iy = iy0 + r, ix = ix0 + ox;
+      if (chok && iy < h && ix < w) {
+        uint16_t* dst = dx + (((int64_t)img * h + iy) * w + ix) * c + c0;
+        float v0 = acc[r][0] * sw, v1 = acc[r][1] * sw;
+        if (accumulate) { const uint32_t o = *(const uint32_t*)dst; v0 += bf2f(o & 0xffff); v1 += bf2f(o >> 16); }
+        *(uint32_t*)dst = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+      }
+    }
+  }
+}
+template <int K, int S>
+static int launch_dw_dgrad(const uint16_t* dc, const int8_t* wq, const float* qw, int n, int h, int w, int c, int ho, int wo,
+                           uint16_t* dx, int accumulate, hipStream_t s) {
+  constexpr int PAD = (K - 1) / 2; constexpr int LO = fdiv(-PAD, S);
+  constexpr int DH = (TH - 1 + PAD) / S - LO + 1, DW = (TW - 1 + PAD) / S - LO + 1;
+  const int ncb = (c + CB - 1) / CB; const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+  const int64_t ntiles = (int64_t)n * tiles_x * tiles_y;
+  int64_t want = 1536 / ncb; if (want < 1) want = 1;
+  const int ngroups = (int)(ntiles < want ? ntiles : want);
+  hipLaunchKernelGGL((k_dw_dgrad2<K, S>), dim3(ncb * ngroups), dim3(512), (size_t)DH * DW * CB * 2, s, dc, wq, qw, n, h, w, c,
+                     round_up(c, 16), ho, wo, dx, accumulate, ncb, ngroups, tiles_x, tiles_y);
+  return frost_check_launch("dw_dgrad");
 }
 extern "C" int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c,
                               int k, int stride, uint16_t* dx, int accumulate, void* stream) {
+  FROST_REQUIRE(c % 8 == 0, "dw_dgrad: channels must be a multiple of 8");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
-  int64_t tot = (int64_t)n * h * w * (c / 4); int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(k_dw_dgrad, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dc, wq_pack, qrec_w, n, h, w, c,
-                     round_up(c, 16), k, stride, ho, wo, dx, accumulate);
-  return frost_check_launch("dw_dgrad");
+  hipStream_t s = as_stream(stream);
+  if (k == 3 && stride == 1) return launch_dw_dgrad<3, 1>(dc, wq_pack, qrec_w, n, h, w, c, ho, wo, dx, accumulate, s);
+  if (k == 3 && stride == 2) return launch_dw_dgrad<3, 2>(dc, wq_pack, qrec_w, n, h, w, c, ho, wo, dx, accumulate, s);
+  if (k == 5 && stride == 1) return launch_dw_dgrad<5, 1>(dc, wq_pack, qrec_w, n, h, w, c, ho, wo, dx, accumulate, s);
+  if (k == 5 && stride == 2) return launch_dw_dgrad<5, 2>(dc, wq_pack, qrec_w, n, h, w, c, ho, wo, dx, accumulate, s);
+  frost_set_error("dw_dgrad: unsupported kernel/stride"); return 1;
 }
 
 // ---- depthwise wgrad: dwq[c][ky][kx] += s_x * sum_{n,oy,ox} dc * (q - zp)     (dwq fp32 [c][k*k], pre-zeroed)
-template <int K>
-__global__ __launch_bounds__(256) void k_dw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
-                                                  int n, int h, int w, int c, int stride, int ho, int wo, float* dwq, int ngroups) {
-  constexpr int pad = (K - 1) / 2;
-  const int cq = threadIdx.x & 15; const int pl = threadIdx.x >> 4;   // 16 pixel lanes
-  const int ncb = (c + 63) / 64; const int cb = blockIdx.x % ncb, grp = blockIdx.x / ncb;
-  const int c0 = cb * 64 + cq * 4; const bool chok = c0 < c;
-  const int zp = __float_as_int(qx[FROST_Q_ZP]); const float sx = qx[FROST_Q_SCALE];
-  float acc[K * K][4];
+// Same tiling as the forward kernel: the x halo tile is staged in LDS, each thread holds dc for its 8 outputs x 2
+// channels and slides over the tile accumulating K*K x 2 partial sums in registers across ALL its tiles; one block
+// reduction + K*K*64 atomics per workgroup at the end.
+template <int K, int S>
+__global__ __launch_bounds__(512, ((K == 3 && S == 1) ? 4 : 2)) void k_dw_wgrad(const DwP p, float* __restrict__ dwq) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int cp = tid & 31, ox = tid >> 5;
+  const int cb = blockIdx.x % p.ncb, grp = blockIdx.x / p.ncb;
+  const int c0 = cb * CB + cp * 2;
+  const bool chok = c0 < p.c;
+  const int zp = __float_as_int(p.qx[FROST_Q_ZP]);
+  const float zpf = (float)zp;
+  const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
+  float acc[K * K][2];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) { acc[t][0] = 0; acc[t][1] = 0; acc[t][2] = 0; acc[t][3] = 0; }
-  const int64_t npix = (int64_t)n * ho * wo;
-  if (chok) {
-    for (int64_t pi = (int64_t)grp * 16 + pl; pi < npix; pi += (int64_t)ngroups * 16) {
-      const int ox = (int)(pi % wo); int64_t t = pi / wo; const int oy = (int)(t % ho); const int img = (int)(t / ho);
-      const uint2 gv = *(const uint2*)(dc + pi * c + c0);
-      const float gq[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
+  for (int t = 0; t < K * K; ++t) { acc[t][0] = 0; acc[t][1] = 0; }
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
+    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
+    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+    float g[TH][2];
+#pragma unroll
+    for (int o = 0; o < TH; ++o) {
+      const int oy = oy0 + o, oxx = ox0 + ox;
+      uint32_t gv = 0;
+      if (chok && oy < p.ho && oxx < p.wo) gv = *(const uint32_t*)(p.dc + (((int64_t)img * p.ho + oy) * p.wo + oxx) * p.c + c0);
+      g[o][0] = bf2f(gv & 0xffff); g[o][1] = bf2f(gv >> 16);
+    }
+    __syncthreads();
+    dw_stage_tile<K, S>(p.x, smem, tid, img, oy0 * S - p.pad, ox0 * S - p.pad, cb, p.h, p.w, p.c, zfill);
+    __syncthreads();
+#pragma unroll
+    for (int iy = 0; iy < IH; ++iy) {
+      float xf[K][2];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) { unpack2(*(const uint16_t*)(smem + (iy * IW + ox * S + kx) * CB + cp * 2), xf[kx]); xf[kx][0] -= zpf; xf[kx][1] -= zpf; }
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
+        if ((iy - ky) >= 0 && ((iy - ky) % S) == 0 && (iy - ky) / S < TH) {
+          const int o = (iy - ky) / S;
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
-          float xf[4]; unpack4(*(const uint32_t*)(x + (((int64_t)img * h + iy) * w + ix) * c + c0), xf);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ky * K + kx][r] = fmaf(gq[r], xf[r] - (float)zp, acc[ky * K + kx][r]);
+          for (int kx = 0; kx < K; ++kx) {
+            acc[ky * K + kx][0] = fmaf(g[o][0], xf[kx][0], acc[ky * K + kx][0]);
+            acc[ky * K + kx][1] = fmaf(g[o][1], xf[kx][1], acc[ky * K + kx][1]);
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __shared__ float red[K * K][64];
-  for (int i = threadIdx.x; i < K * K * 64; i += 256) ((float*)red)[i] = 0.0f;
+  __syncthreads();
+  float* red = (float*)smem;                      // [K*K][64]
+  for (int i = tid; i < K * K * 64; i += 512) red[i] = 0.0f;
   __syncthreads();
   if (chok) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[t][cq * 4 + r], acc[t][r]);
+    for (int t = 0; t < K * K; ++t) { atomicAdd(&red[t * 64 + cp * 2], acc[t][0]); atomicAdd(&red[t * 64 + cp * 2 + 1], acc[t][1]); }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * K * 64; i += 256) {
+  const float sx = p.qx[FROST_Q_SCALE];
+  for (int i = tid; i < K * K * 64; i += 512) {
     const int t = i / 64, cc = i % 64; const int ch = cb * 64 + cc;
-    if (ch < c) atomicAdd(dwq + (int64_t)ch * K * K + t, red[t][cc] * sx);
+    if (ch < p.c) atomicAdd(dwq + (int64_t)ch * K * K + t, red[i] * sx);
   }
 }
+template <int K, int S>
+static int launch_dw_wgrad(DwP& p, float* dwq, hipStream_t s) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  size_t lds = (size_t)IH * IW * CB; if (lds < (size_t)K * K * 64 * 4) lds = (size_t)K * K * 64 * 4;
+  int64_t want = 1024 / p.ncb; if (want < 1) want = 1;
+  p.ngroups = (int)(p.ntiles < want ? p.ntiles : want);
+  hipLaunchKernelGGL((k_dw_wgrad<K, S>), dim3(p.ncb * p.ngroups), dim3(512), lds, s, p, dwq);
+  return frost_check_launch("dw_wgrad");
+}
+static void fill_dw(DwP& p, const int8_t* x, const float* qx, const int8_t* wq, const int32_t* wsum, int n, int h, int w, int c, int k, int stride);
 extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                               int stride, float* dwq, void* stream) {
-  const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
-  const int ncb = (c + 63) / 64; int ngroups = 1024 / ncb; if (ngroups < 1) ngroups = 1;
-  int64_t npix = (int64_t)n * ho * wo; if (ngroups > (npix + 15) / 16) ngroups = (int)((npix + 15) / 16);
-  if (k == 3) hipLaunchKernelGGL(k_dw_wgrad<3>, dim3(ncb * ngroups), dim3(256), 0, as_stream(stream), dc, x, qrec_x, n, h, w, c, stride, ho, wo, dwq, ngroups);
-  else if (k == 5) hipLaunchKernelGGL(k_dw_wgrad<5>, dim3(ncb * ngroups), dim3(256), 0, as_stream(stream), dc, x, qrec_x, n, h, w, c, stride, ho, wo, dwq, ngroups);
-  else { frost_set_error("dw_wgrad: k must be 3 or 5"); return 1; }
-  return frost_check_launch("dw_wgrad");
+  DwP p = {}; fill_dw(p, x, qrec_x, nullptr, nullptr, n, h, w, c, k, stride); p.dc = (uint16_t*)dc;
+  hipStream_t s = as_stream(stream);
+  if (k == 3 && stride == 1) return launch_dw_wgrad<3, 1>(p, dwq, s);
+  if (k == 3 && stride == 2) return launch_dw_wgrad<3, 2>(p, dwq, s);
+  if (k == 5 && stride == 1) return launch_dw_wgrad<5, 1>(p, dwq, s);
+  if (k == 5 && stride == 2) return launch_dw_wgrad<5, 2>(p, dwq, s);
+  frost_set_error("dw_wgrad: unsupported kernel/stride"); return 1;
 }
 
 // ---------------------------------------------------------------------------------------------------- stem

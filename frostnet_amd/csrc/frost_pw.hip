@@ -32,9 +32,41 @@ struct PwP {
 
 template <int MODE> struct ModeTraits { static constexpr bool bf16 = (MODE == M_DGRAD); };
 
+// DPP row reductions (16-lane rows = the 16 pixel columns of an MFMA tile): inclusive scan with row_shr 1,2,4,8;
+// lane 15 of every row ends up with the row total.  Pure VALU -- no LDS traffic (unlike __shfl_xor -> ds_bpermute).
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int row_sum_i(int v) {
+  v += dpp_i<0x111>(v, 0); v += dpp_i<0x112>(v, 0); v += dpp_i<0x114>(v, 0); v += dpp_i<0x118>(v, 0); return v;
+}
+__device__ __forceinline__ int row_min_i(int v) {
+  v = min(v, dpp_i<0x111>(v, INT32_MAX)); v = min(v, dpp_i<0x112>(v, INT32_MAX)); v = min(v, dpp_i<0x114>(v, INT32_MAX)); v = min(v, dpp_i<0x118>(v, INT32_MAX)); return v;
+}
+__device__ __forceinline__ int row_max_i(int v) {
+  v = max(v, dpp_i<0x111>(v, INT32_MIN)); v = max(v, dpp_i<0x112>(v, INT32_MIN)); v = max(v, dpp_i<0x114>(v, INT32_MIN)); v = max(v, dpp_i<0x118>(v, INT32_MIN)); return v;
+}
+__device__ __forceinline__ float row_sum_f(float v) {
+  v += __int_as_float(dpp_i<0x111>(__float_as_int(v), 0)); v += __int_as_float(dpp_i<0x112>(__float_as_int(v), 0));
+  v += __int_as_float(dpp_i<0x114>(__float_as_int(v), 0)); v += __int_as_float(dpp_i<0x118>(__float_as_int(v), 0)); return v;
+}
+__device__ __forceinline__ long long row_sum_ll(long long v) {
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
+    int slo, shi;
+    if (step == 0) { slo = dpp_i<0x111>(lo, 0); shi = dpp_i<0x111>(hi, 0); }
+    else if (step == 1) { slo = dpp_i<0x112>(lo, 0); shi = dpp_i<0x112>(hi, 0); }
+    else if (step == 2) { slo = dpp_i<0x114>(lo, 0); shi = dpp_i<0x114>(hi, 0); }
+    else { slo = dpp_i<0x118>(lo, 0); shi = dpp_i<0x118>(hi, 0); }
+    v += (long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo);
+  }
+  return v;
+}
+
 template <int MODE, int WP>
-__global__ __launch_bounds__(256) void k_pw(const PwP p) {
-  constexpr int WC = 4 / WP;          // waves along channels
+__global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
+  constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
   constexpr bool BF = ModeTraits<MODE>::bf16;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -55,15 +87,15 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
   const int CT = p.cpad >> 4;
 
   if (MODE == M_STATS) {
-    for (int c = tid; c < p.cpad; c += 256) { l_s1[c] = 0; l_s2[c] = 0; l_mn[c] = INT32_MAX; l_mx[c] = INT32_MIN; }
+    for (int c = tid; c < p.cpad; c += 512) { l_s1[c] = 0; l_s2[c] = 0; l_mn[c] = INT32_MAX; l_mx[c] = INT32_MIN; }
   } else if (MODE == M_BRED) {
-    for (int c = tid; c < p.cpad; c += 256) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
+    for (int c = tid; c < p.cpad; c += 512) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
   }
 
-  int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; int y_zp = 0;
+  int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; int y_zp = 0; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD) sw = p.qw[FROST_Q_SCALE];
-  if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zp = __float_as_int(p.qy[FROST_Q_ZP]); }
+  if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zp = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)y_zp; }
 
   for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BP;
@@ -84,7 +116,7 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
           __syncthreads();
           if (((p.rowbytes | kc0) & 15) == 0) {
             const int U = kcw_pad >> 4; const int total = BP * U;
-            for (int u = tid; u < total; u += 256) {
+            for (int u = tid; u < total; u += 512) {
               int row = u / U; int col = (u - row * U) << 4; int64_t pix = p0 + row;
               uint4 v = make_uint4(0, 0, 0, 0);
               if (pix < p.npix && col < kcw) v = *(const uint4*)(p.T + pix * p.rowbytes + kc0 + col);
@@ -92,7 +124,7 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
             }
           } else {
             const int U = kcw_pad >> 3; const int total = BP * U;
-            for (int u = tid; u < total; u += 256) {
+            for (int u = tid; u < total; u += 512) {
               int row = u / U; int col = (u - row * U) << 3; int64_t pix = p0 + row;
               uint2 v = make_uint2(0, 0);
               if (pix < p.npix && col < kcw) v = *(const uint2*)(p.T + pix * p.rowbytes + kc0 + col);
@@ -164,13 +196,10 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            long long a = s1[r], b = s2[r]; int c = mn[r], d = mx[r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              a += __shfl_xor(a, o); b += __shfl_xor(b, o); c = min(c, __shfl_xor(c, o)); d = max(d, __shfl_xor(d, o));
-            }
-            if (j == 0 && chok) {
-              atomicAdd((unsigned long long*)&l_s1[ch0 + r], (unsigned long long)a);
+            const int a = row_sum_i(s1[r]); const long long b = row_sum_ll(s2[r]);
+            const int c = row_min_i(mn[r]), d = row_max_i(mx[r]);
+            if (j == 15 && chok) {
+              atomicAdd((unsigned long long*)&l_s1[ch0 + r], (unsigned long long)(long long)a);
               atomicAdd(&l_s2[ch0 + r], (unsigned long long)b);
               atomicMin(&l_mn[ch0 + r], c); atomicMax(&l_mx[ch0 + r], d);
             }
@@ -189,9 +218,10 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
             for (int r = 0; r < 4; ++r) {
               float yv = fmaf(A[r], (float)(acci[m][t][r] - corr[r]), B[r]);
               if (p.relu) yv = fmaxf(yv, 0.0f);
-              packed |= ((uint32_t)((fq_index(yv, y_inv, y_zp, 0, 255) - 128) & 255)) << (8 * r);
+              // q = clamp(rint(y*inv)+zp, 0, 255): v_cvt_pk_u8_f32 saturates to [0,255] and inserts the byte in one op
+              packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
             }
-            if (pix < p.npix && chok) *(uint32_t*)(p.y + pix * p.cout + ch0) = packed;
+            if (pix < p.npix && chok) *(uint32_t*)(p.y + pix * p.cout + ch0) = packed ^ 0x80808080u;
           }
           continue;
         }
@@ -237,10 +267,8 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
         if (MODE == M_BRED) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float a = r1[r], b = r2[r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            if (j == 0 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+            const float a = row_sum_f(r1[r]), b = row_sum_f(r2[r]);
+            if (j == 15 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
           }
         }
       }
@@ -251,14 +279,14 @@ __global__ __launch_bounds__(256) void k_pw(const PwP p) {
     __syncthreads();
     int64_t* g_s1 = (int64_t*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
-    for (int c = tid; c < p.cout; c += 256) {
+    for (int c = tid; c < p.cout; c += 512) {
       atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
       atomicAdd(&g_s2[c], l_s2[c]);
       atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
     }
   } else if (MODE == M_BRED) {
     __syncthreads();
-    for (int c = tid; c < p.cout; c += 256) {
+    for (int c = tid; c < p.cout; c += 512) {
       atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
       atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, l_f2[c]);
     }
@@ -276,20 +304,20 @@ static int launch_pw(PwP& p, hipStream_t s) {
   int occ = lds <= 78 * 1024 ? 2 : 1;
   int64_t grid = p.ntiles < 256 * occ ? p.ntiles : 256 * occ;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_pw<MODE, WP>), dim3((unsigned)grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_pw<MODE, WP>), dim3((unsigned)grid), dim3(512), lds, s, p);
   return frost_check_launch("pw");
 }
 
 template <int MODE>
 static int dispatch_pw(PwP& p, hipStream_t s) {
   const int CT = p.cpad / 16;
-  int WPsel = CT <= 4 ? 4 : (CT <= 8 ? 2 : 1);
-  int WC = 4 / WPsel;
+  int WPsel = CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
+  int WC = 8 / WPsel;
   p.ngroups = (CT + WC * MI - 1) / (WC * MI);
   p.mi_eff = (CT + p.ngroups * WC - 1) / (p.ngroups * WC);
+  if (WPsel == 8) return launch_pw<MODE, 8>(p, s);
   if (WPsel == 4) return launch_pw<MODE, 4>(p, s);
-  if (WPsel == 2) return launch_pw<MODE, 2>(p, s);
-  return launch_pw<MODE, 1>(p, s);
+  return launch_pw<MODE, 2>(p, s);
 }
 
 static void set_tiling(PwP& p, int64_t npix, int rowbytes) {

@@ -264,4 +264,4 @@ def test_gradboost_kernel(eng_mod, golden, name):
             key = k[len(name) + 7:]
             v = st[key]
             v = v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
-            np.testing.assert_allclose(v, g[k], rtol=1e-5, atol=1e-12, err_msg=key)
+            np.testing.assert_allclose(v, g[k], rtol=1e-4, atol=1e-12, err_msg=key)

@@ -1,0 +1,35 @@
+"""Per-layer, per-pass HIP-event timing of one eager QAT step (which layers/kernels are furthest from their roofline)."""
+import os, sys, warnings
+warnings.filterwarnings("ignore")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as ge
+ge.build()
+from frostnet_amd import _lib as L, frostnet as F
+from frostnet_amd import engine as EN
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+model = F.frostnet_quant_large_1_0(); F.qat_prepare(model, version=0); model.cuda().train()
+x = torch.randn(B, 3, 224, 224, device="cuda").contiguous(memory_format=torch.channels_last)
+t = torch.randint(0, 1000, (B,), device="cuda")
+def step():
+    torch.nn.functional.cross_entropy(model(x), t).backward()
+step(); step(); torch.cuda.synchronize()
+# re-tag: wrap call so label includes the layer name (args hold no name -> use engine hooks)
+orig_launch, orig_bwd = EN.Engine._conv_launch, EN.Engine._conv_backward
+cur = {"name": ""}
+def launch(self, l, x_, mode, y): cur["name"] = l.name; return orig_launch(self, l, x_, mode, y)
+def bwd(self, l, x_, y): cur["name"] = l.name; return orig_bwd(self, l, x_, y)
+EN.Engine._conv_launch, EN.Engine._conv_backward = launch, bwd
+orig_call = L.call
+def call(name, *a, prof=None):
+    if prof is not None: prof = (prof[0] + "|" + cur["name"], prof[1])
+    return orig_call(name, *a, prof=prof)
+EN.call = call
+L.PROFILER = L.Profiler()
+step()
+s = L.PROFILER.summary()
+rows = sorted(s.items(), key=lambda kv: -kv[1]["total_ms"])
+tot = sum(v["total_ms"] for v in s.values())
+print(f"total tagged {tot:.2f} ms")
+for k, v in rows[:60]:
+    print(f"{k:50s} {v['total_ms']:8.3f} ms  {v['bytes_per_launch']/1e6:9.1f} MB  {v['bytes_per_launch']/v['avg_ms']/1e6:8.1f} GB/s")
