@@ -44,6 +44,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even
   return (uint16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2 (lo in bits 0..15), round-to-nearest-even, ONE instruction on gfx950 (no builtin: inline asm)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 // ---- ordered float atomics ---------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
   if (v >= 0.0f) atomicMin((int*)addr, __float_as_int(v));

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, ((K == 3 && (S == 1 || MODE < 2)) ? 4 : 2)) vo
           if (MODE == D_BRED) { r1[r] += gyv; r2[r] += gyv * xhat; }
           else dcv[r] = K1[r] * (gyv - S1[r] - xhat * S2[r]);
         }
-        if (MODE == D_BDC && valid) *(uint32_t*)(p.dc + opix * p.c + c0) = (uint32_t)f2bf(dcv[0]) | ((uint32_t)f2bf(dcv[1]) << 16);
+        if (MODE == D_BDC && valid) *(uint32_t*)(p.dc + opix * p.c + c0) = cvt_pk_bf16(dcv[0], dcv[1]);
       }
     }
   }
@@ -206,7 +206,10 @@ template <int K, int S, int MODE>
 static int launch_dw(DwP& p, hipStream_t s) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   size_t lds = (size_t)IH * IW * CB;
-  int64_t want = 1536 / p.ncb; if (want < 1) want = 1;
+  int occ = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dw<K, S, MODE>, 512, lds) != hipSuccess || occ < 1) occ = 1;
+  if (occ > 4) occ = 4;
+  int64_t want = (256 * occ) / p.ncb; if (want < 1) want = 1;
   p.ngroups = (int)(p.ntiles < want ? p.ntiles : want);
   hipLaunchKernelGGL((k_dw<K, S, MODE>), dim3(p.ncb * p.ngroups), dim3(512), lds, s, p);
   return frost_check_launch("dw");
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void k_dw_dgrad2(const uint16_t* __restrict
         uint16_t* dst = dx + (((int64_t)img * h + iy) * w + ix) * c + c0;
         float v0 = acc[r][0] * sw, v1 = acc[r][1] * sw;
         if (accumulate) { const uint32_t o = *(const uint32_t*)dst; v0 += bf2f(o & 0xffff); v1 += bf2f(o >> 16); }
-        *(uint32_t*)dst = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+        *(uint32_t*)dst = cvt_pk_bf16(v0, v1);
       }
     }
   }

@@ -77,7 +77,7 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
 __device__ __forceinline__ void acc_store4(uint16_t* dst, const float* v, int accumulate) {
   float o[4] = {v[0], v[1], v[2], v[3]};
   if (accumulate) { uint2 t = *(const uint2*)dst; o[0] += bf2f(t.x & 0xffff); o[1] += bf2f(t.x >> 16); o[2] += bf2f(t.y & 0xffff); o[3] += bf2f(t.y >> 16); }
-  uint2 w; w.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16); w.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+  uint2 w; w.x = cvt_pk_bf16(o[0], o[1]); w.y = cvt_pk_bf16(o[2], o[3]);
   *(uint2*)dst = w;
 }
 __global__ __launch_bounds__(256) void k_cat_bwd(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa, int ca,

@@ -6,11 +6,19 @@
 // T is a pixel-major tensor (NHWC activation bytes, or the bf16 dc tensor for dgrad) whose 128-pixel tile is
 // staged ONCE through LDS with fully coalesced loads and stays resident while the workgroup walks every
 // output-channel group (activation-stationary: the big operand is read from HBM exactly once per pass);
-// the small operand (packed weights, L2 resident) is fetched straight into MFMA A-fragments with 1 KiB
+// the small operand (packed weights, L2 resident) is fetched straight into MFMA fragments with 1 KiB
 // wave-loads.  Both element types use a 64-byte K-step (16x16x64 i8 / 16x16x32 bf16), so staging, LDS layout
-// and fragment addressing are shared.  D's lane layout (lane = pixel column, 4 consecutive channels per
-// lane) makes every epilogue access (coefficients, gradients, packed int8 / bf16 stores) a 4-channel vector.
+// and fragment addressing are shared.
+//
+// Orientation: emit / backward / dgrad compute D[chan][pix] (lane = pixel column, 4 consecutive channels per
+// lane) so every global access of the epilogue is a 4-channel vector (packed int8 dword, bf16x4).  The STATS pass
+// swaps the MFMA operands and gets D'[pix][chan] (lane = ONE channel, 4 pixels per register): per-channel
+// sum / sum^2 / min / max then accumulate lane-locally across the whole persistent tile loop and are reduced
+// across lanes once per workgroup instead of once per tile.
+//
+// The zero-point correction -zp'*sum_k(wq) is folded into the accumulator initial value (free).
 #include "frost_common.h"
+#include <stdlib.h>
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
@@ -24,56 +32,32 @@ struct PwP {
   const int32_t* wsum; const float* qx; const float* qy; const float* qw; float* coef;
   uint8_t* stats; int relu;
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
-  int ngroups, mi_eff; int64_t ntiles; float inv_count;
+  int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
 };
 
 #define BP 128
 #define MI 4
 
-template <int MODE> struct ModeTraits { static constexpr bool bf16 = (MODE == M_DGRAD); };
-
-// DPP row reductions (16-lane rows = the 16 pixel columns of an MFMA tile): inclusive scan with row_shr 1,2,4,8;
-// lane 15 of every row ends up with the row total.  Pure VALU -- no LDS traffic (unlike __shfl_xor -> ds_bpermute).
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
 }
-__device__ __forceinline__ int row_sum_i(int v) {
-  v += dpp_i<0x111>(v, 0); v += dpp_i<0x112>(v, 0); v += dpp_i<0x114>(v, 0); v += dpp_i<0x118>(v, 0); return v;
-}
-__device__ __forceinline__ int row_min_i(int v) {
-  v = min(v, dpp_i<0x111>(v, INT32_MAX)); v = min(v, dpp_i<0x112>(v, INT32_MAX)); v = min(v, dpp_i<0x114>(v, INT32_MAX)); v = min(v, dpp_i<0x118>(v, INT32_MAX)); return v;
-}
-__device__ __forceinline__ int row_max_i(int v) {
-  v = max(v, dpp_i<0x111>(v, INT32_MIN)); v = max(v, dpp_i<0x112>(v, INT32_MIN)); v = max(v, dpp_i<0x114>(v, INT32_MIN)); v = max(v, dpp_i<0x118>(v, INT32_MIN)); return v;
-}
+// inclusive scan over a 16-lane row with row_shr 1,2,4,8: lane 15 of every row holds the row total (pure VALU)
 __device__ __forceinline__ float row_sum_f(float v) {
   v += __int_as_float(dpp_i<0x111>(__float_as_int(v), 0)); v += __int_as_float(dpp_i<0x112>(__float_as_int(v), 0));
   v += __int_as_float(dpp_i<0x114>(__float_as_int(v), 0)); v += __int_as_float(dpp_i<0x118>(__float_as_int(v), 0)); return v;
 }
-__device__ __forceinline__ long long row_sum_ll(long long v) {
-#pragma unroll
-  for (int step = 0; step < 4; ++step) {
-    const int lo = (int)(unsigned)(v & 0xffffffffll), hi = (int)(v >> 32);
-    int slo, shi;
-    if (step == 0) { slo = dpp_i<0x111>(lo, 0); shi = dpp_i<0x111>(hi, 0); }
-    else if (step == 1) { slo = dpp_i<0x112>(lo, 0); shi = dpp_i<0x112>(hi, 0); }
-    else if (step == 2) { slo = dpp_i<0x114>(lo, 0); shi = dpp_i<0x114>(hi, 0); }
-    else { slo = dpp_i<0x118>(lo, 0); shi = dpp_i<0x118>(hi, 0); }
-    v += (long long)(((unsigned long long)(unsigned)shi << 32) | (unsigned)slo);
-  }
-  return v;
-}
+
+__device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return cvt_pk_bf16(a, b); }
 
 template <int MODE, int WP>
 __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
-  constexpr bool BF = ModeTraits<MODE>::bf16;
+  constexpr bool BF = (MODE == M_DGRAD);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* xs = smem;
   const int xs_bytes = BP * p.kstr + 64;
-  // per-channel LDS accumulators (stats / backward-reduce modes)
-  int64_t* l_s1 = (int64_t*)(smem + xs_bytes);
+  long long* l_s1 = (long long*)(smem + xs_bytes);
   unsigned long long* l_s2 = (unsigned long long*)(l_s1 + p.cpad);
   int* l_mn = (int*)(l_s2 + p.cpad);
   int* l_mx = l_mn + p.cpad;
@@ -92,21 +76,40 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
     for (int c = tid; c < p.cpad; c += 512) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
   }
 
-  int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; int y_zp = 0; float y_zpf = 0.0f;
+  int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD) sw = p.qw[FROST_Q_SCALE];
-  if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zp = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)y_zp; }
+  if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]); }
+
+  // lane-local accumulators that live across the persistent tile loop (single channel group only)
+  // BRED with WP==2 already holds 64 accumulator registers: deferring would spill (measured 2x slower)
+  const bool defer = (p.ngroups == 1) && !(MODE == M_BRED && WP == 2);
+  long long st1[MI]; long long st2[MI]; int smn[MI], smx[MI];       // STATS: lane's channel = ct*16 + j
+  float br1[MI][4], br2[MI][4];                                     // BRED: lane's channels = ct*16 + 4g + r
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    st1[m] = 0; st2[m] = 0; smn[m] = INT32_MAX; smx[m] = INT32_MIN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { br1[m][r] = 0.0f; br2[m][r] = 0.0f; }
+  }
 
   for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BP;
+    const bool full = (p0 + BP) <= p.npix;
     for (int cg = 0; cg < p.ngroups; ++cg) {
       const int ct0 = (cg * WC + wc) * p.mi_eff;
       int mi_n = CT - ct0; mi_n = mi_n < 0 ? 0 : (mi_n > p.mi_eff ? p.mi_eff : mi_n);
       v4i acci[MI][NT]; v4f accf[MI][NT];
 #pragma unroll
-      for (int m = 0; m < MI; ++m)
+      for (int m = 0; m < MI; ++m) {
+        v4i init = (v4i){0, 0, 0, 0};
+        if (!BF && m < mi_n) {
+          if (MODE == M_STATS) { const int c = -zpx * p.wsum[(ct0 + m) * 16 + j]; init = (v4i){c, c, c, c}; }
+          else { const int4 ws = *(const int4*)(p.wsum + (ct0 + m) * 16 + 4 * g); init = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w}; }
+        }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acci[m][t] = (v4i){0, 0, 0, 0}; accf[m][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < NT; ++t) { acci[m][t] = init; accf[m][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+      }
 
       for (int ch = 0; ch < p.nchunks; ++ch) {
         const int kc0 = ch * p.kc_bytes;
@@ -114,20 +117,21 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
         const int kcw_pad = (kcw + 63) & ~63;
         if (p.nchunks > 1 || cg == 0) {
           __syncthreads();
+          const uint8_t* src = p.T + p0 * p.rowbytes + kc0;
           if (((p.rowbytes | kc0) & 15) == 0) {
             const int U = kcw_pad >> 4; const int total = BP * U;
             for (int u = tid; u < total; u += 512) {
-              int row = u / U; int col = (u - row * U) << 4; int64_t pix = p0 + row;
+              const int row = u / U; const int col = (u - row * U) << 4;
               uint4 v = make_uint4(0, 0, 0, 0);
-              if (pix < p.npix && col < kcw) v = *(const uint4*)(p.T + pix * p.rowbytes + kc0 + col);
+              if ((p0 + row) < p.npix && col < kcw) v = *(const uint4*)(src + row * p.rowbytes + col);
               *(uint4*)(xs + row * p.kstr + col) = v;
             }
           } else {
             const int U = kcw_pad >> 3; const int total = BP * U;
             for (int u = tid; u < total; u += 512) {
-              int row = u / U; int col = (u - row * U) << 3; int64_t pix = p0 + row;
+              const int row = u / U; const int col = (u - row * U) << 3;
               uint2 v = make_uint2(0, 0);
-              if (pix < p.npix && col < kcw) v = *(const uint2*)(p.T + pix * p.rowbytes + kc0 + col);
+              if ((p0 + row) < p.npix && col < kcw) v = *(const uint2*)(src + row * p.rowbytes + col);
               *(uint2*)(xs + row * p.kstr + col) = v;
             }
           }
@@ -150,7 +154,8 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                   if (BF) accf[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[m]), __builtin_bit_cast(v8bf, bfr[t]), accf[m][t], 0, 0, 0);
-                  else acci[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], bfr[t], acci[m][t], 0, 0, 0);
+                  else if (MODE == M_STATS) acci[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr[t], afr[m], acci[m][t], 0, 0, 0);   // D'[pix][chan]
+                  else acci[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], bfr[t], acci[m][t], 0, 0, 0);                        // D[chan][pix]
                 }
               }
             }
@@ -159,49 +164,51 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
       }
 
       // ------------------------------------------------------------------------------- epilogue
+      if (MODE == M_STATS) {
+        // lane: channel ct*16+j; register r of tile t: pixel p0 + (wp*NT+t)*16 + 4g + r
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+          if (m >= mi_n) continue;
+          long long a1 = 0; long long a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int v = acci[m][t][r];
+              if (full || (p0 + (wp * NT + t) * 16 + 4 * g + r) < p.npix) { a1 += v; a2 += (long long)v * v; mn = min(mn, v); mx = max(mx, v); }
+            }
+          }
+          if (defer) { st1[m] += a1; st2[m] += a2; smn[m] = min(smn[m], mn); smx[m] = max(smx[m], mx); }
+          else {
+            a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
+            mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+            const int chn = (ct0 + m) * 16 + j;
+            if (g == 0 && chn < p.cout) {
+              atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)a2);
+              atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         if (m >= mi_n) continue;
         const int ch0 = (ct0 + m) * 16 + 4 * g;          // 4 consecutive channels of this lane
         const bool chok = ch0 < p.cout;
         if (MODE == M_DGRAD) {
+          uint16_t* base = p.dx + p0 * p.cout;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const int64_t pix = p0 + (wp * NT + t) * 16 + j;
-            if (pix < p.npix && chok) {
-              uint16_t* dst = p.dx + pix * p.cout + ch0;
+            const int prow = (wp * NT + t) * 16 + j;
+            if ((full || (p0 + prow) < p.npix) && chok) {
+              uint16_t* dst = base + prow * p.cout + ch0;
               float v[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = accf[m][t][r] * sw;
-              if (p.accumulate) { uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
-              uint2 o; o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+              if (p.accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
+              uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
               *(uint2*)dst = o;
-            }
-          }
-          continue;
-        }
-        const int4 ws4 = *(const int4*)(p.wsum + ch0);
-        const int corr[4] = {zpx * ws4.x, zpx * ws4.y, zpx * ws4.z, zpx * ws4.w};
-        if (MODE == M_STATS) {
-          int s1[4] = {0, 0, 0, 0}; long long s2[4] = {0, 0, 0, 0};
-          int mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const bool valid = (p0 + (wp * NT + t) * 16 + j) < p.npix;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int v = acci[m][t][r] - corr[r];
-              if (valid) { s1[r] += v; s2[r] += (long long)v * v; mn[r] = min(mn[r], v); mx[r] = max(mx[r], v); }
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int a = row_sum_i(s1[r]); const long long b = row_sum_ll(s2[r]);
-            const int c = row_min_i(mn[r]), d = row_max_i(mx[r]);
-            if (j == 15 && chok) {
-              atomicAdd((unsigned long long*)&l_s1[ch0 + r], (unsigned long long)(long long)a);
-              atomicAdd(&l_s2[ch0 + r], (unsigned long long)b);
-              atomicMin(&l_mn[ch0 + r], c); atomicMax(&l_mx[ch0 + r], d);
             }
           }
           continue;
@@ -210,18 +217,21 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
         const float4 B4 = *(const float4*)(p.coef + FROST_COEF_B * p.cpad + ch0);
         const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
         if (MODE == M_EMIT) {
+          int8_t* base = p.y + p0 * p.cout;
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            const int64_t pix = p0 + (wp * NT + t) * 16 + j;
+            const int prow = (wp * NT + t) * 16 + j;
             uint32_t packed = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float yv = fmaf(A[r], (float)(acci[m][t][r] - corr[r]), B[r]);
-              if (p.relu) yv = fmaxf(yv, 0.0f);
-              // q = clamp(rint(y*inv)+zp, 0, 255): v_cvt_pk_u8_f32 saturates to [0,255] and inserts the byte in one op
+              // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
+              // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
+              const float yv = fmaf(A[r], (float)acci[m][t][r], B[r]);
               packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
             }
-            if (pix < p.npix && chok) *(uint32_t*)(p.y + pix * p.cout + ch0) = packed ^ 0x80808080u;
+            if (p.dbg & 1) { asm volatile("" :: "v"(packed)); }
+            else if (p.dbg & 4) { *(uint32_t*)(base + ((((cg * 8 + w) * MI + m) * NT + t) * 64 + lane) * 4) = packed; }
+            else if ((full || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
           }
           continue;
         }
@@ -238,37 +248,45 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
           S1[0] = a4.x * p.inv_count; S1[1] = a4.y * p.inv_count; S1[2] = a4.z * p.inv_count; S1[3] = a4.w * p.inv_count;
           S2[0] = b4.x * p.inv_count; S2[1] = b4.y * p.inv_count; S2[2] = b4.z * p.inv_count; S2[3] = b4.w * p.inv_count;
         }
+        const uint16_t* gbase = p.gout + p0 * p.cout;
+        uint16_t* dbase = p.dc + p0 * p.cout;
+        const float relu_floor = p.relu ? 0.0f : -INFINITY;
         float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const int64_t pix = p0 + (wp * NT + t) * 16 + j;
-          const bool valid = pix < p.npix && chok;
+          const int prow = (wp * NT + t) * 16 + j;
+          const bool valid = (full || (p0 + prow) < p.npix) && chok;
           uint2 gv = make_uint2(0, 0);
-          if (valid) gv = *(const uint2*)(p.gout + pix * p.cout + ch0);
+          if (valid) gv = *(const uint2*)(gbase + prow * p.cout + ch0);
           const float gq[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
           float dcv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float af = (float)(acci[m][t][r] - corr[r]);
-            float yv = fmaf(A[r], af, B[r]);
-            bool alive = true;
-            if (p.relu) { alive = yv > 0.0f; yv = fmaxf(yv, 0.0f); }
-            bool inr; fq_index(yv, y_inv, y_zp, 0, 255, &inr);
-            const float gy = (alive && inr && valid) ? gq[r] : 0.0f;
+            const float af = (float)acci[m][t][r];
+            const float yv = fmaf(A[r], af, B[r]);
+            // STE masks: ReLU alive (y > 0) and fake-quant in range: 0 <= rint(relu(y)*inv)+zp <= 255
+            const float qf = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
+            const bool pass = (yv > relu_floor) && qf >= 0.0f && qf <= 255.0f;
+            const float gy = pass ? gq[r] : 0.0f;
             const float xhat = (af - Mv[r]) * Rv[r];
             if (MODE == M_BRED) { r1[r] += gy; r2[r] += gy * xhat; }
             else dcv[r] = K1[r] * (gy - S1[r] - xhat * S2[r]);
           }
           if (MODE == M_BDC && valid) {
-            uint2 o; o.x = (uint32_t)f2bf(dcv[0]) | ((uint32_t)f2bf(dcv[1]) << 16); o.y = (uint32_t)f2bf(dcv[2]) | ((uint32_t)f2bf(dcv[3]) << 16);
-            *(uint2*)(p.dc + pix * p.cout + ch0) = o;
+            uint2 o; o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]);
+            *(uint2*)(dbase + prow * p.cout + ch0) = o;
           }
         }
         if (MODE == M_BRED) {
+          if (defer) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = row_sum_f(r1[r]), b = row_sum_f(r2[r]);
-            if (j == 15 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+            for (int r = 0; r < 4; ++r) { br1[m][r] += r1[r]; br2[m][r] += r2[r]; }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = row_sum_f(r1[r]), b = row_sum_f(r2[r]);
+              if (j == 15 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+            }
           }
         }
       }
@@ -276,15 +294,43 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   }
 
   if (MODE == M_STATS) {
+    if (defer) {
+      const int ct0 = wc * p.mi_eff;
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        const int chn = (ct0 + m) * 16 + j;
+        long long a1 = st1[m], a2 = st2[m]; int mn = smn[m], mx = smx[m];
+        a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
+        mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+        if (m < p.mi_eff && g == 0 && chn < p.cout && mn <= mx) {
+          atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)a2);
+          atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
+        }
+      }
+    }
     __syncthreads();
-    int64_t* g_s1 = (int64_t*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
     for (int c = tid; c < p.cout; c += 512) {
-      atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
-      atomicAdd(&g_s2[c], l_s2[c]);
-      atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
+      if (l_mn[c] <= l_mx[c]) {
+        atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
+        atomicAdd(&g_s2[c], l_s2[c]);
+        atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
+      }
     }
   } else if (MODE == M_BRED) {
+    if (defer) {
+      const int ct0 = wc * p.mi_eff;
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        const int ch0 = (ct0 + m) * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row_sum_f(br1[m][r]), b = row_sum_f(br2[m][r]);
+          if (m < p.mi_eff && j == 15 && ch0 < p.cout) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+        }
+      }
+    }
     __syncthreads();
     for (int c = tid; c < p.cout; c += 512) {
       atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
@@ -301,7 +347,9 @@ static int launch_pw(PwP& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
-  int occ = lds <= 78 * 1024 ? 2 : 1;
+  int occ = 1;   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP>, 512, lds) != hipSuccess || occ < 1) occ = 1;
+  if (occ > 4) occ = 4;
   int64_t grid = p.ntiles < 256 * occ ? p.ntiles : 256 * occ;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_pw<MODE, WP>), dim3((unsigned)grid), dim3(512), lds, s, p);
@@ -329,6 +377,7 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
   int kpad = ((p.kc_bytes + 63) / 64) * 64;
   p.kstr = kpad + 16;
   p.inv_count = 1.0f / (float)npix;
+  const char* e = getenv("FROST_DBG"); p.dbg = e ? atoi(e) : 0;
 }
 
 extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,

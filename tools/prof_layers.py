@@ -31,5 +31,9 @@ s = L.PROFILER.summary()
 rows = sorted(s.items(), key=lambda kv: -kv[1]["total_ms"])
 tot = sum(v["total_ms"] for v in s.values())
 print(f"total tagged {tot:.2f} ms")
+import collections
+agg = collections.defaultdict(float)
+for k, v in s.items(): agg[k.split("|")[0]] += v["total_ms"]
+print("by kind: " + "  ".join(f"{k}={v:.2f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])))
 for k, v in rows[:60]:
     print(f"{k:50s} {v['total_ms']:8.3f} ms  {v['bytes_per_launch']/1e6:9.1f} MB  {v['bytes_per_launch']/v['avg_ms']/1e6:8.1f} GB/s")
