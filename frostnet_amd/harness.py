@@ -1,0 +1,76 @@
+"""Caller-side pieces of the hot path that the reference keeps in its (non-importable) training scripts, restated so a
+`Classification/train.py`-style driver runs on the HIP path unchanged in behaviour:
+
+  * `make_param_groups`  -- Classification/train.py:121-137 (one group per tensor; depthwise wd 0, other 4-D wd, rest 0.01*wd)
+  * `adjust_learning_rate_cosine` -- Classification/utils/helper_functions.py:231-261 (per-iteration cosine + linear warm-up)
+  * `statassist_qat_switch` -- Classification/train.py:149-173 (StatAssist FP epoch(s) with the SAME optimizer, flip
+    `is_warmup`, then fuse + prepare_qat keeping Parameter identity so optimizer state survives)
+  * `train_one_iter` / `accuracy` -- helper_functions.py:32-46,118-155 (accuracy() fixed for torch>=1.7: reshape, not view)
+"""
+import math
+
+import torch
+
+
+def make_param_groups(model, weight_decay):
+    groups = []
+    others = weight_decay * 0.01
+    for _, value in model.named_parameters():
+        if len(value.shape) == 4:
+            groups.append({"params": [value], "weight_decay": 0.0 if value.shape[1] == 1 else weight_decay})
+        else:
+            groups.append({"params": [value], "weight_decay": others})
+    return groups
+
+
+def cosine_lr(lr, warmup_lr, warmup_epochs, epochs, epoch, it, dataset_len):
+    total_iter = (epochs - warmup_epochs) * dataset_len
+    current_iter = it + (epoch - warmup_epochs) * dataset_len
+    if epoch < warmup_epochs:
+        return warmup_lr + (lr - warmup_lr) * float(it + epoch * dataset_len) / (warmup_epochs * dataset_len)
+    return lr / 2 * (math.cos(math.pi * current_iter / total_iter) + 1)
+
+
+def adjust_learning_rate_cosine(optimizer, epoch, it, dataset_len, args):
+    """args: .anneal, .restart_epochs, .epochs, .warmup_epochs, .warmup_lr, .lr (same attribute names as the reference)."""
+    if getattr(args, "anneal", False):
+        epoch = epoch % args.restart_epochs
+        epochs = args.restart_epochs
+    else:
+        epochs = args.epochs
+    lr = cosine_lr(args.lr, args.warmup_lr, args.warmup_epochs, epochs, epoch, it, dataset_len)
+    for group in optimizer.param_groups:
+        group["lr"] = lr
+    return lr
+
+
+def accuracy(output, target, topk=(1,)):
+    with torch.no_grad():
+        maxk = max(topk)
+        _, pred = output.topk(maxk, 1, True, True)
+        correct = pred.t().eq(target.view(1, -1).expand(maxk, -1))
+        return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / target.size(0)) for k in topk]
+
+
+def train_one_iter(model, criterion, optimizer, x, target, grad_sync=None):
+    """zero_grad -> forward -> loss -> backward -> (DP all-reduce) -> step   (helper_functions.py:139-143)."""
+    optimizer.zero_grad(set_to_none=True)
+    out = model(x)
+    loss = criterion(out, target)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    optimizer.step()
+    return loss, out
+
+
+def statassist_qat_switch(model, optimizer, qconfig_version=0, backend="qnnpack"):
+    """After the FP warm-up epoch(s): turn GradBoost noise on and switch the model to fake-quant mode.  prepare_qat reuses
+    the same Parameter objects, so the optimizer's moments / exp_max statistics stay attached."""
+    from .frostnet import qat_prepare
+    if hasattr(optimizer, "is_warmup"):
+        optimizer.is_warmup = False
+    before = [id(p) for p in model.parameters()]
+    qat_prepare(model, version=qconfig_version, backend=backend)
+    assert before == [id(p) for p in model.parameters()], "prepare_qat must keep parameter identity"
+    return model

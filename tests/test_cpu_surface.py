@@ -1,0 +1,186 @@
+"""CPU-only tests (run with -m "not gpu"): C-ABI exports, nn.Module / optimizer / harness surface parity with the
+reference (golden vectors), data-parallel gradient sync over gloo.  No compute call touches the HIP library here."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frost_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    import frostnet_amd
+    return frostnet_amd
+
+
+def test_cabi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "frost_hip.h")).read()
+    declared = set(re.findall(r"\b(frost_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(built.LIB_PATH)
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/frost_hip.h but not exported"
+    assert set(built.SYMBOLS) == declared          # the ctypes binding covers exactly the header
+    assert built.load_library().frost_abi_version() == 1
+
+
+def test_no_cpu_fallback_on_device_path(built):
+    from frostnet_amd import frostnet as F
+    from frostnet_amd.optimizer import QSGD
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        QSGD([p], lr=0.1).step()                   # GradBoost kernels are HIP-only: CPU tensors fail loudly
+    m = F.frostnet_small_1_0()
+    assert not m._is_qat_prepared()
+
+
+def test_factories_and_state_dict_layout(built, golden):
+    from frostnet_amd import frostnet as F
+    g = golden("g7_scalars")
+    names = [f"frostnet_{q}{m}_{t}" for q in ("quant_", "") for m in ("large", "base", "small")
+             for t in ("1_25", "1_0", "0_75", "0_5", "0_35")]
+    assert sorted(names) == sorted(F.MODEL_REGISTRY) and len(names) == 30
+    for mode in ("large", "base", "small"):
+        for tag in ("1_0", "0_5", "1_25"):
+            net = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_{tag}"](drop_rate=0.0, num_classes=10, pretrained=False)
+            assert list(net.state_dict().keys()) == [str(k) for k in g[f"{mode}_{tag}_float_keys"]]
+            assert [n for n, _ in net.named_parameters()] == [str(k) for k in g[f"{mode}_{tag}_param_names"]]
+            assert [p.numel() for p in net.parameters()] == g[f"{mode}_{tag}_param_numel"].tolist()
+            if tag == "1_0":
+                F.qat_prepare(net, version=0)
+                assert list(net.state_dict().keys()) == [str(k) for k in g[f"{mode}_{tag}_qat_keys"]]
+    net = F.create_model("frostnet_quant_large_1_0")
+    from frostnet_amd.harness import make_param_groups
+    groups = make_param_groups(net, 1.0)
+    cnt = {0.0: 0, 1.0: 0, 0.01: 0}
+    for gr in groups:
+        cnt[gr["weight_decay"]] += gr["params"][0].numel()
+    assert [cnt[0.0], cnt[1.0], cnt[0.01]] == g["large_group_counts"].tolist()
+    assert len(groups) == 209 and sum(p.numel() for p in net.parameters()) == 5807056
+
+
+def test_kaiming_init_parity_with_reference_seed(built, golden):
+    import zlib
+    from frostnet_amd import frostnet as F
+    g = golden("g5_fp32_eval")
+    torch.manual_seed(1882)
+    net = F.frostnet_small_1_0(drop_rate=0.0)
+    sd = net.state_dict()
+    assert np.uint32(zlib.crc32(sd["conv1.conv.0.weight"].numpy().tobytes())) == g["init1882_small_conv1_crc"]
+    assert np.uint32(zlib.crc32(sd["classifier.2.weight"].numpy().tobytes())) == g["init1882_small_cls_crc"]
+
+
+def test_config_c1_small_fp32_forward_cpu(built, golden):
+    """BASELINE.json configs[0]: FrostNet-Small fp32 forward-only, batch=1, 224x224 on CPU (plumbing)."""
+    from frostnet_amd import frostnet as F
+    g = golden("g5_fp32_eval")
+    B, res, seed, wseed = [int(v) for v in g["fp32_eval_small_spec"]]
+    net = F.frostnet_small_1_0(drop_rate=0.0)
+    spec = O.float_state_spec(O.net_cfg("small", 1.0))
+    net.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], wseed))
+    net.eval()
+    with torch.no_grad():
+        y = net(T(O.synth((B, 3, res, res), seed)))
+    np.testing.assert_allclose(y.numpy(), g["fp32_eval_small_logits"], rtol=1e-5, atol=1e-5)
+
+
+def test_qat_cpu_module_path_matches_reference(built, golden):
+    """The stock-module (CPU) QAT graph of frostnet_amd.FrostNet reproduces the reference's QAT step (golden G5)."""
+    from frostnet_amd import frostnet as F
+    g = golden("g5_qat_large")
+    B, res, seed, wseed = [int(v) for v in g["spec"]]
+    torch.set_num_threads(8)
+    net = F.frostnet_quant_large_1_0(drop_rate=0.0)
+    spec = O.float_state_spec(O.net_cfg("large", 1.0))
+    net.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], wseed))
+    F.qat_prepare(net, version=0)
+    y = net(T(O.synth((B, 3, res, res), seed)))
+    np.testing.assert_allclose(y.detach().numpy(), g["s0_logits"], rtol=1e-5, atol=1e-5)
+
+
+def test_lr_schedule_and_get_optimizer(built, golden):
+    from frostnet_amd import harness, optimizer
+    g = golden("g7_scalars")
+
+    class A:
+        anneal, epochs, warmup_epochs, warmup_lr, lr, restart_epochs = False, 400, 5, 0.0, 5e-3, 100
+        learning_rate, weight_decay, nesterov, clip_by, toss_coin, noise_decay, amsgrad = 5e-3, 1e-5, True, 1e-3, True, 1e-2, False
+
+    class Opt:
+        param_groups = [dict(lr=0.0)]
+    for (ep, it), lr in zip(g["lr_points"], g["lr_values"]):
+        assert harness.adjust_learning_rate_cosine(Opt(), int(ep), int(it), 10, A) == pytest.approx(float(lr), rel=1e-12, abs=1e-18)
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    for name, cls in (("SGD", torch.optim.SGD), ("RMS", torch.optim.RMSprop), ("Adam", torch.optim.Adam), ("AdamW", torch.optim.AdamW),
+                      ("QSGD", optimizer.QSGD), ("QRMS", optimizer.QRMSprop), ("QAdam", optimizer.QAdam), ("QAdamW", optimizer.QAdamW)):
+        o = optimizer.get_optimizer(name, p, A)
+        assert type(o) is cls
+        if name.startswith("Q"):
+            assert o.is_warmup is True and o.defaults["clip_by"] == 1e-3
+    out = torch.tensor([[0.1, 0.9, 0.0], [0.8, 0.1, 0.1]])
+    assert [float(a) for a in harness.accuracy(out, torch.tensor([1, 2]), topk=(1, 2))] == [50.0, 50.0]
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from frostnet_amd.parallel import GradSync, broadcast_model
+    sizes = [7, 1000, 13, 2048, 64, 5]
+    offs = np.cumsum([0] + sizes[:-1]).tolist()
+    arena = torch.zeros(sum(sizes))
+    sync = GradSync(arena, offs, nbuckets=3)
+    torch.manual_seed(100 + rank)
+    grads = [torch.randn(s) for s in sizes]
+    for i in reversed(range(len(sizes))):           # backward order = reverse parameter order
+        arena[offs[i]: offs[i] + sizes[i]] = grads[i]
+        sync.ready(offs[i])
+    sync.finish()
+    lin = torch.nn.Linear(3, 2)
+    torch.manual_seed(rank)
+    with torch.no_grad():
+        lin.weight.normal_()
+    broadcast_model(lin)
+    q.put((rank, arena.numpy().copy(), lin.weight.detach().numpy().copy(), len(sync.buckets)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_grad_sync_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    sizes = [7, 1000, 13, 2048, 64, 5]
+    expect = []
+    for s_i, s in enumerate(sizes):
+        gs = []
+        for r in range(2):
+            torch.manual_seed(100 + r)
+            gs.append([torch.randn(x) for x in sizes][s_i])
+        expect.append((gs[0] + gs[1]) / 2)
+    expect = torch.cat(expect)
+    assert res[0][3] >= 2
+    for r in range(2):
+        torch.testing.assert_close(T(res[r][1]), expect)          # every rank holds the mean of the per-shard gradients
+    torch.testing.assert_close(T(res[0][2]), T(res[1][2]))           # broadcast made the replicas identical
