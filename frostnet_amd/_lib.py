@@ -49,6 +49,8 @@ _PROTOS = {
     "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
     "frost_dw_conv_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P],
     "frost_stem_conv_fwd": [P, P, P, P, I, I, I, I, I, P, P, P, I, P, P],
+    "frost_stem_im2col": [P, P, I, I, I, P, P],
+    "frost_stem_wgrad_remap": [P, I, I, P, P],
     "frost_conv_finalize": [P, L, I, P, P, P, P, P, P, P, I, I, I, P, P, P],
     "frost_cat_observe": [P, P, P, I, P],
     "frost_cat_requant": [P, P, I, P, P, I, L, P, P, P],

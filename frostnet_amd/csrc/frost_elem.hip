@@ -216,11 +216,19 @@ __global__ __launch_bounds__(256) void k_wprep_pack(const FrostWDesc* descs) {
       int c = (int)(i % d.cpad), tap = (int)(i / d.cpad);
       d.wq_pack[i] = (int8_t)((c < d.cout) ? wq_at(d, inv, c, tap) : 0);
     }
-  } else if (d.kind == 2) {     // stem (VALU direct conv): [t = tap*cin_g + c][cpad]
-    int64_t nb = (int64_t)d.kk * d.cin_g * d.cpad;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < nb; i += (int64_t)gridDim.x * 256) {
-      int co = (int)(i % d.cpad); int t = (int)(i / d.cpad); int tap = t / d.cin_g, c = t % d.cin_g;
-      d.wq_pack[i] = (int8_t)((co < d.cout) ? wq_at(d, inv, co, c * d.kk + tap) : 0);
+  } else if (d.kind == 2) {     // stem as im2col + pointwise: K index k = tap*4 + c (c == 3 is the zero pad channel), K = 4*kk
+    int CT = d.cpad / 16, KS = d.kpad / 64;
+    int64_t ndw = (int64_t)CT * KS * 64 * 4;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < ndw; i += (int64_t)gridDim.x * 256) {
+      int dwi = (int)(i & 3); int lane = (int)((i >> 2) & 63); int64_t t = i >> 8; int ks = (int)(t % KS); int ct = (int)(t / KS);
+      int co = ct * 16 + (lane & 15); int k0 = ks * 64 + (lane >> 4) * 16 + dwi * 4;
+      uint32_t packed = 0;
+      for (int e = 0; e < 4; ++e) {
+        int k = k0 + e; int tap = k >> 2, c = k & 3; int v = 0;
+        if (co < d.cout && tap < d.kk && c < d.cin_g) v = wq_at(d, inv, co, c * d.kk + tap);
+        packed |= ((uint32_t)(v & 255)) << (8 * e);
+      }
+      ((uint32_t*)d.wq_pack)[i] = packed;
     }
   } else {                      // classifier: plain [cout][cin]
     int64_t nb = (int64_t)d.cout * d.cin_g;
@@ -478,4 +486,46 @@ extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const floa
   hipLaunchKernelGGL(k_classifier_fwd, dim3((nclass + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x, wq,
                      qrec_w, bias, n, cin, nclass, y);
   return frost_check_launch("classifier_fwd");
+}
+
+// ------------------------------------------------------------------------------------------------ stem im2col
+// 3x3 stride-2 pad-1 patches of the 4-byte-per-pixel quantised image -> [npix_out][40] (36 patch bytes + 4 zero-point
+// bytes), so the stem runs on the pointwise int8-MFMA kernels (K = 40) forward AND backward (wgrad = plain pw wgrad).
+__global__ __launch_bounds__(256) void k_stem_im2col(const int8_t* __restrict__ x, const float* qx, int n, int h, int w, int ho, int wo,
+                                                     int8_t* __restrict__ out) {
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
+  const int64_t npix = (int64_t)n * ho * wo;
+  for (int64_t p = blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(p % wo); int64_t t = p / wo; const int oy = (int)(t % ho); const int img = (int)(t / ho);
+    uint32_t v[10];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        v[ky * 3 + kx] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? *(const uint32_t*)(x + (((int64_t)img * h + iy) * w + ix) * 4) : zfill;
+      }
+    v[9] = zfill;
+    uint32_t* dst = (uint32_t*)(out + p * 40);
+#pragma unroll
+    for (int i = 0; i < 10; i += 2) *(uint2*)(dst + i) = make_uint2(v[i], v[i + 1]);
+  }
+}
+extern "C" int frost_stem_im2col(const int8_t* x, const float* qrec_x, int n, int h, int w, int8_t* out, void* stream) {
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(k_stem_im2col, dim3(grid_for((int64_t)n * ho * wo, 256, 8192)), dim3(256), 0, as_stream(stream), x, qrec_x, n, h, w, ho, wo, out);
+  return frost_check_launch("stem_im2col");
+}
+// dwq_col[cout][40] (k = tap*4 + c) -> dwq[cout][cin_g][3][3] (OIHW)
+__global__ void k_stem_wgrad_remap(const float* __restrict__ src, int cout, int cin_g, float* __restrict__ dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * cin_g * 9) return;
+  int co = i / (cin_g * 9), r = i % (cin_g * 9); int c = r / 9, tap = r % 9;
+  dst[i] = src[co * 40 + tap * 4 + c];
+}
+extern "C" int frost_stem_wgrad_remap(const float* dwq_col, int cout, int cin_g, float* dwq, void* stream) {
+  int tot = cout * cin_g * 9;
+  hipLaunchKernelGGL(k_stem_wgrad_remap, dim3((tot + 255) / 256), dim3(256), 0, as_stream(stream), dwq_col, cout, cin_g, dwq);
+  return frost_check_launch("stem_wgrad_remap");
 }

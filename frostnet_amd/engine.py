@@ -104,8 +104,8 @@ class ConvLayer:
             self.wt_pack = torch.zeros(cit * kb * 64 * 8, dtype=torch.int16, device=dev)
         elif kind == "dw":
             self.kpad, nb, self.wt_pack = 0, self.kk * self.cpad, None
-        elif kind == "stem":
-            self.kpad, nb, self.wt_pack = 0, self.kk * self.cin_g * self.cpad, None
+        elif kind == "stem":      # runs as im2col + pointwise with K = 4*kk + 4 = 40 bytes per output pixel
+            self.kpad, nb, self.wt_pack = 64, (self.cpad // 16) * 1024, None
         else:
             self.kpad, nb, self.wt_pack = 0, self.cout * self.cin_g, None
         self.wq_pack = torch.zeros(nb + 64, dtype=torch.int8, device=dev)
@@ -222,7 +222,7 @@ class Engine:
         st = ptr(l.stats)
         nb = x.numel + l.wq_pack.numel() + (y.numel if y is not None else 0)
         tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)
-        if l.kind == "pw":
+        if l.kind in ("pw", "stem"):
             call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
                  ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
         elif l.kind == "dw":
@@ -230,13 +230,18 @@ class Engine:
                  l.stride, mode, st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(),
                  prof=tag)
         else:
-            call("frost_stem_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout, mode,
-                 st, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
+            raise ValueError(l.kind)
 
     def conv(self, l, x, training=True, observe=True):
         """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute)."""
         pad = (l.k - 1) // 2
         ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
+        if l.kind == "stem":      # im2col once (kept for the backward wgrad), then the pointwise int8-MFMA kernels
+            xc = self.new_act(x.n, ho, wo, 40, x.q)
+            call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream(),
+                 prof=("stem_im2col", x.numel + xc.numel))
+            xc.needs_grad = False
+            x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
         need_stats = training or observe
         if need_stats:
@@ -351,7 +356,13 @@ class Engine:
         l.dwq.zero_()
         dc = torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
         s = stream()
-        if l.kind == "pw":
+        if l.kind in ("pw", "stem"):
+            dwq_final = l.dwq
+            if l.kind == "stem":
+                if getattr(l, "dwq_col", None) is None:
+                    l.dwq_col = torch.empty(l.cout * 40, dtype=torch.float32, device=self.device)
+                l.dwq_col.zero_()
+                l.dwq, dwq_final = l.dwq_col, l.dwq
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout)
             # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
             call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
@@ -364,6 +375,9 @@ class Engine:
                      prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
             call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), s,
                  prof=("pw_wgrad", 2 * y.numel + x.numel))
+            if l.kind == "stem":
+                l.dwq = dwq_final
+                call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), s)
         elif l.kind == "dw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
@@ -376,10 +390,6 @@ class Engine:
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
             call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
                  prof=("dw_wgrad", 2 * y.numel + x.numel))
-        else:
-            args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, l.cout)
-            call("frost_stem_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s)
-            call("frost_stem_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(l.dwq), s)
         call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
              l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
         y.grad = None

@@ -111,6 +111,10 @@ int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pac
 int frost_stem_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
                         int w, int cout, int mode, void* stats, const float* coef, const float* qrec_y, int relu,
                         int8_t* y, void* stream);
+/* stem as im2col + pointwise: 3x3/s2/p1 patches of the 4 B/pixel image -> [npix_out][40] bytes (k = tap*4 + c); the stem
+ * then runs on frost_pw_conv_fwd / _bwd / frost_pw_wgrad with cin = 40; frost_stem_wgrad_remap maps dWq back to OIHW. */
+int frost_stem_im2col(const int8_t* x, const float* qrec_x, int n, int h, int w, int8_t* out, void* stream);
+int frost_stem_wgrad_remap(const float* dwq_col, int cout, int cin_g, float* dwq, void* stream);
 /* replaces: conv/scale_factor, BatchNorm2d (train: batch stats + running-stat update; eval: running stats),
  * the activation observer + qparams (conv_fused.py:153-157, fake_quantize.py:229-240).  One launch per layer. */
 int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
