@@ -1,28 +1,38 @@
 // Pointwise weight gradient: dWq[co][ci] += s_x * sum_p dc[p][co] * (q[p][ci] - zp)    (bf16 MFMA, K = pixels)
-// Both operands are pixel-major in HBM, so a 128-pixel block of each is staged to LDS in its natural layout
-// with coalesced loads and the K(pixel)-contiguous MFMA fragments are gathered from LDS with strided 16/8-bit
-// reads.  A workgroup owns a 64x64 (co x ci) output tile; its 4 waves split the staged pixels (one 32-pixel
-// K-step each) and are summed through LDS at the end; the pixel range is split across workgroups (split-M)
-// and combined with fp32 atomics.
+// Both operands are pixel-major in HBM, so a 128-pixel block of each is staged to LDS in its natural layout with
+// coalesced loads; the K(pixel)-contiguous MFMA fragments are produced by the gfx950 LDS transpose reads
+// (ds_read_b64_tr_b16 for the bf16 dc operand, ds_read_b64_tr_b8 for the int8 activation operand -- lane/pointer
+// semantics measured with tools/probe_tr.hip).  A workgroup owns a 64x64 (co x ci) output tile; its 4 waves split
+// the staged pixels (one 32-pixel K-step each) and are summed through LDS at the end; the pixel range is split
+// across workgroups (split-M) and combined with fp32 atomics.
 #include "frost_common.h"
+#include <stdlib.h>
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 #define WT 64
 #define KPIX 128
 #define RSD 136   // dc LDS row stride (bytes): 64 bf16 + 8
-#define RSX 68    // x  LDS row stride (bytes): 64 int8 + 4
+#define RSX 72    // x  LDS row stride (bytes): 64 int8 + 8  (8-byte aligned rows for the 8-byte transpose reads)
+
+__device__ __forceinline__ uint32_t pack_trunc_bf16(float lo, float hi) {   // exact for |integers| <= 256
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
 
 __global__ __launch_bounds__(256) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
                                                   int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4 * WT * WT * 4];   // 64 KB: staging (26 KB) then reduction
+  __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD + KPIX * RSX];   // 26.6 KB: staging, then the 16 KB reduction tile
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nci = (cin + WT - 1) / WT;
-  const int tile = blockIdx.x % (((cout + WT - 1) / WT) * nci), split = blockIdx.x / (((cout + WT - 1) / WT) * nci);
+  const int ntile = ((cout + WT - 1) / WT) * nci;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
   const int co0 = (tile / nci) * WT, ci0 = (tile % nci) * WT;
-  const int zpo = __float_as_int(qx[FROST_Q_ZP]) - 128;      // zero point in the stored (offset-binary) domain
-  const uint32_t zfill = (uint32_t)(zpo & 255) * 0x01010101u;
+  const int zpu = __float_as_int(qx[FROST_Q_ZP]);                  // zero point in the unsigned index domain
+  const float zpf = (float)zpu;
+  const uint32_t zfill = (uint32_t)((zpu - 128) & 255) * 0x01010101u;
 
   v4f acc[4][4];
 #pragma unroll
@@ -30,78 +40,196 @@ __global__ __launch_bounds__(256) void k_pw_wgrad(const uint16_t* __restrict__ d
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+  // transpose-read source addresses (fixed per lane): this wave's 32 pixels = rows w*32 + 8g + e
+  const int pb = w * 32 + g * 8;
+  const uint8_t* a_src = dcs + (pb + (i16 >> 2)) * RSD + (i16 & 3) * 8;          // + a*32 bytes, second read + 4 rows
+  const uint8_t* b_src = xs + (pb + (i16 >> 1)) * RSX + (i16 & 1) * 8;           // + b*16 bytes
+
+  int na = (cout - co0 + 15) / 16; if (na > 4) na = 4;     // live 16-channel tiles of this workgroup's 64x64 output tile
+  int nb = (cin - ci0 + 15) / 16; if (nb > 4) nb = 4;
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
+  // register prefetch of the next 128-pixel block (24 VGPRs) so its HBM latency overlaps the MFMAs of the current one
+  uint4 pd[4]; uint2 px[4];
+#define WG_PREFETCH(BLK_)                                                                                             \
+  {                                                                                                                   \
+    const int64_t q0_ = (BLK_) * KPIX;                                                                                \
+    _Pragma("unroll") for (int jn = 0; jn < 4; ++jn) {                                                                \
+      const int u_ = tid + jn * 256; const int pix_ = u_ >> 3, c8_ = u_ & 7; const int64_t gp_ = q0_ + pix_;          \
+      pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint2(zfill, zfill);                                             \
+      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);            \
+      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);               \
+    }                                                                                                                 \
+  }
+  if (split < nblk) WG_PREFETCH((int64_t)split)
   for (int64_t blk = split; blk < nblk; blk += nsplit) {
-    const int64_t p0 = blk * KPIX;
     __syncthreads();
-    for (int u = tid; u < KPIX * 8; u += 256) {          // dc: 8 x 16B per pixel row
-      const int pix = u >> 3, c8 = u & 7; const int64_t gp = p0 + pix; const int co = co0 + c8 * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (gp < npix && co < cout) v = *(const uint4*)(dc + gp * cout + co);
-      *(uint2*)(dcs + pix * RSD + c8 * 16) = make_uint2(v.x, v.y);
-      *(uint2*)(dcs + pix * RSD + c8 * 16 + 8) = make_uint2(v.z, v.w);
-    }
-    for (int u = tid; u < KPIX * 8; u += 256) {          // x: 8 x 8B per pixel row
-      const int pix = u >> 3, c8 = u & 7; const int64_t gp = p0 + pix; const int ci = ci0 + c8 * 8;
-      uint2 v = make_uint2(zfill, zfill);
-      if (gp < npix && ci < cin) v = *(const uint2*)(x + gp * cin + ci);
-      *(uint32_t*)(xs + pix * RSX + c8 * 8) = v.x; *(uint32_t*)(xs + pix * RSX + c8 * 8 + 4) = v.y;
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int u = tid + jn * 256; const int pix = u >> 3, c8 = u & 7;
+      *(uint2*)(dcs + pix * RSD + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y);
+      *(uint2*)(dcs + pix * RSD + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
+      *(uint2*)(xs + pix * RSX + c8 * 8) = px[jn];
     }
     __syncthreads();
-    const int pb = w * 32 + g * 8;                        // this lane's 8 pixels (K slots)
+    if (blk + nsplit < nblk) WG_PREFETCH(blk + nsplit)
     v4i afr[4], bfr[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {                         // A: dc^T rows = co
-      uint32_t pk[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint16_t lo = *(const uint16_t*)(dcs + (pb + 2 * e) * RSD + (a * 16 + i16) * 2);
-        const uint16_t hi = *(const uint16_t*)(dcs + (pb + 2 * e + 1) * RSD + (a * 16 + i16) * 2);
-        pk[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+    for (int a = 0; a < 4; ++a) {                         // A: dc^T, rows = co; lane i16 gets channel a*16+i16, 8 pixels
+      if (a < na) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + a * 32));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + a * 32 + 4 * RSD));
+        afr[a] = (v4i){(int)((uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16)), (int)((uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16)),
+                       (int)((uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16)), (int)((uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16))};
       }
-      afr[a] = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {                         // B: x^T cols = ci, values (q' - zp') exact in bf16
-      uint32_t pk[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int lo = (int)*(const int8_t*)(xs + (pb + 2 * e) * RSX + b * 16 + i16) - zpo;
-        const int hi = (int)*(const int8_t*)(xs + (pb + 2 * e + 1) * RSX + b * 16 + i16) - zpo;
-        pk[e] = (uint32_t)(__float_as_uint((float)lo) >> 16) | (__float_as_uint((float)hi) & 0xffff0000u);
+    for (int b = 0; b < 4; ++b) {                         // B: x^T, cols = ci; lane i16 gets channel b*16+i16, 8 pixels
+      if (b < nb) {
+        const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(b_src + b * 16));
+        const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;   // offset-binary -> unsigned index
+        bfr[b] = (v4i){(int)pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
+                       (int)pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                       (int)pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
+                       (int)pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf)};
       }
-      bfr[b] = (v4i){(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
+        if (a < na && b < nb)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
   }
-  // cross-wave reduction: red[w][co_local][ci_local]
+  // cross-wave reduction through LDS float atomics into one 64x64 tile
   __syncthreads();
   float* red = (float*)lds;
+  for (int i = tid; i < WT * WT; i += 256) red[i] = 0.0f;
+  __syncthreads();
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
+      if (a < na && b < nb) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(w * WT + a * 16 + 4 * g + r) * WT + b * 16 + i16] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[(a * 16 + 4 * g + r) * WT + b * 16 + i16], acc[a][b][r]);
+      }
   __syncthreads();
   const float sx = qx[FROST_Q_SCALE];
   for (int i = tid; i < WT * WT; i += 256) {
     const int co = co0 + i / WT, ci = ci0 + i % WT;
-    if (co < cout && ci < cin) {
-      const float v = red[i] + red[WT * WT + i] + red[2 * WT * WT + i] + red[3 * WT * WT + i];
-      atomicAdd(dwq + (int64_t)co * cin + ci, v * sx);
+    if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, red[i] * sx);
+  }
+}
+// Large-channel variant: 128x128 (co x ci) output tile, each of the 4 waves owns a 64x64 quadrant over ALL 128 staged
+// pixels (4 K-steps): 2x the arithmetic intensity per staged byte, no cross-wave reduction.
+#define BT 128
+#define RSD2 264   // 128 bf16 + 8 bytes
+#define RSX2 136   // 128 int8 + 8 bytes
+__global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+                                                      int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 51 KB
+  uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD2;
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qa = w >> 1, qb = w & 1;                                   // quadrant of this wave
+  const int nci = (cin + BT - 1) / BT;
+  const int ntile = ((cout + BT - 1) / BT) * nci;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  const int co0 = (tile / nci) * BT, ci0 = (tile % nci) * BT;
+  const int zpu = __float_as_int(qx[FROST_Q_ZP]);
+  const float zpf = (float)zpu;
+  const uint32_t zfill = (uint32_t)((zpu - 128) & 255) * 0x01010101u;
+  int na = (cout - co0 - qa * 64 + 15) / 16; na = na < 0 ? 0 : (na > 4 ? 4 : na);
+  int nb = (cin - ci0 - qb * 64 + 15) / 16; nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
+  v4f acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const uint8_t* a_src = dcs + (g * 8 + (i16 >> 2)) * RSD2 + qa * 128 + (i16 & 3) * 8;
+  const uint8_t* b_src = xs + (g * 8 + (i16 >> 1)) * RSX2 + qb * 64 + (i16 & 1) * 8;
+  const int64_t nblk = (npix + KPIX - 1) / KPIX;
+  uint4 pd[8]; uint2 px[8];         // register prefetch of the next block (48 VGPRs): HBM/L2 latency overlaps the MFMAs
+#define WGB_PREFETCH(BLK_)                                                                                            \
+  {                                                                                                                   \
+    const int64_t q0_ = (BLK_) * KPIX;                                                                                \
+    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) {                                                                \
+      const int u_ = tid + jn * 256; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;         \
+      pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint2(zfill, zfill);                                             \
+      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);            \
+      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);               \
+    }                                                                                                                 \
+  }
+  if (split < nblk) WGB_PREFETCH((int64_t)split)
+  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < 8; ++jn) {
+      const int u = tid + jn * 256; const int pix = u >> 4, c8 = u & 15;
+      *(uint2*)(dcs + pix * RSD2 + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y);
+      *(uint2*)(dcs + pix * RSD2 + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
+      *(uint2*)(xs + pix * RSX2 + c8 * 8) = px[jn];
+    }
+    __syncthreads();
+    if (blk + nsplit < nblk) WGB_PREFETCH(blk + nsplit)
+    if (na > 0 && nb > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        v4i afr[4], bfr[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (a < na) {
+            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32));
+            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32 + 4 * RSD2));
+            afr[a] = (v4i){(int)((uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16)), (int)((uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16)),
+                           (int)((uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16)), (int)((uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16))};
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (b < nb) {
+            const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 16));
+            const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;
+            bfr[b] = (v4i){(int)pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
+                           (int)pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                           (int)pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
+                           (int)pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf)};
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (a < na && b < nb)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
+      }
     }
   }
+  const float sx = qx[FROST_Q_SCALE];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (a < na && b < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * 64 + b * 16 + i16;
+          if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
+        }
+      }
 }
 extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int64_t npix, int cin, int cout,
                               float* dwq, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "pw_wgrad: channels must be multiples of 8");
-  const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
+  if (cin > 64 && cout > 64) {      // wide layers: 128x128 tiles, quadrant-per-wave
+    const int ntile = ((cout + BT - 1) / BT) * ((cin + BT - 1) / BT);
+    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 768;
+    int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
+    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
+    return frost_check_launch("pw_wgrad_big");
+  }
+  const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);
   int nsplit = (1024 + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
   hipLaunchKernelGGL(k_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
   return frost_check_launch("pw_wgrad");
