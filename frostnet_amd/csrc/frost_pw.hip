@@ -49,7 +49,38 @@ __device__ __forceinline__ float row_sum_f(float v) {
 
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return cvt_pk_bf16(a, b); }
 
-template <int MODE, int WP>
+// Next-tile register prefetch (<= 20 VGPRs) for single-chunk rows of <= 320 B.  `tid` is made opaque so LICM does not
+// hoist a dozen per-unit 64-bit addresses out of the persistent tile loop (that spilled every variant).
+__device__ __forceinline__ void pw_prefetch(const PwP& p, int64_t tile, int tid, int kpad0, bool al16, uint4 (&pre)[5]) {
+  asm volatile("" : "+v"(tid));
+  const int64_t q0 = tile * BP; const uint8_t* src = p.T + q0 * p.rowbytes;
+  if (al16) {
+    const int U = kpad0 >> 4; const int total = BP * U;
+#pragma unroll
+    for (int jn = 0; jn < 5; ++jn) {
+      const int u = tid + jn * 512; const int row = u / U; const int col = (u - row * U) << 4;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v = *(const uint4*)(src + row * p.rowbytes + col);
+      pre[jn] = v;
+    }
+  } else {
+    const int U = kpad0 >> 3; const int total = BP * U;
+#pragma unroll
+    for (int jh = 0; jh < 5; ++jh) {
+      uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
+      { const int u = tid + (2 * jh) * 512; const int row = u / U; const int col = (u - row * U) << 3;
+        if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v0 = *(const uint2*)(src + row * p.rowbytes + col); }
+      { const int u = tid + (2 * jh + 1) * 512; const int row = u / U; const int col = (u - row * U) << 3;
+        if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v1 = *(const uint2*)(src + row * p.rowbytes + col); }
+      pre[jh] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+    }
+  }
+}
+
+// RES = "resident" mode for small layers: the packed weights, wsum and the BN/quant coefficient rows are copied into LDS
+// once per workgroup, so the persistent tile loop touches global memory only for the activation stream itself (no
+// per-tile L2 round trips on the critical path), and the next tile is register-prefetched.
+template <int MODE, int WP, bool RES>
 __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
@@ -63,6 +94,13 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   int* l_mx = l_mn + p.cpad;
   float* l_f1 = (float*)(smem + xs_bytes);
   float* l_f2 = l_f1 + p.cpad;
+  const int red_bytes = (MODE == M_STATS) ? p.cpad * 24 : ((MODE == M_BRED) ? p.cpad * 8 : 0);
+  const uint8_t* wl = smem + xs_bytes + red_bytes;                                  // [CT][KS][64][16 B]
+  const int wl_bytes = (p.cpad >> 4) * p.KS * 1024;
+  const float* cl = (const float*)(wl + wl_bytes);                                  // [FROST_COEF_ROWS][cpad]
+  const int* wsl = (const int*)(cl + FROST_COEF_ROWS * p.cpad);                      // [cpad]
+  const float* coefp = RES ? cl : p.coef;
+  const int* wsump = RES ? wsl : p.wsum;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -75,6 +113,12 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   } else if (MODE == M_BRED) {
     for (int c = tid; c < p.cpad; c += 512) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
   }
+  if (RES) {
+    for (int i = tid; i < (wl_bytes >> 4); i += 512) ((uint4*)wl)[i] = ((const uint4*)p.wpack)[i];
+    if (MODE != M_STATS && MODE != M_DGRAD) for (int i = tid; i < FROST_COEF_ROWS * p.cpad; i += 512) ((float*)cl)[i] = p.coef[i];
+    if (MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
+  }
+  if (RES) __syncthreads();
 
   int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
@@ -93,6 +137,12 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
     for (int r = 0; r < 4; ++r) { br1[m][r] = 0.0f; br2[m][r] = 0.0f; }
   }
 
+  const int kpad0 = (p.rowbytes + 63) & ~63;
+  const bool can_pf = RES && (p.nchunks == 1) && (kpad0 <= 320);
+  const bool al16 = (p.rowbytes & 15) == 0;
+  uint4 pre[5];
+  if (can_pf && (int64_t)blockIdx.x < p.ntiles) pw_prefetch(p, (int64_t)blockIdx.x, tid, kpad0, al16, pre);
+
   for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BP;
     const bool full = (p0 + BP) <= p.npix;
@@ -104,8 +154,8 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
       for (int m = 0; m < MI; ++m) {
         v4i init = (v4i){0, 0, 0, 0};
         if (!BF && m < mi_n) {
-          if (MODE == M_STATS) { const int c = -zpx * p.wsum[(ct0 + m) * 16 + j]; init = (v4i){c, c, c, c}; }
-          else { const int4 ws = *(const int4*)(p.wsum + (ct0 + m) * 16 + 4 * g); init = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w}; }
+          if (MODE == M_STATS) { const int c = -zpx * wsump[(ct0 + m) * 16 + j]; init = (v4i){c, c, c, c}; }
+          else { const int4 ws = *(const int4*)(wsump + (ct0 + m) * 16 + 4 * g); init = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w}; }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acci[m][t] = init; accf[m][t] = (v4f){0.f, 0.f, 0.f, 0.f}; }
@@ -118,7 +168,23 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
         if (p.nchunks > 1 || cg == 0) {
           __syncthreads();
           const uint8_t* src = p.T + p0 * p.rowbytes + kc0;
-          if (((p.rowbytes | kc0) & 15) == 0) {
+          if (can_pf) {
+            int t2 = threadIdx.x; asm volatile("" : "+v"(t2));
+            if (al16) {
+              const int U = kpad0 >> 4; const int total = BP * U;
+#pragma unroll
+              for (int jn = 0; jn < 5; ++jn) { const int u = t2 + jn * 512; const int row = u / U; const int col = (u - row * U) << 4; if (u < total) *(uint4*)(xs + row * p.kstr + col) = pre[jn]; }
+            } else {
+              const int U = kpad0 >> 3; const int total = BP * U;
+#pragma unroll
+              for (int jh = 0; jh < 5; ++jh) {
+                { const int u = t2 + (2 * jh) * 512; const int row = u / U; const int col = (u - row * U) << 3;
+                  if (u < total) *(uint2*)(xs + row * p.kstr + col) = make_uint2(pre[jh].x, pre[jh].y); }
+                { const int u = t2 + (2 * jh + 1) * 512; const int row = u / U; const int col = (u - row * U) << 3;
+                  if (u < total) *(uint2*)(xs + row * p.kstr + col) = make_uint2(pre[jh].z, pre[jh].w); }
+              }
+            }
+          } else if (((p.rowbytes | kc0) & 15) == 0) {
             const int U = kcw_pad >> 4; const int total = BP * U;
             for (int u = tid; u < total; u += 512) {
               const int row = u / U; const int col = (u - row * U) << 4;
@@ -136,6 +202,7 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
             }
           }
           __syncthreads();
+          if (can_pf) { const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_prefetch(p, nxt, tid, kpad0, al16, pre); }
         }
         if (mi_n > 0) {
           const int ks_n = kcw_pad >> 6; const int ks0 = kc0 >> 6;
@@ -147,7 +214,7 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
             v4i afr[MI];
 #pragma unroll
             for (int m = 0; m < MI; ++m)
-              if (m < mi_n) afr[m] = *(const v4i*)(p.wpack + ((((int64_t)(ct0 + m) * p.KS + ks0 + ks) * 64 + lane) << 4));
+              if (m < mi_n) afr[m] = *(const v4i*)((RES ? wl : p.wpack) + ((((int64_t)(ct0 + m) * p.KS + ks0 + ks) * 64 + lane) << 4));
 #pragma unroll
             for (int m = 0; m < MI; ++m) {
               if (m < mi_n) {
@@ -213,8 +280,8 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
           }
           continue;
         }
-        const float4 A4 = *(const float4*)(p.coef + FROST_COEF_A * p.cpad + ch0);
-        const float4 B4 = *(const float4*)(p.coef + FROST_COEF_B * p.cpad + ch0);
+        const float4 A4 = *(const float4*)(coefp + FROST_COEF_A * p.cpad + ch0);
+        const float4 B4 = *(const float4*)(coefp + FROST_COEF_B * p.cpad + ch0);
         const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
         if (MODE == M_EMIT) {
           int8_t* base = p.y + p0 * p.cout;
@@ -236,14 +303,14 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
           continue;
         }
         // backward modes
-        const float4 M4 = *(const float4*)(p.coef + FROST_COEF_M * p.cpad + ch0);
-        const float4 R4 = *(const float4*)(p.coef + FROST_COEF_R * p.cpad + ch0);
+        const float4 M4 = *(const float4*)(coefp + FROST_COEF_M * p.cpad + ch0);
+        const float4 R4 = *(const float4*)(coefp + FROST_COEF_R * p.cpad + ch0);
         const float Mv[4] = {M4.x, M4.y, M4.z, M4.w}, Rv[4] = {R4.x, R4.y, R4.z, R4.w};
         float K1[4] = {0, 0, 0, 0}, S1[4] = {0, 0, 0, 0}, S2[4] = {0, 0, 0, 0};
         if (MODE == M_BDC) {
-          const float4 k4 = *(const float4*)(p.coef + FROST_COEF_K1 * p.cpad + ch0);
-          const float4 a4 = *(const float4*)(p.coef + FROST_COEF_S1 * p.cpad + ch0);
-          const float4 b4 = *(const float4*)(p.coef + FROST_COEF_S2 * p.cpad + ch0);
+          const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0);
+          const float4 a4 = *(const float4*)(coefp + FROST_COEF_S1 * p.cpad + ch0);
+          const float4 b4 = *(const float4*)(coefp + FROST_COEF_S2 * p.cpad + ch0);
           K1[0] = k4.x; K1[1] = k4.y; K1[2] = k4.z; K1[3] = k4.w;
           S1[0] = a4.x * p.inv_count; S1[1] = a4.y * p.inv_count; S1[2] = a4.z * p.inv_count; S1[3] = a4.w * p.inv_count;
           S2[0] = b4.x * p.inv_count; S2[1] = b4.y * p.inv_count; S2[2] = b4.z * p.inv_count; S2[3] = b4.w * p.inv_count;
@@ -339,21 +406,30 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   }
 }
 
+template <int MODE, int WP, bool RES>
+static int launch_pw2(PwP& p, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
+  int occ = 1;   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES>, 512, lds) != hipSuccess || occ < 1) occ = 1;
+  if (occ > 4) occ = 4;
+  int64_t grid = p.ntiles < 256 * occ ? p.ntiles : 256 * occ;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_pw<MODE, WP, RES>), dim3((unsigned)grid), dim3(512), lds, s, p);
+  return frost_check_launch("pw");
+}
 template <int MODE, int WP>
 static int launch_pw(PwP& p, hipStream_t s) {
   size_t lds = (size_t)BP * p.kstr + 64;
   if (MODE == M_STATS) lds += (size_t)p.cpad * 24;
   if (MODE == M_BRED) lds += (size_t)p.cpad * 8;
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
-  int occ = 1;   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP>, 512, lds) != hipSuccess || occ < 1) occ = 1;
-  if (occ > 4) occ = 4;
-  int64_t grid = p.ntiles < 256 * occ ? p.ntiles : 256 * occ;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_pw<MODE, WP>), dim3((unsigned)grid), dim3(512), lds, s, p);
-  return frost_check_launch("pw");
+  const size_t res_bytes = (size_t)(p.cpad >> 4) * p.KS * 1024 + (size_t)p.cpad * (FROST_COEF_ROWS + 1) * 4;
+  static const int res_on = getenv("FROST_PW_RES") ? atoi(getenv("FROST_PW_RES")) : 1;
+  // measured per (mode, wave split): resident mode pays where the epilogue is latency-chained and registers allow it
+  constexpr bool res_ok = (WP != 2) && ((MODE == M_BDC) || (MODE == M_DGRAD) || (MODE == M_EMIT && WP == 4) || (MODE == M_BRED && WP == 8));
+  if (res_ok && res_on && res_bytes <= 40 * 1024 && p.ntiles >= 2048) return launch_pw2<MODE, WP, true>(p, lds + res_bytes, s);
+  return launch_pw2<MODE, WP, false>(p, lds, s);
 }
 
 template <int MODE>
