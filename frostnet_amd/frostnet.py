@@ -211,8 +211,14 @@ class FrostNet(_FrostBase):
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
 
+    # Opt-in, OFF by default: let a NOT-yet-quantised (float) model run torch's stock eager modules on the GPU, i.e. exactly
+    # what the reference does for its StatAssist FP warm-up epoch.  This is NOT the native path (no HIP kernels of this
+    # repo run); the device-native float/bf16 graph is a listed gap.  Without the flag a float model on the
+    # GPU raises, so a benchmark can never silently measure torch eager.
+    allow_torch_eager_float = False
+
     def forward(self, x):
-        if x.is_cuda:
+        if x.is_cuda and not (self.allow_torch_eager_float and not self._is_qat_prepared()):
             return self.hip_runner().forward(x)
         if self.quantized:
             x = self.quant(x)

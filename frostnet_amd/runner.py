@@ -27,6 +27,26 @@ class _QATFunction(torch.autograd.Function):
         return None, None, None
 
 
+class _QATFeatFunction(torch.autograd.Function):
+    """image -> the four fake-quantised feature maps [x1, x2, x3, x5] (dequantised fp32 NCHW); DeQuantStub is identity."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, runner):
+        acts = runner._features_impl(x, record=True)
+        ctx.runner, ctx.acts = runner, acts
+        return tuple(a.dequant().contiguous() for a in acts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .engine import float_to_grad
+        for a, g in zip(ctx.acts, grads):     # tap gradients first; later layers' dgrads accumulate on top
+            if g is None:
+                g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
+            a.grad = float_to_grad(g)
+        ctx.runner._backward_impl(None)
+        return None, None, None
+
+
 def _is_fused_fq(fq):
     return type(fq).__name__ == "FusedMovingAvgObsFakeQuantize"
 
@@ -189,6 +209,24 @@ class FrostRunner:
             a = self.block_forward(d, a, training, obs)
             feats.append(a)
         return a, feats
+
+    def forward_features(self, x):
+        if self.model.training and torch.is_grad_enabled():
+            return list(_QATFeatFunction.apply(self._params[0], x, self))
+        acts = self._features_impl(x, record=False)
+        return [a.dequant().contiguous() for a in acts]
+
+    def _features_impl(self, x, record):
+        if x.dtype != torch.float32:
+            x = x.float()
+        _, feats = self._trunk(x, self.model.training)
+        ends, i = [], 0
+        for lname in ("layer1", "layer2", "layer3", "layer4", "layer5"):
+            i += len(getattr(self.model, lname))
+            ends.append(feats[i - 1])
+        if not record:
+            self.E.tape = []
+        return [ends[0], ends[1], ends[2], ends[4]]          # x4 is skipped (frostnet_features.py:350)
 
     def _forward_impl(self, x, record):
         training = self.model.training

@@ -184,3 +184,22 @@ def test_data_parallel_grad_sync_gloo_world2():
     for r in range(2):
         torch.testing.assert_close(T(res[r][1]), expect)          # every rank holds the mean of the per-shard gradients
     torch.testing.assert_close(T(res[0][2]), T(res[1][2]))           # broadcast made the replicas identical
+
+
+def test_features_backbone_cpu_matches_reference(built, golden):
+    """frostnet_features surface: keys, four maps [x1,x2,x3,x5], values vs the reference golden (G8)."""
+    from frostnet_amd import frostnet_features as FF
+    g = golden("g8_features")
+    B, res, seed, wseed = [int(v) for v in g["spec"]]
+    net = FF.FrostNet(mode="large", width_mult=1.0)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    spec = O.float_state_spec(O.net_cfg("large", 1.0), features=True)
+    net.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], wseed))
+    net.eval()
+    with torch.no_grad():
+        fs = net(T(O.synth((B, 3, res, res), seed)))
+    assert len(fs) == 4
+    for i, f in enumerate(fs):
+        assert list(f.shape) == g[f"f{i}_shape"].tolist()
+        np.testing.assert_allclose(f[0, :8, :4, :4].numpy(), g[f"f{i}_crop"], rtol=1e-4, atol=1e-5)
+    assert [f.shape[1] for f in fs] == [24, 40, 96, 320]

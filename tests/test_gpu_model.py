@@ -173,3 +173,31 @@ def test_train_step_large(fa, golden):
             opt.is_warmup = False
         opt.step()
         losses.append(float(loss))
+
+
+def test_features_backbone_qat_gpu_vs_oracle(fa):
+    """Config-5 backbone: quantised feature maps [x1,x2,x3,x5] from the HIP engine vs the oracle (train-mode forward, Small@64:
+    bit-identical sites upstream => feature maps equal up to isolated 1-step flips), plus a backward smoke through all four taps."""
+    from frostnet_amd import frostnet_features as FF
+    from frostnet_amd import frostnet as F
+    torch.set_num_threads(8)
+    mode, res = "small", 64
+    cfg = O.net_cfg(mode, 1.0)
+    spec = O.float_state_spec(cfg, features=True)
+    P, B = O.make_state(spec, 5000, True)
+    qs = O.QState(B)
+    x = T(O.synth((2, 3, res, res), 520))
+    with torch.no_grad():
+        ref = O.frostnet_forward(P, qs, cfg, x, True, True, features=True)
+    net = FF.FrostNet(mode=mode, width_mult=1.0, quantized=True)
+    net.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], 5000), strict=False)
+    F.qat_prepare(net, version=0)
+    net.cuda()
+    feats = net(x.cuda())
+    assert [tuple(f.shape) for f in feats] == [tuple(r.shape) for r in ref]
+    for i, (f, r) in enumerate(zip(feats, ref)):
+        assert relerr(f.detach().cpu(), r) <= 2e-2, (i, relerr(f.detach().cpu(), r))
+    loss = sum((f * f).mean() for f in feats)
+    loss.backward()
+    gn = [float(p.grad.norm()) for p in net.parameters()]
+    assert all(np.isfinite(gn)) and gn[0] > 0
