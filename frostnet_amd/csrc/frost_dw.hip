@@ -230,7 +230,7 @@ static void fill_dw(DwP& p, const int8_t* x, const float* qx, const int8_t* wq, 
   p.tiles_x = (p.wo + TW - 1) / TW; p.tiles_y = (p.ho + TH - 1) / TH; p.ncb = (c + CB - 1) / CB;
   p.ntiles = (int64_t)n * p.tiles_x * p.tiles_y; p.inv_count = 1.0f / (float)((int64_t)n * p.ho * p.wo);
 }
-extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n,
+extern "C" int frost_dw_conv_fwd_v2(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n,
                                  int h, int w, int c, int k, int stride, int mode, void* stats, const float* coef,
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
@@ -238,7 +238,7 @@ extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int
   p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y;
   return mode == 0 ? dispatch_dw<D_STATS>(p, k, stride, as_stream(stream)) : dispatch_dw<D_EMIT>(p, k, stride, as_stream(stream));
 }
-extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+extern "C" int frost_dw_conv_bwd_v2(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                                  const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
                                  const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
@@ -348,7 +348,7 @@ static int launch_dw_dgrad(const uint16_t* dc, const int8_t* wq, const float* qw
                      round_up(c, 16), ho, wo, dx, accumulate, ncb, ngroups, tiles_x, tiles_y);
   return frost_check_launch("dw_dgrad");
 }
-extern "C" int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c,
+extern "C" int frost_dw_dgrad_v2(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c,
                               int k, int stride, uint16_t* dx, int accumulate, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw_dgrad: channels must be a multiple of 8");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
@@ -438,7 +438,7 @@ static int launch_dw_wgrad(DwP& p, float* dwq, hipStream_t s) {
   return frost_check_launch("dw_wgrad");
 }
 static void fill_dw(DwP& p, const int8_t* x, const float* qx, const int8_t* wq, const int32_t* wsum, int n, int h, int w, int c, int k, int stride);
-extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
+extern "C" int frost_dw_wgrad_v2(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                               int stride, float* dwq, void* stream) {
   DwP p = {}; fill_dw(p, x, qrec_x, nullptr, nullptr, n, h, w, c, k, stride); p.dc = (uint16_t*)dc;
   hipStream_t s = as_stream(stream);
