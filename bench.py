@@ -48,6 +48,18 @@ def cpu_baseline(batch=8, res=224):
                        f"kernels via oracle/frost_oracle.py, {dt:.1f} s")
 
 
+def pmc_traffic(label, batch):
+    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r01_kernels_b<batch>.json, made by
+    tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same step, gfx950 correction applied).
+    Counters cannot be collected from inside this process, so the number is the committed one or null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_kernels_b{batch}.json")
+    try:
+        fam = json.load(open(path))["families"][label]
+        return int(fam["hbm_bytes_per_launch"]), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,8 +187,9 @@ def main():
         s2 = L.PROFILER.summary()[dom]
         L.PROFILER = None
         achieved = s2["bytes_per_launch"] / (s2["avg_ms"] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, args.batch if args.res == 224 and args.mode == "large" else -1)
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         avg_launch_ms=round(s2["avg_ms"], 4), launches_per_step=s2["launches"] // 3,
                         algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),
                         whole_step=dict(achieved=round(value / world * ALGO_BYTES_PER_IMG / 1e9, 1), unit="GB/s",

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run ON the GPU box (via gpurun) from the repo root.  Produces under gpurun_out/prof_<tag>/:
+#   stats/   rocprofv3 --kernel-trace --stats of the default bench command (hipGraph replay)
+#   fetch/   PMC pass 1: FETCH_SIZE   (eager step, one kernel-trace + one counter, nothing else)
+#   write/   PMC pass 2: WRITE_SIZE
+# and gpurun_out/prof_<tag>/summary.json (tools/summarize_profiles.py), which is what gets copied to profiles/.
+tag=${1:-r01}
+B=${2:-512}
+root=$(pwd)
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $root
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- \
+    python bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- \
+    python bench.py --batch $B --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- \
+    python bench.py --batch $B --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > $out/write.log 2>&1
+python tools/summarize_profiles.py $out $B > $out/summary.log 2>&1
+tail -3 $out/stats.log | cut -c1-400
+tail -30 $out/summary.log

@@ -1,0 +1,78 @@
+"""Fold the three rocprofv3 passes of tools/collect_profiles.sh into one JSON (profiles/<tag>_kernels.json).
+
+Per kernel family (the labels bench.py's roofline leg uses): launches per step, average launch duration from the
+--kernel-trace --stats pass, and HBM bytes per launch from the two PMC passes, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md (HBM) and cdna_hip_programming.md §7 prescribe for gfx950:
+    hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024        (FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE counts a 128-B
+                                                              streaming request as 64 B, WRITE_SIZE is taken as is)
+usage: python tools/summarize_profiles.py gpurun_out/prof_r01 512
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- kernel-name regex
+    ("pw_fwd_stats", r"k_pw<0,"), ("pw_fwd_emit", r"k_pw<1,"), ("pw_bwd_reduce", r"k_pw<2,"),
+    ("pw_bwd_dc", r"k_pw<3,"), ("pw_dgrad", r"k_pw<4,"), ("pw_wgrad", r"k_pw_wgrad"),
+    ("dw_fwd_stats", r"k_dw3<\d, \d, 0>"), ("dw_fwd_emit", r"k_dw3<\d, \d, 1>"),
+    ("dw_bwd_reduce", r"k_dw3<\d, \d, 2>"), ("dw_bwd_dc", r"k_dw3<\d, \d, 3>"),
+    ("dw_wgrad", r"k_dw3_wgrad"), ("dw_dgrad", r"k_dw3_dgrad"),
+    ("conv_finalize", r"k_conv_finalize"), ("wgrad_finalize", r"k_wgrad_finalize"),
+    ("cat_fwd", r"k_cat_requant"), ("cat_bwd", r"k_cat_bwd"), ("add_fwd_minmax", r"k_add_minmax"),
+    ("add_fwd_emit", r"k_add_requant"), ("add_bwd", r"k_add_bwd"), ("stem_im2col", r"k_stem_im2col"),
+    ("gradboost", r"k_gradboost"), ("weight_prep", r"k_wprep"),
+]
+
+
+def family(name):
+    for lab, rx in FAMILIES:
+        if re.search(rx, name):
+            return lab
+    return None
+
+
+def main():
+    root, batch = sys.argv[1], int(sys.argv[2])
+    out = collections.defaultdict(dict)
+    f = glob.glob(f"{root}/stats/**/*kernel_stats.csv", recursive=True)
+    total_ns = 0.0
+    if f:
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        other = [0, 0.0]
+        for r in csv.DictReader(open(f[0])):
+            lab = family(r["Name"])
+            tgt = agg[lab] if lab else other
+            tgt[0] += int(r["Calls"]); tgt[1] += float(r["TotalDurationNs"])
+            total_ns += float(r["TotalDurationNs"])
+        for lab, (calls, ns) in agg.items():
+            out[lab].update(calls=calls, avg_launch_us=round(ns / calls / 1e3, 2), total_ms=round(ns / 1e6, 3))
+        out["_other"] = dict(calls=other[0], total_ms=round(other[1] / 1e6, 3))
+    for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True)
+        if not f:
+            continue
+        per = collections.defaultdict(lambda: [set(), 0.0])
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] != ctr:
+                continue
+            lab = family(r["Kernel_Name"])
+            if lab:
+                per[lab][0].add(r["Dispatch_Id"]); per[lab][1] += float(r["Counter_Value"])
+        for lab, (ids, kib) in per.items():
+            out[lab][f"{ctr}_KiB_per_launch"] = round(kib / len(ids), 1)
+            out[lab][f"{ctr}_launches"] = len(ids)
+    for lab, d in out.items():
+        if "FETCH_SIZE_KiB_per_launch" in d and "WRITE_SIZE_KiB_per_launch" in d:
+            d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024)
+    doc = dict(batch=batch, correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950; separate --pmc passes, eager step)",
+               stats_total_ms=round(total_ns / 1e6, 3), families=out)
+    json.dump(doc, open(f"{root}/summary.json", "w"), indent=1, sort_keys=True)
+    for lab, d in sorted(out.items(), key=lambda kv: -kv[1].get("total_ms", 0)):
+        print(f"{lab:16s} {d}")
+
+
+if __name__ == "__main__":
+    main()
