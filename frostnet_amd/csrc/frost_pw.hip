@@ -19,6 +19,7 @@
 // The zero-point correction -zp'*sum_k(wq) is folded into the accumulator initial value (free).
 #include "frost_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
@@ -33,6 +34,8 @@ struct PwP {
   uint8_t* stats; int relu;
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
   int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
+  int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
+  int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
 };
 
 #define BP 128
@@ -49,45 +52,62 @@ __device__ __forceinline__ float row_sum_f(float v) {
 
 __device__ __forceinline__ uint32_t pack_bf2(float a, float b) { return cvt_pk_bf16(a, b); }
 
-// Next-tile register prefetch (<= 20 VGPRs) for single-chunk rows of <= 320 B.  `tid` is made opaque so LICM does not
-// hoist a dozen per-unit 64-bit addresses out of the persistent tile loop (that spilled every variant).
-__device__ __forceinline__ void pw_prefetch(const PwP& p, int64_t tile, int tid, int kpad0, bool al16, uint4 (&pre)[5]) {
-  asm volatile("" : "+v"(tid));
-  const int64_t q0 = tile * BP; const uint8_t* src = p.T + q0 * p.rowbytes;
-  if (al16) {
-    const int U = kpad0 >> 4; const int total = BP * U;
-#pragma unroll
-    for (int jn = 0; jn < 5; ++jn) {
-      const int u = tid + jn * 512; const int row = u / U; const int col = (u - row * U) << 4;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v = *(const uint4*)(src + row * p.rowbytes + col);
-      pre[jn] = v;
-    }
+// Direct-to-LDS staging of one 128-pixel tile (gl mode).  A tile is 128*rowbytes CONTIGUOUS bytes of the pixel-major
+// tensor (always a multiple of 1 KiB), so its LDS image is a linear copy: every wave-level global_load_lds_dwordx4 moves one
+// 1 KiB unit (M0 = wave-uniform LDS base, + lane*16) and costs one VALU op -- no staging registers, no index arithmetic, and
+// the copy of tile t+1 runs under the work of tile t (two LDS buffers).  The DMA is issued from inline asm on purpose: when
+// the compiler sees an LDS-DMA in flight it puts s_waitcnt vmcnt(0) in front of EVERY later LDS read (it cannot disprove
+// aliasing), which also drains the epilogue's stores once per channel tile.  Ordering is therefore explicit: vmcnt retires
+// in issue order, so `s_waitcnt vmcnt(N)` with N <= (VMEM instructions this wave issued after its DMA) guarantees the DMA
+// has landed while leaving the younger stores in flight; pw_wait_barrier() does that wait and the workgroup barrier.
+// Only the last, partial tile of a tensor takes the bounds-checked register path (zero fill).
+__device__ __forceinline__ void pw_glds16(const uint8_t* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void pw_stage_linear(const PwP& p, int64_t tile, uint8_t* dst, int tid) {
+  const int64_t p0 = tile * BP;
+  const uint8_t* src = p.T + p0 * p.rowbytes;
+  if ((p0 + BP) <= p.npix) {
+    const int lane = tid & 63; const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nunits = p.tile_bytes >> 10;
+    const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)dst);
+    for (int u = w; u < nunits; u += 8) pw_glds16(src + u * 1024 + lane * 16, lbase + u * 1024);
   } else {
-    const int U = kpad0 >> 3; const int total = BP * U;
-#pragma unroll
-    for (int jh = 0; jh < 5; ++jh) {
-      uint2 v0 = make_uint2(0, 0), v1 = make_uint2(0, 0);
-      { const int u = tid + (2 * jh) * 512; const int row = u / U; const int col = (u - row * U) << 3;
-        if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v0 = *(const uint2*)(src + row * p.rowbytes + col); }
-      { const int u = tid + (2 * jh + 1) * 512; const int row = u / U; const int col = (u - row * U) << 3;
-        if (u < total && (q0 + row) < p.npix && col < p.rowbytes) v1 = *(const uint2*)(src + row * p.rowbytes + col); }
-      pre[jh] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+    const int valid = (int)(p.npix - p0) * p.rowbytes;
+    for (int o = tid * 8; o < p.tile_bytes; o += 512 * 8) {
+      uint2 v = make_uint2(0, 0);
+      if (o < valid) v = *(const uint2*)(src + o);
+      *(uint2*)(dst + o) = v;
     }
+  }
+}
+#define PW_WB_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+__device__ __forceinline__ void pw_wait_barrier(int n_younger) {      // n_younger: wave-uniform lower bound, see above
+  switch (n_younger) {
+    PW_WB_CASE(1) PW_WB_CASE(2) PW_WB_CASE(3) PW_WB_CASE(4) PW_WB_CASE(5) PW_WB_CASE(6) PW_WB_CASE(7) PW_WB_CASE(8)
+    PW_WB_CASE(9) PW_WB_CASE(10) PW_WB_CASE(11) PW_WB_CASE(12) PW_WB_CASE(13) PW_WB_CASE(14) PW_WB_CASE(15) PW_WB_CASE(16)
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
   }
 }
 
 // RES = "resident" mode for small layers: the packed weights, wsum and the BN/quant coefficient rows are copied into LDS
 // once per workgroup, so the persistent tile loop touches global memory only for the activation stream itself (no
 // per-tile L2 round trips on the critical path), and the next tile is register-prefetched.
-template <int MODE, int WP, bool RES>
-__global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
+// waves per SIMD the register allocator must leave room for (measured: 2 -> no spills anywhere but half the residency: slower)
+#ifndef PW_MINW
+#define PW_MINW(MODE, WP) 4
+#endif
+template <int MODE, int WP, bool RES, bool FULLT>
+__global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
   constexpr bool BF = (MODE == M_DGRAD);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const bool gl = p.gl != 0;
   uint8_t* xs = smem;
-  const int xs_bytes = BP * p.kstr + 64;
+  const int xs_bytes = gl ? 2 * p.tile_bytes + 64 : BP * p.kstr + 64;
   long long* l_s1 = (long long*)(smem + xs_bytes);
   unsigned long long* l_s2 = (unsigned long long*)(l_s1 + p.cpad);
   int* l_mn = (int*)(l_s2 + p.cpad);
@@ -115,7 +135,17 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   }
   if (RES) {
     for (int i = tid; i < (wl_bytes >> 4); i += 512) ((uint4*)wl)[i] = ((const uint4*)p.wpack)[i];
-    if (MODE != M_STATS && MODE != M_DGRAD) for (int i = tid; i < FROST_COEF_ROWS * p.cpad; i += 512) ((float*)cl)[i] = p.coef[i];
+    if (MODE == M_EMIT) for (int i = tid; i < 2 * p.cpad; i += 512) ((float*)cl)[i] = p.coef[i];        // rows A, B
+    if (MODE == M_BRED || MODE == M_BDC) {     // folded rows (see the backward epilogue): M row <- -M*R, S1 row <- E, S2 row <- F
+      float* c2 = (float*)cl;
+      for (int c = tid; c < p.cpad; c += 512) {
+        const float Mv = p.coef[FROST_COEF_M * p.cpad + c], Rv = p.coef[FROST_COEF_R * p.cpad + c], Kv = p.coef[FROST_COEF_K1 * p.cpad + c];
+        const float Ev = -Kv * (p.coef[FROST_COEF_S2 * p.cpad + c] * p.inv_count) * Rv;
+        c2[FROST_COEF_A * p.cpad + c] = p.coef[FROST_COEF_A * p.cpad + c]; c2[FROST_COEF_B * p.cpad + c] = p.coef[FROST_COEF_B * p.cpad + c];
+        c2[FROST_COEF_M * p.cpad + c] = -Mv * Rv; c2[FROST_COEF_R * p.cpad + c] = Rv; c2[FROST_COEF_K1 * p.cpad + c] = Kv;
+        c2[FROST_COEF_S1 * p.cpad + c] = Ev; c2[FROST_COEF_S2 * p.cpad + c] = -Kv * (p.coef[FROST_COEF_S1 * p.cpad + c] * p.inv_count) - Ev * Mv;
+      }
+    }
     if (MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
   }
   if (RES) __syncthreads();
@@ -124,28 +154,52 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD) sw = p.qw[FROST_Q_SCALE];
   if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]); }
+  float t_lo = 0.0f, t_hi = 0.0f;            // STE pass window in t = y/scale:  t_lo < t <= t_hi
+  if (MODE == M_BRED || MODE == M_BDC) {
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]);
+    const float hi0 = 255.5f - (float)zpy;                                        // rint(hi0) ties to the even neighbour
+    t_hi = ((255 - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
 
   // lane-local accumulators that live across the persistent tile loop (single channel group only)
   // BRED with WP==2 already holds 64 accumulator registers: deferring would spill (measured 2x slower)
-  const bool defer = (p.ngroups == 1) && !(MODE == M_BRED && WP == 2);
-  long long st1[MI]; long long st2[MI]; int smn[MI], smx[MI];       // STATS: lane's channel = ct*16 + j
+  const bool defer = (WP != 2) && (p.ngroups == 1);      // WP == 2 holds 64 accumulator registers already: deferring would spill
+  long long st1[MI]; double st2[MI]; int smn[MI], smx[MI];       // STATS: lane's channel = ct*16 + j
   float br1[MI][4], br2[MI][4];                                     // BRED: lane's channels = ct*16 + 4g + r
 #pragma unroll
   for (int m = 0; m < MI; ++m) {
-    st1[m] = 0; st2[m] = 0; smn[m] = INT32_MAX; smx[m] = INT32_MIN;
+    st1[m] = 0; st2[m] = 0.0; smn[m] = INT32_MAX; smx[m] = INT32_MIN;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { br1[m][r] = 0.0f; br2[m][r] = 0.0f; }
   }
 
-  const int kpad0 = (p.rowbytes + 63) & ~63;
-  const bool can_pf = RES && (p.nchunks == 1) && (kpad0 <= 320);
-  const bool al16 = (p.rowbytes & 15) == 0;
-  uint4 pre[5];
-  if (can_pf && (int64_t)blockIdx.x < p.ntiles) pw_prefetch(p, (int64_t)blockIdx.x, tid, kpad0, al16, pre);
+  const bool al16 = (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
+  int buf = 0; bool full_prev = false;
+  int n_younger = 0;     // VMEM instructions this wave is certain to issue after its DMA within one tile (last channel group)
+  if (gl && !p.dbg && MODE != M_STATS) {
+    const int ct0l = ((p.ngroups - 1) * WC + wc) * p.mi_eff;
+    int nfull = 0;
+    for (int m = 0; m < p.mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
+    const int per = (MODE == M_BDC) ? 2 : ((MODE == M_DGRAD && p.accumulate) ? 2 : 1);
+    n_younger = nfull * NT * per; if (n_younger > 16) n_younger = 16;
+  }
+  if (gl) {
+    // K padding reads past a row's end (next row / next buffer / the 64-byte tail): harmless for int8 (zero weights), but a
+    // bf16 NaN pattern times zero is NaN, so the dgrad buffers start out zeroed
+    if (BF) { for (int i = tid; i < (xs_bytes >> 4); i += 512) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0); __syncthreads(); }
+    if (p.tile0 + (int64_t)blockIdx.x < p.ntiles) pw_stage_linear(p, p.tile0 + (int64_t)blockIdx.x, smem, tid);
+  }
 
-  for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  for (int64_t tile = p.tile0 + blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * BP;
-    const bool full = (p0 + BP) <= p.npix;
+    const bool full = FULLT;
+    if (gl) {
+      pw_wait_barrier(full_prev ? n_younger : 0);   // tile t has landed (each wave retired its own DMA); buffer buf^1 is free
+      xs = smem + buf * p.tile_bytes;
+      if (RES) { const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid); }
+      full_prev = full;
+    }
     for (int cg = 0; cg < p.ngroups; ++cg) {
       const int ct0 = (cg * WC + wc) * p.mi_eff;
       int mi_n = CT - ct0; mi_n = mi_n < 0 ? 0 : (mi_n > p.mi_eff ? p.mi_eff : mi_n);
@@ -165,26 +219,10 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
         const int kc0 = ch * p.kc_bytes;
         int kcw = p.rowbytes - kc0; if (kcw > p.kc_bytes) kcw = p.kc_bytes;
         const int kcw_pad = (kcw + 63) & ~63;
-        if (p.nchunks > 1 || cg == 0) {
+        if (!gl && (p.nchunks > 1 || cg == 0)) {
           __syncthreads();
           const uint8_t* src = p.T + p0 * p.rowbytes + kc0;
-          if (can_pf) {
-            int t2 = threadIdx.x; asm volatile("" : "+v"(t2));
-            if (al16) {
-              const int U = kpad0 >> 4; const int total = BP * U;
-#pragma unroll
-              for (int jn = 0; jn < 5; ++jn) { const int u = t2 + jn * 512; const int row = u / U; const int col = (u - row * U) << 4; if (u < total) *(uint4*)(xs + row * p.kstr + col) = pre[jn]; }
-            } else {
-              const int U = kpad0 >> 3; const int total = BP * U;
-#pragma unroll
-              for (int jh = 0; jh < 5; ++jh) {
-                { const int u = t2 + (2 * jh) * 512; const int row = u / U; const int col = (u - row * U) << 3;
-                  if (u < total) *(uint2*)(xs + row * p.kstr + col) = make_uint2(pre[jh].x, pre[jh].y); }
-                { const int u = t2 + (2 * jh + 1) * 512; const int row = u / U; const int col = (u - row * U) << 3;
-                  if (u < total) *(uint2*)(xs + row * p.kstr + col) = make_uint2(pre[jh].z, pre[jh].w); }
-              }
-            }
-          } else if (((p.rowbytes | kc0) & 15) == 0) {
+          if (((p.rowbytes | kc0) & 15) == 0) {
             const int U = kcw_pad >> 4; const int total = BP * U;
             for (int u = tid; u < total; u += 512) {
               const int row = u / U; const int col = (u - row * U) << 4;
@@ -202,15 +240,17 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
             }
           }
           __syncthreads();
-          if (can_pf) { const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_prefetch(p, nxt, tid, kpad0, al16, pre); }
         }
         if (mi_n > 0) {
           const int ks_n = kcw_pad >> 6; const int ks0 = kc0 >> 6;
           for (int ks = 0; ks < ks_n; ++ks) {
             v4i bfr[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-              bfr[t] = *(const v4i*)(xs + ((wp * NT + t) * 16 + j) * p.kstr + ks * 64 + g * 16);
+            for (int t = 0; t < NT; ++t) {
+              const uint8_t* fp = xs + ((wp * NT + t) * 16 + j) * p.kstr + ks * 64 + g * 16;
+              if (al16) bfr[t] = *(const v4i*)fp;
+              else { const int2 lo = *(const int2*)fp, hi = *(const int2*)(fp + 8); bfr[t] = (v4i){lo.x, lo.y, hi.x, hi.y}; }
+            }
             v4i afr[MI];
 #pragma unroll
             for (int m = 0; m < MI; ++m)
@@ -230,134 +270,159 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
         }
       }
 
+      if (gl && !RES && cg == p.ngroups - 1) {   // non-resident weights are global loads younger than the DMA would be: issue it after them
+        const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
+      }
       // ------------------------------------------------------------------------------- epilogue
-      if (MODE == M_STATS) {
-        // lane: channel ct*16+j; register r of tile t: pixel p0 + (wp*NT+t)*16 + 4g + r
+      // FULL tiles (all but the last tile of a tensor; their own kernel instance) carry no per-pixel validity logic at all.
+      auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if (MODE == M_STATS) {
+          // lane: channel ct*16+j; register r of tile t: pixel p0 + (wp*NT+t)*16 + 4g + r.  Per element: one int add (sum),
+          // cvt + fma (sum of squares, fp32 within the tile -> double across tiles), half a min3 and half a max3.
+#pragma unroll
+          for (int m = 0; m < MI; ++m) {
+            if (m >= mi_n) continue;
+            int a1 = 0; float a2 = 0.0f; int mn = INT32_MAX, mx = INT32_MIN;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              if (FULL) {
+                const int v0 = acci[m][t][0], v1 = acci[m][t][1], v2 = acci[m][t][2], v3 = acci[m][t][3];
+                a1 += (v0 + v1) + (v2 + v3);
+                const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2, f3 = (float)v3;
+                a2 = fmaf(f0, f0, a2); a2 = fmaf(f1, f1, a2); a2 = fmaf(f2, f2, a2); a2 = fmaf(f3, f3, a2);
+                mn = min(mn, min(v0, v1)); mn = min(mn, min(v2, v3)); mx = max(mx, max(v0, v1)); mx = max(mx, max(v2, v3));
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int v = acci[m][t][r];
+                  if ((p0 + (wp * NT + t) * 16 + 4 * g + r) < p.npix) { a1 += v; const float fv = (float)v; a2 = fmaf(fv, fv, a2); mn = min(mn, v); mx = max(mx, v); }
+                }
+              }
+            }
+            if (defer) { st1[m] += a1; st2[m] += (double)a2; smn[m] = min(smn[m], mn); smx[m] = max(smx[m], mx); }
+            else {
+              long long b1 = a1; double b2 = (double)a2;
+              b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32); b2 += __shfl_xor(b2, 16); b2 += __shfl_xor(b2, 32);
+              mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+              const int chn = (ct0 + m) * 16 + j;
+              if (g == 0 && chn < p.cout && mn <= mx) {
+                atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)b1); atomicAdd(&l_s2[chn], (unsigned long long)__double2ll_rn(b2));
+                atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
+              }
+            }
+          }
+          return;
+        }
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
           if (m >= mi_n) continue;
-          long long a1 = 0; long long a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
+          const int ch0 = (ct0 + m) * 16 + 4 * g;          // 4 consecutive channels of this lane
+          const bool chok = ch0 < p.cout;
+          if (MODE == M_DGRAD) {
+            uint16_t* base = p.dx + p0 * p.cout;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
+              const int prow = (wp * NT + t) * 16 + j;
+              if ((FULL || (p0 + prow) < p.npix) && chok) {
+                uint16_t* dst = base + prow * p.cout + ch0;
+                float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int v = acci[m][t][r];
-              if (full || (p0 + (wp * NT + t) * 16 + 4 * g + r) < p.npix) { a1 += v; a2 += (long long)v * v; mn = min(mn, v); mx = max(mx, v); }
+                for (int r = 0; r < 4; ++r) v[r] = accf[m][t][r] * sw;
+                if (p.accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
+                uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)dst = o;
+              }
             }
+            continue;
           }
-          if (defer) { st1[m] += a1; st2[m] += a2; smn[m] = min(smn[m], mn); smx[m] = max(smx[m], mx); }
-          else {
-            a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
-            mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
-            const int chn = (ct0 + m) * 16 + j;
-            if (g == 0 && chn < p.cout) {
-              atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)a2);
-              atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
+          const float4 A4 = *(const float4*)(coefp + FROST_COEF_A * p.cpad + ch0);
+          const float4 B4 = *(const float4*)(coefp + FROST_COEF_B * p.cpad + ch0);
+          const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
+          if (MODE == M_EMIT) {
+            int8_t* base = p.y + p0 * p.cout;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              const int prow = (wp * NT + t) * 16 + j;
+              uint32_t packed = 0;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
+                // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
+                const float yv = fmaf(A[r], (float)acci[m][t][r], B[r]);
+                packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
+              }
+              if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
             }
+            continue;
           }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int m = 0; m < MI; ++m) {
-        if (m >= mi_n) continue;
-        const int ch0 = (ct0 + m) * 16 + 4 * g;          // 4 consecutive channels of this lane
-        const bool chok = ch0 < p.cout;
-        if (MODE == M_DGRAD) {
-          uint16_t* base = p.dx + p0 * p.cout;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int prow = (wp * NT + t) * 16 + j;
-            if ((full || (p0 + prow) < p.npix) && chok) {
-              uint16_t* dst = base + prow * p.cout + ch0;
-              float v[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = accf[m][t][r] * sw;
-              if (p.accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
-              uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-              *(uint2*)dst = o;
+          // backward modes.  Folded per-channel coefficients (resident mode keeps them folded in LDS):
+          //   xhat = fma(acc, R, MR)                      MR = -M*R
+          //   dc   = fma(gy, K1, fma(acc, E, F))          E = -K1*(S2/n)*R,  F = -K1*(S1/n) - E*M
+          // STE mask in the t = y/scale domain: pass <=> t_lo < t <= t_hi (thresholds derived from the zero point so that the
+          // test equals 0 <= rint(relu(y)/scale)+zp <= 255 and y > relu floor exactly, ties-to-even included).
+          float R[4], MR[4], K1[4] = {0, 0, 0, 0}, E[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};
+          if (RES) {
+            const float4 r4 = *(const float4*)(coefp + FROST_COEF_R * p.cpad + ch0), m4 = *(const float4*)(coefp + FROST_COEF_M * p.cpad + ch0);
+            R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w; MR[0] = m4.x; MR[1] = m4.y; MR[2] = m4.z; MR[3] = m4.w;
+            if (MODE == M_BDC) {
+              const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0), e4 = *(const float4*)(coefp + FROST_COEF_S1 * p.cpad + ch0), f4 = *(const float4*)(coefp + FROST_COEF_S2 * p.cpad + ch0);
+              K1[0] = k4.x; K1[1] = k4.y; K1[2] = k4.z; K1[3] = k4.w; E[0] = e4.x; E[1] = e4.y; E[2] = e4.z; E[3] = e4.w; F[0] = f4.x; F[1] = f4.y; F[2] = f4.z; F[3] = f4.w;
             }
-          }
-          continue;
-        }
-        const float4 A4 = *(const float4*)(coefp + FROST_COEF_A * p.cpad + ch0);
-        const float4 B4 = *(const float4*)(coefp + FROST_COEF_B * p.cpad + ch0);
-        const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
-        if (MODE == M_EMIT) {
-          int8_t* base = p.y + p0 * p.cout;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int prow = (wp * NT + t) * 16 + j;
-            uint32_t packed = 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
-              // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
-              const float yv = fmaf(A[r], (float)acci[m][t][r], B[r]);
-              packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
-            }
-            if (p.dbg & 1) { asm volatile("" :: "v"(packed)); }
-            else if (p.dbg & 4) { *(uint32_t*)(base + ((((cg * 8 + w) * MI + m) * NT + t) * 64 + lane) * 4) = packed; }
-            else if ((full || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
-          }
-          continue;
-        }
-        // backward modes
-        const float4 M4 = *(const float4*)(coefp + FROST_COEF_M * p.cpad + ch0);
-        const float4 R4 = *(const float4*)(coefp + FROST_COEF_R * p.cpad + ch0);
-        const float Mv[4] = {M4.x, M4.y, M4.z, M4.w}, Rv[4] = {R4.x, R4.y, R4.z, R4.w};
-        float K1[4] = {0, 0, 0, 0}, S1[4] = {0, 0, 0, 0}, S2[4] = {0, 0, 0, 0};
-        if (MODE == M_BDC) {
-          const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0);
-          const float4 a4 = *(const float4*)(coefp + FROST_COEF_S1 * p.cpad + ch0);
-          const float4 b4 = *(const float4*)(coefp + FROST_COEF_S2 * p.cpad + ch0);
-          K1[0] = k4.x; K1[1] = k4.y; K1[2] = k4.z; K1[3] = k4.w;
-          S1[0] = a4.x * p.inv_count; S1[1] = a4.y * p.inv_count; S1[2] = a4.z * p.inv_count; S1[3] = a4.w * p.inv_count;
-          S2[0] = b4.x * p.inv_count; S2[1] = b4.y * p.inv_count; S2[2] = b4.z * p.inv_count; S2[3] = b4.w * p.inv_count;
-        }
-        const uint16_t* gbase = p.gout + p0 * p.cout;
-        uint16_t* dbase = p.dc + p0 * p.cout;
-        const float relu_floor = p.relu ? 0.0f : -INFINITY;
-        float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int prow = (wp * NT + t) * 16 + j;
-          const bool valid = (full || (p0 + prow) < p.npix) && chok;
-          uint2 gv = make_uint2(0, 0);
-          if (valid) gv = *(const uint2*)(gbase + prow * p.cout + ch0);
-          const float gq[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
-          float dcv[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float af = (float)acci[m][t][r];
-            const float yv = fmaf(A[r], af, B[r]);
-            // STE masks: ReLU alive (y > 0) and fake-quant in range: 0 <= rint(relu(y)*inv)+zp <= 255
-            const float qf = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
-            const bool pass = (yv > relu_floor) && qf >= 0.0f && qf <= 255.0f;
-            const float gy = pass ? gq[r] : 0.0f;
-            const float xhat = (af - Mv[r]) * Rv[r];
-            if (MODE == M_BRED) { r1[r] += gy; r2[r] += gy * xhat; }
-            else dcv[r] = K1[r] * (gy - S1[r] - xhat * S2[r]);
-          }
-          if (MODE == M_BDC && valid) {
-            uint2 o; o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]);
-            *(uint2*)(dbase + prow * p.cout + ch0) = o;
-          }
-        }
-        if (MODE == M_BRED) {
-          if (defer) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { br1[m][r] += r1[r]; br2[m][r] += r2[r]; }
           } else {
+            const float4 m4 = *(const float4*)(coefp + FROST_COEF_M * p.cpad + ch0), r4 = *(const float4*)(coefp + FROST_COEF_R * p.cpad + ch0);
+            const float Mv[4] = {m4.x, m4.y, m4.z, m4.w};
+            R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) MR[r] = -Mv[r] * R[r];
+            if (MODE == M_BDC) {
+              const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0), a4 = *(const float4*)(coefp + FROST_COEF_S1 * p.cpad + ch0), b4 = *(const float4*)(coefp + FROST_COEF_S2 * p.cpad + ch0);
+              const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, s1[4] = {a4.x, a4.y, a4.z, a4.w}, s2[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { K1[r] = kk[r]; E[r] = -kk[r] * (s2[r] * p.inv_count) * R[r]; F[r] = -kk[r] * (s1[r] * p.inv_count) - E[r] * Mv[r]; }
+            }
+          }
+          const uint16_t* gbase = p.gout + p0 * p.cout;
+          uint16_t* dbase = p.dc + p0 * p.cout;
+          float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int prow = (wp * NT + t) * 16 + j;
+            const bool valid = (FULL || (p0 + prow) < p.npix) && chok;
+            uint2 gv = make_uint2(0, 0);
+            if (valid) gv = *(const uint2*)(gbase + prow * p.cout + ch0);
+            const float gq[4] = {__uint_as_float(gv.x << 16), __uint_as_float(gv.x & 0xffff0000u), __uint_as_float(gv.y << 16), __uint_as_float(gv.y & 0xffff0000u)};
+            float dcv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float a = row_sum_f(r1[r]), b = row_sum_f(r2[r]);
-              if (j == 15 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+              const float af = (float)acci[m][t][r];
+              const float tq = fmaf(A[r], af, B[r]) * y_inv;
+              const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+              if (MODE == M_BRED) { r1[r] += gy; r2[r] = fmaf(gy, fmaf(af, R[r], MR[r]), r2[r]); }
+              else dcv[r] = fmaf(gy, K1[r], fmaf(af, E[r], F[r]));
+            }
+            if (MODE == M_BDC && valid) {
+              uint2 o; o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]);
+              *(uint2*)(dbase + prow * p.cout + ch0) = o;
+            }
+          }
+          if (MODE == M_BRED) {
+            if (defer) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { br1[m][r] += r1[r]; br2[m][r] += r2[r]; }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float a = row_sum_f(r1[r]), b = row_sum_f(r2[r]);
+                if (j == 15 && chok) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+              }
             }
           }
         }
-      }
+      };
+      epilogue(std::integral_constant<bool, FULLT>{});
     }
+    buf ^= 1;
   }
 
   if (MODE == M_STATS) {
@@ -366,11 +431,11 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         const int chn = (ct0 + m) * 16 + j;
-        long long a1 = st1[m], a2 = st2[m]; int mn = smn[m], mx = smx[m];
+        long long a1 = st1[m]; double a2 = st2[m]; int mn = smn[m], mx = smx[m];
         a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
         mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
         if (m < p.mi_eff && g == 0 && chn < p.cout && mn <= mx) {
-          atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)a2);
+          atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)__double2ll_rn(a2));
           atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
         }
       }
@@ -406,30 +471,41 @@ __global__ __launch_bounds__(512, 4) void k_pw(const PwP p) {
   }
 }
 
-template <int MODE, int WP, bool RES>
-static int launch_pw2(PwP& p, size_t lds, hipStream_t s) {
+template <int MODE, int WP, bool RES, bool FULLT>
+static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipStream_t s) {
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
-  int occ = 1;   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES>, 512, lds) != hipSuccess || occ < 1) occ = 1;
-  if (occ > 4) occ = 4;
-  int64_t grid = p.ntiles < 256 * occ ? p.ntiles : 256 * occ;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_pw<MODE, WP, RES>), dim3((unsigned)grid), dim3(512), lds, s, p);
+  static int occ_cache = 0; static size_t occ_lds = (size_t)-1;
+  if (occ_lds != lds) {   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
+    int occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT>, 512, lds) != hipSuccess || occ < 1) occ = 1;
+    occ_cache = occ > 4 ? 4 : occ; occ_lds = lds;
+  }
+  PwP q = p; q.tile0 = tile0; q.ntiles = tile_end;
+  const int64_t n = tile_end - tile0;
+  int64_t grid = n < 256 * occ_cache ? n : 256 * occ_cache;
+  if (grid < 1) return 0;
+  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT>), dim3((unsigned)grid), dim3(512), lds, s, q);
   return frost_check_launch("pw");
 }
 template <int MODE, int WP>
 static int launch_pw(PwP& p, hipStream_t s) {
-  size_t lds = (size_t)BP * p.kstr + 64;
+  size_t lds = p.gl ? (size_t)2 * p.tile_bytes + 64 : (size_t)BP * p.kstr + 64;
   if (MODE == M_STATS) lds += (size_t)p.cpad * 24;
   if (MODE == M_BRED) lds += (size_t)p.cpad * 8;
   const size_t res_bytes = (size_t)(p.cpad >> 4) * p.KS * 1024 + (size_t)p.cpad * (FROST_COEF_ROWS + 1) * 4;
   static const int res_on = getenv("FROST_PW_RES") ? atoi(getenv("FROST_PW_RES")) : 1;
   // measured per (mode, wave split): resident mode pays where the epilogue is latency-chained and registers allow it
   constexpr bool res_ok = (WP != 2) && ((MODE == M_BDC) || (MODE == M_DGRAD) || (MODE == M_EMIT && WP == 4) || (MODE == M_BRED && WP == 8));
-  if (res_ok && res_on && res_bytes <= 40 * 1024 && p.ntiles >= 2048) return launch_pw2<MODE, WP, true>(p, lds + res_bytes, s);
-  return launch_pw2<MODE, WP, false>(p, lds, s);
+  const int64_t nfull = p.npix / BP;           // full tiles: validity-free kernel instance; the ragged tail: one extra tiny launch
+  int rc = 0;
+  if (nfull > 0) {
+    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds + res_bytes <= 80 * 1024 && nfull >= 2048) rc = launch_pw3<MODE, WP, true, true>(p, lds + res_bytes, 0, nfull, s);
+    else rc = launch_pw3<MODE, WP, false, true>(p, lds, 0, nfull, s);
+  }
+  if (rc == 0 && nfull < p.ntiles) rc = launch_pw3<MODE, WP, false, false>(p, lds, nfull, p.ntiles, s);
+  return rc;
 }
 
 template <int MODE>
@@ -452,6 +528,9 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
   else { p.kc_bytes = 512; p.nchunks = (rowbytes + 511) / 512; }
   int kpad = ((p.kc_bytes + 63) / 64) * 64;
   p.kstr = kpad + 16;
+  static const int gl_on = getenv("FROST_PW_GL") ? atoi(getenv("FROST_PW_GL")) : 1;
+  p.gl = 0; p.tile_bytes = BP * rowbytes;
+  if (gl_on && p.nchunks == 1 && p.tile_bytes <= 32 * 1024 && (rowbytes & 7) == 0) { p.gl = 1; p.kstr = rowbytes; }
   p.inv_count = 1.0f / (float)npix;
   const char* e = getenv("FROST_DBG"); p.dbg = e ? atoi(e) : 0;
 }

@@ -35,5 +35,17 @@ import collections
 agg = collections.defaultdict(float)
 for k, v in s.items(): agg[k.split("|")[0]] += v["total_ms"]
 print("by kind: " + "  ".join(f"{k}={v:.2f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])))
-for k, v in rows[:60]:
+bag = collections.defaultdict(float)
+for k, v in s.items(): bag[k.split("|")[0]] += v["bytes_per_launch"] * v["launches"]
+print("by kind GB/s: " + "  ".join(f"{k}={bag[k]/agg[k]/1e6:.0f}" for k, _ in sorted(agg.items(), key=lambda kv: -kv[1])))
+print(f"total tagged bytes {sum(bag.values())/1e9:.2f} GB")
+lay = collections.defaultdict(lambda: [0.0, 0.0])
+for k, v in s.items():
+    if "|" in k:
+        n = k.split("|")[1]; lay[n][0] += v["total_ms"]; lay[n][1] += v["bytes_per_launch"] * v["launches"]
+shapes = {l.name: (l.kind, l.cin_g, l.cout, l.k, l.stride) for l in model.hip_runner().E.layers}
+print("per layer:")
+for n, (ms, by) in sorted(lay.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {n:28s} {str(shapes.get(n, '')):32s} {ms:7.3f} ms {by/1e6:9.1f} MB {by/ms/1e6:8.0f} GB/s")
+for k, v in rows[:int(os.environ.get("ROWS", "60"))]:
     print(f"{k:50s} {v['total_ms']:8.3f} ms  {v['bytes_per_launch']/1e6:9.1f} MB  {v['bytes_per_launch']/v['avg_ms']/1e6:8.1f} GB/s")
