@@ -35,6 +35,7 @@ struct PwP {
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
   int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
   int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
+  int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
   int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
 };
 
@@ -83,6 +84,13 @@ __device__ __forceinline__ void pw_stage_linear(const PwP& p, int64_t tile, uint
     }
   }
 }
+// full-tile DMA of `nbytes` (multiple of 1 KiB) contiguous bytes; wave w takes units w, w+8, ...
+__device__ __forceinline__ void pw_dma_tile(const uint8_t* src, uint8_t* dst, int nbytes, int tid) {
+  const int lane = tid & 63; const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nunits = nbytes >> 10;
+  const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)dst);
+  for (int u = w; u < nunits; u += 8) pw_glds16(src + u * 1024 + lane * 16, lbase + u * 1024);
+}
 #define PW_WB_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
 __device__ __forceinline__ void pw_wait_barrier(int n_younger) {      // n_younger: wave-uniform lower bound, see above
   switch (n_younger) {
@@ -108,14 +116,20 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   const bool gl = p.gl != 0;
   uint8_t* xs = smem;
   const int xs_bytes = gl ? 2 * p.tile_bytes + 64 : BP * p.kstr + 64;
-  long long* l_s1 = (long long*)(smem + xs_bytes);
+  // io region (full-tile kernels of small layers): every global access of the pass is a contiguous 16 B/lane stream --
+  //   reduce/dc: the gout tile [128][cout] bf16 arrives by DMA (two buffers); dc is written IN PLACE over it and leaves as a
+  //   linear copy;  emit/dgrad: the y / dx tile is assembled in LDS and leaves as a linear copy.
+  // (4- and 8-byte accesses at a cout-byte stride kept the texture-address unit ~75 % busy: 16 requests per wave instruction.)
+  const bool g_lds = (p.io & 1) != 0, o_lds = (p.io & 2) != 0;
+  uint8_t* const io_base = smem + xs_bytes;
+  long long* l_s1 = (long long*)(smem + xs_bytes + p.io_bytes);
   unsigned long long* l_s2 = (unsigned long long*)(l_s1 + p.cpad);
   int* l_mn = (int*)(l_s2 + p.cpad);
   int* l_mx = l_mn + p.cpad;
-  float* l_f1 = (float*)(smem + xs_bytes);
+  float* l_f1 = (float*)(smem + xs_bytes + p.io_bytes);
   float* l_f2 = l_f1 + p.cpad;
   const int red_bytes = (MODE == M_STATS) ? p.cpad * 24 : ((MODE == M_BRED) ? p.cpad * 8 : 0);
-  const uint8_t* wl = smem + xs_bytes + red_bytes;                                  // [CT][KS][64][16 B]
+  const uint8_t* wl = smem + xs_bytes + p.io_bytes + red_bytes;                                  // [CT][KS][64][16 B]
   const int wl_bytes = (p.cpad >> 4) * p.KS * 1024;
   const float* cl = (const float*)(wl + wl_bytes);                                  // [FROST_COEF_ROWS][cpad]
   const int* wsl = (const int*)(cl + FROST_COEF_ROWS * p.cpad);                      // [cpad]
@@ -178,17 +192,27 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   int buf = 0; bool full_prev = false;
   int n_younger = 0;     // VMEM instructions this wave is certain to issue after its DMA within one tile (last channel group)
   if (gl && !p.dbg && MODE != M_STATS) {
-    const int ct0l = ((p.ngroups - 1) * WC + wc) * p.mi_eff;
-    int nfull = 0;
-    for (int m = 0; m < p.mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
-    const int per = (MODE == M_BDC) ? 2 : ((MODE == M_DGRAD && p.accumulate) ? 2 : 1);
-    n_younger = nfull * NT * per; if (n_younger > 16) n_younger = 16;
+    if (o_lds) {                                   // the copy-out stores (exact count)
+      const int nu = p.o_bytes >> 10;
+      n_younger = (w < nu) ? (nu - w + 7) / 8 : 0;
+      if (MODE == M_DGRAD && p.accumulate) n_younger *= 2;
+    } else if (!g_lds) {
+      const int ct0l = ((p.ngroups - 1) * WC + wc) * p.mi_eff;
+      int nfull = 0;
+      for (int m = 0; m < p.mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
+      const int per = (MODE == M_BDC) ? 2 : ((MODE == M_DGRAD && p.accumulate) ? 2 : 1);
+      n_younger = nfull * NT * per;
+    }
+    if (n_younger > 16) n_younger = 16;
   }
   if (gl) {
     // K padding reads past a row's end (next row / next buffer / the 64-byte tail): harmless for int8 (zero weights), but a
     // bf16 NaN pattern times zero is NaN, so the dgrad buffers start out zeroed
     if (BF) { for (int i = tid; i < (xs_bytes >> 4); i += 512) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0); __syncthreads(); }
-    if (p.tile0 + (int64_t)blockIdx.x < p.ntiles) pw_stage_linear(p, p.tile0 + (int64_t)blockIdx.x, smem, tid);
+    if (p.tile0 + (int64_t)blockIdx.x < p.ntiles) {
+      pw_stage_linear(p, p.tile0 + (int64_t)blockIdx.x, smem, tid);
+      if (g_lds) pw_dma_tile((const uint8_t*)p.gout + (p.tile0 + (int64_t)blockIdx.x) * p.g_bytes, io_base, p.g_bytes, tid);
+    }
   }
 
   for (int64_t tile = p.tile0 + blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -197,7 +221,13 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     if (gl) {
       pw_wait_barrier(full_prev ? n_younger : 0);   // tile t has landed (each wave retired its own DMA); buffer buf^1 is free
       xs = smem + buf * p.tile_bytes;
-      if (RES) { const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid); }
+      if (RES) {
+        const int64_t nxt = tile + gridDim.x;
+        if (nxt < p.ntiles) {
+          pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
+          if (g_lds) pw_dma_tile((const uint8_t*)p.gout + nxt * p.g_bytes, io_base + (buf ^ 1) * p.g_bytes, p.g_bytes, tid);
+        }
+      }
       full_prev = full;
     }
     for (int cg = 0; cg < p.ngroups; ++cg) {
@@ -271,8 +301,13 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       }
 
       if (gl && !RES && cg == p.ngroups - 1) {   // non-resident weights are global loads younger than the DMA would be: issue it after them
-        const int64_t nxt = tile + gridDim.x; if (nxt < p.ntiles) pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
+        const int64_t nxt = tile + gridDim.x;
+        if (nxt < p.ntiles) {
+          pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
+          if (g_lds) pw_dma_tile((const uint8_t*)p.gout + nxt * p.g_bytes, io_base + (buf ^ 1) * p.g_bytes, p.g_bytes, tid);
+        }
       }
+      uint8_t* const gcur = io_base + (g_lds ? buf * p.g_bytes : 0);      // this tile's gout / dc tile, or the y / dx out tile
       // ------------------------------------------------------------------------------- epilogue
       // FULL tiles (all but the last tile of a tensor; their own kernel instance) carry no per-pixel validity logic at all.
       auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
@@ -324,7 +359,9 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const int prow = (wp * NT + t) * 16 + j;
-              if ((FULL || (p0 + prow) < p.npix) && chok) {
+              if (o_lds) {
+                if (chok) { uint2 o; o.x = pack_bf2(accf[m][t][0] * sw, accf[m][t][1] * sw); o.y = pack_bf2(accf[m][t][2] * sw, accf[m][t][3] * sw); *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o; }
+              } else if ((FULL || (p0 + prow) < p.npix) && chok) {
                 uint16_t* dst = base + prow * p.cout + ch0;
                 float v[4];
 #pragma unroll
@@ -352,7 +389,8 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
                 const float yv = fmaf(A[r], (float)acci[m][t][r], B[r]);
                 packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
               }
-              if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
+              if (o_lds) { if (chok) *(uint32_t*)(gcur + prow * p.cout + ch0) = packed ^ 0x80808080u; }
+              else if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
             }
             continue;
           }
@@ -390,7 +428,8 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
             const int prow = (wp * NT + t) * 16 + j;
             const bool valid = (FULL || (p0 + prow) < p.npix) && chok;
             uint2 gv = make_uint2(0, 0);
-            if (valid) gv = *(const uint2*)(gbase + prow * p.cout + ch0);
+            if (g_lds) { if (chok) gv = *(const uint2*)(gcur + (prow * p.cout + ch0) * 2); }
+            else if (valid) gv = *(const uint2*)(gbase + prow * p.cout + ch0);
             const float gq[4] = {__uint_as_float(gv.x << 16), __uint_as_float(gv.x & 0xffff0000u), __uint_as_float(gv.y << 16), __uint_as_float(gv.y & 0xffff0000u)};
             float dcv[4];
 #pragma unroll
@@ -403,7 +442,8 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
             }
             if (MODE == M_BDC && valid) {
               uint2 o; o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]);
-              *(uint2*)(dbase + prow * p.cout + ch0) = o;
+              if (o_lds) *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o;
+              else *(uint2*)(dbase + prow * p.cout + ch0) = o;
             }
           }
           if (MODE == M_BRED) {
@@ -421,6 +461,23 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         }
       };
       epilogue(std::integral_constant<bool, FULLT>{});
+    }
+    if (o_lds) {             // linear copy-out of the assembled tile: 1 KiB per wave instruction
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const uint8_t* osrc = io_base + ((MODE == M_BDC) ? buf * p.g_bytes : 0);
+      uint8_t* gdst = (MODE == M_EMIT) ? (uint8_t*)p.y + tile * p.o_bytes : ((MODE == M_BDC) ? (uint8_t*)p.dc + tile * p.o_bytes : (uint8_t*)p.dx + tile * p.o_bytes);
+      const int nu = p.o_bytes >> 10;
+      for (int u = w; u < nu; u += 8) {
+        uint4 v = *(const uint4*)(osrc + u * 1024 + lane * 16);
+        if (MODE == M_DGRAD && p.accumulate) {
+          const uint4 o = *(const uint4*)(gdst + u * 1024 + lane * 16);
+          v.x = pack_bf2(bf2f(v.x & 0xffff) + bf2f(o.x & 0xffff), bf2f(v.x >> 16) + bf2f(o.x >> 16));
+          v.y = pack_bf2(bf2f(v.y & 0xffff) + bf2f(o.y & 0xffff), bf2f(v.y >> 16) + bf2f(o.y >> 16));
+          v.z = pack_bf2(bf2f(v.z & 0xffff) + bf2f(o.z & 0xffff), bf2f(v.z >> 16) + bf2f(o.z >> 16));
+          v.w = pack_bf2(bf2f(v.w & 0xffff) + bf2f(o.w & 0xffff), bf2f(v.w >> 16) + bf2f(o.w >> 16));
+        }
+        *(uint4*)(gdst + u * 1024 + lane * 16) = v;
+      }
     }
     buf ^= 1;
   }
@@ -498,11 +555,20 @@ static int launch_pw(PwP& p, hipStream_t s) {
   static const int res_on = getenv("FROST_PW_RES") ? atoi(getenv("FROST_PW_RES")) : 1;
   // measured per (mode, wave split): resident mode pays where the epilogue is latency-chained and registers allow it
   constexpr bool res_ok = (WP != 2) && ((MODE == M_BDC) || (MODE == M_DGRAD) || (MODE == M_EMIT && WP == 4) || (MODE == M_BRED && WP == 8));
+  static const int io_on = getenv("FROST_PW_IO") ? atoi(getenv("FROST_PW_IO")) : 1;
+  PwP pf = p;                                   // the full-tile launch may use the LDS-staged I/O path
+  if (io_on && p.gl && MODE != M_STATS && (p.cout & 7) == 0) {
+    pf.g_bytes = 256 * p.cout; pf.o_bytes = (MODE == M_EMIT) ? 128 * p.cout : 256 * p.cout;
+    pf.io = (MODE == M_BRED) ? 1 : ((MODE == M_BDC) ? 3 : 2);
+    pf.io_bytes = (pf.io & 1) ? 2 * pf.g_bytes : pf.o_bytes;
+    if (lds + pf.io_bytes > 80 * 1024) { pf.io = 0; pf.io_bytes = 0; }
+  }
+  const size_t lds_f = lds + pf.io_bytes;
   const int64_t nfull = p.npix / BP;           // full tiles: validity-free kernel instance; the ragged tail: one extra tiny launch
   int rc = 0;
   if (nfull > 0) {
-    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds + res_bytes <= 80 * 1024 && nfull >= 2048) rc = launch_pw3<MODE, WP, true, true>(p, lds + res_bytes, 0, nfull, s);
-    else rc = launch_pw3<MODE, WP, false, true>(p, lds, 0, nfull, s);
+    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds_f + res_bytes <= 80 * 1024 && nfull >= 2048) rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+    else rc = launch_pw3<MODE, WP, false, true>(pf, lds_f, 0, nfull, s);
   }
   if (rc == 0 && nfull < p.ntiles) rc = launch_pw3<MODE, WP, false, false>(p, lds, nfull, p.ntiles, s);
   return rc;

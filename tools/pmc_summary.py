@@ -35,6 +35,9 @@ for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("dur_us", 0)):
     print(f"== {k}  n={v['n']}  dur={v['dur_us']:.1f} us (under PMC)")
     iv = v.get("SQ_INSTS_VALU", 0); w = max(v.get("SQ_WAVES", 1), 1)
     print("   " + "  ".join(f"{c[3:]}={val:.4g}" for c, val in v.items() if c.startswith("SQ_")))
+    oth = {c: val for c, val in v.items() if c.startswith(("TA_", "TCP_", "TCC_"))}
+    if oth:
+        print("   " + "  ".join(f"{c}={val:.4g}" for c, val in oth.items()))
     if iv:
         print(f"   per wave: valu={iv/w:.0f} salu={v.get('SQ_INSTS_SALU',0)/w:.0f} lds={v.get('SQ_INSTS_LDS',0)/w:.0f} "
               f"vmem={(v.get('SQ_INSTS_VMEM_RD',0)+v.get('SQ_INSTS_VMEM_WR',0))/w:.0f}   "
