@@ -35,12 +35,15 @@ struct PwP {
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
   int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
   int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
+  int cres;                       // BN/quant coefficient rows (folded) live in LDS even when the weights do not (RES)
   int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
   int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
 };
 
 #define BP 128
-#define MI 4
+// channel tiles (16 channels each) a wave carries per channel group: the 4-wave-wide channel split (WP == 2) holds 4 pixel
+// subtiles per channel tile, so its backward passes carry 2 (4 would spill the epilogue state: measured 30% slower)
+#define PW_MI(MODE, WP) (((WP) == 2 && ((MODE) == M_BRED || (MODE) == M_BDC)) ? 2 : 4)
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
@@ -111,6 +114,7 @@ template <int MODE, int WP, bool RES, bool FULLT>
 __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
+  constexpr int MI = PW_MI(MODE, WP);
   constexpr bool BF = (MODE == M_DGRAD);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const bool gl = p.gl != 0;
@@ -130,10 +134,11 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   float* l_f2 = l_f1 + p.cpad;
   const int red_bytes = (MODE == M_STATS) ? p.cpad * 24 : ((MODE == M_BRED) ? p.cpad * 8 : 0);
   const uint8_t* wl = smem + xs_bytes + p.io_bytes + red_bytes;                                  // [CT][KS][64][16 B]
-  const int wl_bytes = (p.cpad >> 4) * p.KS * 1024;
+  const int wl_bytes = RES ? (p.cpad >> 4) * p.KS * 1024 : 0;
+  const bool cres = RES || p.cres;
   const float* cl = (const float*)(wl + wl_bytes);                                  // [FROST_COEF_ROWS][cpad]
   const int* wsl = (const int*)(cl + FROST_COEF_ROWS * p.cpad);                      // [cpad]
-  const float* coefp = RES ? cl : p.coef;
+  const float* coefp = cres ? cl : p.coef;
   const int* wsump = RES ? wsl : p.wsum;
 
   const int tid = threadIdx.x;
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   } else if (MODE == M_BRED) {
     for (int c = tid; c < p.cpad; c += 512) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
   }
-  if (RES) {
-    for (int i = tid; i < (wl_bytes >> 4); i += 512) ((uint4*)wl)[i] = ((const uint4*)p.wpack)[i];
+  if (RES) for (int i = tid; i < (wl_bytes >> 4); i += 512) ((uint4*)wl)[i] = ((const uint4*)p.wpack)[i];
+  if (cres) {
     if (MODE == M_EMIT) for (int i = tid; i < 2 * p.cpad; i += 512) ((float*)cl)[i] = p.coef[i];        // rows A, B
     if (MODE == M_BRED || MODE == M_BDC) {     // folded rows (see the backward epilogue): M row <- -M*R, S1 row <- E, S2 row <- F
       float* c2 = (float*)cl;
@@ -160,9 +165,9 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         c2[FROST_COEF_S1 * p.cpad + c] = Ev; c2[FROST_COEF_S2 * p.cpad + c] = -Kv * (p.coef[FROST_COEF_S1 * p.cpad + c] * p.inv_count) - Ev * Mv;
       }
     }
-    if (MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
   }
-  if (RES) __syncthreads();
+  if (RES && MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
+  if (cres) __syncthreads();
 
   int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
           // STE mask in the t = y/scale domain: pass <=> t_lo < t <= t_hi (thresholds derived from the zero point so that the
           // test equals 0 <= rint(relu(y)/scale)+zp <= 255 and y > relu floor exactly, ties-to-even included).
           float R[4], MR[4], K1[4] = {0, 0, 0, 0}, E[4] = {0, 0, 0, 0}, F[4] = {0, 0, 0, 0};
-          if (RES) {
+          if (cres) {
             const float4 r4 = *(const float4*)(coefp + FROST_COEF_R * p.cpad + ch0), m4 = *(const float4*)(coefp + FROST_COEF_M * p.cpad + ch0);
             R[0] = r4.x; R[1] = r4.y; R[2] = r4.z; R[3] = r4.w; MR[0] = m4.x; MR[1] = m4.y; MR[2] = m4.z; MR[3] = m4.w;
             if (MODE == M_BDC) {
@@ -567,7 +572,9 @@ static int launch_pw(PwP& p, hipStream_t s) {
   const int64_t nfull = p.npix / BP;           // full tiles: validity-free kernel instance; the ragged tail: one extra tiny launch
   int rc = 0;
   if (nfull > 0) {
+    const size_t cres_bytes = (size_t)p.cpad * FROST_COEF_ROWS * 4;
     if (res_ok && res_on && res_bytes <= 40 * 1024 && lds_f + res_bytes <= 80 * 1024 && nfull >= 2048) rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+    else if ((MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) && lds_f + cres_bytes <= 80 * 1024) { pf.cres = 1; rc = launch_pw3<MODE, WP, false, true>(pf, lds_f + cres_bytes, 0, nfull, s); }
     else rc = launch_pw3<MODE, WP, false, true>(pf, lds_f, 0, nfull, s);
   }
   if (rc == 0 && nfull < p.ntiles) rc = launch_pw3<MODE, WP, false, false>(p, lds, nfull, p.ntiles, s);
@@ -579,6 +586,7 @@ static int dispatch_pw(PwP& p, hipStream_t s) {
   const int CT = p.cpad / 16;
   int WPsel = CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
   int WC = 8 / WPsel;
+  const int MI = PW_MI(MODE, WPsel);
   p.ngroups = (CT + WC * MI - 1) / (WC * MI);
   p.mi_eff = (CT + p.ngroups * WC - 1) / (p.ngroups * WC);
   if (WPsel == 8) return launch_pw<MODE, 8>(p, s);
