@@ -455,6 +455,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
             if (defer) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) { br1[m][r] += r1[r]; br2[m][r] += r2[r]; }
+              __builtin_amdgcn_sched_barrier(0);      // keep the next channel tile's coefficient / gout loads from being hoisted (spills)
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -559,7 +560,11 @@ static int launch_pw(PwP& p, hipStream_t s) {
   const size_t res_bytes = (size_t)(p.cpad >> 4) * p.KS * 1024 + (size_t)p.cpad * (FROST_COEF_ROWS + 1) * 4;
   static const int res_on = getenv("FROST_PW_RES") ? atoi(getenv("FROST_PW_RES")) : 1;
   // measured per (mode, wave split): resident mode pays where the epilogue is latency-chained and registers allow it
-  constexpr bool res_ok = (WP != 2) && ((MODE == M_BDC) || (MODE == M_DGRAD) || (MODE == M_EMIT && WP == 4) || (MODE == M_BRED && WP == 8));
+  // resident weights: measured faster (or equal) for every pass and wave split once the tile I/O is staged; the dgrad of a
+  // wide layer (dc rows too long for the DMA path) is the exception
+  constexpr int res_bit = MODE * 3 + (WP == 8 ? 0 : (WP == 4 ? 1 : 2));
+  static const long res_mask = getenv("FROST_PW_RESMASK") ? strtol(getenv("FROST_PW_RESMASK"), nullptr, 0) : 0x7fff;
+  const bool res_ok = (((res_mask >> res_bit) & 1) != 0) && (MODE != M_DGRAD || p.gl);
   static const int io_on = getenv("FROST_PW_IO") ? atoi(getenv("FROST_PW_IO")) : 1;
   PwP pf = p;                                   // the full-tile launch may use the LDS-staged I/O path
   if (io_on && p.gl && MODE != M_STATS && (p.cout & 7) == 0) {
