@@ -15,92 +15,165 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 enum { D_STATS = 0, D_EMIT = 1, D_BRED = 2, D_BDC = 3 };
 #define TH 8
-#define TW 16
-#define CB 64
 #define RH 4
 #define RW 8
+// Tile geometry.  A tile is TH x TWT outputs of a CBW-channel block, made of NSUB horizontally adjacent sub-tiles of SUBW
+// columns; every sub-tile is a different (image, row-tile, column-tile) unit with its own halo, so small feature maps pack
+// several images into one tile (7x7 maps: 38% -> 77% of the lanes do useful work) instead of padding one image to 8x16.
+//   CBW = 64: lane = channel, wave (wy, wx) owns the 4 x 8 patch at rows 4wy, columns 8wx           (TWT = 16)
+//   CBW = 32: lane = (channel = lane & 31, half = lane >> 5), the wave owns two patches, columns 16wx + 8half   (TWT = 32)
+//             -- for channel counts just above a multiple of 64 (32, 72, 96, 144: the high-resolution layers).
+template <int K_, int S_, int CBW_, int SUBW_>
+struct DwGeo {
+  static constexpr int K = K_, S = S_, CBW = CBW_, SUBW = SUBW_;
+  static constexpr int TWT = (CBW == 64) ? 16 : 32;
+  static constexpr int NSUB = TWT / SUBW;
+  static constexpr int UPP = CBW / 8;                          // 8-byte units per pixel
+  static constexpr int IH = (TH - 1) * S + K, IWS = (SUBW - 1) * S + K, IWT = NSUB * IWS;
+  static constexpr int IN_BYTES = ((IH * IWT * CBW + 255) / 256) * 256 + 256;
+  static constexpr int NXR = (RW - 1) * S + K, NBLK = (NXR + 7) / 8, NROW = (RH - 1) * S + K;
+  static constexpr int AUX_BYTES = TH * TWT * CBW * 2;         // bf16 gout / dc tile (16 KB); int8 out tile uses half
+};
 
 struct Dw3P {
   const int8_t* x; const float* qx; const int8_t* wq; const int32_t* wsum; const float* qw;
   int n, h, w, c, cpad, ho, wo, pad;
   uint8_t* stats; float* coef; const float* qy; int relu; int8_t* y;
   const uint16_t* gout; uint16_t* dc; float* dwq; uint16_t* dx; int accumulate;
-  int tiles_x, tiles_y, ncb, ngroups; int64_t ntiles; float inv_count;
+  int tiles_x, tiles_y, ncb, ngroups; int64_t nunits, ntiles; float inv_count;
 };
 
 __host__ __device__ constexpr int fdiv3(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
+// per-sub-tile unit decode (wave-uniform): image and output-domain origin of sub-tile s of block tile `tile`
+template <int NSUB, int SUBW>
+struct DwSub { int img[NSUB], r0[NSUB], c0[NSUB]; bool ok[NSUB]; };
+template <int NSUB, int SUBW>
+__device__ __forceinline__ void dw_decode(const Dw3P& p, int64_t tile, DwSub<NSUB, SUBW>& su) {
+  const int tpi = p.tiles_x * p.tiles_y;
+#pragma unroll
+  for (int s2 = 0; s2 < NSUB; ++s2) {
+    const int64_t u = tile * NSUB + s2;
+    su.ok[s2] = u < p.nunits;
+    const int64_t uu = su.ok[s2] ? u : 0;
+    const int img = (int)(uu / tpi); const int tr = (int)(uu - (int64_t)img * tpi);
+    su.img[s2] = img; su.r0[s2] = (tr / p.tiles_x) * TH; su.c0[s2] = (tr % p.tiles_x) * SUBW;
+  }
+}
+#define DW_SEL(ARR, SUBIDX) ((NSUB > 1 && (SUBIDX) == 1) ? ARR[NSUB > 1 ? 1 : 0] : ((NSUB > 2 && (SUBIDX) == 2) ? ARR[NSUB > 2 ? 2 : 0] : ((NSUB > 3 && (SUBIDX) == 3) ? ARR[NSUB > 3 ? 3 : 0] : ARR[0])))
+
 // 8 consecutive x-pixels of this lane's channel (offset-binary bytes) -> 8 unsigned-index floats
+template <int CBW>
 __device__ __forceinline__ void tr8_run(const uint8_t* tile_row, int col0, int lane, float* out8) {
-  const int jp = lane & 15, G = lane >> 4;
-  const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(tile_row + (col0 + (jp >> 1)) * CB + 16 * G + 8 * (jp & 1)));
+  const int jp = lane & 15, G = (lane >> 4) & (CBW / 16 - 1);
+  const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(tile_row + (col0 + (jp >> 1)) * CBW + 16 * G + 8 * (jp & 1)));
   const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;
   out8[0] = (float)(u0 & 255u); out8[1] = (float)((u0 >> 8) & 255u); out8[2] = (float)((u0 >> 16) & 255u); out8[3] = (float)(u0 >> 24);
   out8[4] = (float)(u1 & 255u); out8[5] = (float)((u1 >> 8) & 255u); out8[6] = (float)((u1 >> 16) & 255u); out8[7] = (float)(u1 >> 24);
 }
-// 4 consecutive x-pixels of this lane's channel from a bf16 [row][col][64 ch] tile
+// 4 consecutive x-pixels of this lane's channel from a bf16 [row][col][CBW ch] tile
+template <int CBW>
 __device__ __forceinline__ void tr16_run(const uint8_t* tile_row, int col0, int lane, float* out4) {
-  const int jp = lane & 15, G = lane >> 4;
-  const v4s raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(tile_row + ((col0 + (jp >> 2)) * CB + 16 * G + 4 * (jp & 3)) * 2));
+  const int jp = lane & 15, G = (lane >> 4) & (CBW / 16 - 1);
+  const v4s raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(tile_row + ((col0 + (jp >> 2)) * CBW + 16 * G + 4 * (jp & 3)) * 2));
   out4[0] = bf2f((uint16_t)raw[0]); out4[1] = bf2f((uint16_t)raw[1]); out4[2] = bf2f((uint16_t)raw[2]); out4[3] = bf2f((uint16_t)raw[3]);
 }
 
-// stage the int8 halo tile [IH][IW][64 B] (8-byte units: channel counts are multiples of 8, not always of 16)
-template <int IH, int IW>
-__device__ __forceinline__ void stage_in_tile(const int8_t* __restrict__ x, uint8_t* tile, int tid, int img, int iy0, int ix0, int cb,
-                                              int h, int w, int c, uint32_t zfill) {
-  constexpr int NUNIT = IH * IW * 8;
+// stage an int8 [NR][NSUB * NCS][CBW] tile (8-byte units: channel counts are multiples of 8, not always of 16).  Sub-tile s
+// covers columns [s*NCS, (s+1)*NCS) and maps to image su.img[s], rows r0[s]*RS + roff.., columns c0[s]*RS + coff..
+template <int NR, int NCS, int NSUB, int SUBW, int CBW>
+__device__ __forceinline__ void stage_i8_tile(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int rs, int roff,
+                                              int cb, int h, int w, int c, uint32_t zfill) {
+  constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
 #pragma unroll 1
   for (int base = 0; base < NUNIT; base += 256 * 8) {
     uint2 v[8];
 #pragma unroll
     for (int jn = 0; jn < 8; ++jn) {
-      const int u = base + tid + jn * 256; const int c8 = u & 7; const int pix = u >> 3; const int iy = pix / IW, ix = pix - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix; const int cc = cb * CB + c8 * 8;
+      const int u = base + tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int iy = pix / NC, ixx = pix - iy * NC;
+      const int sb = ixx / NCS; const int ix = ixx - sb * NCS;
+      const int gy = DW_SEL(su.r0, sb) * rs + roff + iy, gx = DW_SEL(su.c0, sb) * rs + roff + ix; const int cc = cb * CBW + c8 * 8;
       v[jn] = make_uint2(zfill, zfill);
-      if (u < NUNIT && gy >= 0 && gy < h && gx >= 0 && gx < w && cc < c) v[jn] = *(const uint2*)(x + (((int64_t)img * h + gy) * w + gx) * c + cc);
+      if (u < NUNIT && DW_SEL(su.ok, sb) && gy >= 0 && gy < h && gx >= 0 && gx < w && cc < c) v[jn] = *(const uint2*)(x + (((int64_t)DW_SEL(su.img, sb) * h + gy) * w + gx) * c + cc);
     }
 #pragma unroll
     for (int jn = 0; jn < 8; ++jn) { const int u = base + tid + jn * 256; if (u < NUNIT) *(uint2*)(tile + u * 8) = v[jn]; }
   }
 }
-// stage a bf16 [NR][NC][64 ch] tile (16-byte units), rows/cols outside [0,hh)x[0,ww) -> 0
-template <int NR, int NC>
-__device__ __forceinline__ void stage_bf16_tile(const uint16_t* __restrict__ src, uint8_t* tile, int tid, int img, int r0, int c0, int cb,
-                                                int hh, int ww, int c) {
-  constexpr int NUNIT = NR * NC * 8;
+// stage a bf16 [NR][NSUB * NCS][CBW] tile (16-byte units); origin of sub-tile s: rows fdiv(r0[s], dv) + roff, columns fdiv(c0[s], dv) + roff
+template <int NR, int NCS, int NSUB, int SUBW, int CBW>
+__device__ __forceinline__ void stage_bf16_tile(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int dv, int roff,
+                                                int cb, int hh, int ww, int c) {
+  constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
 #pragma unroll 1
   for (int base = 0; base < NUNIT; base += 256 * 4) {
     uint4 v[4];
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
-      const int u = base + tid + jn * 256; const int c8 = u & 7; const int pix = u >> 3; const int ry = pix / NC, rx = pix - ry * NC;
-      const int gy = r0 + ry, gx = c0 + rx; const int cc = cb * CB + c8 * 8;
+      const int u = base + tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int ry = pix / NC, rxx = pix - ry * NC;
+      const int sb = rxx / NCS; const int rx = rxx - sb * NCS;
+      const int gy = DW_SEL(su.r0, sb) / dv + roff + ry, gx = DW_SEL(su.c0, sb) / dv + roff + rx; const int cc = cb * CBW + c8 * 8;
       v[jn] = make_uint4(0, 0, 0, 0);
-      if (u < NUNIT && gy >= 0 && gy < hh && gx >= 0 && gx < ww && cc < c) v[jn] = *(const uint4*)(src + (((int64_t)img * hh + gy) * ww + gx) * c + cc);
+      if (u < NUNIT && DW_SEL(su.ok, sb) && gy >= 0 && gy < hh && gx >= 0 && gx < ww && cc < c) v[jn] = *(const uint4*)(src + (((int64_t)DW_SEL(su.img, sb) * hh + gy) * ww + gx) * c + cc);
     }
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) { const int u = base + tid + jn * 256; if (u < NUNIT) *(uint4*)(tile + u * 16) = v[jn]; }
   }
 }
+// copy an assembled [TH][TWT][CBW] tile (EB bytes per element) out to the NHWC tensor dst[img][hh][ww][c]
+template <int EB, int NSUB, int SUBW, int CBW, bool ACC>
+__device__ __forceinline__ void copy_out_tile(const uint8_t* tile, uint8_t* dst, int tid, const DwSub<NSUB, SUBW>& su, int cb, int hh, int ww, int c) {
+  constexpr int TWT = NSUB * SUBW, UPP = CBW / 8, NUNIT = TH * TWT * UPP;     // units of 8 channels
+#pragma unroll
+  for (int jn = 0; jn < NUNIT / 256; ++jn) {
+    const int u = tid + jn * 256; const int c8 = u % UPP, lp = u / UPP; const int row = lp / TWT, col = lp - row * TWT;
+    const int sb = col / SUBW; const int oy = DW_SEL(su.r0, sb) + row, ox = DW_SEL(su.c0, sb) + (col - sb * SUBW); const int cc = cb * CBW + c8 * 8;
+    if (DW_SEL(su.ok, sb) && oy < hh && ox < ww && cc < c) {
+      uint8_t* d = dst + ((((int64_t)DW_SEL(su.img, sb) * hh + oy) * ww + ox) * c + cc) * EB;
+      if (EB == 1) *(uint2*)d = *(const uint2*)(tile + lp * CBW + c8 * 8);
+      else {
+        uint4 v = *(const uint4*)(tile + (lp * CBW + c8 * 8) * 2);
+        if (ACC) {
+          const uint4 o = *(const uint4*)d;
+          v.x = cvt_pk_bf16(bf2f(v.x & 0xffff) + bf2f(o.x & 0xffff), bf2f(v.x >> 16) + bf2f(o.x >> 16));
+          v.y = cvt_pk_bf16(bf2f(v.y & 0xffff) + bf2f(o.y & 0xffff), bf2f(v.y >> 16) + bf2f(o.y >> 16));
+          v.z = cvt_pk_bf16(bf2f(v.z & 0xffff) + bf2f(o.z & 0xffff), bf2f(v.z >> 16) + bf2f(o.z >> 16));
+          v.w = cvt_pk_bf16(bf2f(v.w & 0xffff) + bf2f(o.w & 0xffff), bf2f(v.w >> 16) + bf2f(o.w >> 16));
+        }
+        *(uint4*)d = v;
+      }
+    }
+  }
+}
 
-template <int K, int S, int MODE>
+// lane geometry shared by the three kernels
+template <typename G>
+struct DwLane {
+  int lane, wv, wy, lc, pc, sb, colo, xcol0;     // channel lane, patch column index, sub-tile, out col in tile, input col of the patch
+  __device__ __forceinline__ DwLane(int tid) {
+    lane = tid & 63; wv = __builtin_amdgcn_readfirstlane(tid >> 6); wy = wv >> 1;
+    const int wx = wv & 1;
+    lc = lane & (G::CBW - 1);
+    pc = (G::CBW == 64) ? wx : wx * 2 + (lane >> 5);
+    colo = pc * RW; sb = colo / G::SUBW;
+    xcol0 = sb * G::IWS + (colo - sb * G::SUBW) * G::S;
+  }
+};
+
+template <typename G, int MODE>
 __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
-  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-  constexpr int IN_BYTES = ((IH * IW * CB + 255) / 256) * 256 + 256;
-  constexpr int NXR = (RW - 1) * S + K;                 // input pixels a lane needs per row
-  constexpr int NBLK = (NXR + 7) / 8;                   // 8-pixel transpose reads per row
+  constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* tin = smem;
-  uint8_t* aux = smem + IN_BYTES;                       // gout / dc bf16 tile (16 KB) or int8 out tile (8 KB)
-  double* red_d = (double*)(smem + IN_BYTES + 16384);   // [4][64][2]
-  float* red_f = (float*)(red_d + 4 * 64 * 2);          // [4][64][2]
+  uint8_t* aux = smem + G::IN_BYTES;                    // gout / dc bf16 tile (16 KB) or int8 out tile (8 KB)
+  double* red_d = (double*)(smem + G::IN_BYTES + G::AUX_BYTES);   // [4][64][2]
+  float* red_f = (float*)(red_d + 4 * 64 * 2);                     // [4][64][2]
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wy = wv >> 1, wx = wv & 1;
+  const int tid = threadIdx.x;
+  const DwLane<G> L(tid);
+  const int lane = L.lane, wv = L.wv, wy = L.wy;
   const int cb = blockIdx.x % p.ncb, grp = blockIdx.x / p.ncb;
-  const int ch = cb * CB + lane;
+  const int ch = cb * CBW + L.lc;
   const bool chok = ch < p.c;
   const int zp = __float_as_int(p.qx[FROST_Q_ZP]);
   const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
@@ -109,25 +182,33 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
 #pragma unroll
   for (int t = 0; t < K * K; ++t) wf[t] = chok ? (float)p.wq[t * p.cpad + ch] : 0.0f;
   const float corr = chok ? (float)(zp * p.wsum[ch]) : 0.0f;
-  float cA = 0, cB = 0, cM = 0, cR = 0, cK1 = 0, cS1 = 0, cS2 = 0, y_inv = 1.0f, y_zpf = 0.0f;
+  float cA = 0, cB = 0, cMR = 0, cR = 0, cK1 = 0, cE = 0, cF = 0, y_inv = 1.0f, y_zpf = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
   if (MODE != D_STATS) {
-    y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]);
+    y_inv = 1.0f / p.qy[FROST_Q_SCALE]; const int zpy = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)zpy;
     if (chok) {
       cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
-      if (MODE != D_EMIT) { cM = p.coef[FROST_COEF_M * p.cpad + ch]; cR = p.coef[FROST_COEF_R * p.cpad + ch]; }
-      if (MODE == D_BDC) { cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch]; cS1 = p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count; cS2 = p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count; }
+      if (MODE != D_EMIT) { const float m = p.coef[FROST_COEF_M * p.cpad + ch]; cR = p.coef[FROST_COEF_R * p.cpad + ch]; cMR = -m * cR;
+        if (MODE == D_BDC) {     // dc = fma(gy, K1, fma(acc, E, F)): same folding as the pointwise backward
+          cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
+          cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
+          cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+        }
+      }
+    }
+    if (MODE == D_BRED || MODE == D_BDC) {   // STE pass window in t = y/scale: t_lo < t <= t_hi (see frost_pw.hip)
+      const float hi0 = 255.5f - (float)zpy;
+      t_hi = ((255 - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+      if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
     }
   }
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
 
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
-    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
-    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
     __syncthreads();
-    stage_in_tile<IH, IW>(p.x, tin, tid, img, oy0 * S - p.pad, ox0 * S - p.pad, cb, p.h, p.w, p.c, zfill);
-    if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, TW>(p.gout, aux, tid, img, oy0, ox0, cb, p.ho, p.wo, p.c);
+    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
+    if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
     __syncthreads();
 
     float acc[RH][RW];
@@ -135,13 +216,12 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     for (int o = 0; o < RH; ++o)
 #pragma unroll
       for (int r = 0; r < RW; ++r) acc[o][r] = 0.0f;
-    constexpr int NROW = (RH - 1) * S + K;
 #pragma unroll
-    for (int jr = 0; jr < NROW; ++jr) {
-      float xr[NBLK * 8];
-      const uint8_t* rowp = tin + ((wy * RH * S + jr) * IW) * CB;
+    for (int jr = 0; jr < G::NROW; ++jr) {
+      float xr[G::NBLK * 8];
+      const uint8_t* rowp = tin + ((wy * RH * S + jr) * IWT) * CBW;
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) tr8_run(rowp, wx * RW * S + b * 8, lane, xr + b * 8);
+      for (int b = 0; b < G::NBLK; ++b) tr8_run<CBW>(rowp, L.xcol0 + b * 8, lane, xr + b * 8);
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         if ((jr - ky) >= 0 && ((jr - ky) % S) == 0 && (jr - ky) / S < RH) {
@@ -155,116 +235,99 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     }
 
     // ---------------------------------------------------------------- epilogue (lane-local, one channel)
+    const int oyb = DW_SEL(su.r0, L.sb) + wy * RH, oxb = DW_SEL(su.c0, L.sb) + (L.colo - L.sb * SUBW);
+    const bool subok = chok && DW_SEL(su.ok, L.sb);
 #pragma unroll
     for (int o = 0; o < RH; ++o) {
-      const int oy = oy0 + wy * RH + o;
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
-        const int ox = ox0 + wx * RW + r;
-        const bool valid = chok && oy < p.ho && ox < p.wo;
+        const bool valid = subok && (oyb + o) < p.ho && (oxb + r) < p.wo;
         const float v = acc[o][r] - corr;
-        const int lp = (wy * RH + o) * TW + wx * RW + r;          // pixel index inside the 8x16 tile
+        const int lp = (wy * RH + o) * TWT + L.colo + r;          // pixel index inside the tile
         if (MODE == D_STATS) {
           if (valid) { st1 += (double)v; st2 += (double)v * (double)v; smn = fminf(smn, v); smx = fmaxf(smx, v); }
         } else if (MODE == D_EMIT) {
           const float yv = fmaf(cA, v, cB);
           const float qf = fminf(fmaxf(rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf, 0.0f), 255.0f);
-          aux[lp * CB + lane] = (uint8_t)(((int)qf - 128) & 255);
+          aux[lp * CBW + L.lc] = (uint8_t)(((int)qf - 128) & 255);
         } else {
-          const float gq = bf2f(*(const uint16_t*)(aux + (lp * CB + lane) * 2));
-          const float yv = fmaf(cA, v, cB);
-          const float qf = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
-          const bool pass = valid && (yv > relu_floor) && qf >= 0.0f && qf <= 255.0f;
-          const float gy = pass ? gq : 0.0f;
-          const float xhat = (v - cM) * cR;
-          if (MODE == D_BRED) { r1 += gy; r2 += gy * xhat; }
-          else *(uint16_t*)(aux + (lp * CB + lane) * 2) = (uint16_t)cvt_pk_bf16(cK1 * (gy - cS1 - xhat * cS2), 0.0f);
+          const float gq = bf2f(*(const uint16_t*)(aux + (lp * CBW + L.lc) * 2));
+          const float tq = fmaf(cA, v, cB) * y_inv;
+          const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq : 0.0f;
+          if (MODE == D_BRED) { r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2); }
+          else *(uint16_t*)(aux + (lp * CBW + L.lc) * 2) = (uint16_t)cvt_pk_bf16(fmaf(gy, cK1, fmaf(v, cE, cF)), 0.0f);
         }
       }
     }
     if (MODE == D_EMIT || MODE == D_BDC) {
       __syncthreads();
-      if (MODE == D_EMIT) {
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {        // 128 pixels x 8 units of 8 B
-          const int u = tid + jn * 256; const int c8 = u & 7, lp = u >> 3; const int oy = oy0 + lp / TW, ox = ox0 + lp % TW; const int cc = cb * CB + c8 * 8;
-          if (oy < p.ho && ox < p.wo && cc < p.c) *(uint2*)(p.y + (((int64_t)img * p.ho + oy) * p.wo + ox) * p.c + cc) = *(const uint2*)(aux + lp * CB + c8 * 8);
-        }
-      } else {
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {        // 128 pixels x 8 units of 16 B
-          const int u = tid + jn * 256; const int c8 = u & 7, lp = u >> 3; const int oy = oy0 + lp / TW, ox = ox0 + lp % TW; const int cc = cb * CB + c8 * 8;
-          if (oy < p.ho && ox < p.wo && cc < p.c) *(uint4*)(p.dc + (((int64_t)img * p.ho + oy) * p.wo + ox) * p.c + cc) = *(const uint4*)(aux + (lp * CB + c8 * 8) * 2);
-        }
-      }
+      if (MODE == D_EMIT) copy_out_tile<1, NSUB, SUBW, CBW, false>(aux, (uint8_t*)p.y, tid, su, cb, p.ho, p.wo, p.c);
+      else copy_out_tile<2, NSUB, SUBW, CBW, false>(aux, (uint8_t*)p.dc, tid, su, cb, p.ho, p.wo, p.c);
     }
   }
 
-  if (MODE == D_STATS || MODE == D_BRED) {      // sum the 4 waves' lane-local partials, one global atomic set per channel
+  if (MODE == D_STATS || MODE == D_BRED) {      // sum the waves' lane-local partials, one global atomic set per channel
     __syncthreads();
     if (MODE == D_STATS) { red_d[(wv * 64 + lane) * 2] = st1; red_d[(wv * 64 + lane) * 2 + 1] = st2; red_f[(wv * 64 + lane) * 2] = smn; red_f[(wv * 64 + lane) * 2 + 1] = smx; }
     else { red_f[(wv * 64 + lane) * 2] = r1; red_f[(wv * 64 + lane) * 2 + 1] = r2; }
     __syncthreads();
-    if (tid < 64 && chok) {
+    if (tid < CBW && (cb * CBW + tid) < p.c) {
+      const int ch2 = cb * CBW + tid;
       if (MODE == D_STATS) {
         double a = 0, b = 0; float c = INFINITY, d = -INFINITY;
-        for (int w2 = 0; w2 < 4; ++w2) { a += red_d[(w2 * 64 + lane) * 2]; b += red_d[(w2 * 64 + lane) * 2 + 1]; c = fminf(c, red_f[(w2 * 64 + lane) * 2]); d = fmaxf(d, red_f[(w2 * 64 + lane) * 2 + 1]); }
+        for (int w2 = 0; w2 < 4; ++w2)
+          for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_d[(w2 * 64 + l2) * 2]; b += red_d[(w2 * 64 + l2) * 2 + 1]; c = fminf(c, red_f[(w2 * 64 + l2) * 2]); d = fmaxf(d, red_f[(w2 * 64 + l2) * 2 + 1]); }
         long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
         int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
         if (c <= d) {
-          atomicAdd((unsigned long long*)&g_s1[ch], (unsigned long long)(long long)a); atomicAdd(&g_s2[ch], (unsigned long long)b);
-          atomicMin(&g_mn[ch], (int)c); atomicMax(&g_mx[ch], (int)d);
+          atomicAdd((unsigned long long*)&g_s1[ch2], (unsigned long long)(long long)a); atomicAdd(&g_s2[ch2], (unsigned long long)b);
+          atomicMin(&g_mn[ch2], (int)c); atomicMax(&g_mx[ch2], (int)d);
         }
       } else {
         float a = 0, b = 0;
-        for (int w2 = 0; w2 < 4; ++w2) { a += red_f[(w2 * 64 + lane) * 2]; b += red_f[(w2 * 64 + lane) * 2 + 1]; }
-        atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch, b);
+        for (int w2 = 0; w2 < 4; ++w2)
+          for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_f[(w2 * 64 + l2) * 2]; b += red_f[(w2 * 64 + l2) * 2 + 1]; }
+        atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch2, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch2, b);
       }
     }
   }
 }
 
 // ---- wgrad: dwq[c][ky][kx] += s_x * sum dc * (q - zp); lane-local K*K sums across the whole persistent loop
-template <int K, int S>
+template <typename G>
 __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
-  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-  constexpr int IN_BYTES = ((IH * IW * CB + 255) / 256) * 256 + 256;
-  constexpr int NXR = (RW - 1) * S + K; constexpr int NBLK = (NXR + 7) / 8;
+  constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tin = smem; uint8_t* aux = smem + IN_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wy = wv >> 1, wx = wv & 1;
+  uint8_t* tin = smem; uint8_t* aux = smem + G::IN_BYTES;
+  const int tid = threadIdx.x;
+  const DwLane<G> L(tid);
+  const int lane = L.lane, wv = L.wv, wy = L.wy;
   const int cb = blockIdx.x % p.ncb, grp = blockIdx.x / p.ncb;
-  const int ch = cb * CB + lane; const bool chok = ch < p.c;
   const int zp = __float_as_int(p.qx[FROST_Q_ZP]); const float zpf = (float)zp;
   const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
   float acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
-    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
-    const int oy0 = (tr / p.tiles_x) * TH, ox0 = (tr % p.tiles_x) * TW;
+    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
     __syncthreads();
-    stage_in_tile<IH, IW>(p.x, tin, tid, img, oy0 * S - p.pad, ox0 * S - p.pad, cb, p.h, p.w, p.c, zfill);
-    stage_bf16_tile<TH, TW>(p.dc, aux, tid, img, oy0, ox0, cb, p.ho, p.wo, p.c);
+    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
+    stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);     // rows/cols outside the map -> 0
     __syncthreads();
     float g[RH][RW];
 #pragma unroll
     for (int o = 0; o < RH; ++o) {
-      const uint8_t* rowp = aux + ((wy * RH + o) * TW) * CB * 2;
-      tr16_run(rowp, wx * RW, lane, &g[o][0]); tr16_run(rowp, wx * RW + 4, lane, &g[o][4]);
+      const uint8_t* rowp = aux + ((wy * RH + o) * TWT) * CBW * 2;
+      tr16_run<CBW>(rowp, L.colo, lane, &g[o][0]); tr16_run<CBW>(rowp, L.colo + 4, lane, &g[o][4]);
     }
-    constexpr int NROW = (RH - 1) * S + K;
 #pragma unroll
-    for (int jr = 0; jr < NROW; ++jr) {
-      float xr[NBLK * 8];
-      const uint8_t* rowp = tin + ((wy * RH * S + jr) * IW) * CB;
+    for (int jr = 0; jr < G::NROW; ++jr) {
+      float xr[G::NBLK * 8];
+      const uint8_t* rowp = tin + ((wy * RH * S + jr) * IWT) * CBW;
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) tr8_run(rowp, wx * RW * S + b * 8, lane, xr + b * 8);
+      for (int b = 0; b < G::NBLK; ++b) tr8_run<CBW>(rowp, L.xcol0 + b * 8, lane, xr + b * 8);
 #pragma unroll
-      for (int i = 0; i < NBLK * 8; ++i) xr[i] -= zpf;
+      for (int i = 0; i < G::NBLK * 8; ++i) xr[i] -= zpf;
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         if ((jr - ky) >= 0 && ((jr - ky) % S) == 0 && (jr - ky) / S < RH) {
@@ -283,51 +346,55 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
   for (int t = 0; t < K * K; ++t) red[(wv * K * K + t) * 64 + lane] = acc[t];
   __syncthreads();
   const float sx = p.qx[FROST_Q_SCALE];
-  for (int i = tid; i < K * K * 64; i += 256) {
-    const int t = i >> 6, l2 = i & 63; const int c2 = cb * CB + l2;
-    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, (red[i] + red[K * K * 64 + i] + red[2 * K * K * 64 + i] + red[3 * K * K * 64 + i]) * sx);
+  for (int i = tid; i < K * K * CBW; i += 256) {
+    const int t = i / CBW, l2 = i % CBW; const int c2 = cb * CBW + l2;
+    float sum = 0.0f;
+    for (int w2 = 0; w2 < 4; ++w2)
+      for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * K * K + t) * 64 + l3];
+    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
   }
 }
 
-// ---- dgrad: dx[iy][ix][c] (+)= s_w * sum_{ky,kx} dc[(iy+pad-ky)/s][(ix+pad-kx)/s][c] * wq[ky][kx][c]
-template <int K, int S>
+// ---- dgrad: dx[iy][ix][c] (+)= s_w * sum_{ky,kx} dc[(iy+pad-ky)/s][(ix+pad-kx)/s][c] * wq[ky][kx][c]   (tiles over dx)
+template <typename G>
 __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
+  constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT;
   constexpr int PAD = (K - 1) / 2;
   constexpr int LO = fdiv3(-PAD, S);
-  constexpr int DH = (TH - 1 + PAD) / S - LO + 1, DW = (TW - 1 + PAD) / S - LO + 1;
-  constexpr int D_BYTES = ((DH * DW * CB * 2 + 255) / 256) * 256 + 512;
+  constexpr int DH = (TH - 1 + PAD) / S - LO + 1, DWS = (SUBW - 1 + PAD) / S - LO + 1, DWT = NSUB * DWS;
+  constexpr int D_BYTES = ((DH * DWT * CBW * 2 + 255) / 256) * 256 + 512;
   constexpr int NJR = (S == 1) ? (RH + K - 1) : ((RH - 1 + PAD) / 2 - LO + 1);
   constexpr int NR4 = (S == 1) ? (RW + K - 1 + 3) / 4 : 2;               // 4-pixel transpose reads per dc row
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tdc = smem; uint8_t* tout = smem + D_BYTES;                   // dx bf16 out tile [128][64]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wy = wv >> 1, wx = wv & 1;
+  uint8_t* tdc = smem; uint8_t* tout = smem + D_BYTES;                   // dx bf16 out tile [TH*TWT][CBW]
+  const int tid = threadIdx.x;
+  const DwLane<G> L(tid);
+  const int lane = L.lane, wy = L.wy;
   const int cb = blockIdx.x % p.ncb, grp = blockIdx.x / p.ncb;
-  const int ch = cb * CB + lane; const bool chok = ch < p.c;
+  const int ch = cb * CBW + L.lc; const bool chok = ch < p.c;
   const float sw = p.qw[FROST_Q_SCALE];
   float wf[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) wf[t] = chok ? (float)p.wq[t * p.cpad + ch] : 0.0f;
-  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int rb = (S == 1) ? wy * RH : wy * (RH / 2);
+  const int cin_sub = L.colo - L.sb * SUBW;                                // patch column inside its sub-tile (multiple of 8)
+  const int cbase = L.sb * DWS + ((S == 1) ? cin_sub : cin_sub / 2);
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
-    const int img = (int)(tile / tiles_per_img); const int tr = (int)(tile - (int64_t)img * tiles_per_img);
-    const int iy0 = (tr / p.tiles_x) * TH, ix0 = (tr % p.tiles_x) * TW;
+    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);        // units over the dx (input) domain
     __syncthreads();
-    stage_bf16_tile<DH, DW>(p.dc, tdc, tid, img, iy0 / S + LO, ix0 / S + LO, cb, p.ho, p.wo, p.c);
+    stage_bf16_tile<DH, DWS, NSUB, SUBW, CBW>(p.dc, tdc, tid, su, S, LO, cb, p.ho, p.wo, p.c);
     __syncthreads();
     float acc[RH][RW];
 #pragma unroll
     for (int o = 0; o < RH; ++o)
 #pragma unroll
       for (int r = 0; r < RW; ++r) acc[o][r] = 0.0f;
-    const int rb = (S == 1) ? wy * RH : wy * (RH / 2), cbase = (S == 1) ? wx * RW : wx * (RW / 2);
 #pragma unroll
     for (int jr = 0; jr < NJR; ++jr) {
       float dcr[NR4 * 4];
-      const uint8_t* rowp = tdc + ((rb + jr) * DW) * CB * 2;
+      const uint8_t* rowp = tdc + ((rb + jr) * DWT) * CBW * 2;
 #pragma unroll
-      for (int b = 0; b < NR4; ++b) tr16_run(rowp, cbase + b * 4, lane, dcr + b * 4);
+      for (int b = 0; b < NR4; ++b) tr16_run<CBW>(rowp, cbase + b * 4, lane, dcr + b * 4);
 #pragma unroll
       for (int o = 0; o < RH; ++o)
 #pragma unroll
@@ -347,24 +414,10 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
 #pragma unroll
     for (int o = 0; o < RH; ++o)
 #pragma unroll
-      for (int r = 0; r < RW; ++r) *(uint16_t*)(tout + (((wy * RH + o) * TW + wx * RW + r) * CB + lane) * 2) = (uint16_t)cvt_pk_bf16(acc[o][r] * sw, 0.0f);
+      for (int r = 0; r < RW; ++r) *(uint16_t*)(tout + (((wy * RH + o) * TWT + L.colo + r) * CBW + L.lc) * 2) = (uint16_t)cvt_pk_bf16(acc[o][r] * sw, 0.0f);
     __syncthreads();
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) {
-      const int u = tid + jn * 256; const int c8 = u & 7, lp = u >> 3; const int iy = iy0 + lp / TW, ix = ix0 + lp % TW; const int cc = cb * CB + c8 * 8;
-      if (iy < p.h && ix < p.w && cc < p.c) {
-        uint16_t* dst = p.dx + (((int64_t)img * p.h + iy) * p.w + ix) * p.c + cc;
-        uint4 v = *(const uint4*)(tout + (lp * CB + c8 * 8) * 2);
-        if (p.accumulate) {
-          const uint4 o = *(const uint4*)dst;
-          v.x = cvt_pk_bf16(bf2f(v.x & 0xffff) + bf2f(o.x & 0xffff), bf2f(v.x >> 16) + bf2f(o.x >> 16));
-          v.y = cvt_pk_bf16(bf2f(v.y & 0xffff) + bf2f(o.y & 0xffff), bf2f(v.y >> 16) + bf2f(o.y >> 16));
-          v.z = cvt_pk_bf16(bf2f(v.z & 0xffff) + bf2f(o.z & 0xffff), bf2f(v.z >> 16) + bf2f(o.z >> 16));
-          v.w = cvt_pk_bf16(bf2f(v.w & 0xffff) + bf2f(o.w & 0xffff), bf2f(v.w >> 16) + bf2f(o.w >> 16));
-        }
-        *(uint4*)dst = v;
-      }
-    }
+    if (p.accumulate) copy_out_tile<2, NSUB, SUBW, CBW, true>(tout, (uint8_t*)p.dx, tid, su, cb, p.h, p.w, p.c);
+    else copy_out_tile<2, NSUB, SUBW, CBW, false>(tout, (uint8_t*)p.dx, tid, su, cb, p.h, p.w, p.c);
   }
 }
 
@@ -372,8 +425,22 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
 static void fill3(Dw3P& p, const int8_t* x, const float* qx, const int8_t* wq, const int32_t* wsum, int n, int h, int w, int c, int k, int stride) {
   p.x = x; p.qx = qx; p.wq = wq; p.wsum = wsum; p.n = n; p.h = h; p.w = w; p.c = c; p.cpad = round_up(c, 16);
   p.pad = (k - 1) / 2; p.ho = (h + 2 * p.pad - k) / stride + 1; p.wo = (w + 2 * p.pad - k) / stride + 1;
-  p.tiles_x = (p.wo + TW - 1) / TW; p.tiles_y = (p.ho + TH - 1) / TH; p.ncb = (c + CB - 1) / CB;
-  p.ntiles = (int64_t)n * p.tiles_x * p.tiles_y; p.inv_count = 1.0f / (float)((int64_t)n * p.ho * p.wo);
+  p.inv_count = 1.0f / (float)((int64_t)n * p.ho * p.wo);
+}
+// geometry choice: 32-channel blocks when they waste fewer lanes than 64-channel blocks; 8-column sub-tiles (two images per
+// tile) for maps no wider than 8.  dom_h/dom_w: the domain the tiles run over (outputs; dx for the dgrad)
+enum { GEO_A = 0, GEO_B = 1, GEO_C = 2 };     // (64,16)  (64,8)  (32,32)
+static int pick_geo(int c, int dom_w, int k, int stride, bool dgrad) {
+  if (dom_w <= 8 && k == 5) return GEO_B;                                   // instantiated for k = 5 only (the 7x7 layers)
+  const bool c_inst = (k == 3) || (k == 5 && stride == 2);                  // GEO_C instantiations
+  if (dgrad && k == 5) return GEO_A;                                       // measured: the k = 5 dgrad prefers 64-channel blocks
+  if (c_inst && round_up(c, 32) < round_up(c, 64) && dom_w > 16) return GEO_C;
+  return GEO_A;
+}
+template <typename G>
+static void set_tiles(Dw3P& p, int dom_h, int dom_w) {
+  p.tiles_x = (dom_w + G::SUBW - 1) / G::SUBW; p.tiles_y = (dom_h + TH - 1) / TH; p.ncb = (p.c + G::CBW - 1) / G::CBW;
+  p.nunits = (int64_t)p.n * p.tiles_x * p.tiles_y; p.ntiles = (p.nunits + G::NSUB - 1) / G::NSUB;
 }
 template <typename KF>
 static int launch3(KF kern, Dw3P& p, size_t lds, const char* what, hipStream_t s) {
@@ -392,24 +459,48 @@ static int launch3(KF kern, Dw3P& p, size_t lds, const char* what, hipStream_t s
   hipLaunchKernelGGL(kern, dim3(p.ncb * p.ngroups), dim3(256), lds, s, p);
   return frost_check_launch(what);
 }
-template <int K, int S> static constexpr size_t in_bytes() { return (size_t)((((TH - 1) * S + K) * ((TW - 1) * S + K) * CB + 255) / 256) * 256 + 256; }
-template <int K, int S, int MODE>
-static int launch_fwd(Dw3P& p, hipStream_t s) { return launch3(k_dw3<K, S, MODE>, p, in_bytes<K, S>() + 16384 + 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4, "dw", s); }
-template <int MODE>
-static int dispatch3(Dw3P& p, int k, int stride, hipStream_t s) {
-  if (k == 3 && stride == 1) return launch_fwd<3, 1, MODE>(p, s);
-  if (k == 3 && stride == 2) return launch_fwd<3, 2, MODE>(p, s);
-  if (k == 5 && stride == 1) return launch_fwd<5, 1, MODE>(p, s);
-  if (k == 5 && stride == 2) return launch_fwd<5, 2, MODE>(p, s);
+template <typename G, int MODE>
+static int launch_fwd(Dw3P& p, hipStream_t s) {
+  set_tiles<G>(p, p.ho, p.wo);
+  return launch3(k_dw3<G, MODE>, p, (size_t)G::IN_BYTES + G::AUX_BYTES + 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4, "dw", s);
+}
+template <typename G>
+static int launch_wgrad(Dw3P& p, hipStream_t s) {
+  set_tiles<G>(p, p.ho, p.wo);
+  size_t lds = (size_t)G::IN_BYTES + G::AUX_BYTES; const size_t red = (size_t)4 * G::K * G::K * 64 * 4;
+  return launch3(k_dw3_wgrad<G>, p, lds > red ? lds : red, "dw_wgrad", s);
+}
+template <typename G>
+static int launch_dgrad(Dw3P& p, hipStream_t s) {
+  constexpr int PAD = (G::K - 1) / 2; constexpr int LO = fdiv3(-PAD, G::S);
+  constexpr int DH = (TH - 1 + PAD) / G::S - LO + 1, DWS = (G::SUBW - 1 + PAD) / G::S - LO + 1;
+  set_tiles<G>(p, p.h, p.w);
+  return launch3(k_dw3_dgrad<G>, p, (size_t)((DH * G::NSUB * DWS * G::CBW * 2 + 255) / 256) * 256 + 512 + G::AUX_BYTES, "dw_dgrad", s);
+}
+// one switch over (k, stride, geometry); OP: 0..3 = conv modes, 4 = wgrad, 5 = dgrad
+#define DW_CASE(KK, SS, CB_, SW_)                                                                             \
+  { typedef DwGeo<KK, SS, CB_, SW_> G_;                                                                       \
+    switch (op) { case 0: return launch_fwd<G_, D_STATS>(p, s); case 1: return launch_fwd<G_, D_EMIT>(p, s);  \
+                  case 2: return launch_fwd<G_, D_BRED>(p, s); case 3: return launch_fwd<G_, D_BDC>(p, s);    \
+                  case 4: return launch_wgrad<G_>(p, s); default: return launch_dgrad<G_>(p, s); } }
+static int dispatch3(Dw3P& p, int k, int stride, int geo, int op, hipStream_t s) {
+  if (geo == GEO_B) { if (k == 5 && stride == 1) DW_CASE(5, 1, 64, 8) if (k == 5 && stride == 2) DW_CASE(5, 2, 64, 8) }
+  if (geo == GEO_C) { if (k == 3 && stride == 1) DW_CASE(3, 1, 32, 32) if (k == 3 && stride == 2) DW_CASE(3, 2, 32, 32) if (k == 5 && stride == 2) DW_CASE(5, 2, 32, 32) }
+  if (k == 3 && stride == 1) DW_CASE(3, 1, 64, 16)
+  if (k == 3 && stride == 2) DW_CASE(3, 2, 64, 16)
+  if (k == 5 && stride == 1) DW_CASE(5, 1, 64, 16)
+  if (k == 5 && stride == 2) DW_CASE(5, 2, 64, 16)
   frost_set_error("dw: unsupported kernel/stride (k in {3,5}, stride in {1,2})"); return 1;
 }
+static int geo_env(int geo) { static const int force = getenv("FROST_DW_GEO") ? atoi(getenv("FROST_DW_GEO")) : -1; return force == 0 ? GEO_A : geo; }
+
 extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n,
                                  int h, int w, int c, int k, int stride, int mode, void* stats, const float* coef,
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y;
-  return mode == 0 ? dispatch3<D_STATS>(p, k, stride, as_stream(stream)) : dispatch3<D_EMIT>(p, k, stride, as_stream(stream));
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), mode == 0 ? 0 : 1, as_stream(stream));
 }
 extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                                  const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
@@ -417,33 +508,17 @@ extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w;
-  return pass == 0 ? dispatch3<D_BRED>(p, k, stride, as_stream(stream)) : dispatch3<D_BDC>(p, k, stride, as_stream(stream));
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), pass == 0 ? 2 : 3, as_stream(stream));
 }
 extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                               int stride, float* dwq, void* stream) {
   Dw3P p = {}; fill3(p, x, qrec_x, nullptr, nullptr, n, h, w, c, k, stride); p.dc = (uint16_t*)dc; p.dwq = dwq;
-  hipStream_t s = as_stream(stream);
-  if (k == 3 && stride == 1) return launch3(k_dw3_wgrad<3, 1>, p, in_bytes<3, 1>() + 16384, "dw_wgrad", s);
-  if (k == 3 && stride == 2) return launch3(k_dw3_wgrad<3, 2>, p, in_bytes<3, 2>() + 16384, "dw_wgrad", s);
-  if (k == 5 && stride == 1) return launch3(k_dw3_wgrad<5, 1>, p, (in_bytes<5, 1>() + 16384 > 25 * 64 * 16 ? in_bytes<5, 1>() + 16384 : 25 * 64 * 16), "dw_wgrad", s);
-  if (k == 5 && stride == 2) return launch3(k_dw3_wgrad<5, 2>, p, in_bytes<5, 2>() + 16384, "dw_wgrad", s);
-  frost_set_error("dw_wgrad: unsupported kernel/stride"); return 1;
-}
-template <int K, int S> static constexpr size_t dgrad_bytes() {
-  constexpr int PAD = (K - 1) / 2; constexpr int LO = fdiv3(-PAD, S);
-  constexpr int DH = (TH - 1 + PAD) / S - LO + 1, DW = (TW - 1 + PAD) / S - LO + 1;
-  return (size_t)((DH * DW * CB * 2 + 255) / 256) * 256 + 512 + 16384;
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 4, as_stream(stream));
 }
 extern "C" int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c,
                               int k, int stride, uint16_t* dx, int accumulate, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw_dgrad: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, nullptr, nullptr, wq_pack, nullptr, n, h, w, c, k, stride);
   p.dc = (uint16_t*)dc; p.dx = dx; p.accumulate = accumulate; p.qw = qrec_w;
-  p.tiles_x = (w + TW - 1) / TW; p.tiles_y = (h + TH - 1) / TH; p.ntiles = (int64_t)n * p.tiles_x * p.tiles_y;   // tiles over dx
-  hipStream_t s = as_stream(stream);
-  if (k == 3 && stride == 1) return launch3(k_dw3_dgrad<3, 1>, p, dgrad_bytes<3, 1>(), "dw_dgrad", s);
-  if (k == 3 && stride == 2) return launch3(k_dw3_dgrad<3, 2>, p, dgrad_bytes<3, 2>(), "dw_dgrad", s);
-  if (k == 5 && stride == 1) return launch3(k_dw3_dgrad<5, 1>, p, dgrad_bytes<5, 1>(), "dw_dgrad", s);
-  if (k == 5 && stride == 2) return launch3(k_dw3_dgrad<5, 2>, p, dgrad_bytes<5, 2>(), "dw_dgrad", s);
-  frost_set_error("dw_dgrad: unsupported kernel/stride"); return 1;
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, w, k, stride, true)), 5, as_stream(stream));
 }
