@@ -71,6 +71,12 @@ __device__ __forceinline__ void tr8_run(const uint8_t* tile_row, int col0, int l
   out8[0] = (float)(u0 & 255u); out8[1] = (float)((u0 >> 8) & 255u); out8[2] = (float)((u0 >> 16) & 255u); out8[3] = (float)(u0 >> 24);
   out8[4] = (float)(u1 & 255u); out8[5] = (float)((u1 >> 8) & 255u); out8[6] = (float)((u1 >> 16) & 255u); out8[7] = (float)(u1 >> 24);
 }
+// the same 8 pixels as packed offset-binary bytes (two dwords) -- operands of the integer dot-product path
+template <int CBW>
+__device__ __forceinline__ v2i tr8_raw(const uint8_t* tile_row, int col0, int lane) {
+  const int jp = lane & 15, G = (lane >> 4) & (CBW / 16 - 1);
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(tile_row + (col0 + (jp >> 1)) * CBW + 16 * G + 8 * (jp & 1)));
+}
 // 4 consecutive x-pixels of this lane's channel from a bf16 [row][col][CBW ch] tile
 template <int CBW>
 __device__ __forceinline__ void tr16_run(const uint8_t* tile_row, int col0, int lane, float* out4) {
@@ -178,10 +184,22 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   const int zp = __float_as_int(p.qx[FROST_Q_ZP]);
   const uint32_t zfill = (uint32_t)((zp - 128) & 255) * 0x01010101u;
 
-  float wf[K * K];
+  // Integer conv core: the lane's 8-pixel runs stay packed (4 offset-binary bytes per dword), every output takes its 4-byte
+  // window with one v_alignbyte and one (k = 3) or two (k = 5) v_dot4_i32_i8 against the packed taps of a kernel row.
+  // acc starts at (128 - zp) * sum(w), so acc = sum w * (q - zp) exactly (zero padding = zero-point fill).
+  constexpr int NPK = (K == 3) ? 1 : 2;
+  int wpk[K][NPK];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) wf[t] = chok ? (float)p.wq[t * p.cpad + ch] : 0.0f;
-  const float corr = chok ? (float)(zp * p.wsum[ch]) : 0.0f;
+  for (int ky = 0; ky < K; ++ky) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u;
+      if (kx < 4) lo |= b << (8 * kx); else hi |= b;
+    }
+    wpk[ky][0] = (int)lo; if (NPK > 1) wpk[ky][NPK - 1] = (int)hi;
+  }
+  const int acc0 = chok ? (128 - zp) * p.wsum[ch] : 0;
   float cA = 0, cB = 0, cMR = 0, cR = 0, cK1 = 0, cE = 0, cF = 0, y_inv = 1.0f, y_zpf = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
   if (MODE != D_STATS) {
     y_inv = 1.0f / p.qy[FROST_Q_SCALE]; const int zpy = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)zpy;
@@ -211,25 +229,34 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
     __syncthreads();
 
-    float acc[RH][RW];
+    int acc[RH][RW];
 #pragma unroll
     for (int o = 0; o < RH; ++o)
 #pragma unroll
-      for (int r = 0; r < RW; ++r) acc[o][r] = 0.0f;
+      for (int r = 0; r < RW; ++r) acc[o][r] = acc0;
+    constexpr int NWIN = (K == 3) ? RW : RW + 4 / S;            // window i starts at byte i*S of the lane's row
 #pragma unroll
     for (int jr = 0; jr < G::NROW; ++jr) {
-      float xr[G::NBLK * 8];
+      int d[G::NBLK * 2 + 1];
       const uint8_t* rowp = tin + ((wy * RH * S + jr) * IWT) * CBW;
 #pragma unroll
-      for (int b = 0; b < G::NBLK; ++b) tr8_run<CBW>(rowp, L.xcol0 + b * 8, lane, xr + b * 8);
+      for (int b = 0; b < G::NBLK; ++b) { const v2i raw = tr8_raw<CBW>(rowp, L.xcol0 + b * 8, lane); d[2 * b] = raw[0]; d[2 * b + 1] = raw[1]; }
+      d[G::NBLK * 2] = 0;
+      int win[NWIN];
+#pragma unroll
+      for (int i = 0; i < NWIN; ++i) {
+        const int off = i * S;
+        win[i] = (off % 4 == 0) ? d[off / 4] : __builtin_amdgcn_alignbyte(d[off / 4 + 1], d[off / 4], off % 4);
+      }
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         if ((jr - ky) >= 0 && ((jr - ky) % S) == 0 && (jr - ky) / S < RH) {
           const int o = (jr - ky) / S;
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-            for (int r = 0; r < RW; ++r) acc[o][r] = fmaf(xr[r * S + kx], wf[ky * K + kx], acc[o][r]);
+          for (int r = 0; r < RW; ++r) {
+            acc[o][r] = __builtin_amdgcn_sdot4(win[r], wpk[ky][0], acc[o][r], false);
+            if (K == 5) acc[o][r] = __builtin_amdgcn_sdot4(win[r + 4 / S], wpk[ky][NPK - 1], acc[o][r], false);
+          }
         }
       }
     }
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const bool valid = subok && (oyb + o) < p.ho && (oxb + r) < p.wo;
-        const float v = acc[o][r] - corr;
+        const float v = (float)acc[o][r];
         const int lp = (wy * RH + o) * TWT + L.colo + r;          // pixel index inside the tile
         if (MODE == D_STATS) {
           if (valid) { st1 += (double)v; st2 += (double)v * (double)v; smn = fminf(smn, v); smx = fmaxf(smx, v); }

@@ -387,23 +387,34 @@ __device__ __forceinline__ float add_val(int ba, int bb, const QP& A, const QP& 
 }
 __global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,
                                                     const float* qb, int64_t n, float* out2) {
+  // 16 B per operand per lane and two independent loads in flight; few, fat workgroups: the final float atomics on the two
+  // result words serialise, so their count (one pair per workgroup) is part of the critical path
   QP A = load_qp(qa), B = load_qp(qb);
   float lo = INFINITY, hi = -INFINITY;
-  int64_t n4 = n >> 2;
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    uint32_t va = ((const uint32_t*)a)[i], vb = ((const uint32_t*)b)[i];
+  const int64_t n16 = n >> 4; const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += 2 * stride) {
+    const uint4 va0 = ((const uint4*)a)[i], vb0 = ((const uint4*)b)[i];
+    const bool two = (i + stride) < n16;
+    uint4 va1 = va0, vb1 = vb0;
+    if (two) { va1 = ((const uint4*)a)[i + stride]; vb1 = ((const uint4*)b)[i + stride]; }
+    const uint32_t wa[8] = {va0.x, va0.y, va0.z, va0.w, va1.x, va1.y, va1.z, va1.w}, wb[8] = {vb0.x, vb0.y, vb0.z, vb0.w, vb1.x, vb1.y, vb1.z, vb1.w};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = add_val((int)(int8_t)(va >> (8 * e)), (int)(int8_t)(vb >> (8 * e)), A, B);
-      lo = fminf(lo, v); hi = fmaxf(hi, v);
-    }
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = add_val((int)(int8_t)(wa[q] >> (8 * e)), (int)(int8_t)(wb[q] >> (8 * e)), A, B);
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+      }
+  }
+  for (int64_t i = (n16 << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {     // tail (n % 16)
+    const float v = add_val((int)a[i], (int)b[i], A, B); lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
   block_minmax_commit(lo, hi, out2);
 }
 extern "C" int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                                 float* minmax2, void* stream) {
   FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
-  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 4096, 2048)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, minmax2);
+  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 32768, 512)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, minmax2);
   return frost_check_launch("add_minmax");
 }
 __global__ __launch_bounds__(256) void k_add_requant(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,
