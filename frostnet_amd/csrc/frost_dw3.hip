@@ -85,10 +85,81 @@ __device__ __forceinline__ void tr16_run(const uint8_t* tile_row, int col0, int 
   out4[0] = bf2f((uint16_t)raw[0]); out4[1] = bf2f((uint16_t)raw[1]); out4[2] = bf2f((uint16_t)raw[2]); out4[3] = bf2f((uint16_t)raw[3]);
 }
 
+// Tile staging plan.  Which (row, column, 8-channel unit) of the halo tile a thread moves is the same for every tile of the
+// persistent loop, so the unit decode (three constant divisions) and the channel bound are computed once per thread and kept
+// packed in one register per unit; per tile and unit there remain a few adds/mads, two unsigned compares and one 64-bit add
+// in front of the load.  EB = bytes per element (1: int8 activations, 8-byte units; 2: bf16, 16-byte units).
+template <int NR, int NCS, int NSUB, int CBW, int EB>
+struct DwPlan {
+  static constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP, NU = (NUNIT + 255) / 256;
+  int pos[NU];        // iy | ix << 8 | sub << 16 | live << 20
+  int cc0, ww_, c_;   // this thread's channel offset (the same for all its units: 256 is a multiple of UPP), row pitch, channels
+  __device__ __forceinline__ int rel(int jn) const { return ((pos[jn] & 255) * ww_ + ((pos[jn] >> 8) & 255)) * c_ + cc0; }
+  __device__ __forceinline__ void init(int tid, int cb, int ww, int c) {
+#pragma unroll
+    for (int jn = 0; jn < NU; ++jn) {
+      const int u = tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int iy = pix / NC, ixx = pix - iy * NC;
+      const int sb = ixx / NCS; const int ix = ixx - sb * NCS; const int cc = cb * CBW + c8 * 8;
+      const bool live = (u < NUNIT) && (cc < c);
+      pos[jn] = iy | (ix << 8) | (sb << 16) | ((live ? 1 : 0) << 20);
+    }
+    cc0 = cb * CBW + (tid % UPP) * 8; ww_ = ww; c_ = c;
+  }
+};
+// stage through the plan: sub-tile s has its origin at (gy0[s], gx0[s]) of image su.img[s] in the [hh][ww][c] tensor
+template <int NR, int NCS, int NSUB, int SUBW, int CBW>
+__device__ __forceinline__ void stage_i8_tile(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwPlan<NR, NCS, NSUB, CBW, 1>& pl,
+                                              const DwSub<NSUB, SUBW>& su, int rs, int roff, int h, int w, int c, uint32_t zfill) {
+  typedef DwPlan<NR, NCS, NSUB, CBW, 1> P;
+  int gy0[NSUB], gx0[NSUB]; const int8_t* bp[NSUB];
+#pragma unroll
+  for (int s2 = 0; s2 < NSUB; ++s2) { gy0[s2] = su.r0[s2] * rs + roff; gx0[s2] = su.c0[s2] * rs + roff; bp[s2] = x + (((int64_t)su.img[s2] * h + gy0[s2]) * w + gx0[s2]) * c; }
+#pragma unroll
+  for (int b0 = 0; b0 < P::NU; b0 += 8) {
+    uint2 v[8];
+#pragma unroll
+    for (int jn = 0; jn < 8; ++jn) {
+      if (b0 + jn < P::NU) {
+        const int ps = pl.pos[b0 + jn]; const int sb = (ps >> 16) & 3;
+        const int gy = DW_SEL(gy0, sb) + (ps & 255), gx = DW_SEL(gx0, sb) + ((ps >> 8) & 255);
+        v[jn] = make_uint2(zfill, zfill);
+        if ((ps >> 20) && DW_SEL(su.ok, sb) && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) v[jn] = *(const uint2*)(DW_SEL(bp, sb) + pl.rel(b0 + jn));
+      }
+    }
+#pragma unroll
+    for (int jn = 0; jn < 8; ++jn)
+      if (b0 + jn < P::NU) { const int u = tid + (b0 + jn) * 256; if (u < P::NUNIT) *(uint2*)(tile + u * 8) = v[jn]; }
+  }
+}
+template <int NR, int NCS, int NSUB, int SUBW, int CBW>
+__device__ __forceinline__ void stage_bf16_tile(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwPlan<NR, NCS, NSUB, CBW, 2>& pl,
+                                                const DwSub<NSUB, SUBW>& su, int dv, int roff, int hh, int ww, int c) {
+  typedef DwPlan<NR, NCS, NSUB, CBW, 2> P;
+  int gy0[NSUB], gx0[NSUB]; const uint16_t* bp[NSUB];
+#pragma unroll
+  for (int s2 = 0; s2 < NSUB; ++s2) { gy0[s2] = su.r0[s2] / dv + roff; gx0[s2] = su.c0[s2] / dv + roff; bp[s2] = src + (((int64_t)su.img[s2] * hh + gy0[s2]) * ww + gx0[s2]) * c; }
+#pragma unroll
+  for (int b0 = 0; b0 < P::NU; b0 += 4) {
+    uint4 v[4];
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      if (b0 + jn < P::NU) {
+        const int ps = pl.pos[b0 + jn]; const int sb = (ps >> 16) & 3;
+        const int gy = DW_SEL(gy0, sb) + (ps & 255), gx = DW_SEL(gx0, sb) + ((ps >> 8) & 255);
+        v[jn] = make_uint4(0, 0, 0, 0);
+        if ((ps >> 20) && DW_SEL(su.ok, sb) && (unsigned)gy < (unsigned)hh && (unsigned)gx < (unsigned)ww) v[jn] = *(const uint4*)(DW_SEL(bp, sb) + pl.rel(b0 + jn));
+      }
+    }
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+      if (b0 + jn < P::NU) { const int u = tid + (b0 + jn) * 256; if (u < P::NUNIT) *(uint4*)(tile + u * 16) = v[jn]; }
+  }
+}
+// on-the-fly variants (no per-thread plan): for the k = 5, stride 2 weight-gradient kernel, whose register budget is spent
 // stage an int8 [NR][NSUB * NCS][CBW] tile (8-byte units: channel counts are multiples of 8, not always of 16).  Sub-tile s
 // covers columns [s*NCS, (s+1)*NCS) and maps to image su.img[s], rows r0[s]*RS + roff.., columns c0[s]*RS + coff..
 template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_i8_tile(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int rs, int roff,
+__device__ __forceinline__ void stage_i8_tile_otf(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int rs, int roff,
                                               int cb, int h, int w, int c, uint32_t zfill) {
   constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
 #pragma unroll 1
@@ -108,7 +179,7 @@ __device__ __forceinline__ void stage_i8_tile(const int8_t* __restrict__ x, uint
 }
 // stage a bf16 [NR][NSUB * NCS][CBW] tile (16-byte units); origin of sub-tile s: rows fdiv(r0[s], dv) + roff, columns fdiv(c0[s], dv) + roff
 template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_bf16_tile(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int dv, int roff,
+__device__ __forceinline__ void stage_bf16_tile_otf(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int dv, int roff,
                                                 int cb, int hh, int ww, int c) {
   constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
 #pragma unroll 1
@@ -221,12 +292,14 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   }
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
+  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; plx.init(tid, cb, p.w, p.c);
+  DwPlan<TH, SUBW, NSUB, CBW, 2> plg; if (MODE == D_BRED || MODE == D_BDC) plg.init(tid, cb, p.wo, p.c);
 
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
     DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
     __syncthreads();
-    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
-    if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
+    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
+    if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);
     __syncthreads();
 
     int acc[RH][RW];
@@ -335,11 +408,19 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
   float acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
+  constexpr bool PLAN = !(K == 5 && S == 2);
+  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; DwPlan<TH, SUBW, NSUB, CBW, 2> plg;
+  if (PLAN) { plx.init(tid, cb, p.w, p.c); plg.init(tid, cb, p.wo, p.c); }
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
     DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
     __syncthreads();
-    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
-    stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);     // rows/cols outside the map -> 0
+    if (PLAN) {
+      stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
+      stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);     // rows/cols outside the map -> 0
+    } else {
+      stage_i8_tile_otf<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
+      stage_bf16_tile_otf<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
+    }
     __syncthreads();
     float g[RH][RW];
 #pragma unroll
@@ -406,10 +487,11 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
   const int rb = (S == 1) ? wy * RH : wy * (RH / 2);
   const int cin_sub = L.colo - L.sb * SUBW;                                // patch column inside its sub-tile (multiple of 8)
   const int cbase = L.sb * DWS + ((S == 1) ? cin_sub : cin_sub / 2);
+  DwPlan<DH, DWS, NSUB, CBW, 2> pld; pld.init(tid, cb, p.wo, p.c);
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
     DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);        // units over the dx (input) domain
     __syncthreads();
-    stage_bf16_tile<DH, DWS, NSUB, SUBW, CBW>(p.dc, tdc, tid, su, S, LO, cb, p.ho, p.wo, p.c);
+    stage_bf16_tile<DH, DWS, NSUB, SUBW, CBW>(p.dc, tdc, tid, pld, su, S, LO, p.ho, p.wo, p.c);
     __syncthreads();
     float acc[RH][RW];
 #pragma unroll
