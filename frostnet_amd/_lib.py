@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrost_hip.so")
+LIB_PATH = os.environ.get("FROST_HIP_LIB", os.path.join(_HERE, "libfrost_hip.so"))   # override: A/B runs of two builds in one GPU session (dev only)
 _lib = None
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float

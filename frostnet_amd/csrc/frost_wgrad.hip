@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t pack_trunc_bf16(float lo, float hi) {   // e
   return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
 }
 
-__global__ __launch_bounds__(256) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+__global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
                                                   int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD + KPIX * RSX];   // 26.6 KB: staging, then the 16 KB reduction tile
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD;
@@ -120,18 +120,20 @@ __global__ __launch_bounds__(256) void k_pw_wgrad(const uint16_t* __restrict__ d
     if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, red[i] * sx);
   }
 }
-// Large-channel variant: 128x128 (co x ci) output tile, each of the 4 waves owns a 64x64 quadrant over ALL 128 staged
-// pixels (4 K-steps): 2x the arithmetic intensity per staged byte, no cross-wave reduction.
+// Large-channel variant: 128x128 (co x ci) output tile over ALL 128 staged pixels (4 K-steps), 8 waves: wave w owns the
+// 64 x 32 block (co half w>>2, ci quarter w&3): 2x the arithmetic intensity per staged byte of the small kernel, no cross-wave
+// reduction, and 32 accumulator + 24 prefetch registers per lane, so two 8-wave workgroups are resident per CU (the 4-wave
+// version needed 224 VGPRs: 8 waves per CU, latency-bound).
 #define BT 128
 #define RSD2 264   // 128 bf16 + 8 bytes
 #define RSX2 136   // 128 int8 + 8 bytes
-__global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
-                                                      int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
+__global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+                                                         int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 51 KB
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD2;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qa = w >> 1, qb = w & 1;                                   // quadrant of this wave
+  const int qa = w >> 2, qb = w & 3;                                   // co half, ci quarter of this wave
   const int nci = (cin + BT - 1) / BT;
   const int ntile = ((cout + BT - 1) / BT) * nci;
   const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
@@ -140,21 +142,21 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict
   const float zpf = (float)zpu;
   const uint32_t zfill = (uint32_t)((zpu - 128) & 255) * 0x01010101u;
   int na = (cout - co0 - qa * 64 + 15) / 16; na = na < 0 ? 0 : (na > 4 ? 4 : na);
-  int nb = (cin - ci0 - qb * 64 + 15) / 16; nb = nb < 0 ? 0 : (nb > 4 ? 4 : nb);
-  v4f acc[4][4];
+  int nb = (cin - ci0 - qb * 32 + 15) / 16; nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
+  v4f acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 2; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
   const uint8_t* a_src = dcs + (g * 8 + (i16 >> 2)) * RSD2 + qa * 128 + (i16 & 3) * 8;
-  const uint8_t* b_src = xs + (g * 8 + (i16 >> 1)) * RSX2 + qb * 64 + (i16 & 1) * 8;
+  const uint8_t* b_src = xs + (g * 8 + (i16 >> 1)) * RSX2 + qb * 32 + (i16 & 1) * 8;
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
-  uint4 pd[8]; uint2 px[8];         // register prefetch of the next block (48 VGPRs): HBM/L2 latency overlaps the MFMAs
+  uint4 pd[4]; uint2 px[4];         // register prefetch of the next block: HBM/L2 latency overlaps the MFMAs
 #define WGB_PREFETCH(BLK_)                                                                                            \
   {                                                                                                                   \
     const int64_t q0_ = (BLK_) * KPIX;                                                                                \
-    _Pragma("unroll") for (int jn = 0; jn < 8; ++jn) {                                                                \
-      const int u_ = tid + jn * 256; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;         \
+    _Pragma("unroll") for (int jn = 0; jn < 4; ++jn) {                                                                \
+      const int u_ = tid + jn * 512; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;         \
       pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint2(zfill, zfill);                                             \
       if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);            \
       if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);               \
@@ -164,8 +166,8 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict
   for (int64_t blk = split; blk < nblk; blk += nsplit) {
     __syncthreads();
 #pragma unroll
-    for (int jn = 0; jn < 8; ++jn) {
-      const int u = tid + jn * 256; const int pix = u >> 4, c8 = u & 15;
+    for (int jn = 0; jn < 4; ++jn) {
+      const int u = tid + jn * 512; const int pix = u >> 4, c8 = u & 15;
       *(uint2*)(dcs + pix * RSD2 + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y);
       *(uint2*)(dcs + pix * RSD2 + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
       *(uint2*)(xs + pix * RSX2 + c8 * 8) = px[jn];
@@ -175,18 +177,17 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict
     if (na > 0 && nb > 0) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        v4i afr[4], bfr[4];
+        v4i afr[4], bfr[2];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           if (a < na) {
-            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32));
-            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32 + 4 * RSD2));
-            afr[a] = (v4i){(int)((uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16)), (int)((uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16)),
-                           (int)((uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16)), (int)((uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16))};
+            const v2i lo = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32)));
+            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32 + 4 * RSD2)));
+            afr[a] = (v4i){lo[0], lo[1], hi[0], hi[1]};
           }
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 2; ++b) {
           if (b < nb) {
             const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 16));
             const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 2; ++b)
             if (a < na && b < nb)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
       }
@@ -209,11 +210,11 @@ __global__ __launch_bounds__(256) void k_pw_wgrad_big(const uint16_t* __restrict
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < 2; ++b)
       if (a < na && b < nb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * 64 + b * 16 + i16;
+          const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * 32 + b * 16 + i16;
           if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
         }
       }
@@ -224,9 +225,9 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
   if (cin > 64 && cout > 64) {      // wide layers: 128x128 tiles, quadrant-per-wave
     const int ntile = ((cout + BT - 1) / BT) * ((cin + BT - 1) / BT);
-    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 768;
+    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 512;     // = resident 8-wave workgroups (2 per CU)
     int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
+    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(512), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
     return frost_check_launch("pw_wgrad_big");
   }
   const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);
