@@ -61,6 +61,7 @@ _PROTOS = {
     "frost_pw_conv_bwd": [P, P, P, P, P, P, L, I, I, I, P, P, I, P, P, P, I, P],
     "frost_pw_wgrad": [P, P, P, L, I, I, P, P],
     "frost_dw_conv_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
+    "frost_dw_conv_bwd_dc_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P],
     "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
     "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
     "frost_stem_conv_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],

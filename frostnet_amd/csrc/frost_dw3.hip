@@ -13,7 +13,7 @@
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
-enum { D_STATS = 0, D_EMIT = 1, D_BRED = 2, D_BDC = 3 };
+enum { D_STATS = 0, D_EMIT = 1, D_BRED = 2, D_BDC = 3, D_BDCW = 4 };   // D_BDCW: dc pass + the weight gradient in the same sweep
 #define TH 8
 #define RH 4
 #define RW 8
@@ -237,8 +237,10 @@ struct DwLane {
   }
 };
 
-template <typename G, int MODE>
+template <typename G, int MODE_>
 __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
+  constexpr int MODE = (MODE_ == D_BDCW) ? D_BDC : MODE_;
+  constexpr bool WG = (MODE_ == D_BDCW);
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* tin = smem;
@@ -292,14 +294,23 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   }
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
-  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; plx.init(tid, cb, p.w, p.c);
-  DwPlan<TH, SUBW, NSUB, CBW, 2> plg; if (MODE == D_BRED || MODE == D_BDC) plg.init(tid, cb, p.wo, p.c);
+  constexpr bool PLAN = !WG;       // the fused weight-gradient variant has no registers to spare for the staging plans
+  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; if (PLAN) plx.init(tid, cb, p.w, p.c);
+  DwPlan<TH, SUBW, NSUB, CBW, 2> plg; if (PLAN && (MODE == D_BRED || MODE == D_BDC)) plg.init(tid, cb, p.wo, p.c);
+  float wacc[WG ? K * K : 1]; float sdc = 0.0f;      // fused weight gradient: sum dc * q (unsigned index) per tap, and sum dc
+#pragma unroll
+  for (int t = 0; t < (WG ? K * K : 1); ++t) wacc[t] = 0.0f;
 
   for (int64_t tile = grp; tile < p.ntiles; tile += p.ngroups) {
     DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
     __syncthreads();
-    stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
-    if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);
+    if (PLAN) {
+      stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
+      if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);
+    } else {
+      stage_i8_tile_otf<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
+      stage_bf16_tile_otf<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
+    }
     __syncthreads();
 
     int acc[RH][RW];
@@ -355,7 +366,34 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
           const float tq = fmaf(cA, v, cB) * y_inv;
           const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq : 0.0f;
           if (MODE == D_BRED) { r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2); }
-          else *(uint16_t*)(aux + (lp * CBW + L.lc) * 2) = (uint16_t)cvt_pk_bf16(fmaf(gy, cK1, fmaf(v, cE, cF)), 0.0f);
+          else {
+            const uint32_t hb = cvt_pk_bf16(fmaf(gy, cK1, fmaf(v, cE, cF)), 0.0f) & 0xffffu;
+            *(uint16_t*)(aux + (lp * CBW + L.lc) * 2) = (uint16_t)hb;
+            if (WG) acc[o][r] = valid ? (int)(hb << 16) : 0;          // the bf16-rounded dc (float bits) replaces the dead accumulator
+          }
+        }
+      }
+    }
+    if (WG) {     // second sweep over the halo rows still in LDS: wacc[ky][kx] += dc[o][r] * q[o*S+ky][r*S+kx]
+#pragma unroll
+      for (int o = 0; o < RH; ++o)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) sdc += __int_as_float(acc[o][r]);
+#pragma unroll
+      for (int jr = 0; jr < G::NROW; ++jr) {
+        float xr[G::NBLK * 8];
+        const uint8_t* rowp = tin + ((wy * RH * S + jr) * IWT) * CBW;
+#pragma unroll
+        for (int b = 0; b < G::NBLK; ++b) tr8_run<CBW>(rowp, L.xcol0 + b * 8, lane, xr + b * 8);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          if ((jr - ky) >= 0 && ((jr - ky) % S) == 0 && (jr - ky) / S < RH) {
+            const int o = (jr - ky) / S;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+              for (int r = 0; r < RW; ++r) wacc[ky * K + kx] = fmaf(__int_as_float(acc[o][r]), xr[r * S + kx], wacc[ky * K + kx]);
+          }
         }
       }
     }
@@ -366,6 +404,22 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     }
   }
 
+  if (WG) {       // dW[c][tap] += s_x * (sum dc*q - zp * sum dc): the 4 waves' (and, for 32-channel blocks, both halves') partials through LDS
+    __syncthreads();
+    float* red = (float*)smem;                       // [4][K*K][64]
+    const float zpf = (float)zp;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) red[(wv * K * K + t) * 64 + lane] = wacc[t] - zpf * sdc;
+    __syncthreads();
+    const float sx = p.qx[FROST_Q_SCALE];
+    for (int i = tid; i < K * K * CBW; i += 256) {
+      const int t = i / CBW, l2 = i % CBW; const int c2 = cb * CBW + l2;
+      float sum = 0.0f;
+      for (int w2 = 0; w2 < 4; ++w2)
+        for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * K * K + t) * 64 + l3];
+      if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
+    }
+  }
   if (MODE == D_STATS || MODE == D_BRED) {      // sum the waves' lane-local partials, one global atomic set per channel
     __syncthreads();
     if (MODE == D_STATS) { red_d[(wv * 64 + lane) * 2] = st1; red_d[(wv * 64 + lane) * 2 + 1] = st2; red_f[(wv * 64 + lane) * 2] = smn; red_f[(wv * 64 + lane) * 2 + 1] = smx; }
@@ -571,7 +625,8 @@ static int launch3(KF kern, Dw3P& p, size_t lds, const char* what, hipStream_t s
 template <typename G, int MODE>
 static int launch_fwd(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.ho, p.wo);
-  return launch3(k_dw3<G, MODE>, p, (size_t)G::IN_BYTES + G::AUX_BYTES + 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4, "dw", s);
+  size_t lds = (size_t)G::IN_BYTES + G::AUX_BYTES + 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4; const size_t red = (size_t)4 * G::K * G::K * 64 * 4;
+  return launch3(k_dw3<G, MODE>, p, lds > red ? lds : red, "dw", s);
 }
 template <typename G>
 static int launch_wgrad(Dw3P& p, hipStream_t s) {
@@ -586,12 +641,19 @@ static int launch_dgrad(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.h, p.w);
   return launch3(k_dw3_dgrad<G>, p, (size_t)((DH * G::NSUB * DWS * G::CBW * 2 + 255) / 256) * 256 + 512 + G::AUX_BYTES, "dw_dgrad", s);
 }
-// one switch over (k, stride, geometry); OP: 0..3 = conv modes, 4 = wgrad, 5 = dgrad
+// dc pass + weight gradient: fused where the combined register state fits (measured: no spills), else two launches
+template <typename G>
+static int launch_bdc_wgrad(Dw3P& p, hipStream_t s) {
+  constexpr bool FUSE = (G::K == 3 && G::S == 1) || (G::K == 5 && G::S == 1 && G::SUBW == 8);
+  if constexpr (FUSE) return launch_fwd<G, D_BDCW>(p, s);
+  else { const int rc = launch_fwd<G, D_BDC>(p, s); return rc ? rc : launch_wgrad<G>(p, s); }
+}
+// one switch over (k, stride, geometry); OP: 0..3 = conv modes, 4 = wgrad, 5 = dgrad, 6 = dc pass with the fused weight gradient
 #define DW_CASE(KK, SS, CB_, SW_)                                                                             \
   { typedef DwGeo<KK, SS, CB_, SW_> G_;                                                                       \
     switch (op) { case 0: return launch_fwd<G_, D_STATS>(p, s); case 1: return launch_fwd<G_, D_EMIT>(p, s);  \
                   case 2: return launch_fwd<G_, D_BRED>(p, s); case 3: return launch_fwd<G_, D_BDC>(p, s);    \
-                  case 4: return launch_wgrad<G_>(p, s); default: return launch_dgrad<G_>(p, s); } }
+                  case 4: return launch_wgrad<G_>(p, s); case 6: return launch_bdc_wgrad<G_>(p, s); default: return launch_dgrad<G_>(p, s); } }
 static int dispatch3(Dw3P& p, int k, int stride, int geo, int op, hipStream_t s) {
   if (geo == GEO_B) { if (k == 5 && stride == 1) DW_CASE(5, 1, 64, 8) if (k == 5 && stride == 2) DW_CASE(5, 2, 64, 8) }
   if (geo == GEO_C) { if (k == 3 && stride == 1) DW_CASE(3, 1, 32, 32) if (k == 3 && stride == 2) DW_CASE(3, 2, 32, 32) if (k == 5 && stride == 2) DW_CASE(5, 2, 32, 32) }
@@ -618,6 +680,14 @@ extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w;
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), pass == 0 ? 2 : 3, as_stream(stream));
+}
+extern "C" int frost_dw_conv_bwd_dc_wgrad(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                                          const float* qrec_w, int n, int h, int w, int c, int k, int stride, float* coef,
+                                          const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, float* dwq, void* stream) {
+  FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
+  Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
+  p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w; p.dwq = dwq;
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 6, as_stream(stream));
 }
 extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                               int stride, float* dwq, void* stream) {

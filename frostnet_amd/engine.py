@@ -9,6 +9,8 @@ torch nniqat.ConvBn(ReLU)2d._forward_approximate and FakeQuantize (SURVEY.md Q1-
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -19,6 +21,9 @@ SLACK = 256  # bytes of slack after every activation buffer (the MFMA K-tail may
 
 def round_up(a, b):
     return (a + b - 1) // b * b
+
+
+_DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
 
 
 class Act:
@@ -382,14 +387,18 @@ class Engine:
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                  prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
-            call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
-                 prof=("dw_bwd_dc", x.numel + 4 * y.numel))
+            if _DW_FUSE:
+                call("frost_dw_conv_bwd_dc_wgrad", *args, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(l.dwq), s,
+                     prof=("dw_bwd_dc", x.numel + 4 * y.numel))       # dc pass + weight gradient (one sweep where registers allow)
+            else:
+                call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
+                     prof=("dw_bwd_dc", x.numel + 4 * y.numel))
+                call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
+                     prof=("dw_wgrad", 2 * y.numel + x.numel))
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
                 call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s,
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
-            call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
-                 prof=("dw_wgrad", 2 * y.numel + x.numel))
         call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
              l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
         y.grad = None

@@ -152,6 +152,10 @@ int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int
 int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                       const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
                       const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream);
+/* pass 1 of frost_dw_conv_bwd with the depthwise weight gradient (frost_dw_wgrad) accumulated in the same sweep */
+int frost_dw_conv_bwd_dc_wgrad(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                               const float* qrec_w, int n, int h, int w, int c, int k, int stride, float* coef,
+                               const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, float* dwq, void* stream);
 int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c, int k,
                    int stride, uint16_t* dx, int accumulate, void* stream);
 int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
