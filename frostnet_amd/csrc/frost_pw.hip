@@ -34,6 +34,7 @@ struct PwP {
   uint8_t* stats; int relu;
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
   int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
+  int csplit, nbt;                // channel-group split across workgroups (few-tile layers), workgroups per split
   int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
   int cres;                       // BN/quant coefficient rows (folded) live in LDS even when the weights do not (RES)
   int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
@@ -183,7 +184,10 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 
   // lane-local accumulators that live across the persistent tile loop (single channel group only)
   // BRED with WP==2 already holds 64 accumulator registers: deferring would spill (measured 2x slower)
-  const bool defer = (WP != 2) && (p.ngroups == 1);      // WP == 2 holds 64 accumulator registers already: deferring would spill
+  // few-tile (7x7) layers: the channel groups are divided among `csplit` sets of workgroups so the launch still fills the chip
+  const int bsplit = (int)blockIdx.x / p.nbt, bslot = (int)blockIdx.x - bsplit * p.nbt;
+  const int cg_lo = (bsplit * p.ngroups) / p.csplit, cg_hi = ((bsplit + 1) * p.ngroups) / p.csplit;
+  const bool defer = (WP != 2) && (cg_hi - cg_lo == 1);      // WP == 2 holds 64 accumulator registers already: deferring would spill
   long long st1[MI]; double st2[MI]; int smn[MI], smx[MI];       // STATS: lane's channel = ct*16 + j
   float br1[MI][4], br2[MI][4];                                     // BRED: lane's channels = ct*16 + 4g + r
 #pragma unroll
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       n_younger = (w < nu) ? (nu - w + 7) / 8 : 0;
       if (MODE == M_DGRAD && p.accumulate) n_younger *= 2;
     } else if (!g_lds) {
-      const int ct0l = ((p.ngroups - 1) * WC + wc) * p.mi_eff;
+      const int ct0l = ((cg_hi - 1) * WC + wc) * p.mi_eff;
       int nfull = 0;
       for (int m = 0; m < p.mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
       const int per = (MODE == M_BDC) ? 2 : ((MODE == M_DGRAD && p.accumulate) ? 2 : 1);
@@ -214,20 +218,20 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     // K padding reads past a row's end (next row / next buffer / the 64-byte tail): harmless for int8 (zero weights), but a
     // bf16 NaN pattern times zero is NaN, so the dgrad buffers start out zeroed
     if (BF) { for (int i = tid; i < (xs_bytes >> 4); i += 512) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0); __syncthreads(); }
-    if (p.tile0 + (int64_t)blockIdx.x < p.ntiles) {
-      pw_stage_linear(p, p.tile0 + (int64_t)blockIdx.x, smem, tid);
-      if (g_lds) pw_dma_tile((const uint8_t*)p.gout + (p.tile0 + (int64_t)blockIdx.x) * p.g_bytes, io_base, p.g_bytes, tid);
+    if (p.tile0 + (int64_t)bslot < p.ntiles) {
+      pw_stage_linear(p, p.tile0 + (int64_t)bslot, smem, tid);
+      if (g_lds) pw_dma_tile((const uint8_t*)p.gout + (p.tile0 + (int64_t)bslot) * p.g_bytes, io_base, p.g_bytes, tid);
     }
   }
 
-  for (int64_t tile = p.tile0 + blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  for (int64_t tile = p.tile0 + bslot; tile < p.ntiles; tile += p.nbt) {
     const int64_t p0 = tile * BP;
     const bool full = FULLT;
     if (gl) {
       pw_wait_barrier(full_prev ? n_younger : 0);   // tile t has landed (each wave retired its own DMA); buffer buf^1 is free
       xs = smem + buf * p.tile_bytes;
       if (RES) {
-        const int64_t nxt = tile + gridDim.x;
+        const int64_t nxt = tile + p.nbt;
         if (nxt < p.ntiles) {
           pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
           if (g_lds) pw_dma_tile((const uint8_t*)p.gout + nxt * p.g_bytes, io_base + (buf ^ 1) * p.g_bytes, p.g_bytes, tid);
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       }
       full_prev = full;
     }
-    for (int cg = 0; cg < p.ngroups; ++cg) {
+    for (int cg = cg_lo; cg < cg_hi; ++cg) {
       const int ct0 = (cg * WC + wc) * p.mi_eff;
       int mi_n = CT - ct0; mi_n = mi_n < 0 ? 0 : (mi_n > p.mi_eff ? p.mi_eff : mi_n);
       v4i acci[MI][NT]; v4f accf[MI][NT];
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         const int kc0 = ch * p.kc_bytes;
         int kcw = p.rowbytes - kc0; if (kcw > p.kc_bytes) kcw = p.kc_bytes;
         const int kcw_pad = (kcw + 63) & ~63;
-        if (!gl && (p.nchunks > 1 || cg == 0)) {
+        if (!gl && (p.nchunks > 1 || cg == cg_lo)) {
           __syncthreads();
           const uint8_t* src = p.T + p0 * p.rowbytes + kc0;
           if (((p.rowbytes | kc0) & 15) == 0) {
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         }
       }
 
-      if (gl && !RES && cg == p.ngroups - 1) {   // non-resident weights are global loads younger than the DMA would be: issue it after them
-        const int64_t nxt = tile + gridDim.x;
+      if (gl && !RES && cg == cg_hi - 1) {   // non-resident weights are global loads younger than the DMA would be: issue it after them
+        const int64_t nxt = tile + p.nbt;
         if (nxt < p.ntiles) {
           pw_stage_linear(p, nxt, smem + (buf ^ 1) * p.tile_bytes, tid);
           if (g_lds) pw_dma_tile((const uint8_t*)p.gout + nxt * p.g_bytes, io_base + (buf ^ 1) * p.g_bytes, p.g_bytes, tid);
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 
   if (MODE == M_STATS) {
     if (defer) {
-      const int ct0 = wc * p.mi_eff;
+      const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         const int chn = (ct0 + m) * 16 + j;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     __syncthreads();
     long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
-    for (int c = tid; c < p.cout; c += 512) {
+    for (int c = cg_lo * WC * p.mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * p.mi_eff * 16; c += 512) {
       if (l_mn[c] <= l_mx[c]) {
         atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
         atomicAdd(&g_s2[c], l_s2[c]);
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     }
   } else if (MODE == M_BRED) {
     if (defer) {
-      const int ct0 = wc * p.mi_eff;
+      const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         const int ch0 = (ct0 + m) * 16 + 4 * g;
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       }
     }
     __syncthreads();
-    for (int c = tid; c < p.cout; c += 512) {
+    for (int c = cg_lo * WC * p.mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * p.mi_eff * 16; c += 512) {
       atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
       atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, l_f2[c]);
     }
@@ -549,7 +553,11 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   const int64_t n = tile_end - tile0;
   int64_t grid = n < 256 * occ_cache ? n : 256 * occ_cache;
   if (grid < 1) return 0;
-  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT>), dim3((unsigned)grid), dim3(512), lds, s, q);
+  static const int cs_on = getenv("FROST_PW_CSPLIT") ? atoi(getenv("FROST_PW_CSPLIT")) : 1;
+  int cs = 1;
+  if (cs_on && !q.io && grid * 2 <= 256 * occ_cache) { cs = (int)((256 * occ_cache) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
+  q.csplit = cs; q.nbt = (int)grid;
+  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
   return frost_check_launch("pw");
 }
 template <int MODE, int WP>
