@@ -22,6 +22,11 @@ class FrostWDesc(C.Structure):
                 ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
 
 
+class FrostGDesc(C.Structure):
+    _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
+                ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FrostOptTensor(C.Structure):
     _fields_ = [("p", P), ("g", P), ("exp_min", P), ("exp_max", P), ("coin", P), ("buf0", P), ("buf1", P), ("buf2", P),
                 ("n", C.c_int64), ("weight_decay", F), ("lr", F), ("first_step", C.c_int32), ("pad", C.c_int32)]
@@ -48,7 +53,6 @@ _PROTOS = {
     "frost_stats_init_table": [P, P, P, I, P],
     "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
     "frost_dw_conv_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P],
-    "frost_stem_conv_fwd": [P, P, P, P, I, I, I, I, I, P, P, P, I, P, P],
     "frost_stem_im2col": [P, P, I, I, I, P, P],
     "frost_stem_wgrad_remap": [P, I, I, P, P],
     "frost_conv_finalize": [P, L, I, P, P, P, P, P, P, P, I, I, I, P, P, P],
@@ -64,8 +68,8 @@ _PROTOS = {
     "frost_dw_conv_bwd_dc_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P],
     "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
     "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
-    "frost_stem_conv_bwd": [P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
     "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
+    "frost_weight_grad_finalize_table": [P, I, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

@@ -555,7 +555,8 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   if (grid < 1) return 0;
   static const int cs_on = getenv("FROST_PW_CSPLIT") ? atoi(getenv("FROST_PW_CSPLIT")) : 1;
   int cs = 1;
-  if (cs_on && !q.io && grid * 2 <= 256 * occ_cache) { cs = (int)((256 * occ_cache) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
+  static const int cs_mul = getenv("FROST_PW_CSMUL") ? atoi(getenv("FROST_PW_CSMUL")) : 1;
+  if (cs_on && !q.io && grid * 2 <= 256 * occ_cache * cs_mul) { cs = (int)((256 * occ_cache * cs_mul) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
   q.csplit = cs; q.nbt = (int)grid;
   hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
   return frost_check_launch("pw");

@@ -310,6 +310,8 @@ class Engine:
     def backward(self, dlogits=None, out_grads=None):
         """Replay the tape in reverse. dlogits: fp32 [n, nclass] gradient of the loss w.r.t. the logits.
         Parameter gradients are written (=, not +=) into l.w.grad / l.gamma.grad / l.beta.grad / l.bias.grad."""
+        self._prepare_dwq()
+        self._pending = []          # conv layers whose weight-gradient finalize is deferred to one table launch
         for entry in reversed(self.tape):
             kind = entry[0]
             if kind == "head":
@@ -345,7 +347,41 @@ class Engine:
                 call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
                      fa, ptr(gb), fb, stream(), prof=("add_bwd", 8 * a.numel))
                 y.grad = None
+        self._finalize_pending()
         self.tape = []
+
+    def _prepare_dwq(self):
+        """One fp32 scratch arena for every layer's dL/d(fake-quantised weight) (the wgrad kernels accumulate with atomics):
+        one fill per step instead of one per layer."""
+        if getattr(self, "_dwq_arena", None) is None or self._dwq_layers != len(self.layers):
+            sizes = [l.w.numel() + (l.cout * 40 if l.kind == "stem" else 0) for l in self.layers]
+            self._dwq_arena = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+            o = 0
+            for l, sz in zip(self.layers, sizes):
+                l.dwq = self._dwq_arena[o: o + l.w.numel()]
+                if l.kind == "stem":
+                    l.dwq_col = self._dwq_arena[o + l.w.numel(): o + sz]
+                o += sz
+            self._dwq_layers = len(self.layers)
+            self._gtable_key = None
+        self._dwq_arena.zero_()
+
+    def _finalize_pending(self):
+        if not self._pending:
+            return
+        for l in self._pending:
+            self._ensure_grad(l)
+        key = tuple((id(l), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr()) for l in self._pending)
+        if getattr(self, "_gtable_key", None) != key:
+            arr = (L.FrostGDesc * len(self._pending))()
+            for i, l in enumerate(self._pending):
+                arr[i] = L.FrostGDesc(l.dwq.data_ptr(), l.w.data_ptr(), l.gamma.data_ptr(), l.sigma.data_ptr(), l.qw.data_ptr(),
+                                      l.coef.data_ptr(), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr(),
+                                      l.cout, l.cin_g * l.kk, l.cpad, 0)
+            self._gtable = L.struct_to_tensor(arr, self.device)
+            self._gtable_key = key
+        call("frost_weight_grad_finalize_table", ptr(self._gtable), len(self._pending), stream())
+        self._pending = []
 
     @staticmethod
     def _ensure_grad(l):
@@ -356,17 +392,11 @@ class Engine:
     def _conv_backward(self, l, x, y):
         self._ensure_grad(l)
         gout = y.grad
-        if l.dwq is None:
-            l.dwq = torch.empty(l.w.numel(), dtype=torch.float32, device=self.device)
-        l.dwq.zero_()
         dc = torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
         s = stream()
         if l.kind in ("pw", "stem"):
             dwq_final = l.dwq
             if l.kind == "stem":
-                if getattr(l, "dwq_col", None) is None:
-                    l.dwq_col = torch.empty(l.cout * 40, dtype=torch.float32, device=self.device)
-                l.dwq_col.zero_()
                 l.dwq, dwq_final = l.dwq_col, l.dwq
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout)
             # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
@@ -399,8 +429,11 @@ class Engine:
                 gx, acc = self._grad_slot(x)
                 call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s,
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
-        call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
-             l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
+        if self.on_layer_grads is None:
+            self._pending.append(l)        # single GPU: all layers finalized by one table launch at the end of the backward
+        else:
+            call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
+                 l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
         y.grad = None
 
 

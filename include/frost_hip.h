@@ -107,11 +107,7 @@ int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pac
 int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
                       int w, int c, int k, int stride, int mode, void* stats, const float* coef, const float* qrec_y,
                       int relu, int8_t* y, void* stream);
-/* replaces: stem 3x3 s2 conv 3->cout (frostnet.py:277); x NHWC with cpad_in=4 */
-int frost_stem_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
-                        int w, int cout, int mode, void* stats, const float* coef, const float* qrec_y, int relu,
-                        int8_t* y, void* stream);
-/* stem as im2col + pointwise: 3x3/s2/p1 patches of the 4 B/pixel image -> [npix_out][40] bytes (k = tap*4 + c); the stem
+/* replaces: stem 3x3 s2 conv 3->cout (frostnet.py:277), as im2col + pointwise: 3x3/s2/p1 patches of the 4 B/pixel image -> [npix_out][40] bytes (k = tap*4 + c); the stem
  * then runs on frost_pw_conv_fwd / _bwd / frost_pw_wgrad with cin = 40; frost_stem_wgrad_remap maps dWq back to OIHW. */
 int frost_stem_im2col(const int8_t* x, const float* qrec_x, int n, int h, int w, int8_t* out, void* stream);
 int frost_stem_wgrad_remap(const float* dwq_col, int cout, int cin_g, float* dwq, void* stream);
@@ -160,14 +156,19 @@ int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_
                    int stride, uint16_t* dx, int accumulate, void* stream);
 int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                    int stride, float* dwq, void* stream);
-int frost_stem_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h,
-                        int w, int cout, int pass, float* coef, const float* qrec_y, int relu, const uint16_t* gout,
-                        float* dwq, void* stream);
 /* fold-path: dW = dWq*mask*sf ; dgamma = S2*vfrac + sum(dWq*mask*W)/sigma_r ; dbeta = S1  (SURVEY H-5) */
 /* sigma_r[c] = sqrt(running_var+eps) as used by THIS step's forward (frost_save_sigma runs before the update) */
 int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,
                                const float* qrec_w, const float* coef, int cout, int cin_g, int kk, int cpad,
                                float* dw, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* the same for a table of layers in one launch (device-resident descriptors; single-GPU path, where nothing waits on
+ * per-layer gradients; the data-parallel path keeps the per-layer call so the bucketed all-reduce can start early) */
+typedef struct FrostGDesc {
+  const float* dwq; const float* w; const float* gamma; const float* sigma_r; const float* qw; const float* coef;
+  float* dw; float* dgamma; float* dbeta;
+  int32_t cout, per, cpad, reserved;
+} FrostGDesc;
+int frost_weight_grad_finalize_table(const FrostGDesc* descs, int nlayers, void* stream);
 int frost_save_sigma(const FrostWDesc* descs, float* const* outs, int nlayers, void* stream);
 /* STE mask of the logits' activation fake-quant: out = g * [0 <= rint(raw/s)+zp <= 255] */
 int frost_mask_logits(const float* g, const float* raw, const float* qrec_y, int64_t n, float* out, void* stream);
