@@ -459,46 +459,6 @@ extern "C" int frost_avgpool(const int8_t* x, const float* qrec_x, int n, int hw
   hipLaunchKernelGGL(k_avgpool, dim3(grid_for((int64_t)n * c, 256)), dim3(256), 0, as_stream(stream), x, qrec_x, n, hw, c, drop_mask, y);
   return frost_check_launch("avgpool");
 }
-// classifier GEMM: y[n][o] = s_w * sum_k x[n][k]*wq[o][k] + bias[o]; 64x64 tile, fp32 VALU through LDS
-__global__ __launch_bounds__(256) void k_classifier_fwd(const float* __restrict__ x, const int8_t* __restrict__ wq,
-                                                        const float* qw, const float* __restrict__ bias, int n, int cin,
-                                                        int nclass, float* __restrict__ y) {
-  __shared__ float xs[64][33]; __shared__ float ws[64][33];
-  int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < cin; k0 += 32) {
-    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-      int r = i >> 5, k = i & 31;
-      xs[r][k] = (r0 + r < n && k0 + k < cin) ? x[(int64_t)(r0 + r) * cin + k0 + k] : 0.0f;
-      ws[r][k] = (c0 + r < nclass && k0 + k < cin) ? (float)wq[(int64_t)(c0 + r) * cin + k0 + k] : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = xs[ty * 4 + i][k]; b[i] = ws[tx * 4 + i][k]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-  float sw = qw[FROST_Q_SCALE];
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
-    int r = r0 + ty * 4 + i, c = c0 + tx * 4 + j;
-    if (r < n && c < nclass) y[(int64_t)r * nclass + c] = acc[i][j] * sw + bias[c];
-  }
-}
-extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
-                                    int cin, int nclass, float* y, void* stream) {
-  hipLaunchKernelGGL(k_classifier_fwd, dim3((nclass + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x, wq,
-                     qrec_w, bias, n, cin, nclass, y);
-  return frost_check_launch("classifier_fwd");
-}
-
 // ------------------------------------------------------------------------------------------------ stem im2col
 // 3x3 stride-2 pad-1 patches of the 4-byte-per-pixel quantised image -> [npix_out][40] (36 patch bytes + 4 zero-point
 // bytes), so the stem runs on the pointwise int8-MFMA kernels (K = 40) forward AND backward (wgrad = plain pw wgrad).

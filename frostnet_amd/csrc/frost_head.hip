@@ -2,41 +2,74 @@
 #include "frost_common.h"
 
 // ---------------------------------------------------------------------------------------------- small GEMM
-// C[M][N] (+)= alpha * sum_k A(m,k) * B(k,n);  A(m,k) = a[m*ars + k*acs], B(k,n) = b[k*brs + n*bcs]
+// C[M][N] (+)= alpha * sum_k A(m,k) * B(k,n) (+ bias[n]);  A(m,k) = a[m*ars + k*acs], B(k,n) = b[k*brs + n*bcs]
+// fp32 operands on the f32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation, the VALU fmaf chain's
+// numerics at 16x its rate).  64x64 tile per workgroup, each of the 4 waves a 32x32 quadrant; 16-deep K stages through
+// LDS with the next stage register-prefetched.  TB = int8_t: the fake-quantised classifier weight, dequantised on load.
 template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
                                                int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
-                                               float alpha, float* __restrict__ c, int accumulate) {
-  __shared__ float as[32][65]; __shared__ float bs[32][65];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+                                               float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate) {
+  __shared__ float as[64][17]; __shared__ float bs[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, lk = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-      int r, k;
-      if (acs == 1) { k = i & 31; r = i >> 5; } else { r = i & 63; k = i >> 6; }
-      as[k][r] = (m0 + r < M && k0 + k < K) ? (float)a[(int64_t)(m0 + r) * ars + (int64_t)(k0 + k) * acs] : 0.0f;
-      if (brs == 1) { k = i & 31; r = i >> 5; } else { r = i & 63; k = i >> 6; }
-      bs[k][r] = (n0 + r < N && k0 + k < K) ? (float)b[(int64_t)(k0 + k) * brs + (int64_t)(n0 + r) * bcs] : 0.0f;
+  v4f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  // staging roles: 1024 elements per operand per stage = 4 per thread; walk the operand along its unit-stride dimension
+  int ar[4], ak[4], br[4], bk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + q * 256;
+    if (acs == 1) { ak[q] = i & 15; ar[q] = i >> 4; } else { ar[q] = i & 63; ak[q] = i >> 6; }
+    if (brs == 1) { bk[q] = i & 15; br[q] = i >> 4; } else { br[q] = i & 63; bk[q] = i >> 6; }
+  }
+  float pa[4], pb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pa[q] = (m0 + ar[q] < M && k0 + ak[q] < K) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
+      pb[q] = (n0 + br[q] < N && k0 + bk[q] < K) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 16) {
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      float av[4], bv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = as[k][ty * 4 + i]; bv[i] = bs[k][tx * 4 + i]; }
+    for (int q = 0; q < 4; ++q) { as[ar[q]][ak[q]] = pa[q]; bs[bk[q]][br[q]] = pb[q]; }
+    __syncthreads();
+    if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int k4 = 0; k4 < 4; ++k4) {
+      float af[2], bf[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+      for (int i = 0; i < 2; ++i) { af[i] = as[wm * 32 + i * 16 + l16][k4 * 4 + lk]; bf[i] = bs[k4 * 4 + lk][wn * 32 + i * 16 + l16]; }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
   }
   const float al = alpha * (alpha_ptr ? *alpha_ptr : 1.0f);
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
-    int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-    if (m < M && n < N) { float v = acc[i][j] * al; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
-  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * lk + r, n = n0 + wn * 32 + j * 16 + l16;
+        if (m < M && n < N) { float v = acc[i][j][r] * al; if (bias) v += bias[n]; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
+      }
+}
+// classifier forward: y[n][o] = s_w * sum_k x[n][k] * wq[o][k] + bias[o]   (frostnet.py:299 on fake-quantised weights)
+extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
+                                    int cin, int nclass, float* y, void* stream) {
+  hipLaunchKernelGGL((k_sgemm<float, int8_t>), dim3((nclass + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x,
+                     (int64_t)cin, (int64_t)1, wq, (int64_t)1, (int64_t)cin, n, nclass, cin, qrec_w + FROST_Q_SCALE, 1.0f, bias, y, 0);
+  return frost_check_launch("classifier_fwd");
 }
 
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int n, int m, float* __restrict__ out) {
@@ -63,11 +96,11 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
                               uint16_t* gx, float* scratch_dpool, void* stream) {
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (nclass + 63) / 64), dim3(256), 0, s, dlogits_masked,
-                     (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, dwq, 0);
+                     (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, (const float*)nullptr, dwq, 0);
   hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
   hipLaunchKernelGGL((k_sgemm<float, int8_t>), dim3((cin + 63) / 64, (n + 63) / 64), dim3(256), 0, s, dlogits_masked,
                      (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass, qrec_w + FROST_Q_SCALE, 1.0f,
-                     scratch_dpool, 0);
+                     (const float*)nullptr, scratch_dpool, 0);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("head_bwd");
