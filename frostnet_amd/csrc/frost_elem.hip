@@ -115,7 +115,15 @@ __global__ __launch_bounds__(256) void k_minmax_strided(const float* __restrict_
 }
 extern "C" int frost_minmax_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
                                   int64_t sw, float* out2, void* stream) {
-  hipLaunchKernelGGL(k_minmax_strided, dim3(grid_for((int64_t)n * c * h * w, 1024, 2048)), dim3(256), 0,
+  // min/max is order-free: a dense tensor (NCHW-contiguous or channels_last) is scanned linearly with 16-byte loads
+  const int64_t tot = (int64_t)n * c * h * w;
+  const bool nchw = (sw == 1 && sh == w && sc == (int64_t)h * w && sn == (int64_t)c * h * w);
+  const bool nhwc = (sc == 1 && sw == c && sh == (int64_t)w * c && sn == (int64_t)h * w * c);
+  if ((nchw || nhwc) && ((uintptr_t)x & 15) == 0) {
+    hipLaunchKernelGGL(k_minmax_f32, dim3(grid_for(tot, 16384, 1024)), dim3(256), 0, as_stream(stream), x, tot, out2);
+    return frost_check_launch("minmax_input");
+  }
+  hipLaunchKernelGGL(k_minmax_strided, dim3(grid_for(tot, 1024, 2048)), dim3(256), 0,
                      as_stream(stream), x, n, c, h, w, sn, sc, sh, sw, out2);
   return frost_check_launch("minmax_input");
 }
