@@ -23,29 +23,40 @@ ALGO_BYTES_PER_IMG = 45_593_016
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def cpu_baseline(batch=8, res=224):
-    """Reference-path stand-in timed on the host cores: the CPU oracle (restated torch eager QAT graph, kind 'port')."""
+def cpu_baseline(res=224):
+    """Reference-path stand-in timed on the host cores: the CPU oracle (restated torch eager QAT graph, kind 'port').
+    Bounded sample: a 2-image probe step sizes the timed step to about 15 s of CPU work (2..32 images)."""
     from oracle import frost_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))          # more intra-op threads than usable cores makes the torch CPU kernels collapse
+    torch.set_num_threads(cores)
     cfg = O.net_cfg("large", 1.0)
-    P, B = O.make_state(O.float_state_spec(cfg), 5000, True)
-    qs = O.QState(B)
-    x = torch.from_numpy(O.synth((batch, 3, res, res), 77))
-    tgt = torch.randint(0, 1000, (batch,))
     hp = dict(lr=5e-3, momentum=0.9, weight_decay=1e-5, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
-    states = {k: {} for k in P}
-    t0 = time.time()
-    y = O.frostnet_forward(P, qs, cfg, x, True, True)
-    torch.nn.functional.cross_entropy(y, tgt).backward()
-    with torch.no_grad():
-        for k, p in P.items():
-            g = p.grad
-            O.gradboost_step("QSGD", p, g, states[k], dict(hp, weight_decay=O.param_group_rule(tuple(p.shape), 1e-5)),
-                             boost=True, noise=torch.empty_like(p).exponential_(), coin=torch.randint(0, 2, p.shape).float())
-    dt = time.time() - t0
-    return dict(value=batch / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
+
+    def one_step(batch):
+        P, B = O.make_state(O.float_state_spec(cfg), 5000, True)
+        qs = O.QState(B)
+        x = torch.from_numpy(O.synth((batch, 3, res, res), 77))
+        tgt = torch.randint(0, 1000, (batch,))
+        states = {k: {} for k in P}
+        t0 = time.time()
+        y = O.frostnet_forward(P, qs, cfg, x, True, True)
+        torch.nn.functional.cross_entropy(y, tgt).backward()
+        with torch.no_grad():
+            for k, p in P.items():
+                O.gradboost_step("QSGD", p, p.grad, states[k], dict(hp, weight_decay=O.param_group_rule(tuple(p.shape), 1e-5)),
+                                 boost=True, noise=torch.empty_like(p).exponential_(), coin=torch.randint(0, 2, p.shape).float())
+        return time.time() - t0
+
+    probe = one_step(2)
+    batch = int(max(2, min(32, 15.0 / (probe / 2))))
+    dt = one_step(batch)
+    return dict(value=batch / dt, unit="images/sec", cores=cores, kind="port",
                 sample=f"1 step, batch {batch} @ {res}x{res}, FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU "
-                       f"kernels via oracle/frost_oracle.py, {dt:.1f} s")
+                       f"kernels via oracle/frost_oracle.py, {dt:.1f} s (after a 2-image probe step of {probe:.1f} s)")
 
 
 def pmc_traffic(label, batch):
