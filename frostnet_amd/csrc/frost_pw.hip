@@ -34,6 +34,7 @@ struct PwP {
   uint8_t* stats; int relu;
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
   int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
+  int nbuf;                       // LDS tile buffers of the DMA path: 2, or 1 when no workgroup gets a second tile
   int csplit, nbt;                // channel-group split across workgroups (few-tile layers), workgroups per split
   int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
   int cres;                       // BN/quant coefficient rows (folded) live in LDS even when the weights do not (RES)
@@ -42,9 +43,12 @@ struct PwP {
 };
 
 #define BP 128
+#ifndef PW_APF
+#define PW_APF(MODE, WP) ((WP) == 2 || ((MODE) == M_BDC && (WP) == 8) || (((MODE) == M_STATS || (MODE) == M_EMIT || (MODE) == M_DGRAD) && (WP) != 2))
+#endif
 // channel tiles (16 channels each) a wave carries per channel group: the 4-wave-wide channel split (WP == 2) holds 4 pixel
 // subtiles per channel tile, so its backward passes carry 2 (4 would spill the epilogue state: measured 30% slower)
-#define PW_MI(MODE, WP) (((WP) == 2 && ((MODE) == M_BRED || (MODE) == M_BDC)) ? 2 : 4)
+#define PW_MI(MODE, WP) (((WP) == 2) ? 2 : 4)
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
@@ -116,11 +120,12 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
   constexpr int MI = PW_MI(MODE, WP);
+  constexpr bool APF = !RES && PW_APF(MODE, WP);          // next-K-step weight-fragment prefetch
   constexpr bool BF = (MODE == M_DGRAD);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const bool gl = p.gl != 0;
   uint8_t* xs = smem;
-  const int xs_bytes = gl ? 2 * p.tile_bytes + 64 : BP * p.kstr + 64;
+  const int xs_bytes = gl ? p.nbuf * p.tile_bytes + 64 : BP * p.kstr + 64;
   // io region (full-tile kernels of small layers): every global access of the pass is a contiguous 16 B/lane stream --
   //   reduce/dc: the gout tile [128][cout] bf16 arrives by DMA (two buffers); dc is written IN PLACE over it and leaves as a
   //   linear copy;  emit/dgrad: the y / dx tile is assembled in LDS and leaves as a linear copy.
@@ -282,6 +287,14 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         }
         if (mi_n > 0) {
           const int ks_n = kcw_pad >> 6; const int ks0 = kc0 >> 6;
+          // non-resident weights come from L2 (~400+ cycles): the fragments of K-step ks+1 are requested before the MFMAs of ks
+          auto load_a = [&](int ks, v4i (&dst)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+              if (m < mi_n) dst[m] = *(const v4i*)((RES ? wl : p.wpack) + ((((int64_t)(ct0 + m) * p.KS + ks0 + ks) * 64 + lane) << 4));
+          };
+          v4i afr[MI], afn[MI];
+          if (APF) load_a(0, afr);
           for (int ks = 0; ks < ks_n; ++ks) {
             v4i bfr[NT];
 #pragma unroll
@@ -290,10 +303,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
               if (al16) bfr[t] = *(const v4i*)fp;
               else { const int2 lo = *(const int2*)fp, hi = *(const int2*)(fp + 8); bfr[t] = (v4i){lo.x, lo.y, hi.x, hi.y}; }
             }
-            v4i afr[MI];
-#pragma unroll
-            for (int m = 0; m < MI; ++m)
-              if (m < mi_n) afr[m] = *(const v4i*)((RES ? wl : p.wpack) + ((((int64_t)(ct0 + m) * p.KS + ks0 + ks) * 64 + lane) << 4));
+            if (APF) { if (ks + 1 < ks_n) load_a(ks + 1, afn); } else load_a(ks, afr);
 #pragma unroll
             for (int m = 0; m < MI; ++m) {
               if (m < mi_n) {
@@ -304,6 +314,10 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
                   else acci[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], bfr[t], acci[m][t], 0, 0, 0);                        // D[chan][pix]
                 }
               }
+            }
+            if (APF) {
+#pragma unroll
+              for (int m = 0; m < MI; ++m) afr[m] = afn[m];
             }
           }
         }
@@ -543,11 +557,21 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   static bool attr_set = false;
   if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
-  static int occ_cache = 0; static size_t occ_lds = (size_t)-1;
-  if (occ_lds != lds) {   // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
+  auto occ_for = [](size_t bytes) {     // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
+    static size_t key[2] = {(size_t)-1, (size_t)-1}; static int val[2] = {0, 0};
+    for (int i = 0; i < 2; ++i) if (key[i] == bytes) return val[i];
     int occ = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT>, 512, lds) != hipSuccess || occ < 1) occ = 1;
-    occ_cache = occ > 4 ? 4 : occ; occ_lds = lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT>, 512, bytes) != hipSuccess || occ < 1) occ = 1;
+    if (occ > 4) occ = 4;
+    key[1] = key[0]; val[1] = val[0]; key[0] = bytes; val[0] = occ;
+    return occ;
+  };
+  int occ_cache = occ_for(lds);
+  p.nbuf = 2;
+  if (p.gl && !p.io) {      // a launch in which every workgroup gets one tile has no use for the second buffer: trade it for residency
+    const size_t lds1 = lds - (size_t)p.tile_bytes;
+    const int occ1 = occ_for(lds1);
+    if (tile_end - tile0 <= (int64_t)256 * occ1) { p.nbuf = 1; lds = lds1; occ_cache = occ1; }
   }
   PwP q = p; q.tile0 = tile0; q.ntiles = tile_end;
   const int64_t n = tile_end - tile0;
