@@ -1,0 +1,51 @@
+"""Full-size path equivalence on the GPU: the kernels choose resident weights, DMA / LDS-staged tile I/O, channel-group
+splitting, depthwise tile geometries and fused passes by layer size, so the small teacher-forced golden layers do not reach
+them.  Here one seeded layer runs at a size where the fast paths engage, once with the defaults and once with every such
+path switched off (environment switches read by libfrost_hip.so at load, hence one subprocess per configuration), and the
+two results must agree: quantised outputs identical up to rare rounding-boundary flips (the fp32 part of the variance sum
+depends on the tile-to-lane assignment), statistics to 1e-6, gradients to bf16/atomic-order noise."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CSPLIT="0", FROST_DW_GEO="0", FROST_DW_FUSE="0")
+CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
+         ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
+         ("dw", 144, 144, 5, 2, 56, 64)]
+
+
+def run(tmp, tag, case, env_extra):
+    out = os.path.join(tmp, f"{tag}.npz")
+    env = dict(os.environ, **env_extra)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "layer_digest.py"), out] + [str(v) for v in case], check=True, env=env,
+                   cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return np.load(out)
+
+
+def bf16_to_f32(a):
+    return (a.astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def relerr(a, b):
+    a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "_".join(str(v) for v in c))
+def test_fast_paths_match_plain_paths(case, tmp_path):
+    fast = run(str(tmp_path), "fast", case, {})
+    plain = run(str(tmp_path), "plain", case, PLAIN)
+    d = np.abs(fast["y"].astype(np.int16) - plain["y"].astype(np.int16))
+    assert d.max() <= 1 and float((d > 0).mean()) <= 1e-4, ("y", int(d.max()), float((d > 0).mean()))
+    np.testing.assert_allclose(fast["qy"][:3], plain["qy"][:3], rtol=1e-6)          # observer min, max, scale
+    assert fast["qy"][3].tobytes() == plain["qy"][3].tobytes()                         # zero point (integer bits)
+    np.testing.assert_allclose(fast["rm"], plain["rm"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(fast["rv"], plain["rv"], rtol=1e-6, atol=1e-7)
+    assert relerr(bf16_to_f32(fast["dx"]), bf16_to_f32(plain["dx"])) <= 2e-3
+    for k in ("dw", "dgamma", "dbeta"):
+        assert relerr(fast[k], plain[k]) <= 1e-3, k
