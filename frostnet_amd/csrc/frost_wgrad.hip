@@ -13,8 +13,12 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 #define WT 64
 #define KPIX 128
+#ifndef RSD
 #define RSD 136   // dc LDS row stride (bytes): 64 bf16 + 8
+#endif
+#ifndef RSX
 #define RSX 72    // x  LDS row stride (bytes): 64 int8 + 8  (8-byte aligned rows for the 8-byte transpose reads)
+#endif
 
 __device__ __forceinline__ uint32_t pack_trunc_bf16(float lo, float hi) {   // exact for |integers| <= 256
   return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
@@ -125,8 +129,12 @@ __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict_
 // reduction, and 32 accumulator + 24 prefetch registers per lane, so two 8-wave workgroups are resident per CU (the 4-wave
 // version needed 224 VGPRs: 8 waves per CU, latency-bound).
 #define BT 128
+#ifndef RSD2
 #define RSD2 264   // 128 bf16 + 8 bytes
+#endif
+#ifndef RSX2
 #define RSX2 136   // 128 int8 + 8 bytes
+#endif
 __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
                                                          int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 51 KB
