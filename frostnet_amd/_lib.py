@@ -22,6 +22,12 @@ class FrostWDesc(C.Structure):
                 ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
 
 
+class FrostIDesc(C.Structure):
+    _fields_ = [("w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("pack", P), ("biasf", P),
+                ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32), ("kind", C.c_int32),
+                ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
+
+
 class FrostGDesc(C.Structure):
     _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
                 ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32)]
@@ -70,6 +76,14 @@ _PROTOS = {
     "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
     "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
     "frost_weight_grad_finalize_table": [P, I, P],
+    "frost_infer_weight_prep": [P, I, P],
+    "frost_infer_stem_im2col": [P, I, I, I, L, L, L, L, P, P],
+    "frost_infer_pw": [P, P, P, L, I, I, I, P, P],
+    "frost_infer_dw": [P, P, P, I, I, I, I, I, I, I, P, P],
+    "frost_infer_cat": [P, I, P, I, L, P, P],
+    "frost_infer_add": [P, P, L, P, P],
+    "frost_infer_avgpool": [P, I, I, I, P, P],
+    "frost_linear_f32": [P, P, P, I, I, I, P, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

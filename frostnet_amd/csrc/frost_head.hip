@@ -64,6 +64,11 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
         if (m < M && n < N) { float v = acc[i][j][r] * al; if (bias) v += bias[n]; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
       }
 }
+extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
+  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((o + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x, (int64_t)k, (int64_t)1, w,
+                     (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, 1.0f, bias, y, 0);
+  return frost_check_launch("linear_f32");
+}
 // classifier forward: y[n][o] = s_w * sum_k x[n][k] * wq[o][k] + bias[o]   (frostnet.py:299 on fake-quantised weights)
 extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
                                     int cin, int nclass, float* y, void* stream) {

@@ -217,6 +217,18 @@ class FrostNet(_FrostBase):
     # GPU raises, so a benchmark can never silently measure torch eager.
     allow_torch_eager_float = False
 
+    def hip_infer_bf16(self, x):
+        """bf16 inference of the float (un-fused, not QAT-prepared) model on the HIP kernels (BASELINE.json config c2):
+        eval-mode BatchNorm folded, NHWC bf16 activations, fp32 accumulation.  See frostnet_amd/infer.py."""
+        if self._is_qat_prepared():
+            raise RuntimeError("hip_infer_bf16 is the float model's inference path; a QAT-prepared model runs model(x)")
+        inf = self.__dict__.get("_bf16_infer")
+        if inf is None or inf.device != next(self.parameters()).device:
+            from .infer import Bf16Inference
+            inf = Bf16Inference(self)
+            self.__dict__["_bf16_infer"] = inf
+        return inf(x)
+
     def forward(self, x):
         if x.is_cuda and not (self.allow_torch_eager_float and not self._is_qat_prepared()):
             return self.hip_runner().forward(x)

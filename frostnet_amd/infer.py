@@ -1,0 +1,135 @@
+"""bf16 inference of the FLOAT (not fake-quantised) FrostNet on the HIP kernels -- BASELINE.json config c2.
+
+Reference semantics: `model.eval(); model(x)` of a float `frostnet_*` model (`frostnet.py:14-60, 108-121, 271-300`): Conv ->
+BatchNorm(running stats) -> ReLU per layer, block wiring squeeze -> cat -> conv1 -> conv2 -> reduce_conv -> (+x), global average
+pool -> (dropout is identity in eval) -> 1x1 classifier.  Here BatchNorm is folded into the convolution once per call
+(`frost_infer_weight_prep`), activations are NHWC bf16, accumulation is fp32.  Deviation from the reference: bf16 storage of
+weights and activations (the c2 configuration asks for bf16); the parity test holds the logits to the fp32 oracle within bf16
+tolerance.  No CPU / torch-eager fallback: a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import call, ptr, stream
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class _ILayer:
+    __slots__ = ("kind", "k", "stride", "relu", "cout", "cin_g", "cpad", "kpad", "pack", "biasf", "conv", "bn")
+
+    def __init__(self, seq, relu, dev, stem=False):
+        conv, bn = seq[0], seq[1]
+        if not isinstance(conv, torch.nn.Conv2d) or not isinstance(bn, torch.nn.BatchNorm2d):
+            raise RuntimeError("bf16 inference expects the un-fused float model (Conv2d + BatchNorm2d per layer)")
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.cout, self.cin_g, self.k = conv.out_channels, conv.in_channels // conv.groups, conv.kernel_size[0]
+        self.stride = conv.stride[0]
+        self.kind = 2 if stem else (1 if conv.groups > 1 else 0)
+        self.cpad = round_up(self.cout, 16)
+        if self.kind == 1:
+            self.kpad = 0
+            self.pack = torch.zeros(self.k * self.k * self.cpad, dtype=torch.float32, device=dev)
+        else:
+            self.kpad = 64 if stem else round_up(self.cin_g, 32)
+            self.pack = torch.zeros((self.cpad // 16) * (self.kpad // 32) * 64 * 8, dtype=torch.int16, device=dev)
+        self.biasf = torch.zeros(self.cpad, dtype=torch.float32, device=dev)
+
+    def desc(self):
+        bn, w = self.bn, self.conv.weight
+        return L.FrostIDesc(w.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                            bn.running_var.data_ptr(), self.pack.data_ptr(), self.biasf.data_ptr(), self.cout, self.cin_g,
+                            self.k * self.k, self.kind, self.cpad, self.kpad, 0, 0)
+
+
+class Bf16Inference:
+    """Binds a float FrostNet (eval mode) to the bf16 HIP inference kernels.  `__call__(x)` -> fp32 logits [N, nclass]."""
+
+    def __init__(self, model):
+        L.load_library()
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("Bf16Inference needs the model on the GPU (no CPU fallback on the product path)")
+        self.model, self.device = model, p.device
+        self.layers = []
+        self.stem = self._add(model.conv1.conv, True, stem=True)
+        self.blocks = []
+        for stage in (model.layer1, model.layer2, model.layer3, model.layer4, model.layer5):
+            for blk in stage:
+                ent = dict(blk=blk, squeeze=None, conv1=None)
+                if blk.expand_ratio != 1:
+                    if blk.block_type == "CAS":
+                        ent["squeeze"] = self._add(blk.squeeze_conv.conv, True)
+                    ent["conv1"] = self._add(blk.conv1.conv, True)
+                ent["conv2"] = self._add(blk.conv2.conv, True)
+                ent["reduce"] = self._add(blk.reduce_conv.conv, False)
+                self.blocks.append(ent)
+        self.last = self._add(model.last_layer.conv, True)
+        self.fc = model.classifier[2]
+        arr = (L.FrostIDesc * len(self.layers))()
+        for i, l in enumerate(self.layers):
+            arr[i] = l.desc()
+        self._table = L.struct_to_tensor(arr, self.device)
+
+    def _add(self, seq, relu, stem=False):
+        l = _ILayer(seq, relu, self.device, stem)
+        self.layers.append(l)
+        return l
+
+    # ---------------------------------------------------------------------------------------------- kernels
+    def _pw(self, l, x, npix, cin):
+        y = torch.empty(npix * l.cout + 64, dtype=torch.int16, device=self.device)
+        call("frost_infer_pw", ptr(x), ptr(l.pack), ptr(l.biasf), npix, cin, l.cout, int(l.relu), ptr(y), stream())
+        return y
+
+    def _dw(self, l, x, n, h, w):
+        pad = (l.k - 1) // 2
+        ho, wo = (h + 2 * pad - l.k) // l.stride + 1, (w + 2 * pad - l.k) // l.stride + 1
+        y = torch.empty(n * ho * wo * l.cout + 64, dtype=torch.int16, device=self.device)
+        call("frost_infer_dw", ptr(x), ptr(l.pack), ptr(l.biasf), n, h, w, l.cout, l.k, l.stride, int(l.relu), ptr(y), stream())
+        return y, ho, wo
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if self.model.training:
+            raise RuntimeError("bf16 inference is the eval-mode graph: call model.eval() first")
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or x.device != self.device:
+            raise ValueError("expected an fp32 (N,3,H,W) tensor on the model's device")
+        n, _, h, w = x.shape
+        call("frost_infer_weight_prep", ptr(self._table), len(self.layers), stream())
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        col = torch.empty(n * ho * wo * 64 + 64, dtype=torch.int16, device=self.device)
+        call("frost_infer_stem_im2col", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col), stream())
+        npix = n * ho * wo
+        a, c, h, w = self._pw(self.stem, col, npix, 64), self.stem.cout, ho, wo
+        for ent in self.blocks:
+            blk = ent["blk"]
+            x_in, c_in, npix = a, c, n * h * w
+            if ent["conv1"] is not None:
+                if ent["squeeze"] is not None:
+                    s = self._pw(ent["squeeze"], a, npix, c)
+                    cs = ent["squeeze"].cout
+                    cat = torch.empty(npix * (cs + c) + 64, dtype=torch.int16, device=self.device)
+                    call("frost_infer_cat", ptr(s), cs, ptr(a), c, npix, ptr(cat), stream())     # cat([squeezed, x], 1)
+                    a, c = cat, cs + c
+                a, c = self._pw(ent["conv1"], a, npix, c), ent["conv1"].cout
+            a, h2, w2 = self._dw(ent["conv2"], a, n, h, w)
+            npix2 = n * h2 * w2
+            a, c = self._pw(ent["reduce"], a, npix2, c), ent["reduce"].cout
+            if not blk.reduction:
+                out = torch.empty_like(a)
+                call("frost_infer_add", ptr(x_in), ptr(a), npix2 * c, ptr(out), stream())
+                a = out
+            h, w = h2, w2
+        npix = n * h * w
+        a, c = self._pw(self.last, a, npix, c), self.last.cout
+        pooled = torch.empty(n, c, dtype=torch.float32, device=self.device)
+        call("frost_infer_avgpool", ptr(a), n, h * w, c, ptr(pooled), stream())
+        logits = torch.empty(n, self.fc.out_channels, dtype=torch.float32, device=self.device)
+        wfc = self.fc.weight.view(self.fc.out_channels, -1)
+        call("frost_linear_f32", ptr(pooled), ptr(wfc), ptr(self.fc.bias), n, c, self.fc.out_channels, ptr(logits), stream())
+        return logits

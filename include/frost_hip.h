@@ -182,6 +182,30 @@ int frost_head_bwd(const float* dlogits_masked, const float* pooled, const int8_
                    float* scratch_dpool, void* stream);
 
 /* ---- GradBoost optimizers (optimizer.py:121-206, 264-359, 411-512, 564-667) ------------------------- */
+/* ---- bf16 inference of the float model (BASELINE.json config c2) ------------------------------------------- */
+/* replaces (eval mode): frostnet.py:14-60 ConvBNReLU/ConvBN with BatchNorm folded, :108-121 block wiring, :295-299 head.
+ * Activations NHWC bf16; fp32 accumulation; one bf16 rounding per layer output. */
+typedef struct FrostIDesc {
+  const float* w;        /* OIHW fp32                                                            */
+  const float* gamma; const float* beta; const float* rmean; const float* rvar;   /* BN (gamma NULL: no BN, beta = conv bias or NULL) */
+  void* pack;            /* kind 0/2: bf16 MFMA A-fragments [cpad/16][kpad/32][64][8]; kind 1: fp32 [kk][cpad] */
+  float* biasf;          /* [cpad] folded bias                                                   */
+  int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem (im2col K = tap*4 + c)       */
+  int32_t cpad, kpad, reserved0, reserved1;
+} FrostIDesc;
+int frost_infer_weight_prep(const FrostIDesc* descs, int nlayers, void* stream);
+int frost_infer_stem_im2col(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, uint16_t* out,
+                            void* stream);
+int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
+                   uint16_t* y, void* stream);
+int frost_infer_dw(const uint16_t* x, const float* wf, const float* biasf, int n, int h, int w, int c, int k, int stride, int relu,
+                   uint16_t* y, void* stream);
+int frost_infer_cat(const uint16_t* a, int ca, const uint16_t* b, int cb, int64_t npix, uint16_t* y, void* stream);
+int frost_infer_add(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* y, void* stream);
+int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void* stream);
+/* y[n][o] = sum_k x[n][k] * w[o][k] + bias[o], fp32 on the f32 MFMA (classifier of the float model) */
+int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream);
+
 typedef struct FrostOptTensor {
   float* p; float* g; float* exp_min; float* exp_max; float* coin; float* buf0; float* buf1; float* buf2;
   int64_t n; float weight_decay; float lr; int32_t first_step; int32_t pad;
