@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     // ---------------------------------------------------------------- epilogue (lane-local, one channel)
     const int oyb = DW_SEL(su.r0, L.sb) + wy * RH, oxb = DW_SEL(su.c0, L.sb) + (L.colo - L.sb * SUBW);
     const bool subok = chok && DW_SEL(su.ok, L.sb);
+    int t1 = 0; double t2 = 0.0; int tmn = INT32_MAX, tmx = INT32_MIN;
 #pragma unroll
     for (int o = 0; o < RH; ++o) {
 #pragma unroll
@@ -355,12 +356,13 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         const bool valid = subok && (oyb + o) < p.ho && (oxb + r) < p.wo;
         const float v = (float)acc[o][r];
         const int lp = (wy * RH + o) * TWT + L.colo + r;          // pixel index inside the tile
-        if (MODE == D_STATS) {
-          if (valid) { st1 += (double)v; st2 += (double)v * (double)v; smn = fminf(smn, v); smx = fmaxf(smx, v); }
+        if (MODE == D_STATS) {     // exact int sum and min/max; sum of squares in double (v*v needs 40 bits)
+          const int vi = acc[o][r];
+          if (valid) { t1 += vi; t2 = fma((double)v, (double)v, t2); tmn = min(tmn, vi); tmx = max(tmx, vi); }
         } else if (MODE == D_EMIT) {
+          // q = clamp(rint(relu(y)/s) + zp, 0, 255): v_cvt_pk_u8_f32 saturates at both ends while converting
           const float yv = fmaf(cA, v, cB);
-          const float qf = fminf(fmaxf(rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf, 0.0f), 255.0f);
-          aux[lp * CBW + L.lc] = (uint8_t)(((int)qf - 128) & 255);
+          aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf, 0, 0u) ^ 0x80u) & 255u);
         } else {
           const float gq = bf2f(*(const uint16_t*)(aux + (lp * CBW + L.lc) * 2));
           const float tq = fmaf(cA, v, cB) * y_inv;
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         }
       }
     }
+    if (MODE == D_STATS) { st1 += (double)t1; st2 += t2; smn = fminf(smn, (float)tmn); smx = fmaxf(smx, (float)tmx); }
     if (MODE == D_EMIT || MODE == D_BDC) {
       __syncthreads();
       if (MODE == D_EMIT) copy_out_tile<1, NSUB, SUBW, CBW, false>(aux, (uint8_t*)p.y, tid, su, cb, p.ho, p.wo, p.c);
