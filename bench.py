@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB
 
 def cpu_baseline(res=224):
     """Reference-path stand-in timed on the host cores: the CPU oracle (restated torch eager QAT graph, kind 'port').
-    Bounded sample: a 2-image probe step sizes the timed step to about 15 s of CPU work (2..32 images)."""
+    Bounded sample: a 2-image probe step sizes the timed step to about 15 s of CPU work (2..128 images)."""
     from oracle import frost_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -52,7 +52,7 @@ def cpu_baseline(res=224):
         return time.time() - t0
 
     probe = one_step(2)
-    batch = int(max(2, min(32, 15.0 / (probe / 2))))
+    batch = int(max(2, min(128, 15.0 / (probe / 2))))
     dt = one_step(batch)
     return dict(value=batch / dt, unit="images/sec", cores=cores, kind="port",
                 sample=f"1 step, batch {batch} @ {res}x{res}, FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU "

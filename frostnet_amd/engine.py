@@ -417,9 +417,11 @@ class Engine:
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                  prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
-            if _DW_FUSE:
+            # dc pass + weight gradient in one sweep where the kernel's register state allows it (the library applies the same
+            # rule and would otherwise run the two kernels itself; calling them separately keeps the profiler tags per kernel)
+            if _DW_FUSE and l.stride == 1 and (l.k == 3 or (l.k == 5 and y.w <= 8)):
                 call("frost_dw_conv_bwd_dc_wgrad", *args, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(l.dwq), s,
-                     prof=("dw_bwd_dc", x.numel + 4 * y.numel))       # dc pass + weight gradient (one sweep where registers allow)
+                     prof=("dw_bwd_dc", 2 * x.numel + 4 * y.numel))
             else:
                 call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
                      prof=("dw_bwd_dc", x.numel + 4 * y.numel))
