@@ -24,6 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_WG_STREAM = os.environ.get("FROST_WG_STREAM", "1") != "0"  # pointwise weight gradients on a second stream (A/B switch)
 
 
 class Act:
@@ -141,6 +142,7 @@ class Engine:
         self.tape = []
         self._table = None
         self.on_layer_grads = None     # callback(layer) after a layer's parameter gradients are final (DP overlap)
+        self._side, self._keep = None, []
 
     # ------------------------------------------------------------------------------------------ plan
     def add_layer(self, layer):
@@ -312,6 +314,16 @@ class Engine:
         Parameter gradients are written (=, not +=) into l.w.grad / l.gamma.grad / l.beta.grad / l.bias.grad."""
         self._prepare_dwq()
         self._pending = []          # conv layers whose weight-gradient finalize is deferred to one table launch
+        # Pointwise weight gradients run on a second stream: nothing downstream needs them until the finalize at the end of the
+        # backward, and the short low-resolution kernels leave launch gaps and tails that an independent kernel can fill.
+        # Off when per-layer gradients are awaited (data parallel) and while the per-kernel profiler times the main stream.
+        self._side = None
+        if _WG_STREAM and self.on_layer_grads is None and L.PROFILER is None and self.device.type == "cuda":
+            if getattr(self, "_wg_stream", None) is None:
+                self._wg_stream = torch.cuda.Stream(device=self.device)
+            self._side = self._wg_stream
+            self._side.wait_stream(torch.cuda.current_stream())          # after the dwq arena fill
+            self._keep = []
         for entry in reversed(self.tape):
             kind = entry[0]
             if kind == "head":
@@ -347,7 +359,11 @@ class Engine:
                 call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
                      fa, ptr(gb), fb, stream(), prof=("add_bwd", 8 * a.numel))
                 y.grad = None
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)          # join: every weight gradient is accumulated
+            self._side = None
         self._finalize_pending()
+        self._keep = []
         self.tape = []
 
     def _prepare_dwq(self):
@@ -404,15 +420,23 @@ class Engine:
                  prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
             call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                  prof=("pw_bwd_dc", x.numel + 4 * y.numel))
+            if self._side is not None:      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
+                ev = torch.cuda.Event()
+                ev.record()
+                self._side.wait_event(ev)
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
                 call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s,
                      prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
-            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), s,
+            sw = s
+            if self._side is not None:      # dc (and x) stay referenced until the join
+                self._keep.append((dc, x.buf))
+                sw = C.c_void_p(self._side.cuda_stream)
+            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw,
                  prof=("pw_wgrad", 2 * y.numel + x.numel))
             if l.kind == "stem":
                 l.dwq = dwq_final
-                call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), s)
+                call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), sw)
         elif l.kind == "dw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
@@ -425,6 +449,7 @@ class Engine:
             else:
                 call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
                      prof=("dw_bwd_dc", x.numel + 4 * y.numel))
+                # (stays on the main stream: beside other work it slows both down -- measured -5 %)
                 call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
                      prof=("dw_wgrad", 2 * y.numel + x.numel))
             if x.needs_grad:
