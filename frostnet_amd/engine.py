@@ -24,7 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
-_WG_STREAM = os.environ.get("FROST_WG_STREAM", "1") != "0"  # pointwise weight gradients on a second stream (A/B switch)
+_WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 
 
 class Act:
@@ -420,7 +420,7 @@ class Engine:
                  prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
             call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                  prof=("pw_bwd_dc", x.numel + 4 * y.numel))
-            if self._side is not None:      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
+            if self._side is not None and (_WG_STREAM & 1):      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
                 ev = torch.cuda.Event()
                 ev.record()
                 self._side.wait_event(ev)
@@ -429,7 +429,7 @@ class Engine:
                 call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s,
                      prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
             sw = s
-            if self._side is not None:      # dc (and x) stay referenced until the join
+            if self._side is not None and (_WG_STREAM & 1):      # dc (and x) stay referenced until the join
                 self._keep.append((dc, x.buf))
                 sw = C.c_void_p(self._side.cuda_stream)
             call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw,
@@ -449,8 +449,15 @@ class Engine:
             else:
                 call("frost_dw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
                      prof=("dw_bwd_dc", x.numel + 4 * y.numel))
-                # (stays on the main stream: beside other work it slows both down -- measured -5 %)
-                call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), s,
+                # (stays on the main stream by default: beside the pointwise weight gradients it slows everything down -- measured -5 %)
+                sw = s
+                if self._side is not None and (_WG_STREAM & 2):
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._side.wait_event(ev)
+                    self._keep.append((dc, x.buf))
+                    sw = C.c_void_p(self._side.cuda_stream)
+                call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), sw,
                      prof=("dw_wgrad", 2 * y.numel + x.numel))
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
