@@ -10,6 +10,9 @@ root=$(pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
+# per-kernel numbers are taken with everything on ONE stream (the production step overlaps the pointwise weight gradients on a
+# second stream, which stretches the durations of whatever runs beside them); bench.py's roofline leg measures the same way
+export FROST_WG_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- \
     python bench.py --batch $B --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- \
