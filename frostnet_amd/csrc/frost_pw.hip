@@ -33,7 +33,7 @@ struct PwP {
   const int32_t* wsum; const float* qx; const float* qy; const float* qw; float* coef;
   uint8_t* stats; int relu;
   int8_t* y; const uint16_t* gout; uint16_t* dc; uint16_t* dx; int accumulate;
-  int ngroups, mi_eff; int64_t ntiles; float inv_count; int dbg;
+  int ngroups, mi_eff; int64_t ntiles; float inv_count;
   int nbuf;                       // LDS tile buffers of the DMA path: 2, or 1 when no workgroup gets a second tile
   int csplit, nbt;                // channel-group split across workgroups (few-tile layers), workgroups per split
   int64_t tile0;                  // first tile of this launch (the partial last tile of a tensor gets its own launch)
@@ -110,7 +110,7 @@ __device__ __forceinline__ void pw_wait_barrier(int n_younger) {      // n_young
 
 // RES = "resident" mode for small layers: the packed weights, wsum and the BN/quant coefficient rows are copied into LDS
 // once per workgroup, so the persistent tile loop touches global memory only for the activation stream itself (no
-// per-tile L2 round trips on the critical path), and the next tile is register-prefetched.
+// per-tile L2 round trips on the critical path); the next tile arrives by DMA (pw_stage_linear).
 // waves per SIMD the register allocator must leave room for (measured: 2 -> no spills anywhere but half the residency: slower)
 #ifndef PW_MINW
 #define PW_MINW(MODE, WP) 4
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   const bool al16 = (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
   int buf = 0; bool full_prev = false;
   int n_younger = 0;     // VMEM instructions this wave is certain to issue after its DMA within one tile (last channel group)
-  if (gl && !p.dbg && MODE != M_STATS) {
+  if (gl && MODE != M_STATS) {
     if (o_lds) {                                   // the copy-out stores (exact count)
       const int nu = p.o_bytes >> 10;
       n_younger = (w < nu) ? (nu - w + 7) / 8 : 0;
@@ -644,7 +644,6 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
   p.gl = 0; p.tile_bytes = BP * rowbytes;
   if (gl_on && p.nchunks == 1 && p.tile_bytes <= 32 * 1024 && (rowbytes & 7) == 0) { p.gl = 1; p.kstr = rowbytes; }
   p.inv_count = 1.0f / (float)npix;
-  const char* e = getenv("FROST_DBG"); p.dbg = e ? atoi(e) : 0;
 }
 
 extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
