@@ -28,6 +28,12 @@ class FrostIDesc(C.Structure):
                 ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
 
 
+class FrostFDesc(C.Structure):
+    _fields_ = [("w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("nbt", P), ("pack", P), ("pack_t", P), ("stat", P),
+                ("coef", P), ("dgamma", P), ("dbeta", P), ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32),
+                ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FrostGDesc(C.Structure):
     _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
                 ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32)]
@@ -84,6 +90,19 @@ _PROTOS = {
     "frost_infer_add": [P, P, L, P, P],
     "frost_infer_avgpool": [P, I, I, I, P, P],
     "frost_linear_f32": [P, P, P, I, I, I, P, P],
+    "frost_float_weight_prep": [P, I, P],
+    "frost_float_bn_finalize": [P, I, L, P],
+    "frost_float_bn_eval": [P, I, P],
+    "frost_float_bwd_finalize": [P, I, L, P],
+    "frost_float_pw": [P, P, P, L, I, I, I, I, P, I, P, I, P],
+    "frost_float_dw": [P, P, I, I, I, I, I, I, I, I, P, P, P],
+    "frost_float_dw_dgrad": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_dw_wgrad": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_pw_wgrad": [P, P, L, I, I, I, P, I, P],
+    "frost_float_stem_wscatter": [P, I, P, P],
+    "frost_float_grad_merge": [P, P, I, I, P, L, I, P, P],
+    "frost_float_avgpool": [P, I, I, I, P, P, P],
+    "frost_float_head_bwd": [P, P, P, I, I, I, I, P, P, P, P, P, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

@@ -1,0 +1,637 @@
+// Float (not fake-quantised) FrostNet TRAINING on the device: the StatAssist warm-up phase (Classification/train.py:149-165 runs the
+// float model for FP_epoch epochs with the same GradBoost optimizer before prepare_qat) and eval-mode forward of the float model.
+// replaces: frostnet.py:14-60 ConvBNReLU / ConvBN in train mode = Conv2d(bias=False) -> BatchNorm2d(batch statistics, running-stat
+// update, momentum 0.1) -> ReLU, and their autograd backward.
+// Storage: activations and activation gradients NHWC bf16, parameters / statistics / accumulators fp32 (sums in double across
+// workgroups).  Same recompute structure as the fake-quant path: forward = statistics pass -> frost_float_bn_finalize -> emit pass;
+// backward = reduce pass (S1 = sum g, S2 = sum g*xhat) -> frost_float_bwd_finalize -> dc pass -> dgrad, wgrad.  Every pass recomputes
+// the convolution with identical arithmetic, so the ReLU mask z > 0 of the backward is exactly the forward's.
+// Pointwise convs (and the im2col'd stem) run on the bf16 MFMA (16x16x32), depthwise convs on fp32 FMAs.
+#include "frost_common.h"
+
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+
+enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3, F_PLAIN = 4 };
+enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, FC_F = 6, FC_VAR = 7 };
+
+// ------------------------------------------------------------------------------------------------ weight preparation (per step)
+// packs the CURRENT fp32 master weights (no BN folding: batch statistics are not known yet) and zeroes the statistics accumulators
+__global__ __launch_bounds__(256) void k_f_prep(const FrostFDesc* descs) {
+  const FrostFDesc d = descs[blockIdx.y];
+  const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+  for (int i = gtid; i < 4 * d.cpad; i += gsz) d.stat[i] = 0.0;
+  if (d.kind == 0 || d.kind == 2) {       // A-fragments [ct][kb][lane][8]: W[ct*16 + (lane&15)][kb*32 + (lane>>4)*8 + e]
+    const int CT = d.cpad / 16, KB = d.kpad / 32;
+    const int64_t nel = (int64_t)CT * KB * 512;
+    uint16_t* pk = (uint16_t*)d.pack;
+    for (int64_t i = gtid; i < nel; i += gsz) {
+      const int e = (int)(i & 7), lane = (int)((i >> 3) & 63); const int64_t t = i >> 9; const int kb = (int)(t % KB), ct = (int)(t / KB);
+      const int co = ct * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8 + e;
+      float v = 0.0f;
+      if (co < d.cout) {
+        if (d.kind == 0) { if (k < d.cin_g) v = d.w[(int64_t)co * d.cin_g + k]; }
+        else { const int tap = k >> 2, c = k & 3; if (tap < d.kk && c < d.cin_g) v = d.w[((int64_t)co * d.cin_g + c) * d.kk + tap]; }   // stem: k = tap*4 + c
+      }
+      pk[i] = f2bf(v);
+    }
+    if (d.pack_t) {                       // dgrad operand: rows = input channel, K = output channel
+      const int CTt = round_up(d.cin_g, 16) / 16, KBt = d.kpad_t / 32;
+      const int64_t nt = (int64_t)CTt * KBt * 512;
+      uint16_t* pt = (uint16_t*)d.pack_t;
+      for (int64_t i = gtid; i < nt; i += gsz) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63); const int64_t t = i >> 9; const int kb = (int)(t % KBt), ct = (int)(t / KBt);
+        const int ci = ct * 16 + (lane & 15), co = kb * 32 + (lane >> 4) * 8 + e;
+        pt[i] = f2bf((ci < d.cin_g && co < d.cout) ? d.w[(int64_t)co * d.cin_g + ci] : 0.0f);
+      }
+    }
+  } else {                                // depthwise: fp32 [tap][cpad]
+    float* pk = (float*)d.pack;
+    const int64_t nel = (int64_t)d.kk * d.cpad;
+    for (int64_t i = gtid; i < nel; i += gsz) {
+      const int c = (int)(i % d.cpad), tap = (int)(i / d.cpad);
+      pk[i] = (c < d.cout) ? d.w[(int64_t)c * d.kk + tap] : 0.0f;
+    }
+  }
+}
+extern "C" int frost_float_weight_prep(const FrostFDesc* descs, int nlayers, void* stream) {
+  if (nlayers <= 0) return 0;
+  hipLaunchKernelGGL(k_f_prep, dim3(64, nlayers), dim3(256), 0, as_stream(stream), descs);
+  return frost_check_launch("float_weight_prep");
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm coefficient kernels
+// train: batch mean / biased variance from the statistics pass -> scale = gamma*invsigma, bias = beta - mean*scale; running statistics
+// updated with momentum 0.1 and the unbiased variance, num_batches_tracked += 1 (torch BatchNorm2d training semantics)
+__global__ __launch_bounds__(256) void k_f_bn_finalize(const FrostFDesc* dp, double count) {
+  const FrostFDesc d = *dp;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && d.nbt) *d.nbt += 1;
+  if (c >= d.cout) return;
+  const double mean = d.stat[c] / count;
+  double var = d.stat[d.cpad + c] / count - mean * mean; if (var < 0.0) var = 0.0;
+  const float inv = (float)(1.0 / sqrt(var + (double)FROST_BN_EPS));
+  const float sc = d.gamma[c] * inv;
+  d.coef[FC_SCALE * d.cpad + c] = sc; d.coef[FC_BIAS * d.cpad + c] = d.beta[c] - (float)mean * sc;
+  d.coef[FC_MEAN * d.cpad + c] = (float)mean; d.coef[FC_INV * d.cpad + c] = inv; d.coef[FC_VAR * d.cpad + c] = (float)var;
+  const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+  d.rmean[c] = (1.0f - FROST_BN_MOM) * d.rmean[c] + FROST_BN_MOM * (float)mean;
+  d.rvar[c] = (1.0f - FROST_BN_MOM) * d.rvar[c] + FROST_BN_MOM * (float)unb;
+}
+extern "C" int frost_float_bn_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream) {
+  hipLaunchKernelGGL(k_f_bn_finalize, dim3((cout + 255) / 256), dim3(256), 0, as_stream(stream), desc, (double)count);
+  return frost_check_launch("float_bn_finalize");
+}
+// eval: running statistics, one launch for the whole table
+__global__ __launch_bounds__(256) void k_f_bn_eval(const FrostFDesc* descs) {
+  const FrostFDesc d = descs[blockIdx.y];
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < d.cout; c += gridDim.x * 256) {
+    const float inv = 1.0f / sqrtf(d.rvar[c] + FROST_BN_EPS), sc = d.gamma[c] * inv;
+    d.coef[FC_SCALE * d.cpad + c] = sc; d.coef[FC_BIAS * d.cpad + c] = d.beta[c] - d.rmean[c] * sc;
+    d.coef[FC_MEAN * d.cpad + c] = d.rmean[c]; d.coef[FC_INV * d.cpad + c] = inv;
+  }
+}
+extern "C" int frost_float_bn_eval(const FrostFDesc* descs, int nlayers, void* stream) {
+  if (nlayers <= 0) return 0;
+  hipLaunchKernelGGL(k_f_bn_eval, dim3(8, nlayers), dim3(256), 0, as_stream(stream), descs);
+  return frost_check_launch("float_bn_eval");
+}
+// backward coefficients: dc = K1*(g - S1/N - xhat*S2/N) = g*K1 + conv*E + F;  dgamma += S2, dbeta += S1
+__global__ __launch_bounds__(256) void k_f_bwd_finalize(const FrostFDesc* dp, double count) {
+  const FrostFDesc d = *dp;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d.cout) return;
+  const double S1 = d.stat[2 * d.cpad + c], S2 = d.stat[3 * d.cpad + c];
+  const float inv = d.coef[FC_INV * d.cpad + c], mean = d.coef[FC_MEAN * d.cpad + c];
+  const float K1 = d.gamma[c] * inv;
+  const float a = (float)(S1 / count), b = (float)(S2 / count);
+  d.coef[FC_K1 * d.cpad + c] = K1;
+  d.coef[FC_E * d.cpad + c] = -K1 * b * inv;
+  d.coef[FC_F * d.cpad + c] = -K1 * a + K1 * b * mean * inv;
+  d.dgamma[c] += (float)S2; d.dbeta[c] += (float)S1;
+}
+extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream) {
+  hipLaunchKernelGGL(k_f_bwd_finalize, dim3((cout + 255) / 256), dim3(256), 0, as_stream(stream), desc, (double)count);
+  return frost_check_launch("float_bwd_finalize");
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise passes (bf16 MFMA)
+// conv[p][co] = sum_k T[p][k] * W[co][k].  64-pixel tile per iteration staged in LDS with coalesced 16-byte loads; wave w owns 16 pixels
+// and walks the channel tiles four at a time (WPX = 4), or the four waves split the channel tiles of a 16-pixel tile (WPX = 1: rows too
+// long for 64 LDS rows).  Workgroups stride over the tiles; the statistics modes keep per-channel partial sums in LDS across all their
+// tiles and flush them once (double atomics), so the number of global atomics is grid x channels, not tiles x channels.
+//   F_STATS: sum / sum of squares of conv            F_EMIT: y = [relu](conv*scale + bias) -> bf16
+//   F_BRED : S1 += g*m, S2 += g*m*xhat               F_BDC : dc = g*m*K1 + conv*E + F -> bf16        (m = z > 0 for ReLU layers)
+//   F_PLAIN: y = conv -> bf16 (the data gradient: T = dc, W = the transposed pack)
+template <int MODE, int WPX>
+__global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16_t* __restrict__ T, const uint16_t* __restrict__ pack, int64_t npix,
+                                              int cin, int cout, int cpad, int KB, int kstr, int relu, const uint16_t* __restrict__ gy, int ldg,
+                                              uint16_t* __restrict__ y, int ldy, int64_t ntiles) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int IPX = 16 * WPX, WCH = 4 / WPX;
+  constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
+  const int wpx = w % WPX, wch = w / WPX;
+  float* sacc = (float*)(smem + IPX * kstr);
+  const float* coef = (MODE == F_PLAIN) ? nullptr : dp->coef;
+  if (RED) for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f;
+  const int rowb = cin * 2; const int U = (KB * 64) >> 4;
+  const int CT = cpad >> 4;
+  const float lo = relu ? 0.0f : -INFINITY;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * IPX;
+    __syncthreads();
+    for (int u = tid; u < IPX * U; u += 256) {
+      const int row = u / U, col = (u - row * U) << 4;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((p0 + row) < npix && col < rowb) v = *(const uint4*)((const uint8_t*)T + (p0 + row) * rowb + col);
+      *(uint4*)(smem + row * kstr + col) = v;
+    }
+    __syncthreads();
+    const int64_t prow = p0 + wpx * 16 + j;
+    const bool pv = prow < npix;
+    for (int ct0 = wch * 4; ct0 < CT; ct0 += 4 * WCH) {
+      v4f acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < KB; ++kb) {
+        const v4i bfr = *(const v4i*)(smem + (wpx * 16 + j) * kstr + kb * 64 + g * 16);
+        v4i afr[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (ct0 + m < CT) afr[m] = *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 3));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (ct0 + m < CT) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr), acc[m], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (ct0 + m >= CT) continue;                 // wave-uniform
+        const int ch0 = (ct0 + m) * 16 + 4 * g;
+        const bool cv = ch0 < cout;
+        const bool ok = cv && pv;
+        if constexpr (MODE == F_PLAIN) {
+          if (ok) { uint2 o; o.x = cvt_pk_bf16(acc[m][0], acc[m][1]); o.y = cvt_pk_bf16(acc[m][2], acc[m][3]); *(uint2*)(y + prow * ldy + ch0) = o; }
+        } else if constexpr (MODE == F_STATS) {
+          float s[4], q[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = ok ? acc[m][r] : 0.0f; s[r] = v; q[r] = v * v; }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] += __shfl_xor(s[r], o); q[r] += __shfl_xor(q[r], o); }
+          if (j == 0 && cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
+          }
+        } else {
+          const int cc = cv ? ch0 : 0;
+          const float4 sc4 = *(const float4*)(coef + FC_SCALE * cpad + cc), bi4 = *(const float4*)(coef + FC_BIAS * cpad + cc);
+          const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
+          if constexpr (MODE == F_EMIT) {
+            if (ok) {
+              uint2 o;
+              o.x = cvt_pk_bf16(fmaxf(fmaf(acc[m][0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[m][1], sc[1], bi[1]), lo));
+              o.y = cvt_pk_bf16(fmaxf(fmaf(acc[m][2], sc[2], bi[2]), lo), fmaxf(fmaf(acc[m][3], sc[3], bi[3]), lo));
+              *(uint2*)(y + prow * ldy + ch0) = o;
+            }
+          } else {
+            uint2 gv = make_uint2(0, 0);
+            if (ok) gv = *(const uint2*)(gy + prow * ldg + ch0);
+            float gm[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
+            if (relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) if (!(fmaf(acc[m][r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
+            }
+            if constexpr (MODE == F_BRED) {
+              const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
+              const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+              float s[4], q[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { const float xh = (acc[m][r] - mu[r]) * iv[r]; s[r] = ok ? gm[r] : 0.0f; q[r] = ok ? gm[r] * xh : 0.0f; }
+#pragma unroll
+              for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[r] += __shfl_xor(s[r], o); q[r] += __shfl_xor(q[r], o); }
+              if (j == 0 && cv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
+              }
+            } else {   // F_BDC
+              const float4 k4 = *(const float4*)(coef + FC_K1 * cpad + cc), e4 = *(const float4*)(coef + FC_E * cpad + cc), f4 = *(const float4*)(coef + FC_F * cpad + cc);
+              const float k1[4] = {k4.x, k4.y, k4.z, k4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
+              if (ok) {
+                float dcv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dcv[r] = fmaf(gm[r], k1[r], fmaf(acc[m][r], ee[r], ff[r]));
+                uint2 o; o.x = cvt_pk_bf16(dcv[0], dcv[1]); o.y = cvt_pk_bf16(dcv[2], dcv[3]);
+                *(uint2*)(y + prow * ldy + ch0) = o;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (RED) {
+    __syncthreads();
+    double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
+    for (int i = tid; i < 2 * cpad; i += 256) { const float v = sacc[i]; if (v != 0.0f) atomicAdd(st + i, (double)v); }
+  }
+}
+template <int MODE>
+static int launch_f_pw(const FrostFDesc* dp, const uint16_t* T, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, const uint16_t* gy,
+                       int ldg, uint16_t* y, int ldy, hipStream_t s) {
+  const int KB = (cin + 31) / 32; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
+  constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
+  const size_t extra = RED ? (size_t)2 * cpad * 4 : 0;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute((const void*)k_f_pw<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_f_pw<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if ((size_t)64 * kstr <= 48 * 1024) {
+    const int64_t nt = (npix + 63) / 64; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((k_f_pw<MODE, 4>), dim3((unsigned)grid), dim3(256), (size_t)64 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
+                       gy, ldg, y, ldy, nt);
+  } else {
+    if ((size_t)16 * kstr + extra > 160 * 1024) { frost_set_error("float_pw: row too long for the LDS tile"); return 1; }
+    const int64_t nt = (npix + 15) / 16; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
+    hipLaunchKernelGGL((k_f_pw<MODE, 1>), dim3((unsigned)grid), dim3(256), (size_t)16 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
+                       gy, ldg, y, ldy, nt);
+  }
+  return frost_check_launch("float_pw");
+}
+// x: bf16 [npix][cin] (cin = the row length: 64 for the im2col'd stem); pack: the layer's forward pack (modes 0..3) or its transposed pack
+// (mode 4, then cin/cout are swapped by the caller); gy / out rows may be slices of wider tensors (ldg / ldy = row length in elements)
+extern "C" int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, int mode,
+                              const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream) {
+  FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "float_pw: cin must be a multiple of 8, cout of 4");
+  FROST_REQUIRE(mode >= 0 && mode <= 4, "float_pw: mode 0..4");
+  hipStream_t s = as_stream(stream);
+  switch (mode) {
+    case F_STATS: return launch_f_pw<F_STATS>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_EMIT: return launch_f_pw<F_EMIT>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_BRED: return launch_f_pw<F_BRED>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_BDC: return launch_f_pw<F_BDC>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    default: return launch_f_pw<F_PLAIN>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise passes (fp32 FMA)
+// one thread = 8 channels (fixed for the thread's whole life, so statistics stay in registers) x a strided set of output pixels
+template <int MODE>
+__global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16_t* __restrict__ x, int n, int h, int w, int c, int cpad, int k, int stride,
+                                              int ho, int wo, int relu, const uint16_t* __restrict__ gy, uint16_t* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
+  float* sacc = (float*)smem;
+  const int tid = threadIdx.x;
+  if (RED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f; __syncthreads(); }
+  const int c8n = c >> 3; const int pad = (k - 1) / 2;
+  const int64_t nthreads = (int64_t)gridDim.x * 256; const int64_t PP = nthreads / c8n;
+  const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+  const int c8 = (int)(t % c8n); const int64_t slot = t / c8n;
+  const int ch = c8 * 8;
+  const int64_t npix = (int64_t)n * ho * wo;
+  const float* wf = (const float*)dp->pack; const float* coef = dp->coef;
+  float sc[8], bi[8], c2[8], c3[8], c4[8];
+  if (MODE != F_STATS) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = coef[FC_SCALE * cpad + ch + e]; bi[e] = coef[FC_BIAS * cpad + ch + e];
+      if (MODE == F_BRED) { c2[e] = coef[FC_MEAN * cpad + ch + e]; c3[e] = coef[FC_INV * cpad + ch + e]; }
+      if (MODE == F_BDC) { c2[e] = coef[FC_K1 * cpad + ch + e]; c3[e] = coef[FC_E * cpad + ch + e]; c4[e] = coef[FC_F * cpad + ch + e]; }
+    }
+  }
+  float s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
+  const float lo = relu ? 0.0f : -INFINITY;
+  if (slot < PP) {
+    for (int64_t p = slot; p < npix; p += PP) {
+      int64_t pp = p; const int ox = (int)(pp % wo); pp /= wo; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+      for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
+          const uint4 v = *(const uint4*)(x + (((int64_t)in * h + iy) * w + ix) * c + ch);
+          const float* wp = wf + (ky * k + kx) * cpad + ch;
+          const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
+          acc[0] = fmaf(bf2f(v.x & 0xffff), w0.x, acc[0]); acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
+          acc[2] = fmaf(bf2f(v.y & 0xffff), w0.z, acc[2]); acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
+          acc[4] = fmaf(bf2f(v.z & 0xffff), w1.x, acc[4]); acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
+          acc[6] = fmaf(bf2f(v.w & 0xffff), w1.z, acc[6]); acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+        }
+      }
+      if constexpr (MODE == F_STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += acc[e]; q[e] = fmaf(acc[e], acc[e], q[e]); }
+      } else if constexpr (MODE == F_EMIT) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(acc[e], sc[e], bi[e]), lo);
+        uint4 o; o.x = cvt_pk_bf16(o8[0], o8[1]); o.y = cvt_pk_bf16(o8[2], o8[3]); o.z = cvt_pk_bf16(o8[4], o8[5]); o.w = cvt_pk_bf16(o8[6], o8[7]);
+        *(uint4*)(y + p * c + ch) = o;
+      } else {
+        const uint4 gv = *(const uint4*)(gy + p * c + ch);
+        float gm[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (!(fmaf(acc[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
+        }
+        if constexpr (MODE == F_BRED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += gm[e]; q[e] = fmaf(gm[e], (acc[e] - c2[e]) * c3[e], q[e]); }
+        } else {
+          float o8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = fmaf(gm[e], c2[e], fmaf(acc[e], c3[e], c4[e]));
+          uint4 o; o.x = cvt_pk_bf16(o8[0], o8[1]); o.y = cvt_pk_bf16(o8[2], o8[3]); o.z = cvt_pk_bf16(o8[4], o8[5]); o.w = cvt_pk_bf16(o8[6], o8[7]);
+          *(uint4*)(y + p * c + ch) = o;
+        }
+      }
+    }
+  }
+  if (RED) {
+    if (slot < PP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&sacc[ch + e], s[e]); atomicAdd(&sacc[cpad + ch + e], q[e]); }
+    }
+    __syncthreads();
+    double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
+    for (int i = tid; i < 2 * cpad; i += 256) { const float v = sacc[i]; if (v != 0.0f) atomicAdd(st + i, (double)v); }
+  }
+}
+extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
+                              const uint16_t* gy, uint16_t* out, void* stream) {
+  FROST_REQUIRE(c % 8 == 0, "float_dw: channels must be a multiple of 8");
+  FROST_REQUIRE(mode >= 0 && mode <= 3, "float_dw: mode 0..3");
+  const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+  const int cpad = round_up(c, 16); const int c8n = c >> 3;
+  const int64_t tot = (int64_t)n * ho * wo * c8n;
+  const bool red = (mode == F_STATS || mode == F_BRED);
+  int64_t grid = (tot + 255) / 256; const int64_t cap = red ? 2048 : 8192; if (grid > cap) grid = cap;
+  const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;      // every channel group needs at least one thread
+  const size_t lds = red ? (size_t)2 * cpad * 4 : 0;
+  hipStream_t s = as_stream(stream);
+#define FDW_LAUNCH(M) hipLaunchKernelGGL(k_f_dw<M>, dim3((unsigned)grid), dim3(256), lds, s, desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, gy, out)
+  switch (mode) { case F_STATS: FDW_LAUNCH(F_STATS); break; case F_EMIT: FDW_LAUNCH(F_EMIT); break; case F_BRED: FDW_LAUNCH(F_BRED); break; default: FDW_LAUNCH(F_BDC); }
+#undef FDW_LAUNCH
+  return frost_check_launch("float_dw");
+}
+
+// depthwise data gradient: dx[n][iy][ix][c] = sum_{ky,kx} dc[n][(iy+pad-ky)/s][(ix+pad-kx)/s][c] * w[c][ky][kx]   (where divisible / in range)
+__global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const uint16_t* __restrict__ dc, int n, int h, int w, int c, int cpad, int k, int stride,
+                                                    int ho, int wo, uint16_t* __restrict__ dx) {
+  const int c8n = c >> 3; const int pad = (k - 1) / 2;
+  const int64_t tot = (int64_t)n * h * w * c8n;
+  const float* wf = (const float*)dp->pack;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n); int64_t p = i / c8n; const int ix = (int)(p % w); p /= w; const int iy = (int)(p % h); const int in = (int)(p / h);
+    const int ch = c8 * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int ty = iy + pad - ky; if (ty < 0 || ty % stride) continue; const int oy = ty / stride; if (oy >= ho) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int tx = ix + pad - kx; if (tx < 0 || tx % stride) continue; const int ox = tx / stride; if (ox >= wo) continue;
+        const uint4 v = *(const uint4*)(dc + (((int64_t)in * ho + oy) * wo + ox) * c + ch);
+        const float* wp = wf + (ky * k + kx) * cpad + ch;
+        const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
+        acc[0] = fmaf(bf2f(v.x & 0xffff), w0.x, acc[0]); acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
+        acc[2] = fmaf(bf2f(v.y & 0xffff), w0.z, acc[2]); acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
+        acc[4] = fmaf(bf2f(v.z & 0xffff), w1.x, acc[4]); acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
+        acc[6] = fmaf(bf2f(v.w & 0xffff), w1.z, acc[6]); acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+      }
+    }
+    uint4 o; o.x = cvt_pk_bf16(acc[0], acc[1]); o.y = cvt_pk_bf16(acc[2], acc[3]); o.z = cvt_pk_bf16(acc[4], acc[5]); o.w = cvt_pk_bf16(acc[6], acc[7]);
+    *(uint4*)(dx + (((int64_t)in * h + iy) * w + ix) * c + ch) = o;
+  }
+}
+extern "C" int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream) {
+  FROST_REQUIRE(c % 8 == 0, "float_dw_dgrad: channels must be a multiple of 8");
+  const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+  const int64_t tot = (int64_t)n * h * w * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(k_f_dw_dgrad, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), desc, dc, n, h, w, c, round_up(c, 16), k, stride, ho, wo, dx);
+  return frost_check_launch("float_dw_dgrad");
+}
+
+// depthwise weight gradient: dW[c][ky][kx] += sum_p dc[p][c] * x[n][oy*s-pad+ky][ox*s-pad+kx][c]
+// workgroup = (32-channel group, kernel row ky) x a strided set of output pixels: thread = 8 channels (4 adjacent threads read one 64-byte
+// segment) x one of 64 pixel lanes, k*8 accumulators; lanes are summed through LDS and leave with one atomic per (channel, tap).
+__global__ __launch_bounds__(256) void k_f_dw_wgrad(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ x, int n, int h, int w, int c, int k, int stride,
+                                                    int ho, int wo, float* __restrict__ dw) {
+  __shared__ float red[32 * 5];
+  const int tid = threadIdx.x, c8l = tid & 3, pl = tid >> 2;
+  const int unit = blockIdx.y; const int ky = unit % k, cg = unit / k;
+  const int ch = cg * 32 + c8l * 8; const bool live = ch < c;
+  const int pad = (k - 1) / 2;
+  const int64_t npix = (int64_t)n * ho * wo;
+  float a[5][8];
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[kx][e] = 0.0f;
+  if (live) {
+    for (int64_t p = (int64_t)blockIdx.x * 64 + pl; p < npix; p += (int64_t)gridDim.x * 64) {
+      int64_t pp = p; const int ox = (int)(pp % wo); pp /= wo; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
+      const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
+      const uint4 gv = *(const uint4*)(dc + p * c + ch);
+      const float g8[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        if (kx >= k) break;
+        const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
+        const uint4 v = *(const uint4*)(x + (((int64_t)in * h + iy) * w + ix) * c + ch);
+        a[kx][0] = fmaf(g8[0], bf2f(v.x & 0xffff), a[kx][0]); a[kx][1] = fmaf(g8[1], bf2f(v.x >> 16), a[kx][1]);
+        a[kx][2] = fmaf(g8[2], bf2f(v.y & 0xffff), a[kx][2]); a[kx][3] = fmaf(g8[3], bf2f(v.y >> 16), a[kx][3]);
+        a[kx][4] = fmaf(g8[4], bf2f(v.z & 0xffff), a[kx][4]); a[kx][5] = fmaf(g8[5], bf2f(v.z >> 16), a[kx][5]);
+        a[kx][6] = fmaf(g8[6], bf2f(v.w & 0xffff), a[kx][6]); a[kx][7] = fmaf(g8[7], bf2f(v.w >> 16), a[kx][7]);
+      }
+    }
+  }
+  for (int i = tid; i < 32 * 5; i += 256) red[i] = 0.0f;
+  __syncthreads();
+  // lanes tid, tid^4, ... share (c8l): fold the 16 pixel lanes of a wave first (lane bits 2..5), then LDS atomics across the 4 waves
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = a[kx][e];
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if ((tid & 63) < 4 && kx < k) atomicAdd(&red[(c8l * 8 + e) * 5 + kx], v);
+    }
+  __syncthreads();
+  for (int i = tid; i < 32 * k; i += 256) {
+    const int cl = i / k, kx = i % k; const int cc = cg * 32 + cl;
+    if (cc < c) atomicAdd(dw + (int64_t)cc * k * k + ky * k + kx, red[cl * 5 + kx]);
+  }
+}
+extern "C" int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream) {
+  FROST_REQUIRE(c % 8 == 0 && k <= 5, "float_dw_wgrad: channels must be a multiple of 8, k <= 5");
+  const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+  const int64_t npix = (int64_t)n * ho * wo;
+  const int units = ((c + 31) / 32) * k;
+  int64_t gx = (npix + 63) / 64; int64_t cap = 4096 / units; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(k_f_dw_wgrad, dim3((unsigned)gx, units), dim3(256), 0, as_stream(stream), dc, x, n, h, w, c, k, stride, ho, wo, dw);
+  return frost_check_launch("float_dw_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise weight gradient (bf16 MFMA, K = pixels)
+// dW[co][ci] += sum_p dc[p][co] * x[p][ci].  Both operands pixel-major bf16: 128-pixel blocks staged in their natural layout, the
+// K(pixel)-contiguous fragments come from the gfx950 LDS transpose read (ds_read_b64_tr_b16).  64x64 output tile per workgroup, the 4
+// waves split the staged pixels, pixel range split across workgroups, fp32 atomics at the end.
+#define FW_T 64
+#define FW_KP 128
+#define FW_RS 136
+__global__ __launch_bounds__(256, 2) void k_f_pw_wgrad(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ x, int64_t npix, int cin, int ldx, int cout,
+                                                       float* __restrict__ dw, int ldw, int nsplit) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * FW_KP * FW_RS];
+  uint8_t* dcs = lds; uint8_t* xs = lds + FW_KP * FW_RS;
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nci = (cin + FW_T - 1) / FW_T;
+  const int ntile = ((cout + FW_T - 1) / FW_T) * nci;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  const int co0 = (tile / nci) * FW_T, ci0 = (tile % nci) * FW_T;
+  v4f acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int pb = w * 32 + g * 8;
+  const uint8_t* a_src = dcs + (pb + (i16 >> 2)) * FW_RS + (i16 & 3) * 8;
+  const uint8_t* b_src = xs + (pb + (i16 >> 2)) * FW_RS + (i16 & 3) * 8;
+  int na = (cout - co0 + 15) / 16; if (na > 4) na = 4;
+  int nb = (cin - ci0 + 15) / 16; if (nb > 4) nb = 4;
+  const int64_t nblk = (npix + FW_KP - 1) / FW_KP;
+  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+    const int64_t q0 = blk * FW_KP;
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int u = tid + jn * 256; const int pix = u >> 3, c8 = u & 7; const int64_t gp = q0 + pix;
+      uint4 pd = make_uint4(0, 0, 0, 0), px = make_uint4(0, 0, 0, 0);
+      if (gp < npix && (co0 + c8 * 8) < cout) pd = *(const uint4*)(dc + gp * cout + co0 + c8 * 8);
+      if (gp < npix && (ci0 + c8 * 8) < cin) px = *(const uint4*)(x + gp * ldx + ci0 + c8 * 8);
+      *(uint2*)(dcs + pix * FW_RS + c8 * 16) = make_uint2(pd.x, pd.y); *(uint2*)(dcs + pix * FW_RS + c8 * 16 + 8) = make_uint2(pd.z, pd.w);
+      *(uint2*)(xs + pix * FW_RS + c8 * 16) = make_uint2(px.x, px.y); *(uint2*)(xs + pix * FW_RS + c8 * 16 + 8) = make_uint2(px.z, px.w);
+    }
+    __syncthreads();
+    v4i afr[4], bfr[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (a < na) {
+        const v2i32 l2 = __builtin_bit_cast(v2i32, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(a_src + a * 32)));
+        const v2i32 h2 = __builtin_bit_cast(v2i32, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(a_src + a * 32 + 4 * FW_RS)));
+        afr[a] = (v4i){l2[0], l2[1], h2[0], h2[1]};
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < nb) {
+        const v2i32 l2 = __builtin_bit_cast(v2i32, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(b_src + b * 32)));
+        const v2i32 h2 = __builtin_bit_cast(v2i32, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s16 __attribute__((address_space(3)))*)(b_src + b * 32 + 4 * FW_RS)));
+        bfr[b] = (v4i){l2[0], l2[1], h2[0], h2[1]};
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        if (a < na && b < nb)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[a]), __builtin_bit_cast(v8bf16, bfr[b]), acc[a][b], 0, 0, 0);
+  }
+  __syncthreads();
+  float* red = (float*)lds;
+  for (int i = tid; i < FW_T * FW_T; i += 256) red[i] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (a < na && b < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[(a * 16 + 4 * g + r) * FW_T + b * 16 + i16], acc[a][b][r]);
+      }
+  __syncthreads();
+  for (int i = tid; i < FW_T * FW_T; i += 256) {
+    const int co = co0 + i / FW_T, ci = ci0 + i % FW_T;
+    if (co < cout && ci < cin) atomicAdd(dw + (int64_t)co * ldw + ci, red[i]);
+  }
+}
+// x: bf16 [npix][ldx] (first cin columns used); dw: fp32 [cout][ldw], accumulated into (must hold the running gradient or zeros)
+extern "C" int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream) {
+  FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0 && ldx % 8 == 0, "float_pw_wgrad: channels must be multiples of 8");
+  const int64_t nblk = (npix + FW_KP - 1) / FW_KP;
+  const int ntile = ((cout + FW_T - 1) / FW_T) * ((cin + FW_T - 1) / FW_T);
+  int nsplit = (1024 + ntile - 1) / ntile;
+  if (nsplit > nblk / 4) nsplit = (int)(nblk / 4); if (nsplit < 1) nsplit = 1;
+  hipLaunchKernelGGL(k_f_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, npix, cin, ldx, cout, dw, ldw, nsplit);
+  return frost_check_launch("float_pw_wgrad");
+}
+// stem: the im2col'd weight gradient [cout][64] (K = tap*4 + c) back to the OIHW parameter layout [cout][3][9]
+__global__ __launch_bounds__(256) void k_f_stem_wscatter(const float* __restrict__ tmp, int cout, float* __restrict__ dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cout * 27) return;
+  const int co = i / 27, r = i % 27, c = r / 9, tap = r % 9;
+  dw[i] += tmp[co * 64 + tap * 4 + c];
+}
+extern "C" int frost_float_stem_wscatter(const float* tmp, int cout, float* dw, void* stream) {
+  hipLaunchKernelGGL(k_f_stem_wscatter, dim3((cout * 27 + 255) / 256), dim3(256), 0, as_stream(stream), tmp, cout, dw);
+  return frost_check_launch("float_stem_wscatter");
+}
+
+// ------------------------------------------------------------------------------------------------ block wiring, backward
+// gradient of a bottleneck's input = [residual branch: the block output's gradient] + [cat branch: columns cs.. of the cat gradient]
+// + [squeeze conv's data gradient]; any of the three may be absent (NULL).
+__global__ __launch_bounds__(256) void k_f_grad_merge(const uint16_t* __restrict__ res, const uint16_t* __restrict__ cat, int cs, int ccat,
+                                                      const uint16_t* __restrict__ sq, int64_t npix, int c, uint16_t* __restrict__ out) {
+  const int cu = c >> 3; const int64_t tot = npix * cu;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int u = (int)(i % cu); const int64_t p = i / cu; const int ch = u * 8;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto add = [&](const uint4 v) {
+      a[0] += bf2f(v.x & 0xffff); a[1] += bf2f(v.x >> 16); a[2] += bf2f(v.y & 0xffff); a[3] += bf2f(v.y >> 16);
+      a[4] += bf2f(v.z & 0xffff); a[5] += bf2f(v.z >> 16); a[6] += bf2f(v.w & 0xffff); a[7] += bf2f(v.w >> 16);
+    };
+    if (res) add(*(const uint4*)(res + p * c + ch));
+    if (cat) add(*(const uint4*)(cat + p * ccat + cs + ch));
+    if (sq) add(*(const uint4*)(sq + p * c + ch));
+    uint4 o; o.x = cvt_pk_bf16(a[0], a[1]); o.y = cvt_pk_bf16(a[2], a[3]); o.z = cvt_pk_bf16(a[4], a[5]); o.w = cvt_pk_bf16(a[6], a[7]);
+    *(uint4*)(out + p * c + ch) = o;
+  }
+}
+extern "C" int frost_float_grad_merge(const uint16_t* res, const uint16_t* cat, int cs, int ccat, const uint16_t* sq, int64_t npix, int c, uint16_t* out,
+                                      void* stream) {
+  FROST_REQUIRE(c % 8 == 0 && cs % 8 == 0 && ccat % 8 == 0, "float_grad_merge: channel counts must be multiples of 8");
+  const int64_t tot = npix * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_f_grad_merge, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), res, cat, cs, ccat, sq, npix, c, out);
+  return frost_check_launch("float_grad_merge");
+}
+
+// ------------------------------------------------------------------------------------------------ head
+// global average pool with the dropout mask applied (mask holds 0 or 1/keep; NULL = no dropout): y fp32 [n][c]
+__global__ __launch_bounds__(256) void k_f_avgpool(const uint16_t* __restrict__ x, int n, int hw, int c, const float* __restrict__ drop, float* __restrict__ y) {
+  const int64_t tot = (int64_t)n * c;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c); const int in = (int)(i / c);
+    float s = 0.0f;
+    for (int p = 0; p < hw; ++p) s += bf2f(x[((int64_t)in * hw + p) * c + ch]);
+    s /= (float)hw;
+    y[i] = drop ? s * drop[i] : s;
+  }
+}
+extern "C" int frost_float_avgpool(const uint16_t* x, int n, int hw, int c, const float* drop, float* y, void* stream) {
+  const int64_t tot = (int64_t)n * c; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_f_avgpool, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, n, hw, c, drop, y);
+  return frost_check_launch("float_avgpool");
+}

@@ -111,6 +111,21 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
   return frost_check_launch("head_bwd");
 }
 
+// float model (StatAssist warm-up): autograd of [avgpool -> dropout -> Conv2d(1280, nclass, 1)] (frostnet.py:295-299), fp32 weights.
+// dw[nclass][cin] = dlogits^T . pooled (pooled = post-dropout); dbias = colsum(dlogits); gx = (dlogits . w) * drop / hw  (bf16)
+extern "C" int frost_float_head_bwd(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
+                                    const float* drop_mask, float* dw, float* dbias, uint16_t* gx, float* scratch_dpool, void* stream) {
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (nclass + 63) / 64), dim3(256), 0, s, dlogits, (int64_t)1, (int64_t)nclass, pooled,
+                     (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, (const float*)nullptr, dw, 0);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
+  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (n + 63) / 64), dim3(256), 0, s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin,
+                     (int64_t)1, n, cin, nclass, (const float*)nullptr, 1.0f, (const float*)nullptr, scratch_dpool, 0);
+  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
+  return frost_check_launch("float_head_bwd");
+}
+
 // ---------------------------------------------------------------------------------------------- cat / add bwd
 __device__ __forceinline__ void acc_store4(uint16_t* dst, const float* v, int accumulate) {
   float o[4] = {v[0], v[1], v[2], v[3]};

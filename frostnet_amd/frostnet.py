@@ -178,10 +178,16 @@ class _FrostBase(nn.Module):
 
     def hip_runner(self):
         """The device executor bound to this module tree (built lazily, rebuilt if parameters were moved)."""
-        from .runner import FrostRunner
+        qat = self._is_qat_prepared()
         r = self.__dict__.get("_hip_runner")
-        if r is None or not r.still_valid():
-            r = FrostRunner(self)
+        if r is None or r.is_qat != qat or not r.still_valid():
+            if qat:
+                from .runner import FrostRunner
+                r = FrostRunner(self)
+            else:                                   # the float model: StatAssist warm-up training / float eval (float_train.py)
+                from .float_train import FloatRunner
+                r = FloatRunner(self)
+            r.is_qat = qat
             self.__dict__["_hip_runner"] = r
         return r
 
@@ -211,10 +217,8 @@ class FrostNet(_FrostBase):
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
 
-    # Opt-in, OFF by default: let a NOT-yet-quantised (float) model run torch's stock eager modules on the GPU, i.e. exactly
-    # what the reference does for its StatAssist FP warm-up epoch.  This is NOT the native path (no HIP kernels of this
-    # repo run); the device-native float/bf16 graph is a listed gap.  Without the flag a float model on the
-    # GPU raises, so a benchmark can never silently measure torch eager.
+    # Opt-in, OFF by default: run a NOT-yet-quantised (float) model through torch's stock eager modules on the GPU instead of this
+    # repo's float kernels (frostnet_amd/float_train.py).  Exists only for A/B checks; nothing in the product path sets it.
     allow_torch_eager_float = False
 
     def hip_infer_bf16(self, x):

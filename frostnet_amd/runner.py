@@ -57,9 +57,8 @@ class FrostRunner:
         self.model = model
         if not model._is_qat_prepared():
             raise NotImplementedError(
-                "frostnet_amd: the HIP path implements the fake-quantised (QAT) FrostNet; call fuse_model() + "
-                "torch.quantization.prepare_qat (or frostnet_amd.qat_prepare) before moving activations to the GPU. "
-                "The float (StatAssist warm-up) graph runs on the CPU path only in this round.")
+                "FrostRunner binds the fake-quantised (QAT-prepared) FrostNet; the float model runs through "
+                "frostnet_amd.float_train.FloatRunner (model.hip_runner() picks the right one).")
         params = list(model.parameters())
         self.device = params[0].device
         self.E = Engine(self.device)

@@ -206,6 +206,42 @@ int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void*
 /* y[n][o] = sum_k x[n][k] * w[o][k] + bias[o], fp32 on the f32 MFMA (classifier of the float model) */
 int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream);
 
+/* ---- float (not fake-quantised) model on the device: StatAssist warm-up training + eval forward ----------------- */
+/* replaces: frostnet.py:14-60 ConvBNReLU / ConvBN in TRAIN mode (Conv2d -> BatchNorm2d with batch statistics -> ReLU) and their
+ * autograd backward, for the FP epochs Classification/train.py:149-165 runs before prepare_qat.  Activations and activation
+ * gradients NHWC bf16, parameters / statistics fp32.  Per conv: forward = mode 0 (statistics) -> frost_float_bn_finalize -> mode 1
+ * (emit); backward = mode 2 (S1, S2) -> frost_float_bwd_finalize -> mode 3 (dc) -> data gradient, weight gradient. */
+typedef struct FrostFDesc {
+  const float* w;        /* OIHW fp32 master weight                                                    */
+  const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;   /* BatchNorm2d parameters / buffers */
+  void* pack;            /* kind 0/2: bf16 MFMA A-fragments [cpad/16][kpad/32][64][8]; kind 1: fp32 [kk][cpad] */
+  void* pack_t;          /* kind 0: A-fragments of W^T [round16(cin)/16][kpad_t/32][64][8] (data gradient); else NULL */
+  double* stat;          /* [4*cpad]: sum, sum of squares (forward), S1, S2 (backward); zeroed by frost_float_weight_prep */
+  float* coef;           /* [8*cpad]: scale, bias, mean, invsigma, K1, E, F, batch variance                    */
+  float* dgamma; float* dbeta;   /* gradient destinations (accumulated into)                                   */
+  int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem (im2col K = tap*4 + c)             */
+  int32_t cpad, kpad, kpad_t, reserved;
+} FrostFDesc;
+int frost_float_weight_prep(const FrostFDesc* descs, int nlayers, void* stream);
+int frost_float_bn_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream);   /* train: batch stats -> coef, running stats */
+int frost_float_bn_eval(const FrostFDesc* descs, int nlayers, void* stream);                  /* eval: running stats -> coef            */
+int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream);
+/* mode 0..3 as above with the layer's forward pack; mode 4: out = x . pack^T with no epilogue (data gradient: x = dc, pack = pack_t,
+ * cin/cout swapped).  gy / out rows may be slices of wider tensors: ldg / ldy = row length in elements. */
+int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, int mode,
+                   const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream);
+int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
+                   const uint16_t* gy, uint16_t* out, void* stream);
+int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream);
+int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream);
+int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream);
+int frost_float_stem_wscatter(const float* tmp, int cout, float* dw, void* stream);
+int frost_float_grad_merge(const uint16_t* res, const uint16_t* cat, int cs, int ccat, const uint16_t* sq, int64_t npix, int c, uint16_t* out,
+                           void* stream);
+int frost_float_avgpool(const uint16_t* x, int n, int hw, int c, const float* drop, float* y, void* stream);
+int frost_float_head_bwd(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
+                         const float* drop_mask, float* dw, float* dbias, uint16_t* gx, float* scratch_dpool, void* stream);
+
 typedef struct FrostOptTensor {
   float* p; float* g; float* exp_min; float* exp_max; float* coin; float* buf0; float* buf1; float* buf2;
   int64_t n; float weight_decay; float lr; int32_t first_step; int32_t pad;

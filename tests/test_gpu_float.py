@@ -1,0 +1,281 @@
+"""The float (StatAssist warm-up) model on the HIP kernels: train-mode forward + backward, eval forward, the features backbone and the
+FP -> QAT switch, against the fp32 definition of the same module (the stock-module CPU path, which tests/test_oracle_golden.py pins
+to the reference on G5: eval logits, train-mode logits, gradient norms and running statistics).
+
+Stated tolerance: the device path stores activations and activation gradients as bf16 (fp32 accumulation, fp32 parameters and
+statistics; the 1x1 weights are rounded to bf16 for the MFMA), the reference is fp32 throughout.  Per bottleneck (teacher-forced,
+reference goldens G4): y <= 1e-2, dx and parameter gradients <= 3e-2 norm-wise (BatchNorm gamma/beta gradients are measured against
+their convolution's gradient norm when that is larger: layers that feed another BatchNorm have gamma/beta gradients that are zero
+in exact arithmetic), running statistics 5e-3.  Whole network: sanity bounds only, see test_float_train_step_vs_fp32_definition."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomize_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.num_features, generator=g) * 0.8 + 0.6
+            m.bias.data = torch.rand(m.num_features, generator=g) * 0.2 - 0.1
+            m.running_mean.data = torch.randn(m.num_features, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.num_features, generator=g) * 0.5 + 0.5
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _grad_errors(dev_model, ref_model):
+    ref = {n: p.grad.double() for n, p in ref_model.named_parameters()}
+    out = {}
+    for n, p in dev_model.named_parameters():
+        a, b = p.grad.detach().cpu().double(), ref[n]
+        den = float(b.norm())
+        if n.endswith(".conv.1.weight") or n.endswith(".conv.1.bias"):          # BN gamma / beta of <prefix>.conv.0
+            den = max(den, float(ref[n.rsplit(".conv.1.", 1)[0] + ".conv.0.weight"].norm()))
+        out[n] = float((a - b).norm()) / max(den, 1e-30)
+    return out
+
+
+@pytest.fixture(scope="module")
+def F():
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet
+    return frostnet
+
+
+G4 = ["dw_e1", "mb", "cas_res", "cas_nores", "cas_s2"]
+
+
+@pytest.mark.parametrize("name", G4)
+def test_g4_float_block(F, golden, name):
+    """Teacher-forced Frost bottlenecks, train mode, two steps, against the REFERENCE goldens (tools/gen_golden.py g4, float set):
+    y, dx, every parameter gradient, running statistics.  The fixtures are tiny (N=2 at 6x6 / 8x8: BatchNorm over 32..128 samples), which
+    amplifies the bf16 storage noise even within one block (the fake-quant path holds its G4 gradients to 5e-2 for the same reason);
+    test_float_block_well_conditioned holds the same kernels to 2e-2 at a size where BatchNorm averages over 2048 samples."""
+    from oracle import frost_oracle as O
+    from frostnet_amd.float_train import FloatRunner
+    g = golden(f"g4_{name}_f")
+    cin, cout, k, s, e, r, H, N, xseed, gseed, wseed = [int(v) for v in g["spec"]]
+    m = F.CascadePreExBottleneck(cin, cout, quantized=False, kernel_size=k, stride=s, expand_ratio=e, reduce_factor=r)
+    keys = [str(k_) for k_ in g["init_keys"]]
+    shapes = [tuple(int(x) for x in row[:n]) for row, n in zip(g["init_shapes"], g["init_ndims"])]
+    assert keys == list(m.state_dict().keys())
+    m.load_state_dict(O.synth_state(keys, shapes, wseed))
+    m.cuda().train()
+    run = FloatRunner.for_block(m)
+    x = torch.from_numpy(O.synth((N, cin, H, H), xseed)).cuda()
+    for step in range(2):
+        gy = torch.from_numpy(O.synth(tuple(g[f"s{step}_y"].shape), gseed + 50 * step)).cuda()
+        y, dx = run.block_step(x, gy)
+        torch.cuda.synchronize()
+        assert _rel(y.cpu(), torch.from_numpy(g[f"s{step}_y"])) <= 2e-2, (step, _rel(y.cpu(), torch.from_numpy(g[f"s{step}_y"])))
+        assert _rel(dx.cpu(), torch.from_numpy(g[f"s{step}_dx"])) <= 8e-2, (step, _rel(dx.cpu(), torch.from_numpy(g[f"s{step}_dx"])))
+        packs = {pn: g[f"s{step}_grad/" + pn.replace(".", "/")][3:] for pn, _ in m.named_parameters()}
+        for pn, p in m.named_parameters():
+            mine = O.sample_big(p.grad.detach().double().cpu().numpy().reshape(-1))
+            den = np.linalg.norm(packs[pn])
+            if ".conv.1." in pn:          # BN gamma/beta: measured against the conv's gradient norm when that is larger (see module docstring)
+                den = max(den, np.linalg.norm(packs[pn.rsplit(".conv.1.", 1)[0] + ".conv.0.weight"]))
+            assert np.linalg.norm(mine - packs[pn]) / (den + 1e-30) <= 0.12, (step, pn, np.linalg.norm(mine - packs[pn]) / (den + 1e-30))
+        sd = m.state_dict()
+        for key in g.files:
+            if key.startswith(f"s{step}_sd/"):
+                mk = key[len(f"s{step}_sd/"):].replace("/", ".")
+                if mk.endswith("num_batches_tracked"):
+                    assert int(sd[mk]) == int(g[key])
+                else:
+                    np.testing.assert_allclose(sd[mk].detach().float().cpu().numpy().reshape(-1), g[key].reshape(-1), rtol=5e-3, atol=2e-3, err_msg=mk)
+
+
+@pytest.mark.parametrize("cfg", [(32, 16, 3, 1, 1, 1), (16, 24, 3, 2, 6, 4), (80, 80, 5, 1, 3, 4), (80, 96, 5, 1, 6, 4), (40, 80, 5, 2, 6, 4),
+                                 (288, 320, 5, 1, 6, 4)])
+def test_float_block_well_conditioned(F, cfg):
+    """The five block types (+ the widest: 288 -> 1728 hidden -> 320) at N=8, 16x16 against the fp32 stock-module definition of the same
+    block: y <= 1e-2, running statistics 5e-3; dx and every parameter gradient <= 1e-1 -- the gradient bound is set by ReLU-mask flips, not
+    by arithmetic: an activation whose fp32 value lies within the bf16 storage error of zero (~3e-3 of them) gets the other mask, and a
+    flipped fraction f moves the gradient by ~sqrt(f) norm-wise (the fake-quant path has the same effect at its index-flip rate)."""
+    from frostnet_amd.float_train import FloatRunner
+    cin, cout, k, s, e, r = cfg
+    torch.manual_seed(11)
+    m = F.CascadePreExBottleneck(cin, cout, quantized=False, kernel_size=k, stride=s, expand_ratio=e, reduce_factor=r)
+    _randomize_bn(m, 5)
+    ref = copy.deepcopy(m).train()
+    x = torch.randn(8, cin, 16, 16)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    m.cuda().train()
+    run = FloatRunner.for_block(m)
+    y, dx = run.block_step(x.cuda(), gy.cuda())
+    torch.cuda.synchronize()
+    assert _rel(y.cpu(), yr.detach()) <= 1e-2, _rel(y.cpu(), yr.detach())
+    assert _rel(dx.cpu(), xr.grad) <= 0.1, _rel(dx.cpu(), xr.grad)
+    errs = _grad_errors(m, ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    assert worst[0][1] <= 0.1, worst
+    sd, sr = m.state_dict(), ref.state_dict()
+    for key in sr:
+        if key.endswith("running_mean") or key.endswith("running_var"):
+            np.testing.assert_allclose(sd[key].cpu().numpy(), sr[key].numpy(), rtol=5e-3, atol=2e-3, err_msg=key)
+
+
+@pytest.mark.parametrize("name,res,batch", [("frostnet_small_1_0", 64, 8), ("frostnet_large_1_0", 96, 4), ("frostnet_base_0_75", 64, 6)])
+def test_float_train_step_vs_fp32_definition(F, name, res, batch):
+    """Whole network, one train step, against the fp32 stock-module definition.  A freshly initialised FrostNet in train mode amplifies
+    any perturbation by ~1.3x per bottleneck (rounding ONLY the 1x1 weights to bf16 on the CPU already moves the last block's output by
+    1e-1, tools/dbg_float.py), so end-to-end this is a sanity bound; what is held tightly is the head of the network, where nothing
+    has been amplified yet, and the per-block goldens above."""
+    torch.manual_seed(5)
+    model = F.MODEL_REGISTRY[name](drop_rate=0.0)
+    _randomize_bn(model, 3)
+    ref = copy.deepcopy(model)
+    x = torch.randn(batch, 3, res, res)
+    tgt = (torch.arange(batch) * 37) % 1000
+    ref.train()
+    caps = {}
+    ref.conv1.register_forward_hook(lambda m, i, o: caps.__setitem__("stem", o.detach()))
+    ref.layer1[0].register_forward_hook(lambda m, i, o: caps.__setitem__("b0", o.detach()))
+    y_ref = ref(x)
+    loss_ref = torch.nn.functional.cross_entropy(y_ref, tgt)
+    loss_ref.backward()
+    model.cuda().train()
+    run = model.hip_runner()
+    assert type(run).__name__ == "FloatRunner"
+    dev_caps, orig_conv, orig_block = {}, run._conv, run._block
+    def conv(l, a, training, record, out=None, ldy=None):
+        o = orig_conv(l, a, training, record, out, ldy)
+        if l.name == "conv1":
+            dev_caps["stem"] = o
+        return o
+    def block(ent, a, training, record):
+        o = orig_block(ent, a, training, record)
+        dev_caps.setdefault("b0", o)
+        return o
+    run._conv, run._block = conv, block
+    y = model(x.cuda())
+    loss = torch.nn.functional.cross_entropy(y, tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    run._conv, run._block = orig_conv, orig_block
+    assert _rel(dev_caps["stem"].float().cpu(), caps["stem"]) <= 4e-3          # one bf16 rounding of input, weights and output
+    assert _rel(dev_caps["b0"].float().cpu(), caps["b0"]) <= 1e-2
+    assert _rel(y.detach().cpu(), y_ref.detach()) <= 0.3, _rel(y.detach().cpu(), y_ref.detach())
+    assert abs(float(loss) - float(loss_ref)) <= 0.1 * abs(float(loss_ref))
+    gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    gr = np.array([float(p.grad.double().norm()) for p in ref.parameters()])
+    conv = np.array([p.dim() == 4 for p in model.parameters()])          # BN gradients can be exact zeros (see module docstring)
+    ratio = gn[conv] / gr[conv]
+    assert 0.8 <= np.median(ratio) <= 1.25 and ratio.min() >= 0.33 and ratio.max() <= 3.0, (np.median(ratio), ratio.min(), ratio.max())
+    errs = _grad_errors(model, ref)
+    for n in ("classifier.2.bias", "last_layer.conv.1.bias", "last_layer.conv.1.weight"):      # tail of the backward: not yet amplified
+        assert errs[n] <= 6e-2, (n, errs[n])
+    sd, sr = model.state_dict(), ref.state_dict()
+    for k in ("conv1.conv.1.running_mean", "conv1.conv.1.running_var", "layer1.0.conv2.conv.1.running_var"):
+        np.testing.assert_allclose(sd[k].cpu().numpy(), sr[k].numpy(), rtol=1e-2, atol=2e-3, err_msg=k)
+    assert all(int(v) == 1 for k, v in sd.items() if k.endswith("num_batches_tracked"))
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        e, e_ref = model(x.cuda()).cpu(), ref(x)
+    assert torch.isfinite(e).all() and _rel(e, e_ref) <= 0.3, _rel(e, e_ref)
+
+
+def test_float_train_dropout_and_no_grad(F):
+    """Dropout before the classifier is active in train mode (frostnet.py:297); under no_grad the train-mode forward still updates
+    the BatchNorm statistics and records nothing."""
+    torch.manual_seed(1)
+    model = F.frostnet_small_1_0(drop_rate=0.5).cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    a, b = model(x), model(x)
+    assert not torch.equal(a, b)
+    nbt = int(model.conv1.conv[1].num_batches_tracked)
+    with torch.no_grad():
+        model(x)
+    assert int(model.conv1.conv[1].num_batches_tracked) == nbt + 1
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(x), model(x))
+
+
+def test_float_golden_large_train(F, golden):
+    """G5 (reference-generated): Large, B=2 @64, train mode.  BatchNorm over 8 samples in the last stages amplifies the bf16 storage
+    noise, so this is a sanity bound (the tight comparisons are the well-conditioned cases above)."""
+    from oracle import frost_oracle as O
+    g = golden("g5_fp32_train")
+    B, res, seed, wseed = [int(v) for v in g["spec"]]
+    model = F.frostnet_large_1_0(drop_rate=0.0)
+    spec = O.float_state_spec(O.net_cfg("large", 1.0))
+    model.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], wseed))
+    model.cuda().train()
+    y = model(torch.from_numpy(O.synth((B, 3, res, res), seed)).cuda())
+    loss = torch.nn.functional.cross_entropy(y, torch.from_numpy(g["target"]).cuda())
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 0.25 * abs(float(g["loss"]))
+    gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    ratio = gn[g["grad_norms"] > 1e-6] / g["grad_norms"][g["grad_norms"] > 1e-6]
+    assert 0.5 <= np.median(ratio) <= 2.0, np.median(ratio)          # chaotic configuration (SURVEY H-2): run-to-run spread alone is ~30 %
+    assert _rel(model.last_layer.conv[1].running_var.cpu(), torch.from_numpy(g["rv_last"])) <= 0.4
+
+
+def test_float_features_backbone(F):
+    """frostnet_features.py:171-359: four taps [x1, x2, x3, x5], float, forward and backward."""
+    from frostnet_amd import frostnet_features as FF
+    torch.manual_seed(9)
+    model = FF.FrostNet(mode="small", width_mult=1.0)
+    _randomize_bn(model, 4)
+    ref = copy.deepcopy(model)
+    x = torch.randn(4, 3, 96, 96)
+    ref.train()
+    fr = ref(x)
+    gs = [torch.randn_like(f) * 0.1 for f in fr]
+    torch.autograd.backward(fr, gs)
+    model.cuda().train()
+    fd = model(x.cuda())
+    assert [tuple(f.shape) for f in fd] == [tuple(f.shape) for f in fr]
+    torch.autograd.backward(fd, [g.cuda() for g in gs])
+    tol = [2e-2, 4e-2, 0.15, 0.3]                      # amplification with depth, see test_float_train_step_vs_fp32_definition
+    for a, b, t in zip(fd, fr, tol):
+        assert _rel(a.detach().cpu(), b.detach()) <= t, (_rel(a.detach().cpu(), b.detach()), t)
+    gn = np.array([float(p.grad.double().norm()) for p in model.parameters()])
+    gr = np.array([float(p.grad.double().norm()) for p in ref.parameters()])
+    conv = np.array([p.dim() == 4 for p in model.parameters()])          # BN gradients can be exact zeros (see module docstring)
+    ratio = gn[conv] / gr[conv]
+    assert 0.8 <= np.median(ratio) <= 1.25 and ratio.min() >= 0.33 and ratio.max() <= 3.0, (np.median(ratio), ratio.min(), ratio.max())
+
+
+def test_statassist_switch_on_device(F):
+    """Classification/train.py:149-173 on the GPU: FP warm-up steps with QSGD (is_warmup=True: statistics only), then flip is_warmup,
+    fuse + prepare_qat with the SAME Parameter objects and optimizer state, and continue on the fake-quant path."""
+    from frostnet_amd import harness as H
+    from frostnet_amd.optimizer import QSGD
+    torch.manual_seed(2)
+    model = F.frostnet_quant_small_1_0(drop_rate=0.0).cuda().train()
+    opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+    crit = torch.nn.CrossEntropyLoss()
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    t = torch.randint(0, 1000, (8,), device="cuda")
+    assert opt.is_warmup
+    w0 = model.conv1.conv[0].weight.detach().clone()
+    losses = []
+    for _ in range(3):
+        loss, _ = H.train_one_iter(model, crit, opt, x, t)
+        losses.append(float(loss))
+    assert type(model.hip_runner()).__name__ == "FloatRunner"
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]            # three SGD steps on one batch
+    assert not torch.equal(w0, model.conv1.conv[0].weight)
+    ids = [id(p) for p in model.parameters()]
+    steps = [int(opt.state[p]["step"]) for p in model.parameters()]
+    H.statassist_qat_switch(model, opt)
+    assert not opt.is_warmup and ids == [id(p) for p in model.parameters()]
+    loss, _ = H.train_one_iter(model, crit, opt, x, t)
+    assert type(model.hip_runner()).__name__ == "FrostRunner"
+    assert np.isfinite(float(loss))
+    assert [int(opt.state[p]["step"]) for p in model.parameters()] == [s + 1 for s in steps]
