@@ -270,6 +270,8 @@ class FloatRunner:
     def _trunk(self, x, training, record):
         if x.dim() != 4 or x.shape[1] != 3 or not x.is_cuda:
             raise ValueError("expected an (N,3,H,W) tensor on the model's device")
+        if x.numel() == 0:
+            raise ValueError("empty batch")
         if x.dtype != torch.float32:
             x = x.float()
         n, _, h, w = x.shape

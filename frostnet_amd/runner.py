@@ -199,6 +199,10 @@ class FrostRunner:
         return self._forward_impl(x, record=False)
 
     def _trunk(self, x, training):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected an (N,3,H,W) tensor")
+        if x.numel() == 0:
+            raise ValueError("empty batch")
         E, obs = self.E, self.observe
         E.begin_step(observe=obs)
         a = E.quantize_input(x, self.q_in, observe=obs)
