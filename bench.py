@@ -20,6 +20,8 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per image, FrostNet-Large w=1.0 @224, int8 activations + bf16 gradients
 ALGO_BYTES_PER_IMG = 45_593_016
+FLOPS_I8_PER_IMG, FLOPS_BF16_PER_IMG = 861626432, 1701576832          # forward convs; dgrad + wgrad
+FLOPS_PER_IMG = FLOPS_I8_PER_IMG + FLOPS_BF16_PER_IMG                        # 2 563 203 264
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
@@ -226,6 +228,11 @@ def main():
                         whole_step=dict(achieved=round(value / world * ALGO_BYTES_PER_IMG / 1e9, 1), unit="GB/s",
                                         frac=round(value / world * ALGO_BYTES_PER_IMG / 1e9 / HBM_PEAK_GBS, 4),
                                         algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG),
+                        # secondary roof (north_star's "MFMA utilisation"): fwd convs on the int8 MFMA (861.6 MFLOP/img), dgrad + wgrad on
+                        # the bf16 MFMA (1701.6 MFLOP/img); dense peaks 5 POP/s int8, 2.5 PFLOP/s bf16.  The path is HBM-bound.
+                        mfma=dict(achieved=round(value / world * FLOPS_PER_IMG / 1e12, 2), unit="TFLOP/s",
+                                  frac_of_time_at_peak=round(value / world * (FLOPS_I8_PER_IMG / 5.0e15 + FLOPS_BF16_PER_IMG / 2.5e15), 4),
+                                  flops_per_image=FLOPS_PER_IMG),
                         breakdown_ms={k: round(v["total_ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
     if world > 1:
         dist.barrier()

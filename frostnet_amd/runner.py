@@ -97,6 +97,21 @@ class FrostRunner:
             rec[L.Q_SCALE] = fq.scale.reshape(-1)[0].float()
             rec[L.Q_INV] = 1.0 / fq.scale.reshape(-1)[0].float()
             rec.view(torch.int32)[L.Q_ZP] = fq.zero_point.reshape(-1)[0].to(torch.int32)
+        # torch.quantization.disable_observer / enable_observer (the helper at Classification/train.py:27-33, evaluate.py:131-143) call
+        # these methods on every FakeQuantize: honour them.  Granularity here is the whole network (the reference only ever applies
+        # them to the whole model): the last call wins.
+        orig_dis, orig_en = fq.disable_observer, fq.enable_observer
+
+        def _disable(orig=orig_dis):
+            orig()
+            self.observe = False
+
+        def _enable(enabled=True, orig=orig_en):
+            orig(enabled)
+            self.observe = bool(enabled)
+        fq.disable_observer, fq.enable_observer = _disable, _enable
+        if int(fq.observer_enabled[0]) == 0:       # frozen before the runner was built (one host read at bind time)
+            self.observe = False
         fq._buffers["scale"] = rec[L.Q_SCALE:L.Q_SCALE + 1]
         fq._buffers["zero_point"] = rec.view(torch.int32)[L.Q_ZP:L.Q_ZP + 1]
         obs._buffers["min_val"] = rec[L.Q_MIN]
@@ -147,6 +162,7 @@ class FrostRunner:
         nsites = 1 + 2 * (2 + 4 * len(blocks)) + 2 * len(blocks) + 2 + 8
         self.qa = QArena(nsites, self.device)
         self.rule127 = False
+        self.observe = True
         self.q_in = self._bind_fq(m.quant.activation_post_process, self.qa.alloc())
         self.stem = self._conv_layer("conv1", m.conv1, "stem")
         self.blocks = []
@@ -163,7 +179,6 @@ class FrostRunner:
                                                   1, 1, False, qw, qy))
             self.drop_rate = float(m.classifier[1].p)
         self.E.rule127 = 1 if self.rule127 else 0
-        self.observe = True
         # buffers were re-pointed: refresh the validity signature
         self._sig = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())
         # flat gradient arena, parameter order = model.parameters() (the reference's registration order)

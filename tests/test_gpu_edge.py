@@ -143,3 +143,56 @@ def test_empty_batch_raises(F):
     torch.cuda.synchronize()
     out = f(torch.randn(2, 3, 64, 64, device="cuda"))          # the device is still usable afterwards
     assert torch.isfinite(out).all()
+
+
+def test_full_size_properties_large_b512(F):
+    """BASELINE config c3 at its full size (Large, B = 512, 224x224) through size-independent properties:
+    (1) with the observers frozen (torch.quantization.disable_observer, Classification/evaluate.py:131-143) eval-mode inference is
+        per-image independent: the logits of a 512-image batch equal, bit for bit, the logits of its first 8 images run alone, and a
+        second run of the same batch is bit-identical (idempotence);
+    (2) a training step is invariant under a permutation of the batch: logits permute (to within a few quantisation steps: fp32
+        sum-of-squares order -> isolated index flips upstream), parameter-gradient norms are unchanged and the classifier's gradient agrees in direction."""
+    torch.manual_seed(1882)
+    model = F.frostnet_quant_large_1_0(drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    x = torch.randn(512, 3, 224, 224, device="cuda")
+    tgt = torch.randint(0, 1000, (512,), device="cuda")
+    for _ in range(2):                                      # observers / running statistics get real values
+        torch.nn.functional.cross_entropy(model(x), tgt).backward()
+    state = copy.deepcopy(model.state_dict())
+    # (2) permutation invariance of a training step
+    perm = torch.randperm(512, device="cuda")
+    outs = []
+    for xs, ts in ((x, tgt), (x[perm], tgt[perm])):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        y = model(xs)
+        torch.nn.functional.cross_entropy(y, ts).backward()
+        outs.append((y.detach().clone(), {n: p.grad.detach().double().clone() for n, p in model.named_parameters()}))
+    (y0, g0), (y1, g1) = outs
+    scale = float(model.classifier[2].activation_post_process.scale)
+    d = (y1 - y0[perm]).abs() / scale
+    # isolated index flips upstream (fp32 sum-of-squares order) reach the 8-bit logits as a perturbation well below one step, which
+    # still moves the ones sitting near a rounding boundary by exactly one step: bound the size, not the count
+    assert float(d.max()) <= 3.01 and _rel(y1, y0[perm]) <= 2e-2, (float(d.max()), _rel(y1, y0[perm]), float((d > 0.5).float().mean()))
+    # gradients: index flips multiply through a freshly initialised 8-bit network (SURVEY H-2: the reference moves 5.5e-2 when its
+    # thread count changes; tools/dbg_sites.py shows 6e-5 flipped indices after the first block becoming 4e-3, 9e-2, 4e-1 after the
+    # next three), so directions are only comparable at the tail of the backward; norms are stable everywhere
+    assert float((g0["classifier.2.weight"] - g1["classifier.2.weight"]).norm() / g0["classifier.2.weight"].norm()) <= 5e-2
+    for n in g0:
+        if g0[n].dim() == 4:
+            assert torch.isfinite(g1[n]).all() and 0.7 <= float(g1[n].norm() / g0[n].norm()) <= 1.4, (n, float(g1[n].norm() / g0[n].norm()))
+    # (1) frozen observers: per-image independence and idempotence in eval mode
+    model.load_state_dict(state)
+    model.eval()
+    model.apply(torch.quantization.disable_observer)
+    assert model.hip_runner().observe is False
+    with torch.no_grad():
+        a = model(x)
+        b = model(x)
+        c = model(x[:8].contiguous())
+    assert torch.equal(a, b)
+    assert torch.equal(a[:8], c)
+    model.apply(torch.quantization.enable_observer)
+    assert model.hip_runner().observe is True
