@@ -71,113 +71,179 @@ extern "C" int frost_infer_stem_im2col(const float* x, int n, int h, int w, int6
 }
 
 // ------------------------------------------------------------------------------------------------ pointwise (bf16 MFMA GEMM)
-// y[p][co] = act( sum_k T[p][k] * W'[co][k] + b'[co] ).  64-pixel tile per workgroup staged once in LDS (coalesced 16-byte loads), each of
-// the 4 waves owns 16 pixels and walks the channel tiles four at a time; weight fragments are 1 KiB wave-loads from the packed (L2-resident) matrix.
-// WPX = waves along pixels (4: 64-pixel tile, every wave all channels; 1: 16-pixel tile shared by the 4 waves, which split the channel
-// tiles -- rows too long for a 64-row LDS tile, i.e. the 7x7 layers with 720..1728 input channels)
-template <int WPX>
+// y[p][co] = act( sum_k T[p][k] * W'[co][k] + b'[co] ).  A pixel tile is staged once in LDS (coalesced 16-byte loads).
+//   WPX = 4, NPS = 2: 128-pixel tile, wave w owns 32 pixels (two 16-pixel subtiles) and walks the channel tiles four at a time: every
+//                     1 KiB weight fragment (L2-resident pack) feeds two MFMAs, and the fragments of K-step kb+1 are requested before the
+//                     MFMAs of kb (an L2 round trip is ~700 cycles: unprefetched it sat on every K step);
+//   WPX = 4, NPS = 1: 64-pixel tile (rows too long for 128 LDS rows);
+//   WPX = 1, NPS = 1: 16-pixel tile shared by the 4 waves, which split the channel tiles (the 7x7 layers with 720..1728 input channels).
+template <int WPX, int NPS, bool RES>
 __global__ __launch_bounds__(256) void k_inf_pw(const uint16_t* __restrict__ T, const uint16_t* __restrict__ pack, const float* __restrict__ biasf,
-                                                int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu, uint16_t* __restrict__ y) {
+                                                int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu, uint16_t* __restrict__ y, int64_t ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int IPX = 16 * WPX, WCH = 4 / WPX;
+  constexpr int IPX = 16 * WPX * NPS, WCH = 4 / WPX;
   const int wpx = w % WPX, wch = w / WPX;
-  const int64_t p0 = (int64_t)blockIdx.x * IPX;
   const int rowb = cin * 2; const int U = (KB * 64) >> 4;          // 16-byte units per (K-padded) row
-  for (int u = tid; u < IPX * U; u += 256) {
-    const int row = u / U, col = (u - row * U) << 4;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if ((p0 + row) < npix && col < rowb) v = *(const uint4*)((const uint8_t*)T + (p0 + row) * rowb + col);
-    *(uint4*)(smem + row * kstr + col) = v;
-  }
-  __syncthreads();
   const int CT = cpad >> 4;
-  const int64_t prow = p0 + wpx * 16 + j;
   const float lo = relu ? 0.0f : -INFINITY;
-  for (int ct0 = wch * 4; ct0 < CT; ct0 += 4 * WCH) {
-    v4f acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int kb = 0; kb < KB; ++kb) {
-      const v4i bfr = *(const v4i*)(smem + (wpx * 16 + j) * kstr + kb * 64 + g * 16);
-      v4i afr[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) if (ct0 + m < CT) afr[m] = *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 3));
+  // RES: the whole packed weight matrix is copied into LDS once per (persistent) workgroup: without it every wave re-fetches all of it
+  // from L2 for each 16 (32) pixels -- 12x the activation bytes on a 16 -> 96 layer
+  const uint8_t* wl = smem + IPX * kstr;
+  if (RES) { for (int i = tid; i < CT * KB * 64; i += 256) ((uint4*)wl)[i] = ((const uint4*)pack)[i]; }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * IPX;
+    __syncthreads();
+    for (int u = tid; u < IPX * U; u += 256) {
+      const int row = u / U, col = (u - row * U) << 4;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((p0 + row) < npix && col < rowb) v = *(const uint4*)((const uint8_t*)T + (p0 + row) * rowb + col);
+      *(uint4*)(smem + row * kstr + col) = v;
+    }
+    __syncthreads();
+    for (int ct0 = wch * 4; ct0 < CT; ct0 += 4 * WCH) {
+      v4f acc[4][NPS];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        if (ct0 + m < CT) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr), acc[m], 0, 0, 0);
-    }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int ch0 = (ct0 + m) * 16 + 4 * g;
-      if (ct0 + m < CT && ch0 < cout && prow < npix) {
-        const float4 b4 = *(const float4*)(biasf + ch0);
-        uint2 o; o.x = cvt_pk_bf16(fmaxf(acc[m][0] + b4.x, lo), fmaxf(acc[m][1] + b4.y, lo)); o.y = cvt_pk_bf16(fmaxf(acc[m][2] + b4.z, lo), fmaxf(acc[m][3] + b4.w, lo));
-        *(uint2*)(y + prow * cout + ch0) = o;
+        for (int t = 0; t < NPS; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+      v4i afr[4], afn[4];
+      auto load_a = [&](int kb, v4i (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (ct0 + m < CT) dst[m] = RES ? *(const v4i*)(wl + ((((ct0 + m) * KB + kb) * 64 + lane) << 4)) : *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 3));
+      };
+      if (!RES) load_a(0, afr);
+      for (int kb = 0; kb < KB; ++kb) {
+        v4i bfr[NPS];
+#pragma unroll
+        for (int t = 0; t < NPS; ++t) bfr[t] = *(const v4i*)(smem + ((wpx * NPS + t) * 16 + j) * kstr + kb * 64 + g * 16);
+        if (RES) load_a(kb, afr); else if (kb + 1 < KB) load_a(kb + 1, afn);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (ct0 + m < CT) {
+#pragma unroll
+            for (int t = 0; t < NPS; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr[t]), acc[m][t], 0, 0, 0);
+          }
+        if (!RES) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) afr[m] = afn[m];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int ch0 = (ct0 + m) * 16 + 4 * g;
+        if (ct0 + m < CT && ch0 < cout) {
+          const float4 b4 = *(const float4*)(biasf + ch0);
+#pragma unroll
+          for (int t = 0; t < NPS; ++t) {
+            const int64_t prow = p0 + (wpx * NPS + t) * 16 + j;
+            if (prow < npix) {
+              uint2 o; o.x = cvt_pk_bf16(fmaxf(acc[m][t][0] + b4.x, lo), fmaxf(acc[m][t][1] + b4.y, lo)); o.y = cvt_pk_bf16(fmaxf(acc[m][t][2] + b4.z, lo), fmaxf(acc[m][t][3] + b4.w, lo));
+              *(uint2*)(y + prow * cout + ch0) = o;
+            }
+          }
+        }
       }
     }
   }
+}
+template <int WPX, int NPS, bool RES>
+static void launch_inf_pw(hipStream_t s, size_t lds, int64_t grid_cap, const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout,
+                          int cpad, int KB, int kstr, int relu, uint16_t* y) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_inf_pw<WPX, NPS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  constexpr int IPX = 16 * WPX * NPS;
+  const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+  hipLaunchKernelGGL((k_inf_pw<WPX, NPS, RES>), dim3((unsigned)grid), dim3(256), lds, s, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y, nt);
 }
 extern "C" int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
                               uint16_t* y, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "infer_pw: cin must be a multiple of 8, cout of 4");
   const int KB = (cin + 31) / 32; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)k_inf_pw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_inf_pw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  if ((size_t)64 * kstr <= 64 * 1024)
-    hipLaunchKernelGGL(k_inf_pw<4>, dim3((unsigned)((npix + 63) / 64)), dim3(256), (size_t)64 * kstr, as_stream(stream), x, pack, biasf, npix, cin, cout,
-                       cpad, KB, kstr, relu, y);
+  hipStream_t s = as_stream(stream);
+  const size_t wbytes = (size_t)(cpad / 16) * KB * 1024;
+  const size_t t128 = (size_t)128 * kstr, t64 = (size_t)64 * kstr;
+  // measured (B = 256): resident weights pay only while 4-5 workgroups still fit a CU (<= 32 KB: +2 %); at 64 KB per workgroup the
+  // stage -> barrier -> compute loop of two resident workgroups no longer overlaps anything (-9 %)
+  if (t64 + wbytes <= 32 * 1024 && npix >= 64 * 2048)
+    launch_inf_pw<4, 1, true>(s, t64 + wbytes, 2560, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
+  else if (t128 <= 40 * 1024 && npix >= 128 * 512)
+    launch_inf_pw<4, 2, false>(s, t128, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
+  else if (t64 <= 64 * 1024)
+    launch_inf_pw<4, 1, false>(s, t64, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
   else {
     FROST_REQUIRE((size_t)16 * kstr <= 160 * 1024, "infer_pw: row too long for the LDS tile");
-    hipLaunchKernelGGL(k_inf_pw<1>, dim3((unsigned)((npix + 15) / 16)), dim3(256), (size_t)16 * kstr, as_stream(stream), x, pack, biasf, npix, cin, cout,
-                       cpad, KB, kstr, relu, y);
+    launch_inf_pw<1, 1, false>(s, (size_t)16 * kstr, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
   }
   return frost_check_launch("infer_pw");
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise (fp32 FMA)
-// one thread = one output pixel x 8 channels: k*k 16-byte loads (NHWC: the 8 channels are contiguous), fp32 accumulate
+// one thread = 8 channels x 4 consecutive output pixels of a row: per kernel row the (3*stride + k) input columns are loaded once
+// (NHWC: 8 channels = one 16-byte load) and every tap's weights once for the four outputs -- 2-2.5x fewer loads than one output per thread
+#define IDW_WO 4
+template <int K, int S>
 __global__ __launch_bounds__(256) void k_inf_dw(const uint16_t* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ biasf, int n,
-                                                int h, int w, int c, int cpad, int k, int stride, int ho, int wo, int relu, uint16_t* __restrict__ y) {
-  const int c8n = c >> 3; const int pad = (k - 1) / 2;
-  const int64_t tot = (int64_t)n * ho * wo * c8n;
+                                                int h, int w, int c, int cpad, int ho, int wo, int relu, uint16_t* __restrict__ y) {
+  constexpr int PAD = (K - 1) / 2, SPAN = (IDW_WO - 1) * S + K;
+  const int c8n = c >> 3; const int wo4 = (wo + IDW_WO - 1) / IDW_WO;
+  const int64_t tot = (int64_t)n * ho * wo4 * c8n;
   const float lo = relu ? 0.0f : -INFINITY;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(i % c8n); int64_t p = i / c8n; const int ox = (int)(p % wo); p /= wo; const int oy = (int)(p % ho); const int in = (int)(p / ho);
-    const int ch = c8 * 8;
-    float acc[8];
-    { const float4 b0 = *(const float4*)(biasf + ch), b1 = *(const float4*)(biasf + ch + 4); acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w; }
-    for (int ky = 0; ky < k; ++ky) {
-      const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
-      for (int kx = 0; kx < k; ++kx) {
-        const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
-        const uint4 v = *(const uint4*)(x + (((int64_t)in * h + iy) * w + ix) * c + ch);
-        const float* wp = wf + (ky * k + kx) * cpad + ch;
+    const int c8 = (int)(i % c8n); int64_t p = i / c8n; const int oxg = (int)(p % wo4); p /= wo4; const int oy = (int)(p % ho); const int in = (int)(p / ho);
+    const int ch = c8 * 8, ox0 = oxg * IDW_WO, ix0 = ox0 * S - PAD;
+    float acc[IDW_WO][8];
+    { const float4 b0 = *(const float4*)(biasf + ch), b1 = *(const float4*)(biasf + ch + 4);
+#pragma unroll
+      for (int o = 0; o < IDW_WO; ++o) { acc[o][0] = b0.x; acc[o][1] = b0.y; acc[o][2] = b0.z; acc[o][3] = b0.w; acc[o][4] = b1.x; acc[o][5] = b1.y; acc[o][6] = b1.z; acc[o][7] = b1.w; } }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S - PAD + ky; if (iy < 0 || iy >= h) continue;
+      const uint16_t* rowp = x + ((int64_t)in * h + iy) * w * c + ch;
+      float col[SPAN][8];
+#pragma unroll
+      for (int q = 0; q < SPAN; ++q) {
+        const int ix = ix0 + q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ix >= 0 && ix < w) v = *(const uint4*)(rowp + (int64_t)ix * c);
+        col[q][0] = bf2f(v.x & 0xffff); col[q][1] = bf2f(v.x >> 16); col[q][2] = bf2f(v.y & 0xffff); col[q][3] = bf2f(v.y >> 16);
+        col[q][4] = bf2f(v.z & 0xffff); col[q][5] = bf2f(v.z >> 16); col[q][6] = bf2f(v.w & 0xffff); col[q][7] = bf2f(v.w >> 16);
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float* wp = wf + (ky * K + kx) * cpad + ch;
         const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
-        acc[0] = fmaf(bf2f(v.x & 0xffff), w0.x, acc[0]); acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
-        acc[2] = fmaf(bf2f(v.y & 0xffff), w0.z, acc[2]); acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
-        acc[4] = fmaf(bf2f(v.z & 0xffff), w1.x, acc[4]); acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
-        acc[6] = fmaf(bf2f(v.w & 0xffff), w1.z, acc[6]); acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int o = 0; o < IDW_WO; ++o)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(col[o * S + kx][e], wv[e], acc[o][e]);
       }
     }
-    uint4 o;
-    o.x = cvt_pk_bf16(fmaxf(acc[0], lo), fmaxf(acc[1], lo)); o.y = cvt_pk_bf16(fmaxf(acc[2], lo), fmaxf(acc[3], lo));
-    o.z = cvt_pk_bf16(fmaxf(acc[4], lo), fmaxf(acc[5], lo)); o.w = cvt_pk_bf16(fmaxf(acc[6], lo), fmaxf(acc[7], lo));
-    *(uint4*)(y + (((int64_t)in * ho + oy) * wo + ox) * c + ch) = o;
+#pragma unroll
+    for (int o = 0; o < IDW_WO; ++o) {
+      if (ox0 + o < wo) {
+        uint4 ov;
+        ov.x = cvt_pk_bf16(fmaxf(acc[o][0], lo), fmaxf(acc[o][1], lo)); ov.y = cvt_pk_bf16(fmaxf(acc[o][2], lo), fmaxf(acc[o][3], lo));
+        ov.z = cvt_pk_bf16(fmaxf(acc[o][4], lo), fmaxf(acc[o][5], lo)); ov.w = cvt_pk_bf16(fmaxf(acc[o][6], lo), fmaxf(acc[o][7], lo));
+        *(uint4*)(y + (((int64_t)in * ho + oy) * wo + ox0 + o) * c + ch) = ov;
+      }
+    }
   }
 }
 extern "C" int frost_infer_dw(const uint16_t* x, const float* wf, const float* biasf, int n, int h, int w, int c, int k, int stride, int relu,
                               uint16_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "infer_dw: channels must be a multiple of 8");
+  FROST_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "infer_dw: 3x3 / 5x5, stride 1 / 2");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
-  const int64_t tot = (int64_t)n * ho * wo * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(k_inf_dw, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, wf, biasf, n, h, w, c, round_up(c, 16), k, stride, ho, wo,
-                     relu, y);
+  const int64_t tot = (int64_t)n * ho * ((wo + IDW_WO - 1) / IDW_WO) * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
+  hipStream_t s = as_stream(stream);
+#define IDW_LAUNCH(K_, S_) hipLaunchKernelGGL((k_inf_dw<K_, S_>), dim3((unsigned)grid), dim3(256), 0, s, x, wf, biasf, n, h, w, c, round_up(c, 16), ho, wo, relu, y)
+  if (k == 3 && stride == 1) IDW_LAUNCH(3, 1); else if (k == 3) IDW_LAUNCH(3, 2); else if (stride == 1) IDW_LAUNCH(5, 1); else IDW_LAUNCH(5, 2);
+#undef IDW_LAUNCH
   return frost_check_launch("infer_dw");
 }
 
