@@ -234,3 +234,27 @@ def test_per_layer_finalize_path_matches_table_path(fa):
         sib = n.replace("bn.weight", "weight").replace("bn.bias", "weight")
         den = max(float(b[n].norm()), float(b[sib].norm()), 1e-30)
         assert float((a[n] - b[n]).norm()) / den <= 5e-2, n
+
+
+def test_qat_training_reduces_loss_on_one_batch(fa):
+    """helper_functions.py:139-143 repeated on ONE batch: forward, CE, backward, GradBoost-SGD step (StatAssist statistics only, i.e.
+    is_warmup=True: no injected noise, so the run is deterministic up to atomic order).  If the gradients or the update were wrong in
+    sign or scale the loss would not fall."""
+    F = fa["frostnet"]
+    from frostnet_amd import harness as H
+    from frostnet_amd.optimizer import QSGD
+    torch.manual_seed(7)
+    model = F.frostnet_quant_small_1_0(drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    model.cuda()
+    opt = QSGD(H.make_param_groups(model, 1e-5), lr=2e-2, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+    assert opt.is_warmup
+    crit = torch.nn.CrossEntropyLoss()
+    x = torch.randn(32, 3, 96, 96, device="cuda")
+    t = torch.randint(0, 1000, (32,), device="cuda")
+    losses = []
+    for _ in range(12):
+        loss, _ = H.train_one_iter(model, crit, opt, x, t)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[-3:]) < 0.8 * losses[0], losses
