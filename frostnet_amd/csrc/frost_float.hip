@@ -281,21 +281,24 @@ extern "C" int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const u
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise passes (fp32 FMA)
-// one thread = 8 channels (fixed for the thread's whole life, so statistics stay in registers) x a strided set of output pixels
-template <int MODE>
-__global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16_t* __restrict__ x, int n, int h, int w, int c, int cpad, int k, int stride,
-                                              int ho, int wo, int relu, const uint16_t* __restrict__ gy, uint16_t* __restrict__ y) {
+// one thread = 8 channels (fixed for the thread's whole life, so statistics stay in registers) x a strided set of output-pixel PAIRS
+// (two horizontally adjacent outputs share the S + K input columns of a kernel row and every tap's weights: 1.5-1.7x fewer loads)
+#define FDW_WO 2
+template <int MODE, int K, int S>
+__global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16_t* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo,
+                                              int relu, const uint16_t* __restrict__ gy, uint16_t* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
+  constexpr int PAD = (K - 1) / 2, SPAN = (FDW_WO - 1) * S + K;
   float* sacc = (float*)smem;
   const int tid = threadIdx.x;
   if (RED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f; __syncthreads(); }
-  const int c8n = c >> 3; const int pad = (k - 1) / 2;
+  const int c8n = c >> 3; const int wog = (wo + FDW_WO - 1) / FDW_WO;
   const int64_t nthreads = (int64_t)gridDim.x * 256; const int64_t PP = nthreads / c8n;
   const int64_t t = (int64_t)blockIdx.x * 256 + tid;
   const int c8 = (int)(t % c8n); const int64_t slot = t / c8n;
   const int ch = c8 * 8;
-  const int64_t npix = (int64_t)n * ho * wo;
+  const int64_t nunits = (int64_t)n * ho * wog;
   const float* wf = (const float*)dp->pack; const float* coef = dp->coef;
   float sc[8], bi[8], c2[8], c3[8], c4[8];
   if (MODE != F_STATS) {
@@ -311,49 +314,68 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
   for (int e = 0; e < 8; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
   const float lo = relu ? 0.0f : -INFINITY;
   if (slot < PP) {
-    for (int64_t p = slot; p < npix; p += PP) {
-      int64_t pp = p; const int ox = (int)(pp % wo); pp /= wo; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
-      float acc[8];
+    for (int64_t u = slot; u < nunits; u += PP) {
+      int64_t pp = u; const int oxg = (int)(pp % wog); pp /= wog; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
+      const int ox0 = oxg * FDW_WO, ix0 = ox0 * S - PAD;
+      float acc[FDW_WO][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
-      for (int ky = 0; ky < k; ++ky) {
-        const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
-        for (int kx = 0; kx < k; ++kx) {
-          const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
-          const uint4 v = *(const uint4*)(x + (((int64_t)in * h + iy) * w + ix) * c + ch);
-          const float* wp = wf + (ky * k + kx) * cpad + ch;
+      for (int o = 0; o < FDW_WO; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - PAD + ky; if (iy < 0 || iy >= h) continue;
+        const uint16_t* rowp = x + ((int64_t)in * h + iy) * w * c + ch;
+        float col[SPAN][8];
+#pragma unroll
+        for (int qx = 0; qx < SPAN; ++qx) {
+          const int ix = ix0 + qx;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (ix >= 0 && ix < w) v = *(const uint4*)(rowp + (int64_t)ix * c);
+          col[qx][0] = bf2f(v.x & 0xffff); col[qx][1] = bf2f(v.x >> 16); col[qx][2] = bf2f(v.y & 0xffff); col[qx][3] = bf2f(v.y >> 16);
+          col[qx][4] = bf2f(v.z & 0xffff); col[qx][5] = bf2f(v.z >> 16); col[qx][6] = bf2f(v.w & 0xffff); col[qx][7] = bf2f(v.w >> 16);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float* wp = wf + (ky * K + kx) * cpad + ch;
           const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
-          acc[0] = fmaf(bf2f(v.x & 0xffff), w0.x, acc[0]); acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
-          acc[2] = fmaf(bf2f(v.y & 0xffff), w0.z, acc[2]); acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
-          acc[4] = fmaf(bf2f(v.z & 0xffff), w1.x, acc[4]); acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
-          acc[6] = fmaf(bf2f(v.w & 0xffff), w1.z, acc[6]); acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int o = 0; o < FDW_WO; ++o)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[o][e] = fmaf(col[o * S + kx][e], wv[e], acc[o][e]);
         }
       }
-      if constexpr (MODE == F_STATS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += acc[e]; q[e] = fmaf(acc[e], acc[e], q[e]); }
-      } else if constexpr (MODE == F_EMIT) {
-        float o8[8];
+      for (int o = 0; o < FDW_WO; ++o) {
+        if (ox0 + o >= wo) continue;
+        const int64_t p = ((int64_t)in * ho + oy) * wo + ox0 + o;
+        if constexpr (MODE == F_STATS) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(acc[e], sc[e], bi[e]), lo);
-        uint4 o; o.x = cvt_pk_bf16(o8[0], o8[1]); o.y = cvt_pk_bf16(o8[2], o8[3]); o.z = cvt_pk_bf16(o8[4], o8[5]); o.w = cvt_pk_bf16(o8[6], o8[7]);
-        *(uint4*)(y + p * c + ch) = o;
-      } else {
-        const uint4 gv = *(const uint4*)(gy + p * c + ch);
-        float gm[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
-        if (relu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) if (!(fmaf(acc[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
-        }
-        if constexpr (MODE == F_BRED) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += gm[e]; q[e] = fmaf(gm[e], (acc[e] - c2[e]) * c3[e], q[e]); }
-        } else {
+          for (int e = 0; e < 8; ++e) { s[e] += acc[o][e]; q[e] = fmaf(acc[o][e], acc[o][e], q[e]); }
+        } else if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = fmaf(gm[e], c2[e], fmaf(acc[e], c3[e], c4[e]));
-          uint4 o; o.x = cvt_pk_bf16(o8[0], o8[1]); o.y = cvt_pk_bf16(o8[2], o8[3]); o.z = cvt_pk_bf16(o8[4], o8[5]); o.w = cvt_pk_bf16(o8[6], o8[7]);
-          *(uint4*)(y + p * c + ch) = o;
+          for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(acc[o][e], sc[e], bi[e]), lo);
+          uint4 ov; ov.x = cvt_pk_bf16(o8[0], o8[1]); ov.y = cvt_pk_bf16(o8[2], o8[3]); ov.z = cvt_pk_bf16(o8[4], o8[5]); ov.w = cvt_pk_bf16(o8[6], o8[7]);
+          *(uint4*)(y + p * c + ch) = ov;
+        } else {
+          const uint4 gv = *(const uint4*)(gy + p * c + ch);
+          float gm[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (!(fmaf(acc[o][e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
+          }
+          if constexpr (MODE == F_BRED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += gm[e]; q[e] = fmaf(gm[e], (acc[o][e] - c2[e]) * c3[e], q[e]); }
+          } else {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = fmaf(gm[e], c2[e], fmaf(acc[o][e], c3[e], c4[e]));
+            uint4 ov; ov.x = cvt_pk_bf16(o8[0], o8[1]); ov.y = cvt_pk_bf16(o8[2], o8[3]); ov.z = cvt_pk_bf16(o8[4], o8[5]); ov.w = cvt_pk_bf16(o8[6], o8[7]);
+            *(uint4*)(y + p * c + ch) = ov;
+          }
         }
       }
     }
@@ -368,21 +390,30 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
     for (int i = tid; i < 2 * cpad; i += 256) { const float v = sacc[i]; if (v != 0.0f) atomicAdd(st + i, (double)v); }
   }
 }
+template <int K, int S>
+static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int cpad, int ho,
+                        int wo, int relu, const uint16_t* gy, uint16_t* out) {
+#define FDW_LAUNCH(M) hipLaunchKernelGGL((k_f_dw<M, K, S>), dim3((unsigned)grid), dim3(256), lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out)
+  switch (mode) { case F_STATS: FDW_LAUNCH(F_STATS); break; case F_EMIT: FDW_LAUNCH(F_EMIT); break; case F_BRED: FDW_LAUNCH(F_BRED); break; default: FDW_LAUNCH(F_BDC); }
+#undef FDW_LAUNCH
+}
 extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
                               const uint16_t* gy, uint16_t* out, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "float_dw: channels must be a multiple of 8");
   FROST_REQUIRE(mode >= 0 && mode <= 3, "float_dw: mode 0..3");
+  FROST_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "float_dw: 3x3 / 5x5, stride 1 / 2");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
-  const int64_t tot = (int64_t)n * ho * wo * c8n;
+  const int64_t tot = (int64_t)n * ho * ((wo + FDW_WO - 1) / FDW_WO) * c8n;
   const bool red = (mode == F_STATS || mode == F_BRED);
   int64_t grid = (tot + 255) / 256; const int64_t cap = red ? 2048 : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;      // every channel group needs at least one thread
   const size_t lds = red ? (size_t)2 * cpad * 4 : 0;
   hipStream_t s = as_stream(stream);
-#define FDW_LAUNCH(M) hipLaunchKernelGGL(k_f_dw<M>, dim3((unsigned)grid), dim3(256), lds, s, desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, gy, out)
-  switch (mode) { case F_STATS: FDW_LAUNCH(F_STATS); break; case F_EMIT: FDW_LAUNCH(F_EMIT); break; case F_BRED: FDW_LAUNCH(F_BRED); break; default: FDW_LAUNCH(F_BDC); }
-#undef FDW_LAUNCH
+  if (k == 3 && stride == 1) launch_f_dw<3, 1>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else if (k == 3) launch_f_dw<3, 2>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else if (stride == 1) launch_f_dw<5, 1>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else launch_f_dw<5, 2>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
   return frost_check_launch("float_dw");
 }
 
