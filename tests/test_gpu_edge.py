@@ -196,3 +196,62 @@ def test_full_size_properties_large_b512(F):
     assert torch.equal(a[:8], c)
     model.apply(torch.quantization.enable_observer)
     assert model.hip_runner().observe is True
+
+
+@pytest.mark.parametrize("mode,width", [("base", 1.25), ("large", 0.35), ("small", 0.75)])
+def test_qat_width_multipliers_vs_oracle(F, mode, width):
+    """The factory grid (frostnet.py:354-451: 3 modes x 5 width multipliers): channel counts off the 1.0 tables (multiples of 8 via
+    _make_divisible) through the same kernels -- train-mode first step at B=4 @ 64, head of the network against the oracle."""
+    tag = {1.25: "1_25", 0.35: "0_35", 0.75: "0_75"}[width]
+    cfg = O.net_cfg(mode, width)
+    spec = O.float_state_spec(cfg)
+    P, B = O.make_state(spec, 5000, True)
+    qs = O.QState(B)
+    x = T(O.synth((4, 3, 64, 64), 900))
+    y_ref = O.frostnet_forward(P, qs, cfg, x, True, True)
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_{tag}"](drop_rate=0.0)
+    assert [k for k, _ in spec] == list(model.state_dict().keys())
+    model.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], 5000))
+    F.qat_prepare(model, version=0)
+    model.cuda()
+    y = model(x.cuda())
+    torch.nn.functional.cross_entropy(y, torch.tensor([1, 2, 3, 4]).cuda()).backward()
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    for k in ("quant.activation_post_process.scale", "conv1.conv.0.activation_post_process.scale", "conv1.conv.0.bn.running_var",
+              "layer1.0.conv2.conv.0.activation_post_process.scale", "layer1.0.reduce_conv.conv.0.bn.running_mean"):
+        np.testing.assert_allclose(sd[k].float().cpu().numpy().reshape(-1), qs.sd[k].float().numpy().reshape(-1), rtol=5e-3, atol=1e-5, err_msg=k)
+    assert y.shape == y_ref.shape and torch.isfinite(y).all()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_checkpoint_resume_round_trip(F):
+    """Classification/train.py:205-222 keeps `state_dict` + `optimizer` in the checkpoint: a model / optimizer pair restored from them on the
+    device continues exactly like the original (forward bit-identical, same update up to atomic-order noise in the gradients)."""
+    from frostnet_amd import harness as H
+    from frostnet_amd.optimizer import QSGD
+
+    def make():
+        m = F.frostnet_quant_small_1_0(drop_rate=0.0)
+        F.qat_prepare(m, version=0)
+        m.cuda()
+        o = QSGD(H.make_param_groups(m, 1e-5), lr=1e-2, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+        return m, o
+    torch.manual_seed(3)
+    crit = torch.nn.CrossEntropyLoss()
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    t = torch.randint(0, 1000, (8,), device="cuda")
+    m1, o1 = make()
+    for _ in range(2):
+        H.train_one_iter(m1, crit, o1, x, t)
+    ck = {"state_dict": {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}, "optimizer": copy.deepcopy(o1.state_dict())}
+    m2, o2 = make()
+    m2.load_state_dict(ck["state_dict"])
+    o2.load_state_dict(ck["optimizer"])
+    assert o2.is_warmup == o1.is_warmup
+    l1, y1 = H.train_one_iter(m1, crit, o1, x, t)
+    l2, y2 = H.train_one_iter(m2, crit, o2, x, t)
+    assert torch.equal(y1, y2) and float(l1) == float(l2)                    # the forward is deterministic given the state
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert float((p1 - p2).abs().max()) <= 1e-3 * max(float(p1.abs().max()), 1e-3), n
+    assert [int(o2.state[p]["step"]) for p in m2.parameters()] == [int(o1.state[p]["step"]) for p in m1.parameters()]
