@@ -73,8 +73,53 @@ def pmc_traffic(label, batch):
         return None, None
 
 
+def side_workload(args, dev):
+    """The two other device workloads, same timing protocol, single GPU: `infer` = BASELINE.json config c2 (float model, bf16 inference,
+    B = 256 by default), `float` = the StatAssist warm-up training step (float model, forward + backward + QSGD step, is_warmup)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, harness as H
+    from frostnet_amd.optimizer import QSGD
+    torch.manual_seed(1882)
+    batch = args.batch if args.batch != 512 else 256
+    model = F.MODEL_REGISTRY[f"frostnet_{args.mode}_1_0"]().to(dev)
+    g = torch.Generator(device=dev).manual_seed(1882)
+    x = torch.randn(batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    tgt = torch.randint(0, 1000, (batch,), device=dev, generator=g)
+    if args.workload == "infer":
+        model.eval()
+        step = lambda: model.hip_infer_bf16(x)
+        bytes_per_img, metric, dtype = 26_130_000, "images/sec FrostNet-Large 224x224 bf16 inference", "bf16"
+        what = f"FrostNet-{args.mode.capitalize()} float model, bf16 inference (BatchNorm folded), batch={batch}, {args.res}x{args.res} NHWC (BASELINE.json config c2)"
+    else:
+        model.train()
+        opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+        crit = torch.nn.CrossEntropyLoss()
+        step = lambda: H.train_one_iter(model, crit, opt, x, tgt)
+        bytes_per_img, metric, dtype = None, "images/sec FrostNet-Large 224x224 float warm-up fwd+bwd", "bf16"
+        what = f"FrostNet-{args.mode.capitalize()} float model (StatAssist warm-up), fwd+bwd + GradBoost-SGD step (is_warmup), batch={batch}, {args.res}x{args.res}"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = batch * args.steps / dt
+    out = dict(metric=metric, value=round(value, 2), unit="images/sec", n_gpus=1, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype,
+               data="synthetic", config=dict(workload=what, per_gpu_batch=batch, resolution=args.res))
+    if bytes_per_img:
+        out["roofline"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, whole_step=dict(
+            achieved=round(value * bytes_per_img / 1e9, 1), frac=round(value * bytes_per_img / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_image=bytes_per_img))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="qat", choices=["qat", "infer", "float"],
+                    help="qat (default): the headline metric, BASELINE.json config c3/c4; infer: config c2; float: the StatAssist warm-up step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -94,6 +139,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload != "qat":
+        assert world == 1, "the side workloads are single-GPU measurements"
+        return side_workload(args, dev)
     import torch.distributed as dist
     dp = world > 1 or args.force_dp
     if dp:
