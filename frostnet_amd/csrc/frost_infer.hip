@@ -70,116 +70,7 @@ extern "C" int frost_infer_stem_im2col(const float* x, int n, int h, int w, int6
   return frost_check_launch("infer_stem_im2col");
 }
 
-// ------------------------------------------------------------------------------------------------ pointwise (bf16 MFMA GEMM)
-// y[p][co] = act( sum_k T[p][k] * W'[co][k] + b'[co] ).  A pixel tile is staged once in LDS (coalesced 16-byte loads).
-//   WPX = 4, NPS = 2: 128-pixel tile, wave w owns 32 pixels (two 16-pixel subtiles) and walks the channel tiles four at a time: every
-//                     1 KiB weight fragment (L2-resident pack) feeds two MFMAs, and the fragments of K-step kb+1 are requested before the
-//                     MFMAs of kb (an L2 round trip is ~700 cycles: unprefetched it sat on every K step);
-//   WPX = 4, NPS = 1: 64-pixel tile (rows too long for 128 LDS rows);
-//   WPX = 1, NPS = 1: 16-pixel tile shared by the 4 waves, which split the channel tiles (the 7x7 layers with 720..1728 input channels).
-template <int WPX, int NPS, bool RES>
-__global__ __launch_bounds__(256) void k_inf_pw(const uint16_t* __restrict__ T, const uint16_t* __restrict__ pack, const float* __restrict__ biasf,
-                                                int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu, uint16_t* __restrict__ y, int64_t ntiles) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int IPX = 16 * WPX * NPS, WCH = 4 / WPX;
-  const int wpx = w % WPX, wch = w / WPX;
-  const int rowb = cin * 2; const int U = (KB * 64) >> 4;          // 16-byte units per (K-padded) row
-  const int CT = cpad >> 4;
-  const float lo = relu ? 0.0f : -INFINITY;
-  // RES: the whole packed weight matrix is copied into LDS once per (persistent) workgroup: without it every wave re-fetches all of it
-  // from L2 for each 16 (32) pixels -- 12x the activation bytes on a 16 -> 96 layer
-  const uint8_t* wl = smem + IPX * kstr;
-  if (RES) { for (int i = tid; i < CT * KB * 64; i += 256) ((uint4*)wl)[i] = ((const uint4*)pack)[i]; }
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t p0 = tile * IPX;
-    __syncthreads();
-    for (int u = tid; u < IPX * U; u += 256) {
-      const int row = u / U, col = (u - row * U) << 4;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((p0 + row) < npix && col < rowb) v = *(const uint4*)((const uint8_t*)T + (p0 + row) * rowb + col);
-      *(uint4*)(smem + row * kstr + col) = v;
-    }
-    __syncthreads();
-    for (int ct0 = wch * 4; ct0 < CT; ct0 += 4 * WCH) {
-      v4f acc[4][NPS];
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int t = 0; t < NPS; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
-      v4i afr[4], afn[4];
-      auto load_a = [&](int kb, v4i (&dst)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (ct0 + m < CT) dst[m] = RES ? *(const v4i*)(wl + ((((ct0 + m) * KB + kb) * 64 + lane) << 4)) : *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 3));
-      };
-      if (!RES) load_a(0, afr);
-      for (int kb = 0; kb < KB; ++kb) {
-        v4i bfr[NPS];
-#pragma unroll
-        for (int t = 0; t < NPS; ++t) bfr[t] = *(const v4i*)(smem + ((wpx * NPS + t) * 16 + j) * kstr + kb * 64 + g * 16);
-        if (RES) load_a(kb, afr); else if (kb + 1 < KB) load_a(kb + 1, afn);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          if (ct0 + m < CT) {
-#pragma unroll
-            for (int t = 0; t < NPS; ++t)
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr[t]), acc[m][t], 0, 0, 0);
-          }
-        if (!RES) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) afr[m] = afn[m];
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int ch0 = (ct0 + m) * 16 + 4 * g;
-        if (ct0 + m < CT && ch0 < cout) {
-          const float4 b4 = *(const float4*)(biasf + ch0);
-#pragma unroll
-          for (int t = 0; t < NPS; ++t) {
-            const int64_t prow = p0 + (wpx * NPS + t) * 16 + j;
-            if (prow < npix) {
-              uint2 o; o.x = cvt_pk_bf16(fmaxf(acc[m][t][0] + b4.x, lo), fmaxf(acc[m][t][1] + b4.y, lo)); o.y = cvt_pk_bf16(fmaxf(acc[m][t][2] + b4.z, lo), fmaxf(acc[m][t][3] + b4.w, lo));
-              *(uint2*)(y + prow * cout + ch0) = o;
-            }
-          }
-        }
-      }
-    }
-  }
-}
-template <int WPX, int NPS, bool RES>
-static void launch_inf_pw(hipStream_t s, size_t lds, int64_t grid_cap, const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout,
-                          int cpad, int KB, int kstr, int relu, uint16_t* y) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_inf_pw<WPX, NPS, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  constexpr int IPX = 16 * WPX * NPS;
-  const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-  hipLaunchKernelGGL((k_inf_pw<WPX, NPS, RES>), dim3((unsigned)grid), dim3(256), lds, s, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y, nt);
-}
-extern "C" int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
-                              uint16_t* y, void* stream) {
-  FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "infer_pw: cin must be a multiple of 8, cout of 4");
-  const int KB = (cin + 31) / 32; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
-  hipStream_t s = as_stream(stream);
-  const size_t wbytes = (size_t)(cpad / 16) * KB * 1024;
-  const size_t t128 = (size_t)128 * kstr, t64 = (size_t)64 * kstr;
-  // measured (B = 256): resident weights pay only while 4-5 workgroups still fit a CU (<= 32 KB: +2 %); at 64 KB per workgroup the
-  // stage -> barrier -> compute loop of two resident workgroups no longer overlaps anything (-9 %)
-  if (t64 + wbytes <= 32 * 1024 && npix >= 64 * 2048)
-    launch_inf_pw<4, 1, true>(s, t64 + wbytes, 2560, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
-  else if (t128 <= 40 * 1024 && npix >= 128 * 512)
-    launch_inf_pw<4, 2, false>(s, t128, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
-  else if (t64 <= 64 * 1024)
-    launch_inf_pw<4, 1, false>(s, t64, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
-  else {
-    FROST_REQUIRE((size_t)16 * kstr <= 160 * 1024, "infer_pw: row too long for the LDS tile");
-    launch_inf_pw<1, 1, false>(s, (size_t)16 * kstr, 0, x, pack, biasf, npix, cin, cout, cpad, KB, kstr, relu, y);
-  }
-  return frost_check_launch("infer_pw");
-}
+// the 1x1 layers (and the im2col'd stem) run on the pointwise skeleton of frost_pw.hip (frost_infer_pw is defined there)
 
 // ------------------------------------------------------------------------------------------------ depthwise (fp32 FMA)
 // one thread = 8 channels x 4 consecutive output pixels of a row: per kernel row the (3*stride + k) input columns are loaded once

@@ -40,6 +40,7 @@ struct PwP {
   int cres;                       // BN/quant coefficient rows (folded) live in LDS even when the weights do not (RES)
   int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
   int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
+  const float* bias; int act_relu;   // bf16 GEMM mode used as an inference layer: + bias[ch], optional ReLU (qw == NULL: no weight scale)
 };
 
 #define BP 128
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 
   int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
-  if (MODE == M_DGRAD) sw = p.qw[FROST_Q_SCALE];
+  if (MODE == M_DGRAD && p.qw) sw = p.qw[FROST_Q_SCALE];
   if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]); }
   float t_lo = 0.0f, t_hi = 0.0f;            // STE pass window in t = y/scale:  t_lo < t <= t_hi
   if (MODE == M_BRED || MODE == M_BDC) {
@@ -379,16 +380,19 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
           const bool chok = ch0 < p.cout;
           if (MODE == M_DGRAD) {
             uint16_t* base = p.dx + p0 * p.cout;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && chok) { const float4 b4 = *(const float4*)(p.bias + ch0); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+            const float flo = p.act_relu ? 0.0f : -INFINITY;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const int prow = (wp * NT + t) * 16 + j;
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(accf[m][t][r], sw, bv[r]), flo);
               if (o_lds) {
-                if (chok) { uint2 o; o.x = pack_bf2(accf[m][t][0] * sw, accf[m][t][1] * sw); o.y = pack_bf2(accf[m][t][2] * sw, accf[m][t][3] * sw); *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o; }
+                if (chok) { uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o; }
               } else if ((FULL || (p0 + prow) < p.npix) && chok) {
                 uint16_t* dst = base + prow * p.cout + ch0;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = accf[m][t][r] * sw;
                 if (p.accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
                 uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
                 *(uint2*)dst = o;
@@ -675,5 +679,18 @@ extern "C" int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int
   d.T = (const uint8_t*)dc; d.cout = cin; d.cpad = round_up(cin, 16); d.wpack = (const uint8_t*)wt_pack;
   d.qw = qrec_w; d.dx = dx; d.accumulate = accumulate;
   set_tiling(d, npix, cout * 2);
+  return dispatch_pw<M_DGRAD>(d, as_stream(stream));
+}
+
+// bf16 inference layer of the float model (BASELINE.json config c2) on the same skeleton as the data gradient: y[p][co] = act(sum_k
+// x[p][k] * W'[co][k] + b'[co]) -- DMA double-buffered pixel tiles, LDS-resident packed weights on small layers, LDS-staged output.
+// replaces (eval mode): frostnet.py:14-60 Conv2d + BatchNorm2d(running stats, folded by frost_infer_weight_prep) + ReLU for 1x1 convs.
+extern "C" int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
+                              uint16_t* y, void* stream) {
+  FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "infer_pw: channels must be multiples of 8");
+  PwP d = {};
+  d.T = (const uint8_t*)x; d.cout = cout; d.cpad = round_up(cout, 16); d.wpack = (const uint8_t*)pack;
+  d.qw = nullptr; d.dx = y; d.accumulate = 0; d.bias = biasf; d.act_relu = relu;
+  set_tiling(d, npix, cin * 2);
   return dispatch_pw<M_DGRAD>(d, as_stream(stream));
 }

@@ -349,7 +349,9 @@ class FloatRunner:
             call("frost_float_pw", l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
-                call("frost_float_pw", l.desc_ptr, ptr(dc), ptr(l.pack_t), npix_o, l.cout, a.c, 0, PLAIN, None, 0, ptr(dx.buf), a.c, stream())
+                # data gradient = a plain bf16 GEMM with the transposed pack: the tuned pointwise skeleton (DMA double-buffered tiles,
+                # resident weights, LDS-staged output) that also serves the fake-quant dgrad and the bf16 inference layers
+                call("frost_infer_pw", ptr(dc), ptr(l.pack_t), None, npix_o, l.cout, a.c, 0, ptr(dx.buf), stream())
             if l.kind == 2:
                 self._stem_tmp.zero_()
                 call("frost_float_pw_wgrad", ptr(dc), ptr(a.buf), npix_o, 64, 64, l.cout, ptr(self._stem_tmp), 64, stream())
