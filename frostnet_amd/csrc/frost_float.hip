@@ -13,7 +13,7 @@ typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 
-enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3, F_PLAIN = 4 };
+enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3 };
 enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, FC_F = 6, FC_VAR = 7 };
 
 // ------------------------------------------------------------------------------------------------ weight preparation (per step)
@@ -123,7 +123,7 @@ extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_
 // tiles and flush them once (double atomics), so the number of global atomics is grid x channels, not tiles x channels.
 //   F_STATS: sum / sum of squares of conv            F_EMIT: y = [relu](conv*scale + bias) -> bf16
 //   F_BRED : S1 += g*m, S2 += g*m*xhat               F_BDC : dc = g*m*K1 + conv*E + F -> bf16        (m = z > 0 for ReLU layers)
-//   F_PLAIN: y = conv -> bf16 (the data gradient: T = dc, W = the transposed pack)
+// (the data gradient dx = dc . W^T is a plain bf16 GEMM: frost_infer_pw on the transposed pack, frost_pw.hip)
 template <int MODE, int WPX>
 __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16_t* __restrict__ T, const uint16_t* __restrict__ pack, int64_t npix,
                                               int cin, int cout, int cpad, int KB, int kstr, int relu, const uint16_t* __restrict__ gy, int ldg,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   const int wpx = w % WPX, wch = w / WPX;
   float* sacc = (float*)(smem + IPX * kstr);
-  const float* coef = (MODE == F_PLAIN) ? nullptr : dp->coef;
+  const float* coef = dp->coef;
   if (RED) for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f;
   const int rowb = cin * 2; const int U = (KB * 64) >> 4;
   const int CT = cpad >> 4;
@@ -171,9 +171,7 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
         const int ch0 = (ct0 + m) * 16 + 4 * g;
         const bool cv = ch0 < cout;
         const bool ok = cv && pv;
-        if constexpr (MODE == F_PLAIN) {
-          if (ok) { uint2 o; o.x = cvt_pk_bf16(acc[m][0], acc[m][1]); o.y = cvt_pk_bf16(acc[m][2], acc[m][3]); *(uint2*)(y + prow * ldy + ch0) = o; }
-        } else if constexpr (MODE == F_STATS) {
+        if constexpr (MODE == F_STATS) {
           float s[4], q[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float v = ok ? acc[m][r] : 0.0f; s[r] = v; q[r] = v * v; }
@@ -264,19 +262,18 @@ static int launch_f_pw(const FrostFDesc* dp, const uint16_t* T, const uint16_t* 
   }
   return frost_check_launch("float_pw");
 }
-// x: bf16 [npix][cin] (cin = the row length: 64 for the im2col'd stem); pack: the layer's forward pack (modes 0..3) or its transposed pack
-// (mode 4, then cin/cout are swapped by the caller); gy / out rows may be slices of wider tensors (ldg / ldy = row length in elements)
+// x: bf16 [npix][cin] (cin = the row length: 64 for the im2col'd stem); pack: the layer's forward pack; gy / out rows may be slices of
+// wider tensors (ldg / ldy = row length in elements)
 extern "C" int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, int mode,
                               const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "float_pw: cin must be a multiple of 8, cout of 4");
-  FROST_REQUIRE(mode >= 0 && mode <= 4, "float_pw: mode 0..4");
+  FROST_REQUIRE(mode >= 0 && mode <= 3, "float_pw: mode 0..3");
   hipStream_t s = as_stream(stream);
   switch (mode) {
     case F_STATS: return launch_f_pw<F_STATS>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
     case F_EMIT: return launch_f_pw<F_EMIT>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
     case F_BRED: return launch_f_pw<F_BRED>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-    case F_BDC: return launch_f_pw<F_BDC>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-    default: return launch_f_pw<F_PLAIN>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    default: return launch_f_pw<F_BDC>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
   }
 }
 

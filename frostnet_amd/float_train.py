@@ -21,7 +21,7 @@ import torch
 from . import _lib as L
 from ._lib import call, ptr, stream
 
-STATS, EMIT, BRED, BDC, PLAIN = 0, 1, 2, 3, 4
+STATS, EMIT, BRED, BDC = 0, 1, 2, 3
 DESC_BYTES = C.sizeof(L.FrostFDesc)
 
 

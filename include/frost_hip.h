@@ -226,8 +226,8 @@ int frost_float_weight_prep(const FrostFDesc* descs, int nlayers, void* stream);
 int frost_float_bn_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream);   /* train: batch stats -> coef, running stats */
 int frost_float_bn_eval(const FrostFDesc* descs, int nlayers, void* stream);                  /* eval: running stats -> coef            */
 int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream);
-/* mode 0..3 as above with the layer's forward pack; mode 4: out = x . pack^T with no epilogue (data gradient: x = dc, pack = pack_t,
- * cin/cout swapped).  gy / out rows may be slices of wider tensors: ldg / ldy = row length in elements. */
+/* mode 0..3 as above with the layer's forward pack (the data gradient dx = dc . W^T is frost_infer_pw on pack_t, no bias).
+ * gy / out rows may be slices of wider tensors: ldg / ldy = row length in elements. */
 int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, int mode,
                    const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream);
 int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
