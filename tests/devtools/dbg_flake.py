@@ -1,6 +1,6 @@
 """dev: run-to-run / path-to-path gradient differences of one train step (table finalize vs per-layer finalize)."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import frost_oracle as O
 import frostnet_amd.frostnet as F
 B, R = int(sys.argv[1]), int(sys.argv[2])

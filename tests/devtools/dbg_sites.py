@@ -1,7 +1,7 @@
 """dev: per-block activation mismatch (index steps) GPU vs CPU oracle, QAT train-mode forward, first step."""
 import os, sys, warnings
 warnings.filterwarnings("ignore")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as ge
 ge.build()

@@ -1,7 +1,7 @@
 """dev: one QAT train step, GPU vs the CPU oracle, per-parameter gradient error (well-conditioned metric) + batch-permutation check."""
 import os, sys, warnings
 warnings.filterwarnings("ignore")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import __graft_entry__ as ge
 ge.build()

@@ -1,7 +1,7 @@
 """Layer-by-layer divergence finder: oracle (CPU) vs HIP engine on the same whole-net QAT train forward."""
 import sys, os, warnings
 warnings.filterwarnings("ignore")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import frost_oracle as O
 import __graft_entry__ as ge

@@ -177,7 +177,7 @@ def test_full_size_properties_large_b512(F):
     # still moves the ones sitting near a rounding boundary by exactly one step: bound the size, not the count
     assert float(d.max()) <= 3.01 and _rel(y1, y0[perm]) <= 2e-2, (float(d.max()), _rel(y1, y0[perm]), float((d > 0.5).float().mean()))
     # gradients: index flips multiply through a freshly initialised 8-bit network (SURVEY H-2: the reference moves 5.5e-2 when its
-    # thread count changes; tools/dbg_sites.py shows 6e-5 flipped indices after the first block becoming 4e-3, 9e-2, 4e-1 after the
+    # thread count changes; tests/devtools/dbg_sites.py shows 6e-5 flipped indices after the first block becoming 4e-3, 9e-2, 4e-1 after the
     # next three), so directions are only comparable at the tail of the backward; norms are stable everywhere
     assert float((g0["classifier.2.weight"] - g1["classifier.2.weight"]).norm() / g0["classifier.2.weight"].norm()) <= 5e-2
     for n in g0:

@@ -209,7 +209,7 @@ def test_per_layer_finalize_path_matches_table_path(fa):
 
     Two separate steps are compared, so the bound is the run-to-run noise of one step (fp32 atomic order in the S1/S2
     reductions -> a bf16 rounding flip of dc), measured at <= 1.2e-2 of a layer's gradient norm over 36 runs
-    (tools/dbg_flake.py).  BatchNorm gamma/beta gradients are measured against their convolution's gradient norm: at
+    (tests/devtools/dbg_flake.py).  BatchNorm gamma/beta gradients are measured against their convolution's gradient norm: at
     initialisation (gamma=1, beta=0, the next layer normalises again) they are exactly zero in exact arithmetic, so their own
     norm is cancellation noise and a relative error against it is meaningless."""
     F = fa["frostnet"]
