@@ -14,6 +14,11 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 
 enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3 };
+// inclusive scan over a 16-lane row with row_shr 1,2,4,8: lane 15 of every row holds the row total (pure VALU, no LDS crossbar)
+template <int CTRL> __device__ __forceinline__ float f_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float f_row_sum(float v) { v += f_dpp<0x111>(v); v += f_dpp<0x112>(v); v += f_dpp<0x114>(v); v += f_dpp<0x118>(v); return v; }
 enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, FC_F = 6, FC_VAR = 7 };
 
 // ------------------------------------------------------------------------------------------------ weight preparation (per step)
@@ -176,10 +181,8 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float v = ok ? acc[m][r] : 0.0f; s[r] = v; q[r] = v * v; }
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] += __shfl_xor(s[r], o); q[r] += __shfl_xor(q[r], o); }
-          if (j == 0 && cv) {
+          for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
+          if (j == 15 && cv) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
           }
@@ -209,10 +212,8 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
 #pragma unroll
               for (int r = 0; r < 4; ++r) { const float xh = (acc[m][r] - mu[r]) * iv[r]; s[r] = ok ? gm[r] : 0.0f; q[r] = ok ? gm[r] * xh : 0.0f; }
 #pragma unroll
-              for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[r] += __shfl_xor(s[r], o); q[r] += __shfl_xor(q[r], o); }
-              if (j == 0 && cv) {
+              for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
+              if (j == 15 && cv) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
               }
@@ -541,19 +542,28 @@ __global__ __launch_bounds__(256, 2) void k_f_pw_wgrad(const uint16_t* __restric
   int na = (cout - co0 + 15) / 16; if (na > 4) na = 4;
   int nb = (cin - ci0 + 15) / 16; if (nb > 4) nb = 4;
   const int64_t nblk = (npix + FW_KP - 1) / FW_KP;
-  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+  uint4 pd[4], px[4];         // register prefetch of the next 128-pixel block: its HBM latency overlaps the MFMAs of the current one
+  auto fetch = [&](int64_t blk) __attribute__((always_inline)) {
     const int64_t q0 = blk * FW_KP;
-    __syncthreads();
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int u = tid + jn * 256; const int pix = u >> 3, c8 = u & 7; const int64_t gp = q0 + pix;
-      uint4 pd = make_uint4(0, 0, 0, 0), px = make_uint4(0, 0, 0, 0);
-      if (gp < npix && (co0 + c8 * 8) < cout) pd = *(const uint4*)(dc + gp * cout + co0 + c8 * 8);
-      if (gp < npix && (ci0 + c8 * 8) < cin) px = *(const uint4*)(x + gp * ldx + ci0 + c8 * 8);
-      *(uint2*)(dcs + pix * FW_RS + c8 * 16) = make_uint2(pd.x, pd.y); *(uint2*)(dcs + pix * FW_RS + c8 * 16 + 8) = make_uint2(pd.z, pd.w);
-      *(uint2*)(xs + pix * FW_RS + c8 * 16) = make_uint2(px.x, px.y); *(uint2*)(xs + pix * FW_RS + c8 * 16 + 8) = make_uint2(px.z, px.w);
+      pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint4(0, 0, 0, 0);
+      if (gp < npix && (co0 + c8 * 8) < cout) pd[jn] = *(const uint4*)(dc + gp * cout + co0 + c8 * 8);
+      if (gp < npix && (ci0 + c8 * 8) < cin) px[jn] = *(const uint4*)(x + gp * ldx + ci0 + c8 * 8);
+    }
+  };
+  if (split < nblk) fetch(split);
+  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int u = tid + jn * 256; const int pix = u >> 3, c8 = u & 7;
+      *(uint2*)(dcs + pix * FW_RS + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y); *(uint2*)(dcs + pix * FW_RS + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
+      *(uint2*)(xs + pix * FW_RS + c8 * 16) = make_uint2(px[jn].x, px[jn].y); *(uint2*)(xs + pix * FW_RS + c8 * 16 + 8) = make_uint2(px[jn].z, px[jn].w);
     }
     __syncthreads();
+    if (blk + nsplit < nblk) fetch(blk + nsplit);
     v4i afr[4], bfr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
