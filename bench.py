@@ -213,7 +213,8 @@ def main():
             with torch.cuda.stream(side):
                 plan = opt.prepare_step()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=side):
+                # RCCL's watchdog thread polls events concurrently: restrict the capture check to this thread when a process group exists
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if dp else "global"):
                     static_loss = fwd_bwd()
                     if not dp:
                         opt.launch(plan)
