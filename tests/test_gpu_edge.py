@@ -262,3 +262,21 @@ def test_checkpoint_resume_round_trip(F):
             d1, d2 = (p1 - before[n]).double(), (p2 - before[n]).double()
             assert float((d1 - d2).norm() / d1.norm()) <= 0.5, (n, float((d1 - d2).norm() / d1.norm()))
     assert [int(o2.state[p]["step"]) for p in m2.parameters()] == [int(o1.state[p]["step"]) for p in m1.parameters()]
+
+
+def test_dataparallel_wrapper_single_device(F):
+    """Classification/train.py:88-92 wraps the model in nn.DataParallel; on one device that is a pass-through to the module, and the
+    reference's access pattern `model.module.<attr>` keeps working."""
+    torch.manual_seed(0)
+    m = F.frostnet_quant_small_1_0(drop_rate=0.0)
+    F.qat_prepare(m, version=0)
+    m.cuda()
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    y = dp(x)
+    y.sum().backward()
+    assert y.shape == (4, 1000) and torch.isfinite(y).all()
+    assert dp.module is m and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    f = F.frostnet_small_1_0(drop_rate=0.0).cuda()
+    yf = torch.nn.DataParallel(f, device_ids=[0])(x)
+    assert yf.shape == (4, 1000) and torch.isfinite(yf).all()
