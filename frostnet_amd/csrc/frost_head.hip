@@ -10,6 +10,10 @@ template <typename TA, typename TB>
 __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
                                                int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
                                                float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate) {
+  // split-K: gridDim.z workgroups share an output tile, each over a K range (multiple of 16), combined with fp32 atomics into a zeroed C
+  const int ksplit = gridDim.z;
+  const int kchunk = ((K + ksplit - 1) / ksplit + 15) & ~15;
+  const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
   __shared__ float as[64][17]; __shared__ float bs[16][65];
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, lk = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
@@ -31,17 +35,17 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      pa[q] = (m0 + ar[q] < M && k0 + ak[q] < K) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
-      pb[q] = (n0 + br[q] < N && k0 + bk[q] < K) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
+      pa[q] = (m0 + ar[q] < M && k0 + ak[q] < kend) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
+      pb[q] = (n0 + br[q] < N && k0 + bk[q] < kend) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) { as[ar[q]][ak[q]] = pa[q]; bs[bk[q]][br[q]] = pb[q]; }
     __syncthreads();
-    if (k0 + 16 < K) fetch(k0 + 16);
+    if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       float af[2], bf[2];
@@ -61,19 +65,32 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 32 + i * 16 + 4 * lk + r, n = n0 + wn * 32 + j * 16 + l16;
-        if (m < M && n < N) { float v = acc[i][j][r] * al; if (bias) v += bias[n]; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
+        if (m < M && n < N) {
+          float v = acc[i][j][r] * al;
+          if (ksplit > 1) { if (bias && blockIdx.z == 0) v += bias[n]; atomicAdd(&c[(int64_t)m * N + n], v); }
+          else { if (bias) v += bias[n]; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
+        }
       }
 }
+// few output tiles and a long K (the classifier GEMMs: 128-320 tiles, K up to 1280) leave most CUs idle behind an 80-stage serial loop:
+// split K so that >= 256 workgroups run (C is zeroed by a memset node first)
+template <typename TA, typename TB>
+static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, const TB* b, int64_t brs, int64_t bcs, int M, int N, int K,
+                         const float* alpha_ptr, const float* bias, float* c, bool split_ok) {
+  const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+  int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible)
+  while (split_ok && ks < 8 && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
+  if (ks > 1) (void)hipMemsetAsync(c, 0, (size_t)M * N * sizeof(float), s);
+  hipLaunchKernelGGL((k_sgemm<TA, TB>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
+}
 extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
-  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((o + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x, (int64_t)k, (int64_t)1, w,
-                     (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, 1.0f, bias, y, 0);
+  launch_sgemm<float, float>(as_stream(stream), x, (int64_t)k, (int64_t)1, w, (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, bias, y, false);
   return frost_check_launch("linear_f32");
 }
 // classifier forward: y[n][o] = s_w * sum_k x[n][k] * wq[o][k] + bias[o]   (frostnet.py:299 on fake-quantised weights)
 extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
                                     int cin, int nclass, float* y, void* stream) {
-  hipLaunchKernelGGL((k_sgemm<float, int8_t>), dim3((nclass + 63) / 64, (n + 63) / 64), dim3(256), 0, as_stream(stream), x,
-                     (int64_t)cin, (int64_t)1, wq, (int64_t)1, (int64_t)cin, n, nclass, cin, qrec_w + FROST_Q_SCALE, 1.0f, bias, y, 0);
+  launch_sgemm<float, int8_t>(as_stream(stream), x, (int64_t)cin, (int64_t)1, wq, (int64_t)1, (int64_t)cin, n, nclass, cin, qrec_w + FROST_Q_SCALE, bias, y, false);
   return frost_check_launch("classifier_fwd");
 }
 
@@ -100,12 +117,10 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
                               int n, int cin, int nclass, int hw, const float* drop_mask, float* dwq, float* dbias,
                               uint16_t* gx, float* scratch_dpool, void* stream) {
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (nclass + 63) / 64), dim3(256), 0, s, dlogits_masked,
-                     (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, (const float*)nullptr, dwq, 0);
+  launch_sgemm<float, float>(s, dlogits_masked, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dwq, true);
   hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
-  hipLaunchKernelGGL((k_sgemm<float, int8_t>), dim3((cin + 63) / 64, (n + 63) / 64), dim3(256), 0, s, dlogits_masked,
-                     (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass, qrec_w + FROST_Q_SCALE, 1.0f,
-                     (const float*)nullptr, scratch_dpool, 0);
+  launch_sgemm<float, int8_t>(s, dlogits_masked, (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass, qrec_w + FROST_Q_SCALE,
+                              (const float*)nullptr, scratch_dpool, true);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("head_bwd");
@@ -116,11 +131,9 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
 extern "C" int frost_float_head_bwd(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
                                     const float* drop_mask, float* dw, float* dbias, uint16_t* gx, float* scratch_dpool, void* stream) {
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (nclass + 63) / 64), dim3(256), 0, s, dlogits, (int64_t)1, (int64_t)nclass, pooled,
-                     (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, 1.0f, (const float*)nullptr, dw, 0);
+  launch_sgemm<float, float>(s, dlogits, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dw, true);
   hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
-  hipLaunchKernelGGL((k_sgemm<float, float>), dim3((cin + 63) / 64, (n + 63) / 64), dim3(256), 0, s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin,
-                     (int64_t)1, n, cin, nclass, (const float*)nullptr, 1.0f, (const float*)nullptr, scratch_dpool, 0);
+  launch_sgemm<float, float>(s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin, (int64_t)1, n, cin, nclass, (const float*)nullptr, (const float*)nullptr, scratch_dpool, true);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("float_head_bwd");
