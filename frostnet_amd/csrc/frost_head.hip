@@ -6,15 +6,16 @@
 // fp32 operands on the f32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation, the VALU fmaf chain's
 // numerics at 16x its rate).  64x64 tile per workgroup, each of the 4 waves a 32x32 quadrant; 16-deep K stages through
 // LDS with the next stage register-prefetched.  TB = int8_t: the fake-quantised classifier weight, dequantised on load.
-template <typename TA, typename TB>
+template <typename TA, typename TB, int KD>
 __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
                                                int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
                                                float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate) {
   // split-K: gridDim.z workgroups share an output tile, each over a K range (multiple of 16), combined with fp32 atomics into a zeroed C
   const int ksplit = gridDim.z;
-  const int kchunk = ((K + ksplit - 1) / ksplit + 15) & ~15;
+  const int kchunk = ((K + ksplit - 1) / ksplit + KD - 1) / KD * KD;
   const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-  __shared__ float as[64][17]; __shared__ float bs[16][65];
+  __shared__ float as[64][KD + 1]; __shared__ float bs[KD][65];      // KD-deep K stages (64: a quarter of the barriers of 16)
+  constexpr int NQ = KD / 4;
   const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, lk = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -24,30 +25,30 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
   // staging roles: 1024 elements per operand per stage = 4 per thread; walk the operand along its unit-stride dimension
-  int ar[4], ak[4], br[4], bk[4];
+  int ar[NQ], ak[NQ], br[NQ], bk[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int i = tid + q * 256;
-    if (acs == 1) { ak[q] = i & 15; ar[q] = i >> 4; } else { ar[q] = i & 63; ak[q] = i >> 6; }
-    if (brs == 1) { bk[q] = i & 15; br[q] = i >> 4; } else { br[q] = i & 63; bk[q] = i >> 6; }
+    if (acs == 1) { ak[q] = i % KD; ar[q] = i / KD; } else { ar[q] = i & 63; ak[q] = i >> 6; }
+    if (brs == 1) { bk[q] = i % KD; br[q] = i / KD; } else { br[q] = i & 63; bk[q] = i >> 6; }
   }
-  float pa[4], pb[4];
+  float pa[NQ], pb[NQ];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       pa[q] = (m0 + ar[q] < M && k0 + ak[q] < kend) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
       pb[q] = (n0 + br[q] < N && k0 + bk[q] < kend) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
     }
   };
   fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += KD) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { as[ar[q]][ak[q]] = pa[q]; bs[bk[q]][br[q]] = pb[q]; }
+    for (int q = 0; q < NQ; ++q) { as[ar[q]][ak[q]] = pa[q]; bs[bk[q]][br[q]] = pb[q]; }
     __syncthreads();
-    if (k0 + 16 < kend) fetch(k0 + 16);
+    if (k0 + KD < kend) fetch(k0 + KD);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
+    for (int k4 = 0; k4 < KD / 4; ++k4) {
       float af[2], bf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) { af[i] = as[wm * 32 + i * 16 + l16][k4 * 4 + lk]; bf[i] = bs[k4 * 4 + lk][wn * 32 + i * 16 + l16]; }
@@ -81,7 +82,8 @@ static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, c
   int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible)
   while (split_ok && ks < 8 && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
   if (ks > 1) (void)hipMemsetAsync(c, 0, (size_t)M * N * sizeof(float), s);
-  hipLaunchKernelGGL((k_sgemm<TA, TB>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
+  if (K / ks >= 256) hipLaunchKernelGGL((k_sgemm<TA, TB, 64>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
+  else hipLaunchKernelGGL((k_sgemm<TA, TB, 16>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
 }
 extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
   launch_sgemm<float, float>(as_stream(stream), x, (int64_t)k, (int64_t)1, w, (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, bias, y, false);
