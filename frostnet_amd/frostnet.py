@@ -217,10 +217,6 @@ class FrostNet(_FrostBase):
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
 
-    # Opt-in, OFF by default: run a NOT-yet-quantised (float) model through torch's stock eager modules on the GPU instead of this
-    # repo's float kernels (frostnet_amd/float_train.py).  Exists only for A/B checks; nothing in the product path sets it.
-    allow_torch_eager_float = False
-
     def hip_infer_bf16(self, x):
         """bf16 inference of the float (un-fused, not QAT-prepared) model on the HIP kernels (BASELINE.json config c2):
         eval-mode BatchNorm folded, NHWC bf16 activations, fp32 accumulation.  See frostnet_amd/infer.py."""
@@ -234,7 +230,7 @@ class FrostNet(_FrostBase):
         return inf(x)
 
     def forward(self, x):
-        if x.is_cuda and not (self.allow_torch_eager_float and not self._is_qat_prepared()):
+        if x.is_cuda:           # device tensors always take the HIP path (fake-quant or float runner); the stock modules below are the CPU definition
             return self.hip_runner().forward(x)
         if self.quantized:
             x = self.quant(x)
