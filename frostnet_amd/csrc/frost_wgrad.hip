@@ -239,7 +239,9 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
     return frost_check_launch("pw_wgrad_big");
   }
   const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);
-  int nsplit = (1024 + ntile - 1) / ntile;
+  // ~512 workgroups: every split ends with one fp32 atomic per output element, and more splits than that cost more in atomics than they
+  // gain in parallelism (168->40 @28x28, B=512: 160 / 120 / 91 / 82 us at 2048 / 1024 / 512 / 256 workgroups; 96->24 @56x56: 151 / 125 / 95 / 131)
+  int nsplit = (512 + ntile - 1) / ntile;
   // every split ends with one fp32 atomic per output element: on low-resolution layers hundreds of splits hammering the same few
   // thousand addresses cost more than the GEMM (measured 56 us for a 7 MB layer), so a split keeps at least 4 pixel blocks
   if (nsplit > nblk / 4) nsplit = (int)(nblk / 4); if (nsplit < 1) nsplit = 1;
