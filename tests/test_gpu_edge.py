@@ -280,3 +280,30 @@ def test_dataparallel_wrapper_single_device(F):
     f = F.frostnet_small_1_0(drop_rate=0.0).cuda()
     yf = torch.nn.DataParallel(f, device_ids=[0])(x)
     assert yf.shape == (4, 1000) and torch.isfinite(yf).all()
+
+
+def test_features_backbone_c5_size(F):
+    """BASELINE config c5's backbone at its size: frostnet_features Large @ 512x512 (frostnet_features.py:342-352 returns [x1, x2, x3, x5]),
+    fake-quantised, train-mode first step, B = 2: tap shapes, the first two taps against the oracle (deeper ones are only bounded: index
+    flips multiply with depth, SURVEY H-2), backward through all four taps finite."""
+    from frostnet_amd import frostnet_features as FF
+    torch.set_num_threads(16)
+    cfg = O.net_cfg("large", 1.0)
+    spec = O.float_state_spec(cfg, features=True)
+    P, B = O.make_state(spec, 5000, True)
+    qs = O.QState(B)
+    x = T(O.synth((2, 3, 512, 512), 950))
+    with torch.no_grad():
+        ref = O.frostnet_forward(P, qs, cfg, x, True, True, features=True)
+    net = FF.FrostNet(mode="large", width_mult=1.0, quantized=True)
+    net.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], 5000), strict=False)
+    F.qat_prepare(net, version=0)
+    net.cuda()
+    feats = net(x.cuda())
+    assert [tuple(f.shape) for f in feats] == [(2, 24, 128, 128), (2, 40, 64, 64), (2, 96, 32, 32), (2, 320, 16, 16)]
+    assert [tuple(f.shape) for f in feats] == [tuple(r.shape) for r in ref]
+    tol = [2e-2, 5e-2, 0.5, 1.0]
+    for i, (f, r) in enumerate(zip(feats, ref)):
+        assert torch.isfinite(f).all() and _rel(f.detach().cpu(), r) <= tol[i], (i, _rel(f.detach().cpu(), r))
+    sum((f * f).mean() for f in feats).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
