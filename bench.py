@@ -1,6 +1,7 @@
 """Headline benchmark: images/sec, FrostNet-Large 224x224 QAT forward+backward (+GradBoost step) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: spawns N ranks itself via torch.distributed.run, or runs as a rank when
+                                                          the launcher's RANK / WORLD_SIZE are already in the environment)
 
 One "step" = one pass of the hot path over one synthetic batch: fake-quantised forward (int8 MFMA / LDS depthwise),
 hand-written backward, GradBoost-SGD multi-tensor update; for N>1 plus the bucketed RCCL gradient all-reduce
@@ -116,27 +117,73 @@ def side_workload(args, dev):
     print(json.dumps(out), flush=True)
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver may also
+    launch us that way itself; then RANK / WORLD_SIZE are already set and this is skipped)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launcher check without GPUs (CPU test / any box): N gloo ranks rendezvous, all-reduce a rank-dependent vector, rank 0 prints
+    one line.  Exercises exactly the spawn + env + rendezvous + single-line-output plumbing of the N>1 path."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        dist.init_process_group("gloo")
+    t = torch.full((4,), float(rank + 1))
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(metric="launcher dry run", n_gpus=world, requested=args.gpus, allreduce_sum=float(t[0]),
+                              expected=world * (world + 1) / 2, dry_run=True)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="qat", choices=["qat", "infer", "float"],
                     help="qat (default): the headline metric, BASELINE.json config c3/c4; infer: config c2; float: the StatAssist warm-up step")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE.json config 3: 512)")
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--mode", default="large")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--overlap-allreduce", action="store_true",
-                    help="N>1: eager step with the bucketed all-reduce overlapped with the backward (default: graph replay + one all-reduce)")
+    ap.add_argument("--buckets", type=int, default=4, help="N>1: gradient buckets = hipGraph segments of the backward pass")
+    ap.add_argument("--single-allreduce", action="store_true",
+                    help="N>1: one graph + ONE all-reduce after the backward instead of the bucketed, backward-overlapped default (A/B)")
     ap.add_argument("--force-dp", action="store_true", help="run the N>1 code path on a 1-rank process group (single-GPU check of that path)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="dev/test: all ranks on cuda:0 with the gloo backend (checks launcher + segmented step + a real 2-rank all-reduce on a 1-GPU box)")
+    ap.add_argument("--dry-run-launcher", action="store_true", help="no GPU: N gloo ranks, one all-reduce, one JSON line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(_self_launch(args))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}: reporting n_gpus={world}", file=sys.stderr)
+    if args.dry_run_launcher:
+        return dry_run(args)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
+    if args.share_gpu:
+        local_rank = 0
+    assert local_rank < torch.cuda.device_count(), f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPUs visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.workload != "qat":
@@ -148,10 +195,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        if rank == 0:
+            print(f"[bench] process group up: backend={dist.get_backend()} world={dist.get_world_size()} (one rank per GPU)", file=sys.stderr, flush=True)
 
     import __graft_entry__ as ge
-    if local_rank == 0:
+    if local_rank == 0 and (rank == 0 or not args.share_gpu):
         ge.build()
     if world > 1:
         dist.barrier()
@@ -159,7 +211,7 @@ def main():
     from frostnet_amd import _lib as L
     from frostnet_amd import frostnet as F
     from frostnet_amd.optimizer import QSGD
-    from frostnet_amd.parallel import broadcast_model
+    from frostnet_amd.parallel import SegmentedStep, broadcast_model
 
     torch.manual_seed(1882)                       # Classification/train.py:38-39
     model = F.MODEL_REGISTRY[f"frostnet_quant_{args.mode}_1_0"]()     # drop_rate 0.2 active, as in training
@@ -172,68 +224,77 @@ def main():
     opt = QSGD(groups, lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2, weight_decay=wd)
     opt.is_warmup = False                         # StatAssist epoch done -> GradBoost noise on (train.py:162-164)
     runner = model.hip_runner()
-    # N>1, default: the compute of a step (forward, backward, weight-gradient finalize) replays as ONE hipGraph per rank exactly as at
-    # N=1, then one RCCL all-reduce of the 23 MB gradient arena (~0.3 ms over xGMI, <1.5 % of a step: not worth un-graphing the
-    # backward for) and the optimizer launch.  --overlap-allreduce keeps the eager, bucketed, backward-overlapped variant.
-    sync = runner.enable_data_parallel(nbuckets=4) if (dp and args.overlap_allreduce) else None
 
     g = torch.Generator(device=dev).manual_seed(1882 + rank)
     x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
     tgt = torch.randint(0, 1000, (args.batch,), device=dev, generator=g)
     crit = torch.nn.CrossEntropyLoss()
 
+    # N = 1: model(x) -> loss.backward() -> optimizer.step() (the reference loop, helper_functions.py:139-143) captured as ONE hipGraph.
+    # N > 1 (default): the same kernels as a chain of hipGraph segments, one per gradient bucket; the bucket's RCCL all-reduce is issued
+    # between segments and runs on RCCL's stream under the rest of the backward (frostnet_amd.parallel.SegmentedStep).
+    seg = SegmentedStep(runner, crit, nbuckets=args.buckets) if (dp and not args.single_allreduce) else None
+
     def fwd_bwd():
         loss = crit(model(x), tgt)
+        if dp:
+            loss = loss / dist.get_world_size()
         loss.backward()
         return loss
 
-    def reduce_grads():
-        if sync is not None:
-            sync.finish()
-        elif dp:
-            dist.all_reduce(runner.grad_arena)
-            if dist.get_world_size() > 1:
-                runner.grad_arena.mul_(1.0 / dist.get_world_size())
-
     def eager_step():
-        loss = fwd_bwd()
-        reduce_grads()
+        if seg is not None:
+            seg.run_eager(x, tgt)
+            seg.finish()
+        else:
+            fwd_bwd()
+            if dp:
+                dist.all_reduce(runner.grad_arena)
         opt.step()
-        return loss
 
     for _ in range(max(1, min(args.warmup, 3))):      # first steps build tables / state before any capture
         eager_step()
     torch.cuda.synchronize()
 
     graph = None
-    if sync is None and not args.no_graph:
+    if not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                plan = opt.prepare_step()
-                graph = torch.cuda.CUDAGraph()
-                # RCCL's watchdog thread polls events concurrently: restrict the capture check to this thread when a process group exists
-                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if dp else "global"):
-                    static_loss = fwd_bwd()
-                    if not dp:
-                        opt.launch(plan)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+            if seg is not None:
+                seg.capture(x, tgt)
+                graph = seg.graphs
+            else:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    plan = opt.prepare_step()
+                    graph = torch.cuda.CUDAGraph()
+                    # RCCL's watchdog thread polls events concurrently: restrict the capture check to this thread when a process group exists
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if dp else "global"):
+                        fwd_bwd()
+                        if not dp:
+                            opt.launch(plan)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
         except Exception as e:  # pragma: no cover
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
+            if seg is not None:
+                seg.graphs = None
             torch.cuda.synchronize()
 
     def step():
-        if graph is not None:
-            plan = opt.prepare_step()
+        if graph is None:
+            return eager_step()
+        plan = opt.prepare_step()
+        if seg is not None:
+            seg.replay()
+            seg.finish()
+            opt.launch(plan)
+        else:
             graph.replay()
             if dp:
-                reduce_grads()
+                dist.all_reduce(runner.grad_arena)
                 opt.launch(plan)
-        else:
-            eager_step()
 
     for _ in range(args.warmup):
         step()
@@ -241,14 +302,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,13 +325,16 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream (eager pass: events cannot be read out of a replayed graph)
+        def local_step():                  # no collective in here: only rank 0 runs this leg
+            crit(model(x), tgt).backward()
+            opt.step()
         L.PROFILER = L.Profiler()
-        eager_step()
+        local_step()
         summ = L.PROFILER.summary()
         dom = max(summ, key=lambda k: summ[k]["total_ms"])
         L.PROFILER = L.Profiler(only=dom)
         for _ in range(3):
-            eager_step()
+            local_step()
         s2 = L.PROFILER.summary()[dom]
         L.PROFILER = None
         achieved = s2["bytes_per_launch"] / (s2["avg_ms"] * 1e-3) / 1e9
@@ -300,7 +369,10 @@ def main():
                                         f"(noise on; StatAssist FP epoch is a one-off before it), batch={args.batch}/GPU, "
                                         f"{args.res}x{args.res} NHWC, qnnpack qconfig v0 (per-tensor)",
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
-                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype="bf16"),
+                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype="bf16",
+                               ms_per_step_median_hip_events=round(ms_median, 3),
+                               grad_allreduce=(None if not dp else ("single, after backward" if seg is None else
+                                               f"{len(seg.cuts)} buckets overlapped with backward, one hipGraph segment per bucket"))),
                    roofline=roofline, cpu_baseline=cpu)
     if dp:
         dist.destroy_process_group()

@@ -11,7 +11,7 @@ _lib = None
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
-Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_FLAGS, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 7, 8
+Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_OBS_EN, Q_FQ_EN, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 8, 10, 12
 COEF_ROWS = 8
 STATS_BYTES_PER_CH = 24
 

@@ -88,6 +88,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi, int symmetric, int rule127,
                                            int observe) {
   float mn = q[FROST_Q_MIN], mx = q[FROST_Q_MAX];
+  observe = observe && (__float_as_int(q[FROST_Q_OBS_EN]) != 0);       // the site's own observer_enabled buffer (device resident)
   if (observe) {
     if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = cur_lo; mx = cur_hi; }
     else { mn = mn + FROST_OBS_C * (cur_lo - mn); mx = mx + FROST_OBS_C * (cur_hi - mx); }

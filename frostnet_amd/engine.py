@@ -72,6 +72,9 @@ class QArena:
         self.t[:, L.Q_ZP] = 0.0
         self.t[:, L.Q_FQMIN] = 0.0
         self.t[:, L.Q_FQMAX] = 0.0
+        ti = self.t.view(torch.int32)
+        ti[:, L.Q_OBS_EN] = 1          # observer_enabled / fake_quant_enabled (8 bytes each, aliased by the torch buffers)
+        ti[:, L.Q_FQ_EN] = 1
 
     def alloc(self):
         i = self.next
@@ -120,6 +123,7 @@ class ConvLayer:
         self.coef = torch.zeros(L.COEF_ROWS, self.cpad, dtype=torch.float32, device=dev)
         self.sigma = torch.ones(self.cout, dtype=torch.float32, device=dev)
         self.stats = None       # view into the engine's stats arena
+        self.bn_mod = None      # the BatchNorm2d module (its .training flag is checked by the runner)
         self.dwq = None         # fp32 scratch for dL/d(fake-quantised weight)
 
     def desc(self):
@@ -304,14 +308,19 @@ class Engine:
             call("frost_minmax_f32", ptr(raw), raw.numel(), ptr(self._head_mm), stream())
             call("frost_observer_update", ptr(l.qy), ptr(self._head_mm), 0, 0, 1, stream())
         logits = torch.empty_like(raw)
+        self.last_raw = raw              # pre-fake-quant classifier output (tests: the north-star 1e-3 comparison point)
         call("frost_fake_quant_f32", ptr(raw), raw.numel(), ptr(l.qy), 0, 255, ptr(logits), None, stream())
         self.tape.append(("head", l, x, pooled, raw, drop_mask))
         return logits
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, dlogits=None, out_grads=None):
+    def backward(self, dlogits=None, out_grads=None, boundaries=None, on_bucket=None):
         """Replay the tape in reverse. dlogits: fp32 [n, nclass] gradient of the loss w.r.t. the logits.
-        Parameter gradients are written (=, not +=) into l.w.grad / l.gamma.grad / l.beta.grad / l.bias.grad."""
+        Parameter gradients are written (=, not +=) into l.w.grad / l.gamma.grad / l.beta.grad / l.bias.grad.
+        boundaries / on_bucket (data parallel, frostnet_amd.parallel.SegmentedStep): `boundaries` maps id(layer) -> bucket index;
+        once that layer's backward is done every gradient of the bucket is final: the side stream is joined, the bucket's weight
+        gradients are finalized with one table launch and on_bucket(index) is called (it ends a hipGraph segment / starts the
+        bucket's all-reduce) while the rest of the backward is still to run."""
         self._prepare_dwq()
         self._pending = []          # conv layers whose weight-gradient finalize is deferred to one table launch
         # Pointwise weight gradients run on a second stream: nothing downstream needs them until the finalize at the end of the
@@ -340,11 +349,15 @@ class Engine:
                      l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0, stream())
                 if self.on_layer_grads is not None:
                     self.on_layer_grads(l)
+                if boundaries is not None and id(l) in boundaries:
+                    self._close_bucket(boundaries[id(l)], on_bucket)
             elif kind == "conv":
                 _, l, x, y = entry
                 self._conv_backward(l, x, y)
                 if self.on_layer_grads is not None:
                     self.on_layer_grads(l)
+                if boundaries is not None and id(l) in boundaries:
+                    self._close_bucket(boundaries[id(l)], on_bucket)
             elif kind == "cat":
                 _, a, b, y = entry
                 ga, fa = self._grad_slot(a)
@@ -379,24 +392,35 @@ class Engine:
                     l.dwq_col = self._dwq_arena[o + l.w.numel(): o + sz]
                 o += sz
             self._dwq_layers = len(self.layers)
-            self._gtable_key = None
+            self._gtables = {}
         self._dwq_arena.zero_()
 
-    def _finalize_pending(self):
+    def _close_bucket(self, index, on_bucket):
+        """Every layer of gradient bucket `index` has run its backward: join the weight-gradient stream, finalize, notify."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._keep = []
+        self._finalize_pending(slot=index)
+        if on_bucket is not None:
+            on_bucket(index)
+
+    def _finalize_pending(self, slot=-1):
+        """One table launch finalizes the weight gradients of every pending layer; the device tables are cached per slot
+        (slot = gradient bucket, -1 = the whole network)."""
         if not self._pending:
             return
         for l in self._pending:
             self._ensure_grad(l)
-        key = tuple((id(l), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr()) for l in self._pending)
-        if getattr(self, "_gtable_key", None) != key:
+        key = tuple((id(l), l.dwq.data_ptr(), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr()) for l in self._pending)
+        cache = self.__dict__.setdefault("_gtables", {})
+        if slot not in cache or cache[slot][0] != key:
             arr = (L.FrostGDesc * len(self._pending))()
             for i, l in enumerate(self._pending):
                 arr[i] = L.FrostGDesc(l.dwq.data_ptr(), l.w.data_ptr(), l.gamma.data_ptr(), l.sigma.data_ptr(), l.qw.data_ptr(),
                                       l.coef.data_ptr(), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr(),
                                       l.cout, l.cin_g * l.kk, l.cpad, 0)
-            self._gtable = L.struct_to_tensor(arr, self.device)
-            self._gtable_key = key
-        call("frost_weight_grad_finalize_table", ptr(self._gtable), len(self._pending), stream())
+            cache[slot] = (key, L.struct_to_tensor(arr, self.device))
+        call("frost_weight_grad_finalize_table", ptr(cache[slot][1]), len(self._pending), stream())
         self._pending = []
 
     @staticmethod

@@ -173,14 +173,25 @@ class _FrostBase(nn.Module):
                 m.fuse_model()
 
     # ---- HIP execution --------------------------------------------------------------------------------
+    def __getstate__(self):
+        """copy.deepcopy / pickle (EMA or best-model snapshots, torch.save(model)): the device executors are per-instance caches
+        and stay behind; the copy builds its own on first use."""
+        d = self.__dict__.copy()
+        d.pop("_hip_runner", None)
+        d.pop("_bf16_infer", None)
+        return d
+
     def _is_qat_prepared(self):
         return hasattr(self.conv1.conv[0], "weight_fake_quant")
 
     def hip_runner(self):
         """The device executor bound to this module tree (built lazily, rebuilt if parameters were moved)."""
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError("nn.DataParallel replicas are not supported by the HIP path (replicas share one runner and its device-0 "
+                               "pointers): data parallelism is one process per GPU -- frostnet_amd.parallel, `bench.py --gpus N`")
         qat = self._is_qat_prepared()
         r = self.__dict__.get("_hip_runner")
-        if r is None or r.is_qat != qat or not r.still_valid():
+        if r is None or r.model is not self or r.is_qat != qat or not r.still_valid():
             if qat:
                 from .runner import FrostRunner
                 r = FrostRunner(self)

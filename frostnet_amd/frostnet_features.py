@@ -24,30 +24,33 @@ except Exception:
         return cls
 
 
+def _strip_parallel_prefix(key):
+    """`module.` in front of a key = the checkpoint was written from a DataParallel / DDP wrapper."""
+    return key[len("module."):] if key.startswith("module.") else key
+
+
 def load_state_dict(checkpoint_path, use_ema=False):
-    """frostnet_features.py:10-30: timm checkpoint ingest (prefers state_dict_ema, strips `module.`)."""
-    if checkpoint_path and os.path.isfile(checkpoint_path):
-        checkpoint = torch.load(checkpoint_path, map_location='cpu')
-        state_dict_key = 'state_dict'
-        if isinstance(checkpoint, dict):
-            if use_ema and 'state_dict_ema' in checkpoint:
-                state_dict_key = 'state_dict_ema'
-        if state_dict_key and state_dict_key in checkpoint:
-            new_state_dict = OrderedDict()
-            for k, v in checkpoint[state_dict_key].items():
-                name = k[7:] if k.startswith('module') else k
-                new_state_dict[name] = v
-            state_dict = new_state_dict
-        else:
-            state_dict = checkpoint
-        print("Loaded {} from checkpoint '{}'".format(state_dict_key, checkpoint_path))
-        return state_dict
-    print("No checkpoint found at '{}'".format(checkpoint_path))
-    raise FileNotFoundError()
+    """Read a timm-style training checkpoint and return a plain name -> tensor mapping for `Module.load_state_dict`.
+
+    Behaviour of the reference's ingest helper (frostnet_features.py:10-30): the file may be a bare state_dict or a dict that wraps
+    one under `state_dict` (and the EMA shadow weights under `state_dict_ema`, preferred when `use_ema`); wrapper prefixes are
+    removed.  A missing file raises FileNotFoundError."""
+    if not checkpoint_path or not os.path.isfile(checkpoint_path):
+        raise FileNotFoundError(f"no checkpoint at '{checkpoint_path}'")
+    blob = torch.load(checkpoint_path, map_location="cpu")
+    picked = None
+    if isinstance(blob, dict):
+        for key in (("state_dict_ema",) if use_ema else ()) + ("state_dict",):
+            if isinstance(blob.get(key), dict):
+                picked = key
+                break
+    weights = blob[picked] if picked is not None else blob
+    return OrderedDict((_strip_parallel_prefix(k), v) for k, v in weights.items())
 
 
 def load_checkpoint(model, checkpoint_path, use_ema=False, strict=True):
-    model.load_state_dict(load_state_dict(checkpoint_path, use_ema), strict=strict)
+    """frostnet_features.py:33-35.  Returns torch's (missing_keys, unexpected_keys) record."""
+    return model.load_state_dict(load_state_dict(checkpoint_path, use_ema), strict=strict)
 
 
 @_register
@@ -70,12 +73,13 @@ class FrostNet(_FrostBase):
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
 
-    def init_weights(self, pretrained):
-        if pretrained != '':
-            load_checkpoint(self, pretrained, use_ema=True, strict=False)
-        else:
-            print('No pretrained backbone provided')
-            self._init_weights()
+    def init_weights(self, pretrained=''):
+        """mmdet backbone hook (frostnet_features.py:314-319): EMA weights of a timm checkpoint when a path is given (non-strict: the
+        classifier head of the checkpoint has no counterpart here), else the Kaiming / unit-BN initialisation."""
+        if pretrained:
+            return load_checkpoint(self, pretrained, use_ema=True, strict=False)
+        self._init_weights()
+        return None
 
     def forward(self, x):
         if x.is_cuda:
@@ -94,8 +98,8 @@ class FrostNet(_FrostBase):
         return feats
 
     def _freeze_stages(self):
-        '''Freeze BatchNorm layers.'''
-        print('Freeze BatchNorm layers.')
-        for layer in self.modules():
-            if isinstance(layer, nn.BatchNorm2d):
-                layer.eval()
+        """frostnet_features.py:354-359: every BatchNorm2d (also the `.bn` of a fused QAT conv) goes to eval mode, i.e. normalises
+        with its running statistics and stops updating them.  On the HIP path a *training* forward with frozen BatchNorm is refused
+        (runner._trunk): the hand-written backward implements the batch-statistics gradient only."""
+        for bn in (m for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
+            bn.eval()

@@ -60,10 +60,24 @@ class _GradBoost(Optimizer):
     def __init__(self, params, defaults, seed=1882):
         self.is_warmup = True
         self._seed = seed
-        self._offset = 0
         self._inject = None
         self._plan = None
         super().__init__(params, defaults)
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("is_warmup", True)
+        self.__dict__.setdefault("_seed", 1882)
+        self.__dict__["_inject"] = None
+        self.__dict__["_plan"] = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._plan = None                   # state tensors and group dicts were replaced: the device table is stale
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._plan = None
 
     # ---- parity hook: recorded |Laplace| draws and coins, concatenated in parameter order
     def inject(self, noise, coin):
@@ -94,9 +108,20 @@ class _GradBoost(Optimizer):
                 if not p.is_cuda:
                     raise RuntimeError("frostnet_amd GradBoost optimizers run on the HIP device only (no CPU fallback)")
                 items.append((p, group))
-        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in items)
+        # the table holds raw pointers to parameters, gradients AND state tensors and the plan holds the group dicts: all of them are
+        # part of the signature (load_state_dict replaces the state tensors and the group dicts)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), id(g)) + tuple(v.data_ptr() for v in self.state.get(p, {}).values() if torch.is_tensor(v))
+                    for p, g in items)
         if self._plan is not None and self._plan["sig"] == sig:
             return self._plan
+        # ONE launch serves every tensor with one hyper-parameter block: only lr and weight_decay may differ between groups (what
+        # the reference's per-tensor groups vary, Classification/train.py:121-137)
+        shared = [k for k in self.defaults if k not in ("lr", "weight_decay")]
+        for _, g in items:
+            for k in shared:
+                if g[k] != items[0][1][k]:
+                    raise NotImplementedError(f"GradBoost multi-tensor step: param groups differ in '{k}' ({g[k]} vs {items[0][1][k]}); "
+                                              "only lr and weight_decay may vary per group")
         arr = (L.FrostOptTensor * len(items))()
         prefix, tot = [], 0
         for i, (p, group) in enumerate(items):
@@ -114,7 +139,10 @@ class _GradBoost(Optimizer):
             tot += p.numel()
         dev = items[0][0].device
         table = L.struct_to_tensor(arr, dev)
-        self._plan = dict(sig=sig, items=items, table=table, words=table.view(torch.int32).view(len(items), _T_STRIDE),
+        # (state was created above for new tensors: the signature is taken again with it)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), id(g)) + tuple(v.data_ptr() for v in self.state[p].values() if torch.is_tensor(v))
+                    for p, g in items)
+        self._plan = dict(sig=sig, items=items, table=table, keep=[list(self.state[p].values()) for p, _ in items], words=table.view(torch.int32).view(len(items), _T_STRIDE),
                           prefix=torch.tensor(prefix, dtype=torch.int64, device=dev),
                           hyper=torch.zeros(C.sizeof(L.FrostOptHyper), dtype=torch.uint8, device=dev),
                           max_n=max(p.numel() for p, _ in items), total=tot,
@@ -139,8 +167,8 @@ class _GradBoost(Optimizer):
         step, rstep = steps.pop()
         group0 = items[0][1]
         h = self._hyper(group0, step, rstep, boost)
-        h.seed, h.offset = self._seed, self._offset
-        self._offset += 1
+        # Philox stream position = the step count (part of state_dict): a resumed run continues the noise stream instead of replaying it
+        h.seed, h.offset = self._seed, step
         plan["hyper"].copy_(torch.frombuffer(bytearray(bytes(memoryview(h).cast("B"))), dtype=torch.uint8), non_blocking=False)
         lrs = [g["lr"] for _, g in items]
         wds = [g["weight_decay"] for _, g in items]

@@ -59,3 +59,101 @@ def broadcast_model(model, src=0, group=None):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+def plan_buckets(runner, nbuckets=4):
+    """Cut the gradient arena into `nbuckets` contiguous buckets along LAYER boundaries, in the order the backward pass
+    completes them (classifier first, stem last).  Returns [(layer, lo, hi)]: once `layer` has run its backward every gradient
+    in arena[lo:hi] is final.  FrostNet's parameters sit at the deep end (classifier 1.28 M + last_layer 0.41 M + layer5 1.1 M of
+    5.8 M), its backward *time* at the shallow end, so the first buckets carry most of the bytes and travel under almost the whole
+    backward pass; the last bucket is a few hundred KB."""
+    offs, off = {}, 0
+    for p in runner._params:
+        offs[p.data_ptr()] = off
+        off += p.numel()
+    total = off
+    layers = [l for l in runner.E.layers]                    # forward order
+    cuts, hi, k = [], total, 1
+    for l in reversed(layers):
+        lo = offs[l.w.data_ptr()]
+        if l is layers[0] or (total - lo) >= total * k / nbuckets:
+            cuts.append((l, lo, hi))
+            hi = lo
+            while (total - lo) >= total * k / nbuckets:
+                k += 1
+    assert cuts[-1][1] == 0 and sum(h - l for _, l, h in cuts) == total
+    return cuts
+
+
+class SegmentedStep:
+    """One rank's forward + backward as a CHAIN of hipGraph segments, one per gradient bucket, with the bucket's RCCL
+    all-reduce issued between segments: segment k+1 (the rest of the backward) replays on the compute stream while bucket k is
+    being reduced over xGMI on RCCL's stream.  The collective itself is never captured (plain torch.distributed launch), so
+    the N-GPU path needs nothing from RCCL beyond what eager training uses.
+
+    replaces: nn.DataParallel's gather / ReduceAddCoalesced (Classification/train.py:88-92), timm DDP's bucketed overlap
+    (training_commands.txt).  The local loss is divided by the world size before the backward pass, so the SUM all-reduce
+    yields the mean gradient with no extra pass over the arena (exact: gradients are linear in dlogits)."""
+
+    def __init__(self, runner, criterion, nbuckets=4, group=None):
+        self.runner, self.crit, self.group = runner, criterion, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuts = plan_buckets(runner, nbuckets)
+        self.boundaries = {id(l): i for i, (l, _, _) in enumerate(self.cuts)}
+        self.graphs, self._handles, self.loss = None, [], None
+
+    # -- the step body: forward, loss, dlogits (torch autograd only for the cross-entropy), hand-written backward
+    def _body(self, x, target, on_bucket):
+        r = self.runner
+        logits = r._forward_impl(x, record=True).detach().requires_grad_(True)
+        loss = self.crit(logits, target)
+        (loss / self.world).backward()
+        r.bind_grads()
+        r.E.backward(logits.grad, boundaries=self.boundaries, on_bucket=on_bucket)
+        return loss.detach()
+
+    def _reduce(self, i):
+        _, lo, hi = self.cuts[i]
+        self._handles.append(dist.all_reduce(self.runner.grad_arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
+    def run_eager(self, x, target):
+        """Eager launches, bucket all-reduces started from inside the backward pass."""
+        self.loss = self._body(x, target, self._reduce if dist.is_initialized() else None)
+        return self.loss
+
+    def capture(self, x, target):
+        """Capture the step on static inputs as len(cuts) graphs sharing one memory pool.  Run a few eager steps first: descriptor
+        tables and state are built on first use and must not be created during capture."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graphs, state = [], {}
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(capture_error_mode="thread_local")
+            state["g"] = g
+
+            def on_bucket(i):
+                state["g"].capture_end()
+                graphs.append(state["g"])
+                if i + 1 < len(self.cuts):
+                    state["g"] = torch.cuda.CUDAGraph()
+                    state["g"].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+            self.loss = self._body(x, target, on_bucket)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert len(graphs) == len(self.cuts)
+        self.graphs = graphs
+        return self.loss
+
+    def replay(self):
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if dist.is_initialized():
+                self._reduce(i)
+        return self.loss

@@ -19,10 +19,13 @@ class _QATFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, runner):
         ctx.runner = runner
-        return runner._forward_impl(x, record=True)
+        out = runner._forward_impl(x, record=True)
+        ctx.gen = runner._new_generation()
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
+        ctx.runner._check_generation(ctx.gen)
         ctx.runner._backward_impl(dlogits)
         return None, None, None
 
@@ -34,11 +37,13 @@ class _QATFeatFunction(torch.autograd.Function):
     def forward(ctx, anchor, x, runner):
         acts = runner._features_impl(x, record=True)
         ctx.runner, ctx.acts = runner, acts
+        ctx.gen = runner._new_generation()
         return tuple(a.dequant().contiguous() for a in acts)
 
     @staticmethod
     def backward(ctx, *grads):
         from .engine import float_to_grad
+        ctx.runner._check_generation(ctx.gen)
         for a, g in zip(ctx.acts, grads):     # tap gradients first; later layers' dgrads accumulate on top
             if g is None:
                 g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
@@ -60,7 +65,12 @@ class FrostRunner:
                 "FrostRunner binds the fake-quantised (QAT-prepared) FrostNet; the float model runs through "
                 "frostnet_amd.float_train.FloatRunner (model.hip_runner() picks the right one).")
         params = list(model.parameters())
+        if not params:
+            raise RuntimeError("this module has no parameters of its own (an nn.DataParallel replica?): the HIP path is one process per "
+                               "GPU -- see frostnet_amd.parallel / `bench.py --gpus N`")
         self.device = params[0].device
+        if self.device.type != "cuda":
+            raise RuntimeError(f"FrostRunner needs the model on the HIP device (parameters are on {self.device})")
         self.E = Engine(self.device)
         self._sig = tuple(p.data_ptr() for p in params) + tuple(b.data_ptr() for b in model.buffers())
         self._build()
@@ -71,7 +81,7 @@ class FrostRunner:
         L.load_library()
         r = cls.__new__(cls)
         r.model, r.device = block, next(block.parameters()).device
-        r.E, r.qa, r.rule127, r.observe = Engine(r.device), QArena(32, r.device), False, True
+        r.E, r.qa, r.rule127 = Engine(r.device), QArena(32, r.device), False
         r.block = r._bind_block("B", block)
         r.E.rule127 = 1 if r.rule127 else 0
         r._params = list(block.parameters())
@@ -81,6 +91,25 @@ class FrostRunner:
             r._grad_views.append(r.grad_arena[off: off + p.numel()].view_as(p))
             off += p.numel()
         return r
+
+    @property
+    def observe(self):
+        """True iff any site's observer is enabled: ONE device->host read of the flag column of the qrecord arena (the torch
+        `observer_enabled` buffers are views into it).  Also the place where a disabled fake-quantizer is refused."""
+        flags = self.qa.t.view(torch.int32)[: self.qa.next][:, [L.Q_OBS_EN, L.Q_FQ_EN]].cpu()
+        if bool((flags[:, 1] == 0).any()):
+            raise NotImplementedError("fake_quant_enabled == 0 (torch.quantization.disable_fake_quant): the int8 engine has no float "
+                                      "activation mode; run the float model (FloatRunner) instead")
+        return bool((flags[:, 0] != 0).any())
+
+    def _observe_hint(self, training):
+        """What the host passes as `observe`: 1 = run the statistics passes and let every site's own device flag decide.  Training
+        needs the statistics anyway (BatchNorm); eval reads the flags once per forward so that a fully frozen network skips them."""
+        if training:
+            return True
+        if not torch.cuda.is_current_stream_capturing():
+            self._obs_cached = self.observe
+        return getattr(self, "_obs_cached", True)
 
     def still_valid(self):
         m = self.model
@@ -97,21 +126,22 @@ class FrostRunner:
             rec[L.Q_SCALE] = fq.scale.reshape(-1)[0].float()
             rec[L.Q_INV] = 1.0 / fq.scale.reshape(-1)[0].float()
             rec.view(torch.int32)[L.Q_ZP] = fq.zero_point.reshape(-1)[0].to(torch.int32)
-        # torch.quantization.disable_observer / enable_observer (the helper at Classification/train.py:27-33, evaluate.py:131-143) call
-        # these methods on every FakeQuantize: honour them.  Granularity here is the whole network (the reference only ever applies
-        # them to the whole model): the last call wins.
-        orig_dis, orig_en = fq.disable_observer, fq.enable_observer
-
-        def _disable(orig=orig_dis):
-            orig()
-            self.observe = False
-
-        def _enable(enabled=True, orig=orig_en):
-            orig(enabled)
-            self.observe = bool(enabled)
-        fq.disable_observer, fq.enable_observer = _disable, _enable
-        if int(fq.observer_enabled[0]) == 0:       # frozen before the runner was built (one host read at bind time)
-            self.observe = False
+        # torch.quantization.disable_observer / enable_observer / disable_fake_quant (the helpers at Classification/train.py:27-33,
+        # evaluate.py:131-143) write 0/1 into the module's `observer_enabled` / `fake_quant_enabled` buffers.  Those buffers are
+        # aliased onto the qrecord like scale / zero_point, so the write lands in device memory and the kernels test the site's own
+        # flag: per-module granularity, no instance patching (deepcopy / pickling of the model stay intact), no host round trip.
+        for name, slot in (("observer_enabled", L.Q_OBS_EN), ("fake_quant_enabled", L.Q_FQ_EN)):
+            buf = fq._buffers[name]
+            ri = rec.view(torch.int32)
+            with torch.no_grad():
+                ri[slot] = (buf.reshape(-1)[0] != 0).to(torch.int32)
+                ri[slot + 1] = 0
+            if buf.dtype == torch.int64:                 # FusedMovingAvgObsFakeQuantize (qconfig version 1)
+                fq._buffers[name] = rec[slot:slot + 2].view(torch.int64)
+            elif buf.dtype == torch.uint8:               # FakeQuantize (version 0)
+                fq._buffers[name] = rec.view(torch.uint8)[4 * slot:4 * slot + 1]
+            else:
+                fq._buffers[name] = ri[slot:slot + 1].view(buf.dtype) if buf.element_size() == 4 else buf
         fq._buffers["scale"] = rec[L.Q_SCALE:L.Q_SCALE + 1]
         fq._buffers["zero_point"] = rec.view(torch.int32)[L.Q_ZP:L.Q_ZP + 1]
         obs._buffers["min_val"] = rec[L.Q_MIN]
@@ -126,6 +156,7 @@ class FrostRunner:
         self.rule127 = self.rule127 or _is_fused_fq(m.weight_fake_quant)
         l = ConvLayer(name, kind, m.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var,
                       m.bn.num_batches_tracked, None, m.kernel_size[0], m.stride[0], relu, qw, qy)
+        l.bn_mod = m.bn
         return self.E.add_layer(l)
 
     def _bind_block(self, pre, b):
@@ -162,7 +193,6 @@ class FrostRunner:
         nsites = 1 + 2 * (2 + 4 * len(blocks)) + 2 * len(blocks) + 2 + 8
         self.qa = QArena(nsites, self.device)
         self.rule127 = False
-        self.observe = True
         self.q_in = self._bind_fq(m.quant.activation_post_process, self.qa.alloc())
         self.stem = self._conv_layer("conv1", m.conv1, "stem")
         self.blocks = []
@@ -207,18 +237,43 @@ class FrostRunner:
                 p.grad = v
 
     # ------------------------------------------------------------------------------------------ execution
+    def _new_generation(self):
+        """The saved activations of a training forward live on the engine's tape, not on the autograd node: one forward, one backward."""
+        self._gen = getattr(self, "_gen", 0) + 1
+        return self._gen
+
+    def _check_generation(self, gen):
+        if gen != getattr(self, "_gen", 0) or not self.E.tape:
+            raise RuntimeError("backward through a FrostNet forward whose tape is gone: the HIP path keeps ONE recorded forward per model "
+                               "(a later forward replaced it, or backward already ran). Run forward -> backward pairs one at a time.")
+
+    def _check_input(self, x):
+        if x.device != self.device:
+            raise RuntimeError(f"input is on {x.device} but the model's parameters (and its HIP runner) are on {self.device}")
+        if x.requires_grad:
+            raise NotImplementedError("the HIP path does not produce a gradient w.r.t. the input image (QuantStub output has none in "
+                                      "the reference's training loops either); detach the input")
+
     def forward(self, x):
+        self._check_input(x)
         training = self.model.training
-        if training and torch.is_grad_enabled():
-            return _QATFunction.apply(self._params[0], x, self)
-        return self._forward_impl(x, record=False)
+        with torch.cuda.device(self.device):          # kernels launch on the CURRENT device's stream: make it the model's
+            if training and torch.is_grad_enabled():
+                return _QATFunction.apply(self._params[0], x, self)
+            return self._forward_impl(x, record=False)
 
     def _trunk(self, x, training):
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected an (N,3,H,W) tensor")
         if x.numel() == 0:
             raise ValueError("empty batch")
-        E, obs = self.E, self.observe
+        if training:
+            for l in self.E.layers:
+                if l.bn_mod is not None and not l.bn_mod.training:
+                    raise NotImplementedError(f"{l.name}: BatchNorm in eval mode inside a training forward (_freeze_stages): the HIP backward "
+                                              "implements the batch-statistics BatchNorm gradient only")
+        E, obs = self.E, self._observe_hint(training)
+        self._obs = obs
         E.begin_step(observe=obs)
         a = E.quantize_input(x, self.q_in, observe=obs)
         a = E.conv(self.stem, a, training, obs)
@@ -229,10 +284,12 @@ class FrostRunner:
         return a, feats
 
     def forward_features(self, x):
-        if self.model.training and torch.is_grad_enabled():
-            return list(_QATFeatFunction.apply(self._params[0], x, self))
-        acts = self._features_impl(x, record=False)
-        return [a.dequant().contiguous() for a in acts]
+        self._check_input(x)
+        with torch.cuda.device(self.device):
+            if self.model.training and torch.is_grad_enabled():
+                return list(_QATFeatFunction.apply(self._params[0], x, self))
+            acts = self._features_impl(x, record=False)
+            return [a.dequant().contiguous() for a in acts]
 
     def _features_impl(self, x, record):
         if x.dtype != torch.float32:
@@ -251,16 +308,18 @@ class FrostRunner:
         if x.dtype != torch.float32:
             x = x.float()
         a, _ = self._trunk(x, training)
-        a = self.E.conv(self.last, a, training, self.observe)
+        a = self.E.conv(self.last, a, training, self._obs)
         drop = None
-        if training and self.drop_rate > 0.0:
-            keep = 1.0 - self.drop_rate
+        drop_rate = float(self.model.classifier[1].p)
+        if training and drop_rate > 0.0:
+            keep = 1.0 - drop_rate
             drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device).bernoulli_(keep).div_(keep)
-        logits = self.E.head(self.cls, a, drop, self.observe)
+        logits = self.E.head(self.cls, a, drop, self._obs)
         if not record:
             self.E.tape = []
         return logits
 
     def _backward_impl(self, dlogits):
-        self.bind_grads()
-        self.E.backward(dlogits)
+        with torch.cuda.device(self.device):
+            self.bind_grads()
+            self.E.backward(dlogits)

@@ -12,8 +12,9 @@
  *  - Activations: NHWC, one signed byte per element holding (q - 128), q = the reference's quint8 index
  *    ("offset-binary index").  Channel counts are multiples of 4 (FrostNet: multiples of 8).
  *    Activation buffers must be allocated with >= 64 bytes of slack after the last element.
- *  - qrecord: 8 floats per fake-quantize site (FROST_Q_*): observer min/max, scale, zero_point(int bits),
- *    fake-quantised tensor min/max, 1/scale.  torch's module buffers are views into these records.
+ *  - qrecord: 12 floats per fake-quantize site (FROST_Q_*): observer min/max, scale, zero_point(int bits),
+ *    fake-quantised tensor min/max, 1/scale, observer_enabled / fake_quant_enabled.  torch's module buffers are views
+ *    into these records.
  *  - gradients of activations: bf16, NHWC.  Parameter gradients: fp32.
  */
 #ifndef FROST_HIP_H
@@ -34,8 +35,12 @@ extern "C" {
 #define FROST_Q_FQMIN 4
 #define FROST_Q_FQMAX 5
 #define FROST_Q_INV 6
-#define FROST_Q_FLAGS 7   /* int32 bits: bit0 observer_enabled(default 1 when 0 written as 0x0?) see frost_qrecord_init */
-#define FROST_Q_STRIDE 8
+#define FROST_Q_RESERVED 7
+#define FROST_Q_OBS_EN 8   /* 8 bytes (slots 8-9): FakeQuantize.observer_enabled, aliased by the torch buffer (uint8[1] or int64[1]);
+                              kernels test the low 32-bit word != 0, so torch.quantization.disable_observer on ANY sub-module is
+                              honoured per site without a host round trip (torch/ao/quantization/fake_quantize.py:170-184) */
+#define FROST_Q_FQ_EN 10   /* 8 bytes (slots 10-11): FakeQuantize.fake_quant_enabled (must stay 1: checked on the host side) */
+#define FROST_Q_STRIDE 12
 
 /* per-conv-layer coefficient rows (floats, each row `cpad` long; cpad = round_up(cout,16)) */
 #define FROST_COEF_A 0      /* y = fma(A, acc, B)                                   */

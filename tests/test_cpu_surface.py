@@ -203,3 +203,72 @@ def test_features_backbone_cpu_matches_reference(built, golden):
         assert list(f.shape) == g[f"f{i}_shape"].tolist()
         np.testing.assert_allclose(f[0, :8, :4, :4].numpy(), g[f"f{i}_crop"], rtol=1e-4, atol=1e-5)
     assert [f.shape[1] for f in fs] == [24, 40, 96, 320]
+
+
+def test_bench_launcher_dry_run_spawns_n_ranks():
+    """`python bench.py --gpus N` must start N ranks itself (VERDICT r1 missing #1).  CPU dry run: N gloo ranks, one all-reduce."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run-launcher"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 3 and rec["allreduce_sum"] == rec["expected"] == 6.0
+    # launched BY a launcher (RANK / WORLD_SIZE already set): no second spawn, world size taken from the environment
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29777")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run-launcher"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1
+
+
+def _shard_oracle_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from frostnet_amd.parallel import GradSync
+    torch.set_num_threads(4)
+    cfg = O.net_cfg("small", 1.0)
+    P, Bf = O.make_state(O.float_state_spec(cfg), 5000, True)          # identical weights on every rank
+    qs = O.QState(Bf)
+    x = T(O.synth((2, 3, 32, 32), 60 + rank))                           # this rank's shard
+    tgt = torch.tensor([1 + rank, 7 + rank])
+    torch.nn.functional.cross_entropy(O.frostnet_forward(P, qs, cfg, x, True, True), tgt).backward()
+    sizes = [p.numel() for p in P.values()]
+    offs = np.cumsum([0] + sizes[:-1]).tolist()
+    arena = torch.zeros(sum(sizes))
+    sync = GradSync(arena, offs, nbuckets=4)
+    for i, p in reversed(list(enumerate(P.values()))):                  # gradients become final in reverse parameter order
+        arena[offs[i]: offs[i] + sizes[i]] = p.grad.reshape(-1)
+        sync.ready(offs[i])
+    sync.finish()
+    q.put((rank, arena.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_shard_oracle_mean_gradient_gloo_world2():
+    """SURVEY 8(e) parity check without a cluster: W=2 shards through the oracle from identical weights -> the mean gradient must be what
+    every rank holds after the bucketed all-reduce (real FrostNet-Small gradients in real parameter order, not random vectors)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_shard_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    cfg = O.net_cfg("small", 1.0)
+    grads = []
+    torch.set_num_threads(4)
+    for r in range(2):
+        P, Bf = O.make_state(O.float_state_spec(cfg), 5000, True)
+        qs = O.QState(Bf)
+        torch.nn.functional.cross_entropy(O.frostnet_forward(P, qs, cfg, T(O.synth((2, 3, 32, 32), 60 + r)), True, True),
+                                          torch.tensor([1 + r, 7 + r])).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in P.values()]))
+    expect = ((grads[0] + grads[1]) / 2).numpy()
+    for r in range(2):
+        np.testing.assert_allclose(res[r][1], expect, rtol=1e-5, atol=1e-7)

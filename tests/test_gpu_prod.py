@@ -1,0 +1,242 @@
+"""Oracle parity at PRODUCTION layer shapes, forward and backward, through the C ABI.
+
+The G3/G4 reference goldens are N=2 at 6x6..16x16, where the fast kernel variants do not engage (resident-weight / full-tile /
+LDS-staged-I/O pointwise instances need >= 2048 full tiles, the channel-split launch needs few tiles of a wide layer, the
+depthwise geometries depend on the true map width, the split-K weight gradient on the pixel count).  Here every real
+FrostNet-Large layer family runs at its true resolution with a batch that selects those variants, teacher-forced on the same
+seeded uint8 indices as the CPU oracle (oracle.convbn_qat, itself pinned to the reference by tests/test_oracle_golden.py).
+
+Stated tolerances: indices |delta| <= 1 with flip rate <= FLIP (integer-exact conv + one fma here, fp32 conv + divide +
+batch_norm there); observer scalars 2e-5; running statistics 1e-3; gradients norm-wise <= GRAD (bf16 gradient storage and
+bf16 MFMA operands); the classifier head against the REFERENCE golden (tests/golden/g3_classifier.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frost_oracle as O
+
+pytestmark = pytest.mark.gpu
+FLIP = 5e-4
+GRAD = 2e-2
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def relerr(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import engine
+    assert torch.cuda.is_available()
+    return engine
+
+
+#        name             cin   cout  k  s  groups H    N   relu   which fast paths this selects
+PROD = [("stem_224",        3,   32,  3, 2, 1,    224, 4,  1),   # im2col + pointwise K=40
+        ("pw16_96_112",    16,   96,  1, 1, 1,    112, 24, 1),   # 2352 full tiles: RES + FULL + LDS-staged I/O, small wgrad split-K
+        ("pw24_144_56",    24,  144,  1, 1, 1,    56,  84, 1),   # 9 channel tiles: 4-wave-wide channel split (WP=2) + RES
+        ("pw96_24_56_lin", 96,   24,  1, 1, 1,    56,  84, 0),   # linear bottleneck (zp != 0), narrow output
+        ("dw3s2_96_112",   96,   96,  3, 2, 96,   112, 4,  1),   # DwGeo<3,2,32,32>
+        ("dw3s1_72_56",    72,   72,  3, 1, 72,   56,  8,  1),   # DwGeo<3,1,32,32>, fused dc + wgrad
+        ("dw5s2_144_56",  144,  144,  5, 2, 144,  56,  8,  1),   # DwGeo<5,2,32,32>
+        ("dw5s1_624_14",  624,  624,  5, 1, 624,  14,  16, 1),   # DwGeo<5,1,64,16>, separate wgrad
+        ("pw104_624_14",  104,  624,  1, 1, 1,    14,  32, 1),   # 49 tiles of a wide layer: channel-group split (csplit)
+        ("pw624_96_14_lin", 624, 96,  1, 1, 1,    14,  32, 0),   # K = 624 > 512: chunked staging, k_pw_wgrad_big
+        ("pw240_1440_7",  240, 1440,  1, 1, 1,    7,   64, 1),   # 7x7, 90 channel tiles
+        ("dw5s1_1440_7", 1440, 1440,  5, 1, 1440, 7,   64, 1),   # DwGeo<5,1,64,8> (two images per tile), fused dc + wgrad
+        ("pw1728_320_7_lin", 1728, 320, 1, 1, 1,  7,   64, 0)]   # K = 1728, signed output
+
+
+def _layer_state(cin, cout, k, groups, seed):
+    spec = O._convbn_spec("L", cin, cout, k, groups)
+    return O.synth_state([k_ for k_, _ in spec], [s_ for _, s_ in spec], seed)
+
+
+@pytest.mark.parametrize("case", PROD, ids=[c[0] for c in PROD])
+def test_prod_layer_vs_oracle(engine, case):
+    name, cin, cout, k, s, groups, H, N, relu = case
+    dev = "cuda"
+    torch.set_num_threads(16)
+    seed = 7000 + 13 * PROD.index(case)
+    sd = _layer_state(cin, cout, k, groups, seed)
+    in_scale, in_zp = 0.0231, (0 if PROD.index(case) % 2 == 0 else 117)
+    xi = np.clip(np.round(O.synth((N, cin, H, H), seed + 1) * 40 + 128 + (0 if in_zp else -60)), 0, 255).astype(np.uint8)
+    # ---- oracle (CPU)
+    P, B = O.split_state({O.float_to_qat_key(k_): v.clone() for k_, v in sd.items()})
+    qs = O.QState(B)
+    xo = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+    # ---- HIP
+    kind = "stem" if (groups == 1 and k == 3) else ("dw" if groups > 1 else "pw")
+    E, qa = engine.Engine(dev), engine.QArena(4, dev)
+    w = sd["L.conv.0.weight"].to(dev).contiguous().requires_grad_(True)
+    gamma, beta = sd["L.conv.1.weight"].to(dev).requires_grad_(True), sd["L.conv.1.bias"].to(dev).requires_grad_(True)
+    l = engine.ConvLayer("L", kind, w, gamma, beta, sd["L.conv.1.running_mean"].to(dev), sd["L.conv.1.running_var"].to(dev),
+                         torch.zeros((), dtype=torch.int64, device=dev), None, k, s, bool(relu), qa.alloc(), qa.alloc())
+    E.add_layer(l)
+    qx = qa.alloc()
+    qa.set_qparams(qx, in_scale, in_zp)
+    xi_t = T(xi)
+    if kind == "stem":
+        xi_t = torch.cat([xi_t, torch.full_like(xi_t[:, :1], in_zp)], 1)
+    for step in range(2):
+        xo.grad = None
+        for p in P.values():
+            p.grad = None
+        yo = O.convbn_qat(P, qs, "L", xo, s, (k - 1) // 2, groups, bool(relu), True)
+        gr = T(O.synth(tuple(yo.shape), seed + 2 + 50 * step))
+        yo.backward(gr)
+        a = "L.conv.0.activation_post_process"
+        idx_o = O.fq_index(yo.detach(), qs.sd[a + ".scale"][0], qs.sd[a + ".zero_point"][0])
+
+        E.begin_step()
+        x = E.act_from_indices(xi_t, qx)
+        y = E.conv(l, x, training=True, observe=True)
+        y.grad = engine.float_to_grad(gr.to(dev))
+        yidx = y.indices().cpu()
+        E.backward()
+        torch.cuda.synchronize()
+
+        d = (yidx.to(torch.int16) - idx_o.to(torch.int16)).abs()
+        mx, rate = int(d.max()), float((d > 0).float().mean())
+        qy, qw = qa.get(l.qy), qa.get(l.qw)
+        e_dw = relerr(l.w.grad.cpu(), P["L.conv.0.weight"].grad)
+        e_dg = relerr(l.gamma.grad.cpu(), P["L.conv.0.bn.weight"].grad)
+        e_db = relerr(l.beta.grad.cpu(), P["L.conv.0.bn.bias"].grad)
+        e_dx = relerr(engine.grad_to_float(x.grad, x.n, x.h, x.w, x.c).cpu(), xo.grad) if kind != "stem" else 0.0
+        print(f"[{name} step {step}] idx max {mx} flip {rate:.2e} | dx {e_dx:.2e} dW {e_dw:.2e} dgamma {e_dg:.2e} dbeta {e_db:.2e}")
+        assert mx <= 1 and rate <= FLIP, (name, step, mx, rate)
+        np.testing.assert_allclose(qy["scale"], float(qs.sd[a + ".scale"][0]), rtol=2e-5)
+        assert qy["zero_point"] == int(qs.sd[a + ".zero_point"][0])
+        np.testing.assert_allclose(qy["min_val"], float(qs.sd[a + ".activation_post_process.min_val"]), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(qy["max_val"], float(qs.sd[a + ".activation_post_process.max_val"]), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(qw["scale"], float(qs.sd["L.conv.0.weight_fake_quant.scale"][0]), rtol=1e-6)
+        np.testing.assert_allclose(l.rmean.cpu().numpy(), qs.sd["L.conv.0.bn.running_mean"].numpy(), rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(l.rvar.cpu().numpy(), qs.sd["L.conv.0.bn.running_var"].numpy(), rtol=1e-3, atol=2e-4)
+        assert max(e_dx, e_dw, e_dg, e_db) <= GRAD, (name, step, e_dx, e_dw, e_dg, e_db)
+
+
+def test_classifier_head_vs_reference_golden(engine, golden):
+    """nnqat.Conv2d head (frostnet.py:295-299): avg-pool -> classifier conv on fake-quantised weights -> activation fake-quant, and
+    its backward, against the fixture generated from the imported reference (tools/gen_golden.py g3c)."""
+    from test_oracle_golden import classifier_case
+    g = golden("g3_classifier")
+    N, H, gseed, in_scale, in_zp, w, x = classifier_case(g)
+    dev = "cuda"
+    E, qa = engine.Engine(dev), engine.QArena(4, dev)
+    W = w["classifier.2.weight"].to(dev).requires_grad_(True)
+    b = w["classifier.2.bias"].to(dev).requires_grad_(True)
+    l = engine.ConvLayer("classifier.2", "cls", W, None, None, None, None, None, b, 1, 1, False, qa.alloc(), qa.alloc())
+    E.add_layer(l)
+    qx = qa.alloc()
+    qa.set_qparams(qx, in_scale, in_zp)
+    for step in range(2):
+        E.begin_step()
+        a = E.act_from_indices(T(g["x_idx"]), qx)
+        logits = E.head(l, a, None, True)
+        gr = T(O.synth((N, 1000, 1, 1), gseed + 50 * step)).reshape(N, 1000).to(dev)
+        E.backward(gr)
+        torch.cuda.synchronize()
+        qy = qa.get(l.qy)
+        pre = f"s{step}_sd/classifier/2/"
+        np.testing.assert_allclose(qy["scale"], float(g[pre + "activation_post_process/scale"][0]), rtol=2e-5)
+        assert qy["zero_point"] == int(g[pre + "activation_post_process/zero_point"][0])
+        np.testing.assert_allclose(qa.get(l.qw)["scale"], float(g[pre + "weight_fake_quant/scale"][0]), rtol=1e-6)
+        idx = torch.round(logits.cpu() / qy["scale"] + qy["zero_point"]).to(torch.int16)
+        d = (idx - T(g[f"s{step}_yidx"]).to(torch.int16)).abs()
+        e_y = relerr(logits.cpu(), T(g[f"s{step}_y"]))
+        dx = engine.grad_to_float(a.grad, a.n, a.h, a.w, a.c).cpu()
+        e_dx = relerr(dx[:, :, 0, 0], T(g[f"s{step}_dx00"]))
+        pack = g[f"s{step}_dw"]
+        mine = O.sample_big(l.w.grad.detach().double().cpu().numpy().reshape(-1))
+        e_dw = float(np.linalg.norm(mine - pack[3:]) / (np.linalg.norm(pack[3:]) + 1e-30))
+        e_db = relerr(l.bias.grad.cpu(), T(g[f"s{step}_db"]))
+        print(f"[classifier step {step}] idx max {int(d.max())} flip {float((d > 0).float().mean()):.2e} y {e_y:.2e} dx {e_dx:.2e} dW {e_dw:.2e} db {e_db:.2e}")
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 2e-3
+        assert float((dx - dx[:, :, :1, :1]).abs().max()) == 0.0
+        assert e_dx <= GRAD and e_dw <= 1e-3 and e_db <= 1e-4          # the head's GEMMs are exact fp32 (v_mfma_f32_16x16x4_f32)
+
+
+def _bind(mode, P, qs, drop=0.0):
+    from frostnet_amd import frostnet as F
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=drop)
+    F.qat_prepare(model, version=0)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
+    model.load_state_dict(sd, strict=False)
+    return model
+
+
+def test_small64_train_forward_site_by_site(engine):
+    """Whole-network QAT TRAIN forward, FrostNet-Small @64, batch 2, first step, fresh observers: every block output (fake-quant
+    site chain) compared index for index with the oracle, and the logits BEFORE their fake-quantiser at the north-star 1e-3."""
+    from frostnet_amd import frostnet as F
+    torch.set_num_threads(16)
+    mode, B, R = "small", 2, 64
+    cfg = O.net_cfg(mode, 1.0)
+    spec = O.float_state_spec(cfg)
+    x = T(O.synth((B, 3, R, R), 11))
+    P, Bf = O.make_state(spec, 5000, True)
+    qs = O.QState(Bf)
+    ref_blocks = []
+    orig = O.block_forward
+
+    def traced(P_, qs_, prefix, x_, bc, quantized, training):
+        o = orig(P_, qs_, prefix, x_, bc, quantized, training)
+        ref_blocks.append((prefix, o.detach()))
+        return o
+    O.block_forward = traced
+    try:
+        with torch.no_grad():
+            y_ref = O.frostnet_forward(P, qs, cfg, x, True, True)
+    finally:
+        O.block_forward = orig
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+    model.load_state_dict(O.synth_state([k for k, _ in spec], [s for _, s in spec], 5000))
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    r = model.hip_runner()
+    dev_blocks = []
+    orig_b = r.block_forward
+    r.block_forward = lambda d, inp, training, obs: (dev_blocks.append(orig_b(d, inp, training, obs)) or dev_blocks[-1])
+    with torch.no_grad():
+        y = model(x.cuda())
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (name, ro), do in zip(ref_blocks, dev_blocks):
+        sc = float(r.qa.get(do.q)["scale"])
+        d = (do.dequant().cpu() - ro).abs() / sc
+        frac = float((d > 0.5).float().mean())
+        worst = max(worst, frac)
+        assert float(d.max()) <= 1.01 and frac <= 1e-3, (name, float(d.max()), frac)
+    e_raw = relerr(r.E.last_raw.cpu(), qs.raw_logits)
+    e_fq = relerr(y.cpu(), y_ref)
+    print(f"[small@64 train] worst per-block flipped fraction {worst:.2e}; pre-fake-quant logits rel {e_raw:.2e}; fake-quantised logits rel {e_fq:.2e}")
+    assert e_raw <= 1e-3, e_raw
+    assert e_fq <= 5e-3, e_fq
+
+
+@pytest.mark.parametrize("mode,res", [("small", 64), ("large", 224)])
+def test_eval_prequant_logits_1e3(engine, mode, res):
+    """north_star: outputs within 1e-3 rel-err of the CPU reference.  The logits of the QAT model are 8-bit fake-quantised (one
+    step ~ 1e-2 norm-wise), so the comparison point is the classifier output BEFORE its fake-quantiser, eval mode, same
+    2-step-trained state on both sides."""
+    from test_gpu_model import _oracle_state_after_train
+    torch.set_num_threads(16)
+    cfg, P, qs = _oracle_state_after_train(mode, 64, 2)
+    model = _bind(mode, P, qs)
+    model.cuda().eval()
+    x = T(O.synth((2, 3, res, res), 529))
+    with torch.no_grad():
+        O.frostnet_forward(P, qs, cfg, x, True, False)
+        model(x.cuda())
+    r = model.hip_runner()
+    e = relerr(r.E.last_raw.cpu(), qs.raw_logits)
+    print(f"[{mode}@{res}] eval pre-fake-quant logits rel-err vs oracle: {e:.2e}")
+    assert e <= 1e-3, e

@@ -121,6 +121,43 @@ def test_g3_layer(golden, name):
         np.testing.assert_allclose(P["L.conv.0.bn.bias"].grad.numpy(), g[f"s{step}_dbeta"], rtol=1e-4, atol=1e-5)
 
 
+def classifier_case(g):
+    """Inputs of the classifier fixture (SURVEY 8c G3 'classifier 1280->1000'): shared with the GPU test."""
+    N, H, xseed, gseed, wseed = [int(v) for v in g["spec"]]
+    in_scale, in_zp = float(g["in_qp"][0]), int(g["in_qp"][1])
+    w = O.synth_state(["classifier.2.weight", "classifier.2.bias"], [(1000, 1280, 1, 1), (1000,)], wseed)
+    x = (T(g["x_idx"].astype(np.float32)) - in_zp) * in_scale
+    return N, H, gseed, in_scale, in_zp, w, x
+
+
+def test_g3_classifier(golden):
+    """nnqat.Conv2d head (frostnet.py:295-299) teacher-forced: logits indices bit-exact, gradients 1e-4, observer state 1e-6."""
+    g = golden("g3_classifier")
+    N, H, gseed, in_scale, in_zp, w, x = classifier_case(g)
+    P = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    qs = O.QState()
+    x = x.requires_grad_(True)
+    for step in range(2):
+        x.grad = None
+        for p in P.values():
+            p.grad = None
+        y = O.classifier_forward(P, qs, x, True)
+        y.backward(T(O.synth(tuple(y.shape), gseed + 50 * step)))
+        a = "classifier.2.activation_post_process"
+        idx = O.fq_index(y.detach(), qs.sd[a + ".scale"][0], qs.sd[a + ".zero_point"][0]).reshape(N, 1000)
+        assert np.array_equal(idx.numpy().astype(np.uint8), g[f"s{step}_yidx"])
+        np.testing.assert_allclose(y.detach().reshape(N, 1000).numpy(), g[f"s{step}_y"], rtol=1e-6, atol=1e-7)
+        for key, v in unpack_state(g, f"s{step}_sd/").items():
+            mine = qs.sd.get(key)
+            if mine is None:
+                assert key.endswith("enabled") or key.endswith("eps"), key
+                continue
+            np.testing.assert_allclose(mine.reshape(-1).double().numpy(), v.reshape(-1).double().numpy(), rtol=1e-6, atol=1e-7, err_msg=key)
+        np.testing.assert_allclose(x.grad[:, :, 0, 0].numpy(), g[f"s{step}_dx00"], rtol=1e-4, atol=1e-7)
+        check_pack(P["classifier.2.weight"].grad, g[f"s{step}_dw"])
+        np.testing.assert_allclose(P["classifier.2.bias"].grad.numpy(), g[f"s{step}_db"], rtol=1e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------ G4
 G4 = ["dw_e1", "mb", "cas_res", "cas_nores", "cas_s2"]
 

@@ -157,6 +157,39 @@ def g3_layers():
              init_ndims=ndims, **outs)
 
 
+def g3_classifier():
+    """SURVEY 8c G3 'classifier 1280->1000': the reference's head (frostnet.py:295-299: AdaptiveAvgPool2d(1) -> Dropout -> Conv2d,
+    QAT-prepared -> nnqat.Conv2d + activation FakeQuantize), teacher-forced on a fake-quantised 7x7 map, forward + backward."""
+    _, reg = refshim.load_frostnet()
+    net = reg["frostnet_quant_small_1_0"](drop_rate=0.0)
+    wseed = 3400
+    w = synth_state(["classifier.2.weight", "classifier.2.bias"], [(1000, 1280, 1, 1), (1000,)], wseed)
+    refshim.qat_prepare(net, version=0)
+    head = net.classifier
+    with torch.no_grad():
+        head[2].weight.copy_(w["classifier.2.weight"])
+        head[2].bias.copy_(w["classifier.2.bias"])
+    N, H = 4, 7
+    in_scale, in_zp = 0.0412, 0
+    xi = np.clip(np.round(np.abs(synth((N, 1280, H, H), 380)) * 30), 0, 255)
+    x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+    outs = {}
+    for step in range(2):
+        x.grad = None
+        net.zero_grad()
+        y = head(x)
+        g = T(synth(tuple(y.shape), 390 + 50 * step))
+        y.backward(g)
+        outs[f"s{step}_y"] = y.detach().reshape(N, 1000).clone()
+        outs[f"s{step}_yidx"] = fq_idx(y, head[2].activation_post_process).reshape(N, 1000).to(torch.uint8)
+        assert float((x.grad - x.grad[:, :, :1, :1]).abs().max()) == 0.0       # avg-pool backward: uniform over the map
+        outs[f"s{step}_dx00"] = x.grad[:, :, 0, 0].clone()
+        outs[f"s{step}_dw"] = grad_pack(head[2].weight.grad)
+        outs[f"s{step}_db"] = head[2].bias.grad.clone()
+        outs.update(sd_np({k: v for k, v in net.state_dict().items() if k.startswith("classifier.")}, f"s{step}_sd/"))
+    save("g3_classifier", spec=np.array([N, H, 380, 390, wseed]), in_qp=np.array([in_scale, in_zp]), x_idx=xi.astype(np.uint8), **outs)
+
+
 # ------------------------------------------------------------------------------------------ G4
 def g4_blocks():
     ref, _ = refshim.load_frostnet()
@@ -381,8 +414,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
-    fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8"]
+    fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
                g7=g7_scalars, g8=g8_features)
     for w in which:
         fns[w]()
