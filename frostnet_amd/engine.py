@@ -433,6 +433,8 @@ class Engine:
         self._ensure_grad(l)
         gout = y.grad
         dc = torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
+        if getattr(self, "_dbg", False):
+            self._last_dc = dc
         s = stream()
         if l.kind in ("pw", "stem"):
             dwq_final = l.dwq

@@ -173,6 +173,20 @@ class _FrostBase(nn.Module):
                 m.fuse_model()
 
     # ---- HIP execution --------------------------------------------------------------------------------
+    def state_dict(self, *args, **kwargs):
+        """As nn.Module.state_dict; the observer / qparam buffers that the HIP runner aliased onto its qrecord arena (float, int32, uint8
+        and int64 views of ONE storage -- torch.save refuses such a set) are returned as detached copies, so
+        `torch.save({'state_dict': model.state_dict(), ...})` (Classification/train.py:210-218) works on the bound model."""
+        sd = super().state_dict(*args, **kwargs)
+        r = self.__dict__.get("_hip_runner")
+        arena = getattr(getattr(r, "qa", None), "t", None)
+        if arena is not None:
+            base = arena.untyped_storage().data_ptr()
+            for k, v in list(sd.items()):
+                if torch.is_tensor(v) and v.device == arena.device and v.untyped_storage().data_ptr() == base:
+                    sd[k] = v.detach().clone()
+        return sd
+
     def __getstate__(self):
         """copy.deepcopy / pickle (EMA or best-model snapshots, torch.save(model)): the device executors are per-instance caches
         and stay behind; the copy builds its own on first use."""

@@ -119,8 +119,8 @@ class _GradBoost(Optimizer):
         shared = [k for k in self.defaults if k not in ("lr", "weight_decay")]
         for _, g in items:
             for k in shared:
-                if g[k] != items[0][1][k]:
-                    raise NotImplementedError(f"GradBoost multi-tensor step: param groups differ in '{k}' ({g[k]} vs {items[0][1][k]}); "
+                if g.get(k) != items[0][1].get(k):
+                    raise NotImplementedError(f"GradBoost multi-tensor step: param groups differ in '{k}' ({g.get(k)} vs {items[0][1].get(k)}); "
                                               "only lr and weight_decay may vary per group")
         arr = (L.FrostOptTensor * len(items))()
         prefix, tot = [], 0
