@@ -76,6 +76,8 @@ _PROTOS = {
     "frost_classifier_fwd": [P, P, P, P, I, I, I, P, P],
     "frost_pw_conv_bwd": [P, P, P, P, P, P, L, I, I, I, P, P, I, P, P, P, I, P],
     "frost_pw_wgrad": [P, P, P, L, I, I, P, P],
+    "frost_pw_bwd_fused_ok": [L, I, I],
+    "frost_pw_conv_bwd_fused": [P, P, P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, P],
     "frost_dw_conv_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
     "frost_dw_conv_bwd_dc_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P],
     "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
@@ -125,7 +127,7 @@ def load_library():
     for name, args in _PROTOS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_int       # (frost_pw_bwd_fused_ok / frost_abi_version return a value, not a status)
     lib.frost_last_error.restype = C.c_char_p
     _lib = lib
     return lib

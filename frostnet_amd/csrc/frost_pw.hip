@@ -41,6 +41,10 @@ struct PwP {
   int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
   int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
   const float* bias; int act_relu;   // bf16 GEMM mode used as an inference layer: + bias[ch], optional ReLU (qw == NULL: no weight scale)
+  // fused backward (k_pw<M_BDC, .., FTW > 0>): the dc tile never leaves LDS -- data gradient and weight gradient are taken from it
+  const uint8_t* wtp; int KSd;       // bf16 transposed weight pack [cin tile][co step][lane][16 B], K steps of 32 output channels
+  float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
+  int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
 };
 
 #define BP 128
@@ -116,8 +120,20 @@ __device__ __forceinline__ void pw_wait_barrier(int n_younger) {      // n_young
 #ifndef PW_MINW
 #define PW_MINW(MODE, WP) 4
 #endif
-template <int MODE, int WP, bool RES, bool FULLT>
+typedef short v4s_ __attribute__((ext_vector_type(4)));
+typedef int v2i_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pw_trunc_bf2(float lo, float hi) {   // exact for |integers| <= 256
+  return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+}
+
+// FTW > 0 (M_BDC, RES, FULLT only) = the fused backward: after the dc tile has been assembled in LDS (over the DMA'd gout tile) the same
+// workgroup computes  dx[pix][ci] (+)= s_w * sum_co dc[pix][co] * wq[co][ci]   (wave w: pixel sub-tile w, all input-channel tiles) and
+// dWq[co][ci] += s_x * sum_pix dc[pix][co] * (q[pix][ci] - zp)   (16x16 output tiles dealt round-robin to the 8 waves, FTW per wave, persistent
+// accumulators flushed once per workgroup) -- so dc is neither written to nor re-read from HBM twice (-6 B per output element), and the
+// weight gradient does not read x again.  Replaces the dc pass + frost_pw dgrad + frost_pw_wgrad for layers with Cout*Cin <= ~19 k.
+template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0>
 __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
+  constexpr bool FUSE = FTW > 0;
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
   constexpr int MI = PW_MI(MODE, WP);
@@ -174,7 +190,12 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     }
   }
   if (RES && MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
+  // the data gradient's K tail reads past a dc row (next row / other buffer / the 64-byte pad): stale LDS bytes x zero weights must not be NaN
+  if (FUSE) for (int i = tid; i < (p.io_bytes >> 4); i += 512) ((uint4*)(smem + xs_bytes))[i] = make_uint4(0, 0, 0, 0);
   if (cres) __syncthreads();
+  v4f wacc[FUSE ? FTW : 1];
+#pragma unroll
+  for (int i = 0; i < (FUSE ? FTW : 1); ++i) wacc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
@@ -219,6 +240,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       n_younger = nfull * NT * per;
     }
     if (n_younger > 16) n_younger = 16;
+    if (FUSE) n_younger = 0;        // the fused tail issues weight loads and dx stores of its own: drain everything (safe lower bound)
   }
   if (gl) {
     // K padding reads past a row's end (next row / next buffer / the 64-byte tail): harmless for int8 (zero weights), but a
@@ -490,7 +512,81 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       };
       epilogue(std::integral_constant<bool, FULLT>{});
     }
-    if (o_lds) {             // linear copy-out of the assembled tile: 1 KiB per wave instruction
+    if (FUSE) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the dc tile [128][cout] bf16 is complete in LDS
+      const uint8_t* dct = io_base + buf * p.g_bytes;
+      const int rbd = p.cout * 2, cin = p.rowbytes;
+      uint8_t* dxo = smem + p.dxo_off;
+      if (p.dx) {                                                                 // ---- data gradient: D[ci][pix], wave w = pixel sub-tile w
+        const float swq = p.qw[FROST_Q_SCALE];
+        const int CTd = (cin + 15) >> 4;
+        const uint8_t* brow = dct + (w * 16 + j) * rbd + g * 16;
+        for (int c0 = 0; c0 < CTd; c0 += 4) {
+          v4f dacc[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) dacc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+          for (int ks = 0; ks < p.KSd; ++ks) {
+            const v4i bf = *(const v4i*)(brow + ks * 64);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              if (c0 + m < CTd) {
+                const v4i af = *(const v4i*)(p.wtp + ((((int64_t)(c0 + m) * p.KSd + ks) * 64 + lane) << 4));
+                dacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af), __builtin_bit_cast(v8bf, bf), dacc[m], 0, 0, 0);
+              }
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int ch0 = (c0 + m) * 16 + 4 * g;
+            if (c0 + m < CTd && ch0 < cin) {
+              uint2 o; o.x = pack_bf2(dacc[m][0] * swq, dacc[m][1] * swq); o.y = pack_bf2(dacc[m][2] * swq, dacc[m][3] * swq);
+              *(uint2*)(dxo + ((w * 16 + j) * cin + ch0) * 2) = o;
+            }
+          }
+        }
+      }
+      {                                                                           // ---- weight gradient: 16x16 (co x ci) tiles, K = the 128 pixels
+        const int nbw = (cin + 15) >> 4, ntw = CT * nbw;
+        const float zpf = (float)(zpx + 128);
+#pragma unroll
+        for (int i = 0; i < FTW; ++i) {
+          const int tt = w + 8 * i;
+          if (tt < ntw) {
+            const int a = tt / nbw, b = tt - a * nbw;
+            const uint8_t* a_src = dct + (g * 8 + (j >> 2)) * rbd + (j & 3) * 8 + a * 32;
+            const uint8_t* b_src = xs + (g * 8 + (j >> 1)) * cin + (j & 1) * 8 + b * 16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const v2i_ lo = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(a_src + ks * 32 * rbd)));
+              const v2i_ hi = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(a_src + ks * 32 * rbd + 4 * rbd)));
+              const v4i af = (v4i){lo[0], lo[1], hi[0], hi[1]};
+              const v2i_ raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i_ __attribute__((address_space(3)))*)(b_src + ks * 32 * cin));
+              const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;   // offset-binary -> unsigned index
+              const v4i bf = (v4i){(int)pw_trunc_bf2((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
+                                   (int)pw_trunc_bf2((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                                   (int)pw_trunc_bf2((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
+                                   (int)pw_trunc_bf2((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf)};
+              wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af), __builtin_bit_cast(v8bf, bf), wacc[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (p.dx) {                                                                 // linear copy-out of the dx tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        uint8_t* gdst = (uint8_t*)p.dx + tile * p.dx_bytes;
+        const int nu = p.dx_bytes >> 10;
+        for (int u = w; u < nu; u += 8) {
+          uint4 v = *(const uint4*)(dxo + u * 1024 + lane * 16);
+          if (p.accumulate) {
+            const uint4 o = *(const uint4*)(gdst + u * 1024 + lane * 16);
+            v.x = pack_bf2(bf2f(v.x & 0xffff) + bf2f(o.x & 0xffff), bf2f(v.x >> 16) + bf2f(o.x >> 16));
+            v.y = pack_bf2(bf2f(v.y & 0xffff) + bf2f(o.y & 0xffff), bf2f(v.y >> 16) + bf2f(o.y >> 16));
+            v.z = pack_bf2(bf2f(v.z & 0xffff) + bf2f(o.z & 0xffff), bf2f(v.z >> 16) + bf2f(o.z >> 16));
+            v.w = pack_bf2(bf2f(v.w & 0xffff) + bf2f(o.w & 0xffff), bf2f(v.w >> 16) + bf2f(o.w >> 16));
+          }
+          *(uint4*)(gdst + u * 1024 + lane * 16) = v;
+        }
+      }
+    } else if (o_lds) {             // linear copy-out of the assembled tile: 1 KiB per wave instruction
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       const uint8_t* osrc = io_base + ((MODE == M_BDC) ? buf * p.g_bytes : 0);
       uint8_t* gdst = (MODE == M_EMIT) ? (uint8_t*)p.y + tile * p.o_bytes : ((MODE == M_BDC) ? (uint8_t*)p.dc + tile * p.o_bytes : (uint8_t*)p.dx + tile * p.o_bytes);
@@ -510,6 +606,22 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
     buf ^= 1;
   }
 
+  if (FUSE) {                          // one flush of this workgroup's weight-gradient partials
+    const int cin = p.rowbytes, nbw = (cin + 15) >> 4, ntw = CT * nbw;
+    const float sx = p.qx[FROST_Q_SCALE];
+#pragma unroll
+    for (int i = 0; i < FTW; ++i) {
+      const int tt = w + 8 * i;
+      if (tt < ntw) {
+        const int a = tt / nbw, b = tt - a * nbw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = a * 16 + 4 * g + r, ci = b * 16 + j;
+          if (co < p.cout && ci < cin) atomicAdd(p.dwq + (int64_t)co * cin + ci, wacc[i][r] * sx);
+        }
+      }
+    }
+  }
   if (MODE == M_STATS) {
     if (defer) {
       const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
@@ -556,16 +668,16 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   }
 }
 
-template <int MODE, int WP, bool RES, bool FULLT>
+template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0>
 static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipStream_t s) {
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT, FTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
   auto occ_for = [](size_t bytes) {     // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
     static size_t key[2] = {(size_t)-1, (size_t)-1}; static int val[2] = {0, 0};
     for (int i = 0; i < 2; ++i) if (key[i] == bytes) return val[i];
     int occ = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT>, 512, bytes) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT, FTW>, 512, bytes) != hipSuccess || occ < 1) occ = 1;
     if (occ > 4) occ = 4;
     key[1] = key[0]; val[1] = val[0]; key[0] = bytes; val[0] = occ;
     return occ;
@@ -586,7 +698,7 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   static const int cs_mul = getenv("FROST_PW_CSMUL") ? atoi(getenv("FROST_PW_CSMUL")) : 1;
   if (cs_on && !q.io && grid * 2 <= 256 * occ_cache * cs_mul) { cs = (int)((256 * occ_cache * cs_mul) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
   q.csplit = cs; q.nbt = (int)grid;
-  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
+  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT, FTW>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
   return frost_check_launch("pw");
 }
 template <int MODE, int WP>
@@ -648,6 +760,60 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
   p.gl = 0; p.tile_bytes = BP * rowbytes;
   if (gl_on && p.nchunks == 1 && p.tile_bytes <= 32 * 1024 && (rowbytes & 7) == 0) { p.gl = 1; p.kstr = rowbytes; }
   p.inv_count = 1.0f / (float)npix;
+}
+
+// ---- fused backward (dc + dgrad + wgrad in one kernel), host side
+struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off; };
+static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
+  FusePlan f = {};
+  static const int on = getenv("FROST_PW_FUSE") ? atoi(getenv("FROST_PW_FUSE")) : 1;
+  if (!on || (cin & 7) || (cout & 7) || npix < BP || (npix % BP) != 0) return f;   // full 128-pixel tiles only (ragged tensors keep the three-kernel path)
+  const int cpad = round_up(cout, 16), CT = cpad / 16, KS = (cin + 63) / 64;
+  const int tile_bytes = BP * cin;
+  if (cin > 512 || tile_bytes > 32 * 1024) return f;                         // the DMA'd linear x tile (set_tiling's gl rule)
+  const int ntw = CT * ((cin + 15) / 16);
+  if (ntw > 88) return f;
+  f.wp = CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
+  f.ftw = ntw <= 16 ? 2 : (ntw <= 48 ? 6 : 11);
+  if ((f.wp == 4 && f.ftw != 2) || (f.wp == 2 && f.ftw == 2)) return f;     // instantiated pairs only
+  const size_t io_bytes = (size_t)2 * 256 * cout + 64;
+  const size_t res_bytes = (size_t)CT * KS * 1024 + (size_t)cpad * (FROST_COEF_ROWS + 1) * 4;
+  size_t lds = (size_t)2 * tile_bytes + 64 + io_bytes + res_bytes;
+  f.dxo_off = (int)((lds + 15) & ~(size_t)15);
+  f.lds = (size_t)f.dxo_off + (want_dx ? (size_t)256 * cin : 0);
+  if (f.lds > 160 * 1024) return f;
+  f.ok = 1;
+  return f;
+}
+extern "C" int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout) { return fuse_plan(npix, cin, cout, true).ok; }
+
+extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                                       const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout, float* coef,
+                                       const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc_scratch, uint16_t* dx,
+                                       int accumulate, float* dwq, void* stream) {
+  const FusePlan f = fuse_plan(npix, cin, cout, dx != nullptr);
+  FROST_REQUIRE(f.ok, "pw_bwd_fused: shape not supported by the fused kernel (ask frost_pw_bwd_fused_ok first)");
+  FROST_REQUIRE(dx == nullptr || wt_pack != nullptr, "pw_bwd_fused: the data gradient needs the transposed weight pack");
+  PwP p = {};
+  p.T = (const uint8_t*)x; p.cout = cout; p.cpad = round_up(cout, 16); p.wpack = (const uint8_t*)wq_pack;
+  p.wsum = wsum; p.qx = qrec_x; p.qy = qrec_y; p.qw = qrec_w; p.coef = coef; p.relu = relu; p.gout = gout; p.dc = dc_scratch;
+  set_tiling(p, npix, cin);
+  FROST_REQUIRE(p.gl, "pw_bwd_fused: linear tile staging unavailable");
+  const int CT = p.cpad / 16, WC = 8 / f.wp, MI = PW_MI(M_BDC, f.wp);
+  p.ngroups = (CT + WC * MI - 1) / (WC * MI);
+  p.mi_eff = (CT + p.ngroups * WC - 1) / (p.ngroups * WC);
+  const int64_t nfull = npix / BP;
+  PwP pf = p;
+  pf.g_bytes = 256 * cout; pf.o_bytes = 256 * cout; pf.io = 3; pf.io_bytes = 2 * pf.g_bytes + 64;
+  pf.wtp = (const uint8_t*)wt_pack; pf.KSd = (cout + 31) / 32; pf.dwq = dwq; pf.dx = dx; pf.accumulate = accumulate;
+  pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin;
+  hipStream_t s = as_stream(stream);
+  int rc;
+  if (f.wp == 8) rc = (f.ftw == 2) ? launch_pw3<M_BDC, 8, true, true, 2>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 8, true, true, 6>(pf, f.lds, 0, nfull, s);
+  else if (f.wp == 4) rc = launch_pw3<M_BDC, 4, true, true, 2>(pf, f.lds, 0, nfull, s);
+  else rc = (f.ftw == 6) ? launch_pw3<M_BDC, 2, true, true, 6>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 2, true, true, 11>(pf, f.lds, 0, nfull, s);
+  if (rc) return rc;
+  return 0;
 }
 
 extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,

@@ -25,14 +25,19 @@ __device__ __forceinline__ uint32_t pack_trunc_bf16(float lo, float hi) {   // e
 }
 
 __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
-                                                  int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
+                                                  int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD + KPIX * RSX];   // 26.6 KB: staging, then the 16 KB reduction tile
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nci = (cin + WT - 1) / WT;
   const int ntile = ((cout + WT - 1) / WT) * nci;
-  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  // XCD-aware block -> (tile, split) map (speed only): block b runs on XCD b % 8 and every output tile of one pixel split reads the SAME
+  // dc / x pixel blocks, so the tiles of a split are placed on one XCD and share that XCD's L2 (the plain map spread them over all eight
+  // L2s: each re-read of a pixel block by another tile was an HBM fetch -- counters showed 2.1x the algorithmic bytes)
+  int tile, split;
+  if (xmap) { const int b = blockIdx.x, xcd = b & 7, jb = b >> 3; split = xcd + 8 * (jb / ntile); tile = jb % ntile; }
+  else { tile = blockIdx.x % ntile; split = blockIdx.x / ntile; }
   const int co0 = (tile / nci) * WT, ci0 = (tile % nci) * WT;
   const int zpu = __float_as_int(qx[FROST_Q_ZP]);                  // zero point in the unsigned index domain
   const float zpf = (float)zpu;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict_
 #define RSX2 136   // 128 int8 + 8 bytes
 #endif
 __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
-                                                         int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit) {
+                                                         int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 51 KB
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD2;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
   const int qa = w >> 2, qb = w & 3;                                   // co half, ci quarter of this wave
   const int nci = (cin + BT - 1) / BT;
   const int ntile = ((cout + BT - 1) / BT) * nci;
-  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  int tile, split;                   // XCD-aware map, see k_pw_wgrad
+  if (xmap) { const int b = blockIdx.x, xcd = b & 7, jb = b >> 3; split = xcd + 8 * (jb / ntile); tile = jb % ntile; }
+  else { tile = blockIdx.x % ntile; split = blockIdx.x / ntile; }
   const int co0 = (tile / nci) * BT, ci0 = (tile % nci) * BT;
   const int zpu = __float_as_int(qx[FROST_Q_ZP]);
   const float zpf = (float)zpu;
@@ -227,6 +234,16 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
         }
       }
 }
+// split counts >= 8 become multiples of 8 so that the XCD-aware map above is a bijection (FROST_WG_XCD=0: the plain map, for A/B runs)
+static int xcd_round(int nsplit, int64_t nblk, int* xmap) {
+  static const int on = getenv("FROST_WG_XCD") ? atoi(getenv("FROST_WG_XCD")) : 1;
+  *xmap = 0;
+  if (nsplit < 8) return nsplit;
+  int r = (nsplit + 7) & ~7; if (r > nblk) r = nsplit & ~7;
+  if (r < 8) return nsplit;
+  *xmap = on;
+  return r;
+}
 extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int64_t npix, int cin, int cout,
                               float* dwq, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "pw_wgrad: channels must be multiples of 8");
@@ -235,7 +252,8 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
     const int ntile = ((cout + BT - 1) / BT) * ((cin + BT - 1) / BT);
     static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 256;     // one 8-wave workgroup per CU: the kernel runs beside the main stream (512 = full residency measured 0.6 % slower end to end, 128 also slower)
     int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(512), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
+    int xmap; nsplit = xcd_round(nsplit, nblk, &xmap);
+    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(512), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit, xmap);
     return frost_check_launch("pw_wgrad_big");
   }
   const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);
@@ -245,6 +263,7 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
   // every split ends with one fp32 atomic per output element: on low-resolution layers hundreds of splits hammering the same few
   // thousand addresses cost more than the GEMM (measured 56 us for a 7 MB layer), so a split keeps at least 4 pixel blocks
   if (nsplit > nblk / 4) nsplit = (int)(nblk / 4); if (nsplit < 1) nsplit = 1;
-  hipLaunchKernelGGL(k_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit);
+  int xmap; nsplit = xcd_round(nsplit, nblk, &xmap);
+  hipLaunchKernelGGL(k_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit, xmap);
   return frost_check_launch("pw_wgrad");
 }

@@ -24,6 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 
 
@@ -432,10 +433,11 @@ class Engine:
     def _conv_backward(self, l, x, y):
         self._ensure_grad(l)
         gout = y.grad
-        dc = torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
+        s = stream()
+        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout))
+        dc = None if fused else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
         if getattr(self, "_dbg", False):
             self._last_dc = dc
-        s = stream()
         if l.kind in ("pw", "stem"):
             dwq_final = l.dwq
             if l.kind == "stem":
@@ -444,6 +446,17 @@ class Engine:
             # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
             call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
                  prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+            if fused:
+                # dc pass + data gradient + weight gradient in one kernel: the dc tile never leaves LDS (layers with Cout*Cin <= ~19 k)
+                gx, acc = self._grad_slot(x) if x.needs_grad else (None, 0)
+                call("frost_pw_conv_bwd_fused", *args, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, ptr(l.dwq), s,
+                     prof=("pw_bwd_fused", x.numel + 2 * y.numel + (2 * x.numel if x.needs_grad else 0)))
+                if l.kind == "stem":
+                    l.dwq = dwq_final
+                    call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), s)
+                self._after_conv_backward(l, s)
+                y.grad = None
+                return
             call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                  prof=("pw_bwd_dc", x.numel + 4 * y.numel))
             if self._side is not None and (_WG_STREAM & 1):      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
@@ -489,12 +502,15 @@ class Engine:
                 gx, acc = self._grad_slot(x)
                 call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s,
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
+        self._after_conv_backward(l, s)
+        y.grad = None
+
+    def _after_conv_backward(self, l, s):
         if self.on_layer_grads is None:
             self._pending.append(l)        # single GPU: all layers finalized by one table launch at the end of the backward
         else:
             call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
                  l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
-        y.grad = None
 
 
 def grad_to_float(g, n, h, w, c):

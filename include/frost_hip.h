@@ -150,6 +150,18 @@ int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pac
 /* dWq[cout][cin] += sum_p dc[p][cout] * (x[p][cin]-zp) * s_x  (fp32 accumulate into dwq, must be zeroed) */
 int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int64_t npix, int cin, int cout,
                    float* dwq, void* stream);
+
+/* Fused pointwise backward for layers with Cout*Cin <= ~19 k (all 112^2 / 56^2 / 28^2 layers of FrostNet): the dc pass, the data gradient and
+ * the weight gradient of frost_pw_conv_bwd(pass 1, 2) + frost_pw_wgrad in ONE kernel -- the dc tile stays in LDS (the 2-byte dc tensor is
+ * neither written nor re-read: -6 B per output element of HBM traffic) and the weight gradient re-uses the staged x tile.
+ * replaces: the same autograd stages as frost_pw_conv_bwd / frost_pw_wgrad (conv_fused.py:130-157 backward through BN-train + ReLU + FQ masks).
+ * frost_pw_bwd_fused_ok() returns 1 when the shape is supported (npix a multiple of 128, LDS budget), else 0 (not an error code).
+ * dx may be NULL (no data gradient wanted, e.g. the stem); dwq (fp32 [cout][cin]) is accumulated with atomics and must be pre-zeroed. */
+int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout);
+int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
+                            const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout, float* coef,
+                            const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc_scratch, uint16_t* dx,
+                            int accumulate, float* dwq, void* stream);
 int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                       const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
                       const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream);
