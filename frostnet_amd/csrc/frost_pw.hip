@@ -45,6 +45,7 @@ struct PwP {
   const uint8_t* wtp; int KSd;       // bf16 transposed weight pack [cin tile][co step][lane][16 B], K steps of 32 output channels
   float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
   int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
+  int wtl_off, wtl_bytes;            // LDS-resident copy of the transposed weight pack
 };
 
 #define BP 128
@@ -191,7 +192,10 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   }
   if (RES && MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
   // the data gradient's K tail reads past a dc row (next row / other buffer / the 64-byte pad): stale LDS bytes x zero weights must not be NaN
-  if (FUSE) for (int i = tid; i < (p.io_bytes >> 4); i += 512) ((uint4*)(smem + xs_bytes))[i] = make_uint4(0, 0, 0, 0);
+  if (FUSE) {
+    for (int i = tid; i < (p.io_bytes >> 4); i += 512) ((uint4*)(smem + xs_bytes))[i] = make_uint4(0, 0, 0, 0);
+    if (p.dx) for (int i = tid; i < (p.wtl_bytes >> 4); i += 512) ((uint4*)(smem + p.wtl_off))[i] = ((const uint4*)p.wtp)[i];
+  }
   if (cres) __syncthreads();
   v4f wacc[FUSE ? FTW : 1];
 #pragma unroll
@@ -240,7 +244,11 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
       n_younger = nfull * NT * per;
     }
     if (n_younger > 16) n_younger = 16;
-    if (FUSE) n_younger = 0;        // the fused tail issues weight loads and dx stores of its own: drain everything (safe lower bound)
+    if (FUSE) {                     // after its DMA a wave issues only the dx copy-out (loads of the accumulate path are consumed, hence retired)
+      const int nu = p.dx ? (p.dx_bytes >> 10) : 0;
+      n_younger = (w < nu) ? (nu - w + 7) / 8 : 0;
+      if (n_younger > 16) n_younger = 16;
+    }
   }
   if (gl) {
     // K padding reads past a row's end (next row / next buffer / the 64-byte tail): harmless for int8 (zero weights), but a
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
               if (c0 + m < CTd) {
-                const v4i af = *(const v4i*)(p.wtp + ((((int64_t)(c0 + m) * p.KSd + ks) * 64 + lane) << 4));
+                const v4i af = *(const v4i*)(smem + p.wtl_off + ((((c0 + m) * p.KSd + ks) * 64 + lane) << 4));
                 dacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af), __builtin_bit_cast(v8bf, bf), dacc[m], 0, 0, 0);
               }
           }
@@ -763,10 +771,12 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
 }
 
 // ---- fused backward (dc + dgrad + wgrad in one kernel), host side
-struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off; };
+struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off, wtl_off, wtl_bytes; };
 static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   FusePlan f = {};
-  static const int on = getenv("FROST_PW_FUSE") ? atoi(getenv("FROST_PW_FUSE")) : 1;
+  // the fused kernel is built from the resident-weight, DMA-staged, LDS-I/O instance: any of those switched off (A/B runs) switches it off too
+  static const int on = (getenv("FROST_PW_FUSE") ? atoi(getenv("FROST_PW_FUSE")) : 1) && (getenv("FROST_PW_GL") ? atoi(getenv("FROST_PW_GL")) : 1) &&
+                        (getenv("FROST_PW_IO") ? atoi(getenv("FROST_PW_IO")) : 1) && (getenv("FROST_PW_RESMASK") ? strtol(getenv("FROST_PW_RESMASK"), nullptr, 0) != 0 : 1);
   if (!on || (cin & 7) || (cout & 7) || npix < BP || (npix % BP) != 0) return f;   // full 128-pixel tiles only (ragged tensors keep the three-kernel path)
   const int cpad = round_up(cout, 16), CT = cpad / 16, KS = (cin + 63) / 64;
   const int tile_bytes = BP * cin;
@@ -780,7 +790,9 @@ static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   const size_t res_bytes = (size_t)CT * KS * 1024 + (size_t)cpad * (FROST_COEF_ROWS + 1) * 4;
   size_t lds = (size_t)2 * tile_bytes + 64 + io_bytes + res_bytes;
   f.dxo_off = (int)((lds + 15) & ~(size_t)15);
-  f.lds = (size_t)f.dxo_off + (want_dx ? (size_t)256 * cin : 0);
+  f.wtl_off = f.dxo_off + (want_dx ? 256 * cin : 0);
+  f.wtl_bytes = want_dx ? ((cin + 15) / 16) * ((cout + 31) / 32) * 1024 : 0;
+  f.lds = (size_t)f.wtl_off + f.wtl_bytes;
   if (f.lds > 160 * 1024) return f;
   f.ok = 1;
   return f;
@@ -806,7 +818,7 @@ extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, con
   PwP pf = p;
   pf.g_bytes = 256 * cout; pf.o_bytes = 256 * cout; pf.io = 3; pf.io_bytes = 2 * pf.g_bytes + 64;
   pf.wtp = (const uint8_t*)wt_pack; pf.KSd = (cout + 31) / 32; pf.dwq = dwq; pf.dx = dx; pf.accumulate = accumulate;
-  pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin;
+  pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin; pf.wtl_off = f.wtl_off; pf.wtl_bytes = f.wtl_bytes;
   hipStream_t s = as_stream(stream);
   int rc;
   if (f.wp == 8) rc = (f.ftw == 2) ? launch_pw3<M_BDC, 8, true, true, 2>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 8, true, true, 6>(pf, f.lds, 0, nfull, s);
