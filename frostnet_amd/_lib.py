@@ -111,6 +111,10 @@ _PROTOS = {
     "frost_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
     "frost_head_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "frost_gradboost_step": [P, I, L, P, P, P, P, P],
+    "frost_conv_finalize_converted": [P, P, P, P, P, P, I, P, P, P],
+    "frost_add_qnnpack": [P, P, P, P, L, P, P, P],
+    "frost_avgpool_q": [P, I, I, I, P, P],
+    "frost_classifier_q": [P, P, P, P, I, I, I, P, P, P, P],
 }
 SYMBOLS = sorted(list(_PROTOS) + ["frost_last_error"])
 

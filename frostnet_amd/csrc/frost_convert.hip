@@ -1,0 +1,122 @@
+// Converted int8 inference: what `torch.quantization.convert(model.eval())` + the QNNPACK engine compute
+// (Classification/evaluate.py:130-134), restated in oracle/frost_oracle.py::converted_forward and pinned bit-exactly to the reference by
+// tests/golden/g9_convert_*.npz.  The convolutions reuse the int8-MFMA / LDS depthwise EMIT kernels (mode 2: integer bias add + fp32
+// requantisation in the epilogue); this file holds the pieces that differ from the fake-quant eval graph:
+//   * the per-layer requantisation coefficients (BN folded with the RUNNING statistics, bias quantised to int32 at scale s_x*s_w),
+//   * QNNPACK's integer fixed-point add (FloatFunctional.add -> quantized::add),
+//   * the quantised adaptive average pool (mean index rounded half-to-even, input qparams kept),
+//   * the classifier as an exact int32 GEMV with requantisation.
+#include "frost_common.h"
+
+// replaces: nniqat.ConvBn(ReLU)2d.to_float -> fuse_conv_bn_weights (bias) + nnq.Conv2d.from_float + aten qconv.cpp (QNNPACK path):
+//   bias_q = nearbyint(b_fold / (s_x*s_w)),  requant scale = s_w*s_x/s_y  (all fp32, this op order).
+// coef row A <- requantisation scale, row B <- bias_q (int32 bits).  gamma == NULL: plain conv with bias `beta` (the classifier).
+__global__ __launch_bounds__(256) void k_finalize_converted(const float* qx, const float* qw, const float* gamma, const float* beta,
+                                                            const float* rmean, const float* rvar, int cout, int cpad, float* coef, const float* qy) {
+  const float sx = qx[FROST_Q_SCALE], sw = qw[FROST_Q_SCALE], sy = qy[FROST_Q_SCALE];
+  const float rs = (sw * sx) / sy;
+  const float bscale = sx * sw;
+  for (int c = threadIdx.x; c < cpad; c += 256) {
+    float A = 0.0f; int bq = 0;
+    if (c < cout) {
+      float b;
+      if (gamma) { const float rstd = 1.0f / sqrtf(rvar[c] + FROST_BN_EPS); b = (0.0f - rmean[c]) * rstd * gamma[c] + beta[c]; }
+      else b = beta ? beta[c] : 0.0f;
+      bq = (int)rintf(b / bscale);
+      A = rs;
+    }
+    coef[FROST_COEF_A * cpad + c] = A;
+    coef[FROST_COEF_B * cpad + c] = __int_as_float(bq);
+  }
+}
+extern "C" int frost_conv_finalize_converted(const float* qrec_x, const float* qrec_w, const float* gamma, const float* beta,
+                                             const float* rmean, const float* rvar, int cout, float* coef, const float* qrec_y, void* stream) {
+  const int cpad = round_up(cout, 16);
+  hipLaunchKernelGGL(k_finalize_converted, dim3(1), dim3(256), 0, as_stream(stream), qrec_x, qrec_w, gamma, beta, rmean, rvar, cout, cpad, coef, qrec_y);
+  return frost_check_launch("conv_finalize_converted");
+}
+
+// replaces: quantized::add on the QNNPACK engine (pytorch_qnnp_create_add_nc_q8 + q8vadd micro-kernel): integer fixed point.
+//   a_mul = lrint(s_a/s_y * 2^shift), shift = 21 - exponent(max(s_a/s_y, s_b/s_y));
+//   acc = a*a_mul + b*b_mul - (a_mul*zp_a + b_mul*zp_b);  y = clamp((acc >> shift) + (rem > thr) + zp_y, 0, 255), rem = (acc & mask) - (acc < 0)
+__global__ __launch_bounds__(256) void k_add_qnnpack(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b, const float* qb,
+                                                     int64_t n, const float* qy, int8_t* __restrict__ y) {
+  const float sa = qa[FROST_Q_SCALE], sb = qb[FROST_Q_SCALE], sy = qy[FROST_Q_SCALE];
+  const int zpa = __float_as_int(qa[FROST_Q_ZP]), zpb = __float_as_int(qb[FROST_Q_ZP]), zpy = __float_as_int(qy[FROST_Q_ZP]);
+  const float aos = sa / sy, bos = sb / sy;
+  const float mx = fmaxf(aos, bos);
+  const int shift = 21 - (int)(((uint32_t)__float_as_int(mx) >> 23) - 127u);
+  const float two = __int_as_float((127 + shift) << 23);
+  const int amul = (int)rintf(aos * two), bmul = (int)rintf(bos * two);
+  const int zpp = -(amul * zpa + bmul * zpb);
+  const int mask = (1 << shift) - 1, thr = mask >> 1;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t va = ((const uint32_t*)a)[i] ^ 0x80808080u, vb = ((const uint32_t*)b)[i] ^ 0x80808080u;   // offset-binary -> unsigned index
+    uint32_t o = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int acc = zpp + (int)((va >> (8 * e)) & 255u) * amul + (int)((vb >> (8 * e)) & 255u) * bmul;
+      const int rem = (acc & mask) - (acc < 0 ? 1 : 0);
+      acc = (acc >> shift) + (rem > thr ? 1 : 0) + zpy;
+      acc = min(max(acc, 0), 255);
+      o |= (uint32_t)acc << (8 * e);
+    }
+    ((uint32_t*)y)[i] = o ^ 0x80808080u;
+  }
+}
+extern "C" int frost_add_qnnpack(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y,
+                                 int8_t* y, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "add_qnnpack: n must be a multiple of 4");
+  int64_t g = (n / 4 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_add_qnnpack, dim3((unsigned)g), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, qrec_y, y);
+  return frost_check_launch("add_qnnpack");
+}
+
+// replaces: quantized adaptive_avg_pool2d(1): out index = rint_half_even(sum q / hw), qparams of the input.  pooled: int32 [n][c]
+__global__ __launch_bounds__(256) void k_avgpool_q(const int8_t* __restrict__ x, int n, int hw, int c, int32_t* __restrict__ pooled) {
+  const int64_t tot = (int64_t)n * c;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c); const int64_t in = i / c;
+    const int8_t* p = x + in * hw * c + ch;
+    int s = 0;
+    for (int t = 0; t < hw; ++t) s += (int)p[(int64_t)t * c] + 128;
+    int q = s / hw; const int r2 = 2 * (s - q * hw);             // exact round-half-even of s / hw
+    if (r2 > hw || (r2 == hw && (q & 1))) ++q;
+    pooled[i] = q;
+  }
+}
+extern "C" int frost_avgpool_q(const int8_t* x, int n, int hw, int c, int32_t* pooled, void* stream) {
+  int64_t g = ((int64_t)n * c + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_avgpool_q, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x, n, hw, c, pooled);
+  return frost_check_launch("avgpool_q");
+}
+
+// replaces: quantized::conv2d of the 1x1 classifier (nnq.Conv2d.from_float of nnqat.Conv2d, frostnet.py:298): one wave per output,
+// exact int32 accumulation, integer bias, fp32 requantisation; writes the dequantised logits (DeQuantStub) and, optionally, the indices.
+__global__ __launch_bounds__(256) void k_classifier_q(const int32_t* __restrict__ pooled, const float* qx, const int8_t* __restrict__ wq, const float* coef,
+                                                      int cpad, int n, int c, int cout, const float* qy, float* __restrict__ logits, uint8_t* __restrict__ idx) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n * cout) return;
+  const int img = wave / cout, co = wave - img * cout;
+  const int zpx = __float_as_int(qx[FROST_Q_ZP]);
+  int acc = 0;
+  for (int k = lane; k < c; k += 64) acc += (pooled[(int64_t)img * c + k] - zpx) * (int)wq[(int64_t)co * c + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    const float rs = coef[FROST_COEF_A * cpad + co]; const int bq = __float_as_int(coef[FROST_COEF_B * cpad + co]);
+    const int zpy = __float_as_int(qy[FROST_Q_ZP]);
+    int q = (int)rintf((float)(acc + bq) * rs) + zpy;
+    q = min(max(q, 0), 255);
+    logits[(int64_t)img * cout + co] = (float)(q - zpy) * qy[FROST_Q_SCALE];
+    if (idx) idx[(int64_t)img * cout + co] = (uint8_t)q;
+  }
+}
+extern "C" int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                                  const float* qrec_y, float* logits, uint8_t* idx, void* stream) {
+  const int64_t waves = (int64_t)n * cout;
+  hipLaunchKernelGGL(k_classifier_q, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), pooled, qrec_x, wq, coef, round_up(cout, 16),
+                     n, c, cout, qrec_y, logits, idx);
+  return frost_check_launch("classifier_q");
+}

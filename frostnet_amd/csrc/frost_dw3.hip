@@ -41,6 +41,7 @@ struct Dw3P {
   uint8_t* stats; float* coef; const float* qy; int relu; int8_t* y;
   const uint16_t* gout; uint16_t* dc; float* dwq; uint16_t* dx; int accumulate;
   int tiles_x, tiles_y, ncb, ngroups; int64_t nunits, ntiles; float inv_count;
+  int cvt;       // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation), see frost_convert.hip
   int xmap;      // XCD-aware block -> (channel block, tile range) map, see dw_block_map
 };
 
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         }
       }
     }
+    if (MODE == D_EMIT && p.cvt) y_inv = 1.0f;        // row A already is the requantisation scale s_x*s_w/s_y
     if (MODE == D_BRED || MODE == D_BDC) {   // STE pass window in t = y/scale: t_lo < t <= t_hi (see frost_pw.hip)
       const float hi0 = 255.5f - (float)zpy;
       t_hi = ((255 - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
           if (valid) { t1 += vi; t2 = fma((double)v, (double)v, t2); tmn = min(tmn, vi); tmx = max(tmx, vi); }
         } else if (MODE == D_EMIT) {
           // q = clamp(rint(relu(y)/s) + zp, 0, 255): v_cvt_pk_u8_f32 saturates at both ends while converting
-          const float yv = fmaf(cA, v, cB);
+          const float yv = p.cvt ? (float)(acc[o][r] + __float_as_int(cB)) * cA : fmaf(cA, v, cB);
           aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf, 0, 0u) ^ 0x80u) & 255u);
         } else {
           const float gq = bf2f(*(const uint16_t*)(aux + (lp * CBW + L.lc) * 2));
@@ -694,7 +696,7 @@ extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
-  p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y;
+  p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2);
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), mode == 0 ? 0 : 1, as_stream(stream));
 }
 extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,

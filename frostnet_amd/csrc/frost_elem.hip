@@ -164,7 +164,12 @@ extern "C" int frost_dequant_act(const int8_t* qv, int64_t n, const float* qrec,
 // ------------------------------------------------------------------------------------------------ weight prep
 __device__ __forceinline__ float w_scaled(const FrostWDesc& d, int co, int rest) {
   float wv = d.w[(int64_t)co * d.cin_g * d.kk + rest];
-  if (d.gamma) { float sf = d.gamma[co] / sqrtf(d.rvar[co] + FROST_BN_EPS); wv = wv * sf; }
+  if (d.gamma) {
+    // QAT forward: scale_factor = gamma / sqrt(running_var + eps) (conv_fused.py:133-135); convert: gamma * rsqrt(running_var + eps)
+    // (torch.nn.utils.fusion.fuse_conv_bn_weights) -- the same number up to one rounding, kept apart so that both modes are bit-faithful
+    const float sf = d.reserved0 ? d.gamma[co] * (1.0f / sqrtf(d.rvar[co] + FROST_BN_EPS)) : d.gamma[co] / sqrtf(d.rvar[co] + FROST_BN_EPS);
+    wv = wv * sf;
+  }
   return wv;
 }
 __global__ __launch_bounds__(256) void k_wprep_minmax(const FrostWDesc* descs) {

@@ -46,6 +46,7 @@ struct PwP {
   float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
   int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
   int wtl_off, wtl_bytes;            // LDS-resident copy of the transposed weight pack
+  int cvt;                           // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation)
 };
 
 #define BP 128
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD && p.qw) sw = p.qw[FROST_Q_SCALE];
   if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]); }
+  if (MODE == M_EMIT && p.cvt) y_inv = 1.0f;           // row A already is the requantisation scale s_x*s_w/s_y, row B carries the int32 bias bits
   float t_lo = 0.0f, t_hi = 0.0f;            // STE pass window in t = y/scale:  t_lo < t <= t_hi
   if (MODE == M_BRED || MODE == M_BDC) {
     const int zpy = __float_as_int(p.qy[FROST_Q_ZP]);
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
               for (int r = 0; r < 4; ++r) {
                 // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
                 // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
-                const float yv = fmaf(A[r], (float)acci[m][t][r], B[r]);
+                const float yv = p.cvt ? (float)(acci[m][t][r] + __float_as_int(B[r])) * A[r] : fmaf(A[r], (float)acci[m][t][r], B[r]);
                 packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
               }
               if (o_lds) { if (chok) *(uint32_t*)(gcur + prow * p.cout + ch0) = packed ^ 0x80808080u; }
@@ -838,6 +840,7 @@ extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int
   p.wsum = wsum; p.qx = qrec_x; p.qy = qrec_y; p.coef = (float*)coef; p.stats = (uint8_t*)stats; p.relu = relu; p.y = y;
   set_tiling(p, npix, cin);
   if (mode == 0) return dispatch_pw<M_STATS>(p, as_stream(stream));
+  p.cvt = (mode == 2);
   return dispatch_pw<M_EMIT>(p, as_stream(stream));
 }
 

@@ -136,6 +136,7 @@ class ConvLayer:
         d.wt_pack = self.wt_pack.data_ptr() if self.wt_pack is not None else None
         d.cout, d.cin_g, d.kk, d.kind = self.cout, self.cin_g, self.kk, self.KIND_ID[self.kind]
         d.cpad, d.kpad = self.cpad, self.kpad
+        d.reserved0 = 1 if getattr(self, "fold_rsqrt", False) else 0      # convert-time BN fold (gamma * rsqrt) instead of the QAT one
         return d
 
 
@@ -233,7 +234,7 @@ class Engine:
         the activation bytes it must move at 1 B/element (+ the packed weights once)."""
         st = ptr(l.stats)
         nb = x.numel + l.wq_pack.numel() + (y.numel if y is not None else 0)
-        tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)
+        tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)      # mode 2 = emit with the converted-inference requantisation
         if l.kind in ("pw", "stem"):
             call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
                  ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
@@ -312,6 +313,49 @@ class Engine:
         self.last_raw = raw              # pre-fake-quant classifier output (tests: the north-star 1e-3 comparison point)
         call("frost_fake_quant_f32", ptr(raw), raw.numel(), ptr(l.qy), 0, 255, ptr(logits), None, stream())
         self.tape.append(("head", l, x, pooled, raw, drop_mask))
+        return logits
+
+    # ------------------------------------------------------------------------------------------ converted int8 inference
+    def prepare_converted(self, observe=True):
+        """torch.quantization.convert: fold BN with the running statistics (gamma * rsqrt(var + eps)), run every weight FakeQuantize once
+        more on the folded weight (the reference converts with observers still enabled, Classification/evaluate.py:130) and keep the
+        resulting int8 packs.  After this the weights are frozen: converted forwards do not touch them again."""
+        for l in self.layers:
+            l.fold_rsqrt = True
+        self._table = None
+        self._ensure_tables()
+        call("frost_weight_prep", ptr(self._table), len(self.layers), self._max_elems, self.rule127, 1 if observe else 0, stream())
+
+    def conv_converted(self, l, x):
+        """quantized::conv2d(_relu) of the converted model: integer bias + fp32 requantisation in the emit epilogue (mode 2)."""
+        pad = (l.k - 1) // 2
+        ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
+        if l.kind == "stem":
+            xc = self.new_act(x.n, ho, wo, 40, x.q)
+            call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream())
+            x = xc
+        y = self.new_act(x.n, ho, wo, l.cout, l.qy)
+        call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
+             ptr(l.qy), stream())
+        self._conv_launch(l, x, 2, y)
+        if getattr(self, "trace", None) is not None:
+            self.trace.append((l.name, y))
+        return y
+
+    def add_converted(self, a, b, q):
+        y = self.new_act(a.n, a.h, a.w, a.c, q)
+        call("frost_add_qnnpack", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream())
+        return y
+
+    def head_converted(self, l, x):
+        n, c = x.n, x.c
+        pooled = torch.empty(n, c, dtype=torch.int32, device=self.device)
+        call("frost_avgpool_q", ptr(x.buf), n, x.h * x.w, c, ptr(pooled), stream())
+        call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), None, ptr(l.bias), None, None, l.cout, ptr(l.coef), ptr(l.qy), stream())
+        logits = torch.empty(n, l.cout, dtype=torch.float32, device=self.device)
+        self.last_logit_idx = torch.empty(n, l.cout, dtype=torch.uint8, device=self.device)
+        call("frost_classifier_q", ptr(pooled), ptr(x.q), ptr(l.wq_pack), ptr(l.coef), n, c, l.cout, ptr(l.qy), ptr(logits),
+             ptr(self.last_logit_idx), stream())
         return logits
 
     # ------------------------------------------------------------------------------------------ backward

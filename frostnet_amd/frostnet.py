@@ -242,6 +242,15 @@ class FrostNet(_FrostBase):
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
 
+    def hip_convert(self):
+        """Device counterpart of `torch.quantization.convert(model.eval(), inplace=True)` (Classification/evaluate.py:130): the QAT-prepared
+        model on the HIP device switches to converted int8 inference semantics (frostnet_amd.runner.FrostRunner.convert)."""
+        if not self._is_qat_prepared():
+            raise RuntimeError("hip_convert needs the QAT-prepared model (fuse_model + prepare_qat), like torch.quantization.convert")
+        self.eval()
+        self.hip_runner().convert()
+        return self
+
     def hip_infer_bf16(self, x):
         """bf16 inference of the float (un-fused, not QAT-prepared) model on the HIP kernels (BASELINE.json config c2):
         eval-mode BatchNorm folded, NHWC bf16 activations, fp32 accumulation.  See frostnet_amd/infer.py."""

@@ -247,6 +247,43 @@ class FrostRunner:
             raise RuntimeError("backward through a FrostNet forward whose tape is gone: the HIP path keeps ONE recorded forward per model "
                                "(a later forward replaced it, or backward already ran). Run forward -> backward pairs one at a time.")
 
+    # ------------------------------------------------------------------------------------------ converted int8 inference
+    def convert(self):
+        """`torch.quantization.convert(model.eval())` on the device (Classification/evaluate.py:130-134): from now on forward() computes what
+        the converted model computes on the QNNPACK engine -- int8 weights frozen at convert time, integer bias, fp32 requantisation,
+        QNNPACK's fixed-point add, rounding average pool -- instead of the fake-quant eval graph (whose observers keep moving and whose
+        pooled features are not re-quantised; the two differ by 8-25 % of the activations' indices, see tests/test_gpu_convert.py)."""
+        if self.cls is None:
+            raise NotImplementedError("convert() is implemented for the classification model")
+        with torch.cuda.device(self.device):
+            self.E.prepare_converted(observe=True)         # per-site observer flags still decide on the device
+        self.converted = True
+        return self
+
+    def _forward_converted(self, x, taps=None):
+        E = self.E
+        if x.dtype != torch.float32:
+            x = x.float()
+        a = E.quantize_input(x, self.q_in, observe=False)
+        a = E.conv_converted(self.stem, a)
+        for d in self.blocks:
+            inp, out = a, a
+            if d["conv1"] is not None:
+                if d["squeeze"] is not None:
+                    out = E.cat(E.conv_converted(d["squeeze"], inp), inp, d["q_cat"], observe=False)
+                out = E.conv_converted(d["conv1"], out)
+            out = E.conv_converted(d["conv2"], out)
+            out = E.conv_converted(d["reduce"], out)
+            if d["q_add"] is not None:
+                out = E.add_converted(inp, out, d["q_add"])
+            a = out
+            if taps is not None:
+                taps.append(a)
+        a = E.conv_converted(self.last, a)
+        logits = E.head_converted(self.cls, a)
+        E.tape = []
+        return logits
+
     def _check_input(self, x):
         if x.device != self.device:
             raise RuntimeError(f"input is on {x.device} but the model's parameters (and its HIP runner) are on {self.device}")
@@ -257,6 +294,11 @@ class FrostRunner:
     def forward(self, x):
         self._check_input(x)
         training = self.model.training
+        if getattr(self, "converted", False):
+            if training:
+                raise RuntimeError("this model was converted to int8 inference (hip_convert): it cannot be trained; rebuild the QAT model")
+            with torch.cuda.device(self.device):
+                return self._forward_converted(x)
         with torch.cuda.device(self.device):          # kernels launch on the CURRENT device's stream: make it the model's
             if training and torch.is_grad_enabled():
                 return _QATFunction.apply(self._params[0], x, self)

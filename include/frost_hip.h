@@ -96,7 +96,9 @@ typedef struct FrostWDesc {
   float* minmax2;        /* scratch {min,max}                                               */
   uint16_t* wt_pack;     /* bf16 transposed pack for dgrad (pw only, may be NULL)           */
   int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem(3x3 dense cin<=4), 3 classifier */
-  int32_t cpad, kpad, reserved0, reserved1;
+  int32_t cpad, kpad;
+  int32_t reserved0;   /* fold mode: 0 = gamma / sqrt(var+eps) (QAT forward), 1 = gamma * rsqrt(var+eps) (convert: fuse_conv_bn_weights) */
+  int32_t reserved1;
 } FrostWDesc;
 int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe, void* stream);
 
@@ -278,6 +280,22 @@ typedef struct FrostOptHyper {
  * memory so a captured hipGraph picks up new lr / bias corrections / offsets without re-capture. */
 int frost_gradboost_step(const FrostOptTensor* table, int ntensors, int64_t max_n, const FrostOptHyper* hyper,
                          const float* noise, const float* coin, const int64_t* prefix, void* stream);
+
+/* ---- converted int8 inference ------------------------------------------------------------------
+ * replaces: torch.quantization.convert(model.eval()) + the QNNPACK kernels (Classification/evaluate.py:130-134).  The convolutions are
+ * frost_pw_conv_fwd / frost_dw_conv_fwd with mode 2 (integer bias add + fp32 requantisation: y = clamp(rint(float(acc + b_q) * rs) + zp));
+ * their coefficient rows come from frost_conv_finalize_converted (BN folded with the running statistics, bias at scale s_x*s_w);
+ * weights are prepared once by frost_weight_prep with FrostWDesc.reserved0 = 1. */
+int frost_conv_finalize_converted(const float* qrec_x, const float* qrec_w, const float* gamma, const float* beta,
+                                  const float* rmean, const float* rvar, int cout, float* coef, const float* qrec_y, void* stream);
+/* replaces: quantized::add (QNNPACK q8add, integer fixed point) -- FloatFunctional.add of a converted model (frostnet.py:142) */
+int frost_add_qnnpack(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y,
+                      int8_t* y, void* stream);
+/* replaces: adaptive_avg_pool2d(1) on a quantised tensor: int32 index rint_half_even(mean), input qparams kept (frostnet.py:296) */
+int frost_avgpool_q(const int8_t* x, int n, int hw, int c, int32_t* pooled, void* stream);
+/* replaces: quantized::conv2d of the classifier (frostnet.py:298) + DeQuantStub: exact int32 GEMV, coefficient rows as above */
+int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                       const float* qrec_y, float* logits, uint8_t* idx, void* stream);
 
 #ifdef __cplusplus
 }

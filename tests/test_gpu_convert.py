@@ -1,0 +1,70 @@
+"""Converted int8 inference on the device against fixtures produced by the REFERENCE: torch.quantization.convert(model.eval())
+of the reference's QAT FrostNet, executed by the QNNPACK engine (tools/gen_golden.py g9; Classification/evaluate.py:126-134).
+The HIP path (model.hip_convert(): int8-MFMA / LDS depthwise convs with integer bias + fp32 requantisation, QNNPACK's fixed-point add,
+rounding average pool, exact int32 classifier) is held to those fixtures INDEX FOR INDEX."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frost_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("mode", ["small", "large"])
+def test_hip_convert_matches_reference_converted_model(golden, mode):
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F
+    from test_oracle_golden import convert_case
+    g = golden(f"g9_convert_{mode}")
+    cfg, P, qs, x = convert_case(g, mode)
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("enabled") or k.endswith("eps") for k in missing), (missing, unexpected)
+    model.cuda()
+    model.hip_convert()
+    assert model.training is False
+    taps = []
+    r = model.hip_runner()
+    with torch.no_grad():
+        y = r._forward_converted(x.cuda(), taps)
+        y2 = model(x.cuda())
+    torch.cuda.synchronize()
+    names = [f"layer{li + 1}.{bi}" for li, blocks in enumerate(cfg["layers"]) for bi in range(len(blocks))]
+    worst = 0.0
+    for name, a in zip(names, taps):
+        key = "blk/" + name.replace(".", "/")
+        q = r.qa.get(a.q)
+        assert [np.float32(q["scale"]), q["zero_point"]] == [np.float32(g[key + "/qp"][0]), int(g[key + "/qp"][1])], name
+        idx = a.indices().cpu().numpy()
+        ref = g[key + "/idx"]
+        mine = idx if idx.size <= 40000 else idx[:, :8, :6, :6]
+        flips = float((mine != ref).mean())
+        worst = max(worst, flips)
+        assert flips == 0.0, (name, flips, int(np.abs(mine.astype(np.int16) - ref.astype(np.int16)).max()))
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(idx).tobytes())) == g[key + "/crc"], name      # the WHOLE tensor, bit for bit
+    assert np.array_equal(y.cpu().numpy(), g["logits"])                   # dequantised logits identical
+    assert torch.equal(y, y2)                                             # model(x) is the converted path now
+    with pytest.raises(RuntimeError, match="converted"):
+        model.train()(x.cuda())
+    # and the statement behind this mode: the fake-quant eval graph is NOT the converted model
+    m2 = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+    F.qat_prepare(m2, version=0)
+    m2.load_state_dict(sd, strict=False)
+    m2.cuda().eval()
+    m2.apply(torch.quantization.disable_observer)
+    with torch.no_grad():
+        y_fq = m2(x.cuda())
+    s_y = float(g["cls_qp"][0])
+    diff = float(((y_fq - y).abs() > 0.5 * s_y).float().mean())
+    print(f"[{mode}] converted logits identical to the reference; fake-quant eval logits differ from them on {diff:.1%} of the entries")

@@ -335,3 +335,33 @@ def test_g8_features(golden):
         assert list(f.shape) == g[f"f{i}_shape"].tolist()
         np.testing.assert_allclose(float(f.double().abs().sum()), float(g[f"f{i}_abssum"]), rtol=1e-5)
         np.testing.assert_allclose(f[0, :8, :4, :4].numpy(), g[f"f{i}_crop"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ G9 converted int8 inference
+def convert_case(g, mode):
+    """State of the reference's QAT model right before torch.quantization.convert (weights by seed, everything else from the fixture)."""
+    B, R, tseed, xseed, wseed = [int(v) for v in g["spec"]]
+    cfg = O.net_cfg(mode, 1.0)
+    P, _ = O.make_state(O.float_state_spec(cfg), wseed, True)
+    qs = O.QState(unpack_state(g, "pre_sd/"))
+    return cfg, P, qs, T(O.synth((B, 3, R, R), xseed))
+
+
+@pytest.mark.parametrize("mode", ["small", "large"])
+def test_g9_converted_inference(golden, mode):
+    """oracle.converted_forward (integer restatement of convert + QNNPACK kernels) == the reference's converted model, index for index:
+    every block output (CRC of the uint8 indices + stored indices), qparams, and the dequantised logits -- bit-exact."""
+    import zlib
+    g = golden(f"g9_convert_{mode}")
+    cfg, P, qs, x = convert_case(g, mode)
+    trace = []
+    with torch.no_grad():
+        y = O.converted_forward(P, qs, cfg, x, True, trace)
+    for name, q, s, z in trace:
+        key = "blk/" + name.replace(".", "/")
+        assert [s, float(z)] == g[key + "/qp"].tolist(), name
+        idx = q.to(torch.uint8).numpy()
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(idx).tobytes())) == g[key + "/crc"], name
+        ref = g[key + "/idx"]
+        assert np.array_equal(idx if idx.size <= 40000 else idx[:, :8, :6, :6], ref), name
+    assert np.array_equal(y.numpy(), g["logits"])

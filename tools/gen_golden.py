@@ -394,6 +394,44 @@ def g7_scalars():
     save("g7_scalars", **out)
 
 
+# ------------------------------------------------------------------------------------------ G9
+def g9_convert():
+    """Converted int8 inference: the reference's deployment artefact.  Flow of Classification/evaluate.py:126-134 -- QAT-prepared model
+    (two train-mode forwards populate BN statistics and observers), eval(), torch.quantization.convert, run -- executed by the QNNPACK
+    engine.  Stored: the non-parameter QAT state BEFORE convert, every block output (uint8 indices; CRC + crop for the large net), logits."""
+    import copy
+    _, reg = refshim.load_frostnet()
+    torch.backends.quantized.engine = "qnnpack"
+    for mode, R, B in (("small", 64, 2), ("large", 224, 1)):
+        net = reg[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+        load_synth(net, 5000)
+        refshim.qat_prepare(net, version=0)
+        net.train()
+        with torch.no_grad():
+            for s_ in range(2):
+                net(T(synth((B, 3, R, R), 520 + s_)))
+        net.eval()
+        out = dict(spec=np.array([B, R, 520, 529, 5000]))
+        out.update(sd_np(net.state_dict(), "pre_sd/"))
+        cv = copy.deepcopy(net)
+        torch.ao.quantization.convert(cv.eval(), inplace=True)
+        taps = {}
+        for ln in ("layer1", "layer2", "layer3", "layer4", "layer5"):
+            for bi, b in enumerate(getattr(cv, ln)):
+                b.register_forward_hook(lambda m, i, o, name=f"{ln}.{bi}": taps.__setitem__(name, o))
+        with torch.no_grad():
+            y = cv(T(synth((B, 3, R, R), 529)))
+        for name, o in taps.items():
+            idx = o.int_repr().numpy()
+            key = "blk/" + name.replace(".", "/")
+            out[key + "/qp"] = np.array([o.q_scale(), o.q_zero_point()], dtype=np.float64)
+            out[key + "/crc"] = crc(idx)
+            out[key + "/idx"] = idx if idx.size <= 40000 else idx[:, :8, :6, :6].copy()
+        out["logits"] = y
+        out["cls_qp"] = np.array([float(cv.classifier[2].scale), int(cv.classifier[2].zero_point)], dtype=np.float64)
+        save(f"g9_convert_{mode}", **out)
+
+
 # ------------------------------------------------------------------------------------------ G8
 def g8_features():
     feat = refshim.load_features()
@@ -414,8 +452,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert)
     for w in which:
         fns[w]()
