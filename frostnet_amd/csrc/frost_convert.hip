@@ -120,3 +120,107 @@ extern "C" int frost_classifier_q(const int32_t* pooled, const float* qrec_x, co
                      n, c, cout, qrec_y, logits, idx);
   return frost_check_launch("classifier_q");
 }
+
+// ------------------------------------------------------------------------------------------------ quantizable h-swish
+// replaces: the reference's quantizable hard-swish (Classification/models/imagenet/mobilenetv3.py:43-56, `_Hswish`):
+//   t   = relu6(add_scalar(x, 3))                            -> observed: prepare_qat hangs a FakeQuantize on nn.ReLU6
+//   out = FloatFunctional.mul(x, t)                           -> observed: activation_post_process of quant_mul1
+//   y   = mul_scalar(out, 1/6)                                -> unobserved: same indices, scale * (1/6)
+// x is a fake-quantised activation, i.e. at most 256 distinct values: both observers' min/max are taken over the indices that
+// are PRESENT, the forward is a 256-entry byte table, the backward a 256-entry float table (STE mask x f'(x) x 1/6).
+__global__ __launch_bounds__(256) void k_hsw_presence(const int8_t* __restrict__ x, int64_t n, uint32_t* __restrict__ present) {
+  __shared__ uint32_t bits[8];
+  if (threadIdx.x < 8) bits[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t v = ((const uint32_t*)x)[i] ^ 0x80808080u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const uint32_t b = (v >> (8 * e)) & 255u; loc[b >> 5] |= 1u << (b & 31u); }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) if (loc[k]) atomicOr(&bits[k], loc[k]);
+  __syncthreads();
+  if (threadIdx.x < 8 && bits[threadIdx.x]) atomicOr(&present[threadIdx.x], bits[threadIdx.x]);
+}
+// one block of 256 threads: thread i = input index i.  lut layout: [0,256) forward bytes (offset-binary), then 256 floats (backward factor)
+__device__ __forceinline__ void hsw_block_minmax(float v, bool here, float* slo, float* shi, float& lo, float& hi) {
+  const int i = threadIdx.x;
+  lo = wave_min(here ? v : INFINITY); hi = wave_max(here ? v : -INFINITY);
+  __syncthreads();
+  if ((i & 63) == 0) { slo[i >> 6] = lo; shi[i >> 6] = hi; }
+  __syncthreads();
+  lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3])); hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+}
+__global__ __launch_bounds__(256) void k_hsw_finalize(const float* qx, uint32_t* present, float* qr6, float* qsite, float* qout, int observe, uint8_t* lut) {
+  const int i = threadIdx.x;
+  __shared__ float slo[4], shi[4];
+  const float sx = qx[FROST_Q_SCALE]; const int zpx = __float_as_int(qx[FROST_Q_ZP]);
+  const float xv = (float)(i - zpx) * sx;
+  const bool here = (present[i >> 5] >> (i & 31)) & 1u;
+  // site 1: the FakeQuantize prepare_qat hangs on nn.ReLU6 (observed: min/max of relu6(x + 3) over the values present)
+  const float t0 = xv + 3.0f;
+  const float t = fminf(fmaxf(t0, 0.0f), 6.0f);
+  float lo, hi;
+  hsw_block_minmax(t, here, slo, shi, lo, hi);
+  if (i == 0) observer_update_dev(qr6, lo, hi, 0, 0, observe);
+  __syncthreads();
+  bool in6; const float s6r = qr6[FROST_Q_SCALE]; const int zp6 = __float_as_int(qr6[FROST_Q_ZP]);
+  const int q6 = fq_index(t, 1.0f / s6r, zp6, 0, 255, &in6);
+  const float tq = (float)(q6 - zp6) * s6r;
+  // site 2: quant_mul1.mul(x, .) with its FakeQuantize
+  const float f = xv * tq;
+  hsw_block_minmax(f, here, slo, shi, lo, hi);
+  if (i == 0) {
+    observer_update_dev(qsite, lo, hi, 0, 0, observe);
+    for (int k = 0; k < FROST_Q_STRIDE; ++k) qout[k] = qsite[k];                 // mul_scalar(1/6): same indices, scale * (1/6)
+    const float s6 = qsite[FROST_Q_SCALE] * (1.0f / 6.0f);
+    qout[FROST_Q_SCALE] = s6; qout[FROST_Q_INV] = 1.0f / s6;
+    qout[FROST_Q_FQMIN] = qsite[FROST_Q_FQMIN] * (1.0f / 6.0f); qout[FROST_Q_FQMAX] = qsite[FROST_Q_FQMAX] * (1.0f / 6.0f);
+  }
+  __syncthreads();
+  if (i < 8) present[i] = 0u;                                                      // re-armed for the next call
+  const float inv = 1.0f / qsite[FROST_Q_SCALE]; const int zp = __float_as_int(qsite[FROST_Q_ZP]);
+  bool inr; const int q = fq_index(f, inv, zp, 0, 255, &inr);
+  lut[i] = (uint8_t)((q - 128) & 255);
+  // d/dx [x * FQ(relu6(x + 3))] = FQ(.) + x * [FQ in range] * [0 < x + 3 < 6]   (hardtanh backward: strict inequalities)
+  const float dfdx = tq + ((in6 && t0 > 0.0f && t0 < 6.0f) ? xv : 0.0f);
+  ((float*)(lut + 256))[i] = inr ? dfdx * (1.0f / 6.0f) : 0.0f;
+}
+__global__ __launch_bounds__(256) void k_hsw_apply(const int8_t* __restrict__ x, int64_t n, const uint8_t* __restrict__ lut, int8_t* __restrict__ y) {
+  __shared__ uint8_t l[256];
+  l[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t v = ((const uint32_t*)x)[i] ^ 0x80808080u;
+    ((uint32_t*)y)[i] = (uint32_t)l[v & 255u] | ((uint32_t)l[(v >> 8) & 255u] << 8) | ((uint32_t)l[(v >> 16) & 255u] << 16) | ((uint32_t)l[v >> 24] << 24);
+  }
+}
+__global__ __launch_bounds__(256) void k_hsw_bwd(const uint16_t* __restrict__ gout, const int8_t* __restrict__ x, int64_t n, const uint8_t* __restrict__ lut,
+                                                 uint16_t* __restrict__ dx, int accumulate) {
+  __shared__ float l[256];
+  l[threadIdx.x] = ((const float*)(lut + 256))[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = bf2f(gout[i]) * l[((int)x[i] + 128) & 255];
+    if (accumulate) v += bf2f(dx[i]);
+    dx[i] = f2bf(v);
+  }
+}
+extern "C" int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n, uint32_t* present8, float* qrec_relu6, float* qrec_site, float* qrec_out,
+                                int observe, uint8_t* lut, int8_t* y, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "hswish: n must be a multiple of 4");
+  hipStream_t s = as_stream(stream);
+  int64_t g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_hsw_presence, dim3((unsigned)g), dim3(256), 0, s, x, n, present8);
+  hipLaunchKernelGGL(k_hsw_finalize, dim3(1), dim3(256), 0, s, qrec_x, present8, qrec_relu6, qrec_site, qrec_out, observe, lut);
+  hipLaunchKernelGGL(k_hsw_apply, dim3((unsigned)g), dim3(256), 0, s, x, n, lut, y);
+  return frost_check_launch("hswish_fwd");
+}
+extern "C" int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream) {
+  int64_t g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_hsw_bwd, dim3((unsigned)g), dim3(256), 0, as_stream(stream), gout, x, n, lut, dx, accumulate);
+  return frost_check_launch("hswish_bwd");
+}

@@ -296,6 +296,18 @@ class Engine:
         self.tape.append(("add", a, b, y))
         return y
 
+    def hswish(self, x, q_relu6, q_site, q_out, observe=True):
+        """Quantizable hard-swish on a fake-quantised activation (reference `_Hswish`, mobilenetv3.py:43-56): q_relu6 / q_site = the FakeQuantize
+        records of `relu6` and `quant_mul1` (both observed), q_out = the record of the result after mul_scalar(1/6).  Table-driven: see csrc/frost_convert.hip."""
+        if not hasattr(self, "_hsw_present"):
+            self._hsw_present = torch.zeros(8, dtype=torch.int32, device=self.device)
+        lut = torch.empty(256 + 1024, dtype=torch.uint8, device=self.device)
+        y = self.new_act(x.n, x.h, x.w, x.c, q_out)
+        call("frost_hswish_fwd", ptr(x.buf), ptr(x.q), x.numel, ptr(self._hsw_present), ptr(q_relu6), ptr(q_site), ptr(q_out), 1 if observe else 0, ptr(lut),
+             ptr(y.buf), stream(), prof=("hswish_fwd", 3 * x.numel))
+        self.tape.append(("hswish", x, y, lut))
+        return y
+
     def head(self, l, x, drop_mask=None, observe=True):
         """AdaptiveAvgPool2d(1) -> Dropout -> nnqat.Conv2d(1280,nclass,1) + activation FQ (frostnet.py:295-299)."""
         n, c = x.n, x.c
@@ -409,6 +421,11 @@ class Engine:
                 gb, fb = self._grad_slot(b)
                 call("frost_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q),
                      ptr(ga), fa, ptr(gb), fb, stream(), prof=("cat_bwd", 5 * y.numel))
+                y.grad = None
+            elif kind == "hswish":
+                _, x, y, lut = entry
+                gx, acc = self._grad_slot(x)
+                call("frost_hswish_bwd", ptr(y.grad), ptr(x.buf), x.numel, ptr(lut), ptr(gx), acc, stream(), prof=("hswish_bwd", 5 * x.numel))
                 y.grad = None
             elif kind == "add":
                 _, a, b, y = entry

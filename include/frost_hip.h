@@ -297,6 +297,15 @@ int frost_avgpool_q(const int8_t* x, int n, int hw, int c, int32_t* pooled, void
 int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
                        const float* qrec_y, float* logits, uint8_t* idx, void* stream);
 
+/* ---- quantizable hard-swish (the reference keeps it in its MobileNetV3 baselines, FrostNet itself uses ReLU) -------------
+ * replaces: `_Hswish` (Classification/models/imagenet/mobilenetv3.py:43-56): relu6(add_scalar(x, 3)) with the FakeQuantize prepare_qat hangs on
+ * nn.ReLU6 (qrec_relu6), FloatFunctional.mul(x, .) with its FakeQuantize (qrec_site), then mul_scalar(1/6) (qrec_out: same indices, scale / 6).  x is an int8
+ * activation (<= 256 distinct values): presence bitmap -> observer -> 256-entry tables (lut: 256 bytes forward + 256 floats backward).
+ * present8: 8 zeroed uint32 (re-armed by the call).  Backward: dx (+)= gout * [STE mask * f'(x) / 6], bf16. */
+int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n, uint32_t* present8, float* qrec_relu6, float* qrec_site, float* qrec_out,
+                     int observe, uint8_t* lut, int8_t* y, void* stream);
+int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

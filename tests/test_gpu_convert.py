@@ -68,3 +68,37 @@ def test_hip_convert_matches_reference_converted_model(golden, mode):
     s_y = float(g["cls_qp"][0])
     diff = float(((y_fq - y).abs() > 0.5 * s_y).float().mean())
     print(f"[{mode}] converted logits identical to the reference; fake-quant eval logits differ from them on {diff:.1%} of the entries")
+
+
+def test_hswish_vs_reference_golden(golden):
+    """Quantizable hard-swish (reference `_Hswish`, Classification/models/imagenet/mobilenetv3.py:43-56) on the device, teacher-forced
+    on the reference's inputs: both observers (relu6 and quant_mul1) and the output indices bit-exact over 3 steps, input gradient to bf16."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import engine
+    g = golden("g10_hswish")
+    in_scale, in_zp = float(g["in_qp"][0]), int(g["in_qp"][1])
+    N, C, H, W, xseed, gseed = [int(v) for v in g["spec"]]
+    dev = "cuda"
+    E, qa = engine.Engine(dev), engine.QArena(4, dev)
+    qx, q6, qs, qo = qa.alloc(), qa.alloc(), qa.alloc(), qa.alloc()
+    qa.set_qparams(qx, in_scale, in_zp)
+    for step in range(3):
+        E.tape = []
+        x = E.act_from_indices(T(g[f"s{step}_xidx"]), qx)
+        y = E.hswish(x, q6, qs, qo)
+        y.grad = engine.float_to_grad(T(O.synth((N, C, H, W), gseed + step)).to(dev))
+        yidx = y.indices().cpu()
+        E.backward()
+        torch.cuda.synchronize()
+        site = qa.get(qs)
+        ref_qp = g[f"s{step}_qp"]
+        assert np.array_equal(np.float32([site["scale"], site["zero_point"], site["min_val"], site["max_val"]]), ref_qp), (step, site, ref_qp)
+        ref_idx = torch.round(T(g[f"s{step}_y"]).double() * 6.0 / float(ref_qp[0]) + float(ref_qp[1])).to(torch.uint8)
+        assert torch.equal(yidx, ref_idx), step
+        out = qa.get(qo)
+        np.testing.assert_allclose(out["scale"], float(ref_qp[0]) / 6.0, rtol=2e-7)
+        np.testing.assert_allclose(y.dequant().cpu().numpy(), g[f"s{step}_y"], rtol=3e-7, atol=1e-9)
+        dx = engine.grad_to_float(x.grad, N, H, W, C).cpu()
+        ref = T(g[f"s{step}_dx"])
+        assert float((dx - ref).norm() / ref.norm()) <= 5e-3, step          # bf16 gradient storage on both ends

@@ -365,3 +365,21 @@ def test_g9_converted_inference(golden, mode):
         ref = g[key + "/idx"]
         assert np.array_equal(idx if idx.size <= 40000 else idx[:, :8, :6, :6], ref), name
     assert np.array_equal(y.numpy(), g["logits"])
+
+
+# ------------------------------------------------------------------------------------------ G10 quantizable hard-swish
+def test_g10_hswish(golden):
+    g = golden("g10_hswish")
+    in_scale, in_zp = float(g["in_qp"][0]), int(g["in_qp"][1])
+    N, C, H, W, xseed, gseed = [int(v) for v in g["spec"]]
+    qs = O.QState()
+    for step in range(3):
+        x = ((T(g[f"s{step}_xidx"].astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+        y = O.hswish_qat(qs, "act", x)
+        y.backward(T(O.synth((N, C, H, W), gseed + step)))
+        np.testing.assert_array_equal(y.detach().numpy(), g[f"s{step}_y"])          # bit-exact
+        np.testing.assert_array_equal(x.grad.numpy(), g[f"s{step}_dx"])
+        a = "act.quant_mul1.activation_post_process"
+        mine = np.float32([qs.sd[a + ".scale"][0], qs.sd[a + ".zero_point"][0], qs.sd[a + ".activation_post_process.min_val"],
+                           qs.sd[a + ".activation_post_process.max_val"]])
+        assert np.array_equal(mine, g[f"s{step}_qp"]), (step, mine, g[f"s{step}_qp"])

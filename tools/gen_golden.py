@@ -432,6 +432,33 @@ def g9_convert():
         save(f"g9_convert_{mode}", **out)
 
 
+# ------------------------------------------------------------------------------------------ G10
+def g10_hswish():
+    """The reference's quantizable hard-swish (`_Hswish`, Classification/models/imagenet/mobilenetv3.py:43-56) under the qnnpack QAT qconfig,
+    teacher-forced on fake-quantised inputs: 3 steps (observer first call + 2 EMA steps), forward values and input gradients."""
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    mv3 = refshim.load_mobilenetv3()
+    m = mv3._Hswish(inplace=False)
+    m.train()
+    m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+    prepare_qat(m, inplace=True)
+    in_scale, in_zp = 0.0473, 131
+    out = dict(in_qp=np.array([in_scale, in_zp]), spec=np.array([2, 24, 10, 10, 900, 910]))
+    for step in range(3):
+        xi = np.clip(np.round(synth((2, 24, 10, 10), 900 + step) * (40 + 15 * step) + 128), 0, 255)
+        x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+        y = m(x)
+        g = T(synth(tuple(y.shape), 910 + step))
+        y.backward(g)
+        fq = m.quant_mul1.activation_post_process
+        out[f"s{step}_xidx"] = xi.astype(np.uint8)
+        out[f"s{step}_y"] = y.detach().clone()
+        out[f"s{step}_dx"] = x.grad.clone()
+        out[f"s{step}_qp"] = np.array([float(fq.scale[0]), float(fq.zero_point[0]), float(fq.activation_post_process.min_val),
+                                       float(fq.activation_post_process.max_val)], dtype=np.float32)
+    save("g10_hswish", **out)
+
+
 # ------------------------------------------------------------------------------------------ G8
 def g8_features():
     feat = refshim.load_features()
@@ -452,8 +479,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features, g9=g9_convert)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish)
     for w in which:
         fns[w]()

@@ -90,6 +90,13 @@ def load_features():
     return _load("refpkg.backbones.frostnet_features", f"{REF}/frostnet_features.py")
 
 
+def load_mobilenetv3():
+    """The reference's MobileNetV3 baseline file: only its quantizable `_Hswish` module is used."""
+    if "ref_mobilenetv3" in sys.modules:
+        return sys.modules["ref_mobilenetv3"]
+    return _load("ref_mobilenetv3", f"{REF}/Classification/models/imagenet/mobilenetv3.py")
+
+
 def load_optimizer():
     if "ref_optimizer" in sys.modules:
         return sys.modules["ref_optimizer"]
