@@ -83,11 +83,53 @@ def side_workload(args, dev):
     from frostnet_amd.optimizer import QSGD
     torch.manual_seed(1882)
     batch = args.batch if args.batch != 512 else 256
-    model = F.MODEL_REGISTRY[f"frostnet_{args.mode}_1_0"]().to(dev)
     g = torch.Generator(device=dev).manual_seed(1882)
-    x = torch.randn(batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
-    tgt = torch.randint(0, 1000, (batch,), device=dev, generator=g)
-    if args.workload == "infer":
+    if args.workload in ("infer", "float"):
+        model = F.MODEL_REGISTRY[f"frostnet_{args.mode}_1_0"]().to(dev)
+        x = torch.randn(batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        tgt = torch.randint(0, 1000, (batch,), device=dev, generator=g)
+    if args.workload == "detect":
+        from frostnet_amd import ssdlite as S
+        batch = args.batch if args.batch != 512 else 32
+        res = args.res if args.res != 224 else 512
+        model = S.SSDLiteFrostNet(num_classes=21, mode=args.mode)
+        F.qat_prepare(model, version=0)
+        model.to(dev).train()
+        x = torch.randn(batch, 3, res, res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        rng = torch.Generator().manual_seed(1882)
+        tgts = []
+        for i in range(batch):
+            k = 1 + i % 4
+            c, wh = torch.rand(k, 2, generator=rng) * 0.5 + 0.25, torch.rand(k, 2, generator=rng) * 0.3 + 0.1
+            tgts.append(torch.cat([c - wh / 2, c + wh / 2, torch.randint(0, 20, (k, 1), generator=rng).float()], 1).to(dev))
+        opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+        opt.is_warmup = False
+        crit = S.MultiBoxLoss(21)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loc, conf, pri = model(x)
+            ll, lc = crit((loc, conf, pri), tgts)
+            (ll + lc).backward()
+            opt.step()
+        bytes_per_img, metric, dtype = None, f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {res}x{res} QAT fwd+bwd", "int8"
+        what = (f"SSDLite on the FrostNet-{args.mode.capitalize()} backbone (frostnet_amd.ssdlite), int8 fake-quant QAT fwd+bwd + MultiBoxLoss + GradBoost-SGD step, "
+                f"batch={batch}, {res}x{res} (BASELINE.json config c5, per GPU)")
+        args.res = res
+    elif args.workload == "int8":
+        batch = args.batch if args.batch != 512 else 256
+        model = F.MODEL_REGISTRY[f"frostnet_quant_{args.mode}_1_0"]()
+        F.qat_prepare(model, version=0)
+        model.to(dev).train()
+        x = torch.randn(batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            model(x)                         # one calibration forward (observers, BN statistics), as Classification/evaluate.py:104-112
+        model.hip_convert()
+        step = lambda: model(x)
+        bytes_per_img, metric, dtype = 13_066_856, "images/sec FrostNet-Large 224x224 converted int8 inference", "int8"
+        what = (f"FrostNet-{args.mode.capitalize()} converted int8 inference (torch.quantization.convert + QNNPACK semantics, bit-exact vs the reference), "
+                f"batch={batch}, {args.res}x{args.res}")
+    elif args.workload == "infer":
         model.eval()
         step = lambda: model.hip_infer_bf16(x)
         bytes_per_img, metric, dtype = 26_130_000, "images/sec FrostNet-Large 224x224 bf16 inference", "bf16"
@@ -152,8 +194,9 @@ def dry_run(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="qat", choices=["qat", "infer", "float"],
-                    help="qat (default): the headline metric, BASELINE.json config c3/c4; infer: config c2; float: the StatAssist warm-up step")
+    ap.add_argument("--workload", default="qat", choices=["qat", "infer", "float", "detect", "int8"],
+                    help="qat (default): the headline metric, BASELINE.json config c3/c4; infer: config c2; float: the StatAssist warm-up step; "
+                         "detect: config c5 (SSDLite-FrostNet 512x512 QAT fwd+bwd+step, per GPU); int8: converted int8 inference (SURVEY N2)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)

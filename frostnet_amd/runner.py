@@ -190,7 +190,7 @@ class FrostRunner:
     def _build(self):
         m = self.model
         blocks = [b for layer in (m.layer1, m.layer2, m.layer3, m.layer4, m.layer5) for b in layer]
-        nsites = 1 + 2 * (2 + 4 * len(blocks)) + 2 * len(blocks) + 2 + 8
+        nsites = sum(1 for mod in m.modules() if hasattr(mod, "observer_enabled")) + 16     # every FakeQuantize of the tree + slack
         self.qa = QArena(nsites, self.device)
         self.rule127 = False
         self.q_in = self._bind_fq(m.quant.activation_post_process, self.qa.alloc())
@@ -208,6 +208,7 @@ class FrostRunner:
             self.cls = self.E.add_layer(ConvLayer("classifier.2", "cls", c.weight, None, None, None, None, None, c.bias,
                                                   1, 1, False, qw, qy))
             self.drop_rate = float(m.classifier[1].p)
+        self._bind_extra()
         self.E.rule127 = 1 if self.rule127 else 0
         # buffers were re-pointed: refresh the validity signature
         self._sig = tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())
@@ -219,6 +220,9 @@ class FrostRunner:
             self._grad_views.append(self.grad_arena[off: off + p.numel()].view_as(p))
             off += p.numel()
         self._params = params
+
+    def _bind_extra(self):
+        """Subclasses bind further layers here (SSDRunner: extras + prediction heads)."""
 
     def enable_data_parallel(self, nbuckets=4, group=None):
         """Attach the bucketed, backward-overlapped gradient all-reduce (frostnet_amd.parallel.GradSync)."""
@@ -365,3 +369,69 @@ class FrostRunner:
         with torch.cuda.device(self.device):
             self.bind_grads()
             self.E.backward(dlogits)
+
+
+class _QATMapsFunction(torch.autograd.Function):
+    """image -> a list of fake-quantised maps, dequantised to fp32 NCHW (one DeQuantStub per map); backward feeds their gradients to the tape."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, runner):
+        acts = runner._maps_impl(x, record=True)
+        ctx.runner, ctx.acts = runner, acts
+        ctx.gen = runner._new_generation()
+        return tuple(a.dequant().contiguous() for a in acts)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .engine import float_to_grad
+        ctx.runner._check_generation(ctx.gen)
+        with torch.cuda.device(ctx.runner.device):
+            for a, g in zip(ctx.acts, grads):
+                if g is None:
+                    g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
+                a.grad = float_to_grad(g)
+            ctx.runner._backward_impl(None)
+        return None, None, None
+
+
+class SSDRunner(FrostRunner):
+    """frostnet_amd.ssdlite.SSDLiteFrostNet on the engine: backbone (sources at strides 8/16/32) + SSDLite extras + separable prediction heads,
+    every layer a fake-quantised ConvBN(ReLU) on the int8-MFMA / LDS depthwise kernels; twelve dequantised maps come back."""
+
+    def _bind_extra(self):
+        m = self.model
+        self.extras = [[self._conv_layer(f"extras.{i}.pw1", e.pw1, "pw"), self._conv_layer(f"extras.{i}.dw", e.dw, "dw"),
+                        self._conv_layer(f"extras.{i}.pw2", e.pw2, "pw")] for i, e in enumerate(m.extras)]
+        self.heads = []
+        for i, (l, c) in enumerate(zip(m.loc, m.conf)):
+            self.heads.append((self._conv_layer(f"loc.{i}.dw", l.dw, "dw"), self._conv_layer(f"loc.{i}.pw", l.pw, "pw"),
+                               self._conv_layer(f"conf.{i}.dw", c.dw, "dw"), self._conv_layer(f"conf.{i}.pw", c.pw, "pw")))
+
+    def forward_maps(self, x):
+        self._check_input(x)
+        with torch.cuda.device(self.device):
+            if self.model.training and torch.is_grad_enabled():
+                return list(_QATMapsFunction.apply(self._params[0], x, self))
+            return [a.dequant().contiguous() for a in self._maps_impl(x, record=False)]
+
+    def _maps_impl(self, x, record):
+        training = self.model.training
+        if x.dtype != torch.float32:
+            x = x.float()
+        a, feats = self._trunk(x, training)
+        obs, E = self._obs, self.E
+        ends, i = [], 0
+        for lname in ("layer1", "layer2", "layer3", "layer4", "layer5"):
+            i += len(getattr(self.model, lname))
+            ends.append(feats[i - 1])
+        sources = [ends[1], ends[2], ends[4]]
+        for pw1, dw, pw2 in self.extras:
+            a = E.conv(pw2, E.conv(dw, E.conv(pw1, a, training, obs), training, obs), training, obs)
+            sources.append(a)
+        maps = []
+        for s, (ldw, lpw, cdw, cpw) in zip(sources, self.heads):
+            maps.append(E.conv(lpw, E.conv(ldw, s, training, obs), training, obs))
+            maps.append(E.conv(cpw, E.conv(cdw, s, training, obs), training, obs))
+        if not record:
+            E.tape = []
+        return maps

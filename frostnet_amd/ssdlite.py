@@ -1,0 +1,207 @@
+"""SSDLite detector on the FrostNet feature backbone -- BASELINE.json config c5 ("SSDLite-FrostNet backbone 512x512 QAT detection").
+
+The reference never wired FrostNet into its detector (Object_Detection/ssd_qmv2.py hard-codes MobileNetV2 @300), so this is the
+composition SURVEY N3 asks for, following the reference's conventions:
+  * one QuantStub at the image, one DeQuantStub per prediction map (ssd_qmv2.py:205-216,249-252);
+  * sources = backbone stages at strides 8 / 16 / 32 (x2, x3, x5 of frostnet_features.py:342-352) + extra stages at 64 / 128 / 256;
+  * SSDLite form (MobileNetV2 paper, sec. 6.3): every regular conv of the SSD extras / prediction layers becomes depthwise 3x3 + pointwise 1x1 --
+    exactly the two conv kinds the Frost bottleneck is made of, so the whole detector runs on the fake-quantised HIP engine
+    (ConvBNReLU / ConvBN of frostnet.py:14-60, BN in every layer like the reference's `ConvBN` head layers, ssd_qmv2.py:56-77);
+  * PriorBox (layers/functions/prior_box.py:28-55) and MultiBoxLoss (layers/modules/multibox_loss.py:48-117, layers/box_utils.py:71-139)
+    restated in vectorised, device-agnostic torch (they are the caller's loss, not conv math) and pinned to the reference by goldens.
+Class-score maps are padded to a multiple of 8 channels (the HIP backward's channel granularity); the padding is sliced off before the loss."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .frostnet import _SETTINGS, CascadePreExBottleneck, ConvBN, ConvBNReLU, _FrostBase, _make_divisible
+
+# 512x512 analogue of the reference's SSD300 VOC table (data/config.py:18-34): same aspect ratios / variances, sizes scaled by 512/300
+SSD512_VOC = dict(num_classes=21, min_dim=512, feature_maps=[64, 32, 16, 8, 4, 2], steps=[8, 16, 32, 64, 128, 256],
+                  min_sizes=[51, 102, 189, 276, 363, 450], max_sizes=[102, 189, 276, 363, 450, 537],
+                  aspect_ratios=[[2], [2, 3], [2, 3], [2, 3], [2], [2]], variance=[0.1, 0.2], clip=True, name="VOC")
+
+
+def prior_boxes(cfg):
+    """PriorBox.get_prior (layers/functions/prior_box.py:28-55): [sum_k f_k^2 * (2 + 2*len(ar_k)), 4] boxes (cx, cy, w, h) in [0, 1]."""
+    size = cfg["min_dim"]
+    out = []
+    for k, f in enumerate(cfg["feature_maps"]):
+        f_k = size / cfg["steps"][k]
+        s_k = cfg["min_sizes"][k] / size
+        s_kp = math.sqrt(s_k * (cfg["max_sizes"][k] / size))
+        wh = [(s_k, s_k), (s_kp, s_kp)]
+        for ar in cfg["aspect_ratios"][k]:
+            r = math.sqrt(ar)
+            wh += [(s_k * r, s_k / r), (s_k / r, s_k * r)]
+        c = (torch.arange(f, dtype=torch.float64) + 0.5) / f_k
+        cy, cx = torch.meshgrid(c, c, indexing="ij")                        # row-major: i (y) outer, j (x) inner, like product(range(f), repeat=2)
+        whs = torch.tensor(wh, dtype=torch.float64)
+        box = torch.cat([cx.reshape(-1, 1, 1).expand(-1, len(wh), 1), cy.reshape(-1, 1, 1).expand(-1, len(wh), 1),
+                         whs.unsqueeze(0).expand(f * f, -1, -1)], 2)
+        out.append(box.reshape(-1, 4))
+    out = torch.cat(out).to(torch.float32)
+    return out.clamp_(0, 1) if cfg["clip"] else out
+
+
+def _point_form(b):
+    return torch.cat([b[:, :2] - b[:, 2:] / 2, b[:, :2] + b[:, 2:] / 2], 1)
+
+
+def _jaccard(a, b):
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(2)
+    area_a = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]
+    area_b = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :]
+    return inter / (area_a + area_b - inter)
+
+
+def match_priors(threshold, truths, priors, variances, labels):
+    """layers/box_utils.py:71-139 `match` + `encode` for one image: every ground-truth box keeps its best prior, every prior takes its best
+    ground truth; overlap < threshold -> background (label 0).  Returns (loc_t [P,4], conf_t [P])."""
+    ov = _jaccard(truths, _point_form(priors))
+    best_prior_idx = ov.argmax(1)
+    best_truth_overlap, best_truth_idx = ov.max(0)
+    best_truth_overlap.index_fill_(0, best_prior_idx, 2)
+    for j in range(best_prior_idx.size(0)):                 # (sequential on purpose: a later ground truth wins a shared prior, as in the reference)
+        best_truth_idx[best_prior_idx[j]] = j
+    matched = truths[best_truth_idx]
+    conf = labels[best_truth_idx].long() + 1
+    conf[best_truth_overlap < threshold] = 0
+    g_cxcy = ((matched[:, :2] + matched[:, 2:]) / 2 - priors[:, :2]) / (variances[0] * priors[:, 2:])
+    g_wh = torch.log((matched[:, 2:] - matched[:, :2]) / priors[:, 2:]) / variances[1]
+    return torch.cat([g_cxcy, g_wh], 1), conf
+
+
+class MultiBoxLoss(nn.Module):
+    """SSD loss (layers/modules/multibox_loss.py:48-117): smooth-L1 on the matched priors + cross-entropy on positives and the hardest
+    negatives (3:1), both divided by the number of positives.  forward((loc [N,P,4], conf [N,P,C], priors [P,4]), targets list of [n_i,5])."""
+
+    def __init__(self, num_classes, overlap_thresh=0.5, neg_pos=3, variance=(0.1, 0.2)):
+        super().__init__()
+        self.num_classes, self.threshold, self.negpos_ratio, self.variance = num_classes, overlap_thresh, neg_pos, variance
+
+    def forward(self, predictions, targets):
+        loc_data, conf_data, priors = predictions
+        num, num_priors = loc_data.size(0), loc_data.size(1)
+        priors = priors[:num_priors].to(loc_data.device)
+        loc_t, conf_t = [], []
+        with torch.no_grad():
+            for t in targets:
+                t = t.to(loc_data.device)
+                lt, ct = match_priors(self.threshold, t[:, :-1], priors, self.variance, t[:, -1])
+                loc_t.append(lt)
+                conf_t.append(ct)
+            loc_t, conf_t = torch.stack(loc_t), torch.stack(conf_t)
+        pos = conf_t > 0
+        loss_l = F.smooth_l1_loss(loc_data[pos], loc_t[pos], reduction="sum")
+        with torch.no_grad():                                   # hard negative mining: rank the non-positive priors by their loss
+            batch_conf = conf_data.reshape(-1, self.num_classes)
+            lc = torch.logsumexp(batch_conf, 1) - batch_conf.gather(1, conf_t.reshape(-1, 1)).squeeze(1)   # == the reference's max-shifted log_sum_exp
+            lc = lc.reshape(num, -1).masked_fill(pos, 0)
+            _, loss_idx = lc.sort(1, descending=True)
+            _, idx_rank = loss_idx.sort(1)
+            num_pos = pos.long().sum(1, keepdim=True)
+            num_neg = torch.clamp(self.negpos_ratio * num_pos, max=pos.size(1) - 1)
+            neg = idx_rank < num_neg
+        sel = pos | neg
+        loss_c = F.cross_entropy(conf_data[sel], conf_t[sel], reduction="sum")
+        n = num_pos.sum().to(loss_l.dtype)
+        return loss_l / n, loss_c / n
+
+
+class ExtraBlock(nn.Module):
+    """SSDLite extra stage: 1x1 (-> c/2) -> depthwise 3x3 stride 2 -> 1x1 (-> c), ReLU after each (the reference applies F.relu after every
+    extra layer, ssd_qmv2.py:240-243)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        mid = cout // 2
+        self.pw1 = ConvBNReLU(cin, mid, 1)
+        self.dw = ConvBNReLU(mid, mid, 3, 2, 1, 1, groups=mid)
+        self.pw2 = ConvBNReLU(mid, cout, 1)
+
+    def forward(self, x):
+        return self.pw2(self.dw(self.pw1(x)))
+
+
+class SepHead(nn.Module):
+    """SSDLite prediction layer: depthwise 3x3 + BN + ReLU, then 1x1 + BN (linear), like the reference's ConvBN head layers but separable."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.dw = ConvBNReLU(cin, cin, 3, 1, 1, 1, groups=cin)
+        self.pw = ConvBN(cin, cout, 1)
+
+    def forward(self, x):
+        return self.pw(self.dw(x))
+
+
+class SSDLiteFrostNet(_FrostBase):
+    ANCHORS = [4, 6, 6, 6, 4, 4]
+    EXTRAS = [512, 256, 256]
+
+    def __init__(self, num_classes=21, mode="large", width_mult=1.0, cfg=None, bottleneck=CascadePreExBottleneck):
+        super().__init__()
+        self.quantized = True
+        self.num_classes, self.cfg = num_classes, dict(cfg or SSD512_VOC)
+        l1, l2, l3, l4, l5 = _SETTINGS[mode]
+        self.in_channels = _make_divisible(int(32 * min(1.0, width_mult)))
+        self.conv1 = ConvBNReLU(3, self.in_channels, 3, 2, 1)
+        chans = []
+        for i, st in enumerate((l1, l2, l3, l4, l5)):
+            setattr(self, f"layer{i + 1}", self._make_layer(bottleneck, st, width_mult, 1))
+            chans.append(self.in_channels)
+        src = [chans[1], chans[2], chans[4]]
+        self.extras = nn.ModuleList()
+        cin = chans[4]
+        for c in self.EXTRAS:
+            self.extras.append(ExtraBlock(cin, c))
+            src.append(c)
+            cin = c
+        self.source_channels = src
+        self.conf_pad = [(a * num_classes + 7) // 8 * 8 for a in self.ANCHORS]
+        self.loc = nn.ModuleList([SepHead(c, a * 4) for c, a in zip(src, self.ANCHORS)])
+        self.conf = nn.ModuleList([SepHead(c, p) for c, p in zip(src, self.conf_pad)])
+        self.quant = torch.quantization.QuantStub()
+        self.dequant = torch.quantization.DeQuantStub()
+        self._init_weights()
+        self.register_buffer("priors", prior_boxes(self.cfg), persistent=False)
+
+    def _assemble(self, maps):
+        """12 dequantised NCHW maps [loc0, conf0, loc1, ...] -> (loc [N,P,4], conf [N,P,C], priors)."""
+        n = maps[0].size(0)
+        loc = torch.cat([m.permute(0, 2, 3, 1).reshape(n, -1) for m in maps[0::2]], 1).view(n, -1, 4)
+        conf = torch.cat([m.permute(0, 2, 3, 1)[..., : a * self.num_classes].reshape(n, -1) for m, a in zip(maps[1::2], self.ANCHORS)], 1)
+        return loc, conf.view(n, -1, self.num_classes), self.priors
+
+    def forward(self, x):
+        if x.is_cuda:
+            return self._assemble(self.hip_runner().forward_maps(x))
+        x = self.conv1(self.quant(x))
+        sources = []
+        for i in range(5):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in (1, 2, 4):
+                sources.append(x)
+        for e in self.extras:
+            x = e(x)
+            sources.append(x)
+        maps = []
+        for s, l, c in zip(sources, self.loc, self.conf):
+            maps += [self.dequant(l(s)), self.dequant(c(s))]
+        return self._assemble(maps)
+
+    def hip_runner(self):
+        r = self.__dict__.get("_hip_runner")
+        if r is None or r.model is not self or not r.still_valid():
+            if not self._is_qat_prepared():
+                raise NotImplementedError("the SSDLite detector runs on the HIP device in fake-quant (QAT-prepared) mode: fuse_model() + prepare_qat first")
+            from .runner import SSDRunner
+            r = SSDRunner(self)
+            r.is_qat = True
+            self.__dict__["_hip_runner"] = r
+        return r

@@ -272,3 +272,40 @@ def test_data_parallel_shard_oracle_mean_gradient_gloo_world2():
     expect = ((grads[0] + grads[1]) / 2).numpy()
     for r in range(2):
         np.testing.assert_allclose(res[r][1], expect, rtol=1e-5, atol=1e-7)
+
+
+def test_ssd_priorbox_and_multibox_loss_match_reference(built, golden):
+    """PriorBox and MultiBoxLoss of frostnet_amd.ssdlite (vectorised restatements) against the reference's own classes
+    (Object_Detection/layers/functions/prior_box.py, layers/modules/multibox_loss.py; fixture tools/gen_golden.py g11)."""
+    import zlib
+    from frostnet_amd import ssdlite as S
+    g = golden("g11_detection")
+    pri = S.prior_boxes(S.SSD512_VOC)
+    assert list(pri.shape) == g["priors_shape"].tolist()
+    assert np.uint32(zlib.crc32(pri.numpy().tobytes())) == g["priors_crc"]            # bit-exact
+    crit = S.MultiBoxLoss(21, 0.5, 3, (0.1, 0.2))
+    P = pri.shape[0]
+    for case in range(2):
+        loc = (T(O.synth((3, P, 4), 1100 + case)) * 0.5).requires_grad_(True)
+        conf = (T(O.synth((3, P, 21), 1110 + case)) * (1.0 + case)).requires_grad_(True)
+        tg = [T(g[f"c{case}_t{n}"]) for n in range(3)]
+        ll, lc = crit((loc, conf, pri), tg)
+        (ll + lc).backward()
+        np.testing.assert_allclose([float(ll), float(lc)], g[f"c{case}_losses"], rtol=2e-6)
+        for name, t in (("dloc", loc.grad), ("dconf", conf.grad)):
+            pack = g[f"c{case}_{name}"]
+            mine = O.sample_big(t.double().numpy())
+            np.testing.assert_allclose(mine, pack[3:], rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(np.abs(t.double().numpy()).sum(), pack[1], rtol=1e-6)
+
+
+def test_ssdlite_module_surface(built):
+    from frostnet_amd import ssdlite as S, frostnet as F
+    m = S.SSDLiteFrostNet(num_classes=21, mode="small")
+    assert m.source_channels == [40, 96, 320, 512, 256, 256] and m.priors.shape == (24528, 4)
+    F.qat_prepare(m, version=0)
+    loc, conf, pri = m(torch.randn(2, 3, 128, 128))
+    assert loc.shape == (2, 1536, 4) and conf.shape == (2, 1536, 21)
+    keys = list(m.state_dict().keys())
+    assert "extras.0.dw.conv.0.weight_fake_quant.scale" in keys and "conf.5.pw.conv.0.bn.running_var" in keys
+    assert "priors" not in keys

@@ -459,6 +459,39 @@ def g10_hswish():
     save("g10_hswish", **out)
 
 
+# ------------------------------------------------------------------------------------------ G11
+def g11_detection():
+    """The reference's PriorBox (layers/functions/prior_box.py) and MultiBoxLoss (layers/modules/multibox_loss.py) on the 512x512 table of
+    frostnet_amd.ssdlite: prior boxes, and losses + gradients for seeded predictions / ground truth."""
+    from frostnet_amd.ssdlite import SSD512_VOC
+    PriorBox, MultiBoxLoss = refshim.load_detection()
+    pri = PriorBox(dict(SSD512_VOC)).get_prior()
+    out = dict(priors_shape=np.array(pri.shape), priors_sum=np.float64(pri.double().sum()), priors_crc=crc(pri.numpy()),
+               priors_head=pri[:64].clone(), priors_tail=pri[-64:].clone())
+    crit = MultiBoxLoss(21, 0.5, True, 0, True, 3, 0.5, False, use_gpu=False)
+    P = pri.shape[0]
+    for case in range(2):
+        N = 3
+        loc = (T(synth((N, P, 4), 1100 + case)) * 0.5).requires_grad_(True)
+        conf = (T(synth((N, P, 21), 1110 + case)) * (1.0 + case)).requires_grad_(True)
+        rng = np.random.Generator(np.random.PCG64(1120 + case))
+        tg = []
+        for n in range(N):
+            k = 1 + (n + case) % 3
+            c = rng.random((k, 2)) * 0.6 + 0.2
+            wh = rng.random((k, 2)) * 0.35 + 0.05
+            lab = rng.integers(0, 20, (k, 1)).astype(np.float64)
+            tg.append(T(np.concatenate([c - wh / 2, c + wh / 2, lab], 1).astype(np.float32)))
+        ll, lc = crit((loc, conf, pri), tg)
+        (ll + lc).backward()
+        out[f"c{case}_losses"] = np.array([float(ll), float(lc)], dtype=np.float64)
+        out[f"c{case}_dloc"] = grad_pack(loc.grad)
+        out[f"c{case}_dconf"] = grad_pack(conf.grad)
+        for n, t in enumerate(tg):
+            out[f"c{case}_t{n}"] = t
+    save("g11_detection", **out)
+
+
 # ------------------------------------------------------------------------------------------ G8
 def g8_features():
     feat = refshim.load_features()
@@ -479,8 +512,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection)
     for w in which:
         fns[w]()

@@ -97,6 +97,21 @@ def load_mobilenetv3():
     return _load("ref_mobilenetv3", f"{REF}/Classification/models/imagenet/mobilenetv3.py")
 
 
+def load_detection():
+    """The reference's SSD loss pieces (Object_Detection/layers): PriorBox and MultiBoxLoss.  cv2 / torchvision are absent here and only
+    imported at module level by files we do not execute: stub them."""
+    if "layers" not in sys.modules:
+        sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+        if "torchvision" not in sys.modules:
+            tv, tvo = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+            tv.ops, tvo.nms = tvo, None
+            sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, tvo
+        sys.path.insert(0, f"{REF}/Object_Detection")
+    from layers.functions.prior_box import PriorBox
+    from layers.modules.multibox_loss import MultiBoxLoss
+    return PriorBox, MultiBoxLoss
+
+
 def load_optimizer():
     if "ref_optimizer" in sys.modules:
         return sys.modules["ref_optimizer"]
