@@ -34,6 +34,11 @@ class FrostFDesc(C.Structure):
                 ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("reserved", C.c_int32)]
 
 
+class FrostFinDesc(C.Structure):
+    _fields_ = [("qrec_w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("nbt", P), ("coef", P), ("qrec_y", P), ("counter", P),
+                ("training", C.c_int32), ("relu", C.c_int32), ("observe", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FrostGDesc(C.Structure):
     _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
                 ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32)]
@@ -64,6 +69,8 @@ _PROTOS = {
     "frost_weight_prep": [P, I, I, I, I, P],
     "frost_stats_init_table": [P, P, P, I, P],
     "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
+    "frost_pw_conv_fwd_fin": [P, P, P, P, L, I, I, P, P, P],
+    "frost_dw_conv_fwd_fin": [P, P, P, P, I, I, I, I, I, I, P, P, P],
     "frost_dw_conv_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P],
     "frost_stem_im2col": [P, P, I, I, I, P, P],
     "frost_stem_wgrad_remap": [P, I, I, P, P],

@@ -119,4 +119,81 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
   q[FROST_Q_FQMAX] = (float)(ihi - zp) * scale;
 }
 
+// ---- conv finalize (shared by k_conv_finalize and the statistics kernels' last-workgroup tail) ------------------------------
+// Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
+// workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read
+// with agent-scope loads.  sh: >= 2 * (nthr / 64) floats of shared memory.
+__device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, int cout, int cpad, const float* qx, const float* qw,
+                                         const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
+                                         int relu, int observe, int have_stats, float* coef, float* qy, int tid, int nthr, float* sh) {
+  const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
+  const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
+  const float sx = qx[FROST_Q_SCALE], sw = qw[FROST_Q_SCALE];
+  float lo = INFINITY, hi = -INFINITY;
+  for (int c = tid; c < cpad; c += nthr) {
+    float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
+    if (c < cout) {
+      const float sigr = sqrtf(rvar[c] + FROST_BN_EPS);
+      const float sf = gamma[c] / sigr;
+      const double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha
+      double mean_acc, mu, v;
+      if (training) {
+        const int64_t v1 = __hip_atomic_load(&s1[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t v2 = __hip_atomic_load(&s2[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mean_acc = (double)v1 / (double)count;
+        double var_acc = (double)v2 / (double)count - mean_acc * mean_acc;
+        if (var_acc < 0) var_acc = 0;
+        mu = mean_acc * alpha; v = var_acc * alpha * alpha;
+        const double unb = (count > 1) ? v * (double)count / (double)(count - 1) : v;
+        rmean[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rmean[c] + (double)FROST_BN_MOM * mu);
+        rvar[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rvar[c] + (double)FROST_BN_MOM * unb);
+      } else {
+        mu = (double)rmean[c]; v = (double)rvar[c]; mean_acc = mu / alpha;
+      }
+      const double invstd = 1.0 / sqrt(v + (double)FROST_BN_EPS);
+      const double a = (double)gamma[c] * invstd * alpha;
+      A = (float)a; B = (float)((double)beta[c] - a * mean_acc);
+      M = (float)mean_acc; R = (float)(alpha * invstd);
+      K1 = (float)(invstd * (double)sigr);                         // gamma*invstd/sf
+      VF = (float)(v / (v + (double)FROST_BN_EPS));
+      if (have_stats) {
+        const int32_t imn = __hip_atomic_load(&mnp[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int32_t imx = __hip_atomic_load(&mxp[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float ya = fmaf(A, (float)imn, B), yb = fmaf(A, (float)imx, B);
+        if (relu) { ya = fmaxf(ya, 0.0f); yb = fmaxf(yb, 0.0f); }
+        lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
+      }
+    }
+    coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
+    coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
+    coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
+  }
+  const int nw = nthr >> 6;
+  lo = wave_min(lo); hi = wave_max(hi);
+  __syncthreads();
+  if ((tid & 63) == 0) { sh[tid >> 6] = lo; sh[nw + (tid >> 6)] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < nw; ++i) { lo = fminf(lo, sh[i]); hi = fmaxf(hi, sh[nw + i]); }
+    if (training && nbt) *nbt += 1;
+    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe);
+    else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
+  }
+}
+
+// Last-workgroup-done tail of a statistics kernel: every thread has issued its atomics; returns true in ALL threads of the one workgroup
+// that arrives last (its view of the other workgroups' atomics is then complete).  sflag: one int of shared memory.
+__device__ __forceinline__ bool last_block_done(uint32_t* counter, unsigned total, int* sflag) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's atomics have been performed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned t = atomicAdd(counter, 1u);
+    *sflag = (t == total - 1u) ? 1 : 0;
+    if (t == total - 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); *counter = 0u; }    // re-armed for the next step
+  }
+  __syncthreads();
+  return *sflag != 0;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

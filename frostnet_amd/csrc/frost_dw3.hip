@@ -41,6 +41,7 @@ struct Dw3P {
   uint8_t* stats; float* coef; const float* qy; int relu; int8_t* y;
   const uint16_t* gout; uint16_t* dc; float* dwq; uint16_t* dx; int accumulate;
   int tiles_x, tiles_y, ncb, ngroups; int64_t nunits, ntiles; float inv_count;
+  FrostFinDesc fin; int fin_on;       // statistics pass: finalize folded into the last workgroup's tail
   int cvt;       // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation), see frost_convert.hip
   int xmap;      // XCD-aware block -> (channel block, tile range) map, see dw_block_map
 };
@@ -467,6 +468,14 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch2, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch2, b);
       }
     }
+    if (MODE == D_STATS && p.fin_on) {       // last workgroup done -> conv finalize in this launch (see frost_common.h)
+      int* sflag = (int*)smem;
+      if (last_block_done(p.fin.counter, gridDim.x, sflag)) {
+        float* sh = (float*)(smem + 16);
+        conv_finalize_dev(p.stats, (int64_t)p.n * p.ho * p.wo, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar,
+                          p.fin.nbt, p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh);
+      }
+    }
   }
 }
 
@@ -698,6 +707,14 @@ extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2);
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), mode == 0 ? 0 : 1, as_stream(stream));
+}
+extern "C" int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
+                                     int stride, void* stats, const FrostFinDesc* fin, void* stream) {
+  FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y, "dw_fwd_fin: incomplete finalize descriptor");
+  Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
+  p.stats = (uint8_t*)stats; p.coef = fin->coef; p.qy = fin->qrec_y; p.relu = fin->relu; p.fin = *fin; p.fin_on = 1;
+  return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 0, as_stream(stream));
 }
 extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                                  const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,

@@ -293,54 +293,9 @@ __global__ __launch_bounds__(256) void k_conv_finalize(const uint8_t* stats, int
                                                        const float* qx, const float* qw, const float* gamma,
                                                        const float* beta, float* rmean, float* rvar, int64_t* nbt,
                                                        int training, int relu, int observe, int have_stats, float* coef, float* qy) {
-  const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
-  const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
-  float sx = qx[FROST_Q_SCALE], sw = qw[FROST_Q_SCALE];
-  float lo = INFINITY, hi = -INFINITY;
-  for (int c = threadIdx.x; c < cpad; c += 256) {
-    float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
-    if (c < cout) {
-      float sigr = sqrtf(rvar[c] + FROST_BN_EPS);
-      float sf = gamma[c] / sigr;
-      double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha
-      double mean_acc, mu, v;
-      if (training) {
-        mean_acc = (double)s1[c] / (double)count;
-        double var_acc = (double)s2[c] / (double)count - mean_acc * mean_acc;
-        if (var_acc < 0) var_acc = 0;
-        mu = mean_acc * alpha; v = var_acc * alpha * alpha;
-        double unb = (count > 1) ? v * (double)count / (double)(count - 1) : v;
-        rmean[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rmean[c] + (double)FROST_BN_MOM * mu);
-        rvar[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rvar[c] + (double)FROST_BN_MOM * unb);
-      } else {
-        mu = (double)rmean[c]; v = (double)rvar[c]; mean_acc = mu / alpha;
-      }
-      double invstd = 1.0 / sqrt(v + (double)FROST_BN_EPS);
-      double a = (double)gamma[c] * invstd * alpha;
-      A = (float)a; B = (float)((double)beta[c] - a * mean_acc);
-      M = (float)mean_acc; R = (float)(alpha * invstd);
-      K1 = (float)(invstd * (double)sigr);                         // gamma*invstd/sf
-      VF = (float)(v / (v + (double)FROST_BN_EPS));
-      if (have_stats) {
-        float ya = fmaf(A, (float)mnp[c], B), yb = fmaf(A, (float)mxp[c], B);
-        if (relu) { ya = fmaxf(ya, 0.0f); yb = fmaxf(yb, 0.0f); }
-        lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
-      }
-    }
-    coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
-    coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
-    coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
-  }
-  __shared__ float slo[4], shi[4];
-  lo = wave_min(lo); hi = wave_max(hi);
-  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 4; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
-    if (training && nbt) *nbt += 1;
-    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe);
-    else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
-  }
+  __shared__ float sh[8];
+  conv_finalize_dev(stats, count, cout, cpad, qx, qw, gamma, beta, rmean, rvar, nbt, training, relu, observe, have_stats, coef, qy,
+                    threadIdx.x, 256, sh);
 }
 extern "C" int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
                                    const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,

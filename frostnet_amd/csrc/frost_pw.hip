@@ -46,6 +46,7 @@ struct PwP {
   float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
   int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
   int wtl_off, wtl_bytes;            // LDS-resident copy of the transposed weight pack
+  FrostFinDesc fin; int fin_on; unsigned fin_total;   // statistics pass: finalize folded into the last workgroup's tail
   int cvt;                           // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation)
 };
 
@@ -657,6 +658,14 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
         atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
       }
     }
+    if (p.fin_on) {            // last workgroup done: the layer's statistics are complete -> conv finalize here instead of in its own launch
+      int* sflag = (int*)smem;
+      if (last_block_done(p.fin.counter, p.fin_total, sflag)) {
+        float* sh = (float*)(smem + 16);
+        conv_finalize_dev(p.stats, p.npix, p.cout, p.cpad, p.qx, p.fin.qrec_w, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+                          p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 512, sh);
+      }
+    }
   } else if (MODE == M_BRED) {
     if (defer) {
       const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
@@ -708,6 +717,7 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   static const int cs_mul = getenv("FROST_PW_CSMUL") ? atoi(getenv("FROST_PW_CSMUL")) : 1;
   if (cs_on && !q.io && grid * 2 <= 256 * occ_cache * cs_mul) { cs = (int)((256 * occ_cache * cs_mul) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
   q.csplit = cs; q.nbt = (int)grid;
+  q.fin_total = (unsigned)(grid * cs);
   hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT, FTW>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
   return frost_check_launch("pw");
 }
@@ -734,6 +744,7 @@ static int launch_pw(PwP& p, hipStream_t s) {
   }
   const size_t lds_f = lds + pf.io_bytes;
   const int64_t nfull = p.npix / BP;           // full tiles: validity-free kernel instance; the ragged tail: one extra tiny launch
+  if (nfull < p.ntiles) pf.fin_on = 0;          // the folded finalize belongs to the LAST launch of the pass (stream order makes the first one's atomics visible)
   int rc = 0;
   if (nfull > 0) {
     const size_t cres_bytes = (size_t)p.cpad * FROST_COEF_ROWS * 4;
@@ -842,6 +853,19 @@ extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int
   if (mode == 0) return dispatch_pw<M_STATS>(p, as_stream(stream));
   p.cvt = (mode == 2);
   return dispatch_pw<M_EMIT>(p, as_stream(stream));
+}
+
+extern "C" int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                                     void* stats, const FrostFinDesc* fin, void* stream) {
+  FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "pw_fwd: cin must be a multiple of 8, cout of 4");
+  FROST_REQUIRE(((uintptr_t)x & 15) == 0, "pw_fwd: x must be 16B aligned");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y, "pw_fwd_fin: incomplete finalize descriptor");
+  PwP p = {};
+  p.T = (const uint8_t*)x; p.cout = cout; p.cpad = round_up(cout, 16); p.wpack = (const uint8_t*)wq_pack;
+  p.wsum = wsum; p.qx = qrec_x; p.qy = fin->qrec_y; p.coef = fin->coef; p.stats = (uint8_t*)stats; p.relu = fin->relu;
+  p.fin = *fin; p.fin_on = 1;
+  set_tiling(p, npix, cin);
+  return dispatch_pw<M_STATS>(p, as_stream(stream));
 }
 
 extern "C" int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,

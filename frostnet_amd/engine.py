@@ -24,6 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 
@@ -124,6 +125,7 @@ class ConvLayer:
         self.coef = torch.zeros(L.COEF_ROWS, self.cpad, dtype=torch.float32, device=dev)
         self.sigma = torch.ones(self.cout, dtype=torch.float32, device=dev)
         self.stats = None       # view into the engine's stats arena
+        self.fin_counter = torch.zeros(1, dtype=torch.int32, device=dev)     # last-workgroup-done ticket of the statistics pass
         self.bn_mod = None      # the BatchNorm2d module (its .training flag is checked by the runner)
         self.dwq = None         # fp32 scratch for dL/d(fake-quantised weight)
 
@@ -257,11 +259,23 @@ class Engine:
             x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
         need_stats = training or observe
-        if need_stats:
-            self._conv_launch(l, x, 0, None)
-        call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
-             ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
-             1 if observe else 0, ptr(l.coef), ptr(l.qy), stream())
+        if need_stats and _FIN_FOLD:
+            # statistics pass with the finalize folded into its last workgroup (two launches per conv forward instead of three)
+            fin = L.FrostFinDesc(l.qw.data_ptr(), l.gamma.data_ptr(), l.beta.data_ptr(), l.rmean.data_ptr(), l.rvar.data_ptr(), l.nbt.data_ptr(),
+                                 l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0)
+            nb = x.numel + l.wq_pack.numel()
+            if l.kind in ("pw", "stem"):
+                call("frost_pw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin),
+                     stream(), prof=(f"{l.kind}_fwd_stats", nb))
+            else:
+                call("frost_dw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.stats),
+                     C.byref(fin), stream(), prof=("dw_fwd_stats", nb))
+        else:
+            if need_stats:
+                self._conv_launch(l, x, 0, None)
+            call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
+                 ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
+                 1 if observe else 0, ptr(l.coef), ptr(l.qy), stream())
         self._conv_launch(l, x, 1, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))

@@ -281,6 +281,21 @@ typedef struct FrostOptHyper {
 int frost_gradboost_step(const FrostOptTensor* table, int ntensors, int64_t max_n, const FrostOptHyper* hyper,
                          const float* noise, const float* coin, const int64_t* prefix, void* stream);
 
+/* ---- statistics pass with the finalize folded into its tail --------------------------------------------------------------------------
+ * frost_pw_conv_fwd / frost_dw_conv_fwd (mode 0) + frost_conv_finalize in ONE launch: the last workgroup to finish (device-scope ticket)
+ * turns the integer statistics into the BN coefficients / running statistics / activation qparams, so a conv forward is two launches
+ * (statistics+finalize, emit) instead of three.  `fin` is a HOST struct (copied into the kernel arguments); `counter` is one zeroed uint32
+ * per layer in device memory (re-armed by the kernel). */
+typedef struct {
+  const float* qrec_w; const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;
+  float* coef; float* qrec_y; uint32_t* counter;
+  int32_t training, relu, observe, reserved;
+} FrostFinDesc;
+int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                          void* stats, const FrostFinDesc* fin, void* stream);
+int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
+                          int stride, void* stats, const FrostFinDesc* fin, void* stream);
+
 /* ---- converted int8 inference ------------------------------------------------------------------
  * replaces: torch.quantization.convert(model.eval()) + the QNNPACK kernels (Classification/evaluate.py:130-134).  The convolutions are
  * frost_pw_conv_fwd / frost_dw_conv_fwd with mode 2 (integer bias add + fp32 requantisation: y = clamp(rint(float(acc + b_q) * rs) + zp));

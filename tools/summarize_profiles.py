@@ -16,7 +16,7 @@ import sys
 
 FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- kernel-name regex
     ("pw_fwd_stats", r"k_pw<0,"), ("pw_fwd_emit", r"k_pw<1,"), ("pw_bwd_reduce", r"k_pw<2,"),
-    ("pw_bwd_dc", r"k_pw<3,"), ("pw_dgrad", r"k_pw<4,"), ("pw_wgrad", r"k_pw_wgrad"),
+    ("pw_bwd_fused", r"k_pw<3, \d+, \w+, \w+, [1-9]\d*>"), ("pw_bwd_dc", r"k_pw<3,"), ("pw_dgrad", r"k_pw<4,"), ("pw_wgrad", r"k_pw_wgrad"),
     ("dw_fwd_stats", r"k_dw3<DwGeo<[^>]*>, 0>"), ("dw_fwd_emit", r"k_dw3<DwGeo<[^>]*>, 1>"),
     ("dw_bwd_reduce", r"k_dw3<DwGeo<[^>]*>, 2>"), ("dw_bwd_dc", r"k_dw3<DwGeo<[^>]*>, [34]>"),
     ("dw_wgrad", r"k_dw3_wgrad"), ("dw_dgrad", r"k_dw3_dgrad"),
@@ -64,10 +64,37 @@ def main():
         for lab, (ids, kib) in per.items():
             out[lab][f"{ctr}_KiB_per_launch"] = round(kib / len(ids), 1)
             out[lab][f"{ctr}_launches"] = len(ids)
+    # MFMA / VALU counters (separate --pmc passes): per family totals per launch
+    for d_ in sorted(glob.glob(f"{root}/mfma_*")):
+        f = glob.glob(f"{d_}/**/*counter_collection.csv", recursive=True)
+        if not f:
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(lambda: [set(), 0.0]))
+        for r in csv.DictReader(open(f[0])):
+            lab = family(r["Kernel_Name"])
+            if lab:
+                e = per[lab][r["Counter_Name"]]
+                e[0].add(r["Dispatch_Id"]); e[1] += float(r["Counter_Value"])
+        for lab, cs in per.items():
+            for ctr, (ids, val) in cs.items():
+                out[lab][f"{ctr}_per_launch"] = round(val / max(1, len(ids)), 1)
+    # FETCH_SIZE / WRITE_SIZE calibration (tools/probe_fetch.hip)
+    cal = {}
+    for sub, ctr in (("cal_fetch", "FETCH_SIZE"), ("cal_write", "WRITE_SIZE")):
+        f = glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True)
+        if not f:
+            continue
+        per = collections.defaultdict(lambda: [set(), 0.0])
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == ctr:
+                k = r["Kernel_Name"].split("(")[0]
+                per[k][0].add(r["Dispatch_Id"]); per[k][1] += float(r["Counter_Value"])
+        for k, (ids, kib) in per.items():
+            cal.setdefault(k, {})[f"{ctr}_KiB_per_launch"] = round(kib / len(ids), 1)
     for lab, d in out.items():
         if "FETCH_SIZE_KiB_per_launch" in d and "WRITE_SIZE_KiB_per_launch" in d:
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024)
-    doc = dict(batch=batch, correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950; separate --pmc passes, eager step)",
+    doc = dict(batch=batch, fetch_calibration=cal, correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950; separate --pmc passes, eager step)",
                stats_total_ms=round(total_ns / 1e6, 3), families=out)
     json.dump(doc, open(f"{root}/summary.json", "w"), indent=1, sort_keys=True)
     for lab, d in sorted(out.items(), key=lambda kv: -kv[1].get("total_ms", 0)):
