@@ -63,10 +63,10 @@ def cpu_baseline(res=224):
 
 
 def pmc_traffic(label, batch):
-    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r01_kernels_b<batch>.json, made by
+    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r02_kernels_b<batch>.json, made by
     tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same step, gfx950 correction applied).
     Counters cannot be collected from inside this process, so the number is the committed one or null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_kernels_b{batch}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_kernels_b{batch}.json")
     try:
         fam = json.load(open(path))["families"][label]
         return int(fam["hbm_bytes_per_launch"]), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
@@ -394,7 +394,14 @@ def main():
                         mfma=dict(achieved=round(value / world * FLOPS_PER_IMG / 1e12, 2), unit="TFLOP/s",
                                   frac_of_time_at_peak=round(value / world * (FLOPS_I8_PER_IMG / 5.0e15 + FLOPS_BF16_PER_IMG / 2.5e15), 4),
                                   flops_per_image=FLOPS_PER_IMG),
-                        breakdown_ms={k: round(v["total_ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
+                        breakdown_ms={k: round(v["total_ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])},
+                        # every family: launches per step, average launch (us, HIP events), algorithmic MB per launch, achieved GB/s, and the
+                        # PMC traffic ratio (HBM bytes from the committed counter passes / algorithmic bytes)
+                        families={k: dict(n=v["launches"], us=round(v["avg_ms"] * 1e3, 1), mb=round(v["bytes_per_launch"] / 1e6, 1),
+                                          gbs=round(v["bytes_per_launch"] / (v["avg_ms"] * 1e-3) / 1e9, 0),
+                                          traffic_ratio=(round(pmc_traffic(k, args.batch)[0] / v["bytes_per_launch"], 2)
+                                                         if pmc_traffic(k, args.batch)[0] and args.res == 224 and args.mode == "large" else None))
+                                  for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
     if world > 1:
         dist.barrier()
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <stdlib.h>
 #include "../../include/frost_hip.h"
 
 #define FROST_BN_EPS 1e-5f
@@ -50,6 +51,25 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+
+// ---- stochastic rounding fp32 -> bf16 for the dc tensor (gradient w.r.t. the conv output) ----------------------------------------
+// Why: dc[p][c] = K1[c] * g[p][c] + small terms, with g itself on the bf16 lattice and K1 constant per channel -- round-to-nearest then has a
+// deterministic per-channel bias (~1e-4 relative, measured: tests/devtools/dbg_wgrad.py).  The weight gradient sums dc * x over all pixels of a
+// batch (up to 6.4 M) while training-mode BatchNorm makes sum_p dc = 0, so that bias is amplified by sqrt(pixels): 1.6e-2 (dW) / 4.5e-2 (dgamma)
+// at 263 k pixels against the fp64 evaluation, and growing with the batch.  Stochastic rounding (add 16 pseudo-random bits below the kept
+// mantissa, truncate) is unbiased whatever the lattice: the error stays at the 2^-9/sqrt(3) level independent of the pixel count.
+// The generator is a 24-bit LCG per lane (v_mad_u32_u24, full rate), seeded from the workgroup / thread index: launches are reproducible.
+__device__ __forceinline__ uint32_t sr_seed(uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu; return (h ^ (h >> 15)) | 1u; }
+__device__ __forceinline__ uint32_t sr_next16(uint32_t& st) {
+  st = __umul24(st, 0x5BD1E5u) + 0x9E3779u;      // the top 16 of the low 24 bits are the random number
+  return (st >> 8) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t sr_bf16(float v, uint32_t& st) { return (__float_as_uint(v) + sr_next16(st)) >> 16; }
+__device__ __forceinline__ uint32_t sr_pk_bf16(float lo, float hi, uint32_t& st) {
+  const uint32_t a = __float_as_uint(lo) + sr_next16(st), b = __float_as_uint(hi) + sr_next16(st);
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);              // {b[31:16], a[31:16]}
+}
+static inline int frost_sr_enabled() { static const int on = getenv("FROST_SR") ? atoi(getenv("FROST_SR")) : 1; return on; }
 
 // ---- ordered float atomics ---------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {

@@ -42,6 +42,7 @@ struct Dw3P {
   const uint16_t* gout; uint16_t* dc; float* dwq; uint16_t* dx; int accumulate;
   int tiles_x, tiles_y, ncb, ngroups; int64_t nunits, ntiles; float inv_count;
   FrostFinDesc fin; int fin_on;       // statistics pass: finalize folded into the last workgroup's tail
+  int sr;        // dc is rounded to bf16 stochastically (unbiased; see sr_bf16 in frost_common.h)
   int cvt;       // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation), see frost_convert.hip
   int xmap;      // XCD-aware block -> (channel block, tile range) map, see dw_block_map
 };
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     }
   }
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
   constexpr bool PLAN = !WG;       // the fused weight-gradient variant has no registers to spare for the staging plans
   DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; if (PLAN) plx.init(tid, cb, p.w, p.c);
@@ -390,7 +392,8 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
           const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq : 0.0f;
           if (MODE == D_BRED) { r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2); }
           else {
-            const uint32_t hb = cvt_pk_bf16(fmaf(gy, cK1, fmaf(v, cE, cF)), 0.0f) & 0xffffu;
+            const float dcf = fmaf(gy, cK1, fmaf(v, cE, cF));
+            const uint32_t hb = p.sr ? sr_bf16(dcf, rng) : (cvt_pk_bf16(dcf, 0.0f) & 0xffffu);
             *(uint16_t*)(aux + (lp * CBW + L.lc) * 2) = (uint16_t)hb;
             if (WG) acc[o][r] = valid ? (int)(hb << 16) : 0;          // the bf16-rounded dc (float bits) replaces the dead accumulator
           }
@@ -721,7 +724,7 @@ extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int
                                  const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
-  p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w;
+  p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w; p.sr = frost_sr_enabled();
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), pass == 0 ? 2 : 3, as_stream(stream));
 }
 extern "C" int frost_dw_conv_bwd_dc_wgrad(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
@@ -729,7 +732,7 @@ extern "C" int frost_dw_conv_bwd_dc_wgrad(const int8_t* x, const float* qrec_x, 
                                           const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, float* dwq, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
-  p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w; p.dwq = dwq;
+  p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w; p.dwq = dwq; p.sr = frost_sr_enabled();
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 6, as_stream(stream));
 }
 extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,

@@ -47,6 +47,7 @@ struct PwP {
   int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
   int wtl_off, wtl_bytes;            // LDS-resident copy of the transposed weight pack
   FrostFinDesc fin; int fin_on; unsigned fin_total;   // statistics pass: finalize folded into the last workgroup's tail
+  int sr;                            // dc is rounded to bf16 stochastically (unbiased; see sr_pk_bf16 in frost_common.h)
   int cvt;                           // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation)
 };
 
@@ -134,8 +135,11 @@ __device__ __forceinline__ uint32_t pw_trunc_bf2(float lo, float hi) {   // exac
 // dWq[co][ci] += s_x * sum_pix dc[pix][co] * (q[pix][ci] - zp)   (16x16 output tiles dealt round-robin to the 8 waves, FTW per wave, persistent
 // accumulators flushed once per workgroup) -- so dc is neither written to nor re-read from HBM twice (-6 B per output element), and the
 // weight gradient does not read x again.  Replaces the dc pass + frost_pw dgrad + frost_pw_wgrad for layers with Cout*Cin <= ~19 k.
+#ifndef PW_FUSE_MINW
+#define PW_FUSE_MINW 4
+#endif
 template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0>
-__global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
+__global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr bool FUSE = FTW > 0;
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
 #pragma unroll
   for (int i = 0; i < (FUSE ? FTW : 1); ++i) wacc[i] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
   int zpx = 0; float sw = 1.0f; float y_inv = 1.0f; float y_zpf = 0.0f;
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD && p.qw) sw = p.qw[FROST_Q_SCALE];
@@ -501,7 +506,9 @@ __global__ __launch_bounds__(512, PW_MINW(MODE, WP)) void k_pw(const PwP p) {
               else dcv[r] = fmaf(gy, K1[r], fmaf(af, E[r], F[r]));
             }
             if (MODE == M_BDC && valid) {
-              uint2 o; o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]);
+              uint2 o;
+              if (p.sr) { o.x = sr_pk_bf16(dcv[0], dcv[1], rng); o.y = sr_pk_bf16(dcv[2], dcv[3], rng); }
+              else { o.x = pack_bf2(dcv[0], dcv[1]); o.y = pack_bf2(dcv[2], dcv[3]); }
               if (o_lds) *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o;
               else *(uint2*)(dbase + prow * p.cout + ch0) = o;
             }
@@ -823,6 +830,7 @@ extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, con
   p.T = (const uint8_t*)x; p.cout = cout; p.cpad = round_up(cout, 16); p.wpack = (const uint8_t*)wq_pack;
   p.wsum = wsum; p.qx = qrec_x; p.qy = qrec_y; p.qw = qrec_w; p.coef = coef; p.relu = relu; p.gout = gout; p.dc = dc_scratch;
   set_tiling(p, npix, cin);
+  p.sr = frost_sr_enabled();
   FROST_REQUIRE(p.gl, "pw_bwd_fused: linear tile staging unavailable");
   const int CT = p.cpad / 16, WC = 8 / f.wp, MI = PW_MI(M_BDC, f.wp);
   p.ngroups = (CT + WC * MI - 1) / (WC * MI);
@@ -877,6 +885,7 @@ extern "C" int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int
   p.T = (const uint8_t*)x; p.cout = cout; p.cpad = round_up(cout, 16); p.wpack = (const uint8_t*)wq_pack;
   p.wsum = wsum; p.qx = qrec_x; p.qy = qrec_y; p.qw = qrec_w; p.coef = coef; p.relu = relu; p.gout = gout; p.dc = dc;
   set_tiling(p, npix, cin);
+  p.sr = frost_sr_enabled();
   if (pass == 0) return dispatch_pw<M_BRED>(p, as_stream(stream));
   if (pass == 1) return dispatch_pw<M_BDC>(p, as_stream(stream));
   // pass 2: dgrad   dx[pix][cin] (+)= s_w * sum_co dc[pix][co] * wq[co][cin]

@@ -24,6 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -557,7 +558,7 @@ class Engine:
                  prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
             # dc pass + weight gradient in one sweep where the kernel's register state allows it (the library applies the same
             # rule and would otherwise run the two kernels itself; calling them separately keeps the profiler tags per kernel)
-            if _DW_FUSE and l.stride == 1 and (l.k == 3 or (l.k == 5 and y.w <= 8)):
+            if _DW_FUSE and l.stride == 1 and (l.k == 3 or (l.k == 5 and y.w <= 8 and _DW_FUSE_K5)):
                 call("frost_dw_conv_bwd_dc_wgrad", *args, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(l.dwq), s,
                      prof=("dw_bwd_dc", 2 * x.numel + 4 * y.numel))
             else:

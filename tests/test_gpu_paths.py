@@ -3,7 +3,7 @@ splitting, depthwise tile geometries, XCD-aware block maps and fused passes (inc
 them.  Here one seeded layer runs at a size where the fast paths engage, once with the defaults and once with every such
 path switched off (environment switches read by libfrost_hip.so at load, hence one subprocess per configuration), and the
 two results must agree: quantised outputs identical up to rare rounding-boundary flips (the fp32 part of the variance sum
-depends on the tile-to-lane assignment), statistics to 1e-6, gradients to bf16/atomic-order noise."""
+depends on the tile-to-lane assignment), statistics to 1e-6, gradients to the bf16 rounding noise of the dc tensor."""
 import os
 import subprocess
 import sys
@@ -46,6 +46,10 @@ def test_fast_paths_match_plain_paths(case, tmp_path):
     assert fast["qy"][3].tobytes() == plain["qy"][3].tobytes()                         # zero point (integer bits)
     np.testing.assert_allclose(fast["rm"], plain["rm"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(fast["rv"], plain["rv"], rtol=1e-6, atol=1e-7)
-    assert relerr(bf16_to_f32(fast["dx"]), bf16_to_f32(plain["dx"])) <= 2e-3
-    for k in ("dw", "dgamma", "dbeta"):
-        assert relerr(fast[k], plain[k]) <= 1e-3, k
+    # dc is rounded to bf16 STOCHASTICALLY (unbiased, frost_common.h) with a generator seeded from the workgroup / thread index: two tilings of
+    # the same layer draw different rounding noise, so everything downstream of dc agrees to the bf16 rounding level (2^-9 / sqrt(3) per
+    # element), not to atomic-order noise
+    assert relerr(bf16_to_f32(fast["dx"]), bf16_to_f32(plain["dx"])) <= 8e-3
+    for k in ("dw", "dgamma"):
+        assert relerr(fast[k], plain[k]) <= 1e-2, k
+    assert relerr(fast["dbeta"], plain["dbeta"]) <= 1e-3

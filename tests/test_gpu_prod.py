@@ -129,14 +129,12 @@ def test_prod_layer_vs_oracle(engine, case):
         np.testing.assert_allclose(qw["scale"], float(qs.sd["L.conv.0.weight_fake_quant.scale"][0]), rtol=1e-6)
         np.testing.assert_allclose(l.rmean.cpu().numpy(), qs.sd["L.conv.0.bn.running_mean"].numpy(), rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(l.rvar.cpu().numpy(), qs.sd["L.conv.0.bn.running_var"].numpy(), rtol=1e-3, atol=2e-4)
-        # dx / dbeta: GRAD everywhere.  dW / dgamma: GRAD up to ~50 k pixels; at 263 k pixels the sum over pixels cancels to ~1/500 of its
-        # terms (training-mode BatchNorm makes sum_p dc = 0 and the synthetic upstream gradient is white noise), which exposes a
-        # per-channel rounding bias of the bf16 dc tensor (dc = K1[c] * g with g itself on the bf16 lattice: ~1e-4 relative, measured with
-        # tests/devtools/dbg_wgrad.py; the weight-gradient kernel reproduces an fp64 GEMM of the same dc to 4e-7) -- and the reference's
-        # own fp32 evaluation is 2e-2 (dW) / 6e-2 (dgamma) from the exact value on the 24->144 case.  Bound there: max(8e-2, 2 x ref32).
-        big = (N * (H // s) ** 2) > 200_000
+        # All four gradients within GRAD of the fp64 evaluation of the reference's formulas.  (With round-to-nearest dc the 263 k-pixel cases
+        # were 1.6e-2 / 4.5e-2 (dW / dgamma) off: a per-channel rounding bias amplified by sqrt(pixels); dc is now rounded stochastically,
+        # frost_common.h, and sits at the bf16 floor.)  Where the reference's OWN fp32 evaluation is further than GRAD from fp64 (24->144 @56^2,
+        # step 0: 2.4e-2 / 6.4e-2 -- an ill-conditioned channel), the bound is 1.5 x that distance: the device agrees with the fp32 reference there.
         assert max(e_dx, e_db) <= GRAD, (name, step, e_dx, e_db)
-        assert e_dw <= (max(8e-2, 2 * r_dw) if big else GRAD) and e_dg <= (max(1.2e-1, 2 * r_dg) if big else GRAD), (name, step, e_dw, e_dg, r_dw, r_dg)
+        assert e_dw <= max(GRAD, 1.5 * r_dw) and e_dg <= max(GRAD, 1.5 * r_dg), (name, step, e_dw, e_dg, r_dw, r_dg)
 
 
 def test_classifier_head_vs_reference_golden(engine, golden):
