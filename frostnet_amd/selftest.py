@@ -33,7 +33,7 @@ def smoke():
     gn = float(dict(model.named_parameters())["last_layer.conv.0.weight"].grad.norm())
     opt.step()
     torch.cuda.synchronize()
-    assert np.isfinite(float(loss)) and 0.5 < gn / gn_ref < 2.0, (float(loss), gn, gn_ref)
+    assert np.isfinite(float(loss)) and 0.9 < gn / gn_ref < 1.1, (float(loss), gn, gn_ref)       # measured 0.999
     # eval parity from the oracle's post-step state
     sd = {k: v.detach().clone() for k, v in P.items()}
     sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
@@ -46,5 +46,5 @@ def smoke():
         ref = O.frostnet_forward(P, qs, cfg, x1, True, False)
         out = m2(x1.cuda()).cpu()
     rel = float((out - ref).norm() / ref.norm())
-    assert rel < 2e-2, rel
+    assert rel < 5e-3, rel          # measured 0.0 at this size (every logit index identical)
     print(f"smoke ok: loss {float(loss):.4f}, grad-norm ratio {gn / gn_ref:.3f}, eval logits rel-err vs oracle {rel:.2e}")

@@ -17,7 +17,7 @@ import torch
 from oracle import frost_oracle as O
 
 pytestmark = pytest.mark.gpu
-FLIP_RATE = 2e-3
+FLIP_RATE = 5e-4       # measured 0 .. 3.4e-4 (K = 624 / 1728 layers; the reference's fp32 conv sum rounds where the integer sum does not)
 GRAD_TOL = 2e-2
 
 
