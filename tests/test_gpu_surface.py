@@ -268,3 +268,32 @@ def test_checkpoint_ingest_ema_and_module_prefix(fa, tmp_path):
     with torch.no_grad():
         feats = dst(torch.randn(2, 3, 64, 64, device="cuda"))
     assert [f.shape[1] for f in feats] == [24, 40, 96, 320] and all(torch.isfinite(f).all() for f in feats)
+
+
+def test_flops_counter_style_hooks_survive(fa):
+    """the reference wraps the model with add_flops_counting_methods (Classification/train.py:80-84: methods bound onto the module,
+    forward hooks and `__flops__` attributes on every conv) BEFORE moving it to the GPU and preparing QAT.  Same treatment here: the CPU pass
+    counts through the stock modules, the HIP path afterwards is unaffected by the leftovers."""
+    F = fa["F"]
+    torch.manual_seed(1)
+    m = F.frostnet_quant_small_1_0(drop_rate=0.0)
+    macs = {"n": 0}
+
+    def hook(mod, inp, out):
+        mod.__flops__ += out.numel() // out.shape[0] * (mod.in_channels // mod.groups) * mod.kernel_size[0] * mod.kernel_size[1]
+        macs["n"] += 1
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.__flops__ = 0
+            mod.__flops_handle__ = mod.register_forward_hook(hook)
+    m.compute_average_flops_cost = (lambda self: sum(mod.__flops__ for mod in self.modules() if isinstance(mod, torch.nn.Conv2d))).__get__(m)
+    m.eval()
+    with torch.no_grad():
+        m(torch.zeros(1, 3, 224, 224))
+    assert macs["n"] == 54 and m.compute_average_flops_cost() == 315_344_912          # SURVEY Appendix A: FrostNet-Small @224, 54 convs
+    F.qat_prepare(m, version=0)
+    m.cuda().train()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    loss = m(x).sum()
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
