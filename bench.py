@@ -271,7 +271,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1882 + rank)
     x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
     tgt = torch.randint(0, 1000, (args.batch,), device=dev, generator=g)
-    crit = torch.nn.CrossEntropyLoss()
+    from frostnet_amd.harness import CrossEntropyLoss
+    crit = CrossEntropyLoss()                     # nn.CrossEntropyLoss semantics, forward + backward in one HIP kernel (harness.py)
 
     # N = 1: model(x) -> loss.backward() -> optimizer.step() (the reference loop, helper_functions.py:139-143) captured as ONE hipGraph.
     # N > 1 (default): the same kernels as a chain of hipGraph segments, one per gradient bucket; the bucket's RCCL all-reduce is issued

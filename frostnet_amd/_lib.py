@@ -118,6 +118,8 @@ _PROTOS = {
     "frost_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
     "frost_head_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, P, P],
     "frost_gradboost_step": [P, I, L, P, P, P, P, P],
+    "frost_softmax_ce": [P, P, I, I, F, P, P, P],
+    "frost_dropout_mask": [P, C.c_uint64, L, F, P, P],
     "frost_conv_finalize_converted": [P, P, P, P, P, P, I, P, P, P],
     "frost_add_qnnpack": [P, P, P, P, L, P, P, P],
     "frost_avgpool_q": [P, I, I, I, P, P],

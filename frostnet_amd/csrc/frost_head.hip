@@ -296,3 +296,66 @@ extern "C" int frost_mask_logits(const float* g, const float* raw, const float* 
   hipLaunchKernelGGL(k_mask_logits, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), g, raw, qrec_y, n, out);
   return frost_check_launch("mask_logits");
 }
+
+// ------------------------------------------------------------------------------------------------ loss + dropout mask (K13)
+// replaces: nn.CrossEntropyLoss (mean reduction) forward AND backward of the training loop (Classification/train.py:147,
+// helper_functions.py:140-142): one wave per sample -- log-sum-exp, loss_i = lse - x[target], dlogits = (softmax - onehot) * gscale / n_valid.
+// loss: ONE float, accumulated with atomics (zeroed by the caller); targets < 0 are ignored (ignore_index = -100).
+__global__ __launch_bounds__(256) void k_softmax_ce(const float* __restrict__ x, const int64_t* __restrict__ tgt, int n, int c, float inv_n,
+                                                    float* __restrict__ loss, float* __restrict__ dx) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* xr = x + (int64_t)row * c;
+  const int64_t t = tgt[row];
+  float m = -INFINITY;
+  for (int k = lane; k < c; k += 64) m = fmaxf(m, xr[k]);
+  m = wave_max(m);
+  float s = 0.0f;
+  for (int k = lane; k < c; k += 64) s += expf(xr[k] - m);
+  s = wave_sum(s);
+  const float lse = m + logf(s);
+  const bool valid = t >= 0 && t < c;
+  if (dx) {
+    const float w = valid ? inv_n / s : 0.0f;
+    for (int k = lane; k < c; k += 64) dx[(int64_t)row * c + k] = expf(xr[k] - m) * w - ((valid && k == (int)t) ? inv_n : 0.0f);
+  }
+  if (lane == 0 && valid) atomicAdd(loss, (lse - xr[t]) * inv_n);
+}
+extern "C" int frost_softmax_ce(const float* logits, const int64_t* target, int n, int c, float inv_n, float* loss, float* dlogits, void* stream) {
+  hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, as_stream(stream), logits, target, n, c, inv_n, loss, dlogits);
+  return frost_check_launch("softmax_ce");
+}
+
+// replaces: nn.Dropout's mask (frostnet.py:297) -- Bernoulli(keep) / keep per pooled feature, Philox4x32-10 keyed by `seed`, counter =
+// (element index, *draw): `draw` is a device-resident uint64 that the kernel's last thread advances, so a captured hipGraph draws a fresh
+// mask at every replay without host involvement.
+__device__ __forceinline__ void dm_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void k_dropout_mask(unsigned long long* draw, unsigned long long seed, int64_t n, float keep, float* __restrict__ out) {
+  const unsigned long long d = *draw;                       // single workgroup grid-stride kernel: every thread reads before thread 0 advances
+  __syncthreads();
+  const float inv = 1.0f / keep;
+  for (int64_t i = threadIdx.x; i < (n + 3) / 4; i += 256) {
+    uint32_t r[4];
+    dm_philox((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)d, (uint32_t)(d >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = i * 4 + e;
+      if (j < n) out[j] = (((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f) < keep) ? inv : 0.0f;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *draw = d + 1ull;
+}
+extern "C" int frost_dropout_mask(void* draw_counter, uint64_t seed, int64_t n, float keep, float* out, void* stream) {
+  FROST_REQUIRE(keep > 0.0f && keep <= 1.0f, "dropout_mask: keep probability must be in (0, 1]");
+  hipLaunchKernelGGL(k_dropout_mask, dim3(1), dim3(256), 0, as_stream(stream), (unsigned long long*)draw_counter, (unsigned long long)seed, n, keep, out);
+  return frost_check_launch("dropout_mask");
+}

@@ -12,6 +12,37 @@ import math
 import torch
 
 
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        from ._lib import call, ptr, stream
+        n, c = logits.shape
+        x = logits.contiguous().float()
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        dlogits = torch.empty_like(x)
+        call("frost_softmax_ce", ptr(x), ptr(target.contiguous()), n, c, 1.0 / n, ptr(loss), ptr(dlogits), stream())
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """`nn.CrossEntropyLoss()` (mean reduction; Classification/train.py:147) with forward and backward in ONE hand-written kernel on the
+    device (`frost_softmax_ce`): loss and dlogits come out of the same pass, no host synchronisation (capturable).  Every target must be a
+    valid class index (the reference's loaders never produce ignore_index); CPU tensors take torch's implementation."""
+
+    def forward(self, logits, target):
+        if not logits.is_cuda:
+            return torch.nn.functional.cross_entropy(logits, target)
+        if target.dtype != torch.int64 or target.dim() != 1 or logits.dim() != 2:
+            raise ValueError("CrossEntropyLoss expects (N, C) logits and (N,) int64 class indices")
+        return _CEFunction.apply(logits, target)
+
+
 def make_param_groups(model, weight_decay):
     groups = []
     others = weight_decay * 0.01

@@ -296,6 +296,14 @@ int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
 int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
                           int stride, void* stats, const FrostFinDesc* fin, void* stream);
 
+/* ---- loss and dropout mask of the training step -------------------------------------------------------------------
+ * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
+ * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */
+int frost_softmax_ce(const float* logits, const int64_t* target, int n, int c, float inv_n, float* loss, float* dlogits, void* stream);
+/* replaces: nn.Dropout's Bernoulli mask on the pooled features (frostnet.py:297): out[i] in {0, 1/keep}, Philox4x32-10, counter =
+ * (index, *draw_counter); the kernel advances the device-resident uint64 draw counter itself (hipGraph replays draw fresh masks). */
+int frost_dropout_mask(void* draw_counter, uint64_t seed, int64_t n, float keep, float* out, void* stream);
+
 /* ---- converted int8 inference ------------------------------------------------------------------
  * replaces: torch.quantization.convert(model.eval()) + the QNNPACK kernels (Classification/evaluate.py:130-134).  The convolutions are
  * frost_pw_conv_fwd / frost_dw_conv_fwd with mode 2 (integer bias add + fp32 requantisation: y = clamp(rint(float(acc + b_q) * rs) + zp));

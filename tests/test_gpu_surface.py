@@ -297,3 +297,33 @@ def test_flops_counter_style_hooks_survive(fa):
     loss = m(x).sum()
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_cross_entropy_and_dropout_kernels(fa):
+    """K13: nn.CrossEntropyLoss forward + backward and the Dropout mask as hand-written kernels (frostnet_amd.harness.CrossEntropyLoss,
+    frost_dropout_mask) against torch's fp32 definitions."""
+    from frostnet_amd import harness as H, _lib as L
+    torch.manual_seed(0)
+    x = (torch.randn(37, 1000, device="cuda") * 3).requires_grad_(True)
+    t = torch.randint(0, 1000, (37,), device="cuda")
+    loss = H.CrossEntropyLoss()(x, t)
+    (loss * 2.5).backward()
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t)
+    (ref * 2.5).backward()
+    torch.testing.assert_close(loss, ref, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-8)
+    # dropout mask: values in {0, 1/keep}, keep rate, fresh draw per call, reproducible for the same (seed, draw)
+    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    n, keep = 512 * 1280, 0.8
+    a, b = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(a), L.stream())
+    L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(b), L.stream())
+    assert int(ctr) == 2
+    assert set(torch.unique(a).tolist()) == {0.0, 1.25}
+    assert abs(float((a > 0).float().mean()) - keep) < 3e-3 and abs(float((b > 0).float().mean()) - keep) < 3e-3
+    assert not torch.equal(a, b) and abs(float(((a > 0) == (b > 0)).float().mean()) - (keep * keep + (1 - keep) ** 2)) < 5e-3
+    ctr.zero_()
+    c = torch.empty(n, device="cuda")
+    L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(c), L.stream())
+    assert torch.equal(a, c)
