@@ -11,14 +11,14 @@ _lib = None
 
 P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
-Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_OBS_EN, Q_FQ_EN, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 8, 10, 12
+Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_QMAX, Q_OBS_EN, Q_FQ_EN, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12
 COEF_ROWS = 8
 STATS_BYTES_PER_CH = 24
 
 
 class FrostWDesc(C.Structure):
     _fields_ = [("w", P), ("gamma", P), ("rvar", P), ("qrec", P), ("wq_pack", P), ("wsum", P), ("minmax2", P),
-                ("wt_pack", P), ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32), ("kind", C.c_int32),
+                ("wt_pack", P), ("wscale", P), ("wmin", P), ("wmax", P), ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32), ("kind", C.c_int32),
                 ("cpad", C.c_int32), ("kpad", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32)]
 
 
@@ -36,12 +36,12 @@ class FrostFDesc(C.Structure):
 
 class FrostFinDesc(C.Structure):
     _fields_ = [("qrec_w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("nbt", P), ("coef", P), ("qrec_y", P), ("counter", P),
-                ("training", C.c_int32), ("relu", C.c_int32), ("observe", C.c_int32), ("reserved", C.c_int32)]
+                ("training", C.c_int32), ("relu", C.c_int32), ("observe", C.c_int32), ("reserved", C.c_int32), ("wscale", P)]
 
 
 class FrostGDesc(C.Structure):
     _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
-                ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32)]
+                ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32), ("wscale", P)]
 
 
 class FrostOptTensor(C.Structure):
@@ -74,22 +74,22 @@ _PROTOS = {
     "frost_dw_conv_fwd": [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P, P],
     "frost_stem_im2col": [P, P, I, I, I, P, P],
     "frost_stem_wgrad_remap": [P, I, I, P, P],
-    "frost_conv_finalize": [P, L, I, P, P, P, P, P, P, P, I, I, I, P, P, P],
+    "frost_conv_finalize": [P, L, I, P, P, P, P, P, P, P, I, I, I, P, P, P, P],
     "frost_cat_observe": [P, P, P, I, P],
     "frost_cat_requant": [P, P, I, P, P, I, L, P, P, P],
     "frost_add_minmax": [P, P, P, P, L, P, P],
     "frost_add_requant": [P, P, P, P, L, P, P, P],
     "frost_avgpool": [P, P, I, I, I, P, P, P],
-    "frost_classifier_fwd": [P, P, P, P, I, I, I, P, P],
+    "frost_classifier_fwd": [P, P, P, P, I, I, I, P, P, P],
     "frost_pw_conv_bwd": [P, P, P, P, P, P, L, I, I, I, P, P, I, P, P, P, I, P],
     "frost_pw_wgrad": [P, P, P, L, I, I, P, P],
     "frost_pw_bwd_fused_ok": [L, I, I],
     "frost_pw_conv_bwd_fused": [P, P, P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, P],
     "frost_dw_conv_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
     "frost_dw_conv_bwd_dc_wgrad": [P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P],
-    "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P],
+    "frost_dw_dgrad": [P, P, P, I, I, I, I, I, I, P, I, P, P],
     "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
-    "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P],
+    "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P, P],
     "frost_weight_grad_finalize_table": [P, I, P],
     "frost_infer_weight_prep": [P, I, P],
     "frost_infer_stem_im2col": [P, I, I, I, L, L, L, L, P, P],
@@ -116,7 +116,7 @@ _PROTOS = {
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],
     "frost_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
-    "frost_head_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "frost_head_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, P, P, P],
     "frost_gradboost_step": [P, I, L, P, P, P, P, P],
     "frost_softmax_ce": [P, P, I, I, F, P, P, P],
     "frost_dropout_mask": [P, C.c_uint64, L, F, P, P],

@@ -24,9 +24,10 @@ int frost_check_launch(const char* what);
 __host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---- qrecord access ---------------------------------------------------------------------------------------
-struct QP { float scale, inv; int zp; };
+struct QP { float scale, inv; int zp, hi; };
+__device__ __forceinline__ int q_hi(const float* q) { const float m = q[FROST_Q_QMAX]; return (m > 0.0f) ? (int)m : 255; }   // activation index range 0..hi
 __device__ __forceinline__ QP load_qp(const float* q) {
-  QP r; r.scale = q[FROST_Q_SCALE]; r.zp = __float_as_int(q[FROST_Q_ZP]); r.inv = 1.0f / r.scale; return r;
+  QP r; r.scale = q[FROST_Q_SCALE]; r.zp = __float_as_int(q[FROST_Q_ZP]); r.inv = 1.0f / r.scale; r.hi = q_hi(q); return r;
 }
 // fake-quantise to the uint8 index (torch fake_quantize_per_tensor_affine): q = clamp(rint(x*inv)+zp, lo, hi)
 __device__ __forceinline__ int fq_index(float x, float inv, int zp, int lo, int hi, bool* inrange = nullptr) {
@@ -122,10 +123,10 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
         else scale = fmaxf(-mn_neg, mx_pos) / 127.5f;
         scale = fmaxf(scale, FROST_F32_EPS);
       } else {
-        scale = (mx_pos - mn_neg) / 255.0f;
+        scale = (mx_pos - mn_neg) / (float)q_hi(q);          // (qmax - qmin): 255, or 127 with reduce_range
         scale = fmaxf(scale, FROST_F32_EPS);
         zp = 0 - (int)rintf(mn_neg / scale);
-        zp = min(max(zp, 0), 255);
+        zp = min(max(zp, 0), q_hi(q));
       }
     }
     q[FROST_Q_SCALE] = scale; q[FROST_Q_ZP] = __int_as_float(zp);
@@ -133,7 +134,7 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
   float scale = q[FROST_Q_SCALE]; int zp = __float_as_int(q[FROST_Q_ZP]);
   float inv = 1.0f / scale;
   q[FROST_Q_INV] = inv;
-  int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : 255;
+  int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : q_hi(q);
   int ilo = fq_index(cur_lo, inv, zp, lo, hi), ihi = fq_index(cur_hi, inv, zp, lo, hi);
   q[FROST_Q_FQMIN] = (float)(ilo - zp) * scale;
   q[FROST_Q_FQMAX] = (float)(ihi - zp) * scale;
@@ -143,16 +144,17 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
 // Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
 // workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read
 // with agent-scope loads.  sh: >= 2 * (nthr / 64) floats of shared memory.
-__device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, int cout, int cpad, const float* qx, const float* qw,
+__device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, int cout, int cpad, const float* qx, const float* qw, const float* wscale,
                                          const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
                                          int relu, int observe, int have_stats, float* coef, float* qy, int tid, int nthr, float* sh) {
   const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
   const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
-  const float sx = qx[FROST_Q_SCALE], sw = qw[FROST_Q_SCALE];
+  const float sx = qx[FROST_Q_SCALE], sw0 = qw[FROST_Q_SCALE];
   float lo = INFINITY, hi = -INFINITY;
   for (int c = tid; c < cpad; c += nthr) {
     float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
     if (c < cout) {
+      const float sw = wscale ? wscale[c] : sw0;            // per-output-channel weight scale (per-tensor mode: all equal)
       const float sigr = sqrtf(rvar[c] + FROST_BN_EPS);
       const float sf = gamma[c] / sigr;
       const double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_hsw_finalize(const float* qx, uint32_t*
   if (i == 0) observer_update_dev(qr6, lo, hi, 0, 0, observe);
   __syncthreads();
   bool in6; const float s6r = qr6[FROST_Q_SCALE]; const int zp6 = __float_as_int(qr6[FROST_Q_ZP]);
-  const int q6 = fq_index(t, 1.0f / s6r, zp6, 0, 255, &in6);
+  const int q6 = fq_index(t, 1.0f / s6r, zp6, 0, q_hi(qr6), &in6);
   const float tq = (float)(q6 - zp6) * s6r;
   // site 2: quant_mul1.mul(x, .) with its FakeQuantize
   const float f = xv * tq;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_hsw_finalize(const float* qx, uint32_t*
   __syncthreads();
   if (i < 8) present[i] = 0u;                                                      // re-armed for the next call
   const float inv = 1.0f / qsite[FROST_Q_SCALE]; const int zp = __float_as_int(qsite[FROST_Q_ZP]);
-  bool inr; const int q = fq_index(f, inv, zp, 0, 255, &inr);
+  bool inr; const int q = fq_index(f, inv, zp, 0, q_hi(qsite), &inr);
   lut[i] = (uint8_t)((q - 128) & 255);
   // d/dx [x * FQ(relu6(x + 3))] = FQ(.) + x * [FQ in range] * [0 < x + 3 < 6]   (hardtanh backward: strict inequalities)
   const float dfdx = tq + ((in6 && t0 > 0.0f && t0 < 6.0f) ? xv : 0.0f);

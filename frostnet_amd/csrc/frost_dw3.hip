@@ -42,6 +42,7 @@ struct Dw3P {
   const uint16_t* gout; uint16_t* dc; float* dwq; uint16_t* dx; int accumulate;
   int tiles_x, tiles_y, ncb, ngroups; int64_t nunits, ntiles; float inv_count;
   FrostFinDesc fin; int fin_on;       // statistics pass: finalize folded into the last workgroup's tail
+  const float* wscale;   // [cpad] per-output-channel weight scale (NULL: the scalar of qw)
   int sr;        // dc is rounded to bf16 stochastically (unbiased; see sr_bf16 in frost_common.h)
   int cvt;       // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation), see frost_convert.hip
   int xmap;      // XCD-aware block -> (channel block, tile range) map, see dw_block_map
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
     wpk[ky][0] = (int)lo; if (NPK > 1) wpk[ky][NPK - 1] = (int)hi;
   }
   const int acc0 = chok ? (128 - zp) * p.wsum[ch] : 0;
+  float qcap = 255.0f; bool lowq = false;        // 7-bit activations (reduce_range): the u8 conversion saturates at 255 only
   float cA = 0, cB = 0, cMR = 0, cR = 0, cK1 = 0, cE = 0, cF = 0, y_inv = 1.0f, y_zpf = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
   if (MODE != D_STATS) {
     y_inv = 1.0f / p.qy[FROST_Q_SCALE]; const int zpy = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)zpy;
@@ -307,10 +309,12 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         }
       }
     }
-    if (MODE == D_EMIT && p.cvt) y_inv = 1.0f;        // row A already is the requantisation scale s_x*s_w/s_y
+    if (MODE == D_EMIT && p.cvt) y_inv = 1.0f;
+    if (MODE == D_EMIT) { qcap = (float)q_hi(p.qy); lowq = qcap < 255.0f; }        // row A already is the requantisation scale s_x*s_w/s_y
     if (MODE == D_BRED || MODE == D_BDC) {   // STE pass window in t = y/scale: t_lo < t <= t_hi (see frost_pw.hip)
-      const float hi0 = 255.5f - (float)zpy;
-      t_hi = ((255 - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+      const int qhi = q_hi(p.qy);
+      const float hi0 = (float)qhi + 0.5f - (float)zpy;
+      t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
       if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
     }
   }
@@ -385,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
         } else if (MODE == D_EMIT) {
           // q = clamp(rint(relu(y)/s) + zp, 0, 255): v_cvt_pk_u8_f32 saturates at both ends while converting
           const float yv = p.cvt ? (float)(acc[o][r] + __float_as_int(cB)) * cA : fmaf(cA, v, cB);
-          aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf, 0, 0u) ^ 0x80u) & 255u);
+          float qv = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
         } else {
           const float gq = bf2f(*(const uint16_t*)(aux + (lp * CBW + L.lc) * 2));
           const float tq = fmaf(cA, v, cB) * y_inv;
@@ -475,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
       int* sflag = (int*)smem;
       if (last_block_done(p.fin.counter, gridDim.x, sflag)) {
         float* sh = (float*)(smem + 16);
-        conv_finalize_dev(p.stats, (int64_t)p.n * p.ho * p.wo, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar,
+        conv_finalize_dev(p.stats, (int64_t)p.n * p.ho * p.wo, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar,
                           p.fin.nbt, p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh);
       }
     }
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
   const int lane = L.lane, wy = L.wy;
   const DwMap bm = dw_block_map(p); const int cb = bm.cb;
   const int ch = cb * CBW + L.lc; const bool chok = ch < p.c;
-  const float sw = p.qw[FROST_Q_SCALE];
+  const float sw = (p.wscale && chok) ? p.wscale[ch] : p.qw[FROST_Q_SCALE];     // lane = channel: the per-channel weight scale is a per-lane scalar
   float wf[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) wf[t] = chok ? (float)p.wq[t * p.cpad + ch] : 0.0f;
@@ -741,9 +747,9 @@ extern "C" int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 4, as_stream(stream));
 }
 extern "C" int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c,
-                              int k, int stride, uint16_t* dx, int accumulate, void* stream) {
+                              int k, int stride, uint16_t* dx, int accumulate, const float* wscale, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw_dgrad: channels must be a multiple of 8");
   Dw3P p = {}; fill3(p, nullptr, nullptr, wq_pack, nullptr, n, h, w, c, k, stride);
-  p.dc = (uint16_t*)dc; p.dx = dx; p.accumulate = accumulate; p.qw = qrec_w;
+  p.dc = (uint16_t*)dc; p.dx = dx; p.accumulate = accumulate; p.qw = qrec_w; p.wscale = wscale;
   return dispatch3(p, k, stride, geo_env(pick_geo(c, w, k, stride, true)), 5, as_stream(stream));
 }

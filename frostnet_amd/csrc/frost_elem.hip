@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_quantize_input(const float* __restrict_
     uint32_t packed = 0;
     for (int ch = 0; ch < cpad; ++ch) {
       int idx = q.zp;
-      if (ch < c) idx = fq_index(px[ch * sc], q.inv, q.zp, 0, 255);
+      if (ch < c) idx = fq_index(px[ch * sc], q.inv, q.zp, 0, q.hi);
       packed |= ((uint32_t)((idx - 128) & 255)) << (8 * (ch & 3));
       if ((ch & 3) == 3) { *(uint32_t*)(out + p * cpad + ch - 3) = packed; packed = 0; }
     }
@@ -190,8 +190,48 @@ __global__ void k_wprep_observe(const FrostWDesc* descs, int nlayers, int rule12
   observer_update_dev(d.qrec, d.minmax2[0], d.minmax2[1], 1, rule127, observe);
   d.minmax2[0] = INFINITY; d.minmax2[1] = -INFINITY;
 }
+// Per-output-channel weight scales (always produced: the downstream kernels read d.wscale[c]).
+//   per-tensor mode (qnnpack qconfig): wscale[c] = qrec.scale for every channel.
+//   per-channel mode (FrostWDesc.reserved1; torch MovingAveragePerChannelMinMaxObserver + per_channel_symmetric qint8, ch_axis 0):
+//     one wave per output channel: min/max of the BN-scaled weights of that channel, EMA (c = 0.01, first call takes the values),
+//     s_c = max(-min-, max+) / 127.5 (v0 rule; rule127: max(-min-/128, max+/127)), eps clamp; qrec.scale <- max_c s_c.
+__global__ __launch_bounds__(256) void k_wprep_scales(const FrostWDesc* descs, int rule127, int observe) {
+  const FrostWDesc d = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (!d.reserved1) {
+    const float s = d.qrec[FROST_Q_SCALE];
+    for (int c = tid; c < d.cpad; c += 256) d.wscale[c] = s;
+    return;
+  }
+  const bool obs = observe && (__float_as_int(d.qrec[FROST_Q_OBS_EN]) != 0);
+  const int per = d.cin_g * d.kk;
+  __shared__ float smax[4];
+  float best = 0.0f;
+  for (int co = wv; co < d.cpad; co += 4) {
+    float sc = 1.0f;
+    if (co < d.cout) {
+      if (obs) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int r = lane; r < per; r += 64) { const float v = w_scaled(d, co, r); lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        lo = wave_min(lo); hi = wave_max(hi);
+        float mn = d.wmin[co], mx = d.wmax[co];
+        if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = lo; mx = hi; }
+        else { mn = mn + FROST_OBS_C * (lo - mn); mx = mx + FROST_OBS_C * (hi - mx); }
+        if (lane == 0) { d.wmin[co] = mn; d.wmax[co] = mx; }
+        const float mn_neg = fminf(mn, 0.0f), mx_pos = fmaxf(mx, 0.0f);
+        sc = rule127 ? fmaxf(-mn_neg / 128.0f, mx_pos / 127.0f) : fmaxf(-mn_neg, mx_pos) / 127.5f;
+        sc = fmaxf(sc, FROST_F32_EPS);
+      } else sc = d.wscale[co];
+      best = fmaxf(best, sc);
+    }
+    if (lane == 0) d.wscale[co] = sc;
+  }
+  if (lane == 0) smax[wv] = best;
+  __syncthreads();
+  if (tid == 0) { const float m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])); d.qrec[FROST_Q_SCALE] = m; d.qrec[FROST_Q_INV] = 1.0f / m; }
+}
 __device__ __forceinline__ int wq_at(const FrostWDesc& d, float inv, int co, int rest) {
-  return fq_index(w_scaled(d, co, rest), inv, 0, -128, 127);
+  return fq_index(w_scaled(d, co, rest), d.reserved1 ? 1.0f / d.wscale[co] : inv, 0, -128, 127);
 }
 // pack kernel: one thread per packed dword
 __global__ __launch_bounds__(256) void k_wprep_pack(const FrostWDesc* descs) {
@@ -218,8 +258,8 @@ __global__ __launch_bounds__(256) void k_wprep_pack(const FrostWDesc* descs) {
         int e = (int)(i & 7); int lane = (int)((i >> 3) & 63); int64_t t = i >> 9; int kb = (int)(t % KB); int cit = (int)(t / KB);
         int ci = cit * 16 + (lane & 15); int g = lane >> 4;
         int co = kb * 32 + 8 * g + e;
-        float v = 0.0f;
-        if (co < d.cout && ci < d.cin_g) v = (float)wq_at(d, inv, co, ci);
+        float v = 0.0f;      // per-channel mode: the data-gradient kernels apply the scalar qrec.scale, so the pack carries s_c / scale (1 in per-tensor mode)
+        if (co < d.cout && ci < d.cin_g) v = (float)wq_at(d, inv, co, ci) * (d.reserved1 ? d.wscale[co] * inv : 1.0f);
         d.wt_pack[i] = f2bf(v);
       }
     }
@@ -270,6 +310,7 @@ extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_e
   int gx = grid_for(max_elems, 1024, 64);
   if (observe) hipLaunchKernelGGL(k_wprep_minmax, dim3(gx, nlayers), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(k_wprep_observe, dim3((nlayers + 63) / 64), dim3(64), 0, s, descs, nlayers, rule127, observe);
+  hipLaunchKernelGGL(k_wprep_scales, dim3(nlayers), dim3(256), 0, s, descs, rule127, observe);
   hipLaunchKernelGGL(k_wprep_pack, dim3(gx, nlayers), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(k_wprep_wsum, dim3(32, nlayers), dim3(256), 0, s, descs);
   return frost_check_launch("weight_prep");
@@ -292,17 +333,17 @@ extern "C" int frost_stats_init_table(void* stats, const int32_t* cpads, const i
 __global__ __launch_bounds__(256) void k_conv_finalize(const uint8_t* stats, int64_t count, int cout, int cpad,
                                                        const float* qx, const float* qw, const float* gamma,
                                                        const float* beta, float* rmean, float* rvar, int64_t* nbt,
-                                                       int training, int relu, int observe, int have_stats, float* coef, float* qy) {
+                                                       int training, int relu, int observe, int have_stats, float* coef, float* qy, const float* wscale) {
   __shared__ float sh[8];
-  conv_finalize_dev(stats, count, cout, cpad, qx, qw, gamma, beta, rmean, rvar, nbt, training, relu, observe, have_stats, coef, qy,
+  conv_finalize_dev(stats, count, cout, cpad, qx, qw, wscale, gamma, beta, rmean, rvar, nbt, training, relu, observe, have_stats, coef, qy,
                     threadIdx.x, 256, sh);
 }
 extern "C" int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
                                    const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt,
-                                   int training, int relu, int observe, float* coef, float* qrec_y, void* stream) {
+                                   int training, int relu, int observe, float* coef, float* qrec_y, const float* wscale, void* stream) {
   int cpad = round_up(cout, 16);
   hipLaunchKernelGGL(k_conv_finalize, dim3(1), dim3(256), 0, as_stream(stream), (const uint8_t*)stats, count, cout, cpad,
-                     qrec_x, qrec_w, gamma, beta, rmean, rvar, nbt, training, relu, observe, stats ? 1 : 0, coef, qrec_y);
+                     qrec_x, qrec_w, gamma, beta, rmean, rvar, nbt, training, relu, observe, stats ? 1 : 0, coef, qrec_y, wscale);
   return frost_check_launch("conv_finalize");
 }
 
@@ -325,8 +366,8 @@ __global__ __launch_bounds__(256) void k_cat_requant(const int8_t* __restrict__ 
     int i = threadIdx.x;   // i = stored byte as unsigned; offset-binary index q = (int8)i + 128
     int q = (int)(int8_t)i + 128;
     float va = (float)(q - A.zp) * A.scale, vb = (float)(q - B.zp) * B.scale;
-    lut[0][i] = (uint8_t)((fq_index(va, Y.inv, Y.zp, 0, 255) - 128) & 255);
-    lut[1][i] = (uint8_t)((fq_index(vb, Y.inv, Y.zp, 0, 255) - 128) & 255);
+    lut[0][i] = (uint8_t)((fq_index(va, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
+    lut[1][i] = (uint8_t)((fq_index(vb, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
   }
   __syncthreads();
   int cy = ca + cb; int dpp = cy >> 2;           // dwords per pixel (channels multiple of 4)
@@ -394,7 +435,7 @@ __global__ __launch_bounds__(256) void k_add_requant(const int8_t* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float v = add_val((int)(int8_t)(va >> (8 * e)), (int)(int8_t)(vb >> (8 * e)), A, B);
-      o |= ((uint32_t)((fq_index(v, Y.inv, Y.zp, 0, 255) - 128) & 255)) << (8 * e);
+      o |= ((uint32_t)((fq_index(v, Y.inv, Y.zp, 0, Y.hi) - 128) & 255)) << (8 * e);
     }
     ((uint32_t*)y)[i] = o;
   }

@@ -9,7 +9,10 @@
 template <typename TA, typename TB, int KD>
 __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
                                                int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
-                                               float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate) {
+                                               float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate,
+                                               const float* __restrict__ nscale, const float* __restrict__ kscale) {
+  // nscale[n] multiplies output column n, kscale[k] multiplies B(k, .) on load: the per-output-channel weight scales of a per-channel
+  // fake-quantised classifier (forward: column = class; data gradient: k = class)
   // split-K: gridDim.z workgroups share an output tile, each over a K range (multiple of 16), combined with fp32 atomics into a zeroed C
   const int ksplit = gridDim.z;
   const int kchunk = ((K + ksplit - 1) / ksplit + KD - 1) / KD * KD;
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
     for (int q = 0; q < NQ; ++q) {
       pa[q] = (m0 + ar[q] < M && k0 + ak[q] < kend) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
       pb[q] = (n0 + br[q] < N && k0 + bk[q] < kend) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
+      if (kscale && k0 + bk[q] < kend) pb[q] *= kscale[k0 + bk[q]];
     }
   };
   fetch(kbeg);
@@ -68,6 +72,7 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
         const int m = m0 + wm * 32 + i * 16 + 4 * lk + r, n = n0 + wn * 32 + j * 16 + l16;
         if (m < M && n < N) {
           float v = acc[i][j][r] * al;
+          if (nscale) v *= nscale[n];
           if (ksplit > 1) { if (bias && blockIdx.z == 0) v += bias[n]; atomicAdd(&c[(int64_t)m * N + n], v); }
           else { if (bias) v += bias[n]; if (accumulate) v += c[(int64_t)m * N + n]; c[(int64_t)m * N + n] = v; }
         }
@@ -77,13 +82,13 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
 // split K so that >= 256 workgroups run (C is zeroed by a memset node first)
 template <typename TA, typename TB>
 static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, const TB* b, int64_t brs, int64_t bcs, int M, int N, int K,
-                         const float* alpha_ptr, const float* bias, float* c, bool split_ok) {
+                         const float* alpha_ptr, const float* bias, float* c, bool split_ok, const float* nscale = nullptr, const float* kscale = nullptr) {
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
   int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible)
   while (split_ok && ks < 8 && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
   if (ks > 1) (void)hipMemsetAsync(c, 0, (size_t)M * N * sizeof(float), s);
-  if (K / ks >= 256) hipLaunchKernelGGL((k_sgemm<TA, TB, 64>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
-  else hipLaunchKernelGGL((k_sgemm<TA, TB, 16>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0);
+  if (K / ks >= 256) hipLaunchKernelGGL((k_sgemm<TA, TB, 64>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
+  else hipLaunchKernelGGL((k_sgemm<TA, TB, 16>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
 }
 extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
   launch_sgemm<float, float>(as_stream(stream), x, (int64_t)k, (int64_t)1, w, (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, bias, y, false);
@@ -91,8 +96,9 @@ extern "C" int frost_linear_f32(const float* x, const float* w, const float* bia
 }
 // classifier forward: y[n][o] = s_w * sum_k x[n][k] * wq[o][k] + bias[o]   (frostnet.py:299 on fake-quantised weights)
 extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n,
-                                    int cin, int nclass, float* y, void* stream) {
-  launch_sgemm<float, int8_t>(as_stream(stream), x, (int64_t)cin, (int64_t)1, wq, (int64_t)1, (int64_t)cin, n, nclass, cin, qrec_w + FROST_Q_SCALE, bias, y, false);
+                                    int cin, int nclass, float* y, const float* wscale, void* stream) {
+  launch_sgemm<float, int8_t>(as_stream(stream), x, (int64_t)cin, (int64_t)1, wq, (int64_t)1, (int64_t)cin, n, nclass, cin,
+                              wscale ? nullptr : qrec_w + FROST_Q_SCALE, bias, y, false, wscale, nullptr);
   return frost_check_launch("classifier_fwd");
 }
 
@@ -117,12 +123,12 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ dpoo
 // dwq[nclass][cin] = dlogits^T . pooled ; dbias = colsum(dlogits); gx = (dlogits . wq * s_w) * drop / hw
 extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, const int8_t* wq, const float* qrec_w,
                               int n, int cin, int nclass, int hw, const float* drop_mask, float* dwq, float* dbias,
-                              uint16_t* gx, float* scratch_dpool, void* stream) {
+                              uint16_t* gx, float* scratch_dpool, const float* wscale, void* stream) {
   hipStream_t s = as_stream(stream);
   launch_sgemm<float, float>(s, dlogits_masked, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dwq, true);
   hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
-  launch_sgemm<float, int8_t>(s, dlogits_masked, (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass, qrec_w + FROST_Q_SCALE,
-                              (const float*)nullptr, scratch_dpool, true);
+  launch_sgemm<float, int8_t>(s, dlogits_masked, (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass,
+                              wscale ? nullptr : qrec_w + FROST_Q_SCALE, (const float*)nullptr, scratch_dpool, true, nullptr, wscale);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("head_bwd");
@@ -155,8 +161,8 @@ __global__ __launch_bounds__(256) void k_cat_bwd(const uint16_t* __restrict__ gy
   {
     QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
     int i = threadIdx.x; int q = (int)(int8_t)i + 128; bool ia, ib;
-    fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, 255, &ia);
-    fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, 255, &ib);
+    fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, Y.hi, &ia);
+    fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, Y.hi, &ib);
     ok[0][i] = ia; ok[1][i] = ib;
   }
   __syncthreads();
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void k_add_bwd(const uint16_t* __restrict__ gy
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = (float)((int)(int8_t)(va >> (8 * r)) + 128 - A.zp) * A.scale + (float)((int)(int8_t)(vb >> (8 * r)) + 128 - B.zp) * B.scale;
-      bool inr; fq_index(v, Y.inv, Y.zp, 0, 255, &inr);
+      bool inr; fq_index(v, Y.inv, Y.zp, 0, Y.hi, &inr);
       if (!inr) g[r] = 0.0f;
     }
     acc_store4(ga + i * 4, g, acc_a);
@@ -216,12 +222,13 @@ extern "C" int frost_add_bwd(const uint16_t* gy, const int8_t* a, const float* q
 __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict__ dwq, const float* __restrict__ w,
                                                         const float* gamma, const float* rvar_saved_sigma, const float* qw,
                                                         const float* coef, int cout, int per, int cpad, float* __restrict__ dw,
-                                                        float* dgamma, float* dbeta, int accumulate) {
-  const float inv = 1.0f / qw[FROST_Q_SCALE];
+                                                        float* dgamma, float* dbeta, int accumulate, const float* wscale) {
+  const float inv0 = 1.0f / qw[FROST_Q_SCALE];
   const int lane = threadIdx.x & 63;
   for (int co = blockIdx.x * 4 + (threadIdx.x >> 6); co < cout; co += gridDim.x * 4) {
     float sf = 1.0f, sigr = 1.0f;
     if (gamma) { sigr = rvar_saved_sigma[co]; sf = gamma[co] / sigr; }
+    const float inv = wscale ? 1.0f / wscale[co] : inv0;
     float dot = 0.0f;
     for (int r = lane; r < per; r += 64) {
       const int64_t idx = (int64_t)co * per + r;
@@ -242,11 +249,12 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
 // the same for a table of layers in ONE launch (blockIdx.y = layer): 70 finalize launches of ~6.6 us each were 1.4 % of a step
 __global__ __launch_bounds__(256) void k_wgrad_finalize_table(const FrostGDesc* __restrict__ descs) {
   const FrostGDesc d = descs[blockIdx.y];
-  const float inv = 1.0f / d.qw[FROST_Q_SCALE];
+  const float inv0 = 1.0f / d.qw[FROST_Q_SCALE];
   const int lane = threadIdx.x & 63;
   for (int co = blockIdx.x * 4 + (threadIdx.x >> 6); co < d.cout; co += gridDim.x * 4) {
     float sf = 1.0f, sigr = 1.0f;
     if (d.gamma) { sigr = d.sigma_r[co]; sf = d.gamma[co] / sigr; }
+    const float inv = d.wscale ? 1.0f / d.wscale[co] : inv0;
     float dot = 0.0f;
     for (int r = lane; r < d.per; r += 64) {
       const int64_t idx = (int64_t)co * d.per + r;
@@ -269,10 +277,10 @@ extern "C" int frost_weight_grad_finalize_table(const FrostGDesc* descs, int nla
 // sigma_r[c] = sqrt(running_var + eps) must be the value used in THIS step's forward (saved before the update).
 extern "C" int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,
                                           const float* qrec_w, const float* coef, int cout, int cin_g, int kk, int cpad,
-                                          float* dw, float* dgamma, float* dbeta, int accumulate, void* stream) {
+                                          float* dw, float* dgamma, float* dbeta, int accumulate, const float* wscale, void* stream) {
   int grid = (cout + 3) / 4; if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(k_wgrad_finalize, dim3(grid), dim3(256), 0, as_stream(stream), dwq, w, gamma, sigma_r, qrec_w, coef, cout,
-                     cin_g * kk, cpad, dw, dgamma, dbeta, accumulate);
+                     cin_g * kk, cpad, dw, dgamma, dbeta, accumulate, wscale);
   return frost_check_launch("weight_grad_finalize");
 }
 // save sigma_r = sqrt(rv+eps) for a list of layers BEFORE the forward updates running_var (one launch)
@@ -289,7 +297,7 @@ extern "C" int frost_save_sigma(const FrostWDesc* descs, float* const* outs, int
 // logits fake-quant backward mask applied to dlogits:  g *= [0 <= rint(raw*inv)+zp <= 255]
 __global__ __launch_bounds__(256) void k_mask_logits(const float* __restrict__ g, const float* __restrict__ raw, const float* qy, int64_t n, float* __restrict__ out) {
   QP Y = load_qp(qy);
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { bool inr; fq_index(raw[i], Y.inv, Y.zp, 0, 255, &inr); out[i] = inr ? g[i] : 0.0f; }
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) { bool inr; fq_index(raw[i], Y.inv, Y.zp, 0, Y.hi, &inr); out[i] = inr ? g[i] : 0.0f; }
 }
 extern "C" int frost_mask_logits(const float* g, const float* raw, const float* qrec_y, int64_t n, float* out, void* stream) {
   int64_t grid = (n + 255) / 256; if (grid > 2048) grid = 2048;

@@ -212,12 +212,13 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   if (!BF) zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   if (MODE == M_DGRAD && p.qw) sw = p.qw[FROST_Q_SCALE];
   if (MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) { y_inv = 1.0f / p.qy[FROST_Q_SCALE]; y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]); }
+  const float qcap = (MODE == M_EMIT) ? (float)q_hi(p.qy) : 255.0f; const bool lowq = qcap < 255.0f;      // 7-bit activations (reduce_range): cvt_pk_u8 saturates at 255 only
   if (MODE == M_EMIT && p.cvt) y_inv = 1.0f;           // row A already is the requantisation scale s_x*s_w/s_y, row B carries the int32 bias bits
   float t_lo = 0.0f, t_hi = 0.0f;            // STE pass window in t = y/scale:  t_lo < t <= t_hi
   if (MODE == M_BRED || MODE == M_BDC) {
-    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]);
-    const float hi0 = 255.5f - (float)zpy;                                        // rint(hi0) ties to the even neighbour
-    t_hi = ((255 - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
+    const float hi0 = (float)qhi + 0.5f - (float)zpy;                             // rint(hi0) ties to the even neighbour
+    t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
     if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
   }
 
@@ -452,7 +453,9 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
                 // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
                 // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
                 const float yv = p.cvt ? (float)(acci[m][t][r] + __float_as_int(B[r])) * A[r] : fmaf(A[r], (float)acci[m][t][r], B[r]);
-                packed = __builtin_amdgcn_cvt_pk_u8_f32(rintf(yv * y_inv) + y_zpf, r, packed);
+                float qv = rintf(yv * y_inv) + y_zpf;
+                if (lowq) qv = fminf(qv, qcap);
+                packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
               }
               if (o_lds) { if (chok) *(uint32_t*)(gcur + prow * p.cout + ch0) = packed ^ 0x80808080u; }
               else if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       int* sflag = (int*)smem;
       if (last_block_done(p.fin.counter, p.fin_total, sflag)) {
         float* sh = (float*)(smem + 16);
-        conv_finalize_dev(p.stats, p.npix, p.cout, p.cpad, p.qx, p.fin.qrec_w, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+        conv_finalize_dev(p.stats, p.npix, p.cout, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
                           p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 512, sh);
       }
     }

@@ -75,6 +75,7 @@ class QArena:
         self.t[:, L.Q_ZP] = 0.0
         self.t[:, L.Q_FQMIN] = 0.0
         self.t[:, L.Q_FQMAX] = 0.0
+        self.t[:, L.Q_QMAX] = 255.0        # activation index range 0..255 (127 under the fbgemm qconfig's reduce_range; set at bind time)
         ti = self.t.view(torch.int32)
         ti[:, L.Q_OBS_EN] = 1          # observer_enabled / fake_quant_enabled (8 bytes each, aliased by the torch buffers)
         ti[:, L.Q_FQ_EN] = 1
@@ -122,6 +123,9 @@ class ConvLayer:
             self.kpad, nb, self.wt_pack = 0, self.cout * self.cin_g, None
         self.wq_pack = torch.zeros(nb + 64, dtype=torch.int8, device=dev)
         self.wsum = torch.zeros(self.cpad, dtype=torch.int32, device=dev)
+        self.wscale = torch.ones(self.cpad, dtype=torch.float32, device=dev)     # weight scale per output channel (per-tensor mode: replicated)
+        self.wmin = self.wmax = None      # per-channel observer state (MovingAveragePerChannelMinMaxObserver), bound by the runner
+        self.per_channel = False
         self.minmax2 = torch.tensor([float("inf"), float("-inf")], dtype=torch.float32, device=dev)
         self.coef = torch.zeros(L.COEF_ROWS, self.cpad, dtype=torch.float32, device=dev)
         self.sigma = torch.ones(self.cout, dtype=torch.float32, device=dev)
@@ -137,6 +141,9 @@ class ConvLayer:
         d.qrec, d.wq_pack, d.wsum, d.minmax2 = self.qw.data_ptr(), self.wq_pack.data_ptr(), self.wsum.data_ptr(), \
             self.minmax2.data_ptr()
         d.wt_pack = self.wt_pack.data_ptr() if self.wt_pack is not None else None
+        d.wscale = self.wscale.data_ptr()
+        d.wmin, d.wmax = (self.wmin.data_ptr(), self.wmax.data_ptr()) if self.per_channel else (None, None)
+        d.reserved1 = 1 if self.per_channel else 0
         d.cout, d.cin_g, d.kk, d.kind = self.cout, self.cin_g, self.kk, self.KIND_ID[self.kind]
         d.cpad, d.kpad = self.cpad, self.kpad
         d.reserved0 = 1 if getattr(self, "fold_rsqrt", False) else 0      # convert-time BN fold (gamma * rsqrt) instead of the QAT one
@@ -263,7 +270,8 @@ class Engine:
         if need_stats and _FIN_FOLD:
             # statistics pass with the finalize folded into its last workgroup (two launches per conv forward instead of three)
             fin = L.FrostFinDesc(l.qw.data_ptr(), l.gamma.data_ptr(), l.beta.data_ptr(), l.rmean.data_ptr(), l.rvar.data_ptr(), l.nbt.data_ptr(),
-                                 l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0)
+                                 l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0,
+                                 l.wscale.data_ptr())
             nb = x.numel + l.wq_pack.numel()
             if l.kind in ("pw", "stem"):
                 call("frost_pw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin),
@@ -276,7 +284,7 @@ class Engine:
                 self._conv_launch(l, x, 0, None)
             call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
                  ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
-                 1 if observe else 0, ptr(l.coef), ptr(l.qy), stream())
+                 1 if observe else 0, ptr(l.coef), ptr(l.qy), ptr(l.wscale), stream())
         self._conv_launch(l, x, 1, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
@@ -329,7 +337,8 @@ class Engine:
         pooled = torch.empty(n, c, dtype=torch.float32, device=self.device)
         call("frost_avgpool", ptr(x.buf), ptr(x.q), n, x.h * x.w, c, ptr(drop_mask), ptr(pooled), stream())
         raw = torch.empty(n, l.cout, dtype=torch.float32, device=self.device)
-        call("frost_classifier_fwd", ptr(pooled), ptr(l.wq_pack), ptr(l.qw), ptr(l.bias), n, c, l.cout, ptr(raw), stream())
+        call("frost_classifier_fwd", ptr(pooled), ptr(l.wq_pack), ptr(l.qw), ptr(l.bias), n, c, l.cout, ptr(raw),
+             ptr(l.wscale) if l.per_channel else None, stream())
         if observe:
             if not hasattr(self, "_head_mm"):
                 self._head_mm = torch.empty(2, dtype=torch.float32, device=self.device)
@@ -338,7 +347,7 @@ class Engine:
             call("frost_observer_update", ptr(l.qy), ptr(self._head_mm), 0, 0, 1, stream())
         logits = torch.empty_like(raw)
         self.last_raw = raw              # pre-fake-quant classifier output (tests: the north-star 1e-3 comparison point)
-        call("frost_fake_quant_f32", ptr(raw), raw.numel(), ptr(l.qy), 0, 255, ptr(logits), None, stream())
+        call("frost_fake_quant_f32", ptr(raw), raw.numel(), ptr(l.qy), 0, getattr(self, "act_qmax", 255), ptr(logits), None, stream())
         self.tape.append(("head", l, x, pooled, raw, drop_mask))
         return logits
 
@@ -416,9 +425,9 @@ class Engine:
                 dpool = torch.empty_like(pooled)
                 self._ensure_grad(l)
                 call("frost_head_bwd", ptr(g), ptr(pooled), ptr(l.wq_pack), ptr(l.qw), x.n, x.c, l.cout, x.h * x.w,
-                     ptr(drop), ptr(dwq), ptr(l.bias.grad), ptr(gx), ptr(dpool), stream())
+                     ptr(drop), ptr(dwq), ptr(l.bias.grad), ptr(gx), ptr(dpool), ptr(l.wscale) if l.per_channel else None, stream())
                 call("frost_weight_grad_finalize", ptr(dwq), ptr(l.w), None, None, ptr(l.qw), ptr(l.coef), l.cout,
-                     l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0, stream())
+                     l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0, ptr(l.wscale), stream())
                 if self.on_layer_grads is not None:
                     self.on_layer_grads(l)
                 if boundaries is not None and id(l) in boundaries:
@@ -495,7 +504,7 @@ class Engine:
             for i, l in enumerate(self._pending):
                 arr[i] = L.FrostGDesc(l.dwq.data_ptr(), l.w.data_ptr(), l.gamma.data_ptr(), l.sigma.data_ptr(), l.qw.data_ptr(),
                                       l.coef.data_ptr(), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr(),
-                                      l.cout, l.cin_g * l.kk, l.cpad, 0)
+                                      l.cout, l.cin_g * l.kk, l.cpad, 0, l.wscale.data_ptr())
             cache[slot] = (key, L.struct_to_tensor(arr, self.device))
         call("frost_weight_grad_finalize_table", ptr(cache[slot][1]), len(self._pending), stream())
         self._pending = []
@@ -576,7 +585,8 @@ class Engine:
                      prof=("dw_wgrad", 2 * y.numel + x.numel))
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
-                call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc, s,
+                call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc,
+                     ptr(l.wscale) if l.per_channel else None, s,
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))
         self._after_conv_backward(l, s)
         y.grad = None
@@ -586,7 +596,7 @@ class Engine:
             self._pending.append(l)        # single GPU: all layers finalized by one table launch at the end of the backward
         else:
             call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
-                 l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, s)
+                 l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, ptr(l.wscale), s)
 
 
 def grad_to_float(g, n, h, w, c):

@@ -117,19 +117,35 @@ class FrostRunner:
         return sig == self._sig
 
     # ------------------------------------------------------------------------------------------ binding
-    def _bind_fq(self, fq, rec):
-        """Copy the module's current observer/qparam values into the qrecord, then alias the buffers onto it."""
+    @staticmethod
+    def _is_per_channel(fq):
+        return getattr(fq, "qscheme", None) in (torch.per_channel_symmetric, torch.per_channel_affine)
+
+    def _bind_weight_per_channel(self, fq, rec, layer):
+        """Weight FakeQuantize with a MovingAveragePerChannelMinMaxObserver (qint8, per_channel_symmetric, ch_axis 0 -- the reference's
+        'fbgemm' qconfig, Classification/latency_check.py:221-226): min_val / max_val / scale are [cout] vectors, aliased onto the layer's
+        device arrays; zero_point is all zeros; the enable flags live in the qrecord like everywhere else."""
         obs = fq.activation_post_process
+        if getattr(obs, "ch_axis", 0) != 0:
+            raise NotImplementedError("per-channel weight quantisation along ch_axis != 0")
+        dev, cout = layer.w.device, layer.cout
+        layer.per_channel = True
+        layer.wmin = torch.full((cout,), float("inf"), dtype=torch.float32, device=dev)
+        layer.wmax = torch.full((cout,), float("-inf"), dtype=torch.float32, device=dev)
         with torch.no_grad():
-            rec[L.Q_MIN] = obs.min_val.reshape(-1)[0].float() if obs.min_val.numel() else float("inf")
-            rec[L.Q_MAX] = obs.max_val.reshape(-1)[0].float() if obs.max_val.numel() else float("-inf")
-            rec[L.Q_SCALE] = fq.scale.reshape(-1)[0].float()
-            rec[L.Q_INV] = 1.0 / fq.scale.reshape(-1)[0].float()
-            rec.view(torch.int32)[L.Q_ZP] = fq.zero_point.reshape(-1)[0].to(torch.int32)
-        # torch.quantization.disable_observer / enable_observer / disable_fake_quant (the helpers at Classification/train.py:27-33,
-        # evaluate.py:131-143) write 0/1 into the module's `observer_enabled` / `fake_quant_enabled` buffers.  Those buffers are
-        # aliased onto the qrecord like scale / zero_point, so the write lands in device memory and the kernels test the site's own
-        # flag: per-module granularity, no instance patching (deepcopy / pickling of the model stay intact), no host round trip.
+            if obs.min_val.numel() == cout:
+                layer.wmin.copy_(obs.min_val.float())
+                layer.wmax.copy_(obs.max_val.float())
+            if fq.scale.numel() == cout:
+                layer.wscale[:cout].copy_(fq.scale.float())
+                rec[L.Q_SCALE] = fq.scale.float().max()
+        self._alias_flags(fq, rec)
+        fq._buffers["scale"] = layer.wscale[:cout]
+        fq._buffers["zero_point"] = torch.zeros(cout, dtype=torch.int32, device=dev)
+        obs._buffers["min_val"], obs._buffers["max_val"] = layer.wmin, layer.wmax
+        return rec
+
+    def _alias_flags(self, fq, rec):
         for name, slot in (("observer_enabled", L.Q_OBS_EN), ("fake_quant_enabled", L.Q_FQ_EN)):
             buf = fq._buffers[name]
             ri = rec.view(torch.int32)
@@ -142,6 +158,25 @@ class FrostRunner:
                 fq._buffers[name] = rec.view(torch.uint8)[4 * slot:4 * slot + 1]
             else:
                 fq._buffers[name] = ri[slot:slot + 1].view(buf.dtype) if buf.element_size() == 4 else buf
+
+    def _bind_fq(self, fq, rec):
+        """Copy the module's current observer/qparam values into the qrecord, then alias the buffers onto it."""
+        obs = fq.activation_post_process
+        if fq.dtype == torch.quint8:                     # activation site: index range 0..quant_max (127 with reduce_range)
+            with torch.no_grad():
+                rec[L.Q_QMAX] = float(fq.quant_max)
+            self.E.act_qmax = int(fq.quant_max)
+        with torch.no_grad():
+            rec[L.Q_MIN] = obs.min_val.reshape(-1)[0].float() if obs.min_val.numel() else float("inf")
+            rec[L.Q_MAX] = obs.max_val.reshape(-1)[0].float() if obs.max_val.numel() else float("-inf")
+            rec[L.Q_SCALE] = fq.scale.reshape(-1)[0].float()
+            rec[L.Q_INV] = 1.0 / fq.scale.reshape(-1)[0].float()
+            rec.view(torch.int32)[L.Q_ZP] = fq.zero_point.reshape(-1)[0].to(torch.int32)
+        # torch.quantization.disable_observer / enable_observer / disable_fake_quant (the helpers at Classification/train.py:27-33,
+        # evaluate.py:131-143) write 0/1 into the module's `observer_enabled` / `fake_quant_enabled` buffers.  Those buffers are
+        # aliased onto the qrecord like scale / zero_point, so the write lands in device memory and the kernels test the site's own
+        # flag: per-module granularity, no instance patching (deepcopy / pickling of the model stay intact), no host round trip.
+        self._alias_flags(fq, rec)
         fq._buffers["scale"] = rec[L.Q_SCALE:L.Q_SCALE + 1]
         fq._buffers["zero_point"] = rec.view(torch.int32)[L.Q_ZP:L.Q_ZP + 1]
         obs._buffers["min_val"] = rec[L.Q_MIN]
@@ -151,11 +186,14 @@ class FrostRunner:
     def _conv_layer(self, name, blk, kind):
         m = blk.conv[0]   # nniqat.ConvBnReLU2d / ConvBn2d
         relu = type(m).__name__ == "ConvBnReLU2d"
-        qw = self._bind_fq(m.weight_fake_quant, self.qa.alloc())
+        pc = self._is_per_channel(m.weight_fake_quant)
+        qw = self.qa.alloc() if pc else self._bind_fq(m.weight_fake_quant, self.qa.alloc())
         qy = self._bind_fq(m.activation_post_process, self.qa.alloc())
         self.rule127 = self.rule127 or _is_fused_fq(m.weight_fake_quant)
         l = ConvLayer(name, kind, m.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var,
                       m.bn.num_batches_tracked, None, m.kernel_size[0], m.stride[0], relu, qw, qy)
+        if pc:
+            self._bind_weight_per_channel(m.weight_fake_quant, qw, l)
         l.bn_mod = m.bn
         return self.E.add_layer(l)
 
@@ -203,10 +241,13 @@ class FrostRunner:
         self.cls = None
         if hasattr(m, "classifier"):
             c = m.classifier[2]
-            qw = self._bind_fq(c.weight_fake_quant, self.qa.alloc())
+            pc = self._is_per_channel(c.weight_fake_quant)
+            qw = self.qa.alloc() if pc else self._bind_fq(c.weight_fake_quant, self.qa.alloc())
             qy = self._bind_fq(c.activation_post_process, self.qa.alloc())
             self.cls = self.E.add_layer(ConvLayer("classifier.2", "cls", c.weight, None, None, None, None, None, c.bias,
                                                   1, 1, False, qw, qy))
+            if pc:
+                self._bind_weight_per_channel(c.weight_fake_quant, qw, self.cls)
             self.drop_rate = float(m.classifier[1].p)
         self._bind_extra()
         self.E.rule127 = 1 if self.rule127 else 0
@@ -259,6 +300,9 @@ class FrostRunner:
         pooled features are not re-quantised; the two differ by 8-25 % of the activations' indices, see tests/test_gpu_convert.py)."""
         if self.cls is None:
             raise NotImplementedError("convert() is implemented for the classification model")
+        if any(l.per_channel for l in self.E.layers):
+            raise NotImplementedError("convert() restates the QNNPACK kernels (per-tensor weights); a per-channel (fbgemm qconfig) model "
+                                      "runs the fake-quant graph only")
         with torch.cuda.device(self.device):
             self.E.prepare_converted(observe=True)         # per-site observer flags still decide on the device
         self.converted = True

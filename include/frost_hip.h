@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FROST_ABI_VERSION 1
+#define FROST_ABI_VERSION 2
 
 /* qrecord field indices (floats) */
 #define FROST_Q_MIN 0
@@ -35,7 +35,7 @@ extern "C" {
 #define FROST_Q_FQMIN 4
 #define FROST_Q_FQMAX 5
 #define FROST_Q_INV 6
-#define FROST_Q_RESERVED 7
+#define FROST_Q_QMAX 7    /* float: upper index of an ACTIVATION site, 255 (qnnpack) or 127 (fbgemm qconfig: reduce_range); 0 = 255 */
 #define FROST_Q_OBS_EN 8   /* 8 bytes (slots 8-9): FakeQuantize.observer_enabled, aliased by the torch buffer (uint8[1] or int64[1]);
                               kernels test the low 32-bit word != 0, so torch.quantization.disable_observer on ANY sub-module is
                               honoured per site without a host round trip (torch/ao/quantization/fake_quantize.py:170-184) */
@@ -94,11 +94,14 @@ typedef struct FrostWDesc {
   int8_t* wq_pack;       /* packed int8 weights, layout by `kind`                           */
   int32_t* wsum;         /* [cpad] sum_k wq                                                 */
   float* minmax2;        /* scratch {min,max}                                               */
-  uint16_t* wt_pack;     /* bf16 transposed pack for dgrad (pw only, may be NULL)           */
+  uint16_t* wt_pack;     /* bf16 transposed pack for dgrad (pw only, may be NULL): wq * (wscale[co] / qrec.scale)   */
+  float* wscale;         /* [cpad] weight scale PER OUTPUT CHANNEL, always filled: per-tensor mode replicates qrec.scale  */
+  float* wmin; float* wmax;   /* [cout] per-channel observer state (MovingAveragePerChannelMinMaxObserver); NULL per-tensor */
   int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem(3x3 dense cin<=4), 3 classifier */
   int32_t cpad, kpad;
   int32_t reserved0;   /* fold mode: 0 = gamma / sqrt(var+eps) (QAT forward), 1 = gamma * rsqrt(var+eps) (convert: fuse_conv_bn_weights) */
-  int32_t reserved1;
+  int32_t reserved1;   /* 1 = per-channel symmetric weight quantisation (the reference's 'fbgemm' qconfig of its latency_check scripts):
+                          scale per output channel, qrec.scale = the largest of them (the scalar the data-gradient kernels apply)  */
 } FrostWDesc;
 int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe, void* stream);
 
@@ -122,7 +125,8 @@ int frost_stem_wgrad_remap(const float* dwq_col, int cout, int cin_g, float* dwq
  * the activation observer + qparams (conv_fused.py:153-157, fake_quantize.py:229-240).  One launch per layer. */
 int frost_conv_finalize(const void* stats, int64_t count, int cout, const float* qrec_x, const float* qrec_w,
                         const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
-                        int relu, int observe, float* coef, float* qrec_y, void* stream);
+                        int relu, int observe, float* coef, float* qrec_y, const float* wscale, void* stream);
+/* (wscale: [cpad] per-output-channel weight scales, FrostWDesc.wscale; NULL = the scalar of qrec_w) */
 
 /* ---- cat / add ------------------------------------------------------------------------------------------ */
 /* replaces: FloatFunctional.cat + its FakeQuantize (frostnet.py:129) */
@@ -140,7 +144,7 @@ int frost_avgpool(const int8_t* x, const float* qrec_x, int n, int hw, int c, co
                   void* stream);
 /* y[n][nclass] = x[n][cin] . wq^T * s_w + bias  (fp32, weights int8 fake-quantised) */
 int frost_classifier_fwd(const float* x, const int8_t* wq, const float* qrec_w, const float* bias, int n, int cin,
-                         int nclass, float* y, void* stream);
+                         int nclass, float* y, const float* wscale, void* stream);
 
 /* ---- backward ------------------------------------------------------------------------------------------- */
 /* pass 0: S1=sum gy, S2=sum gy*xhat (into coef rows S1,S2); pass 1: write dc (bf16 [npix][cout]) and
@@ -172,20 +176,21 @@ int frost_dw_conv_bwd_dc_wgrad(const int8_t* x, const float* qrec_x, const int8_
                                const float* qrec_w, int n, int h, int w, int c, int k, int stride, float* coef,
                                const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, float* dwq, void* stream);
 int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_w, int n, int h, int w, int c, int k,
-                   int stride, uint16_t* dx, int accumulate, void* stream);
+                   int stride, uint16_t* dx, int accumulate, const float* wscale, void* stream);
 int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                    int stride, float* dwq, void* stream);
 /* fold-path: dW = dWq*mask*sf ; dgamma = S2*vfrac + sum(dWq*mask*W)/sigma_r ; dbeta = S1  (SURVEY H-5) */
 /* sigma_r[c] = sqrt(running_var+eps) as used by THIS step's forward (frost_save_sigma runs before the update) */
 int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,
                                const float* qrec_w, const float* coef, int cout, int cin_g, int kk, int cpad,
-                               float* dw, float* dgamma, float* dbeta, int accumulate, void* stream);
+                               float* dw, float* dgamma, float* dbeta, int accumulate, const float* wscale, void* stream);
 /* the same for a table of layers in one launch (device-resident descriptors; single-GPU path, where nothing waits on
  * per-layer gradients; the data-parallel path keeps the per-layer call so the bucketed all-reduce can start early) */
 typedef struct FrostGDesc {
   const float* dwq; const float* w; const float* gamma; const float* sigma_r; const float* qw; const float* coef;
   float* dw; float* dgamma; float* dbeta;
   int32_t cout, per, cpad, reserved;
+  const float* wscale;   /* [cpad] per-output-channel weight scale (NULL = qw's scalar) */
 } FrostGDesc;
 int frost_weight_grad_finalize_table(const FrostGDesc* descs, int nlayers, void* stream);
 int frost_save_sigma(const FrostWDesc* descs, float* const* outs, int nlayers, void* stream);
@@ -198,7 +203,7 @@ int frost_add_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, cons
                   int64_t n, const float* qrec_y, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream);
 int frost_head_bwd(const float* dlogits_masked, const float* pooled, const int8_t* wq, const float* qrec_w, int n,
                    int cin, int nclass, int hw, const float* drop_mask, float* dwq, float* dbias, uint16_t* gx,
-                   float* scratch_dpool, void* stream);
+                   float* scratch_dpool, const float* wscale, void* stream);
 
 /* ---- GradBoost optimizers (optimizer.py:121-206, 264-359, 411-512, 564-667) ------------------------- */
 /* ---- bf16 inference of the float model (BASELINE.json config c2) ------------------------------------------- */
@@ -290,6 +295,7 @@ typedef struct {
   const float* qrec_w; const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;
   float* coef; float* qrec_y; uint32_t* counter;
   int32_t training, relu, observe, reserved;
+  const float* wscale;     /* [cpad] per-output-channel weight scale (FrostWDesc.wscale); NULL = qrec_w's scalar */
 } FrostFinDesc;
 int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
                           void* stats, const FrostFinDesc* fin, void* stream);

@@ -383,3 +383,57 @@ def test_g10_hswish(golden):
         mine = np.float32([qs.sd[a + ".scale"][0], qs.sd[a + ".zero_point"][0], qs.sd[a + ".activation_post_process.min_val"],
                            qs.sd[a + ".activation_post_process.max_val"]])
         assert np.array_equal(mine, g[f"s{step}_qp"]), (step, mine, g[f"s{step}_qp"])
+
+
+# ------------------------------------------------------------------------------------------ G12 per-channel / reduce_range (fbgemm qconfig)
+G12 = ["pw16_96", "dw5s1_144", "pw312_80_lin"]
+
+
+@pytest.mark.parametrize("name", G12)
+def test_g12_fbgemm_layer(golden, name):
+    """The reference's 'fbgemm' qconfig (Classification/latency_check.py:221-226), QAT flavour: per-channel symmetric weights
+    (MovingAveragePerChannelMinMaxObserver) + 7-bit affine activations; teacher-forced layer, 2 steps, forward + backward."""
+    g = golden("g12_fbgemm_" + name)
+    cin, cout, k, s, groups, H, N, xseed, gseed, relu, wseed = [int(v) for v in g["spec"]]
+    in_scale, in_zp = float(g["in_qp"][0]), int(g["in_qp"][1])
+    P, B = init_from_fixture(g, wseed, True)
+    P = {"L." + k_: v for k_, v in P.items()}
+    qs = O.QState({"L." + k_: v for k_, v in B.items()}, qconfig="fbgemm")
+    x = ((T(g["x_idx"].astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+    for step in range(2):
+        x.grad = None
+        for p in P.values():
+            p.grad = None
+        y = O.convbn_qat(P, qs, "L", x, s, (k - 1) // 2, groups, bool(relu), True)
+        y.backward(T(O.synth(tuple(y.shape), gseed + 50 * step)))
+        sd = qs.sd
+        a = "L.conv.0.activation_post_process"
+        idx = O.fq_index(y.detach(), sd[a + ".scale"][0], sd[a + ".zero_point"][0])
+        assert int(idx.max()) <= 127
+        assert np.array_equal(idx.numpy().astype(np.uint8), g[f"s{step}_yidx"])
+        for key, v in unpack_state(g, f"s{step}_sd/").items():
+            mine = sd.get("L." + key)
+            if mine is None:
+                assert key.endswith("enabled") or key.endswith("eps"), key
+                continue
+            np.testing.assert_allclose(mine.reshape(-1).double().numpy(), v.reshape(-1).double().numpy(), rtol=1e-6, atol=1e-7, err_msg=key)
+        np.testing.assert_allclose(x.grad.numpy(), g[f"s{step}_dx"], rtol=1e-4, atol=1e-6)
+        check_pack(P["L.conv.0.weight"].grad, g[f"s{step}_dw"])
+        np.testing.assert_allclose(P["L.conv.0.bn.weight"].grad.numpy(), g[f"s{step}_dgamma"], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(P["L.conv.0.bn.bias"].grad.numpy(), g[f"s{step}_dbeta"], rtol=1e-4, atol=1e-5)
+
+
+def fbgemm_eval_case(g):
+    B, R, tseed, xseed, wseed = [int(v) for v in g["spec"]]
+    cfg = O.net_cfg("small", 1.0)
+    P, _ = O.make_state(O.float_state_spec(cfg), wseed, True)
+    qs = O.QState(unpack_state(g, "pre_sd/"), qconfig="fbgemm")
+    return cfg, P, qs, T(O.synth((B, 3, R, R), xseed))
+
+
+def test_g12_fbgemm_small_eval(golden):
+    g = golden("g12_fbgemm_small_eval")
+    cfg, P, qs, x = fbgemm_eval_case(g)
+    with torch.no_grad():
+        y = O.frostnet_forward(P, qs, cfg, x, True, False)
+    np.testing.assert_allclose(y.numpy(), g["logits"], rtol=1e-5, atol=1e-6)

@@ -492,6 +492,59 @@ def g11_detection():
     save("g11_detection", **out)
 
 
+# ------------------------------------------------------------------------------------------ G12
+def g12_fbgemm():
+    """Per-channel mode = the reference's 'fbgemm' qconfig (Classification/latency_check.py:221-226), QAT flavour, version 0: activations quint8
+    affine with reduce_range (0..127), weights qint8 per_channel_symmetric with a MovingAveragePerChannelMinMaxObserver.  Teacher-forced
+    ConvBN(ReLU) layers (2 steps) and a whole FrostNet-Small eval forward after two training-mode forwards."""
+    ref, reg = refshim.load_frostnet()
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    specs = [("pw16_96", "cbr", 16, 96, 1, 1, 1, 12), ("dw5s1_144", "cbr", 144, 144, 5, 1, 144, 8), ("pw312_80_lin", "cb", 312, 80, 1, 1, 1, 6)]
+    for i, (name, kind, cin, cout, k, s, groups, H) in enumerate(specs):
+        cls = ref.ConvBNReLU if kind == "cbr" else ref.ConvBN
+        m = cls(cin, cout, k, s, (k - 1) // 2, 1, groups)
+        keys, shapes, ndims = load_synth(m, 3600 + 20 * i)
+        m.train()
+        m.fuse_model()
+        m.qconfig = get_default_qat_qconfig("fbgemm", version=0)
+        prepare_qat(m, inplace=True)
+        fused = m.conv[0]
+        in_scale, in_zp = 0.0462, (0 if i % 2 == 0 else 58)                 # 7-bit input indices (0..127)
+        xi = np.clip(np.round(synth((2, cin, H, H), 1360 + i) * 20 + 64 + (0 if in_zp else -30)), 0, 127)
+        x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+        outs = {}
+        for step in range(2):
+            x.grad = None
+            m.zero_grad()
+            y = m(x)
+            g = T(synth(tuple(y.shape), 1370 + i + 50 * step))
+            y.backward(g)
+            outs[f"s{step}_yidx"] = fq_idx(y, fused.activation_post_process).to(torch.uint8)
+            outs[f"s{step}_dx"] = x.grad.clone()
+            outs[f"s{step}_dw"] = grad_pack(fused.weight.grad)
+            outs[f"s{step}_dgamma"] = fused.bn.weight.grad.clone()
+            outs[f"s{step}_dbeta"] = fused.bn.bias.grad.clone()
+            outs.update(sd_np(m.state_dict(), f"s{step}_sd/"))
+        save(f"g12_fbgemm_{name}", spec=np.array([cin, cout, k, s, groups, H, 2, 1360 + i, 1370 + i, int(kind == "cbr"), 3600 + 20 * i]),
+             in_qp=np.array([in_scale, in_zp]), x_idx=xi.astype(np.uint8), init_keys=keys, init_shapes=shapes, init_ndims=ndims, **outs)
+    net = reg["frostnet_quant_small_1_0"](drop_rate=0.0)
+    load_synth(net, 5000)
+    net.train()
+    net.fuse_model()
+    net.qconfig = get_default_qat_qconfig("fbgemm", version=0)
+    prepare_qat(net, inplace=True)
+    with torch.no_grad():
+        for s_ in range(2):
+            net(T(synth((2, 3, 64, 64), 520 + s_)))
+    net.eval()
+    out = dict(spec=np.array([2, 64, 520, 529, 5000]))
+    out.update(sd_np(net.state_dict(), "pre_sd/"))
+    with torch.no_grad():
+        out["logits"] = net(T(synth((2, 3, 64, 64), 529)))
+    out.update(sd_np({k: v for k, v in net.state_dict().items() if k.startswith("classifier.2.activation_post_process")}, "post_sd/"))
+    save("g12_fbgemm_small_eval", **out)
+
+
 # ------------------------------------------------------------------------------------------ G8
 def g8_features():
     feat = refshim.load_features()
@@ -512,8 +565,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection, g12=g12_fbgemm)
     for w in which:
         fns[w]()
