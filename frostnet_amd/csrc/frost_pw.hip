@@ -57,7 +57,10 @@ struct PwP {
 #endif
 // channel tiles (16 channels each) a wave carries per channel group: the 4-wave-wide channel split (WP == 2) holds 4 pixel
 // subtiles per channel tile, so its backward passes carry 2 (4 would spill the epilogue state: measured 30% slower)
-#define PW_MI(MODE, WP) (((WP) == 2) ? 2 : 4)
+#ifndef PW_MI_DGRAD2
+#define PW_MI_DGRAD2 2
+#endif
+#define PW_MI(MODE, WP) (((WP) == 2) ? (((MODE) == M_DGRAD) ? PW_MI_DGRAD2 : 2) : 4)
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
