@@ -45,6 +45,7 @@ struct Dw3P {
   const float* wscale;   // [cpad] per-output-channel weight scale (NULL: the scalar of qw)
   int sr;        // dc is rounded to bf16 stochastically (unbiased; see sr_bf16 in frost_common.h)
   int cvt;       // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation), see frost_convert.hip
+  int nb;        // LDS input-tile buffers (1 or 2), see dw_nbuf
   int xmap;      // XCD-aware block -> (channel block, tile range) map, see dw_block_map
 };
 
@@ -107,116 +108,74 @@ __device__ __forceinline__ void tr16_run(const uint8_t* tile_row, int col0, int 
   out4[0] = bf2f((uint16_t)raw[0]); out4[1] = bf2f((uint16_t)raw[1]); out4[2] = bf2f((uint16_t)raw[2]); out4[3] = bf2f((uint16_t)raw[3]);
 }
 
-// Tile staging plan.  Which (row, column, 8-channel unit) of the halo tile a thread moves is the same for every tile of the
-// persistent loop, so the unit decode (three constant divisions) and the channel bound are computed once per thread and kept
-// packed in one register per unit; per tile and unit there remain a few adds/mads, two unsigned compares and one 64-bit add
-// in front of the load.  EB = bytes per element (1: int8 activations, 8-byte units; 2: bf16, 16-byte units).
-template <int NR, int NCS, int NSUB, int CBW, int EB>
+// Tile staging: direct-to-LDS loads.  A halo tile is [row][col][CBW channels] -- a linear array of 16-byte units (16 int8 or 8 bf16
+// channels of one pixel), 64 consecutive units = 1 KiB per wave instruction.  Every lane of a global_load_lds_dwordx4 supplies its own
+// global address (row / column / channel-block strided) while the LDS side is linear (M0 base + lane * 16), so the natural tile layout IS
+// the DMA layout: no staging registers, no ds_write, and the copy of tile t+1 runs under the arithmetic of tile t (two buffers where the
+// LDS budget keeps two workgroups per CU, see dw_nbuf).  Units that fall outside the image (zero padding = zero-point fill) or belong to an
+// absent sub-tile are written by the same lane with an ordinary 16-byte LDS store instead (exec-masked DMA lanes write nothing).
+// The DMA is issued from inline asm (the compiler would otherwise drain vmcnt in front of every later LDS read); dw_wait_barrier() is the
+// one place where a wave waits for its own copies before the workgroup barrier.  When C % 16 == 8 the last unit of a pixel reads 8 bytes
+// of its neighbour (dead lanes: their weights are zero and they never reach a statistic or a store; buffers carry SLACK bytes).
+__device__ __forceinline__ void dw_glds16(const uint8_t* gsrc, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dw_wait_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Which (row, column, channel unit) of the tile a thread moves is the same for every tile of the persistent loop: decoded once per
+// thread, one packed register per unit.  EB = bytes per element (1: int8 activations, 2: bf16 gradients).
+// LEAN: nothing is kept, the decode is redone per unit (the k = 5, stride 2 weight-gradient kernel has no registers to spare).
+template <int NR, int NCS, int NSUB, int CBW, int EB, bool LEAN = false>
 struct DwPlan {
-  static constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP, NU = (NUNIT + 255) / 256;
-  int pos[NU];        // iy | ix << 8 | sub << 16 | live << 20
-  int cc0, ww_, c_;   // this thread's channel offset (the same for all its units: 256 is a multiple of UPP), row pitch, channels
-  __device__ __forceinline__ int rel(int jn) const { return ((pos[jn] & 255) * ww_ + ((pos[jn] >> 8) & 255)) * c_ + cc0; }
+  static constexpr int UPP = CBW * EB / 16, CPU = 16 / EB, NC = NSUB * NCS, NUNIT = NR * NC * UPP, NU = (NUNIT + 255) / 256;
+  int pos_[LEAN ? 1 : NU];        // iy | ix << 8 | sub << 16 | live << 20
+  int cc0, ww_, c_, tid_, cb_;    // this thread's channel offset (the same for all its units: 256 is a multiple of UPP), row pitch, channels
+  __device__ __forceinline__ static int decode(int tid, int jn, int cb, int c) {
+    const int u = tid + jn * 256; const int cu = u % UPP; const int pix = u / UPP; const int iy = pix / NC, ixx = pix - iy * NC;
+    const int sb = ixx / NCS; const int ix = ixx - sb * NCS; const int cc = cb * CBW + cu * CPU;
+    const bool live = (u < NUNIT) && (cc < c);
+    return iy | (ix << 8) | (sb << 16) | ((live ? 1 : 0) << 20);
+  }
+  __device__ __forceinline__ int pos(int jn) const { return LEAN ? decode(tid_, jn, cb_, c_) : pos_[LEAN ? 0 : jn]; }
+  __device__ __forceinline__ int rel(int ps) const { return ((ps & 255) * ww_ + ((ps >> 8) & 255)) * c_ + cc0; }
   __device__ __forceinline__ void init(int tid, int cb, int ww, int c) {
+    if (!LEAN) {
 #pragma unroll
-    for (int jn = 0; jn < NU; ++jn) {
-      const int u = tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int iy = pix / NC, ixx = pix - iy * NC;
-      const int sb = ixx / NCS; const int ix = ixx - sb * NCS; const int cc = cb * CBW + c8 * 8;
-      const bool live = (u < NUNIT) && (cc < c);
-      pos[jn] = iy | (ix << 8) | (sb << 16) | ((live ? 1 : 0) << 20);
+      for (int jn = 0; jn < NU; ++jn) pos_[LEAN ? 0 : jn] = decode(tid, jn, cb, c);
     }
-    cc0 = cb * CBW + (tid % UPP) * 8; ww_ = ww; c_ = c;
+    cc0 = cb * CBW + (tid % UPP) * CPU; ww_ = ww; c_ = c; tid_ = tid; cb_ = cb;
   }
 };
-// stage through the plan: sub-tile s has its origin at (gy0[s], gx0[s]) of image su.img[s] in the [hh][ww][c] tensor
-template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_i8_tile(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwPlan<NR, NCS, NSUB, CBW, 1>& pl,
-                                              const DwSub<NSUB, SUBW>& su, int rs, int roff, int h, int w, int c, uint32_t zfill) {
-  typedef DwPlan<NR, NCS, NSUB, CBW, 1> P;
-  int gy0[NSUB], gx0[NSUB]; const int8_t* bp[NSUB];
+// sub-tile s has its origin at row su.r0[s] * mul / dv + roff (columns alike) of image su.img[s] in the [hh][ww][c] tensor
+template <int NR, int NCS, int NSUB, int SUBW, int CBW, int EB, bool LEAN>
+__device__ __forceinline__ void stage_tile(const void* __restrict__ src, uint8_t* tile, int tid, const DwPlan<NR, NCS, NSUB, CBW, EB, LEAN>& pl,
+                                           const DwSub<NSUB, SUBW>& su, int mul, int dv, int roff, int hh, int ww, int c, uint32_t fill) {
+  typedef DwPlan<NR, NCS, NSUB, CBW, EB, LEAN> P;
+  int gy0[NSUB], gx0[NSUB]; const uint8_t* bp[NSUB];
 #pragma unroll
-  for (int s2 = 0; s2 < NSUB; ++s2) { gy0[s2] = su.r0[s2] * rs + roff; gx0[s2] = su.c0[s2] * rs + roff; bp[s2] = x + (((int64_t)su.img[s2] * h + gy0[s2]) * w + gx0[s2]) * c; }
-#pragma unroll
-  for (int b0 = 0; b0 < P::NU; b0 += 8) {
-    uint2 v[8];
-#pragma unroll
-    for (int jn = 0; jn < 8; ++jn) {
-      if (b0 + jn < P::NU) {
-        const int ps = pl.pos[b0 + jn]; const int sb = (ps >> 16) & 3;
-        const int gy = DW_SEL(gy0, sb) + (ps & 255), gx = DW_SEL(gx0, sb) + ((ps >> 8) & 255);
-        v[jn] = make_uint2(zfill, zfill);
-        if ((ps >> 20) && DW_SEL(su.ok, sb) && (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) v[jn] = *(const uint2*)(DW_SEL(bp, sb) + pl.rel(b0 + jn));
-      }
-    }
-#pragma unroll
-    for (int jn = 0; jn < 8; ++jn)
-      if (b0 + jn < P::NU) { const int u = tid + (b0 + jn) * 256; if (u < P::NUNIT) *(uint2*)(tile + u * 8) = v[jn]; }
+  for (int s2 = 0; s2 < NSUB; ++s2) {
+    gy0[s2] = su.r0[s2] * mul / dv + roff; gx0[s2] = su.c0[s2] * mul / dv + roff;
+    bp[s2] = (const uint8_t*)src + (((int64_t)su.img[s2] * hh + gy0[s2]) * ww + gx0[s2]) * c * EB;
   }
-}
-template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_bf16_tile(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwPlan<NR, NCS, NSUB, CBW, 2>& pl,
-                                                const DwSub<NSUB, SUBW>& su, int dv, int roff, int hh, int ww, int c) {
-  typedef DwPlan<NR, NCS, NSUB, CBW, 2> P;
-  int gy0[NSUB], gx0[NSUB]; const uint16_t* bp[NSUB];
-#pragma unroll
-  for (int s2 = 0; s2 < NSUB; ++s2) { gy0[s2] = su.r0[s2] / dv + roff; gx0[s2] = su.c0[s2] / dv + roff; bp[s2] = src + (((int64_t)su.img[s2] * hh + gy0[s2]) * ww + gx0[s2]) * c; }
-#pragma unroll
-  for (int b0 = 0; b0 < P::NU; b0 += 4) {
-    uint4 v[4];
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) {
-      if (b0 + jn < P::NU) {
-        const int ps = pl.pos[b0 + jn]; const int sb = (ps >> 16) & 3;
-        const int gy = DW_SEL(gy0, sb) + (ps & 255), gx = DW_SEL(gx0, sb) + ((ps >> 8) & 255);
-        v[jn] = make_uint4(0, 0, 0, 0);
-        if ((ps >> 20) && DW_SEL(su.ok, sb) && (unsigned)gy < (unsigned)hh && (unsigned)gx < (unsigned)ww) v[jn] = *(const uint4*)(DW_SEL(bp, sb) + pl.rel(b0 + jn));
-      }
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)tile);
+  const uint4 f4 = make_uint4(fill, fill, fill, fill);
+  auto unit = [&](int jn) __attribute__((always_inline)) {
+    const int ps = pl.pos(jn); const int sb = (ps >> 16) & 3;
+    const int gy = DW_SEL(gy0, sb) + (ps & 255), gx = DW_SEL(gx0, sb) + ((ps >> 8) & 255);
+    if (ps >> 20) {
+      if (DW_SEL(su.ok, sb) && (unsigned)gy < (unsigned)hh && (unsigned)gx < (unsigned)ww)
+        dw_glds16(DW_SEL(bp, sb) + (int64_t)pl.rel(ps) * EB, lbase + (uint32_t)(jn * 4 + wv) * 1024u);
+      else *(uint4*)(tile + (tid + jn * 256) * 16) = f4;
     }
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-      if (b0 + jn < P::NU) { const int u = tid + (b0 + jn) * 256; if (u < P::NUNIT) *(uint4*)(tile + u * 16) = v[jn]; }
-  }
-}
-// on-the-fly variants (no per-thread plan): for the k = 5, stride 2 weight-gradient kernel, whose register budget is spent
-// stage an int8 [NR][NSUB * NCS][CBW] tile (8-byte units: channel counts are multiples of 8, not always of 16).  Sub-tile s
-// covers columns [s*NCS, (s+1)*NCS) and maps to image su.img[s], rows r0[s]*RS + roff.., columns c0[s]*RS + coff..
-template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_i8_tile_otf(const int8_t* __restrict__ x, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int rs, int roff,
-                                              int cb, int h, int w, int c, uint32_t zfill) {
-  constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
+  };
+  if (LEAN) {
 #pragma unroll 1
-  for (int base = 0; base < NUNIT; base += 256 * 8) {
-    uint2 v[8];
+    for (int jn = 0; jn < P::NU; ++jn) unit(jn);
+  } else {
 #pragma unroll
-    for (int jn = 0; jn < 8; ++jn) {
-      const int u = base + tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int iy = pix / NC, ixx = pix - iy * NC;
-      const int sb = ixx / NCS; const int ix = ixx - sb * NCS;
-      const int gy = DW_SEL(su.r0, sb) * rs + roff + iy, gx = DW_SEL(su.c0, sb) * rs + roff + ix; const int cc = cb * CBW + c8 * 8;
-      v[jn] = make_uint2(zfill, zfill);
-      if (u < NUNIT && DW_SEL(su.ok, sb) && gy >= 0 && gy < h && gx >= 0 && gx < w && cc < c) v[jn] = *(const uint2*)(x + (((int64_t)DW_SEL(su.img, sb) * h + gy) * w + gx) * c + cc);
-    }
-#pragma unroll
-    for (int jn = 0; jn < 8; ++jn) { const int u = base + tid + jn * 256; if (u < NUNIT) *(uint2*)(tile + u * 8) = v[jn]; }
-  }
-}
-// stage a bf16 [NR][NSUB * NCS][CBW] tile (16-byte units); origin of sub-tile s: rows fdiv(r0[s], dv) + roff, columns fdiv(c0[s], dv) + roff
-template <int NR, int NCS, int NSUB, int SUBW, int CBW>
-__device__ __forceinline__ void stage_bf16_tile_otf(const uint16_t* __restrict__ src, uint8_t* tile, int tid, const DwSub<NSUB, SUBW>& su, int dv, int roff,
-                                                int cb, int hh, int ww, int c) {
-  constexpr int UPP = CBW / 8, NC = NSUB * NCS, NUNIT = NR * NC * UPP;
-#pragma unroll 1
-  for (int base = 0; base < NUNIT; base += 256 * 4) {
-    uint4 v[4];
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) {
-      const int u = base + tid + jn * 256; const int c8 = u % UPP; const int pix = u / UPP; const int ry = pix / NC, rxx = pix - ry * NC;
-      const int sb = rxx / NCS; const int rx = rxx - sb * NCS;
-      const int gy = DW_SEL(su.r0, sb) / dv + roff + ry, gx = DW_SEL(su.c0, sb) / dv + roff + rx; const int cc = cb * CBW + c8 * 8;
-      v[jn] = make_uint4(0, 0, 0, 0);
-      if (u < NUNIT && DW_SEL(su.ok, sb) && gy >= 0 && gy < hh && gx >= 0 && gx < ww && cc < c) v[jn] = *(const uint4*)(src + (((int64_t)DW_SEL(su.img, sb) * hh + gy) * ww + gx) * c + cc);
-    }
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn) { const int u = base + tid + jn * 256; if (u < NUNIT) *(uint4*)(tile + u * 16) = v[jn]; }
+    for (int jn = 0; jn < P::NU; ++jn) unit(jn);
   }
 }
 // copy an assembled [TH][TWT][CBW] tile (EB bytes per element) out to the NHWC tensor dst[img][hh][ww][c]
@@ -245,6 +204,11 @@ __device__ __forceinline__ void copy_out_tile(const uint8_t* tile, uint8_t* dst,
   }
 }
 
+// LDS bytes of the auxiliary tile per conv mode: int8 out tile (emit), bf16 gout / dc tile (backward).  The statistics pass has no such
+// tile but keeps the allocation: the residency it would gain (more workgroups = more atomics in front of the finalize) measured slower.
+template <typename G>
+__host__ __device__ constexpr int dw_aux_bytes(int mode) { return mode == D_EMIT ? G::AUX_BYTES / 2 : G::AUX_BYTES; }
+
 // lane geometry shared by the three kernels
 template <typename G>
 struct DwLane {
@@ -265,9 +229,11 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   constexpr bool WG = (MODE_ == D_BDCW);
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tin = smem;
-  uint8_t* aux = smem + G::IN_BYTES;                    // gout / dc bf16 tile (16 KB) or int8 out tile (8 KB)
-  double* red_d = (double*)(smem + G::IN_BYTES + G::AUX_BYTES);   // [4][64][2]
+  const int nb = p.nb;                                   // LDS tile buffers: 2 = the next tile's copy runs under this tile's arithmetic
+  constexpr int AUXB = dw_aux_bytes<G>(MODE_);
+  uint8_t* const tin0 = smem;
+  uint8_t* const aux0 = smem + nb * G::IN_BYTES;        // gout / dc bf16 tile (16 KB) or int8 out tile (8 KB)
+  double* red_d = (double*)(smem + nb * (G::IN_BYTES + AUXB));   // [4][64][2]
   float* red_f = (float*)(red_d + 4 * 64 * 2);                     // [4][64][2]
 
   const int tid = threadIdx.x;
@@ -321,24 +287,25 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
   uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
-  constexpr bool PLAN = !WG;       // the fused weight-gradient variant has no registers to spare for the staging plans
-  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; if (PLAN) plx.init(tid, cb, p.w, p.c);
-  DwPlan<TH, SUBW, NSUB, CBW, 2> plg; if (PLAN && (MODE == D_BRED || MODE == D_BDC)) plg.init(tid, cb, p.wo, p.c);
+  DwPlan<G::IH, G::IWS, NSUB, CBW, 1, WG> plx; plx.init(tid, cb, p.w, p.c);          // the fused weight-gradient variant has no registers to spare: lean plans
+  DwPlan<TH, SUBW, NSUB, CBW, 2, WG> plg; if (MODE == D_BRED || MODE == D_BDC) plg.init(tid, cb, p.wo, p.c);
   float wacc[WG ? K * K : 1]; float sdc = 0.0f;      // fused weight gradient: sum dc * q (unsigned index) per tap, and sum dc
 #pragma unroll
   for (int t = 0; t < (WG ? K * K : 1); ++t) wacc[t] = 0.0f;
+  auto stage = [&](const DwSub<NSUB, SUBW>& s_, int b) __attribute__((always_inline)) {
+    stage_tile<G::IH, G::IWS, NSUB, SUBW, CBW, 1>(p.x, tin0 + b * G::IN_BYTES, tid, plx, s_, S, 1, -p.pad, p.h, p.w, p.c, zfill);
+    if (MODE == D_BRED || MODE == D_BDC) stage_tile<TH, SUBW, NSUB, SUBW, CBW, 2>(p.gout, aux0 + b * AUXB, tid, plg, s_, 1, 1, 0, p.ho, p.wo, p.c, 0u);
+  };
+  DwSub<NSUB, SUBW> su, sun;
+  int buf = 0;
+  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage(su, 0); }
 
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
-    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
-    __syncthreads();
-    if (PLAN) {
-      stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
-      if (MODE == D_BRED || MODE == D_BDC) stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);
-    } else {
-      stage_i8_tile_otf<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
-      stage_bf16_tile_otf<TH, SUBW, NSUB, SUBW, CBW>(p.gout, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
-    }
-    __syncthreads();
+    dw_wait_barrier();                // this tile has landed (every wave waited for its own copies); the other buffer is free
+    const bool more = (tile + bm.step) < bm.t1;
+    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage(sun, buf ^ 1); }
+    uint8_t* const tin = tin0 + buf * G::IN_BYTES;
+    uint8_t* const aux = aux0 + buf * AUXB;
 
     int acc[RH][RW];
 #pragma unroll
@@ -435,6 +402,11 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
       if (MODE == D_EMIT) copy_out_tile<1, NSUB, SUBW, CBW, false>(aux, (uint8_t*)p.y, tid, su, cb, p.ho, p.wo, p.c);
       else copy_out_tile<2, NSUB, SUBW, CBW, false>(aux, (uint8_t*)p.dc, tid, su, cb, p.ho, p.wo, p.c);
     }
+    if (more) {
+      if (nb == 1) { __syncthreads(); stage(sun, 0); }     // single buffer: every wave is done with the tile before it is overwritten
+      else buf ^= 1;
+      su = sun;
+    }
   }
 
   if (WG) {       // dW[c][tap] += s_x * (sum dc*q - zp * sum dc): the 4 waves' (and, for 32-channel blocks, both halves') partials through LDS
@@ -493,7 +465,8 @@ template <typename G>
 __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tin = smem; uint8_t* aux = smem + G::IN_BYTES;
+  const int nb = p.nb;
+  uint8_t* const tin0 = smem; uint8_t* const aux0 = smem + nb * G::IN_BYTES;
   const int tid = threadIdx.x;
   const DwLane<G> L(tid);
   const int lane = L.lane, wv = L.wv, wy = L.wy;
@@ -503,20 +476,22 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
   float acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
-  constexpr bool PLAN = !(K == 5 && S == 2);
-  DwPlan<G::IH, G::IWS, NSUB, CBW, 1> plx; DwPlan<TH, SUBW, NSUB, CBW, 2> plg;
-  if (PLAN) { plx.init(tid, cb, p.w, p.c); plg.init(tid, cb, p.wo, p.c); }
+  constexpr bool LEAN = (K == 5 && S == 2);
+  DwPlan<G::IH, G::IWS, NSUB, CBW, 1, LEAN> plx; DwPlan<TH, SUBW, NSUB, CBW, 2, LEAN> plg;
+  plx.init(tid, cb, p.w, p.c); plg.init(tid, cb, p.wo, p.c);
+  auto stage = [&](const DwSub<NSUB, SUBW>& s_, int b) __attribute__((always_inline)) {
+    stage_tile<G::IH, G::IWS, NSUB, SUBW, CBW, 1>(p.x, tin0 + b * G::IN_BYTES, tid, plx, s_, S, 1, -p.pad, p.h, p.w, p.c, zfill);
+    stage_tile<TH, SUBW, NSUB, SUBW, CBW, 2>(p.dc, aux0 + b * G::AUX_BYTES, tid, plg, s_, 1, 1, 0, p.ho, p.wo, p.c, 0u);     // rows/cols outside the map -> 0
+  };
+  DwSub<NSUB, SUBW> su, sun;
+  int buf = 0;
+  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage(su, 0); }
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
-    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);
-    __syncthreads();
-    if (PLAN) {
-      stage_i8_tile<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, plx, su, S, -p.pad, p.h, p.w, p.c, zfill);
-      stage_bf16_tile<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, plg, su, 1, 0, p.ho, p.wo, p.c);     // rows/cols outside the map -> 0
-    } else {
-      stage_i8_tile_otf<G::IH, G::IWS, NSUB, SUBW, CBW>(p.x, tin, tid, su, S, -p.pad, cb, p.h, p.w, p.c, zfill);
-      stage_bf16_tile_otf<TH, SUBW, NSUB, SUBW, CBW>(p.dc, aux, tid, su, 1, 0, cb, p.ho, p.wo, p.c);
-    }
-    __syncthreads();
+    dw_wait_barrier();
+    const bool more = (tile + bm.step) < bm.t1;
+    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage(sun, buf ^ 1); }
+    const uint8_t* const tin = tin0 + buf * G::IN_BYTES;
+    const uint8_t* const aux = aux0 + buf * G::AUX_BYTES;
     float g[RH][RW];
 #pragma unroll
     for (int o = 0; o < RH; ++o) {
@@ -541,6 +516,11 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
             for (int r = 0; r < RW; ++r) acc[ky * K + kx] = fmaf(g[o][r], xr[r * S + kx], acc[ky * K + kx]);
         }
       }
+    }
+    if (more) {
+      if (nb == 1) { __syncthreads(); stage(sun, 0); }
+      else buf ^= 1;
+      su = sun;
     }
   }
   __syncthreads();
@@ -569,7 +549,8 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
   constexpr int NJR = (S == 1) ? (RH + K - 1) : ((RH - 1 + PAD) / 2 - LO + 1);
   constexpr int NR4 = (S == 1) ? (RW + K - 1 + 3) / 4 : 2;               // 4-pixel transpose reads per dc row
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tdc = smem; uint8_t* tout = smem + D_BYTES;                   // dx bf16 out tile [TH*TWT][CBW]
+  const int nb = p.nb;
+  uint8_t* const tdc0 = smem; uint8_t* const tout = smem + nb * D_BYTES;     // dx bf16 out tile [TH*TWT][CBW]
   const int tid = threadIdx.x;
   const DwLane<G> L(tid);
   const int lane = L.lane, wy = L.wy;
@@ -583,11 +564,14 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
   const int cin_sub = L.colo - L.sb * SUBW;                                // patch column inside its sub-tile (multiple of 8)
   const int cbase = L.sb * DWS + ((S == 1) ? cin_sub : cin_sub / 2);
   DwPlan<DH, DWS, NSUB, CBW, 2> pld; pld.init(tid, cb, p.wo, p.c);
+  DwSub<NSUB, SUBW> su, sun;                                             // units over the dx (input) domain
+  int buf = 0;
+  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0, tid, pld, su, 1, S, LO, p.ho, p.wo, p.c, 0u); }
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
-    DwSub<NSUB, SUBW> su; dw_decode<NSUB, SUBW>(p, tile, su);        // units over the dx (input) domain
-    __syncthreads();
-    stage_bf16_tile<DH, DWS, NSUB, SUBW, CBW>(p.dc, tdc, tid, pld, su, S, LO, p.ho, p.wo, p.c);
-    __syncthreads();
+    dw_wait_barrier();               // dc tile landed; the previous tile's copy-out has read tout
+    const bool more = (tile + bm.step) < bm.t1;
+    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0 + (buf ^ 1) * D_BYTES, tid, pld, sun, 1, S, LO, p.ho, p.wo, p.c, 0u); }
+    const uint8_t* const tdc = tdc0 + buf * D_BYTES;
     float acc[RH][RW];
 #pragma unroll
     for (int o = 0; o < RH; ++o)
@@ -622,6 +606,11 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
     __syncthreads();
     if (p.accumulate) copy_out_tile<2, NSUB, SUBW, CBW, true>(tout, (uint8_t*)p.dx, tid, su, cb, p.h, p.w, p.c);
     else copy_out_tile<2, NSUB, SUBW, CBW, false>(tout, (uint8_t*)p.dx, tid, su, cb, p.h, p.w, p.c);
+    if (more) {
+      if (nb == 1) { __syncthreads(); stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0, tid, pld, sun, 1, S, LO, p.ho, p.wo, p.c, 0u); }
+      else buf ^= 1;
+      su = sun;
+    }
   }
 }
 
@@ -666,16 +655,27 @@ static int launch3(KF kern, Dw3P& p, size_t lds, const char* what, hipStream_t s
   hipLaunchKernelGGL(kern, dim3(p.ncb * p.ngroups), dim3(256), lds, s, p);
   return frost_check_launch(what);
 }
+// Input buffers per workgroup.  Measured (tests/devtools/pw_micro.py, every FrostNet-Large depthwise shape): ONE buffer and the residency it
+// leaves (3-6 workgroups per CU cover each other's copies) beats two buffers (copy of tile t+1 under the arithmetic of tile t) by 8-30 %;
+// FROST_DW_NB=2 keeps the double-buffered loop reachable for experiments.
+static int dw_nbuf(size_t per_buffer, size_t fixed) {
+  static const int force = getenv("FROST_DW_NB") ? atoi(getenv("FROST_DW_NB")) : 1;
+  return (force == 2 && 2 * per_buffer + fixed <= 158 * 1024) ? 2 : 1;
+}
 template <typename G, int MODE>
 static int launch_fwd(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.ho, p.wo);
-  size_t lds = (size_t)G::IN_BYTES + G::AUX_BYTES + 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4; const size_t red = (size_t)4 * G::K * G::K * 64 * 4;
+  const size_t per = (size_t)G::IN_BYTES + dw_aux_bytes<G>(MODE), fixed = 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4, red = (size_t)4 * G::K * G::K * 64 * 4;
+  p.nb = dw_nbuf(per, fixed);
+  const size_t lds = p.nb * per + fixed;
   return launch3(k_dw3<G, MODE>, p, lds > red ? lds : red, "dw", s);
 }
 template <typename G>
 static int launch_wgrad(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.ho, p.wo);
-  size_t lds = (size_t)G::IN_BYTES + G::AUX_BYTES; const size_t red = (size_t)4 * G::K * G::K * 64 * 4;
+  const size_t per = (size_t)G::IN_BYTES + G::AUX_BYTES, red = (size_t)4 * G::K * G::K * 64 * 4;
+  p.nb = dw_nbuf(per, 0);
+  const size_t lds = p.nb * per;
   return launch3(k_dw3_wgrad<G>, p, lds > red ? lds : red, "dw_wgrad", s);
 }
 template <typename G>
@@ -683,7 +683,9 @@ static int launch_dgrad(Dw3P& p, hipStream_t s) {
   constexpr int PAD = (G::K - 1) / 2; constexpr int LO = fdiv3(-PAD, G::S);
   constexpr int DH = (TH - 1 + PAD) / G::S - LO + 1, DWS = (G::SUBW - 1 + PAD) / G::S - LO + 1;
   set_tiles<G>(p, p.h, p.w);
-  return launch3(k_dw3_dgrad<G>, p, (size_t)((DH * G::NSUB * DWS * G::CBW * 2 + 255) / 256) * 256 + 512 + G::AUX_BYTES, "dw_dgrad", s);
+  const size_t per = (size_t)((DH * G::NSUB * DWS * G::CBW * 2 + 255) / 256) * 256 + 512;
+  p.nb = dw_nbuf(per, G::AUX_BYTES);
+  return launch3(k_dw3_dgrad<G>, p, p.nb * per + G::AUX_BYTES, "dw_dgrad", s);
 }
 // dc pass + weight gradient: fused where the combined register state fits (measured: no spills), else two launches
 template <typename G>

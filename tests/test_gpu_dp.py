@@ -107,41 +107,56 @@ def test_two_rank_allreduce_equals_mean_of_shard_gradients():
 
 
 def test_graph_segments_replay_equals_eager():
-    """SegmentedStep.capture/replay (what bench.py runs for N>1) against the eager step, one process, no process group."""
+    """SegmentedStep.capture/replay (what bench.py runs for N>1) against the eager step, one process, no process group.
+
+    Both sides start from the SAME restored state and take ONE step: the forward is bit-reproducible (integer / fp64 statistics), the
+    backward differs by the order of fp32 atomics and the stochastic bf16 roundings that order flips.  A multi-step trajectory is not
+    compared: at B = 2 (2x2 final maps) a 1e-9 parameter difference moves a zero-point or an index in the next forward and the runs
+    branch (tests/devtools/dbg_segments.py: eager vs eager branches just as often as eager vs graph)."""
     sys.path.insert(0, ROOT)
     from frostnet_amd import frostnet as F
     from frostnet_amd.optimizer import QSGD
     from frostnet_amd.parallel import SegmentedStep
 
-    def run(graph):
-        torch.manual_seed(0)
-        model = F.frostnet_quant_small_1_0(drop_rate=0.0)
-        F.qat_prepare(model, version=0)
-        model.cuda().train()
-        opt = QSGD([{"params": [p]} for p in model.parameters()], lr=1e-3, momentum=0.9, nesterov=True)     # is_warmup: no noise
-        seg = SegmentedStep(model.hip_runner(), torch.nn.CrossEntropyLoss(), nbuckets=4)
-        x, tgt = _shard(0)
-        x, tgt = x.cuda(), tgt.cuda()
-        seg.run_eager(x, tgt)
-        opt.step()
-        if graph:
-            seg.capture(x, tgt)
-            assert len(seg.graphs) == len(seg.cuts) >= 2
-        for _ in range(2):
-            plan = opt.prepare_step()
-            if graph:
-                seg.replay()
-            else:
-                seg.run_eager(x, tgt)
-            opt.launch(plan)
+    torch.manual_seed(0)
+    model = F.frostnet_quant_small_1_0(drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    opt = QSGD([{"params": [p]} for p in model.parameters()], lr=1e-3, momentum=0.9, nesterov=True)     # is_warmup: no noise
+    runner = model.hip_runner()
+    seg = SegmentedStep(runner, torch.nn.CrossEntropyLoss(), nbuckets=4)
+    x, tgt = _shard(0)
+    x, tgt = x.cuda(), tgt.cuda()
+    seg.run_eager(x, tgt)                 # descriptor tables and observer state exist before the capture
+    opt.step()
+    torch.cuda.synchronize()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    seg.capture(x, tgt)
+    assert len(seg.graphs) == len(seg.cuts) >= 2
+
+    def one(graph):
+        model.load_state_dict(sd0)
+        loss = seg.replay() if graph else seg.run_eager(x, tgt)
         torch.cuda.synchronize()
-        return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(), model.hip_runner().grad_arena.cpu().clone()
-    pe, ge_ = run(False)
-    pg, gg = run(True)
-    rel_p = float((pe - pg).norm() / pe.norm())
-    rel_g = float((ge_ - gg).norm() / ge_.norm())
-    print(f"[segments] params rel {rel_p:.2e}, last gradient rel {rel_g:.2e} (fp32 atomics order only)")
-    assert rel_p <= 1e-5 and rel_g <= 2e-2
+        post = torch.cat([v.detach().float().reshape(-1) for k, v in model.state_dict().items() if "running_" in k or "min_val" in k or "max_val" in k])
+        return float(loss), runner.grad_arena.clone(), torch.nan_to_num(post, posinf=0.0, neginf=0.0)     # never-used sites keep +-inf
+    le, ge_, se = one(False)
+    lg, gg, sg = one(True)
+    lg2, gg2, _ = one(True)
+    rel_g, rel_g2 = float((ge_ - gg).norm() / ge_.norm()), float((gg2 - gg).norm() / gg.norm())
+    rel_s = float((se - sg).norm() / se.norm())
+    print(f"[segments] loss eager {le:.7f} graph {lg:.7f}; gradient rel eager/graph {rel_g:.2e}, graph/graph {rel_g2:.2e}; forward state rel {rel_s:.2e}")
+    assert abs(le - lg) <= 1e-6 * abs(le) and lg2 == lg          # forward: reproducible
+    assert rel_s <= 1e-6                                          # observers and running statistics after the step
+    assert rel_g <= 2e-2 and rel_g2 <= 2e-2                       # measured 1e-7 ... 3e-3 (one flipped rounding, amplified by the S1/S2 cancellation)
+    # and the replayed gradients drive the optimizer
+    p0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    plan = opt.prepare_step()
+    seg.replay()
+    opt.launch(plan)
+    torch.cuda.synchronize()
+    p1 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert float((p1 - p0).norm()) > 0 and bool(torch.isfinite(p1).all())
 
 
 def test_bench_gpus2_spawns_two_ranks():
