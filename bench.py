@@ -139,8 +139,10 @@ def side_workload(args, dev):
         opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
         crit = torch.nn.CrossEntropyLoss()
         step = lambda: H.train_one_iter(model, crit, opt, x, tgt)
-        bytes_per_img, metric, dtype = None, "images/sec FrostNet-Large 224x224 float warm-up fwd+bwd", "bf16"
-        what = f"FrostNet-{args.mode.capitalize()} float model (StatAssist warm-up), fwd+bwd + GradBoost-SGD step (is_warmup), batch={batch}, {args.res}x{args.res}"
+        prec = model.hip_runner().precision          # activation storage: bf16 (default) or fp32 (FROST_FLOAT_PRECISION=fp32, the reference's precision)
+        bytes_per_img, metric, dtype = None, "images/sec FrostNet-Large 224x224 float warm-up fwd+bwd", prec
+        what = (f"FrostNet-{args.mode.capitalize()} float model (StatAssist warm-up), {prec} activations, fwd+bwd + GradBoost-SGD step (is_warmup), "
+                f"batch={batch}, {args.res}x{args.res}")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

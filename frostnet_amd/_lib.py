@@ -31,7 +31,7 @@ class FrostIDesc(C.Structure):
 class FrostFDesc(C.Structure):
     _fields_ = [("w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("nbt", P), ("pack", P), ("pack_t", P), ("stat", P),
                 ("coef", P), ("dgamma", P), ("dbeta", P), ("cout", C.c_int32), ("cin_g", C.c_int32), ("kk", C.c_int32),
-                ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("reserved", C.c_int32)]
+                ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("fp32", C.c_int32)]
 
 
 class FrostFinDesc(C.Structure):
@@ -112,6 +112,17 @@ _PROTOS = {
     "frost_float_grad_merge": [P, P, I, I, P, L, I, P, P],
     "frost_float_avgpool": [P, I, I, I, P, P, P],
     "frost_float_head_bwd": [P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "frost_float_pw_f32": [P, P, P, L, I, I, I, I, P, I, P, I, P],
+    "frost_float_dw_f32": [P, P, I, I, I, I, I, I, I, I, P, P, P],
+    "frost_float_dw_dgrad_f32": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_dw_wgrad_f32": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_pw_wgrad_f32": [P, P, L, I, I, I, P, I, P],
+    "frost_float_grad_merge_f32": [P, P, I, I, P, L, I, P, P],
+    "frost_float_avgpool_f32": [P, I, I, I, P, P, P],
+    "frost_float_head_bwd_f32": [P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "frost_float_cat_f32": [P, I, P, I, L, P, P],
+    "frost_float_add_f32": [P, P, L, P, P],
+    "frost_float_stem_im2col_f32": [P, I, I, I, L, L, L, L, P, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

@@ -2,23 +2,57 @@
 // float model for FP_epoch epochs with the same GradBoost optimizer before prepare_qat) and eval-mode forward of the float model.
 // replaces: frostnet.py:14-60 ConvBNReLU / ConvBN in train mode = Conv2d(bias=False) -> BatchNorm2d(batch statistics, running-stat
 // update, momentum 0.1) -> ReLU, and their autograd backward.
-// Storage: activations and activation gradients NHWC bf16, parameters / statistics / accumulators fp32 (sums in double across
-// workgroups).  Same recompute structure as the fake-quant path: forward = statistics pass -> frost_float_bn_finalize -> emit pass;
+// Storage: activations and activation gradients NHWC, either bf16 (the fast default) or fp32 (the reference's own precision: every
+// kernel below is a template on the element type, the *_f32 entries instantiate it with float and the pointwise products run on the
+// fp32 MFMA, so the FP32-train end-to-end gate of the reference applies); parameters / statistics / accumulators fp32 (sums in double
+// across workgroups).  Same recompute structure as the fake-quant path: forward = statistics pass -> frost_float_bn_finalize -> emit pass;
 // backward = reduce pass (S1 = sum g, S2 = sum g*xhat) -> frost_float_bwd_finalize -> dc pass -> dgrad, wgrad.  Every pass recomputes
 // the convolution with identical arithmetic, so the ReLU mask z > 0 of the backward is exactly the forward's.
 // Pointwise convs (and the im2col'd stem) run on the bf16 MFMA (16x16x32), depthwise convs on fp32 FMAs.
 #include "frost_common.h"
+#include <type_traits>
 
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 
-enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3 };
+enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3, F_PLAIN = 4 };      // F_PLAIN: out = conv (the data-gradient GEMM of the fp32 mode)
+// element access for the two storage types
+template <typename T> struct FEl;
+template <> struct FEl<uint16_t> {
+  static __device__ __forceinline__ void ld8(const uint16_t* p, float* o) {
+    const uint4 v = *(const uint4*)p;
+    o[0] = bf2f(v.x & 0xffff); o[1] = bf2f(v.x >> 16); o[2] = bf2f(v.y & 0xffff); o[3] = bf2f(v.y >> 16);
+    o[4] = bf2f(v.z & 0xffff); o[5] = bf2f(v.z >> 16); o[6] = bf2f(v.w & 0xffff); o[7] = bf2f(v.w >> 16);
+  }
+  static __device__ __forceinline__ void st8(uint16_t* p, const float* v) {
+    uint4 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]); o.z = cvt_pk_bf16(v[4], v[5]); o.w = cvt_pk_bf16(v[6], v[7]);
+    *(uint4*)p = o;
+  }
+  static __device__ __forceinline__ void ld4(const uint16_t* p, float* o) {
+    const uint2 v = *(const uint2*)p; o[0] = bf2f(v.x & 0xffff); o[1] = bf2f(v.x >> 16); o[2] = bf2f(v.y & 0xffff); o[3] = bf2f(v.y >> 16);
+  }
+  static __device__ __forceinline__ void st4(uint16_t* p, const float* v) { uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]); *(uint2*)p = o; }
+  static __device__ __forceinline__ float ld1(const uint16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st1(uint16_t* p, float v) { *p = f2bf(v); }
+};
+template <> struct FEl<float> {
+  static __device__ __forceinline__ void ld8(const float* p, float* o) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  }
+  static __device__ __forceinline__ void st8(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+  static __device__ __forceinline__ void ld4(const float* p, float* o) { const float4 a = *(const float4*)p; o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+  static __device__ __forceinline__ void st4(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
 // inclusive scan over a 16-lane row with row_shr 1,2,4,8: lane 15 of every row holds the row total (pure VALU, no LDS crossbar)
 template <int CTRL> __device__ __forceinline__ float f_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float f_row_sum(float v) { v += f_dpp<0x111>(v); v += f_dpp<0x112>(v); v += f_dpp<0x114>(v); v += f_dpp<0x118>(v); return v; }
+__device__ __forceinline__ double f_row_sum(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
 enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, FC_F = 6, FC_VAR = 7 };
 
 // ------------------------------------------------------------------------------------------------ weight preparation (per step)
@@ -27,7 +61,31 @@ __global__ __launch_bounds__(256) void k_f_prep(const FrostFDesc* descs) {
   const FrostFDesc d = descs[blockIdx.y];
   const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
   for (int i = gtid; i < 4 * d.cpad; i += gsz) d.stat[i] = 0.0;
-  if (d.kind == 0 || d.kind == 2) {       // A-fragments [ct][kb][lane][8]: W[ct*16 + (lane&15)][kb*32 + (lane>>4)*8 + e]
+  if ((d.kind == 0 || d.kind == 2) && d.fp32) {       // fp32 mode: A-fragments [ct][kb][lane][4]: W[ct*16 + (lane&15)][kb*16 + (lane>>4)*4 + e]
+    const int CT = d.cpad / 16, KB = d.kpad / 16;
+    const int64_t nel = (int64_t)CT * KB * 256;
+    float* pk = (float*)d.pack;
+    for (int64_t i = gtid; i < nel; i += gsz) {
+      const int e = (int)(i & 3), lane = (int)((i >> 2) & 63); const int64_t t = i >> 8; const int kb = (int)(t % KB), ct = (int)(t / KB);
+      const int co = ct * 16 + (lane & 15), k = kb * 16 + (lane >> 4) * 4 + e;
+      float v = 0.0f;
+      if (co < d.cout) {
+        if (d.kind == 0) { if (k < d.cin_g) v = d.w[(int64_t)co * d.cin_g + k]; }
+        else { const int tap = k >> 2, c = k & 3; if (tap < d.kk && c < d.cin_g) v = d.w[((int64_t)co * d.cin_g + c) * d.kk + tap]; }
+      }
+      pk[i] = v;
+    }
+    if (d.pack_t) {
+      const int CTt = round_up(d.cin_g, 16) / 16, KBt = d.kpad_t / 16;
+      const int64_t nt = (int64_t)CTt * KBt * 256;
+      float* pt = (float*)d.pack_t;
+      for (int64_t i = gtid; i < nt; i += gsz) {
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63); const int64_t t = i >> 8; const int kb = (int)(t % KBt), ct = (int)(t / KBt);
+        const int ci = ct * 16 + (lane & 15), co = kb * 16 + (lane >> 4) * 4 + e;
+        pt[i] = (ci < d.cin_g && co < d.cout) ? d.w[(int64_t)co * d.cin_g + ci] : 0.0f;
+      }
+    }
+  } else if (d.kind == 0 || d.kind == 2) {       // A-fragments [ct][kb][lane][8]: W[ct*16 + (lane&15)][kb*32 + (lane>>4)*8 + e]
     const int CT = d.cpad / 16, KB = d.kpad / 32;
     const int64_t nel = (int64_t)CT * KB * 512;
     uint16_t* pk = (uint16_t*)d.pack;
@@ -112,8 +170,12 @@ __global__ __launch_bounds__(256) void k_f_bwd_finalize(const FrostFDesc* dp, do
   const float K1 = d.gamma[c] * inv;
   const float a = (float)(S1 / count), b = (float)(S2 / count);
   d.coef[FC_K1 * d.cpad + c] = K1;
-  d.coef[FC_E * d.cpad + c] = -K1 * b * inv;
-  d.coef[FC_F * d.cpad + c] = -K1 * a + K1 * b * mean * inv;
+  if (d.fp32) {        // fp32 mode evaluates dc = K1 * ((g - a) - xhat * b) with xhat = (conv - mean) * inv, the reference's own order: rows E / F carry b / a
+    d.coef[FC_E * d.cpad + c] = b; d.coef[FC_F * d.cpad + c] = a;
+  } else {             // bf16 mode: folded, dc = g*K1 + conv*E + F (two fmas; the cancellation it carries is below the bf16 storage error)
+    d.coef[FC_E * d.cpad + c] = -K1 * b * inv;
+    d.coef[FC_F * d.cpad + c] = -K1 * a + K1 * b * mean * inv;
+  }
   d.dgamma[c] += (float)S2; d.dbeta[c] += (float)S1;
 }
 extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream) {
@@ -129,20 +191,23 @@ extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_
 //   F_STATS: sum / sum of squares of conv            F_EMIT: y = [relu](conv*scale + bias) -> bf16
 //   F_BRED : S1 += g*m, S2 += g*m*xhat               F_BDC : dc = g*m*K1 + conv*E + F -> bf16        (m = z > 0 for ReLU layers)
 // (the data gradient dx = dc . W^T is a plain bf16 GEMM: frost_infer_pw on the transposed pack, frost_pw.hip)
-template <int MODE, int WPX>
-__global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16_t* __restrict__ T, const uint16_t* __restrict__ pack, int64_t npix,
-                                              int cin, int cout, int cpad, int KB, int kstr, int relu, const uint16_t* __restrict__ gy, int ldg,
-                                              uint16_t* __restrict__ y, int ldy, int64_t ntiles) {
+template <int MODE, int WPX, typename ET>
+__global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __restrict__ T, const void* __restrict__ packv, int64_t npix,
+                                              int cin, int cout, int cpad, int KB, int kstr, int relu, const ET* __restrict__ gy, int ldg,
+                                              ET* __restrict__ y, int ldy, int64_t ntiles) {
+  constexpr bool F32 = sizeof(ET) == 4;          // K step = 64 bytes of a row either way: 32 bf16 (one 16x16x32 MFMA) or 16 floats (four 16x16x4 MFMAs)
+  const uint8_t* pack = (const uint8_t*)packv;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int IPX = 16 * WPX, WCH = 4 / WPX;
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   const int wpx = w % WPX, wch = w / WPX;
-  float* sacc = (float*)(smem + IPX * kstr);
-  const float* coef = dp->coef;
-  if (RED) for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f;
-  const int rowb = cin * 2; const int U = (KB * 64) >> 4;
+  using SA = typename std::conditional<F32, double, float>::type;     // fp32 mode: statistics partials in double (the reference's CPU BatchNorm accumulates in double)
+  SA* sacc = (SA*)(smem + IPX * kstr);
+  const float* coef = (MODE == F_PLAIN) ? nullptr : dp->coef;
+  if (RED) for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = (SA)0;
+  const int rowb = cin * (int)sizeof(ET); const int U = (KB * 64) >> 4;
   const int CT = cpad >> 4;
   const float lo = relu ? 0.0f : -INFINITY;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -165,10 +230,15 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
         const v4i bfr = *(const v4i*)(smem + (wpx * 16 + j) * kstr + kb * 64 + g * 16);
         v4i afr[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) if (ct0 + m < CT) afr[m] = *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 3));
+        for (int m = 0; m < 4; ++m) if (ct0 + m < CT) afr[m] = *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 4));
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-          if (ct0 + m < CT) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr), acc[m], 0, 0, 0);
+          if (ct0 + m < CT) {
+            if (F32) {         // lane (i, g) holds k = 4g .. 4g+3 of this 16-wide K block in both operands: instruction e contracts {4g + e}
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(afr[m][e]), __int_as_float(bfr[e]), acc[m], 0, 0, 0);
+            } else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr), acc[m], 0, 0, 0);
+          }
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -176,10 +246,12 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
         const int ch0 = (ct0 + m) * 16 + 4 * g;
         const bool cv = ch0 < cout;
         const bool ok = cv && pv;
-        if constexpr (MODE == F_STATS) {
-          float s[4], q[4];
+        if constexpr (MODE == F_PLAIN) {
+          if (ok) { const float o4[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]}; FEl<ET>::st4(y + prow * ldy + ch0, o4); }
+        } else if constexpr (MODE == F_STATS) {
+          SA s[4], q[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = ok ? acc[m][r] : 0.0f; s[r] = v; q[r] = v * v; }
+          for (int r = 0; r < 4; ++r) { const SA v = ok ? (SA)acc[m][r] : (SA)0; s[r] = v; q[r] = v * v; }
 #pragma unroll
           for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
           if (j == 15 && cv) {
@@ -192,15 +264,13 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
           const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
           if constexpr (MODE == F_EMIT) {
             if (ok) {
-              uint2 o;
-              o.x = cvt_pk_bf16(fmaxf(fmaf(acc[m][0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[m][1], sc[1], bi[1]), lo));
-              o.y = cvt_pk_bf16(fmaxf(fmaf(acc[m][2], sc[2], bi[2]), lo), fmaxf(fmaf(acc[m][3], sc[3], bi[3]), lo));
-              *(uint2*)(y + prow * ldy + ch0) = o;
+              const float o4[4] = {fmaxf(fmaf(acc[m][0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[m][1], sc[1], bi[1]), lo),
+                                   fmaxf(fmaf(acc[m][2], sc[2], bi[2]), lo), fmaxf(fmaf(acc[m][3], sc[3], bi[3]), lo)};
+              FEl<ET>::st4(y + prow * ldy + ch0, o4);
             }
           } else {
-            uint2 gv = make_uint2(0, 0);
-            if (ok) gv = *(const uint2*)(gy + prow * ldg + ch0);
-            float gm[4] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16)};
+            float gm[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok) FEl<ET>::ld4(gy + prow * ldg + ch0, gm);
             if (relu) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) if (!(fmaf(acc[m][r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
@@ -208,9 +278,9 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
             if constexpr (MODE == F_BRED) {
               const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
               const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
-              float s[4], q[4];
+              SA s[4], q[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) { const float xh = (acc[m][r] - mu[r]) * iv[r]; s[r] = ok ? gm[r] : 0.0f; q[r] = ok ? gm[r] * xh : 0.0f; }
+              for (int r = 0; r < 4; ++r) { const float xh = (acc[m][r] - mu[r]) * iv[r]; s[r] = ok ? (SA)gm[r] : (SA)0; q[r] = ok ? (SA)gm[r] * (SA)xh : (SA)0; }
 #pragma unroll
               for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
               if (j == 15 && cv) {
@@ -222,10 +292,16 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
               const float k1[4] = {k4.x, k4.y, k4.z, k4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
               if (ok) {
                 float dcv[4];
+                if (F32) {
+                  const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
+                  const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dcv[r] = fmaf(gm[r], k1[r], fmaf(acc[m][r], ee[r], ff[r]));
-                uint2 o; o.x = cvt_pk_bf16(dcv[0], dcv[1]); o.y = cvt_pk_bf16(dcv[2], dcv[3]);
-                *(uint2*)(y + prow * ldy + ch0) = o;
+                  for (int r = 0; r < 4; ++r) dcv[r] = k1[r] * ((gm[r] - ff[r]) - ((acc[m][r] - mu[r]) * iv[r]) * ee[r]);
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) dcv[r] = fmaf(gm[r], k1[r], fmaf(acc[m][r], ee[r], ff[r]));
+                }
+                FEl<ET>::st4(y + prow * ldy + ch0, dcv);
               }
             }
           }
@@ -236,61 +312,74 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const uint16
   if (RED) {
     __syncthreads();
     double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
-    for (int i = tid; i < 2 * cpad; i += 256) { const float v = sacc[i]; if (v != 0.0f) atomicAdd(st + i, (double)v); }
+    for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
-template <int MODE>
-static int launch_f_pw(const FrostFDesc* dp, const uint16_t* T, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, const uint16_t* gy,
-                       int ldg, uint16_t* y, int ldy, hipStream_t s) {
-  const int KB = (cin + 31) / 32; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
+template <int MODE, typename ET>
+static int launch_f_pw(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int relu, const ET* gy,
+                       int ldg, ET* y, int ldy, hipStream_t s) {
+  const int KB = (cin * (int)sizeof(ET) + 63) / 64; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
-  const size_t extra = RED ? (size_t)2 * cpad * 4 : 0;
+  const size_t extra = RED ? (size_t)2 * cpad * sizeof(typename std::conditional<sizeof(ET) == 4, double, float>::type) : 0;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute((const void*)k_f_pw<MODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_f_pw<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_f_pw<MODE, 4, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_f_pw<MODE, 1, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   if ((size_t)64 * kstr <= 48 * 1024) {
     const int64_t nt = (npix + 63) / 64; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((k_f_pw<MODE, 4>), dim3((unsigned)grid), dim3(256), (size_t)64 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
+    hipLaunchKernelGGL((k_f_pw<MODE, 4, ET>), dim3((unsigned)grid), dim3(256), (size_t)64 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
                        gy, ldg, y, ldy, nt);
   } else {
     if ((size_t)16 * kstr + extra > 160 * 1024) { frost_set_error("float_pw: row too long for the LDS tile"); return 1; }
     const int64_t nt = (npix + 15) / 16; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((k_f_pw<MODE, 1>), dim3((unsigned)grid), dim3(256), (size_t)16 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
+    hipLaunchKernelGGL((k_f_pw<MODE, 1, ET>), dim3((unsigned)grid), dim3(256), (size_t)16 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
                        gy, ldg, y, ldy, nt);
   }
   return frost_check_launch("float_pw");
 }
-// x: bf16 [npix][cin] (cin = the row length: 64 for the im2col'd stem); pack: the layer's forward pack; gy / out rows may be slices of
+template <typename ET>
+static int float_pw_any(const FrostFDesc* desc, const ET* x, const void* pack, int64_t npix, int cin, int cout, int relu, int mode, const ET* gy, int ldg,
+                        ET* out, int ldy, hipStream_t s) {
+  switch (mode) {
+    case F_STATS: return launch_f_pw<F_STATS, ET>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_EMIT: return launch_f_pw<F_EMIT, ET>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_BRED: return launch_f_pw<F_BRED, ET>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    case F_BDC: return launch_f_pw<F_BDC, ET>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+    default: return launch_f_pw<F_PLAIN, ET>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
+  }
+}
+// x: [npix][cin] (cin = the row length: 64 for the im2col'd stem); pack: the layer's forward pack; gy / out rows may be slices of
 // wider tensors (ldg / ldy = row length in elements)
 extern "C" int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pack, int64_t npix, int cin, int cout, int relu, int mode,
                               const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "float_pw: cin must be a multiple of 8, cout of 4");
   FROST_REQUIRE(mode >= 0 && mode <= 3, "float_pw: mode 0..3");
-  hipStream_t s = as_stream(stream);
-  switch (mode) {
-    case F_STATS: return launch_f_pw<F_STATS>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-    case F_EMIT: return launch_f_pw<F_EMIT>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-    case F_BRED: return launch_f_pw<F_BRED>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-    default: return launch_f_pw<F_BDC>(desc, x, pack, npix, cin, cout, relu, gy, ldg, out, ldy, s);
-  }
+  return float_pw_any<uint16_t>(desc, x, pack, npix, cin, cout, relu, mode, gy, ldg, out, ldy, as_stream(stream));
+}
+// fp32 activations; mode 4 = plain GEMM out = x . pack^T (the data gradient: x = dc, pack = the layer's transposed pack, desc unused)
+extern "C" int frost_float_pw_f32(const FrostFDesc* desc, const float* x, const float* pack, int64_t npix, int cin, int cout, int relu, int mode,
+                                  const float* gy, int ldg, float* out, int ldy, void* stream) {
+  FROST_REQUIRE(cin % 4 == 0 && cout % 4 == 0, "float_pw_f32: channel counts must be multiples of 4");
+  FROST_REQUIRE(mode >= 0 && mode <= 4, "float_pw_f32: mode 0..4");
+  return float_pw_any<float>(desc, x, pack, npix, cin, cout, relu, mode, gy, ldg, out, ldy, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise passes (fp32 FMA)
 // one thread = 8 channels (fixed for the thread's whole life, so statistics stay in registers) x a strided set of output-pixel PAIRS
 // (two horizontally adjacent outputs share the S + K input columns of a kernel row and every tap's weights: 1.5-1.7x fewer loads)
 #define FDW_WO 2
-template <int MODE, int K, int S>
-__global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16_t* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo,
-                                              int relu, const uint16_t* __restrict__ gy, uint16_t* __restrict__ y) {
+template <int MODE, int K, int S, typename ET>
+__global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo,
+                                              int relu, const ET* __restrict__ gy, ET* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   constexpr int PAD = (K - 1) / 2, SPAN = (FDW_WO - 1) * S + K;
-  float* sacc = (float*)smem;
+  using SA = typename std::conditional<sizeof(ET) == 4, double, float>::type;     // fp32 mode: statistics partials in double
+  SA* sacc = (SA*)smem;
   const int tid = threadIdx.x;
-  if (RED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = 0.0f; __syncthreads(); }
+  if (RED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = (SA)0; __syncthreads(); }
   const int c8n = c >> 3; const int wog = (wo + FDW_WO - 1) / FDW_WO;
   const int64_t nthreads = (int64_t)gridDim.x * 256; const int64_t PP = nthreads / c8n;
   const int64_t t = (int64_t)blockIdx.x * 256 + tid;
@@ -298,18 +387,19 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
   const int ch = c8 * 8;
   const int64_t nunits = (int64_t)n * ho * wog;
   const float* wf = (const float*)dp->pack; const float* coef = dp->coef;
-  float sc[8], bi[8], c2[8], c3[8], c4[8];
+  float sc[8], bi[8], c2[8], c3[8], c4[8], c5[8], c6[8];
   if (MODE != F_STATS) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sc[e] = coef[FC_SCALE * cpad + ch + e]; bi[e] = coef[FC_BIAS * cpad + ch + e];
       if (MODE == F_BRED) { c2[e] = coef[FC_MEAN * cpad + ch + e]; c3[e] = coef[FC_INV * cpad + ch + e]; }
-      if (MODE == F_BDC) { c2[e] = coef[FC_K1 * cpad + ch + e]; c3[e] = coef[FC_E * cpad + ch + e]; c4[e] = coef[FC_F * cpad + ch + e]; }
+      if (MODE == F_BDC) { c2[e] = coef[FC_K1 * cpad + ch + e]; c3[e] = coef[FC_E * cpad + ch + e]; c4[e] = coef[FC_F * cpad + ch + e];
+                           if (sizeof(ET) == 4) { c5[e] = coef[FC_MEAN * cpad + ch + e]; c6[e] = coef[FC_INV * cpad + ch + e]; } }
     }
   }
-  float s[8], q[8];
+  SA s[8], q[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { s[e] = 0.0f; q[e] = 0.0f; }
+  for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
   const float lo = relu ? 0.0f : -INFINITY;
   if (slot < PP) {
     for (int64_t u = slot; u < nunits; u += PP) {
@@ -323,15 +413,14 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * S - PAD + ky; if (iy < 0 || iy >= h) continue;
-        const uint16_t* rowp = x + ((int64_t)in * h + iy) * w * c + ch;
+        const ET* rowp = x + ((int64_t)in * h + iy) * w * c + ch;
         float col[SPAN][8];
 #pragma unroll
         for (int qx = 0; qx < SPAN; ++qx) {
           const int ix = ix0 + qx;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (ix >= 0 && ix < w) v = *(const uint4*)(rowp + (int64_t)ix * c);
-          col[qx][0] = bf2f(v.x & 0xffff); col[qx][1] = bf2f(v.x >> 16); col[qx][2] = bf2f(v.y & 0xffff); col[qx][3] = bf2f(v.y >> 16);
-          col[qx][4] = bf2f(v.z & 0xffff); col[qx][5] = bf2f(v.z >> 16); col[qx][6] = bf2f(v.w & 0xffff); col[qx][7] = bf2f(v.w >> 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) col[qx][e] = 0.0f;
+          if (ix >= 0 && ix < w) FEl<ET>::ld8(rowp + (int64_t)ix * c, col[qx]);
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
@@ -350,29 +439,28 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
         const int64_t p = ((int64_t)in * ho + oy) * wo + ox0 + o;
         if constexpr (MODE == F_STATS) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += acc[o][e]; q[e] = fmaf(acc[o][e], acc[o][e], q[e]); }
+          for (int e = 0; e < 8; ++e) { s[e] += (SA)acc[o][e]; q[e] += (SA)acc[o][e] * (SA)acc[o][e]; }
         } else if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(acc[o][e], sc[e], bi[e]), lo);
-          uint4 ov; ov.x = cvt_pk_bf16(o8[0], o8[1]); ov.y = cvt_pk_bf16(o8[2], o8[3]); ov.z = cvt_pk_bf16(o8[4], o8[5]); ov.w = cvt_pk_bf16(o8[6], o8[7]);
-          *(uint4*)(y + p * c + ch) = ov;
+          FEl<ET>::st8(y + p * c + ch, o8);
         } else {
-          const uint4 gv = *(const uint4*)(gy + p * c + ch);
-          float gm[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+          float gm[8];
+          FEl<ET>::ld8(gy + p * c + ch, gm);
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (!(fmaf(acc[o][e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
           }
           if constexpr (MODE == F_BRED) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s[e] += gm[e]; q[e] = fmaf(gm[e], (acc[o][e] - c2[e]) * c3[e], q[e]); }
+            for (int e = 0; e < 8; ++e) { s[e] += (SA)gm[e]; q[e] += (SA)gm[e] * (SA)((acc[o][e] - c2[e]) * c3[e]); }
           } else {
             float o8[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = fmaf(gm[e], c2[e], fmaf(acc[o][e], c3[e], c4[e]));
-            uint4 ov; ov.x = cvt_pk_bf16(o8[0], o8[1]); ov.y = cvt_pk_bf16(o8[2], o8[3]); ov.z = cvt_pk_bf16(o8[4], o8[5]); ov.w = cvt_pk_bf16(o8[6], o8[7]);
-            *(uint4*)(y + p * c + ch) = ov;
+            for (int e = 0; e < 8; ++e)
+              o8[e] = (sizeof(ET) == 4) ? c2[e] * ((gm[e] - c4[e]) - ((acc[o][e] - c5[e]) * c6[e]) * c3[e]) : fmaf(gm[e], c2[e], fmaf(acc[o][e], c3[e], c4[e]));
+            FEl<ET>::st8(y + p * c + ch, o8);
           }
         }
       }
@@ -385,18 +473,18 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const uint16
     }
     __syncthreads();
     double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
-    for (int i = tid; i < 2 * cpad; i += 256) { const float v = sacc[i]; if (v != 0.0f) atomicAdd(st + i, (double)v); }
+    for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
-template <int K, int S>
-static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int cpad, int ho,
-                        int wo, int relu, const uint16_t* gy, uint16_t* out) {
-#define FDW_LAUNCH(M) hipLaunchKernelGGL((k_f_dw<M, K, S>), dim3((unsigned)grid), dim3(256), lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out)
+template <int K, int S, typename ET>
+static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho,
+                        int wo, int relu, const ET* gy, ET* out) {
+#define FDW_LAUNCH(M) hipLaunchKernelGGL((k_f_dw<M, K, S, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out)
   switch (mode) { case F_STATS: FDW_LAUNCH(F_STATS); break; case F_EMIT: FDW_LAUNCH(F_EMIT); break; case F_BRED: FDW_LAUNCH(F_BRED); break; default: FDW_LAUNCH(F_BDC); }
 #undef FDW_LAUNCH
 }
-extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
-                              const uint16_t* gy, uint16_t* out, void* stream) {
+template <typename ET>
+static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int k, int stride, int relu, int mode, const ET* gy, ET* out, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0, "float_dw: channels must be a multiple of 8");
   FROST_REQUIRE(mode >= 0 && mode <= 3, "float_dw: mode 0..3");
   FROST_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "float_dw: 3x3 / 5x5, stride 1 / 2");
@@ -406,18 +494,26 @@ extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, 
   const bool red = (mode == F_STATS || mode == F_BRED);
   int64_t grid = (tot + 255) / 256; const int64_t cap = red ? 2048 : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;      // every channel group needs at least one thread
-  const size_t lds = red ? (size_t)2 * cpad * 4 : 0;
-  hipStream_t s = as_stream(stream);
-  if (k == 3 && stride == 1) launch_f_dw<3, 1>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
-  else if (k == 3) launch_f_dw<3, 2>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
-  else if (stride == 1) launch_f_dw<5, 1>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
-  else launch_f_dw<5, 2>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  const size_t lds = red ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
+  if (k == 3 && stride == 1) launch_f_dw<3, 1, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else if (k == 3) launch_f_dw<3, 2, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else if (stride == 1) launch_f_dw<5, 1, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
+  else launch_f_dw<5, 2, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
   return frost_check_launch("float_dw");
+}
+extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
+                              const uint16_t* gy, uint16_t* out, void* stream) {
+  return float_dw_any<uint16_t>(desc, x, n, h, w, c, k, stride, relu, mode, gy, out, as_stream(stream));
+}
+extern "C" int frost_float_dw_f32(const FrostFDesc* desc, const float* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
+                                  const float* gy, float* out, void* stream) {
+  return float_dw_any<float>(desc, x, n, h, w, c, k, stride, relu, mode, gy, out, as_stream(stream));
 }
 
 // depthwise data gradient: dx[n][iy][ix][c] = sum_{ky,kx} dc[n][(iy+pad-ky)/s][(ix+pad-kx)/s][c] * w[c][ky][kx]   (where divisible / in range)
-__global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const uint16_t* __restrict__ dc, int n, int h, int w, int c, int cpad, int k, int stride,
-                                                    int ho, int wo, uint16_t* __restrict__ dx) {
+template <typename ET>
+__global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const ET* __restrict__ dc, int n, int h, int w, int c, int cpad, int k, int stride,
+                                                    int ho, int wo, ET* __restrict__ dx) {
   const int c8n = c >> 3; const int pad = (k - 1) / 2;
   const int64_t tot = (int64_t)n * h * w * c8n;
   const float* wf = (const float*)dp->pack;
@@ -431,31 +527,37 @@ __global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const 
       const int ty = iy + pad - ky; if (ty < 0 || ty % stride) continue; const int oy = ty / stride; if (oy >= ho) continue;
       for (int kx = 0; kx < k; ++kx) {
         const int tx = ix + pad - kx; if (tx < 0 || tx % stride) continue; const int ox = tx / stride; if (ox >= wo) continue;
-        const uint4 v = *(const uint4*)(dc + (((int64_t)in * ho + oy) * wo + ox) * c + ch);
+        float v[8];
+        FEl<ET>::ld8(dc + (((int64_t)in * ho + oy) * wo + ox) * c + ch, v);
         const float* wp = wf + (ky * k + kx) * cpad + ch;
         const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
-        acc[0] = fmaf(bf2f(v.x & 0xffff), w0.x, acc[0]); acc[1] = fmaf(bf2f(v.x >> 16), w0.y, acc[1]);
-        acc[2] = fmaf(bf2f(v.y & 0xffff), w0.z, acc[2]); acc[3] = fmaf(bf2f(v.y >> 16), w0.w, acc[3]);
-        acc[4] = fmaf(bf2f(v.z & 0xffff), w1.x, acc[4]); acc[5] = fmaf(bf2f(v.z >> 16), w1.y, acc[5]);
-        acc[6] = fmaf(bf2f(v.w & 0xffff), w1.z, acc[6]); acc[7] = fmaf(bf2f(v.w >> 16), w1.w, acc[7]);
+        acc[0] = fmaf(v[0], w0.x, acc[0]); acc[1] = fmaf(v[1], w0.y, acc[1]); acc[2] = fmaf(v[2], w0.z, acc[2]); acc[3] = fmaf(v[3], w0.w, acc[3]);
+        acc[4] = fmaf(v[4], w1.x, acc[4]); acc[5] = fmaf(v[5], w1.y, acc[5]); acc[6] = fmaf(v[6], w1.z, acc[6]); acc[7] = fmaf(v[7], w1.w, acc[7]);
       }
     }
-    uint4 o; o.x = cvt_pk_bf16(acc[0], acc[1]); o.y = cvt_pk_bf16(acc[2], acc[3]); o.z = cvt_pk_bf16(acc[4], acc[5]); o.w = cvt_pk_bf16(acc[6], acc[7]);
-    *(uint4*)(dx + (((int64_t)in * h + iy) * w + ix) * c + ch) = o;
+    FEl<ET>::st8(dx + (((int64_t)in * h + iy) * w + ix) * c + ch, acc);
   }
 }
-extern "C" int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream) {
+template <typename ET>
+static int float_dw_dgrad_any(const FrostFDesc* desc, const ET* dc, int n, int h, int w, int c, int k, int stride, ET* dx, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0, "float_dw_dgrad: channels must be a multiple of 8");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   const int64_t tot = (int64_t)n * h * w * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL(k_f_dw_dgrad, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), desc, dc, n, h, w, c, round_up(c, 16), k, stride, ho, wo, dx);
+  hipLaunchKernelGGL(k_f_dw_dgrad<ET>, dim3((unsigned)grid), dim3(256), 0, s, desc, dc, n, h, w, c, round_up(c, 16), k, stride, ho, wo, dx);
   return frost_check_launch("float_dw_dgrad");
+}
+extern "C" int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream) {
+  return float_dw_dgrad_any<uint16_t>(desc, dc, n, h, w, c, k, stride, dx, as_stream(stream));
+}
+extern "C" int frost_float_dw_dgrad_f32(const FrostFDesc* desc, const float* dc, int n, int h, int w, int c, int k, int stride, float* dx, void* stream) {
+  return float_dw_dgrad_any<float>(desc, dc, n, h, w, c, k, stride, dx, as_stream(stream));
 }
 
 // depthwise weight gradient: dW[c][ky][kx] += sum_p dc[p][c] * x[n][oy*s-pad+ky][ox*s-pad+kx][c]
 // workgroup = (32-channel group, kernel row ky) x a strided set of output pixels: thread = 8 channels (4 adjacent threads read one 64-byte
 // segment) x one of 64 pixel lanes, k*8 accumulators; lanes are summed through LDS and leave with one atomic per (channel, tap).
-__global__ __launch_bounds__(256) void k_f_dw_wgrad(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ x, int n, int h, int w, int c, int k, int stride,
+template <typename ET>
+__global__ __launch_bounds__(256) void k_f_dw_wgrad(const ET* __restrict__ dc, const ET* __restrict__ x, int n, int h, int w, int c, int k, int stride,
                                                     int ho, int wo, float* __restrict__ dw) {
   __shared__ float red[32 * 5];
   const int tid = threadIdx.x, c8l = tid & 3, pl = tid >> 2;
@@ -472,17 +574,16 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const uint16_t* __restrict__
     for (int64_t p = (int64_t)blockIdx.x * 64 + pl; p < npix; p += (int64_t)gridDim.x * 64) {
       int64_t pp = p; const int ox = (int)(pp % wo); pp /= wo; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
       const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
-      const uint4 gv = *(const uint4*)(dc + p * c + ch);
-      const float g8[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+      float g8[8];
+      FEl<ET>::ld8(dc + p * c + ch, g8);
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx) {
         if (kx >= k) break;
         const int ix = ox * stride - pad + kx; if (ix < 0 || ix >= w) continue;
-        const uint4 v = *(const uint4*)(x + (((int64_t)in * h + iy) * w + ix) * c + ch);
-        a[kx][0] = fmaf(g8[0], bf2f(v.x & 0xffff), a[kx][0]); a[kx][1] = fmaf(g8[1], bf2f(v.x >> 16), a[kx][1]);
-        a[kx][2] = fmaf(g8[2], bf2f(v.y & 0xffff), a[kx][2]); a[kx][3] = fmaf(g8[3], bf2f(v.y >> 16), a[kx][3]);
-        a[kx][4] = fmaf(g8[4], bf2f(v.z & 0xffff), a[kx][4]); a[kx][5] = fmaf(g8[5], bf2f(v.z >> 16), a[kx][5]);
-        a[kx][6] = fmaf(g8[6], bf2f(v.w & 0xffff), a[kx][6]); a[kx][7] = fmaf(g8[7], bf2f(v.w >> 16), a[kx][7]);
+        float v[8];
+        FEl<ET>::ld8(x + (((int64_t)in * h + iy) * w + ix) * c + ch, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[kx][e] = fmaf(g8[e], v[e], a[kx][e]);
       }
     }
   }
@@ -504,14 +605,21 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const uint16_t* __restrict__
     if (cc < c) atomicAdd(dw + (int64_t)cc * k * k + ky * k + kx, red[cl * 5 + kx]);
   }
 }
-extern "C" int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream) {
+template <typename ET>
+static int float_dw_wgrad_any(const ET* dc, const ET* x, int n, int h, int w, int c, int k, int stride, float* dw, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0 && k <= 5, "float_dw_wgrad: channels must be a multiple of 8, k <= 5");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   const int64_t npix = (int64_t)n * ho * wo;
   const int units = ((c + 31) / 32) * k;
   int64_t gx = (npix + 63) / 64; int64_t cap = 4096 / units; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(k_f_dw_wgrad, dim3((unsigned)gx, units), dim3(256), 0, as_stream(stream), dc, x, n, h, w, c, k, stride, ho, wo, dw);
+  hipLaunchKernelGGL(k_f_dw_wgrad<ET>, dim3((unsigned)gx, units), dim3(256), 0, s, dc, x, n, h, w, c, k, stride, ho, wo, dw);
   return frost_check_launch("float_dw_wgrad");
+}
+extern "C" int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream) {
+  return float_dw_wgrad_any<uint16_t>(dc, x, n, h, w, c, k, stride, dw, as_stream(stream));
+}
+extern "C" int frost_float_dw_wgrad_f32(const float* dc, const float* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream) {
+  return float_dw_wgrad_any<float>(dc, x, n, h, w, c, k, stride, dw, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ pointwise weight gradient (bf16 MFMA, K = pixels)
@@ -616,6 +724,83 @@ extern "C" int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64
   hipLaunchKernelGGL(k_f_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, npix, cin, ldx, cout, dw, ldw, nsplit);
   return frost_check_launch("float_pw_wgrad");
 }
+// fp32 storage: the same 64x64 output tile per workgroup on the fp32 MFMA (16x16x4).  64-pixel blocks staged in their natural layout
+// ([pixel][64 channels] floats); wave w contracts pixels 16w .. 16w+15 of the block: lane (i, g) supplies, for instruction e, pixel
+// 16w + 4g + e of channel i in both operands (the contraction order is free as long as both operands agree).
+#define FW32_KP 64
+#define FW32_RS 272
+__global__ __launch_bounds__(256, 2) void k_f_pw_wgrad_f32(const float* __restrict__ dc, const float* __restrict__ x, int64_t npix, int cin, int ldx, int cout,
+                                                           float* __restrict__ dw, int ldw, int nsplit) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * FW32_KP * FW32_RS];
+  uint8_t* dcs = lds; uint8_t* xs = lds + FW32_KP * FW32_RS;
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nci = (cin + FW_T - 1) / FW_T;
+  const int ntile = ((cout + FW_T - 1) / FW_T) * nci;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  const int co0 = (tile / nci) * FW_T, ci0 = (tile % nci) * FW_T;
+  v4f acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+  int na = (cout - co0 + 15) / 16; if (na > 4) na = 4;
+  int nb = (cin - ci0 + 15) / 16; if (nb > 4) nb = 4;
+  const int64_t nblk = (npix + FW32_KP - 1) / FW32_KP;
+  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+    const int64_t q0 = blk * FW32_KP;
+    __syncthreads();
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {          // 64 pixels x 16 four-channel units per operand
+      const int u = tid + jn * 256; const int pix = u >> 4, c4 = u & 15; const int64_t gp = q0 + pix;
+      float4 vd = make_float4(0.f, 0.f, 0.f, 0.f), vx = vd;
+      if (gp < npix && (co0 + c4 * 4) < cout) vd = *(const float4*)(dc + gp * cout + co0 + c4 * 4);
+      if (gp < npix && (ci0 + c4 * 4) < cin) vx = *(const float4*)(x + gp * ldx + ci0 + c4 * 4);
+      *(float4*)(dcs + pix * FW32_RS + c4 * 16) = vd; *(float4*)(xs + pix * FW32_RS + c4 * 16) = vx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pix = w * 16 + g * 4 + e;
+      float afr[4], bfr[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) afr[a] = (a < na) ? *(const float*)(dcs + pix * FW32_RS + (a * 16 + i16) * 4) : 0.0f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bfr[b] = (b < nb) ? *(const float*)(xs + pix * FW32_RS + (b * 16 + i16) * 4) : 0.0f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (a < na && b < nb) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = (float*)lds;
+  for (int i = tid; i < FW_T * FW_T; i += 256) red[i] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (a < na && b < nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&red[(a * 16 + 4 * g + r) * FW_T + b * 16 + i16], acc[a][b][r]);
+      }
+  __syncthreads();
+  for (int i = tid; i < FW_T * FW_T; i += 256) {
+    const int co = co0 + i / FW_T, ci = ci0 + i % FW_T;
+    if (co < cout && ci < cin) atomicAdd(dw + (int64_t)co * ldw + ci, red[i]);
+  }
+}
+extern "C" int frost_float_pw_wgrad_f32(const float* dc, const float* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream) {
+  FROST_REQUIRE(cin % 4 == 0 && cout % 4 == 0 && ldx % 4 == 0, "float_pw_wgrad_f32: channels must be multiples of 4");
+  const int64_t nblk = (npix + FW32_KP - 1) / FW32_KP;
+  const int ntile = ((cout + FW_T - 1) / FW_T) * ((cin + FW_T - 1) / FW_T);
+  int nsplit = (1024 + ntile - 1) / ntile;
+  if (nsplit > nblk / 4) nsplit = (int)(nblk / 4); if (nsplit < 1) nsplit = 1;
+  hipLaunchKernelGGL(k_f_pw_wgrad_f32, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, npix, cin, ldx, cout, dw, ldw, nsplit);
+  return frost_check_launch("float_pw_wgrad_f32");
+}
 // stem: the im2col'd weight gradient [cout][64] (K = tap*4 + c) back to the OIHW parameter layout [cout][3][9]
 __global__ __launch_bounds__(256) void k_f_stem_wscatter(const float* __restrict__ tmp, int cout, float* __restrict__ dw) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -631,45 +816,109 @@ extern "C" int frost_float_stem_wscatter(const float* tmp, int cout, float* dw, 
 // ------------------------------------------------------------------------------------------------ block wiring, backward
 // gradient of a bottleneck's input = [residual branch: the block output's gradient] + [cat branch: columns cs.. of the cat gradient]
 // + [squeeze conv's data gradient]; any of the three may be absent (NULL).
-__global__ __launch_bounds__(256) void k_f_grad_merge(const uint16_t* __restrict__ res, const uint16_t* __restrict__ cat, int cs, int ccat,
-                                                      const uint16_t* __restrict__ sq, int64_t npix, int c, uint16_t* __restrict__ out) {
+template <typename ET>
+__global__ __launch_bounds__(256) void k_f_grad_merge(const ET* __restrict__ res, const ET* __restrict__ cat, int cs, int ccat,
+                                                      const ET* __restrict__ sq, int64_t npix, int c, ET* __restrict__ out) {
   const int cu = c >> 3; const int64_t tot = npix * cu;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     const int u = (int)(i % cu); const int64_t p = i / cu; const int ch = u * 8;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto add = [&](const uint4 v) {
-      a[0] += bf2f(v.x & 0xffff); a[1] += bf2f(v.x >> 16); a[2] += bf2f(v.y & 0xffff); a[3] += bf2f(v.y >> 16);
-      a[4] += bf2f(v.z & 0xffff); a[5] += bf2f(v.z >> 16); a[6] += bf2f(v.w & 0xffff); a[7] += bf2f(v.w >> 16);
+    auto add = [&](const ET* src) {
+      float v[8];
+      FEl<ET>::ld8(src, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
     };
-    if (res) add(*(const uint4*)(res + p * c + ch));
-    if (cat) add(*(const uint4*)(cat + p * ccat + cs + ch));
-    if (sq) add(*(const uint4*)(sq + p * c + ch));
-    uint4 o; o.x = cvt_pk_bf16(a[0], a[1]); o.y = cvt_pk_bf16(a[2], a[3]); o.z = cvt_pk_bf16(a[4], a[5]); o.w = cvt_pk_bf16(a[6], a[7]);
-    *(uint4*)(out + p * c + ch) = o;
+    if (res) add(res + p * c + ch);
+    if (cat) add(cat + p * ccat + cs + ch);
+    if (sq) add(sq + p * c + ch);
+    FEl<ET>::st8(out + p * c + ch, a);
   }
+}
+template <typename ET>
+static int float_grad_merge_any(const ET* res, const ET* cat, int cs, int ccat, const ET* sq, int64_t npix, int c, ET* out, hipStream_t s) {
+  FROST_REQUIRE(c % 8 == 0 && cs % 8 == 0 && ccat % 8 == 0, "float_grad_merge: channel counts must be multiples of 8");
+  const int64_t tot = npix * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_f_grad_merge<ET>, dim3((unsigned)grid), dim3(256), 0, s, res, cat, cs, ccat, sq, npix, c, out);
+  return frost_check_launch("float_grad_merge");
 }
 extern "C" int frost_float_grad_merge(const uint16_t* res, const uint16_t* cat, int cs, int ccat, const uint16_t* sq, int64_t npix, int c, uint16_t* out,
                                       void* stream) {
-  FROST_REQUIRE(c % 8 == 0 && cs % 8 == 0 && ccat % 8 == 0, "float_grad_merge: channel counts must be multiples of 8");
-  const int64_t tot = npix * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(k_f_grad_merge, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), res, cat, cs, ccat, sq, npix, c, out);
-  return frost_check_launch("float_grad_merge");
+  return float_grad_merge_any<uint16_t>(res, cat, cs, ccat, sq, npix, c, out, as_stream(stream));
+}
+extern "C" int frost_float_grad_merge_f32(const float* res, const float* cat, int cs, int ccat, const float* sq, int64_t npix, int c, float* out, void* stream) {
+  return float_grad_merge_any<float>(res, cat, cs, ccat, sq, npix, c, out, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------ head
 // global average pool with the dropout mask applied (mask holds 0 or 1/keep; NULL = no dropout): y fp32 [n][c]
-__global__ __launch_bounds__(256) void k_f_avgpool(const uint16_t* __restrict__ x, int n, int hw, int c, const float* __restrict__ drop, float* __restrict__ y) {
+template <typename ET>
+__global__ __launch_bounds__(256) void k_f_avgpool(const ET* __restrict__ x, int n, int hw, int c, const float* __restrict__ drop, float* __restrict__ y) {
   const int64_t tot = (int64_t)n * c;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c); const int in = (int)(i / c);
     float s = 0.0f;
-    for (int p = 0; p < hw; ++p) s += bf2f(x[((int64_t)in * hw + p) * c + ch]);
+    for (int p = 0; p < hw; ++p) s += FEl<ET>::ld1(x + ((int64_t)in * hw + p) * c + ch);
     s /= (float)hw;
     y[i] = drop ? s * drop[i] : s;
   }
 }
 extern "C" int frost_float_avgpool(const uint16_t* x, int n, int hw, int c, const float* drop, float* y, void* stream) {
   const int64_t tot = (int64_t)n * c; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_f_avgpool, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, n, hw, c, drop, y);
+  hipLaunchKernelGGL(k_f_avgpool<uint16_t>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, n, hw, c, drop, y);
   return frost_check_launch("float_avgpool");
+}
+extern "C" int frost_float_avgpool_f32(const float* x, int n, int hw, int c, const float* drop, float* y, void* stream) {
+  const int64_t tot = (int64_t)n * c; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_f_avgpool<float>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, n, hw, c, drop, y);
+  return frost_check_launch("float_avgpool_f32");
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 mode: block wiring and the stem's im2col
+// (the bf16 mode uses frost_infer_cat / frost_infer_add / frost_infer_stem_im2col of the inference path)
+__global__ __launch_bounds__(256) void k_f32_cat(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb, int64_t npix, float* __restrict__ y) {
+  const int cu = (ca + cb) >> 2; const int64_t tot = npix * cu;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int u = (int)(i % cu); const int64_t p = i / cu; const int ch = u * 4;
+    *(float4*)(y + p * (ca + cb) + ch) = (ch < ca) ? *(const float4*)(a + p * ca + ch) : *(const float4*)(b + p * cb + (ch - ca));
+  }
+}
+extern "C" int frost_float_cat_f32(const float* a, int ca, const float* b, int cb, int64_t npix, float* y, void* stream) {
+  FROST_REQUIRE(ca % 4 == 0 && cb % 4 == 0, "float_cat_f32: channel counts must be multiples of 4");
+  const int64_t tot = npix * ((ca + cb) >> 2); int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_f32_cat, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a, ca, b, cb, npix, y);
+  return frost_check_launch("float_cat_f32");
+}
+__global__ __launch_bounds__(256) void k_f32_add(const float* __restrict__ a, const float* __restrict__ b, int64_t n4, float* __restrict__ y) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
+    ((float4*)y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+extern "C" int frost_float_add_f32(const float* a, const float* b, int64_t n, float* y, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "float_add_f32: n must be a multiple of 4");
+  int64_t grid = ((n >> 2) + 255) / 256; if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_f32_add, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a, b, n >> 2, y);
+  return frost_check_launch("float_add_f32");
+}
+// 3x3 stride-2 pad-1 patches of the logical (N,3,H,W) fp32 image -> [npix_out][64] fp32, K index = tap*4 + c (c == 3 and k >= 36: 0)
+__global__ __launch_bounds__(256) void k_f32_stem_im2col(const float* __restrict__ x, int n, int h, int w, int ho, int wo, int64_t sn, int64_t sc,
+                                                         int64_t sh, int64_t sw, float* __restrict__ out) {
+  const int64_t tot = (int64_t)n * ho * wo * 16;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int tap = (int)(i & 15); int64_t p = i >> 4; const int ox = (int)(p % wo); p /= wo; const int oy = (int)(p % ho); const int in = (int)(p / ho);
+    float v[3] = {0.f, 0.f, 0.f};
+    if (tap < 9) {
+      const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+      if (iy >= 0 && iy < h && ix >= 0 && ix < w)
+        for (int c = 0; c < 3; ++c) v[c] = x[in * sn + c * sc + iy * sh + ix * sw];
+    }
+    *(float4*)(out + (i << 2)) = make_float4(v[0], v[1], v[2], 0.0f);
+  }
+}
+extern "C" int frost_float_stem_im2col_f32(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* out, void* stream) {
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int64_t tot = (int64_t)n * ho * wo * 16; int64_t grid = (tot + 255) / 256; if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_f32_stem_im2col, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, n, h, w, ho, wo, sn, sc, sh, sw, out);
+  return frost_check_launch("float_stem_im2col_f32");
 }

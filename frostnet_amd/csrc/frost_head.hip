@@ -110,13 +110,14 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int
   out[c] = s;
 }
 // gx[n][hw][c] = dpool[n][c] * drop[n][c] / hw   (bf16)
+template <typename ET>
 __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ dpool, const float* __restrict__ drop, int n, int hw,
-                                                  int c, uint16_t* __restrict__ gx) {
+                                                  int c, ET* __restrict__ gx) {
   int64_t tot = (int64_t)n * hw * c;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     int ch = (int)(i % c); int64_t in = i / ((int64_t)hw * c);
     float v = dpool[in * c + ch]; if (drop) v *= drop[in * c + ch];
-    gx[i] = f2bf(v / (float)hw);
+    if (sizeof(ET) == 4) ((float*)gx)[i] = v / (float)hw; else ((uint16_t*)gx)[i] = f2bf(v / (float)hw);
   }
 }
 // replaces: autograd of [avgpool -> dropout -> nnqat.Conv2d] (frostnet.py:295-299). dlogits already STE-masked.
@@ -130,7 +131,7 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
   launch_sgemm<float, int8_t>(s, dlogits_masked, (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass,
                               wscale ? nullptr : qrec_w + FROST_Q_SCALE, (const float*)nullptr, scratch_dpool, true, nullptr, wscale);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
+  hipLaunchKernelGGL(k_pool_bwd<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("head_bwd");
 }
 
@@ -143,8 +144,19 @@ extern "C" int frost_float_head_bwd(const float* dlogits, const float* pooled, c
   hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
   launch_sgemm<float, float>(s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin, (int64_t)1, n, cin, nclass, (const float*)nullptr, (const float*)nullptr, scratch_dpool, true);
   int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
+  hipLaunchKernelGGL(k_pool_bwd<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("float_head_bwd");
+}
+// the same with an fp32 data gradient (fp32 activation mode of the float path)
+extern "C" int frost_float_head_bwd_f32(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
+                                        const float* drop_mask, float* dw, float* dbias, float* gx, float* scratch_dpool, void* stream) {
+  hipStream_t s = as_stream(stream);
+  launch_sgemm<float, float>(s, dlogits, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dw, true);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
+  launch_sgemm<float, float>(s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin, (int64_t)1, n, cin, nclass, (const float*)nullptr, (const float*)nullptr, scratch_dpool, true);
+  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pool_bwd<float>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
+  return frost_check_launch("float_head_bwd_f32");
 }
 
 // ---------------------------------------------------------------------------------------------- cat / add bwd

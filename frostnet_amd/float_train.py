@@ -7,14 +7,17 @@ for `FP_epoch` epochs with the same GradBoost optimizer, `is_warmup=True`, befor
 Reference semantics kept: BatchNorm2d training semantics (batch mean / biased variance to normalise, running statistics updated
 with momentum 0.1 and the unbiased variance, `num_batches_tracked += 1`), eval mode uses the running statistics, dropout before the
 classifier, parameter gradients accumulated into `p.grad`.  Deviation from the reference (stated tolerance in
-`tests/test_gpu_float.py`): activations and activation gradients are stored as NHWC bf16 (fp32 accumulation everywhere, fp32
-parameters / statistics / weight gradients); the reference keeps fp32 activations.
+`tests/test_gpu_float.py`): by default activations and activation gradients are stored as NHWC bf16 (fp32 accumulation everywhere,
+fp32 parameters / statistics / weight gradients).  `precision="fp32"` (FloatRunner argument, `model.float_precision`, or the environment
+variable FROST_FLOAT_PRECISION) keeps them in fp32 like the reference and runs the products on the fp32 MFMA: the reference's FP32-train
+end-to-end gate applies to that mode (tests/test_gpu_float.py::test_fp32_mode_*).
 
 The module tree stays the owner of every Parameter and buffer; parameter gradients live in one flat fp32 arena (views assigned to
 `p.grad`), the same contract as the fake-quant runner, so the multi-tensor GradBoost step and the data-parallel all-reduce work
 on it unchanged and `statassist_qat_switch` keeps the optimizer state attached.  No CPU / torch-eager fallback: a missing library raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -30,7 +33,7 @@ def round_up(a, b):
 
 
 class FAct:
-    """NHWC bf16 activation (int16 storage, 64 elements of slack for the 16-byte tail loads)."""
+    """NHWC activation, bf16 (int16 storage) or fp32; 64 elements of slack for the 16-byte tail loads."""
     __slots__ = ("buf", "n", "h", "w", "c")
 
     def __init__(self, buf, n, h, w, c):
@@ -41,11 +44,13 @@ class FAct:
         return self.n * self.h * self.w
 
     def float(self):
-        return self.buf[: self.npix * self.c].view(torch.bfloat16).float().view(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2)
+        v = self.buf[: self.npix * self.c]
+        v = v.view(torch.bfloat16).float() if v.dtype == torch.int16 else v
+        return v.view(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2)
 
 
 class _FLayer:
-    def __init__(self, name, seq, relu, dev, stem=False):
+    def __init__(self, name, seq, relu, dev, stem=False, fp32=False):
         conv, bn = seq[0], seq[1]
         if not isinstance(conv, torch.nn.Conv2d) or not isinstance(bn, torch.nn.BatchNorm2d):
             raise RuntimeError("the float device path expects the un-fused float model (Conv2d + BatchNorm2d per layer)")
@@ -54,16 +59,17 @@ class _FLayer:
         self.stride = conv.stride[0]
         self.kind = 2 if stem else (1 if conv.groups > 1 else 0)
         self.cpad = round_up(self.cout, 16)
-        self.pack_t, self.kpad_t = None, 0
+        self.pack_t, self.kpad_t, self.fp32 = None, 0, fp32
+        kq = 16 if fp32 else 32                 # elements per 64-byte K step of the MFMA A-fragment pack
         if self.kind == 1:
             self.kpad = 0
             self.pack = torch.zeros(self.k * self.k * self.cpad, dtype=torch.float32, device=dev)
         else:
-            self.kpad = 64 if stem else round_up(self.cin_g, 32)
-            self.pack = torch.zeros((self.cpad // 16) * (self.kpad // 32) * 512, dtype=torch.int16, device=dev)
+            self.kpad = 64 if stem else round_up(self.cin_g, kq)
+            self.pack = torch.zeros((self.cpad // 16) * (self.kpad // kq) * 1024, dtype=torch.uint8, device=dev)
             if self.kind == 0:
-                self.kpad_t = round_up(self.cout, 32)
-                self.pack_t = torch.zeros((round_up(self.cin_g, 16) // 16) * (self.kpad_t // 32) * 512, dtype=torch.int16, device=dev)
+                self.kpad_t = round_up(self.cout, kq)
+                self.pack_t = torch.zeros((round_up(self.cin_g, 16) // 16) * (self.kpad_t // kq) * 1024, dtype=torch.uint8, device=dev)
         self.stat = torch.zeros(4 * self.cpad, dtype=torch.float64, device=dev)
         self.coef = torch.zeros(8 * self.cpad, dtype=torch.float32, device=dev)
         self.x = None          # saved input of the last recorded forward
@@ -75,7 +81,7 @@ class _FLayer:
                             bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(), self.pack.data_ptr(),
                             self.pack_t.data_ptr() if self.pack_t is not None else None, self.stat.data_ptr(), self.coef.data_ptr(),
                             gviews[id(bn.weight)].data_ptr(), gviews[id(bn.bias)].data_ptr(), self.cout, self.cin_g,
-                            self.k * self.k, self.kind, self.cpad, self.kpad, self.kpad_t, 0)
+                            self.k * self.k, self.kind, self.cpad, self.kpad, self.kpad_t, 1 if self.fp32 else 0)
 
 
 class _FloatFunction(torch.autograd.Function):
@@ -111,8 +117,9 @@ class _FloatFeatFunction(torch.autograd.Function):
 class FloatRunner:
     """Binds a float FrostNet (classification model or features backbone) to the float HIP kernels."""
 
-    def __init__(self, model):
+    def __init__(self, model, precision=None):
         L.load_library()
+        self._set_precision(precision or getattr(model, "float_precision", None))
         params = list(model.parameters())
         if not params[0].is_cuda:
             raise RuntimeError("FloatRunner needs the model on the GPU (no CPU fallback on the product path)")
@@ -133,11 +140,29 @@ class FloatRunner:
         self._finish()
         self._stem_tmp = torch.zeros(self.stem.cout * 64, dtype=torch.float32, device=self.device)
 
+    def _set_precision(self, precision):
+        precision = precision or os.environ.get("FROST_FLOAT_PRECISION", "bf16")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("float path precision is 'bf16' or 'fp32'")
+        self.precision, self.fp32 = precision, precision == "fp32"
+        self._adt = torch.float32 if self.fp32 else torch.int16          # activation / activation-gradient storage
+        sfx = "_f32" if self.fp32 else ""
+        self._fn = {n: n + sfx for n in ("frost_float_pw", "frost_float_dw", "frost_float_dw_dgrad", "frost_float_dw_wgrad", "frost_float_pw_wgrad",
+                                         "frost_float_grad_merge", "frost_float_avgpool", "frost_float_head_bwd")}
+        self._fn["cat"] = "frost_float_cat_f32" if self.fp32 else "frost_infer_cat"
+        self._fn["add"] = "frost_float_add_f32" if self.fp32 else "frost_infer_add"
+        self._fn["im2col"] = "frost_float_stem_im2col_f32" if self.fp32 else "frost_infer_stem_im2col"
+
+    def _store(self, dst, src_nhwc):
+        """fp32 NHWC tensor -> the activation storage type."""
+        dst.copy_(src_nhwc.reshape(-1) if self.fp32 else src_nhwc.to(torch.bfloat16).view(torch.int16).reshape(-1))
+
     @classmethod
-    def for_block(cls, block):
+    def for_block(cls, block, precision=None):
         """Bind a single float CascadePreExBottleneck (teacher-forced block tests: `block_step`)."""
         L.load_library()
         r = cls.__new__(cls)
+        r._set_precision(precision)
         r.model, r.device = block, next(block.parameters()).device
         r._bind_params(list(block.parameters()))
         r.layers, r.stem, r.last, r.fc = [], None, None, None
@@ -180,7 +205,7 @@ class FloatRunner:
         """fp32 (N,C,H,W) -> NHWC bf16 activation."""
         n, c, h, w = x.shape
         a = self._new(n, h, w, c)
-        a.buf[: n * h * w * c] = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).view(torch.int16).reshape(-1)
+        self._store(a.buf[: n * h * w * c], x.permute(0, 2, 3, 1).contiguous())
         return a
 
     def block_step(self, x, gy):
@@ -193,7 +218,7 @@ class FloatRunner:
         return yf, dx.float().contiguous()
 
     def _add(self, name, seq, relu, stem=False):
-        l = _FLayer(name, seq, relu, self.device, stem)
+        l = _FLayer(name, seq, relu, self.device, stem, self.fp32)
         self.layers.append(l)
         return l
 
@@ -219,7 +244,7 @@ class FloatRunner:
                 p.grad = v
 
     def _new(self, n, h, w, c):
-        return FAct(torch.empty(n * h * w * c + 64, dtype=torch.int16, device=self.device), n, h, w, c)
+        return FAct(torch.empty(n * h * w * c + 64, dtype=self._adt, device=self.device), n, h, w, c)
 
     # ------------------------------------------------------------------------------------------ forward
     def _conv(self, l, a, training, record, out=None, ldy=None):
@@ -233,15 +258,15 @@ class FloatRunner:
         npix_o = a.n * ho * wo
         if l.kind == 1:
             if training:
-                call("frost_float_dw", l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, None, stream())
+                call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, None, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call("frost_float_dw", l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), EMIT, None, ptr(y.buf), stream())
+            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), EMIT, None, ptr(y.buf), stream())
         else:
             if training:
-                call("frost_float_pw", l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, None, 0, stream())
+                call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, None, 0, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
             dst, ld = (ptr(y.buf), l.cout) if out is None else (out, ldy)
-            call("frost_float_pw", l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
+            call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
         if record:
             l.x = a
         return y
@@ -254,14 +279,14 @@ class FloatRunner:
                 cs = ent["squeeze"].cout
                 cat = self._new(a.n, a.h, a.w, cs + a.c)
                 sq = self._conv(ent["squeeze"], a, training, record)
-                call("frost_infer_cat", ptr(sq.buf), cs, ptr(a.buf), a.c, a.npix, ptr(cat.buf), stream())     # cat([squeezed, x], 1)
+                call(self._fn["cat"], ptr(sq.buf), cs, ptr(a.buf), a.c, a.npix, ptr(cat.buf), stream())     # cat([squeezed, x], 1)
                 a = cat
             a = self._conv(ent["conv1"], a, training, record)
         a = self._conv(ent["conv2"], a, training, record)
         a = self._conv(ent["reduce"], a, training, record)
         if not blk.reduction:
             out = self._new(a.n, a.h, a.w, a.c)
-            call("frost_infer_add", ptr(inp.buf), ptr(a.buf), a.npix * a.c, ptr(out.buf), stream())
+            call(self._fn["add"], ptr(inp.buf), ptr(a.buf), a.npix * a.c, ptr(out.buf), stream())
             a = out
         if record:
             ent["inp"], ent["out"] = inp, a
@@ -280,7 +305,7 @@ class FloatRunner:
             call("frost_float_bn_eval", ptr(self._table), len(self.layers), stream())
         ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         col = self._new(n, ho, wo, 64)
-        call("frost_infer_stem_im2col", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col.buf), stream())
+        call(self._fn["im2col"], ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col.buf), stream())
         a = self._conv(self.stem, col, training, record)
         outs = []
         for ent in self.blocks:
@@ -302,7 +327,7 @@ class FloatRunner:
             keep = 1.0 - self.drop_rate
             drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device).bernoulli_(keep).div_(keep)
         pooled = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device)
-        call("frost_float_avgpool", ptr(a.buf), a.n, a.h * a.w, a.c, ptr(drop), ptr(pooled), stream())
+        call(self._fn["frost_float_avgpool"], ptr(a.buf), a.n, a.h * a.w, a.c, ptr(drop), ptr(pooled), stream())
         nclass = self.fc.out_channels
         logits = torch.empty(a.n, nclass, dtype=torch.float32, device=self.device)
         call("frost_linear_f32", ptr(pooled), ptr(self.fc.weight), ptr(self.fc.bias), a.n, a.c, nclass, ptr(logits), stream())
@@ -330,34 +355,37 @@ class FloatRunner:
         else:
             ho, wo = a.h, a.w
         npix_o = a.n * ho * wo
-        dc = torch.empty(npix_o * l.cout + 64, dtype=torch.int16, device=self.device)
+        dc = torch.empty(npix_o * l.cout + 64, dtype=self._adt, device=self.device)
         gw = self._gv[id(l.conv.weight)]
         dx = None
         if l.kind == 1:
             if ldg != l.cout:
                 raise RuntimeError("depthwise gradients are dense")
-            call("frost_float_dw", l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BRED, gy, None, stream())
+            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BRED, gy, None, stream())
             call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call("frost_float_dw", l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BDC, gy, ptr(dc), stream())
+            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BDC, gy, ptr(dc), stream())
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
-                call("frost_float_dw_dgrad", l.desc_ptr, ptr(dc), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(dx.buf), stream())
-            call("frost_float_dw_wgrad", ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream())
+                call(self._fn["frost_float_dw_dgrad"], l.desc_ptr, ptr(dc), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(dx.buf), stream())
+            call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream())
         else:
-            call("frost_float_pw", l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
+            call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
             call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call("frost_float_pw", l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
+            call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
                 # data gradient = a plain bf16 GEMM with the transposed pack: the tuned pointwise skeleton (DMA double-buffered tiles,
                 # resident weights, LDS-staged output) that also serves the fake-quant dgrad and the bf16 inference layers
-                call("frost_infer_pw", ptr(dc), ptr(l.pack_t), None, npix_o, l.cout, a.c, 0, ptr(dx.buf), stream())
+                if self.fp32:     # the same GEMM on the fp32 MFMA (mode 4 of the float pointwise kernel)
+                    call("frost_float_pw_f32", None, ptr(dc), ptr(l.pack_t), npix_o, l.cout, a.c, 0, 4, None, 0, ptr(dx.buf), a.c, stream())
+                else:
+                    call("frost_infer_pw", ptr(dc), ptr(l.pack_t), None, npix_o, l.cout, a.c, 0, ptr(dx.buf), stream())
             if l.kind == 2:
                 self._stem_tmp.zero_()
-                call("frost_float_pw_wgrad", ptr(dc), ptr(a.buf), npix_o, 64, 64, l.cout, ptr(self._stem_tmp), 64, stream())
+                call(self._fn["frost_float_pw_wgrad"], ptr(dc), ptr(a.buf), npix_o, 64, 64, l.cout, ptr(self._stem_tmp), 64, stream())
                 call("frost_float_stem_wscatter", ptr(self._stem_tmp), l.cout, ptr(gw), stream())
             else:
-                call("frost_float_pw_wgrad", ptr(dc), ptr(a.buf), npix_o, a.c, a.c, l.cout, ptr(gw), a.c, stream())
+                call(self._fn["frost_float_pw_wgrad"], ptr(dc), ptr(a.buf), npix_o, a.c, a.c, l.cout, ptr(gw), a.c, stream())
         l.x = None
         return dx
 
@@ -380,7 +408,7 @@ class FloatRunner:
             return d
         out = self._new(inp.n, inp.h, inp.w, inp.c)
         direct = d if cat is None else sq                     # dense gradient w.r.t. the block input from the conv chain
-        call("frost_float_grad_merge", ptr(res.buf) if res is not None else None, ptr(cat.buf) if cat is not None else None, cs,
+        call(self._fn["frost_float_grad_merge"], ptr(res.buf) if res is not None else None, ptr(cat.buf) if cat is not None else None, cs,
              cat.c if cat is not None else 8, ptr(direct.buf) if direct is not None else None, inp.npix, inp.c, ptr(out.buf), stream())
         return out
 
@@ -396,7 +424,7 @@ class FloatRunner:
                     g = t
                 else:
                     s = self._new(g.n, g.h, g.w, g.c)
-                    call("frost_infer_add", ptr(g.buf), ptr(t.buf), g.npix * g.c, ptr(s.buf), stream())
+                    call(self._fn["add"], ptr(g.buf), ptr(t.buf), g.npix * g.c, ptr(s.buf), stream())
                     g = s
             if g is None:
                 continue
@@ -413,7 +441,7 @@ class FloatRunner:
         n, nclass = dl.shape
         g = self._new(a.n, a.h, a.w, a.c)
         scratch = torch.empty(n, a.c, dtype=torch.float32, device=self.device)
-        call("frost_float_head_bwd", ptr(dl), ptr(pooled), ptr(self.fc.weight), n, a.c, nclass, a.h * a.w, ptr(drop),
+        call(self._fn["frost_float_head_bwd"], ptr(dl), ptr(pooled), ptr(self.fc.weight), n, a.c, nclass, a.h * a.w, ptr(drop),
              ptr(self._gv[id(self.fc.weight)]), ptr(self._gv[id(self.fc.bias)]), ptr(g.buf), ptr(scratch), stream())
         g = self._conv_bwd(self.last, ptr(g.buf), g.c, True)
         self._trunk_bwd(g)
@@ -426,7 +454,7 @@ class FloatRunner:
             if gr is None:
                 continue
             t = self._new(a.n, a.h, a.w, a.c)
-            t.buf[: a.npix * a.c] = gr.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).view(torch.int16).reshape(-1)
+            self._store(t.buf[: a.npix * a.c], gr.float().permute(0, 2, 3, 1).contiguous())
             taps[bi] = t
         # blocks after the last tap (x4 -> x5 are all used; nothing is dead in the reference's backbone)
         self._trunk_bwd(None, taps)

@@ -205,6 +205,9 @@ class _FrostBase(nn.Module):
                                "pointers): data parallelism is one process per GPU -- frostnet_amd.parallel, `bench.py --gpus N`")
         qat = self._is_qat_prepared()
         r = self.__dict__.get("_hip_runner")
+        want = getattr(self, "float_precision", None)        # 'bf16' (default) | 'fp32': activation storage of the float (warm-up) path
+        if r is not None and not qat and want is not None and getattr(r, "precision", want) != want:
+            r = None
         if r is None or r.model is not self or r.is_qat != qat or not r.still_valid():
             if qat:
                 from .runner import FrostRunner

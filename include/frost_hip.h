@@ -233,7 +233,8 @@ int frost_linear_f32(const float* x, const float* w, const float* bias, int n, i
 /* ---- float (not fake-quantised) model on the device: StatAssist warm-up training + eval forward ----------------- */
 /* replaces: frostnet.py:14-60 ConvBNReLU / ConvBN in TRAIN mode (Conv2d -> BatchNorm2d with batch statistics -> ReLU) and their
  * autograd backward, for the FP epochs Classification/train.py:149-165 runs before prepare_qat.  Activations and activation
- * gradients NHWC bf16, parameters / statistics fp32.  Per conv: forward = mode 0 (statistics) -> frost_float_bn_finalize -> mode 1
+ * gradients NHWC bf16 (default) or fp32 (the *_f32 entries below; FrostFDesc.fp32 = 1 makes frost_float_weight_prep write fp32 packs
+ * [cpad/16][kpad/16][64][4], kpad / kpad_t multiples of 16), parameters / statistics fp32.  Per conv: forward = mode 0 (statistics) -> frost_float_bn_finalize -> mode 1
  * (emit); backward = mode 2 (S1, S2) -> frost_float_bwd_finalize -> mode 3 (dc) -> data gradient, weight gradient. */
 typedef struct FrostFDesc {
   const float* w;        /* OIHW fp32 master weight                                                    */
@@ -244,7 +245,7 @@ typedef struct FrostFDesc {
   float* coef;           /* [8*cpad]: scale, bias, mean, invsigma, K1, E, F, batch variance                    */
   float* dgamma; float* dbeta;   /* gradient destinations (accumulated into)                                   */
   int32_t cout, cin_g, kk, kind;   /* kind: 0 pointwise, 1 depthwise, 2 stem (im2col K = tap*4 + c)             */
-  int32_t cpad, kpad, kpad_t, reserved;
+  int32_t cpad, kpad, kpad_t, fp32;
 } FrostFDesc;
 int frost_float_weight_prep(const FrostFDesc* descs, int nlayers, void* stream);
 int frost_float_bn_finalize(const FrostFDesc* desc, int cout, int64_t count, void* stream);   /* train: batch stats -> coef, running stats */
@@ -265,6 +266,22 @@ int frost_float_grad_merge(const uint16_t* res, const uint16_t* cat, int cs, int
 int frost_float_avgpool(const uint16_t* x, int n, int hw, int c, const float* drop, float* y, void* stream);
 int frost_float_head_bwd(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
                          const float* drop_mask, float* dw, float* dbias, uint16_t* gx, float* scratch_dpool, void* stream);
+/* fp32 activation storage (the reference's own precision; products on the fp32 MFMA): same arguments, float elements.
+ * frost_float_pw_f32 mode 4 = plain GEMM out = x . pack^T (the data gradient on pack_t; desc may be NULL). */
+int frost_float_pw_f32(const FrostFDesc* desc, const float* x, const float* pack, int64_t npix, int cin, int cout, int relu, int mode,
+                       const float* gy, int ldg, float* out, int ldy, void* stream);
+int frost_float_dw_f32(const FrostFDesc* desc, const float* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
+                       const float* gy, float* out, void* stream);
+int frost_float_dw_dgrad_f32(const FrostFDesc* desc, const float* dc, int n, int h, int w, int c, int k, int stride, float* dx, void* stream);
+int frost_float_dw_wgrad_f32(const float* dc, const float* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream);
+int frost_float_pw_wgrad_f32(const float* dc, const float* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream);
+int frost_float_grad_merge_f32(const float* res, const float* cat, int cs, int ccat, const float* sq, int64_t npix, int c, float* out, void* stream);
+int frost_float_avgpool_f32(const float* x, int n, int hw, int c, const float* drop, float* y, void* stream);
+int frost_float_head_bwd_f32(const float* dlogits, const float* pooled, const float* wfc, int n, int cin, int nclass, int hw,
+                             const float* drop_mask, float* dw, float* dbias, float* gx, float* scratch_dpool, void* stream);
+int frost_float_cat_f32(const float* a, int ca, const float* b, int cb, int64_t npix, float* y, void* stream);      /* y = cat([a, b], channels) */
+int frost_float_add_f32(const float* a, const float* b, int64_t n, float* y, void* stream);
+int frost_float_stem_im2col_f32(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float* out, void* stream);
 
 typedef struct FrostOptTensor {
   float* p; float* g; float* exp_min; float* exp_max; float* coin; float* buf0; float* buf1; float* buf2;

@@ -279,3 +279,107 @@ def test_statassist_switch_on_device(F):
     assert type(model.hip_runner()).__name__ == "FrostRunner"
     assert np.isfinite(float(loss))
     assert [int(opt.state[p]["step"]) for p in model.parameters()] == [s + 1 for s in steps]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fp32 activation mode (FloatRunner(precision="fp32"), model.float_precision = "fp32", FROST_FLOAT_PRECISION=fp32): the reference's own
+# precision, products on the fp32 MFMA.  This is the mode the reference's FP32-train end-to-end gate applies to (SURVEY H-2: two fp32
+# evaluations of the float model agree to ~2e-6 in the logits).  Yardstick: the fp64 evaluation of the stock modules; the CPU fp32 run of
+# the same modules is measured against it too and printed.  Forward quantities (outputs, logits, loss, running statistics) are held to
+# fp32 round-off.  Gradients additionally see ReLU-mask flips: a pre-activation within round-off of zero gets the other mask in one of the
+# two evaluations (the CPU fp32 run flips as well, elsewhere); the test counts the candidates (|z| < 3e-6 rms in the fp64 run) and allows
+# 3 * sqrt(candidates / activations) norm-wise on top of round-off -- with no candidate the bound is round-off alone.
+def _flip_budget(ref, run_ref):
+    cnt = [0, 0]
+    def hook(m, i, o):
+        z = i[0].detach()
+        cnt[0] += int((z.abs() < 3e-6 * z.pow(2).mean().sqrt()).sum()); cnt[1] += z.numel()
+    hs = [m.register_forward_hook(hook) for m in ref.modules() if isinstance(m, torch.nn.ReLU)]
+    out = run_ref()
+    for h in hs:
+        h.remove()
+    return out, cnt[0], 3.0 * (cnt[0] / max(cnt[1], 1)) ** 0.5
+
+
+@pytest.mark.parametrize("cfg", [(32, 16, 3, 1, 1, 1), (16, 24, 3, 2, 6, 4), (80, 80, 5, 1, 3, 4), (80, 96, 5, 1, 6, 4), (40, 80, 5, 2, 6, 4),
+                                 (288, 320, 5, 1, 6, 4)])
+def test_fp32_mode_block(F, cfg):
+    """Every block type, teacher-forced, N=8 at 16x16, against the fp64 stock-module definition: y 5e-6, running statistics 1e-5, dx and every
+    parameter gradient 2e-5 + the flip budget (measured: 1e-7 .. 5e-7 everywhere without a flip, equal to the CPU fp32 run's own error)."""
+    from frostnet_amd.float_train import FloatRunner
+    cin, cout, k, s, e, r = cfg
+    torch.manual_seed(11)
+    m = F.CascadePreExBottleneck(cin, cout, quantized=False, kernel_size=k, stride=s, expand_ratio=e, reduce_factor=r)
+    _randomize_bn(m, 5)
+    ref, ref32 = copy.deepcopy(m).double().train(), copy.deepcopy(m).train()
+    x = torch.randn(8, cin, 16, 16)
+    xr = x.double().requires_grad_(True)
+    yr, cands, budget = _flip_budget(ref, lambda: ref(xr))
+    gy = torch.randn(yr.shape)
+    yr.backward(gy.double())
+    x32 = x.clone().requires_grad_(True)
+    y32 = ref32(x32)
+    y32.backward(gy)
+    m.cuda().train()
+    run = FloatRunner.for_block(m, precision="fp32")
+    y, dx = run.block_step(x.cuda(), gy.cuda())
+    torch.cuda.synchronize()
+    ey, edx = _rel(y.cpu(), yr.detach()), _rel(dx.cpu(), xr.grad)
+    errs = _grad_errors(m, ref)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:2]
+    e32 = _grad_errors(ref32, ref)
+    print(f"[fp32 block {cfg}] device vs fp64: y {ey:.1e} dx {edx:.1e} worst grad {worst[0][1]:.1e} | CPU fp32 vs fp64: y {_rel(y32.detach(), yr.detach()):.1e} "
+          f"dx {_rel(x32.grad, xr.grad):.1e} worst grad {max(e32.values()):.1e} | {cands} flip candidates, budget {budget:.1e}")
+    assert ey <= 5e-6, ey
+    assert edx <= 2e-5 + budget and worst[0][1] <= 2e-5 + budget, (edx, worst, budget)
+    sd, sr = m.state_dict(), ref.state_dict()
+    for key in sr:
+        if key.endswith("running_mean") or key.endswith("running_var"):
+            np.testing.assert_allclose(sd[key].cpu().numpy(), sr[key].float().numpy(), rtol=1e-5, atol=1e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("name,res,batch", [("frostnet_small_1_0", 64, 8), ("frostnet_large_1_0", 96, 4)])
+def test_fp32_mode_train_step_end_to_end(F, name, res, batch):
+    """The FP32-train end-to-end gate: one train step of the whole float network in fp32 mode against the fp64 evaluation of the stock
+    modules.  Logits 3e-5 and within 2x of the CPU fp32 run's own error (measured: equal to it, 7e-6 / 8e-6), loss 1e-6, running statistics
+    2e-4, eval-mode logits 3e-5.  The gradient (all parameters concatenated): 1e-4 + 10x the flip budget -- through 18 BatchNorm'd blocks at
+    these batch sizes one flipped mask moves the whole upstream gradient (measured 6e-3 .. 2e-2; the CPU fp32 run sits at 1.4e-2 on Small and,
+    with no flip of its own, 1.4e-5 on Large); the flip-free precision of the backward is what test_fp32_mode_block holds (5e-7)."""
+    torch.manual_seed(5)
+    model = F.MODEL_REGISTRY[name](drop_rate=0.0)
+    _randomize_bn(model, 3)
+    ref, ref32 = copy.deepcopy(model).double().train(), copy.deepcopy(model).train()
+    x = torch.randn(batch, 3, res, res)
+    tgt = (torch.arange(batch) * 37) % 1000
+    y_ref, cands, budget = _flip_budget(ref, lambda: ref(x.double()))
+    loss_ref = torch.nn.functional.cross_entropy(y_ref, tgt)
+    loss_ref.backward()
+    y32 = ref32(x)
+    torch.nn.functional.cross_entropy(y32, tgt).backward()
+    model.float_precision = "fp32"
+    model.cuda().train()
+    assert model.hip_runner().precision == "fp32"
+    y = model(x.cuda())
+    loss = torch.nn.functional.cross_entropy(y, tgt.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    ey, ey32 = _rel(y.detach().cpu(), y_ref.detach()), _rel(y32.detach(), y_ref.detach())
+    cat = lambda mod: torch.cat([p.grad.detach().double().cpu().reshape(-1) for p in mod.parameters()])
+    eg, eg32 = _rel(cat(model), cat(ref)), _rel(cat(ref32), cat(ref))
+    errs = _grad_errors(model, ref)
+    med = float(np.median(list(errs.values())))
+    print(f"[fp32 e2e {name}] logits: device {ey:.1e} / CPU fp32 {ey32:.1e}; gradient (all parameters): device {eg:.1e} / CPU fp32 {eg32:.1e}, median parameter "
+          f"{med:.1e}; {cands} flip candidates, budget {budget:.1e}")
+    assert ey <= 3e-5 and ey <= 2 * ey32 + 1e-6, (ey, ey32)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-6 * abs(float(loss_ref))
+    assert eg <= 1e-4 + 10 * budget, (eg, med, budget)
+    sd, sr = model.state_dict(), ref.state_dict()
+    for k in sr:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(sd[k].cpu().numpy(), sr[k].float().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        e, e_ref = model(x.cuda()).cpu(), ref(x.double())
+    assert _rel(e, e_ref) <= 3e-5, _rel(e, e_ref)
+    model.float_precision = "bf16"                 # switching the precision rebinds
+    assert model.hip_runner().precision == "bf16"
