@@ -61,13 +61,20 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
 // mantissa, truncate) is unbiased whatever the lattice: the error stays at the 2^-9/sqrt(3) level independent of the pixel count.
 // The generator is a 24-bit LCG per lane (v_mad_u32_u24, full rate), seeded from the workgroup / thread index: launches are reproducible.
 __device__ __forceinline__ uint32_t sr_seed(uint32_t a, uint32_t b) { uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu; return (h ^ (h >> 15)) | 1u; }
-__device__ __forceinline__ uint32_t sr_next16(uint32_t& st) {
-  st = __umul24(st, 0x5BD1E5u) + 0x9E3779u;      // the top 16 of the low 24 bits are the random number
-  return (st >> 8) & 0xffffu;
+// One LCG step = two full-rate VALU instructions, kept opaque: left to itself the compiler rewrites four consecutive steps as four independent
+// closed forms x*a^k + c_k with 32-bit constants, i.e. four quarter-rate v_mul_lo_u32 per four elements (seen in the ISA of the dc epilogue).
+__device__ __forceinline__ uint32_t sr_step(uint32_t st) {
+  uint32_t r;
+  asm("v_mul_u32_u24_e32 %0, 0x5bd1e5, %1\n\tv_add_u32_e32 %0, 0x9e3779, %0" : "=v"(r) : "v"(st));
+  return r;
 }
+__device__ __forceinline__ uint32_t sr_next16(uint32_t& st) { st = sr_step(st); return (st >> 8) & 0xffffu; }    // the top 16 of the low 24 bits
 __device__ __forceinline__ uint32_t sr_bf16(float v, uint32_t& st) { return (__float_as_uint(v) + sr_next16(st)) >> 16; }
+// two values per step: 12 random bits each (bits 12..23 and 0..11 of the state: both halves run through all 4096 values once per 4096 steps),
+// placed in bits 4..15 below the kept mantissa -- the rounding threshold is quantised to 1/4096 ulp, the expectation error is <= 2^-13 ulp
 __device__ __forceinline__ uint32_t sr_pk_bf16(float lo, float hi, uint32_t& st) {
-  const uint32_t a = __float_as_uint(lo) + sr_next16(st), b = __float_as_uint(hi) + sr_next16(st);
+  st = sr_step(st);
+  const uint32_t a = (__builtin_amdgcn_ubfe(st, 12, 12) << 4) + __float_as_uint(lo), b = ((st & 0xfffu) << 4) + __float_as_uint(hi);
   return __builtin_amdgcn_perm(b, a, 0x07060302u);              // {b[31:16], a[31:16]}
 }
 static inline int frost_sr_enabled() { static const int on = getenv("FROST_SR") ? atoi(getenv("FROST_SR")) : 1; return on; }

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   //   reduce/dc: the gout tile [128][cout] bf16 arrives by DMA (two buffers); dc is written IN PLACE over it and leaves as a
   //   linear copy;  emit/dgrad: the y / dx tile is assembled in LDS and leaves as a linear copy.
   // (4- and 8-byte accesses at a cout-byte stride kept the texture-address unit ~75 % busy: 16 requests per wave instruction.)
-  const bool g_lds = (p.io & 1) != 0, o_lds = (p.io & 2) != 0;
+  const bool g_lds = FUSE || (p.io & 1) != 0, o_lds = FUSE || (p.io & 2) != 0;      // the fused instance always stages both through LDS: compile-time there
   uint8_t* const io_base = smem + xs_bytes;
   long long* l_s1 = (long long*)(smem + xs_bytes + p.io_bytes);
   unsigned long long* l_s2 = (unsigned long long*)(l_s1 + p.cpad);
