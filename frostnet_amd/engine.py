@@ -28,6 +28,9 @@ _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-ima
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
+# depthwise weight gradients of maps no wider than this also go to the second stream.  Measured (two boxes, 2-3 runs each): 14 -> -0.2 ms, but
+# 7, 28, 56 and "only the 14x14 maps" -> +1.1 ms (the captured graph serialises differently): too close to a cliff for a default, stays off
+_DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
 
 
 class Act:
@@ -575,7 +578,7 @@ class Engine:
                      prof=("dw_bwd_dc", x.numel + 4 * y.numel))
                 # (stays on the main stream by default: beside the pointwise weight gradients it slows everything down -- measured -5 %)
                 sw = s
-                if self._side is not None and (_WG_STREAM & 2):
+                if self._side is not None and ((_WG_STREAM & 2) or y.w <= _DW_WG_MAXW):
                     ev = torch.cuda.Event()
                     ev.record()
                     self._side.wait_event(ev)
