@@ -141,9 +141,16 @@ __device__ __forceinline__ uint32_t pw_trunc_bf2(float lo, float hi) {   // exac
 #ifndef PW_FUSE_MINW
 #define PW_FUSE_MINW 4
 #endif
-template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0>
+// SP > 0 = shape-specialised instance for the large narrow layers (stem, 32->16, 16->96: 3.6 ms of the step): ONE channel group whose channel
+// tiles are all full (cout == WC * MIE * 16), no channel-group split, standard LDS-staged I/O.  SP = MIE + 8 * (rows 16-byte aligned).  The
+// generic instance decides all of that at run time, per channel tile and per MFMA: the counters showed 130-260 SALU instructions per wave and
+// tile (s_cbranch / exec masking around every guarded block, SGPRs spilled to VGPR lanes) beside ~190-320 VALU -- the scalar unit is shared
+// by the CU's four SIMDs.  With the shape known the guards fold away.
+template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0, int SP = 0>
 __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr bool FUSE = FTW > 0;
+  constexpr bool SPC = SP > 0;
+  constexpr int MIE = SP & 7;
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
   constexpr int MI = PW_MI(MODE, WP);
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   //   reduce/dc: the gout tile [128][cout] bf16 arrives by DMA (two buffers); dc is written IN PLACE over it and leaves as a
   //   linear copy;  emit/dgrad: the y / dx tile is assembled in LDS and leaves as a linear copy.
   // (4- and 8-byte accesses at a cout-byte stride kept the texture-address unit ~75 % busy: 16 requests per wave instruction.)
-  const bool g_lds = FUSE || (p.io & 1) != 0, o_lds = FUSE || (p.io & 2) != 0;      // the fused instance always stages both through LDS: compile-time there
+  // the fused and the specialised instances always stage their tile I/O through LDS: compile-time there
+  const bool g_lds = FUSE || (SPC ? (MODE == M_BRED || MODE == M_BDC) : (p.io & 1) != 0), o_lds = FUSE || (SPC ? (MODE == M_EMIT || MODE == M_BDC || MODE == M_DGRAD) : (p.io & 2) != 0);
   uint8_t* const io_base = smem + xs_bytes;
   long long* l_s1 = (long long*)(smem + xs_bytes + p.io_bytes);
   unsigned long long* l_s2 = (unsigned long long*)(l_s1 + p.cpad);
@@ -178,7 +186,8 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   const int lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = w / WC, wc = w % WC;
-  const int CT = p.cpad >> 4;
+  const int CT = SPC ? (8 / WP) * MIE : (p.cpad >> 4);
+  const int mi_eff = SPC ? MIE : p.mi_eff;
 
   if (MODE == M_STATS) {
     for (int c = tid; c < p.cpad; c += 512) { l_s1[c] = 0; l_s2[c] = 0; l_mn[c] = INT32_MAX; l_mx[c] = INT32_MIN; }
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   // BRED with WP==2 already holds 64 accumulator registers: deferring would spill (measured 2x slower)
   // few-tile (7x7) layers: the channel groups are divided among `csplit` sets of workgroups so the launch still fills the chip
   const int bsplit = (int)blockIdx.x / p.nbt, bslot = (int)blockIdx.x - bsplit * p.nbt;
-  const int cg_lo = (bsplit * p.ngroups) / p.csplit, cg_hi = ((bsplit + 1) * p.ngroups) / p.csplit;
+  const int cg_lo = SPC ? 0 : (bsplit * p.ngroups) / p.csplit, cg_hi = SPC ? 1 : ((bsplit + 1) * p.ngroups) / p.csplit;
   const bool defer = (WP != 2) && (cg_hi - cg_lo == 1);      // WP == 2 holds 64 accumulator registers already: deferring would spill
   long long st1[MI]; double st2[MI]; int smn[MI], smx[MI];       // STATS: lane's channel = ct*16 + j
   float br1[MI][4], br2[MI][4];                                     // BRED: lane's channels = ct*16 + 4g + r
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     for (int r = 0; r < 4; ++r) { br1[m][r] = 0.0f; br2[m][r] = 0.0f; }
   }
 
-  const bool al16 = (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
+  const bool al16 = SPC ? ((SP >> 3) & 1) != 0 : (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
   int buf = 0; bool full_prev = false;
   int n_younger = 0;     // VMEM instructions this wave is certain to issue after its DMA within one tile (last channel group)
   if (gl && MODE != M_STATS) {
@@ -249,9 +258,9 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       n_younger = (w < nu) ? (nu - w + 7) / 8 : 0;
       if (MODE == M_DGRAD && p.accumulate) n_younger *= 2;
     } else if (!g_lds) {
-      const int ct0l = ((cg_hi - 1) * WC + wc) * p.mi_eff;
+      const int ct0l = ((cg_hi - 1) * WC + wc) * mi_eff;
       int nfull = 0;
-      for (int m = 0; m < p.mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
+      for (int m = 0; m < mi_eff; ++m) if ((ct0l + m) * 16 + 16 <= p.cout) ++nfull;
       const int per = (MODE == M_BDC) ? 2 : ((MODE == M_DGRAD && p.accumulate) ? 2 : 1);
       n_younger = nfull * NT * per;
     }
@@ -288,8 +297,9 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       full_prev = full;
     }
     for (int cg = cg_lo; cg < cg_hi; ++cg) {
-      const int ct0 = (cg * WC + wc) * p.mi_eff;
-      int mi_n = CT - ct0; mi_n = mi_n < 0 ? 0 : (mi_n > p.mi_eff ? p.mi_eff : mi_n);
+      const int ct0 = (cg * WC + wc) * mi_eff;
+      int mi_n = CT - ct0; mi_n = mi_n < 0 ? 0 : (mi_n > mi_eff ? mi_eff : mi_n);
+      if (SPC) mi_n = MIE;
       v4i acci[MI][NT]; v4f accf[MI][NT];
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
         for (int m = 0; m < MI; ++m) {
           if (m >= mi_n) continue;
           const int ch0 = (ct0 + m) * 16 + 4 * g;          // 4 consecutive channels of this lane
-          const bool chok = ch0 < p.cout;
+          const bool chok = SPC || ch0 < p.cout;
           if (MODE == M_DGRAD) {
             uint16_t* base = p.dx + p0 * p.cout;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
               for (int r = 0; r < 4; ++r) {
                 // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
                 // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
-                const float yv = p.cvt ? (float)(acci[m][t][r] + __float_as_int(B[r])) * A[r] : fmaf(A[r], (float)acci[m][t][r], B[r]);
+                const float yv = (!SPC && p.cvt) ? (float)(acci[m][t][r] + __float_as_int(B[r])) * A[r] : fmaf(A[r], (float)acci[m][t][r], B[r]);
                 float qv = rintf(yv * y_inv) + y_zpf;
                 if (lowq) qv = fminf(qv, qcap);
                 packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
@@ -648,14 +658,14 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   }
   if (MODE == M_STATS) {
     if (defer) {
-      const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
+      const int ct0 = (cg_lo * WC + wc) * mi_eff;
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         const int chn = (ct0 + m) * 16 + j;
         long long a1 = st1[m]; double a2 = st2[m]; int mn = smn[m], mx = smx[m];
         a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32); a2 += __shfl_xor(a2, 16); a2 += __shfl_xor(a2, 32);
         mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
-        if (m < p.mi_eff && g == 0 && chn < p.cout && mn <= mx) {
+        if (m < mi_eff && g == 0 && chn < p.cout && mn <= mx) {
           atomicAdd((unsigned long long*)&l_s1[chn], (unsigned long long)a1); atomicAdd(&l_s2[chn], (unsigned long long)__double2ll_rn(a2));
           atomicMin(&l_mn[chn], mn); atomicMax(&l_mx[chn], mx);
         }
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     __syncthreads();
     long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
-    for (int c = cg_lo * WC * p.mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * p.mi_eff * 16; c += 512) {
+    for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {
       if (l_mn[c] <= l_mx[c]) {
         atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
         atomicAdd(&g_s2[c], l_s2[c]);
@@ -681,35 +691,35 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     }
   } else if (MODE == M_BRED) {
     if (defer) {
-      const int ct0 = (cg_lo * WC + wc) * p.mi_eff;
+      const int ct0 = (cg_lo * WC + wc) * mi_eff;
 #pragma unroll
       for (int m = 0; m < MI; ++m) {
         const int ch0 = (ct0 + m) * 16 + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a = row_sum_f(br1[m][r]), b = row_sum_f(br2[m][r]);
-          if (m < p.mi_eff && j == 15 && ch0 < p.cout) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
+          if (m < mi_eff && j == 15 && ch0 < p.cout) { atomicAdd(&l_f1[ch0 + r], a); atomicAdd(&l_f2[ch0 + r], b); }
         }
       }
     }
     __syncthreads();
-    for (int c = cg_lo * WC * p.mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * p.mi_eff * 16; c += 512) {
+    for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {
       atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
       atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, l_f2[c]);
     }
   }
 }
 
-template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0>
+template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0, int SP = 0>
 static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipStream_t s) {
   static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT, FTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_pw<MODE, WP, RES, FULLT, FTW, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   FROST_REQUIRE(lds <= 160 * 1024, "pw: LDS budget exceeded");
   auto occ_for = [](size_t bytes) {     // persistent workgroups: residency = what the register/LDS budget admits (queried, not guessed)
     static size_t key[2] = {(size_t)-1, (size_t)-1}; static int val[2] = {0, 0};
     for (int i = 0; i < 2; ++i) if (key[i] == bytes) return val[i];
     int occ = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT, FTW>, 512, bytes) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pw<MODE, WP, RES, FULLT, FTW, SP>, 512, bytes) != hipSuccess || occ < 1) occ = 1;
     if (occ > 4) occ = 4;
     key[1] = key[0]; val[1] = val[0]; key[0] = bytes; val[0] = occ;
     return occ;
@@ -731,8 +741,21 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   if (cs_on && !q.io && grid * 2 <= 256 * occ_cache * cs_mul) { cs = (int)((256 * occ_cache * cs_mul) / grid); if (cs > q.ngroups) cs = q.ngroups; if (cs < 1) cs = 1; }
   q.csplit = cs; q.nbt = (int)grid;
   q.fin_total = (unsigned)(grid * cs);
-  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT, FTW>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
+  if (SP > 0) FROST_REQUIRE(cs == 1, "pw: the specialised instance takes no channel-group split");
+  hipLaunchKernelGGL((k_pw<MODE, WP, RES, FULLT, FTW, SP>), dim3((unsigned)(grid * cs)), dim3(512), lds, s, q);
   return frost_check_launch("pw");
+}
+// which specialised instance (k_pw's SP) fits this launch, 0 = none.  Instantiated: the stem (32 channels, 40-byte rows), 32->16, 16->96.
+template <int WP>
+static int pw_spec(const PwP& p, bool io_std) {
+  static const int on = getenv("FROST_PW_SPEC") ? atoi(getenv("FROST_PW_SPEC")) : 1;
+  constexpr int WC = 8 / WP;
+  if (!on || WP == 2 || !io_std || p.cvt || p.ngroups != 1 || p.cout != p.cpad || (p.cpad >> 4) != WC * p.mi_eff || !p.gl) return 0;
+  const bool al = (p.kstr & 15) == 0;
+  if (WP == 8 && p.mi_eff == 2 && !al) return 2;
+  if (WP == 8 && p.mi_eff == 1 && al) return 9;
+  if (WP == 4 && p.mi_eff == 3 && al) return 11;
+  return 0;
 }
 template <int MODE, int WP>
 static int launch_pw(PwP& p, hipStream_t s) {
@@ -761,7 +784,17 @@ static int launch_pw(PwP& p, hipStream_t s) {
   int rc = 0;
   if (nfull > 0) {
     const size_t cres_bytes = (size_t)p.cpad * FROST_COEF_ROWS * 4;
-    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds_f + res_bytes <= 80 * 1024 && nfull >= 2048) rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds_f + res_bytes <= 80 * 1024 && nfull >= 2048) {
+      const int sp = (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED) ? pw_spec<WP>(pf, MODE == M_STATS || pf.io != 0) : 0;
+      if constexpr (WP == 8 && (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED)) {
+        if (sp == 2) rc = launch_pw3<MODE, 8, true, true, 0, 2>(pf, lds_f + res_bytes, 0, nfull, s);
+        else if (sp == 9) rc = launch_pw3<MODE, 8, true, true, 0, 9>(pf, lds_f + res_bytes, 0, nfull, s);
+        else rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+      } else if constexpr (WP == 4 && (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED)) {
+        if (sp == 11) rc = launch_pw3<MODE, 4, true, true, 0, 11>(pf, lds_f + res_bytes, 0, nfull, s);
+        else rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+      } else rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
+    }
     else if ((MODE == M_EMIT || MODE == M_BRED || MODE == M_BDC) && lds_f + cres_bytes <= 80 * 1024) { pf.cres = 1; rc = launch_pw3<MODE, WP, false, true>(pf, lds_f + cres_bytes, 0, nfull, s); }
     else rc = launch_pw3<MODE, WP, false, true>(pf, lds_f, 0, nfull, s);
   }
@@ -848,7 +881,11 @@ extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, con
   pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin; pf.wtl_off = f.wtl_off; pf.wtl_bytes = f.wtl_bytes;
   hipStream_t s = as_stream(stream);
   int rc;
-  if (f.wp == 8) rc = (f.ftw == 2) ? launch_pw3<M_BDC, 8, true, true, 2>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 8, true, true, 6>(pf, f.lds, 0, nfull, s);
+  const int sp = (f.ftw == 2 && nfull >= 2048) ? (f.wp == 8 ? pw_spec<8>(pf, true) : (f.wp == 4 ? pw_spec<4>(pf, true) : 0)) : 0;
+  if (sp == 2) rc = launch_pw3<M_BDC, 8, true, true, 2, 2>(pf, f.lds, 0, nfull, s);
+  else if (sp == 9) rc = launch_pw3<M_BDC, 8, true, true, 2, 9>(pf, f.lds, 0, nfull, s);
+  else if (sp == 11) rc = launch_pw3<M_BDC, 4, true, true, 2, 11>(pf, f.lds, 0, nfull, s);
+  else if (f.wp == 8) rc = (f.ftw == 2) ? launch_pw3<M_BDC, 8, true, true, 2>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 8, true, true, 6>(pf, f.lds, 0, nfull, s);
   else if (f.wp == 4) rc = launch_pw3<M_BDC, 4, true, true, 2>(pf, f.lds, 0, nfull, s);
   else rc = (f.ftw == 6) ? launch_pw3<M_BDC, 2, true, true, 6>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 2, true, true, 11>(pf, f.lds, 0, nfull, s);
   if (rc) return rc;
