@@ -145,11 +145,13 @@ __device__ __forceinline__ uint32_t pw_trunc_bf2(float lo, float hi) {   // exac
 // tiles are all full (cout == WC * MIE * 16), no channel-group split, standard LDS-staged I/O.  SP = MIE + 8 * (rows 16-byte aligned).  The
 // generic instance decides all of that at run time, per channel tile and per MFMA: the counters showed 130-260 SALU instructions per wave and
 // tile (s_cbranch / exec masking around every guarded block, SGPRs spilled to VGPR lanes) beside ~190-320 VALU -- the scalar unit is shared
-// by the CU's four SIMDs.  With the shape known the guards fold away.
+// by the CU's four SIMDs.  With the shape known the guards fold away.  SP & 16: the last channel tile is partial (cout = 24, 40: the channel
+// bound stays a run-time test, so does the row alignment).
 template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0, int SP = 0>
 __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr bool FUSE = FTW > 0;
   constexpr bool SPC = SP > 0;
+  constexpr bool SPF = SPC && !(SP & 16);        // every channel tile full
   constexpr int MIE = SP & 7;
   constexpr int WC = 8 / WP;          // waves along channels
   constexpr int NT = 8 / WP;          // 16-pixel tiles per wave
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     for (int r = 0; r < 4; ++r) { br1[m][r] = 0.0f; br2[m][r] = 0.0f; }
   }
 
-  const bool al16 = SPC ? ((SP >> 3) & 1) != 0 : (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
+  const bool al16 = SPF ? ((SP >> 3) & 1) != 0 : (p.kstr & 15) == 0;       // gl mode keeps the natural row stride: rows of 8 (mod 16) bytes -> 2 x b64 fragment reads
   int buf = 0; bool full_prev = false;
   int n_younger = 0;     // VMEM instructions this wave is certain to issue after its DMA within one tile (last channel group)
   if (gl && MODE != M_STATS) {
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
         for (int m = 0; m < MI; ++m) {
           if (m >= mi_n) continue;
           const int ch0 = (ct0 + m) * 16 + 4 * g;          // 4 consecutive channels of this lane
-          const bool chok = SPC || ch0 < p.cout;
+          const bool chok = SPF || ch0 < p.cout;
           if (MODE == M_DGRAD) {
             uint16_t* base = p.dx + p0 * p.cout;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -750,10 +752,15 @@ template <int WP>
 static int pw_spec(const PwP& p, bool io_std) {
   static const int on = getenv("FROST_PW_SPEC") ? atoi(getenv("FROST_PW_SPEC")) : 1;
   constexpr int WC = 8 / WP;
-  if (!on || WP == 2 || !io_std || p.cvt || p.ngroups != 1 || p.cout != p.cpad || (p.cpad >> 4) != WC * p.mi_eff || !p.gl) return 0;
+  if (!on || WP == 2 || !io_std || p.cvt || p.ngroups != 1 || (p.cpad >> 4) != WC * p.mi_eff || !p.gl) return 0;
   const bool al = (p.kstr & 15) == 0;
+  if (p.cout != p.cpad) {                  // partial last channel tile: 24 and 40 output channels (96->24, 72->24, 144->40, 168->40)
+    if (WP == 8 && p.mi_eff == 2) return 18;
+    if (WP == 8 && p.mi_eff == 3) return 19;
+    return 0;
+  }
   if (WP == 8 && p.mi_eff == 2 && !al) return 2;
-  if (WP == 8 && p.mi_eff == 1 && al) return 9;
+  if (WP == 8 && p.mi_eff == 1) return al ? 9 : 1;
   if (WP == 4 && p.mi_eff == 3 && al) return 11;
   return 0;
 }
@@ -789,6 +796,9 @@ static int launch_pw(PwP& p, hipStream_t s) {
       if constexpr (WP == 8 && (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED)) {
         if (sp == 2) rc = launch_pw3<MODE, 8, true, true, 0, 2>(pf, lds_f + res_bytes, 0, nfull, s);
         else if (sp == 9) rc = launch_pw3<MODE, 8, true, true, 0, 9>(pf, lds_f + res_bytes, 0, nfull, s);
+        else if (sp == 1) rc = launch_pw3<MODE, 8, true, true, 0, 1>(pf, lds_f + res_bytes, 0, nfull, s);
+        else if (sp == 18) rc = launch_pw3<MODE, 8, true, true, 0, 18>(pf, lds_f + res_bytes, 0, nfull, s);
+        else if (sp == 19) rc = launch_pw3<MODE, 8, true, true, 0, 19>(pf, lds_f + res_bytes, 0, nfull, s);
         else rc = launch_pw3<MODE, WP, true, true>(pf, lds_f + res_bytes, 0, nfull, s);
       } else if constexpr (WP == 4 && (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED)) {
         if (sp == 11) rc = launch_pw3<MODE, 4, true, true, 0, 11>(pf, lds_f + res_bytes, 0, nfull, s);
@@ -884,6 +894,9 @@ extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, con
   const int sp = (f.ftw == 2 && nfull >= 2048) ? (f.wp == 8 ? pw_spec<8>(pf, true) : (f.wp == 4 ? pw_spec<4>(pf, true) : 0)) : 0;
   if (sp == 2) rc = launch_pw3<M_BDC, 8, true, true, 2, 2>(pf, f.lds, 0, nfull, s);
   else if (sp == 9) rc = launch_pw3<M_BDC, 8, true, true, 2, 9>(pf, f.lds, 0, nfull, s);
+  else if (sp == 1) rc = launch_pw3<M_BDC, 8, true, true, 2, 1>(pf, f.lds, 0, nfull, s);
+  else if (sp == 18) rc = launch_pw3<M_BDC, 8, true, true, 2, 18>(pf, f.lds, 0, nfull, s);
+  else if (sp == 19) rc = launch_pw3<M_BDC, 8, true, true, 2, 19>(pf, f.lds, 0, nfull, s);
   else if (sp == 11) rc = launch_pw3<M_BDC, 4, true, true, 2, 11>(pf, f.lds, 0, nfull, s);
   else if (f.wp == 8) rc = (f.ftw == 2) ? launch_pw3<M_BDC, 8, true, true, 2>(pf, f.lds, 0, nfull, s) : launch_pw3<M_BDC, 8, true, true, 6>(pf, f.lds, 0, nfull, s);
   else if (f.wp == 4) rc = launch_pw3<M_BDC, 4, true, true, 2>(pf, f.lds, 0, nfull, s);
