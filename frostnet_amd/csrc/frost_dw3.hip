@@ -68,19 +68,47 @@ __device__ __forceinline__ DwMap dw_block_map(const Dw3P& p) {
 
 __host__ __device__ constexpr int fdiv3(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-// per-sub-tile unit decode (wave-uniform): image and output-domain origin of sub-tile s of block tile `tile`
+// per-sub-tile unit decode (wave-uniform): image and output-domain origin of sub-tile s of block tile `tile`.  The first tile of a workgroup is
+// decoded with divisions; every later one is reached by dw_it_next with adds and compares only (the persistent loop visits tiles at a constant
+// stride, so the (image, tile row, tile column) increment is a constant plus carries) -- the 64-bit division alone was ~160 scalar
+// instructions per tile, a quarter of the SALU stream of the stride-1 kernels.
 template <int NSUB, int SUBW>
 struct DwSub { int img[NSUB], r0[NSUB], c0[NSUB]; bool ok[NSUB]; };
-template <int NSUB, int SUBW>
-__device__ __forceinline__ void dw_decode(const Dw3P& p, int64_t tile, DwSub<NSUB, SUBW>& su) {
+template <int NSUB>
+struct DwIt { int u[NSUB], img[NSUB], ty[NSUB], tx[NSUB]; };          // iterator state: unit index, image, tile row, tile column per sub-tile
+struct DwStep { int du, dimg, dy, dx; };
+template <int NSUB>
+__device__ __forceinline__ void dw_it_init(const Dw3P& p, int64_t tile, DwIt<NSUB>& it) {
   const int tpi = p.tiles_x * p.tiles_y;
 #pragma unroll
   for (int s2 = 0; s2 < NSUB; ++s2) {
-    const int64_t u = tile * NSUB + s2;
-    su.ok[s2] = u < p.nunits;
-    const int64_t uu = su.ok[s2] ? u : 0;
-    const int img = (int)(uu / tpi); const int tr = (int)(uu - (int64_t)img * tpi);
-    su.img[s2] = img; su.r0[s2] = (tr / p.tiles_x) * TH; su.c0[s2] = (tr % p.tiles_x) * SUBW;
+    const int u = (int)tile * NSUB + s2;
+    const int img = u / tpi; const int tr = u - img * tpi;
+    it.u[s2] = u; it.img[s2] = img; it.ty[s2] = tr / p.tiles_x; it.tx[s2] = tr - it.ty[s2] * p.tiles_x;
+  }
+}
+template <int NSUB>
+__device__ __forceinline__ DwStep dw_step(const Dw3P& p, int step) {
+  const int tpi = p.tiles_x * p.tiles_y;
+  DwStep d; d.du = step * NSUB; d.dimg = d.du / tpi;
+  const int rem = d.du - d.dimg * tpi; d.dy = rem / p.tiles_x; d.dx = rem - d.dy * p.tiles_x;
+  return d;
+}
+template <int NSUB>
+__device__ __forceinline__ void dw_it_next(const Dw3P& p, const DwStep& d, DwIt<NSUB>& it) {
+#pragma unroll
+  for (int s2 = 0; s2 < NSUB; ++s2) {
+    it.u[s2] += d.du;
+    int tx = it.tx[s2] + d.dx; const int cx = tx >= p.tiles_x ? 1 : 0; tx -= cx ? p.tiles_x : 0;
+    int ty = it.ty[s2] + d.dy + cx; const int cy = ty >= p.tiles_y ? 1 : 0; ty -= cy ? p.tiles_y : 0;
+    it.img[s2] += d.dimg + cy; it.tx[s2] = tx; it.ty[s2] = ty;
+  }
+}
+template <int NSUB, int SUBW>
+__device__ __forceinline__ void dw_fill(const Dw3P& p, const DwIt<NSUB>& it, DwSub<NSUB, SUBW>& su) {
+#pragma unroll
+  for (int s2 = 0; s2 < NSUB; ++s2) {
+    su.ok[s2] = it.u[s2] < (int)p.nunits; su.img[s2] = it.img[s2]; su.r0[s2] = it.ty[s2] * TH; su.c0[s2] = it.tx[s2] * SUBW;
   }
 }
 #define DW_SEL(ARR, SUBIDX) ((NSUB > 1 && (SUBIDX) == 1) ? ARR[NSUB > 1 ? 1 : 0] : ((NSUB > 2 && (SUBIDX) == 2) ? ARR[NSUB > 2 ? 2 : 0] : ((NSUB > 3 && (SUBIDX) == 3) ? ARR[NSUB > 3 ? 3 : 0] : ARR[0])))
@@ -298,12 +326,14 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   };
   DwSub<NSUB, SUBW> su, sun;
   int buf = 0;
-  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage(su, 0); }
+  const DwStep dstep = dw_step<NSUB>(p, bm.step);
+  DwIt<NSUB> it;
+  if (bm.t0 < bm.t1) { dw_it_init<NSUB>(p, bm.t0, it); dw_fill<NSUB, SUBW>(p, it, su); stage(su, 0); }
 
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
     dw_wait_barrier();                // this tile has landed (every wave waited for its own copies); the other buffer is free
     const bool more = (tile + bm.step) < bm.t1;
-    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage(sun, buf ^ 1); }
+    if (more) { dw_it_next<NSUB>(p, dstep, it); dw_fill<NSUB, SUBW>(p, it, sun); if (nb == 2) stage(sun, buf ^ 1); }
     uint8_t* const tin = tin0 + buf * G::IN_BYTES;
     uint8_t* const aux = aux0 + buf * AUXB;
 
@@ -485,11 +515,13 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
   };
   DwSub<NSUB, SUBW> su, sun;
   int buf = 0;
-  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage(su, 0); }
+  const DwStep dstep = dw_step<NSUB>(p, bm.step);
+  DwIt<NSUB> it;
+  if (bm.t0 < bm.t1) { dw_it_init<NSUB>(p, bm.t0, it); dw_fill<NSUB, SUBW>(p, it, su); stage(su, 0); }
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
     dw_wait_barrier();
     const bool more = (tile + bm.step) < bm.t1;
-    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage(sun, buf ^ 1); }
+    if (more) { dw_it_next<NSUB>(p, dstep, it); dw_fill<NSUB, SUBW>(p, it, sun); if (nb == 2) stage(sun, buf ^ 1); }
     const uint8_t* const tin = tin0 + buf * G::IN_BYTES;
     const uint8_t* const aux = aux0 + buf * G::AUX_BYTES;
     float g[RH][RW];
@@ -566,11 +598,13 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
   DwPlan<DH, DWS, NSUB, CBW, 2> pld; pld.init(tid, cb, p.wo, p.c);
   DwSub<NSUB, SUBW> su, sun;                                             // units over the dx (input) domain
   int buf = 0;
-  if (bm.t0 < bm.t1) { dw_decode<NSUB, SUBW>(p, bm.t0, su); stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0, tid, pld, su, 1, S, LO, p.ho, p.wo, p.c, 0u); }
+  const DwStep dstep = dw_step<NSUB>(p, bm.step);
+  DwIt<NSUB> it;
+  if (bm.t0 < bm.t1) { dw_it_init<NSUB>(p, bm.t0, it); dw_fill<NSUB, SUBW>(p, it, su); stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0, tid, pld, su, 1, S, LO, p.ho, p.wo, p.c, 0u); }
   for (int64_t tile = bm.t0; tile < bm.t1; tile += bm.step) {
     dw_wait_barrier();               // dc tile landed; the previous tile's copy-out has read tout
     const bool more = (tile + bm.step) < bm.t1;
-    if (more) { dw_decode<NSUB, SUBW>(p, tile + bm.step, sun); if (nb == 2) stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0 + (buf ^ 1) * D_BYTES, tid, pld, sun, 1, S, LO, p.ho, p.wo, p.c, 0u); }
+    if (more) { dw_it_next<NSUB>(p, dstep, it); dw_fill<NSUB, SUBW>(p, it, sun); if (nb == 2) stage_tile<DH, DWS, NSUB, SUBW, CBW, 2>(p.dc, tdc0 + (buf ^ 1) * D_BYTES, tid, pld, sun, 1, S, LO, p.ho, p.wo, p.c, 0u); }
     const uint8_t* const tdc = tdc0 + buf * D_BYTES;
     float acc[RH][RW];
 #pragma unroll
@@ -647,6 +681,7 @@ static int launch3(KF kern, Dw3P& p, size_t lds, const char* what, hipStream_t s
     occ_cache[key] = occ;
   } else occ = it->second;
   if (occ > 8) occ = 8;
+  FROST_REQUIRE(p.nunits < ((int64_t)1 << 30), "dw: too many tiles for the 32-bit tile iterator");
   int64_t want = (256 * occ) / p.ncb; if (want < 1) want = 1;
   p.ngroups = (int)(p.ntiles < want ? p.ntiles : want);
   static const int xon = getenv("FROST_DW_XCD") ? atoi(getenv("FROST_DW_XCD")) : 1;
