@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   const int acc0 = chok ? (128 - zp) * p.wsum[ch] : 0;
   float qcap = 255.0f; bool lowq = false;        // 7-bit activations (reduce_range): the u8 conversion saturates at 255 only
   float cA = 0, cB = 0, cMR = 0, cR = 0, cK1 = 0, cE = 0, cF = 0, y_inv = 1.0f, y_zpf = 0.0f, t_lo = 0.0f, t_hi = 0.0f;
+  int emit_add = 0; float emit_b = 0.0f;
   if (MODE != D_STATS) {
     y_inv = 1.0f / p.qy[FROST_Q_SCALE]; const int zpy = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)zpy;
     if (chok) {
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
       }
     }
     if (MODE == D_EMIT && p.cvt) y_inv = 1.0f;
+    // converted inference: y = float(acc + bias_q) * requant scale (row B carries the int32 bias bits); training / eval: y = fma(A, acc, B)
+    if (MODE == D_EMIT) { emit_add = p.cvt ? __float_as_int(cB) : 0; emit_b = p.cvt ? 0.0f : cB; }
     if (MODE == D_EMIT) { qcap = (float)q_hi(p.qy); lowq = qcap < 255.0f; }        // row A already is the requantisation scale s_x*s_w/s_y
     if (MODE == D_BRED || MODE == D_BDC) {   // STE pass window in t = y/scale: t_lo < t <= t_hi (see frost_pw.hip)
       const int qhi = q_hi(p.qy);
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
   }
   const float relu_floor = p.relu ? 0.0f : -INFINITY;
   uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  const bool sr_on = p.sr != 0;
   double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
   DwPlan<G::IH, G::IWS, NSUB, CBW, 1, WG> plx; plx.init(tid, cb, p.w, p.c);          // the fused weight-gradient variant has no registers to spare: lean plans
   DwPlan<TH, SUBW, NSUB, CBW, 2, WG> plg; if (MODE == D_BRED || MODE == D_BDC) plg.init(tid, cb, p.wo, p.c);
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
           if (valid) { t1 += vi; t2 = fma((double)v, (double)v, t2); tmn = min(tmn, vi); tmx = max(tmx, vi); }
         } else if (MODE == D_EMIT) {
           // q = clamp(rint(relu(y)/s) + zp, 0, 255): v_cvt_pk_u8_f32 saturates at both ends while converting
-          const float yv = p.cvt ? (float)(acc[o][r] + __float_as_int(cB)) * cA : fmaf(cA, v, cB);
+          const float yv = fmaf(cA, (float)(acc[o][r] + emit_add), emit_b);       // one form for both emit flavours (see emit_add): no per-output branch
           float qv = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
           if (lowq) qv = fminf(qv, qcap);
           aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
@@ -396,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
           if (MODE == D_BRED) { r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2); }
           else {
             const float dcf = fmaf(gy, cK1, fmaf(v, cE, cF));
-            const uint32_t hb = p.sr ? sr_bf16(dcf, rng) : (cvt_pk_bf16(dcf, 0.0f) & 0xffffu);
+            // stochastic (default) or nearest-even rounding from ONE instruction stream: the added 16 bits are the draw or 0x7fff + lsb
+            const uint32_t db = __float_as_uint(dcf), dr = sr_next16(rng);
+            const uint32_t hb = (db + (sr_on ? dr : 0x7fffu + ((db >> 16) & 1u))) >> 16;
             *(uint16_t*)(aux + (lp * CBW + L.lc) * 2) = (uint16_t)hb;
             if (WG) acc[o][r] = valid ? (int)(hb << 16) : 0;          // the bf16-rounded dc (float bits) replaces the dead accumulator
           }

@@ -461,6 +461,11 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
           const float4 B4 = *(const float4*)(coefp + FROST_COEF_B * p.cpad + ch0);
           const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
           if (MODE == M_EMIT) {
+            // converted inference: y = float(acc + bias_q) * requant scale (row B carries the int32 bias bits); training / eval: y = fma(A, acc, B)
+            const bool cvq = !SPC && p.cvt;
+            int addq[4]; float Bq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { addq[r] = cvq ? __float_as_int(B[r]) : 0; Bq[r] = cvq ? 0.0f : B[r]; }
             int8_t* base = p.y + p0 * p.cout;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
               for (int r = 0; r < 4; ++r) {
                 // q = clamp(rint(y*inv)+zp, 0, 255); ReLU is implied: ReLU layers have zp == 0 and v_cvt_pk_u8_f32
                 // saturates at 0 (and at 255) while inserting the byte -- one op for clamp + convert + pack.
-                const float yv = (!SPC && p.cvt) ? (float)(acci[m][t][r] + __float_as_int(B[r])) * A[r] : fmaf(A[r], (float)acci[m][t][r], B[r]);
+                const float yv = fmaf(A[r], (float)(acci[m][t][r] + addq[r]), Bq[r]);     // one form for both emit flavours: no per-element branch
                 float qv = rintf(yv * y_inv) + y_zpf;
                 if (lowq) qv = fminf(qv, qcap);
                 packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
