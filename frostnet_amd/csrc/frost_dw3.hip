@@ -10,6 +10,7 @@
 // Zero padding = zero-point fill, so acc_true = sum(w*q) - zp*sum(w) also holds at the borders.
 #include "frost_common.h"
 #include <map>
+#include <type_traits>
 
 typedef short v4s __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -232,6 +233,24 @@ __device__ __forceinline__ void copy_out_tile(const uint8_t* tile, uint8_t* dst,
   }
 }
 
+// Shape specialisation.  The three big high-resolution depthwise layers (and 144 @ 56) spend a third of their instruction stream on index
+// arithmetic whose operands never change: with the map size and the channel count known at compile time the bounds, pitches and tile counts
+// fold into immediates (strength-reduced multiplies, no 64-bit pitch products, constant carries in the tile iterator).  DwAny = run-time shape.
+struct DwAny { static constexpr int H = 0, W = 0, C = 0; };
+template <int H_, int W_, int C_> struct DwShape { static constexpr int H = H_, W = W_, C = C_; };
+template <typename SH, typename G, bool DGRAD>
+__device__ __forceinline__ Dw3P dw_fix(const Dw3P& pin) {
+  Dw3P q = pin;
+  if constexpr (SH::H > 0) {
+    constexpr int PAD = (G::K - 1) / 2, HO = (SH::H + 2 * PAD - G::K) / G::S + 1, WO = (SH::W + 2 * PAD - G::K) / G::S + 1;
+    constexpr int DH_ = DGRAD ? SH::H : HO, DW_ = DGRAD ? SH::W : WO;
+    q.h = SH::H; q.w = SH::W; q.c = SH::C; q.cpad = (SH::C + 15) / 16 * 16; q.pad = PAD; q.ho = HO; q.wo = WO;
+    q.tiles_x = (DW_ + G::SUBW - 1) / G::SUBW; q.tiles_y = (DH_ + TH - 1) / TH; q.ncb = (SH::C + G::CBW - 1) / G::CBW;
+    q.nunits = (int64_t)q.n * q.tiles_x * q.tiles_y; q.ntiles = (q.nunits + G::NSUB - 1) / G::NSUB;
+  }
+  return q;
+}
+
 // LDS bytes of the auxiliary tile per conv mode: int8 out tile (emit), bf16 gout / dc tile (backward).  The statistics pass has no such
 // tile but keeps the allocation: the residency it would gain (more workgroups = more atomics in front of the finalize) measured slower.
 template <typename G>
@@ -251,8 +270,9 @@ struct DwLane {
   }
 };
 
-template <typename G, int MODE_>
-__global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
+template <typename G, int MODE_, typename SH = DwAny>
+__global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
+  const Dw3P p = dw_fix<SH, G, false>(pin);
   constexpr int MODE = (MODE_ == D_BDCW) ? D_BDC : MODE_;
   constexpr bool WG = (MODE_ == D_BDCW);
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
@@ -497,8 +517,9 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P p) {
 }
 
 // ---- wgrad: dwq[c][ky][kx] += s_x * sum dc * (q - zp); lane-local K*K sums across the whole persistent loop
-template <typename G>
-__global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
+template <typename G, typename SH = DwAny>
+__global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P pin) {
+  const Dw3P p = dw_fix<SH, G, false>(pin);
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT, IWT = G::IWT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int nb = p.nb;
@@ -577,8 +598,9 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P p) {
 }
 
 // ---- dgrad: dx[iy][ix][c] (+)= s_w * sum_{ky,kx} dc[(iy+pad-ky)/s][(ix+pad-kx)/s][c] * wq[ky][kx][c]   (tiles over dx)
-template <typename G>
-__global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P p) {
+template <typename G, typename SH = DwAny>
+__global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P pin) {
+  const Dw3P p = dw_fix<SH, G, true>(pin);
   constexpr int K = G::K, S = G::S, CBW = G::CBW, SUBW = G::SUBW, NSUB = G::NSUB, TWT = G::TWT;
   constexpr int PAD = (K - 1) / 2;
   constexpr int LO = fdiv3(-PAD, S);
@@ -703,37 +725,37 @@ static int dw_nbuf(size_t per_buffer, size_t fixed) {
   static const int force = getenv("FROST_DW_NB") ? atoi(getenv("FROST_DW_NB")) : 1;
   return (force == 2 && 2 * per_buffer + fixed <= 158 * 1024) ? 2 : 1;
 }
-template <typename G, int MODE>
+template <typename G, int MODE, typename SH = DwAny>
 static int launch_fwd(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.ho, p.wo);
   const size_t per = (size_t)G::IN_BYTES + dw_aux_bytes<G>(MODE), fixed = 4 * 64 * 2 * 8 + 4 * 64 * 2 * 4, red = (size_t)4 * G::K * G::K * 64 * 4;
   p.nb = dw_nbuf(per, fixed);
   const size_t lds = p.nb * per + fixed;
-  return launch3(k_dw3<G, MODE>, p, lds > red ? lds : red, "dw", s);
+  return launch3(k_dw3<G, MODE, SH>, p, lds > red ? lds : red, "dw", s);
 }
-template <typename G>
+template <typename G, typename SH = DwAny>
 static int launch_wgrad(Dw3P& p, hipStream_t s) {
   set_tiles<G>(p, p.ho, p.wo);
   const size_t per = (size_t)G::IN_BYTES + G::AUX_BYTES, red = (size_t)4 * G::K * G::K * 64 * 4;
   p.nb = dw_nbuf(per, 0);
   const size_t lds = p.nb * per;
-  return launch3(k_dw3_wgrad<G>, p, lds > red ? lds : red, "dw_wgrad", s);
+  return launch3(k_dw3_wgrad<G, SH>, p, lds > red ? lds : red, "dw_wgrad", s);
 }
-template <typename G>
+template <typename G, typename SH = DwAny>
 static int launch_dgrad(Dw3P& p, hipStream_t s) {
   constexpr int PAD = (G::K - 1) / 2; constexpr int LO = fdiv3(-PAD, G::S);
   constexpr int DH = (TH - 1 + PAD) / G::S - LO + 1, DWS = (G::SUBW - 1 + PAD) / G::S - LO + 1;
   set_tiles<G>(p, p.h, p.w);
   const size_t per = (size_t)((DH * G::NSUB * DWS * G::CBW * 2 + 255) / 256) * 256 + 512;
   p.nb = dw_nbuf(per, G::AUX_BYTES);
-  return launch3(k_dw3_dgrad<G>, p, p.nb * per + G::AUX_BYTES, "dw_dgrad", s);
+  return launch3(k_dw3_dgrad<G, SH>, p, p.nb * per + G::AUX_BYTES, "dw_dgrad", s);
 }
 // dc pass + weight gradient: fused where the combined register state fits (measured: no spills), else two launches
-template <typename G>
+template <typename G, typename SH = DwAny>
 static int launch_bdc_wgrad(Dw3P& p, hipStream_t s) {
   constexpr bool FUSE = (G::K == 3 && G::S == 1) || (G::K == 5 && G::S == 1 && G::SUBW == 8);
-  if constexpr (FUSE) return launch_fwd<G, D_BDCW>(p, s);
-  else { const int rc = launch_fwd<G, D_BDC>(p, s); return rc ? rc : launch_wgrad<G>(p, s); }
+  if constexpr (FUSE) return launch_fwd<G, D_BDCW, SH>(p, s);
+  else { const int rc = launch_fwd<G, D_BDC, SH>(p, s); return rc ? rc : launch_wgrad<G, SH>(p, s); }
 }
 // one switch over (k, stride, geometry); OP: 0..3 = conv modes, 4 = wgrad, 5 = dgrad, 6 = dc pass with the fused weight gradient
 #define DW_CASE(KK, SS, CB_, SW_)                                                                             \
@@ -741,7 +763,19 @@ static int launch_bdc_wgrad(Dw3P& p, hipStream_t s) {
     switch (op) { case 0: return launch_fwd<G_, D_STATS>(p, s); case 1: return launch_fwd<G_, D_EMIT>(p, s);  \
                   case 2: return launch_fwd<G_, D_BRED>(p, s); case 3: return launch_fwd<G_, D_BDC>(p, s);    \
                   case 4: return launch_wgrad<G_>(p, s); case 6: return launch_bdc_wgrad<G_>(p, s); default: return launch_dgrad<G_>(p, s); } }
+// FW: the fused dc + weight-gradient kernel too (not for 32 @ 112: its specialised instance needs 21 more VGPRs and loses a wave: +10 %)
+#define DW_SHAPE_CASE(KK, SS, CB_, SW_, H_, W_, C_, FW)                                                                           \
+  if (spec_on && k == KK && stride == SS && p.h == H_ && p.w == W_ && p.c == C_) { typedef DwGeo<KK, SS, CB_, SW_> G_; typedef DwShape<H_, W_, C_> S_;   \
+    typedef typename std::conditional<FW, S_, DwAny>::type SW2_;                                                                  \
+    switch (op) { case 0: return launch_fwd<G_, D_STATS, S_>(p, s); case 1: return launch_fwd<G_, D_EMIT, S_>(p, s);                \
+                  case 2: return launch_fwd<G_, D_BRED, S_>(p, s); case 3: return launch_fwd<G_, D_BDC, S_>(p, s);                  \
+                  case 4: return launch_wgrad<G_, S_>(p, s); case 6: return launch_bdc_wgrad<G_, SW2_>(p, s); default: return launch_dgrad<G_, S_>(p, s); } }
 static int dispatch3(Dw3P& p, int k, int stride, int geo, int op, hipStream_t s) {
+  static const int spec_on = getenv("FROST_DW_SPEC") ? atoi(getenv("FROST_DW_SPEC")) : 1;
+  if (geo == GEO_C) {       // FrostNet-Large @ 224: layer1.0 / 1.1 / 1.2 / 2.0 depthwise convs
+    DW_SHAPE_CASE(3, 1, 32, 32, 112, 112, 32, false) DW_SHAPE_CASE(3, 2, 32, 32, 112, 112, 96, true) DW_SHAPE_CASE(3, 1, 32, 32, 56, 56, 72, true)
+    DW_SHAPE_CASE(5, 2, 32, 32, 56, 56, 144, true)
+  }
   if (geo == GEO_B) { if (k == 5 && stride == 1) DW_CASE(5, 1, 64, 8) if (k == 5 && stride == 2) DW_CASE(5, 2, 64, 8) }
   if (geo == GEO_C) { if (k == 3 && stride == 1) DW_CASE(3, 1, 32, 32) if (k == 3 && stride == 2) DW_CASE(3, 2, 32, 32) if (k == 5 && stride == 2) DW_CASE(5, 2, 32, 32) }
   if (k == 3 && stride == 1) DW_CASE(3, 1, 64, 16)
