@@ -213,8 +213,10 @@ class FloatRunner:
         call("frost_float_weight_prep", ptr(self._table), len(self.layers), stream())
         y = self._block(self.blocks[0], self.to_act(x), True, True)
         yf = y.float().contiguous()
+        self._grads_written = False              # a test entry: p.grad is overwritten, not accumulated
         self._begin_backward()
         dx = self._block_bwd(self.blocks[0], self.to_act(gy))
+        self._end_backward()
         return yf, dx.float().contiguous()
 
     def _add(self, name, seq, relu, stem=False):
@@ -413,8 +415,27 @@ class FloatRunner:
         return out
 
     def _begin_backward(self):
+        """torch semantics: backward() accumulates into p.grad until zero_grad().  Gradients the caller has not cleared are set aside (one copy of
+        the arena) and added back by _end_backward; in the usual loop (zero_grad() -> p.grad is None) nothing is copied."""
+        prev = None
+        live = [getattr(self, "_grads_written", False) and p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                for p, v in zip(self._params, self._grad_views)]
+        if any(live):
+            if getattr(self, "grad_sync", None) is not None:
+                raise RuntimeError("gradient accumulation over several backward passes is not supported together with the data-parallel exchange")
+            prev = self.grad_arena.clone()
+            for ok, v in zip(live, self._grad_views):
+                if not ok:
+                    prev[v.storage_offset(): v.storage_offset() + v.numel()].zero_()
         self.bind_grads()
         self.grad_arena.zero_()
+        self._carry = prev
+
+    def _end_backward(self):
+        if getattr(self, "_carry", None) is not None:
+            self.grad_arena.add_(self._carry)
+        self._carry = None
+        self._grads_written = True
 
     def _trunk_bwd(self, g, taps=None):
         for i in range(len(self.blocks) - 1, -1, -1):
@@ -430,6 +451,7 @@ class FloatRunner:
                 continue
             g = self._block_bwd(self.blocks[i], g)
         self._conv_bwd(self.stem, ptr(g.buf), g.c, False)
+        self._end_backward()
         if self.on_grads_ready is not None:
             self.on_grads_ready()
 

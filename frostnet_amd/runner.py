@@ -281,6 +281,24 @@ class FrostRunner:
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v
 
+    def _carry_over(self):
+        """torch semantics: `backward()` ACCUMULATES into p.grad until `zero_grad()`.  The kernels write (=) into the flat arena, so the
+        gradients a caller has not cleared are set aside here and added back after the backward pass.  Returns None in the usual loop
+        (`zero_grad()` -> p.grad is None, or no backward has run yet): no copy, no extra launch."""
+        if not getattr(self, "_grads_written", False):
+            return None
+        live = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self._params, self._grad_views)]
+        if not any(live):
+            return None
+        if getattr(self, "grad_sync", None) is not None:
+            raise RuntimeError("gradient accumulation over several backward passes is not supported together with the data-parallel exchange: "
+                               "call zero_grad() (set_to_none=True) between steps")
+        prev = self.grad_arena.clone()
+        for ok, v in zip(live, self._grad_views):
+            if not ok:                       # this parameter's gradient was cleared (or replaced): nothing to carry
+                prev[v.storage_offset(): v.storage_offset() + v.numel()].zero_()
+        return prev
+
     # ------------------------------------------------------------------------------------------ execution
     def _new_generation(self):
         """The saved activations of a training forward live on the engine's tape, not on the autograd node: one forward, one backward."""
@@ -414,8 +432,12 @@ class FrostRunner:
 
     def _backward_impl(self, dlogits):
         with torch.cuda.device(self.device):
+            prev = self._carry_over()
             self.bind_grads()
             self.E.backward(dlogits)
+            if prev is not None:
+                self.grad_arena.add_(prev)
+            self._grads_written = True
 
 
 class _QATMapsFunction(torch.autograd.Function):

@@ -327,3 +327,43 @@ def test_cross_entropy_and_dropout_kernels(fa):
     c = torch.empty(n, device="cuda")
     L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(c), L.stream())
     assert torch.equal(a, c)
+
+
+# ------------------------------------------------------------------------------------------ gradient accumulation (torch semantics)
+@pytest.mark.parametrize("quant", [True, False])
+def test_backward_accumulates_until_zero_grad(fa, quant):
+    """`loss.backward()` twice without `zero_grad()` leaves the SUM of the two gradients in p.grad (torch semantics: the kernels write the flat
+    arena, the runner carries uncleared gradients over); `zero_grad()` -- either flavour -- starts over.  Compared against a twin model that
+    clears in between.  Tolerance: the stochastic bf16 rounding of dc (QAT); the float model runs in its fp32 mode, where the sum is exact to rounding."""
+    F = fa["F"]
+
+    def make():
+        torch.manual_seed(3)
+        m = (F.frostnet_quant_small_1_0 if quant else F.frostnet_small_1_0)(drop_rate=0.0)
+        if quant:
+            F.qat_prepare(m, version=0)
+        else:
+            m.float_precision = "fp32"           # the bf16 float path's run-to-run spread (atomics order x bf16 storage; tests/devtools/dbg_accumulate.py)
+        return m.cuda().train()                  # would hide the mechanism under test; in fp32 the sum is exact to 1e-6
+    x1, x2 = torch.randn(4, 3, 64, 64, device="cuda"), torch.randn(4, 3, 64, 64, device="cuda")
+    t = torch.tensor([1, 2, 3, 4], device="cuda")
+    ce = torch.nn.functional.cross_entropy
+    flat = lambda m: torch.cat([p.grad.detach().reshape(-1) for p in m.parameters()]).clone()
+    a = make()                                   # twin: separate gradients
+    ce(a(x1), t).backward(); g1 = flat(a)
+    a.zero_grad()                                # set_to_none=True: p.grad is None
+    assert all(p.grad is None for p in a.parameters())
+    ce(a(x2), t).backward(); g2 = flat(a)
+    b = make()                                   # accumulating model: same two batches, nothing cleared in between
+    ce(b(x1), t).backward()
+    ce(b(x2), t).backward()
+    gacc = flat(b)
+    rel = float((gacc - (g1 + g2)).norm() / (g1 + g2).norm())
+    print(f"[accumulate quant={quant}] |g_acc - (g1 + g2)| / |g1 + g2| = {rel:.2e}")
+    assert rel <= (3e-2 if quant else 1e-4), rel
+    assert float((gacc - g2).norm() / g2.norm()) > 0.3                    # and it is not just the last gradient
+    c = copy.deepcopy(b)                         # same state from here on: clearing in place vs clearing to None give the same next gradient
+    b.zero_grad(set_to_none=False)
+    c.zero_grad()
+    ce(b(x2), t).backward(); ce(c(x2), t).backward()
+    assert float((flat(b) - flat(c)).norm() / flat(c).norm()) <= (3e-2 if quant else 1e-4)
