@@ -105,6 +105,7 @@ def side_workload(args, dev):
         opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
         opt.is_warmup = False
         crit = S.MultiBoxLoss(21)
+        tgts = S.pad_targets(tgts, dev)          # the collate step of a detection data loader: ragged boxes -> [N, K, 5] + validity mask
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -282,6 +283,7 @@ def main():
     seg = SegmentedStep(runner, crit, nbuckets=args.buckets) if (dp and not args.single_allreduce) else None
 
     def fwd_bwd():
+        opt.zero_grad(set_to_none=True)               # the reference loop (helper_functions.py:139); host-side only: p.grad = None, nothing is launched
         loss = crit(model(x), tgt)
         if dp:
             loss = loss / dist.get_world_size()

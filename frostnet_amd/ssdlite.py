@@ -46,39 +46,52 @@ def prior_boxes(cfg):
     return out.clamp_(0, 1) if cfg["clip"] else out
 
 
-def _point_form(b):
-    return torch.cat([b[:, :2] - b[:, 2:] / 2, b[:, :2] + b[:, 2:] / 2], 1)
+def pad_targets(targets, device):
+    """Ragged ground truth (list of [n_i, 5] rows x1, y1, x2, y2, label) -> (boxes [N, K, 5], valid [N, K]) with K = max n_i.  The row counts are
+    host knowledge (tensor shapes), so this is one concatenation and one gather on the device -- no per-image work, no synchronisation."""
+    lens = [int(t.size(0)) for t in targets]
+    k = max(1, max(lens))
+    flat = torch.cat([t.reshape(-1, 5).to(device) for t in targets] + [torch.zeros(1, 5, device=device)])     # last row = the padding row
+    idx = torch.full((len(lens), k), flat.size(0) - 1, dtype=torch.long)
+    off = 0
+    for i, n in enumerate(lens):
+        idx[i, :n] = torch.arange(off, off + n)
+        off += n
+    valid = torch.tensor([[j < n for j in range(k)] for n in lens], dtype=torch.bool)
+    return flat[idx.to(device)], valid.to(device)
 
 
-def _jaccard(a, b):
-    lt = torch.max(a[:, None, :2], b[None, :, :2])
-    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
-    inter = (rb - lt).clamp(min=0).prod(2)
-    area_a = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]
-    area_b = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))[None, :]
-    return inter / (area_a + area_b - inter)
-
-
-def match_priors(threshold, truths, priors, variances, labels):
-    """layers/box_utils.py:71-139 `match` + `encode` for one image: every ground-truth box keeps its best prior, every prior takes its best
-    ground truth; overlap < threshold -> background (label 0).  Returns (loc_t [P,4], conf_t [P])."""
-    ov = _jaccard(truths, _point_form(priors))
-    best_prior_idx = ov.argmax(1)
-    best_truth_overlap, best_truth_idx = ov.max(0)
-    best_truth_overlap.index_fill_(0, best_prior_idx, 2)
-    for j in range(best_prior_idx.size(0)):                 # (sequential on purpose: a later ground truth wins a shared prior, as in the reference)
-        best_truth_idx[best_prior_idx[j]] = j
-    matched = truths[best_truth_idx]
-    conf = labels[best_truth_idx].long() + 1
-    conf[best_truth_overlap < threshold] = 0
-    g_cxcy = ((matched[:, :2] + matched[:, 2:]) / 2 - priors[:, :2]) / (variances[0] * priors[:, 2:])
-    g_wh = torch.log((matched[:, 2:] - matched[:, :2]) / priors[:, 2:]) / variances[1]
-    return torch.cat([g_cxcy, g_wh], 1), conf
+def match_priors(threshold, truths, valid, priors, variances, labels):
+    """layers/box_utils.py:71-139 `match` + `encode`, for the whole batch at once: every ground-truth box keeps its best prior, every prior takes
+    its best ground truth; overlap < threshold -> background (label 0).  truths [N,K,4], valid [N,K], labels [N,K] -> (loc_t [N,P,4], conf_t [N,P]).
+    Padding rows overlap nothing (-1) and write to a spare column P."""
+    n, k, P = truths.size(0), truths.size(1), priors.size(0)
+    pp = torch.cat([priors[:, :2] - priors[:, 2:] / 2, priors[:, :2] + priors[:, 2:] / 2], 1)                 # point_form
+    lt = torch.max(truths[:, :, None, :2], pp[None, None, :, :2])
+    rb = torch.min(truths[:, :, None, 2:], pp[None, None, :, 2:])
+    inter = (rb - lt).clamp(min=0).prod(3)
+    area_t = ((truths[..., 2] - truths[..., 0]) * (truths[..., 3] - truths[..., 1]))[:, :, None]
+    area_p = ((pp[:, 2] - pp[:, 0]) * (pp[:, 3] - pp[:, 1]))[None, None, :]
+    ov = torch.where(valid[:, :, None], inter / (area_t + area_p - inter), inter.new_full((), -1.0))          # jaccard [N,K,P]
+    best_prior_idx = torch.where(valid, ov.argmax(2), torch.full_like(ov[:, :, 0], P, dtype=torch.long))      # [N,K]
+    bto, bti = ov.max(1)                                                                                      # [N,P]
+    bto = torch.cat([bto, bto.new_zeros(n, 1)], 1).scatter_(1, best_prior_idx, 2.0)
+    bti = torch.cat([bti, bti.new_zeros(n, 1)], 1)
+    for j in range(k):                                      # (sequential on purpose: a later ground truth wins a shared prior, as in the reference)
+        bti.scatter_(1, best_prior_idx[:, j:j + 1], j)
+    bto, bti = bto[:, :P], bti[:, :P]
+    matched = truths.gather(1, bti[:, :, None].expand(-1, -1, 4))
+    conf = torch.where(bto < threshold, torch.zeros_like(bti), labels.gather(1, bti).long() + 1)
+    g_cxcy = ((matched[..., :2] + matched[..., 2:]) / 2 - priors[None, :, :2]) / (variances[0] * priors[None, :, 2:])
+    g_wh = torch.log((matched[..., 2:] - matched[..., :2]) / priors[None, :, 2:]) / variances[1]
+    return torch.cat([g_cxcy, g_wh], 2), conf
 
 
 class MultiBoxLoss(nn.Module):
     """SSD loss (layers/modules/multibox_loss.py:48-117): smooth-L1 on the matched priors + cross-entropy on positives and the hardest
-    negatives (3:1), both divided by the number of positives.  forward((loc [N,P,4], conf [N,P,C], priors [P,4]), targets list of [n_i,5])."""
+    negatives (3:1), both divided by the number of positives.  forward((loc [N,P,4], conf [N,P,C], priors [P,4]), targets) with targets the
+    reference's list of [n_i,5], or pad_targets(...) of it made ahead of time.  Fixed shapes and no host synchronisation throughout (masked sums
+    instead of boolean gathers), so the loss records into a HIP graph with the rest of the step."""
 
     def __init__(self, num_classes, overlap_thresh=0.5, neg_pos=3, variance=(0.1, 0.2)):
         super().__init__()
@@ -88,27 +101,21 @@ class MultiBoxLoss(nn.Module):
         loc_data, conf_data, priors = predictions
         num, num_priors = loc_data.size(0), loc_data.size(1)
         priors = priors[:num_priors].to(loc_data.device)
-        loc_t, conf_t = [], []
+        boxes, valid = targets if isinstance(targets, tuple) else pad_targets(targets, loc_data.device)
         with torch.no_grad():
-            for t in targets:
-                t = t.to(loc_data.device)
-                lt, ct = match_priors(self.threshold, t[:, :-1], priors, self.variance, t[:, -1])
-                loc_t.append(lt)
-                conf_t.append(ct)
-            loc_t, conf_t = torch.stack(loc_t), torch.stack(conf_t)
-        pos = conf_t > 0
-        loss_l = F.smooth_l1_loss(loc_data[pos], loc_t[pos], reduction="sum")
-        with torch.no_grad():                                   # hard negative mining: rank the non-positive priors by their loss
-            batch_conf = conf_data.reshape(-1, self.num_classes)
-            lc = torch.logsumexp(batch_conf, 1) - batch_conf.gather(1, conf_t.reshape(-1, 1)).squeeze(1)   # == the reference's max-shifted log_sum_exp
-            lc = lc.reshape(num, -1).masked_fill(pos, 0)
-            _, loss_idx = lc.sort(1, descending=True)
-            _, idx_rank = loss_idx.sort(1)
+            loc_t, conf_t = match_priors(self.threshold, boxes[..., :4], valid, priors, self.variance, boxes[..., 4])
+            pos = conf_t > 0
             num_pos = pos.long().sum(1, keepdim=True)
+        zero = loc_data.new_zeros(())
+        loss_l = torch.where(pos[:, :, None], F.smooth_l1_loss(loc_data, loc_t, reduction="none"), zero).sum()
+        # per-prior classification loss: log-sum-exp minus the target's score (== cross-entropy; the reference's max-shifted log_sum_exp)
+        lc = torch.logsumexp(conf_data, 2) - conf_data.gather(2, conf_t[:, :, None]).squeeze(2)
+        with torch.no_grad():                                   # hard negative mining: rank the non-positive priors by their loss
+            _, loss_idx = lc.detach().masked_fill(pos, 0).sort(1, descending=True)
+            _, idx_rank = loss_idx.sort(1)
             num_neg = torch.clamp(self.negpos_ratio * num_pos, max=pos.size(1) - 1)
-            neg = idx_rank < num_neg
-        sel = pos | neg
-        loss_c = F.cross_entropy(conf_data[sel], conf_t[sel], reduction="sum")
+            sel = pos | (idx_rank < num_neg)
+        loss_c = torch.where(sel, lc, zero).sum()
         n = num_pos.sum().to(loss_l.dtype)
         return loss_l / n, loss_c / n
 
