@@ -191,16 +191,17 @@ extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_
 //   F_STATS: sum / sum of squares of conv            F_EMIT: y = [relu](conv*scale + bias) -> bf16
 //   F_BRED : S1 += g*m, S2 += g*m*xhat               F_BDC : dc = g*m*K1 + conv*E + F -> bf16        (m = z > 0 for ReLU layers)
 // (the data gradient dx = dc . W^T is a plain bf16 GEMM: frost_infer_pw on the transposed pack, frost_pw.hip)
-template <int MODE, int WPX, typename ET>
+template <int MODE, int WPX, typename ET, int NT = 1>
 __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __restrict__ T, const void* __restrict__ packv, int64_t npix,
                                               int cin, int cout, int cpad, int KB, int kstr, int relu, const ET* __restrict__ gy, int ldg,
                                               ET* __restrict__ y, int ldy, int64_t ntiles) {
   constexpr bool F32 = sizeof(ET) == 4;          // K step = 64 bytes of a row either way: 32 bf16 (one 16x16x32 MFMA) or 16 floats (four 16x16x4 MFMAs)
+  static_assert(NT == 1 || WPX == 4, "several pixel sub-tiles per wave only in the pixel-split layout");
   const uint8_t* pack = (const uint8_t*)packv;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int IPX = 16 * WPX, WCH = 4 / WPX;
+  constexpr int IPX = 16 * WPX * NT, WCH = 4 / WPX;     // NT 16-pixel sub-tiles per wave: every weight fragment fetched from L2 feeds NT MFMAs
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   const int wpx = w % WPX, wch = w / WPX;
   using SA = typename std::conditional<F32, double, float>::type;     // fp32 mode: statistics partials in double (the reference's CPU BatchNorm accumulates in double)
@@ -220,24 +221,30 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
       *(uint4*)(smem + row * kstr + col) = v;
     }
     __syncthreads();
-    const int64_t prow = p0 + wpx * 16 + j;
-    const bool pv = prow < npix;
-    for (int ct0 = wch * 4; ct0 < CT; ct0 += 4 * WCH) {
-      v4f acc[4];
+    const int lrow0 = wpx * 16 * NT + j;                 // sub-tile t of this wave: LDS rows lrow0 + 16 t
+    for (int ct0 = (blockIdx.y * WCH + wch) * 4; ct0 < CT; ct0 += 4 * WCH * gridDim.y) {      // gridDim.y > 1: low-resolution layers split their channel tiles over workgroups
+      v4f acc[NT][4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m] = (v4f){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[t][m] = (v4f){0.f, 0.f, 0.f, 0.f};
       for (int kb = 0; kb < KB; ++kb) {
-        const v4i bfr = *(const v4i*)(smem + (wpx * 16 + j) * kstr + kb * 64 + g * 16);
+        v4i bfr[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bfr[t] = *(const v4i*)(smem + (lrow0 + 16 * t) * kstr + kb * 64 + g * 16);
         v4i afr[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) if (ct0 + m < CT) afr[m] = *(const v4i*)(pack + ((((int64_t)(ct0 + m) * KB + kb) * 64 + lane) << 4));
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           if (ct0 + m < CT) {
-            if (F32) {         // lane (i, g) holds k = 4g .. 4g+3 of this 16-wide K block in both operands: instruction e contracts {4g + e}
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(afr[m][e]), __int_as_float(bfr[e]), acc[m], 0, 0, 0);
-            } else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr), acc[m], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+              if (F32) {         // lane (i, g) holds k = 4g .. 4g+3 of this 16-wide K block in both operands: instruction e contracts {4g + e}
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(__int_as_float(afr[m][e]), __int_as_float(bfr[t][e]), acc[t][m], 0, 0, 0);
+              } else acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, afr[m]), __builtin_bit_cast(v8bf16, bfr[t]), acc[t][m], 0, 0, 0);
+            }
           }
       }
 #pragma unroll
@@ -245,27 +252,27 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
         if (ct0 + m >= CT) continue;                 // wave-uniform
         const int ch0 = (ct0 + m) * 16 + 4 * g;
         const bool cv = ch0 < cout;
-        const bool ok = cv && pv;
-        if constexpr (MODE == F_PLAIN) {
-          if (ok) { const float o4[4] = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]}; FEl<ET>::st4(y + prow * ldy + ch0, o4); }
-        } else if constexpr (MODE == F_STATS) {
-          SA s[4], q[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const SA v = ok ? (SA)acc[m][r] : (SA)0; s[r] = v; q[r] = v * v; }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
-          if (j == 15 && cv) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
-          }
-        } else {
-          const int cc = cv ? ch0 : 0;
+        const int cc = cv ? ch0 : 0;
+        float sc[4] = {0.f, 0.f, 0.f, 0.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE != F_PLAIN && MODE != F_STATS) {
           const float4 sc4 = *(const float4*)(coef + FC_SCALE * cpad + cc), bi4 = *(const float4*)(coef + FC_BIAS * cpad + cc);
-          const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w};
-          if constexpr (MODE == F_EMIT) {
+          sc[0] = sc4.x; sc[1] = sc4.y; sc[2] = sc4.z; sc[3] = sc4.w; bi[0] = bi4.x; bi[1] = bi4.y; bi[2] = bi4.z; bi[3] = bi4.w;
+        }
+        SA rs[4] = {(SA)0, (SA)0, (SA)0, (SA)0}, rq[4] = {(SA)0, (SA)0, (SA)0, (SA)0};      // statistics partials of this lane over its NT sub-tiles
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int64_t prow = p0 + lrow0 + 16 * t;
+          const bool ok = cv && prow < npix;
+          const v4f a = acc[t][m];
+          if constexpr (MODE == F_PLAIN) {
+            if (ok) { const float o4[4] = {a[0], a[1], a[2], a[3]}; FEl<ET>::st4(y + prow * ldy + ch0, o4); }
+          } else if constexpr (MODE == F_STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const SA v = ok ? (SA)a[r] : (SA)0; rs[r] += v; rq[r] += v * v; }
+          } else if constexpr (MODE == F_EMIT) {
             if (ok) {
-              const float o4[4] = {fmaxf(fmaf(acc[m][0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[m][1], sc[1], bi[1]), lo),
-                                   fmaxf(fmaf(acc[m][2], sc[2], bi[2]), lo), fmaxf(fmaf(acc[m][3], sc[3], bi[3]), lo)};
+              const float o4[4] = {fmaxf(fmaf(a[0], sc[0], bi[0]), lo), fmaxf(fmaf(a[1], sc[1], bi[1]), lo),
+                                   fmaxf(fmaf(a[2], sc[2], bi[2]), lo), fmaxf(fmaf(a[3], sc[3], bi[3]), lo)};
               FEl<ET>::st4(y + prow * ldy + ch0, o4);
             }
           } else {
@@ -273,20 +280,13 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
             if (ok) FEl<ET>::ld4(gy + prow * ldg + ch0, gm);
             if (relu) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) if (!(fmaf(acc[m][r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
+              for (int r = 0; r < 4; ++r) if (!(fmaf(a[r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
             }
             if constexpr (MODE == F_BRED) {
               const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
               const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
-              SA s[4], q[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) { const float xh = (acc[m][r] - mu[r]) * iv[r]; s[r] = ok ? (SA)gm[r] : (SA)0; q[r] = ok ? (SA)gm[r] * (SA)xh : (SA)0; }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { s[r] = f_row_sum(s[r]); q[r] = f_row_sum(q[r]); }
-              if (j == 15 && cv) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], s[r]); atomicAdd(&sacc[cpad + ch0 + r], q[r]); }
-              }
+              for (int r = 0; r < 4; ++r) { const float xh = (a[r] - mu[r]) * iv[r]; if (ok) { rs[r] += (SA)gm[r]; rq[r] += (SA)gm[r] * (SA)xh; } }
             } else {   // F_BDC
               const float4 k4 = *(const float4*)(coef + FC_K1 * cpad + cc), e4 = *(const float4*)(coef + FC_E * cpad + cc), f4 = *(const float4*)(coef + FC_F * cpad + cc);
               const float k1[4] = {k4.x, k4.y, k4.z, k4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -296,14 +296,22 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
                   const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
                   const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) dcv[r] = k1[r] * ((gm[r] - ff[r]) - ((acc[m][r] - mu[r]) * iv[r]) * ee[r]);
+                  for (int r = 0; r < 4; ++r) dcv[r] = k1[r] * ((gm[r] - ff[r]) - ((a[r] - mu[r]) * iv[r]) * ee[r]);
                 } else {
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) dcv[r] = fmaf(gm[r], k1[r], fmaf(acc[m][r], ee[r], ff[r]));
+                  for (int r = 0; r < 4; ++r) dcv[r] = fmaf(gm[r], k1[r], fmaf(a[r], ee[r], ff[r]));
                 }
                 FEl<ET>::st4(y + prow * ldy + ch0, dcv);
               }
             }
+          }
+        }
+        if constexpr (RED) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { rs[r] = f_row_sum(rs[r]); rq[r] = f_row_sum(rq[r]); }
+          if (j == 15 && cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { atomicAdd(&sacc[ch0 + r], rs[r]); atomicAdd(&sacc[cpad + ch0 + r], rq[r]); }
           }
         }
       }
@@ -315,27 +323,49 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
     for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
+static int f_pw_nt() {        // FROST_FPW_NT=1/2/4 caps the pixel sub-tiles per wave (A/B knob; default 4)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("FROST_FPW_NT"); v = e ? atoi(e) : 4; if (v != 1 && v != 2 && v != 4) v = 4; }
+  return v;
+}
+static int f_pw_csplit_cap() {      // FROST_FPW_CSPLIT=1 turns the channel split off (A/B knob)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("FROST_FPW_CSPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 1; }
+  return v;
+}
+template <int MODE, typename ET, int WPX, int NT>
+static void launch_f_pw_nt(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu,
+                           const ET* gy, int ldg, ET* y, int ldy, size_t extra, hipStream_t s) {
+  constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
+  constexpr int IPX = 16 * WPX * NT;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)k_f_pw<MODE, WPX, ET, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
+  // few pixel tiles and many channel tiles (the 14x14 / 7x7 expand layers): the groups of 4 channel tiles a workgroup walks are dealt out over
+  // gridDim.y workgroups, each staging the (small) x tile again, until the launch has ~4 workgroups per CU
+  const int groups = ((cpad >> 4) + 4 * (4 / WPX) - 1) / (4 * (4 / WPX));
+  int csplit = 1;
+  while (grid * csplit < 1024 && csplit * 2 <= groups && csplit < f_pw_csplit_cap()) csplit *= 2;
+  hipLaunchKernelGGL((k_f_pw<MODE, WPX, ET, NT>), dim3((unsigned)grid, (unsigned)csplit), dim3(256), (size_t)IPX * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
+                     gy, ldg, y, ldy, nt);
+}
 template <int MODE, typename ET>
 static int launch_f_pw(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int relu, const ET* gy,
                        int ldg, ET* y, int ldy, hipStream_t s) {
   const int KB = (cin * (int)sizeof(ET) + 63) / 64; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   const size_t extra = RED ? (size_t)2 * cpad * sizeof(typename std::conditional<sizeof(ET) == 4, double, float>::type) : 0;
-  static bool attr = false;
-  if (!attr) {
-    hipFuncSetAttribute((const void*)k_f_pw<MODE, 4, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)k_f_pw<MODE, 1, ET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  if ((size_t)64 * kstr <= 48 * 1024) {
-    const int64_t nt = (npix + 63) / 64; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((k_f_pw<MODE, 4, ET>), dim3((unsigned)grid), dim3(256), (size_t)64 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
-                       gy, ldg, y, ldy, nt);
-  } else {
+  const int cap = f_pw_nt();
+  // the x tile (64 NT rows) stays under 64 KB of LDS so that two workgroups share a CU; a tile needs >= 2 x the CU count to be worth widening
+  if (cap >= 4 && (size_t)256 * kstr + extra <= 64 * 1024 && npix >= 256 * 1024)
+    launch_f_pw_nt<MODE, ET, 4, 4>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
+  else if (cap >= 2 && (size_t)128 * kstr + extra <= 64 * 1024 && npix >= 64 * 1024)
+    launch_f_pw_nt<MODE, ET, 4, 2>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
+  else if ((size_t)64 * kstr <= 48 * 1024)
+    launch_f_pw_nt<MODE, ET, 4, 1>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
+  else {
     if ((size_t)16 * kstr + extra > 160 * 1024) { frost_set_error("float_pw: row too long for the LDS tile"); return 1; }
-    const int64_t nt = (npix + 15) / 16; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
-    hipLaunchKernelGGL((k_f_pw<MODE, 1, ET>), dim3((unsigned)grid), dim3(256), (size_t)16 * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
-                       gy, ldg, y, ldy, nt);
+    launch_f_pw_nt<MODE, ET, 1, 1>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
   }
   return frost_check_launch("float_pw");
 }
@@ -719,8 +749,14 @@ extern "C" int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64
   FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0 && ldx % 8 == 0, "float_pw_wgrad: channels must be multiples of 8");
   const int64_t nblk = (npix + FW_KP - 1) / FW_KP;
   const int ntile = ((cout + FW_T - 1) / FW_T) * ((cin + FW_T - 1) / FW_T);
-  int nsplit = (1024 + ntile - 1) / ntile;
-  if (nsplit > nblk / 4) nsplit = (int)(nblk / 4); if (nsplit < 1) nsplit = 1;
+  // pixel split: every workgroup ends with 4096 fp32 atomics into dW, so a split must own enough 128-pixel blocks to pay for them
+  static int target = -1, minblk = 32;
+  if (target < 0) {
+    const char* e = getenv("FROST_FWG_TARGET"); target = e ? atoi(e) : 1024; if (target < 64) target = 64;
+    e = getenv("FROST_FWG_MINBLK"); if (e) minblk = atoi(e); if (minblk < 1) minblk = 1;
+  }
+  int nsplit = (target + ntile - 1) / ntile;
+  if (nsplit > nblk / minblk) nsplit = (int)(nblk / minblk); if (nsplit < 1) nsplit = 1;
   hipLaunchKernelGGL(k_f_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, npix, cin, ldx, cout, dw, ldw, nsplit);
   return frost_check_launch("float_pw_wgrad");
 }

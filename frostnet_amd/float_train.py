@@ -49,6 +49,9 @@ class FAct:
         return v.view(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2)
 
 
+_WGRAD_SIDE = os.environ.get("FROST_FLOAT_WGRAD_SIDE", "1") != "0"      # weight gradients on a second stream (A/B knob)
+
+
 class _FLayer:
     def __init__(self, name, seq, relu, dev, stem=False, fp32=False):
         conv, bn = seq[0], seq[1]
@@ -369,7 +372,7 @@ class FloatRunner:
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
                 call(self._fn["frost_float_dw_dgrad"], l.desc_ptr, ptr(dc), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(dx.buf), stream())
-            call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream())
+            self._on_side(lambda: call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream()), dc, a)
         else:
             call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
             call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
@@ -387,7 +390,7 @@ class FloatRunner:
                 call(self._fn["frost_float_pw_wgrad"], ptr(dc), ptr(a.buf), npix_o, 64, 64, l.cout, ptr(self._stem_tmp), 64, stream())
                 call("frost_float_stem_wscatter", ptr(self._stem_tmp), l.cout, ptr(gw), stream())
             else:
-                call(self._fn["frost_float_pw_wgrad"], ptr(dc), ptr(a.buf), npix_o, a.c, a.c, l.cout, ptr(gw), a.c, stream())
+                self._on_side(lambda: call(self._fn["frost_float_pw_wgrad"], ptr(dc), ptr(a.buf), npix_o, a.c, a.c, l.cout, ptr(gw), a.c, stream()), dc, a)
         l.x = None
         return dx
 
@@ -430,8 +433,25 @@ class FloatRunner:
         self.bind_grads()
         self.grad_arena.zero_()
         self._carry = prev
+        self._keep = []
+
+    def _on_side(self, launch, *keep):
+        """Weight gradients are off the backward's critical path (nothing reads them before the optimizer): they run on a second stream under
+        the next layers' passes, which at the 14x14 / 7x7 stages leave most of the GPU idle.  `keep`: the buffers the launch reads -- held until
+        the join in _end_backward, so the caching allocator cannot hand them to the main stream while the side stream still reads them."""
+        if not _WGRAD_SIDE:
+            return launch()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            launch()
+        self._keep.extend(keep)
 
     def _end_backward(self):
+        if getattr(self, "_side", None) is not None and self._keep:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._keep = []
         if getattr(self, "_carry", None) is not None:
             self.grad_arena.add_(self._carry)
         self._carry = None
