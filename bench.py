@@ -107,12 +107,12 @@ def side_workload(args, dev):
         crit = S.MultiBoxLoss(21)
         tgts = S.pad_targets(tgts, dev)          # the collate step of a detection data loader: ragged boxes -> [N, K, 5] + validity mask
 
-        def step():
+        def body():
             opt.zero_grad(set_to_none=True)
             loc, conf, pri = model(x)
             ll, lc = crit((loc, conf, pri), tgts)
             (ll + lc).backward()
-            opt.step()
+        step = None
         bytes_per_img, metric, dtype = None, f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {res}x{res} QAT fwd+bwd", "int8"
         what = (f"SSDLite on the FrostNet-{args.mode.capitalize()} backbone (frostnet_amd.ssdlite), int8 fake-quant QAT fwd+bwd + MultiBoxLoss + GradBoost-SGD step, "
                 f"batch={batch}, {res}x{res} (BASELINE.json config c5, per GPU)")
@@ -139,11 +139,44 @@ def side_workload(args, dev):
         model.train()
         opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
         crit = torch.nn.CrossEntropyLoss()
-        step = lambda: H.train_one_iter(model, crit, opt, x, tgt)
+
+        def body():                              # harness.train_one_iter without its optimizer step (helper_functions.py:139-142)
+            opt.zero_grad(set_to_none=True)
+            crit(model(x), tgt).backward()
+        step = None
         prec = model.hip_runner().precision          # activation storage: bf16 (default) or fp32 (FROST_FLOAT_PRECISION=fp32, the reference's precision)
         bytes_per_img, metric, dtype = None, "images/sec FrostNet-Large 224x224 float warm-up fwd+bwd", prec
         what = (f"FrostNet-{args.mode.capitalize()} float model (StatAssist warm-up), {prec} activations, fwd+bwd + GradBoost-SGD step (is_warmup), "
                 f"batch={batch}, {args.res}x{args.res}")
+    graphed = False
+    if step is None:                             # a training workload: zero_grad -> forward -> loss -> backward -> optimizer step, as ONE hipGraph like the headline
+        def step():
+            body()
+            opt.step()
+        for _ in range(3):                       # tables / optimizer state exist before the capture
+            step()
+        torch.cuda.synchronize()
+        # (the float warm-up step is GPU-bound with its weight gradients on a second stream: 33.5 ms eager, 34.4 ms replayed -- left eager)
+        if not args.no_graph and args.workload == "detect":
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    plan = opt.prepare_step()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        body()
+                        opt.launch(plan)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+
+                def step():
+                    opt.prepare_step()           # host side of the optimizer step: counters and the device-resident scalars the captured launch reads
+                    graph.replay()
+                graphed = True
+            except Exception as e:  # pragma: no cover
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -155,7 +188,7 @@ def side_workload(args, dev):
     value = batch * args.steps / dt
     out = dict(metric=metric, value=round(value, 2), unit="images/sec", n_gpus=1, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype,
-               data="synthetic", config=dict(workload=what, per_gpu_batch=batch, resolution=args.res))
+               data="synthetic", config=dict(workload=what, per_gpu_batch=batch, resolution=args.res, hip_graph=graphed))
     if bytes_per_img:
         out["roofline"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, whole_step=dict(
             achieved=round(value * bytes_per_img / 1e9, 1), frac=round(value * bytes_per_img / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_image=bytes_per_img))
