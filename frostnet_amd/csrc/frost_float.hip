@@ -33,6 +33,17 @@ template <> struct FEl<uint16_t> {
     const uint2 v = *(const uint2*)p; o[0] = bf2f(v.x & 0xffff); o[1] = bf2f(v.x >> 16); o[2] = bf2f(v.y & 0xffff); o[3] = bf2f(v.y >> 16);
   }
   static __device__ __forceinline__ void st4(uint16_t* p, const float* v) { uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]); *(uint2*)p = o; }
+  using R8 = uint4;
+  static __device__ __forceinline__ R8 ldr8(const uint16_t* p) { return *(const uint4*)p; }
+  static __device__ __forceinline__ R8 zero8() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ void cv8(R8 v, float* o) {
+    o[0] = bf2f(v.x & 0xffff); o[1] = bf2f(v.x >> 16); o[2] = bf2f(v.y & 0xffff); o[3] = bf2f(v.y >> 16);
+    o[4] = bf2f(v.z & 0xffff); o[5] = bf2f(v.z >> 16); o[6] = bf2f(v.w & 0xffff); o[7] = bf2f(v.w >> 16);
+  }
+  using R4 = uint2;           // four elements as loaded (conversion deferred: the load is issued long before its use)
+  static __device__ __forceinline__ R4 ldr4(const uint16_t* p) { return *(const uint2*)p; }
+  static __device__ __forceinline__ R4 zero4() { return make_uint2(0, 0); }
+  static __device__ __forceinline__ void cv4(R4 v, float* o) { o[0] = bf2f(v.x & 0xffff); o[1] = bf2f(v.x >> 16); o[2] = bf2f(v.y & 0xffff); o[3] = bf2f(v.y >> 16); }
   static __device__ __forceinline__ float ld1(const uint16_t* p) { return bf2f(*p); }
   static __device__ __forceinline__ void st1(uint16_t* p, float v) { *p = f2bf(v); }
 };
@@ -44,6 +55,14 @@ template <> struct FEl<float> {
   static __device__ __forceinline__ void st8(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]); }
   static __device__ __forceinline__ void ld4(const float* p, float* o) { const float4 a = *(const float4*)p; o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
   static __device__ __forceinline__ void st4(float* p, const float* v) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+  struct R8 { float4 a, b; };
+  static __device__ __forceinline__ R8 ldr8(const float* p) { R8 r; r.a = *(const float4*)p; r.b = *(const float4*)(p + 4); return r; }
+  static __device__ __forceinline__ R8 zero8() { R8 r; r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; return r; }
+  static __device__ __forceinline__ void cv8(R8 v, float* o) { o[0] = v.a.x; o[1] = v.a.y; o[2] = v.a.z; o[3] = v.a.w; o[4] = v.b.x; o[5] = v.b.y; o[6] = v.b.z; o[7] = v.b.w; }
+  using R4 = float4;
+  static __device__ __forceinline__ R4 ldr4(const float* p) { return *(const float4*)p; }
+  static __device__ __forceinline__ R4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ void cv4(R4 v, float* o) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
   static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 };
@@ -191,7 +210,7 @@ extern "C" int frost_float_bwd_finalize(const FrostFDesc* desc, int cout, int64_
 //   F_STATS: sum / sum of squares of conv            F_EMIT: y = [relu](conv*scale + bias) -> bf16
 //   F_BRED : S1 += g*m, S2 += g*m*xhat               F_BDC : dc = g*m*K1 + conv*E + F -> bf16        (m = z > 0 for ReLU layers)
 // (the data gradient dx = dc . W^T is a plain bf16 GEMM: frost_infer_pw on the transposed pack, frost_pw.hip)
-template <int MODE, int WPX, typename ET, int NT = 1>
+template <int MODE, int WPX, typename ET, int NT = 1, bool CL = false>
 __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __restrict__ T, const void* __restrict__ packv, int64_t npix,
                                               int cin, int cout, int cpad, int KB, int kstr, int relu, const ET* __restrict__ gy, int ldg,
                                               ET* __restrict__ y, int ldy, int64_t ntiles) {
@@ -208,6 +227,14 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
   SA* sacc = (SA*)(smem + IPX * kstr);
   const float* coef = (MODE == F_PLAIN) ? nullptr : dp->coef;
   if (RED) for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = (SA)0;
+  // CL: the layer's coefficient rows live in LDS for the kernel's life (narrow layers): the epilogue then has no dependent global load left but
+  // gy, and gy is requested before the K loop -- the passes of the 112x112 / 56x56 layers were chains of five memory latencies per tile
+  float* cl = (float*)(smem + IPX * kstr + (RED ? 2 * cpad * (int)sizeof(SA) : 0));
+  if constexpr (CL) for (int i = tid; i < 7 * cpad; i += 256) cl[i] = coef[i];
+  auto C4 = [&](int row, int cc) __attribute__((always_inline)) -> float4 {
+    if constexpr (CL) return *(const float4*)(cl + row * cpad + cc);
+    else return *(const float4*)(coef + row * cpad + cc);
+  };
   const int rowb = cin * (int)sizeof(ET); const int U = (KB * 64) >> 4;
   const int CT = cpad >> 4;
   const float lo = relu ? 0.0f : -INFINITY;
@@ -228,6 +255,17 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[t][m] = (v4f){0.f, 0.f, 0.f, 0.f};
+      typename FEl<ET>::R4 gpre[NT][4];
+      if constexpr (MODE == F_BRED || MODE == F_BDC) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int64_t prow = p0 + lrow0 + 16 * t; const int ch0 = (ct0 + m) * 16 + 4 * g;
+            gpre[t][m] = FEl<ET>::zero4();
+            if (ct0 + m < CT && ch0 < cout && prow < npix) gpre[t][m] = FEl<ET>::ldr4(gy + prow * ldg + ch0);
+          }
+      }
       for (int kb = 0; kb < KB; ++kb) {
         v4i bfr[NT];
 #pragma unroll
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
         const int cc = cv ? ch0 : 0;
         float sc[4] = {0.f, 0.f, 0.f, 0.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MODE != F_PLAIN && MODE != F_STATS) {
-          const float4 sc4 = *(const float4*)(coef + FC_SCALE * cpad + cc), bi4 = *(const float4*)(coef + FC_BIAS * cpad + cc);
+          const float4 sc4 = C4(FC_SCALE, cc), bi4 = C4(FC_BIAS, cc);
           sc[0] = sc4.x; sc[1] = sc4.y; sc[2] = sc4.z; sc[3] = sc4.w; bi[0] = bi4.x; bi[1] = bi4.y; bi[2] = bi4.z; bi[3] = bi4.w;
         }
         SA rs[4] = {(SA)0, (SA)0, (SA)0, (SA)0}, rq[4] = {(SA)0, (SA)0, (SA)0, (SA)0};      // statistics partials of this lane over its NT sub-tiles
@@ -276,24 +314,24 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
               FEl<ET>::st4(y + prow * ldy + ch0, o4);
             }
           } else {
-            float gm[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ok) FEl<ET>::ld4(gy + prow * ldg + ch0, gm);
+            float gm[4];
+            FEl<ET>::cv4(gpre[t][m], gm);               // requested before the K loop (zeros outside the tensor)
             if (relu) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) if (!(fmaf(a[r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
             }
             if constexpr (MODE == F_BRED) {
-              const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
+              const float4 iv4 = C4(FC_INV, cc), mu4 = C4(FC_MEAN, cc);
               const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) { const float xh = (a[r] - mu[r]) * iv[r]; if (ok) { rs[r] += (SA)gm[r]; rq[r] += (SA)gm[r] * (SA)xh; } }
             } else {   // F_BDC
-              const float4 k4 = *(const float4*)(coef + FC_K1 * cpad + cc), e4 = *(const float4*)(coef + FC_E * cpad + cc), f4 = *(const float4*)(coef + FC_F * cpad + cc);
+              const float4 k4 = C4(FC_K1, cc), e4 = C4(FC_E, cc), f4 = C4(FC_F, cc);
               const float k1[4] = {k4.x, k4.y, k4.z, k4.w}, ee[4] = {e4.x, e4.y, e4.z, e4.w}, ff[4] = {f4.x, f4.y, f4.z, f4.w};
               if (ok) {
                 float dcv[4];
                 if (F32) {
-                  const float4 iv4 = *(const float4*)(coef + FC_INV * cpad + cc), mu4 = *(const float4*)(coef + FC_MEAN * cpad + cc);
+                  const float4 iv4 = C4(FC_INV, cc), mu4 = C4(FC_MEAN, cc);
                   const float iv[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
 #pragma unroll
                   for (int r = 0; r < 4; ++r) dcv[r] = k1[r] * ((gm[r] - ff[r]) - ((a[r] - mu[r]) * iv[r]) * ee[r]);
@@ -323,9 +361,9 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
     for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
-static int f_pw_nt() {        // FROST_FPW_NT=1/2/4 caps the pixel sub-tiles per wave (A/B knob; default 4)
+static int f_pw_nt() {        // FROST_FPW_NT=1/2/4 caps the pixel sub-tiles per wave (A/B knob; default 1: more resident workgroups beat the fragment reuse)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("FROST_FPW_NT"); v = e ? atoi(e) : 4; if (v != 1 && v != 2 && v != 4) v = 4; }
+  if (v < 0) { const char* e = getenv("FROST_FPW_NT"); v = e ? atoi(e) : 1; if (v != 1 && v != 2 && v != 4) v = 1; }
   return v;
 }
 static int f_pw_csplit_cap() {      // FROST_FPW_CSPLIT=1 turns the channel split off (A/B knob)
@@ -333,21 +371,35 @@ static int f_pw_csplit_cap() {      // FROST_FPW_CSPLIT=1 turns the channel spli
   if (v < 0) { const char* e = getenv("FROST_FPW_CSPLIT"); v = e ? atoi(e) : 16; if (v < 1) v = 1; }
   return v;
 }
-template <int MODE, typename ET, int WPX, int NT>
-static void launch_f_pw_nt(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu,
+template <int MODE, typename ET, int WPX, int NT, bool CL>
+static void launch_f_pw_cl(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu,
                            const ET* gy, int ldg, ET* y, int ldy, size_t extra, hipStream_t s) {
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   constexpr int IPX = 16 * WPX * NT;
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)k_f_pw<MODE, WPX, ET, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if (!attr) { hipFuncSetAttribute((const void*)k_f_pw<MODE, WPX, ET, NT, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
   // few pixel tiles and many channel tiles (the 14x14 / 7x7 expand layers): the groups of 4 channel tiles a workgroup walks are dealt out over
   // gridDim.y workgroups, each staging the (small) x tile again, until the launch has ~4 workgroups per CU
   const int groups = ((cpad >> 4) + 4 * (4 / WPX) - 1) / (4 * (4 / WPX));
   int csplit = 1;
   while (grid * csplit < 1024 && csplit * 2 <= groups && csplit < f_pw_csplit_cap()) csplit *= 2;
-  hipLaunchKernelGGL((k_f_pw<MODE, WPX, ET, NT>), dim3((unsigned)grid, (unsigned)csplit), dim3(256), (size_t)IPX * kstr + extra, s, dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu,
-                     gy, ldg, y, ldy, nt);
+  hipLaunchKernelGGL((k_f_pw<MODE, WPX, ET, NT, CL>), dim3((unsigned)grid, (unsigned)csplit), dim3(256), (size_t)IPX * kstr + extra + (CL ? (size_t)7 * cpad * 4 : 0), s,
+                     dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, nt);
+}
+static size_t f_pw_cl_bytes(int mode, int cpad) {      // coefficient rows in LDS: the epilogue modes of narrow layers (FROST_FPW_CL=0 turns it off)
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FROST_FPW_CL"); on = e ? atoi(e) : 1; }
+  const size_t b = (size_t)7 * cpad * 4;
+  return (on && (mode == F_EMIT || mode == F_BRED || mode == F_BDC) && b <= 16 * 1024) ? b : 0;
+}
+template <int MODE, typename ET, int WPX, int NT>
+static void launch_f_pw_nt(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int cpad, int KB, int kstr, int relu,
+                           const ET* gy, int ldg, ET* y, int ldy, size_t extra, hipStream_t s) {
+  if constexpr (MODE == F_EMIT || MODE == F_BRED || MODE == F_BDC) {
+    if (f_pw_cl_bytes(MODE, cpad)) return launch_f_pw_cl<MODE, ET, WPX, NT, true>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
+  }
+  launch_f_pw_cl<MODE, ET, WPX, NT, false>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
 }
 template <int MODE, typename ET>
 static int launch_f_pw(const FrostFDesc* dp, const ET* T, const void* pack, int64_t npix, int cin, int cout, int relu, const ET* gy,
@@ -355,16 +407,17 @@ static int launch_f_pw(const FrostFDesc* dp, const ET* T, const void* pack, int6
   const int KB = (cin * (int)sizeof(ET) + 63) / 64; const int kstr = KB * 64 + 16; const int cpad = round_up(cout, 16);
   constexpr bool RED = (MODE == F_STATS || MODE == F_BRED);
   const size_t extra = RED ? (size_t)2 * cpad * sizeof(typename std::conditional<sizeof(ET) == 4, double, float>::type) : 0;
+  const size_t fix = extra + f_pw_cl_bytes(MODE, cpad);
   const int cap = f_pw_nt();
   // the x tile (64 NT rows) stays under 64 KB of LDS so that two workgroups share a CU; a tile needs >= 2 x the CU count to be worth widening
-  if (cap >= 4 && (size_t)256 * kstr + extra <= 64 * 1024 && npix >= 256 * 1024)
+  if (cap >= 4 && (size_t)256 * kstr + fix <= 64 * 1024 && npix >= 256 * 1024)
     launch_f_pw_nt<MODE, ET, 4, 4>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
-  else if (cap >= 2 && (size_t)128 * kstr + extra <= 64 * 1024 && npix >= 64 * 1024)
+  else if (cap >= 2 && (size_t)128 * kstr + fix <= 64 * 1024 && npix >= 64 * 1024)
     launch_f_pw_nt<MODE, ET, 4, 2>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
   else if ((size_t)64 * kstr <= 48 * 1024)
     launch_f_pw_nt<MODE, ET, 4, 1>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
   else {
-    if ((size_t)16 * kstr + extra > 160 * 1024) { frost_set_error("float_pw: row too long for the LDS tile"); return 1; }
+    if ((size_t)16 * kstr + fix > 160 * 1024) { frost_set_error("float_pw: row too long for the LDS tile"); return 1; }
     launch_f_pw_nt<MODE, ET, 1, 1>(dp, T, pack, npix, cin, cout, cpad, KB, kstr, relu, gy, ldg, y, ldy, extra, s);
   }
   return frost_check_launch("float_pw");
@@ -440,6 +493,14 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
       for (int o = 0; o < FDW_WO; ++o)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[o][e] = 0.0f;
+      typename FEl<ET>::R8 graw[FDW_WO];          // the output gradient is requested before the taps: its latency runs under theirs
+      if constexpr (MODE == F_BRED || MODE == F_BDC) {
+#pragma unroll
+        for (int o = 0; o < FDW_WO; ++o) {
+          graw[o] = FEl<ET>::zero8();
+          if (ox0 + o < wo) graw[o] = FEl<ET>::ldr8(gy + (((int64_t)in * ho + oy) * wo + ox0 + o) * c + ch);
+        }
+      }
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * S - PAD + ky; if (iy < 0 || iy >= h) continue;
@@ -477,7 +538,7 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
           FEl<ET>::st8(y + p * c + ch, o8);
         } else {
           float gm[8];
-          FEl<ET>::ld8(gy + p * c + ch, gm);
+          FEl<ET>::cv8(graw[o], gm);
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (!(fmaf(acc[o][e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
