@@ -464,11 +464,14 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
   const int tid = threadIdx.x;
   if (RED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = (SA)0; __syncthreads(); }
   const int c8n = c >> 3; const int wog = (wo + FDW_WO - 1) / FDW_WO;
-  const int64_t nthreads = (int64_t)gridDim.x * 256; const int64_t PP = nthreads / c8n;
-  const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+  // XCD-aware map (workgroups go to the 8 XCDs round-robin): XCD x owns the x-th contiguous eighth of the output units, its workgroups stride inside it,
+  // so the K input rows neighbouring units share are fetched into ONE L2 instead of eight (gridDim.x is a multiple of 8)
+  const int xcd = blockIdx.x & 7; const int64_t nthreads = (int64_t)(gridDim.x >> 3) * 256; const int64_t PP = nthreads / c8n;
+  const int64_t t = (int64_t)(blockIdx.x >> 3) * 256 + tid;
   const int c8 = (int)(t % c8n); const int64_t slot = t / c8n;
   const int ch = c8 * 8;
-  const int64_t nunits = (int64_t)n * ho * wog;
+  const int64_t nunits_all = (int64_t)n * ho * wog; const int64_t upx = (nunits_all + 7) >> 3;
+  const int64_t u_lo = xcd * upx; const int64_t nunits = (u_lo + upx < nunits_all) ? u_lo + upx : nunits_all;
   const float* wf = (const float*)dp->pack; const float* coef = dp->coef;
   float sc[8], bi[8], c2[8], c3[8], c4[8], c5[8], c6[8];
   if (MODE != F_STATS) {
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
   for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
   const float lo = relu ? 0.0f : -INFINITY;
   if (slot < PP) {
-    for (int64_t u = slot; u < nunits; u += PP) {
+    for (int64_t u = u_lo + slot; u < nunits; u += PP) {
       int64_t pp = u; const int oxg = (int)(pp % wog); pp /= wog; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
       const int ox0 = oxg * FDW_WO, ix0 = ox0 * S - PAD;
       float acc[FDW_WO][8];
@@ -584,7 +587,8 @@ static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w
   const int64_t tot = (int64_t)n * ho * ((wo + FDW_WO - 1) / FDW_WO) * c8n;
   const bool red = (mode == F_STATS || mode == F_BRED);
   int64_t grid = (tot + 255) / 256; const int64_t cap = red ? 2048 : 8192; if (grid > cap) grid = cap;
-  const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;      // every channel group needs at least one thread
+  const int64_t gmin = (c8n + 255) / 256; if (grid < 8 * gmin) grid = 8 * gmin;      // every channel group needs at least one thread in every XCD's share
+  grid = (grid + 7) & ~(int64_t)7;
   const size_t lds = red ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
   if (k == 3 && stride == 1) launch_f_dw<3, 1, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
   else if (k == 3) launch_f_dw<3, 2, ET>(mode, grid, lds, s, desc, x, n, h, w, c, cpad, ho, wo, relu, gy, out);
@@ -608,7 +612,9 @@ __global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const 
   const int c8n = c >> 3; const int pad = (k - 1) / 2;
   const int64_t tot = (int64_t)n * h * w * c8n;
   const float* wf = (const float*)dp->pack;
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+  const int64_t ipx = (((tot + 7) >> 3) + c8n - 1) / c8n * c8n;        // XCD x owns the x-th contiguous eighth of the input pixels (see k_f_dw)
+  const int64_t i_lo = (blockIdx.x & 7) * ipx; const int64_t i_hi = (i_lo + ipx < tot) ? i_lo + ipx : tot;
+  for (int64_t i = i_lo + (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x; i < i_hi; i += (int64_t)(gridDim.x >> 3) * 256) {
     const int c8 = (int)(i % c8n); int64_t p = i / c8n; const int ix = (int)(p % w); p /= w; const int iy = (int)(p % h); const int in = (int)(p / h);
     const int ch = c8 * 8;
     float acc[8];
@@ -634,6 +640,7 @@ static int float_dw_dgrad_any(const FrostFDesc* desc, const ET* dc, int n, int h
   FROST_REQUIRE(c % 8 == 0, "float_dw_dgrad: channels must be a multiple of 8");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   const int64_t tot = (int64_t)n * h * w * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
+  grid = (grid + 7) & ~(int64_t)7;
   hipLaunchKernelGGL(k_f_dw_dgrad<ET>, dim3((unsigned)grid), dim3(256), 0, s, desc, dc, n, h, w, c, round_up(c, 16), k, stride, ho, wo, dx);
   return frost_check_launch("float_dw_dgrad");
 }
@@ -662,7 +669,8 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const ET* __restrict__ dc, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[kx][e] = 0.0f;
   if (live) {
-    for (int64_t p = (int64_t)blockIdx.x * 64 + pl; p < npix; p += (int64_t)gridDim.x * 64) {
+    const int64_t ppx = (npix + 7) >> 3; const int64_t p_lo = (blockIdx.x & 7) * ppx; const int64_t p_hi = (p_lo + ppx < npix) ? p_lo + ppx : npix;   // XCD-aware, see k_f_dw
+    for (int64_t p = p_lo + (int64_t)(blockIdx.x >> 3) * 64 + pl; p < p_hi; p += (int64_t)(gridDim.x >> 3) * 64) {
       int64_t pp = p; const int ox = (int)(pp % wo); pp /= wo; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
       const int iy = oy * stride - pad + ky; if (iy < 0 || iy >= h) continue;
       float g8[8];
@@ -703,6 +711,7 @@ static int float_dw_wgrad_any(const ET* dc, const ET* x, int n, int h, int w, in
   const int64_t npix = (int64_t)n * ho * wo;
   const int units = ((c + 31) / 32) * k;
   int64_t gx = (npix + 63) / 64; int64_t cap = 4096 / units; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
+  gx = (gx + 7) & ~(int64_t)7;
   hipLaunchKernelGGL(k_f_dw_wgrad<ET>, dim3((unsigned)gx, units), dim3(256), 0, s, dc, x, n, h, w, c, k, stride, ho, wo, dw);
   return frost_check_launch("float_dw_wgrad");
 }
