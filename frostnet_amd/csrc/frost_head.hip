@@ -102,22 +102,40 @@ extern "C" int frost_classifier_fwd(const float* x, const int8_t* wq, const floa
   return frost_check_launch("classifier_fwd");
 }
 
+// out[c] = sum_r g[r][c]: workgroup = 32 columns x 8 row lanes (a thread per column walked all n rows alone: 49 us for 512 x 1000)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int n, int m, float* __restrict__ out) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= m) return;
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.0f;
-  for (int r = 0; r < n; ++r) s += g[(int64_t)r * m + c];
-  out[c] = s;
+  if (c < m) for (int r = rl; r < n; r += 8) s += g[(int64_t)r * m + c];
+  part[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < m) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += part[i][cl];
+    out[c] = s;
+  }
 }
-// gx[n][hw][c] = dpool[n][c] * drop[n][c] / hw   (bf16)
+// gx[n][hw][c] = dpool[n][c] * drop[n][c] / hw: a thread = 8 channels of one pixel (c % 8 == 0), 32-bit index arithmetic
 template <typename ET>
 __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ dpool, const float* __restrict__ drop, int n, int hw,
                                                   int c, ET* __restrict__ gx) {
-  int64_t tot = (int64_t)n * hw * c;
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    int ch = (int)(i % c); int64_t in = i / ((int64_t)hw * c);
-    float v = dpool[in * c + ch]; if (drop) v *= drop[in * c + ch];
-    if (sizeof(ET) == 4) ((float*)gx)[i] = v / (float)hw; else ((uint16_t*)gx)[i] = f2bf(v / (float)hw);
+  const int c8n = c >> 3; const unsigned tot = (unsigned)n * hw * c8n;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+    const unsigned pix = i / c8n; const int ch = (int)(i - pix * c8n) * 8; const int in = (int)(pix / hw);
+    const float4 a = *(const float4*)(dpool + (int64_t)in * c + ch), b = *(const float4*)(dpool + (int64_t)in * c + ch + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (drop) {
+      const float4 d0 = *(const float4*)(drop + (int64_t)in * c + ch), d1 = *(const float4*)(drop + (int64_t)in * c + ch + 4);
+      v[0] *= d0.x; v[1] *= d0.y; v[2] *= d0.z; v[3] *= d0.w; v[4] *= d1.x; v[5] *= d1.y; v[6] *= d1.z; v[7] *= d1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] / (float)hw;
+    ET* dst = gx + (int64_t)pix * c + ch;
+    if (sizeof(ET) == 4) { *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]); *(float4*)((float*)dst + 4) = make_float4(v[4], v[5], v[6], v[7]); }
+    else { uint4 o; o.x = f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); o.y = f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+           o.z = f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); o.w = f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16); *(uint4*)dst = o; }
   }
 }
 // replaces: autograd of [avgpool -> dropout -> nnqat.Conv2d] (frostnet.py:295-299). dlogits already STE-masked.
@@ -127,10 +145,11 @@ extern "C" int frost_head_bwd(const float* dlogits_masked, const float* pooled, 
                               uint16_t* gx, float* scratch_dpool, const float* wscale, void* stream) {
   hipStream_t s = as_stream(stream);
   launch_sgemm<float, float>(s, dlogits_masked, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dwq, true);
-  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 31) / 32), dim3(256), 0, s, dlogits_masked, n, nclass, dbias);
   launch_sgemm<float, int8_t>(s, dlogits_masked, (int64_t)nclass, (int64_t)1, wq, (int64_t)cin, (int64_t)1, n, cin, nclass,
                               wscale ? nullptr : qrec_w + FROST_Q_SCALE, (const float*)nullptr, scratch_dpool, true, nullptr, wscale);
-  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  FROST_REQUIRE(cin % 8 == 0, "head_bwd: the feature width must be a multiple of 8");
+  int64_t tot = (int64_t)n * hw * (cin >> 3); int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("head_bwd");
 }
@@ -141,9 +160,10 @@ extern "C" int frost_float_head_bwd(const float* dlogits, const float* pooled, c
                                     const float* drop_mask, float* dw, float* dbias, uint16_t* gx, float* scratch_dpool, void* stream) {
   hipStream_t s = as_stream(stream);
   launch_sgemm<float, float>(s, dlogits, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dw, true);
-  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 31) / 32), dim3(256), 0, s, dlogits, n, nclass, dbias);
   launch_sgemm<float, float>(s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin, (int64_t)1, n, cin, nclass, (const float*)nullptr, (const float*)nullptr, scratch_dpool, true);
-  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  FROST_REQUIRE(cin % 8 == 0, "head_bwd: the feature width must be a multiple of 8");
+  int64_t tot = (int64_t)n * hw * (cin >> 3); int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("float_head_bwd");
 }
@@ -152,9 +172,10 @@ extern "C" int frost_float_head_bwd_f32(const float* dlogits, const float* poole
                                         const float* drop_mask, float* dw, float* dbias, float* gx, float* scratch_dpool, void* stream) {
   hipStream_t s = as_stream(stream);
   launch_sgemm<float, float>(s, dlogits, (int64_t)1, (int64_t)nclass, pooled, (int64_t)cin, (int64_t)1, nclass, cin, n, (const float*)nullptr, (const float*)nullptr, dw, true);
-  hipLaunchKernelGGL(k_colsum, dim3((nclass + 255) / 256), dim3(256), 0, s, dlogits, n, nclass, dbias);
+  hipLaunchKernelGGL(k_colsum, dim3((nclass + 31) / 32), dim3(256), 0, s, dlogits, n, nclass, dbias);
   launch_sgemm<float, float>(s, dlogits, (int64_t)nclass, (int64_t)1, wfc, (int64_t)cin, (int64_t)1, n, cin, nclass, (const float*)nullptr, (const float*)nullptr, scratch_dpool, true);
-  int64_t tot = (int64_t)n * hw * cin; int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
+  FROST_REQUIRE(cin % 8 == 0, "head_bwd: the feature width must be a multiple of 8");
+  int64_t tot = (int64_t)n * hw * (cin >> 3); int64_t grid = (tot + 255) / 256; if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pool_bwd<float>, dim3((unsigned)grid), dim3(256), 0, s, scratch_dpool, drop_mask, n, hw, cin, gx);
   return frost_check_launch("float_head_bwd_f32");
 }
@@ -359,23 +380,32 @@ __device__ __forceinline__ void dm_philox(uint32_t c0, uint32_t c1, uint32_t c2,
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 __global__ __launch_bounds__(256) void k_dropout_mask(unsigned long long* draw, unsigned long long seed, int64_t n, float keep, float* __restrict__ out) {
-  const unsigned long long d = *draw;                       // single workgroup grid-stride kernel: every thread reads before thread 0 advances
-  __syncthreads();
+  // draw[0] = the draw counter, draw[1] = arrival ticket.  Every workgroup reads the counter before it takes its ticket; the last one to arrive
+  // advances the counter and re-arms the ticket (a single-workgroup version of this kernel was 180 us on the forward's critical path)
+  const unsigned long long d = __hip_atomic_load(draw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const float inv = 1.0f / keep;
-  for (int64_t i = threadIdx.x; i < (n + 3) / 4; i += 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (n + 3) / 4; i += (int64_t)gridDim.x * 256) {
     uint32_t r[4];
     dm_philox((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)d, (uint32_t)(d >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float o[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int64_t j = i * 4 + e;
-      if (j < n) out[j] = (((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f) < keep) ? inv : 0.0f;
+    for (int e = 0; e < 4; ++e) o[e] = (((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f) < keep) ? inv : 0.0f;
+    if (i * 4 + 3 < n) *(float4*)(out + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (i * 4 + e < n) out[i * 4 + e] = o[e];
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) *draw = d + 1ull;
+  __syncthreads();                                          // every thread of this workgroup holds d
+  if (threadIdx.x == 0) {
+    const unsigned long long t = atomicAdd(draw + 1, 1ull);
+    if (t == (unsigned long long)gridDim.x - 1ull) { atomicExch(draw + 1, 0ull); atomicExch(draw, d + 1ull); }
+  }
 }
 extern "C" int frost_dropout_mask(void* draw_counter, uint64_t seed, int64_t n, float keep, float* out, void* stream) {
   FROST_REQUIRE(keep > 0.0f && keep <= 1.0f, "dropout_mask: keep probability must be in (0, 1]");
-  hipLaunchKernelGGL(k_dropout_mask, dim3(1), dim3(256), 0, as_stream(stream), (unsigned long long*)draw_counter, (unsigned long long)seed, n, keep, out);
+  FROST_REQUIRE(((uintptr_t)out & 15) == 0, "dropout_mask: out must be 16-byte aligned");
+  int64_t grid = ((n + 3) / 4 + 255) / 256; if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (unsigned long long*)draw_counter, (unsigned long long)seed, n, keep, out);
   return frost_check_launch("dropout_mask");
 }

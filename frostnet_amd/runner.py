@@ -422,7 +422,7 @@ class FrostRunner:
         if training and drop_rate > 0.0:
             keep = 1.0 - drop_rate
             if getattr(self, "_drop_ctr", None) is None:          # device-resident draw counter: a captured graph draws a fresh mask per replay
-                self._drop_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+                self._drop_ctr = torch.zeros(2, dtype=torch.int64, device=self.device)        # {draw, arrival ticket}
             drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device)
             L.call("frost_dropout_mask", L.ptr(self._drop_ctr), 1882, a.n * a.c, keep, L.ptr(drop), L.stream())
         logits = self.E.head(self.cls, a, drop, self._obs)

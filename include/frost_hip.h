@@ -324,7 +324,8 @@ int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
  * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */
 int frost_softmax_ce(const float* logits, const int64_t* target, int n, int c, float inv_n, float* loss, float* dlogits, void* stream);
 /* replaces: nn.Dropout's Bernoulli mask on the pooled features (frostnet.py:297): out[i] in {0, 1/keep}, Philox4x32-10, counter =
- * (index, *draw_counter); the kernel advances the device-resident uint64 draw counter itself (hipGraph replays draw fresh masks). */
+ * (index, draw_counter[0]); draw_counter = TWO device-resident uint64 {draw, arrival ticket (zero)}: the last workgroup to finish advances the
+ * draw counter itself (hipGraph replays draw fresh masks).  out: 16-byte aligned. */
 int frost_dropout_mask(void* draw_counter, uint64_t seed, int64_t n, float keep, float* out, void* stream);
 
 /* ---- converted int8 inference ------------------------------------------------------------------

@@ -314,12 +314,12 @@ def test_cross_entropy_and_dropout_kernels(fa):
     torch.testing.assert_close(loss, ref, rtol=2e-6, atol=1e-6)
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-8)
     # dropout mask: values in {0, 1/keep}, keep rate, fresh draw per call, reproducible for the same (seed, draw)
-    ctr = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ctr = torch.zeros(2, dtype=torch.int64, device="cuda")           # {draw counter, arrival ticket}
     n, keep = 512 * 1280, 0.8
     a, b = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
     L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(a), L.stream())
     L.call("frost_dropout_mask", L.ptr(ctr), 1882, n, keep, L.ptr(b), L.stream())
-    assert int(ctr) == 2
+    assert ctr.tolist() == [2, 0]
     assert set(torch.unique(a).tolist()) == {0.0, 1.25}
     assert abs(float((a > 0).float().mean()) - keep) < 3e-3 and abs(float((b > 0).float().mean()) - keep) < 3e-3
     assert not torch.equal(a, b) and abs(float(((a > 0) == (b > 0)).float().mean()) - (keep * keep + (1 - keep) ** 2)) < 5e-3
