@@ -105,6 +105,8 @@ _PROTOS = {
     "frost_float_bwd_finalize": [P, I, L, P],
     "frost_float_pw": [P, P, P, L, I, I, I, I, P, I, P, I, P],
     "frost_float_dw": [P, P, I, I, I, I, I, I, I, I, P, P, P],
+    "frost_float_ew": [P, P, L, I, I, I, P, I, P, I, P],
+    "frost_float_ew_f32": [P, P, L, I, I, I, P, I, P, I, P],
     "frost_float_dw_dgrad": [P, P, I, I, I, I, I, I, P, P],
     "frost_float_dw_wgrad": [P, P, I, I, I, I, I, I, P, P],
     "frost_float_pw_wgrad": [P, P, L, I, I, I, P, I, P],

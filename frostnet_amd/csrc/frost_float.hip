@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
           } else if constexpr (MODE == F_STATS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const SA v = ok ? (SA)a[r] : (SA)0; rs[r] += v; rq[r] += v * v; }
+            if (y && ok) { const float o4[4] = {a[0], a[1], a[2], a[3]}; FEl<ET>::st4(y + prow * ldy + ch0, o4); }       // the conv output itself (training: kept for the element-wise passes)
           } else if constexpr (MODE == F_EMIT) {
             if (ok) {
               const float o4[4] = {fmaxf(fmaf(a[0], sc[0], bi[0]), lo), fmaxf(fmaf(a[1], sc[1], bi[1]), lo),
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
         if constexpr (MODE == F_STATS) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) { s[e] += (SA)acc[o][e]; q[e] += (SA)acc[o][e] * (SA)acc[o][e]; }
+          if (y) FEl<ET>::st8(y + p * c + ch, acc[o]);
         } else if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
@@ -603,6 +605,99 @@ extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, 
 extern "C" int frost_float_dw_f32(const FrostFDesc* desc, const float* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
                                   const float* gy, float* out, void* stream) {
   return float_dw_any<float>(desc, x, n, h, w, c, k, stride, relu, mode, gy, out, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise passes over a kept conv output
+// A training forward keeps every layer's convolution output c (the statistics pass stores it), so the passes that only need c per element do not
+// recompute it:  F_EMIT: y = [relu](c*scale + bias)     F_BRED: S1 += g*m, S2 += g*m*xhat     F_BDC: dc = g*m*K1 + c*E + F     (m = z > 0 for ReLU layers)
+// c: dense [npix][ch]; gy / out rows of ldg / ldy elements.  Thread = 8 channels (fixed: coefficients and partial sums in registers) x strided pixels.
+template <int MODE, typename ET>
+__global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __restrict__ cv, int64_t npix, int c, int cpad, int relu,
+                                              const ET* __restrict__ gy, int ldg, ET* __restrict__ y, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  using SA = typename std::conditional<sizeof(ET) == 4, double, float>::type;
+  constexpr bool F32 = sizeof(ET) == 4;
+  SA* sacc = (SA*)smem;
+  const int tid = threadIdx.x;
+  if (MODE == F_BRED) { for (int i = tid; i < 2 * cpad; i += 256) sacc[i] = (SA)0; __syncthreads(); }
+  const int c8n = c >> 3;
+  const int64_t PP = ((int64_t)gridDim.x * 256) / c8n;
+  const int64_t t = (int64_t)blockIdx.x * 256 + tid;
+  const int c8 = (int)(t % c8n); const int64_t slot = t / c8n;
+  const int ch = c8 * 8;
+  const float* coef = dp->coef;
+  float sc[8], bi[8], c2[8], c3[8], c4[8], c5[8], c6[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = coef[FC_SCALE * cpad + ch + e]; bi[e] = coef[FC_BIAS * cpad + ch + e];
+    if (MODE == F_BRED) { c2[e] = coef[FC_MEAN * cpad + ch + e]; c3[e] = coef[FC_INV * cpad + ch + e]; }
+    if (MODE == F_BDC) { c2[e] = coef[FC_K1 * cpad + ch + e]; c3[e] = coef[FC_E * cpad + ch + e]; c4[e] = coef[FC_F * cpad + ch + e];
+                         if (F32) { c5[e] = coef[FC_MEAN * cpad + ch + e]; c6[e] = coef[FC_INV * cpad + ch + e]; } }
+  }
+  SA s[8], q[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
+  const float lo = relu ? 0.0f : -INFINITY;
+  if (slot < PP) {
+    for (int64_t p = slot; p < npix; p += PP) {
+      float a[8];
+      FEl<ET>::ld8(cv + p * c + ch, a);
+      if constexpr (MODE == F_EMIT) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(a[e], sc[e], bi[e]), lo);
+        FEl<ET>::st8(y + p * ldy + ch, o8);
+      } else {
+        float gm[8];
+        FEl<ET>::ld8(gy + p * ldg + ch, gm);
+        if (relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) if (!(fmaf(a[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
+        }
+        if constexpr (MODE == F_BRED) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += (SA)gm[e]; q[e] += (SA)gm[e] * (SA)((a[e] - c2[e]) * c3[e]); }
+        } else {
+          float o8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o8[e] = F32 ? c2[e] * ((gm[e] - c4[e]) - ((a[e] - c5[e]) * c6[e]) * c3[e]) : fmaf(gm[e], c2[e], fmaf(a[e], c3[e], c4[e]));
+          FEl<ET>::st8(y + p * ldy + ch, o8);
+        }
+      }
+    }
+  }
+  if (MODE == F_BRED) {
+    if (slot < PP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&sacc[ch + e], s[e]); atomicAdd(&sacc[cpad + ch + e], q[e]); }
+    }
+    __syncthreads();
+    double* st = dp->stat + 2 * cpad;
+    for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
+  }
+}
+template <typename ET>
+static int float_ew_any(const FrostFDesc* desc, const ET* cv, int64_t npix, int c, int relu, int mode, const ET* gy, int ldg, ET* out, int ldy, hipStream_t s) {
+  FROST_REQUIRE(c % 8 == 0 && ldg % 8 == 0 && ldy % 8 == 0, "float_ew: channels and row strides must be multiples of 8");
+  FROST_REQUIRE(mode >= 1 && mode <= 3, "float_ew: mode 1 (emit), 2 (reduce), 3 (dc)");
+  const int cpad = round_up(c, 16); const int c8n = c >> 3;
+  const int64_t tot = npix * c8n;
+  int64_t grid = (tot + 255) / 256; const int64_t cap = (mode == F_BRED) ? 2048 : 8192; if (grid > cap) grid = cap;
+  const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;
+  const size_t lds = (mode == F_BRED) ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
+  if (mode == F_EMIT) hipLaunchKernelGGL((k_f_ew<F_EMIT, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
+  else if (mode == F_BRED) hipLaunchKernelGGL((k_f_ew<F_BRED, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
+  else hipLaunchKernelGGL((k_f_ew<F_BDC, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
+  return frost_check_launch("float_ew");
+}
+extern "C" int frost_float_ew(const FrostFDesc* desc, const uint16_t* conv, int64_t npix, int c, int relu, int mode, const uint16_t* gy, int ldg,
+                              uint16_t* out, int ldy, void* stream) {
+  return float_ew_any<uint16_t>(desc, conv, npix, c, relu, mode, gy, ldg, out, ldy, as_stream(stream));
+}
+extern "C" int frost_float_ew_f32(const FrostFDesc* desc, const float* conv, int64_t npix, int c, int relu, int mode, const float* gy, int ldg,
+                                  float* out, int ldy, void* stream) {
+  return float_ew_any<float>(desc, conv, npix, c, relu, mode, gy, ldg, out, ldy, as_stream(stream));
 }
 
 // depthwise data gradient: dx[n][iy][ix][c] = sum_{ky,kx} dc[n][(iy+pad-ky)/s][(ix+pad-kx)/s][c] * w[c][ky][kx]   (where divisible / in range)

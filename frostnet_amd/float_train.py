@@ -49,6 +49,7 @@ class FAct:
         return v.view(self.n, self.h, self.w, self.c).permute(0, 3, 1, 2)
 
 
+_KEEP_CONV = os.environ.get("FROST_FLOAT_KEEP_CONV", "1") != "0"        # training keeps each layer's conv output for element-wise passes (A/B knob)
 _WGRAD_SIDE = os.environ.get("FROST_FLOAT_WGRAD_SIDE", "1") != "0"      # weight gradients on a second stream (A/B knob)
 
 
@@ -76,6 +77,7 @@ class _FLayer:
         self.stat = torch.zeros(4 * self.cpad, dtype=torch.float64, device=dev)
         self.coef = torch.zeros(8 * self.cpad, dtype=torch.float32, device=dev)
         self.x = None          # saved input of the last recorded forward
+        self.c = None          # kept conv output of the last recorded training forward (element-wise backward passes)
         self.desc_ptr = None   # device address of this layer's FrostFDesc
 
     def desc(self, gviews):
@@ -150,7 +152,7 @@ class FloatRunner:
         self.precision, self.fp32 = precision, precision == "fp32"
         self._adt = torch.float32 if self.fp32 else torch.int16          # activation / activation-gradient storage
         sfx = "_f32" if self.fp32 else ""
-        self._fn = {n: n + sfx for n in ("frost_float_pw", "frost_float_dw", "frost_float_dw_dgrad", "frost_float_dw_wgrad", "frost_float_pw_wgrad",
+        self._fn = {n: n + sfx for n in ("frost_float_pw", "frost_float_dw", "frost_float_ew", "frost_float_dw_dgrad", "frost_float_dw_wgrad", "frost_float_pw_wgrad",
                                          "frost_float_grad_merge", "frost_float_avgpool", "frost_float_head_bwd")}
         self._fn["cat"] = "frost_float_cat_f32" if self.fp32 else "frost_infer_cat"
         self._fn["add"] = "frost_float_add_f32" if self.fp32 else "frost_infer_add"
@@ -261,16 +263,27 @@ class FloatRunner:
             ho, wo = a.h, a.w
         y = self._new(a.n, ho, wo, l.cout) if out is None else None
         npix_o = a.n * ho * wo
-        if l.kind == 1:
+        dst, ld = (ptr(y.buf), l.cout) if out is None else (out, ldy)
+        if training and _KEEP_CONV:
+            # training: ONE convolution per layer.  The statistics pass stores the conv output c; y = [relu](c*scale + bias) is an element-wise pass
+            # over c, and so are the backward's statistics and dc (frost_float_ew) -- c is kept until the layer's backward
+            cbuf = torch.empty(npix_o * l.cout + 64, dtype=self._adt, device=self.device)
+            if l.kind == 1:
+                call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, ptr(cbuf), stream())
+            else:
+                call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, ptr(cbuf), l.cout, stream())
+            call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
+            call(self._fn["frost_float_ew"], l.desc_ptr, ptr(cbuf), npix_o, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
+            l.c = cbuf if record else None
+        elif l.kind == 1:
             if training:
                 call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, None, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), EMIT, None, ptr(y.buf), stream())
+            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), EMIT, None, dst, stream())
         else:
             if training:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, None, 0, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            dst, ld = (ptr(y.buf), l.cout) if out is None else (out, ldy)
             call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
         if record:
             l.x = a
@@ -363,20 +376,28 @@ class FloatRunner:
         dc = torch.empty(npix_o * l.cout + 64, dtype=self._adt, device=self.device)
         gw = self._gv[id(l.conv.weight)]
         dx = None
-        if l.kind == 1:
-            if ldg != l.cout:
-                raise RuntimeError("depthwise gradients are dense")
-            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BRED, gy, None, stream())
+        kept = getattr(l, "c", None)
+        if kept is not None:          # the conv output of the forward is at hand: statistics and dc are element-wise
+            call(self._fn["frost_float_ew"], l.desc_ptr, ptr(kept), npix_o, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
             call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BDC, gy, ptr(dc), stream())
+            call(self._fn["frost_float_ew"], l.desc_ptr, ptr(kept), npix_o, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
+            l.c = None
+        if l.kind == 1:
+            if kept is None:
+                if ldg != l.cout:
+                    raise RuntimeError("depthwise gradients are dense")
+                call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BRED, gy, None, stream())
+                call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
+                call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), BDC, gy, ptr(dc), stream())
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
                 call(self._fn["frost_float_dw_dgrad"], l.desc_ptr, ptr(dc), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(dx.buf), stream())
             self._on_side(lambda: call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream()), dc, a)
         else:
-            call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
-            call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
+            if kept is None:
+                call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())
+                call("frost_float_bwd_finalize", l.desc_ptr, l.cout, npix_o, stream())
+                call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BDC, gy, ldg, ptr(dc), l.cout, stream())
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
                 # data gradient = a plain bf16 GEMM with the transposed pack: the tuned pointwise skeleton (DMA double-buffered tiles,

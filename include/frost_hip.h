@@ -257,6 +257,13 @@ int frost_float_pw(const FrostFDesc* desc, const uint16_t* x, const uint16_t* pa
                    const uint16_t* gy, int ldg, uint16_t* out, int ldy, void* stream);
 int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
                    const uint16_t* gy, uint16_t* out, void* stream);
+/* element-wise passes over a KEPT conv output (mode 0 of frost_float_pw / frost_float_dw stores the convolution output into `out` when it is
+ * non-NULL): mode 1 y = [relu](conv*scale + bias), mode 2 the backward statistics, mode 3 dc -- the same results as modes 1..3 of the conv entries
+ * without recomputing the convolution (replaces: the second evaluation of F.conv2d inside _forward_approximate and autograd's saved tensors). */
+int frost_float_ew(const FrostFDesc* desc, const uint16_t* conv, int64_t npix, int c, int relu, int mode, const uint16_t* gy, int ldg,
+                   uint16_t* out, int ldy, void* stream);
+int frost_float_ew_f32(const FrostFDesc* desc, const float* conv, int64_t npix, int c, int relu, int mode, const float* gy, int ldg,
+                       float* out, int ldy, void* stream);
 int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream);
 int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream);
 int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream);
