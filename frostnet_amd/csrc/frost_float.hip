@@ -72,6 +72,7 @@ template <int CTRL> __device__ __forceinline__ float f_dpp(float v) {
 }
 __device__ __forceinline__ float f_row_sum(float v) { v += f_dpp<0x111>(v); v += f_dpp<0x112>(v); v += f_dpp<0x114>(v); v += f_dpp<0x118>(v); return v; }
 __device__ __forceinline__ double f_row_sum(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+#define FST_SLOTS 8       // statistic partials are spread over 8 copies of the table (workgroup index & 7): 8x fewer same-address atomics for the L2 to serialise; the finalize kernels add the copies up
 enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, FC_F = 6, FC_VAR = 7 };
 
 // ------------------------------------------------------------------------------------------------ weight preparation (per step)
@@ -79,7 +80,7 @@ enum { FC_SCALE = 0, FC_BIAS = 1, FC_MEAN = 2, FC_INV = 3, FC_K1 = 4, FC_E = 5, 
 __global__ __launch_bounds__(256) void k_f_prep(const FrostFDesc* descs) {
   const FrostFDesc d = descs[blockIdx.y];
   const int gtid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
-  for (int i = gtid; i < 4 * d.cpad; i += gsz) d.stat[i] = 0.0;
+  for (int i = gtid; i < FST_SLOTS * 4 * d.cpad; i += gsz) d.stat[i] = 0.0;
   if ((d.kind == 0 || d.kind == 2) && d.fp32) {       // fp32 mode: A-fragments [ct][kb][lane][4]: W[ct*16 + (lane&15)][kb*16 + (lane>>4)*4 + e]
     const int CT = d.cpad / 16, KB = d.kpad / 16;
     const int64_t nel = (int64_t)CT * KB * 256;
@@ -151,8 +152,10 @@ __global__ __launch_bounds__(256) void k_f_bn_finalize(const FrostFDesc* dp, dou
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c == 0 && d.nbt) *d.nbt += 1;
   if (c >= d.cout) return;
-  const double mean = d.stat[c] / count;
-  double var = d.stat[d.cpad + c] / count - mean * mean; if (var < 0.0) var = 0.0;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < FST_SLOTS; ++k) { s1 += d.stat[k * 4 * d.cpad + c]; s2 += d.stat[k * 4 * d.cpad + d.cpad + c]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean; if (var < 0.0) var = 0.0;
   const float inv = (float)(1.0 / sqrt(var + (double)FROST_BN_EPS));
   const float sc = d.gamma[c] * inv;
   d.coef[FC_SCALE * d.cpad + c] = sc; d.coef[FC_BIAS * d.cpad + c] = d.beta[c] - (float)mean * sc;
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(256) void k_f_bwd_finalize(const FrostFDesc* dp, do
   const FrostFDesc d = *dp;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d.cout) return;
-  const double S1 = d.stat[2 * d.cpad + c], S2 = d.stat[3 * d.cpad + c];
+  double S1 = 0.0, S2 = 0.0;
+  for (int k = 0; k < FST_SLOTS; ++k) { S1 += d.stat[k * 4 * d.cpad + 2 * d.cpad + c]; S2 += d.stat[k * 4 * d.cpad + 3 * d.cpad + c]; }
   const float inv = d.coef[FC_INV * d.cpad + c], mean = d.coef[FC_MEAN * d.cpad + c];
   const float K1 = d.gamma[c] * inv;
   const float a = (float)(S1 / count), b = (float)(S2 / count);
@@ -358,13 +362,18 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
   }
   if (RED) {
     __syncthreads();
-    double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
+    double* st = dp->stat + (size_t)((blockIdx.x + blockIdx.y) & (FST_SLOTS - 1)) * 4 * cpad + (MODE == F_BRED ? 2 * cpad : 0);
     for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
 static int f_pw_nt() {        // FROST_FPW_NT=1/2/4 caps the pixel sub-tiles per wave (A/B knob; default 1: more resident workgroups beat the fragment reuse)
   static int v = -1;
   if (v < 0) { const char* e = getenv("FROST_FPW_NT"); v = e ? atoi(e) : 1; if (v != 1 && v != 2 && v != 4) v = 1; }
+  return v;
+}
+static int f_red_cap() {      // workgroups of a statistics launch (FROST_FRED_CAP): every one ends with an LDS fold + 2*cpad global atomics -- fewer, fatter workgroups win (2048 -> 1024: -0.6 ms per step)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("FROST_FRED_CAP"); v = e ? atoi(e) : 1024; if (v < 64) v = 64; }
   return v;
 }
 static int f_pw_csplit_cap() {      // FROST_FPW_CSPLIT=1 turns the channel split off (A/B knob)
@@ -379,7 +388,7 @@ static void launch_f_pw_cl(const FrostFDesc* dp, const ET* T, const void* pack, 
   constexpr int IPX = 16 * WPX * NT;
   static bool attr = false;
   if (!attr) { hipFuncSetAttribute((const void*)k_f_pw<MODE, WPX, ET, NT, CL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (RED && grid > 2048) grid = 2048;
+  const int64_t nt = (npix + IPX - 1) / IPX; int64_t grid = nt; if (RED && grid > f_red_cap()) grid = f_red_cap();
   // few pixel tiles and many channel tiles (the 14x14 / 7x7 expand layers): the groups of 4 channel tiles a workgroup walks are dealt out over
   // gridDim.y workgroups, each staging the (small) x tile again, until the launch has ~4 workgroups per CU
   const int groups = ((cpad >> 4) + 4 * (4 / WPX) - 1) / (4 * (4 / WPX));
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
       for (int e = 0; e < 8; ++e) { atomicAdd(&sacc[ch + e], s[e]); atomicAdd(&sacc[cpad + ch + e], q[e]); }
     }
     __syncthreads();
-    double* st = dp->stat + (MODE == F_BRED ? 2 * cpad : 0);
+    double* st = dp->stat + (size_t)((blockIdx.x + blockIdx.y) & (FST_SLOTS - 1)) * 4 * cpad + (MODE == F_BRED ? 2 * cpad : 0);
     for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
@@ -588,7 +597,7 @@ static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
   const int64_t tot = (int64_t)n * ho * ((wo + FDW_WO - 1) / FDW_WO) * c8n;
   const bool red = (mode == F_STATS || mode == F_BRED);
-  int64_t grid = (tot + 255) / 256; const int64_t cap = red ? 2048 : 8192; if (grid > cap) grid = cap;
+  int64_t grid = (tot + 255) / 256; const int64_t cap = red ? f_red_cap() : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < 8 * gmin) grid = 8 * gmin;      // every channel group needs at least one thread in every XCD's share
   grid = (grid + 7) & ~(int64_t)7;
   const size_t lds = red ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
@@ -639,30 +648,42 @@ __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __
   for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
   const float lo = relu ? 0.0f : -INFINITY;
   if (slot < PP) {
-    for (int64_t p = slot; p < npix; p += PP) {
-      float a[8];
-      FEl<ET>::ld8(cv + p * c + ch, a);
-      if constexpr (MODE == F_EMIT) {
-        float o8[8];
+    for (int64_t p0 = slot; p0 < npix; p0 += 4 * PP) {          // four pixels per trip: their loads are in flight together
+      typename FEl<ET>::R8 ra[4], rg[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(a[e], sc[e], bi[e]), lo);
-        FEl<ET>::st8(y + p * ldy + ch, o8);
-      } else {
-        float gm[8];
-        FEl<ET>::ld8(gy + p * ldg + ch, gm);
-        if (relu) {
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u * PP;
+        ra[u] = FEl<ET>::zero8(); rg[u] = FEl<ET>::zero8();
+        if (p < npix) { ra[u] = FEl<ET>::ldr8(cv + p * c + ch); if (MODE != F_EMIT) rg[u] = FEl<ET>::ldr8(gy + p * ldg + ch); }
+      }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) if (!(fmaf(a[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
-        }
-        if constexpr (MODE == F_BRED) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { s[e] += (SA)gm[e]; q[e] += (SA)gm[e] * (SA)((a[e] - c2[e]) * c3[e]); }
-        } else {
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u * PP;
+        if (p >= npix) continue;
+        float a[8];
+        FEl<ET>::cv8(ra[u], a);
+        if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            o8[e] = F32 ? c2[e] * ((gm[e] - c4[e]) - ((a[e] - c5[e]) * c6[e]) * c3[e]) : fmaf(gm[e], c2[e], fmaf(a[e], c3[e], c4[e]));
+          for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(a[e], sc[e], bi[e]), lo);
           FEl<ET>::st8(y + p * ldy + ch, o8);
+        } else {
+          float gm[8];
+          FEl<ET>::cv8(rg[u], gm);
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (!(fmaf(a[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
+          }
+          if constexpr (MODE == F_BRED) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += (SA)gm[e]; q[e] += (SA)gm[e] * (SA)((a[e] - c2[e]) * c3[e]); }
+          } else {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              o8[e] = F32 ? c2[e] * ((gm[e] - c4[e]) - ((a[e] - c5[e]) * c6[e]) * c3[e]) : fmaf(gm[e], c2[e], fmaf(a[e], c3[e], c4[e]));
+            FEl<ET>::st8(y + p * ldy + ch, o8);
+          }
         }
       }
     }
@@ -673,7 +694,7 @@ __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __
       for (int e = 0; e < 8; ++e) { atomicAdd(&sacc[ch + e], s[e]); atomicAdd(&sacc[cpad + ch + e], q[e]); }
     }
     __syncthreads();
-    double* st = dp->stat + 2 * cpad;
+    double* st = dp->stat + (size_t)(blockIdx.x & (FST_SLOTS - 1)) * 4 * cpad + 2 * cpad;
     for (int i = tid; i < 2 * cpad; i += 256) { const SA v = sacc[i]; if (v != (SA)0) atomicAdd(st + i, (double)v); }
   }
 }
@@ -683,7 +704,9 @@ static int float_ew_any(const FrostFDesc* desc, const ET* cv, int64_t npix, int 
   FROST_REQUIRE(mode >= 1 && mode <= 3, "float_ew: mode 1 (emit), 2 (reduce), 3 (dc)");
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
   const int64_t tot = npix * c8n;
-  int64_t grid = (tot + 255) / 256; const int64_t cap = (mode == F_BRED) ? 2048 : 8192; if (grid > cap) grid = cap;
+  static int rcap = -1;
+  if (rcap < 0) { const char* e = getenv("FROST_FEW_CAP"); rcap = e ? atoi(e) : 512; }
+  int64_t grid = (tot + 255) / 256; const int64_t cap = (mode == F_BRED) ? rcap : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;
   const size_t lds = (mode == F_BRED) ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
   if (mode == F_EMIT) hipLaunchKernelGGL((k_f_ew<F_EMIT, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);

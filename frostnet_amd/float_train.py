@@ -74,7 +74,7 @@ class _FLayer:
             if self.kind == 0:
                 self.kpad_t = round_up(self.cout, kq)
                 self.pack_t = torch.zeros((round_up(self.cin_g, 16) // 16) * (self.kpad_t // kq) * 1024, dtype=torch.uint8, device=dev)
-        self.stat = torch.zeros(4 * self.cpad, dtype=torch.float64, device=dev)
+        self.stat = torch.zeros(8 * 4 * self.cpad, dtype=torch.float64, device=dev)       # FST_SLOTS copies of [sum, sum of squares, S1, S2]
         self.coef = torch.zeros(8 * self.cpad, dtype=torch.float32, device=dev)
         self.x = None          # saved input of the last recorded forward
         self.c = None          # kept conv output of the last recorded training forward (element-wise backward passes)
