@@ -33,7 +33,8 @@ def smoke():
     gn = float(dict(model.named_parameters())["last_layer.conv.0.weight"].grad.norm())
     opt.step()
     torch.cuda.synchronize()
-    assert np.isfinite(float(loss)) and 0.9 < gn / gn_ref < 1.1, (float(loss), gn, gn_ref)       # measured 0.999
+    lv = float(loss.detach())
+    assert np.isfinite(lv) and 0.9 < gn / gn_ref < 1.1, (lv, gn, gn_ref)       # measured 0.999
     # eval parity from the oracle's post-step state
     sd = {k: v.detach().clone() for k, v in P.items()}
     sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
@@ -47,4 +48,4 @@ def smoke():
         out = m2(x1.cuda()).cpu()
     rel = float((out - ref).norm() / ref.norm())
     assert rel < 5e-3, rel          # measured 0.0 at this size (every logit index identical)
-    print(f"smoke ok: loss {float(loss):.4f}, grad-norm ratio {gn / gn_ref:.3f}, eval logits rel-err vs oracle {rel:.2e}")
+    print(f"smoke ok: loss {lv:.4f}, grad-norm ratio {gn / gn_ref:.3f}, eval logits rel-err vs oracle {rel:.2e}")
