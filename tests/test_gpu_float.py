@@ -54,8 +54,17 @@ def F():
 G4 = ["dw_e1", "mb", "cas_res", "cas_nores", "cas_s2"]
 
 
+@pytest.fixture(params=["kept_conv", "recompute"])
+def conv_path(request, monkeypatch):
+    """The training step keeps each layer's conv output and runs emit / reduce / dc element-wise over it (default); the recomputing GEMM / tap-loop
+    modes of the same entries (what eval-mode emit uses, and the A/B switch FROST_FLOAT_KEEP_CONV=0) are held to the same goldens."""
+    from frostnet_amd import float_train
+    monkeypatch.setattr(float_train, "_KEEP_CONV", request.param == "kept_conv")
+    return request.param
+
+
 @pytest.mark.parametrize("name", G4)
-def test_g4_float_block(F, golden, name):
+def test_g4_float_block(F, golden, name, conv_path):
     """Teacher-forced Frost bottlenecks, train mode, two steps, against the REFERENCE goldens (tools/gen_golden.py g4, float set):
     y, dx, every parameter gradient, running statistics.  The fixtures are tiny (N=2 at 6x6 / 8x8: BatchNorm over 32..128 samples), which
     amplifies the bf16 storage noise even within one block (the fake-quant path holds its G4 gradients to 5e-2 for the same reason);
