@@ -78,6 +78,7 @@ _PROTOS = {
     "frost_cat_observe": [P, P, P, I, P],
     "frost_cat_requant": [P, P, I, P, P, I, L, P, P, P],
     "frost_add_minmax": [P, P, P, P, L, P, P],
+    "frost_add_minmax_observe": [P, P, P, P, L, P, P, I, P],
     "frost_add_requant": [P, P, P, P, L, P, P, P],
     "frost_avgpool": [P, P, I, I, I, P, P, P],
     "frost_classifier_fwd": [P, P, P, P, I, I, I, P, P, P],

@@ -398,7 +398,7 @@ __device__ __forceinline__ float add_val(int ba, int bb, const QP& A, const QP& 
   return (float)(ba + 128 - A.zp) * A.scale + (float)(bb + 128 - B.zp) * B.scale;
 }
 __global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,
-                                                    const float* qb, int64_t n, float* out2) {
+                                                    const float* qb, int64_t n, float* out2, float* qy, uint32_t* ticket, int observe) {
   // 16 B per operand per lane and two independent loads in flight; few, fat workgroups: the final float atomics on the two
   // result words serialise, so their count (one pair per workgroup) is part of the critical path
   QP A = load_qp(qa), B = load_qp(qb);
@@ -422,11 +422,29 @@ __global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a
     const float v = add_val((int)a[i], (int)b[i], A, B); lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
   block_minmax_commit(lo, hi, out2);
+  if (ticket) {        // last workgroup done: the range is complete -> observer update here (no launch of its own), range words re-armed for the next add
+    __shared__ int sflag;
+    if (last_block_done(ticket, gridDim.x, &sflag) && threadIdx.x == 0) {
+      const float flo = __hip_atomic_load(out2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fhi = __hip_atomic_load(out2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      observer_update_dev(qy, flo, fhi, 0, 0, observe);
+      __hip_atomic_store(out2, INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(out2 + 1, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// range pass + MovingAverageMinMax update of the sum's FakeQuantize in one launch.  state3: {lo, hi, arrival ticket}; lo / hi must hold (+inf, -inf) on
+// entry (frost_fill_minmax once) and hold them again on exit, the ticket 0.
+extern "C" int frost_add_minmax_observe(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                                        float* state3, float* qrec_y, int observe, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
+  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 32768, 512)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, state3, qrec_y,
+                     (uint32_t*)(state3 + 2), observe);
+  return frost_check_launch("add_minmax_observe");
 }
 extern "C" int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                                 float* minmax2, void* stream) {
   FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
-  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 32768, 512)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, minmax2);
+  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 32768, 512)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, minmax2, (float*)nullptr,
+                     (uint32_t*)nullptr, 0);
   return frost_check_launch("add_minmax");
 }
 __global__ __launch_bounds__(256) void k_add_requant(const int8_t* __restrict__ a, const float* qa, const int8_t* __restrict__ b,

@@ -307,13 +307,11 @@ class Engine:
 
     def add(self, a, b, q, observe=True):
         """FloatFunctional.add + its FakeQuantize (frostnet.py:142)."""
-        if not hasattr(self, "_add_mm"):
-            self._add_mm = torch.empty(2, dtype=torch.float32, device=self.device)
-        if observe:
-            call("frost_fill_minmax", ptr(self._add_mm), 1, stream())
-            call("frost_add_minmax", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), stream(),
+        if not hasattr(self, "_add_mm"):      # {lo, hi, arrival ticket}: armed once, every launch leaves it armed again
+            self._add_mm = torch.tensor([float("inf"), float("-inf"), 0.0], dtype=torch.float32, device=self.device)
+        if observe:                           # range of the sum + observer update in one launch (the update runs in the last workgroup)
+            call("frost_add_minmax_observe", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), ptr(q), 1, stream(),
                  prof=("add_fwd_minmax", 2 * a.numel))
-            call("frost_observer_update", ptr(q), ptr(self._add_mm), 0, 0, 1, stream())
         y = self.new_act(a.n, a.h, a.w, a.c, q)
         call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream(),
              prof=("add_fwd_emit", 3 * a.numel))

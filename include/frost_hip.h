@@ -136,6 +136,10 @@ int frost_cat_requant(const int8_t* a, const float* qrec_a, int ca, const int8_t
 /* replaces: FloatFunctional.add + its FakeQuantize (frostnet.py:142): pass 0 = min/max of a+b, pass 1 = emit */
 int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                      float* minmax2, void* stream);
+/* the same range pass with the MovingAverageMinMax update of the sum's FakeQuantize folded into its last workgroup (replaces frost_fill_minmax +
+ * frost_add_minmax + frost_observer_update: one launch instead of three).  state3 = {lo, hi, arrival ticket}: (+inf, -inf, 0) on entry and again on exit. */
+int frost_add_minmax_observe(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
+                             float* state3, float* qrec_y, int observe, void* stream);
 int frost_add_requant(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                       const float* qrec_y, int8_t* y, void* stream);
 
