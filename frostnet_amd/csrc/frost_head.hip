@@ -187,6 +187,45 @@ __device__ __forceinline__ void acc_store4(uint16_t* dst, const float* v, int ac
   uint2 w; w.x = cvt_pk_bf16(o[0], o[1]); w.y = cvt_pk_bf16(o[2], o[3]);
   *(uint2*)dst = w;
 }
+__device__ __forceinline__ void acc_store8(uint16_t* dst, const float* v, int accumulate) {
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = v[e];
+  if (accumulate) {
+    const uint4 t = *(const uint4*)dst;
+    o[0] += bf2f(t.x & 0xffff); o[1] += bf2f(t.x >> 16); o[2] += bf2f(t.y & 0xffff); o[3] += bf2f(t.y >> 16);
+    o[4] += bf2f(t.z & 0xffff); o[5] += bf2f(t.z >> 16); o[6] += bf2f(t.w & 0xffff); o[7] += bf2f(t.w >> 16);
+  }
+  uint4 w; w.x = cvt_pk_bf16(o[0], o[1]); w.y = cvt_pk_bf16(o[2], o[3]); w.z = cvt_pk_bf16(o[4], o[5]); w.w = cvt_pk_bf16(o[6], o[7]);
+  *(uint4*)dst = w;
+}
+// 8 channels per thread (ca, cb multiples of 8; 32-bit index arithmetic): 16-byte gradient pieces, 8-byte index pieces
+__global__ __launch_bounds__(256) void k_cat_bwd8(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa, int ca,
+                                                  const int8_t* __restrict__ b, const float* qb, int cb, unsigned npix, const float* qy,
+                                                  uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ gb, int acc_b) {
+  __shared__ uint8_t ok[2][256];
+  {
+    QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+    int i = threadIdx.x; int q = (int)(int8_t)i + 128; bool ia, ib;
+    fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, Y.hi, &ia);
+    fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, Y.hi, &ib);
+    ok[0][i] = ia; ok[1][i] = ib;
+  }
+  __syncthreads();
+  const unsigned cy = ca + cb, dpp = cy >> 3; const unsigned nun = npix * dpp;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nun; i += gridDim.x * 256) {
+    const unsigned p = i / dpp; const int c0 = (int)(i - p * dpp) * 8;
+    const uint4 gv = *(const uint4*)(gy + (int64_t)p * cy + c0);
+    float g[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+    const bool first = c0 < ca;
+    const int cc = first ? c0 : c0 - ca;
+    const uint2 src = first ? *(const uint2*)(a + (int64_t)p * ca + cc) : *(const uint2*)(b + (int64_t)p * cb + cc);
+    const uint8_t* tb = ok[first ? 0 : 1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { if (!tb[(src.x >> (8 * r)) & 255]) g[r] = 0.0f; if (!tb[(src.y >> (8 * r)) & 255]) g[4 + r] = 0.0f; }
+    if (first) acc_store8(ga + (int64_t)p * ca + cc, g, acc_a); else acc_store8(gb + (int64_t)p * cb + cc, g, acc_b);
+  }
+}
 __global__ __launch_bounds__(256) void k_cat_bwd(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa, int ca,
                                                  const int8_t* __restrict__ b, const float* qb, int cb, int64_t npix, const float* qy,
                                                  uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ gb, int acc_b) {
@@ -220,9 +259,35 @@ __global__ __launch_bounds__(256) void k_cat_bwd(const uint16_t* __restrict__ gy
 extern "C" int frost_cat_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, int ca, const int8_t* b,
                              const float* qrec_b, int cb, int64_t npix, const float* qrec_y, uint16_t* ga, int acc_a,
                              uint16_t* gb, int acc_b, void* stream) {
+  if ((ca & 7) == 0 && (cb & 7) == 0 && npix * ((ca + cb) / 8) < (int64_t)1 << 31) {
+    const int64_t nun = npix * ((ca + cb) / 8); int64_t grid = (nun + 511) / 512; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_cat_bwd8, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, ca, b, qrec_b, cb, (unsigned)npix, qrec_y, ga, acc_a, gb, acc_b);
+    return frost_check_launch("cat_bwd");
+  }
   int64_t ndw = npix * ((ca + cb) / 4); int64_t grid = (ndw + 1023) / 1024; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_cat_bwd, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, ca, b, qrec_b, cb, npix, qrec_y, ga, acc_a, gb, acc_b);
   return frost_check_launch("cat_bwd");
+}
+__global__ __launch_bounds__(256) void k_add_bwd8(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa,
+                                                  const int8_t* __restrict__ b, const float* qb, int64_t n8, const float* qy,
+                                                  uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ gb, int acc_b) {
+  QP A = load_qp(qa), B = load_qp(qb), Y = load_qp(qy);
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const uint2 va = ((const uint2*)a)[i], vb = ((const uint2*)b)[i];
+    const uint4 gv = *(const uint4*)(gy + i * 8);
+    float g[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+    const uint32_t wa[2] = {va.x, va.y}, wb[2] = {vb.x, vb.y};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = (float)((int)(int8_t)(wa[h] >> (8 * r)) + 128 - A.zp) * A.scale + (float)((int)(int8_t)(wb[h] >> (8 * r)) + 128 - B.zp) * B.scale;
+        bool inr; fq_index(v, Y.inv, Y.zp, 0, Y.hi, &inr);
+        if (!inr) g[4 * h + r] = 0.0f;
+      }
+    acc_store8(ga + i * 8, g, acc_a);
+    acc_store8(gb + i * 8, g, acc_b);
+  }
 }
 __global__ __launch_bounds__(256) void k_add_bwd(const uint16_t* __restrict__ gy, const int8_t* __restrict__ a, const float* qa,
                                                  const int8_t* __restrict__ b, const float* qb, int64_t n4, const float* qy,
@@ -244,6 +309,11 @@ __global__ __launch_bounds__(256) void k_add_bwd(const uint16_t* __restrict__ gy
 }
 extern "C" int frost_add_bwd(const uint16_t* gy, const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b,
                              int64_t n, const float* qrec_y, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream) {
+  if ((n & 7) == 0) {
+    const int64_t n8 = n / 8; int64_t grid = (n8 + 511) / 512; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_add_bwd8, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, b, qrec_b, n8, qrec_y, ga, acc_a, gb, acc_b);
+    return frost_check_launch("add_bwd");
+  }
   int64_t n4 = n / 4; int64_t grid = (n4 + 1023) / 1024; if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_add_bwd, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), gy, a, qrec_a, b, qrec_b, n4, qrec_y, ga, acc_a, gb, acc_b);
   return frost_check_launch("add_bwd");
