@@ -274,7 +274,8 @@ class FloatRunner:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, ptr(cbuf), l.cout, stream())
             call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
             call(self._fn["frost_float_ew"], l.desc_ptr, ptr(cbuf), npix_o, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
-            l.c = cbuf if record else None
+            if record:
+                l.c = cbuf
         elif l.kind == 1:
             if training:
                 call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, None, stream())
