@@ -267,3 +267,116 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
   hipLaunchKernelGGL(k_pw_wgrad, dim3(ntile * nsplit), dim3(256), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit, xmap);
   return frost_check_launch("pw_wgrad");
 }
+
+// ------------------------------------------------------------------------------------------------ data gradient of wide pointwise layers
+// dx[p][ci] (+)= s_w * sum_co dc[p][co] * wq[co][ci] as a plain bf16 GEMM with M = pixels, N = Cin, K = Cout (K = 312 .. 1728: dc rows too long
+// for k_pw's DMA-staged tile, whose chunked fallback is a chain of synchronised stages).  Workgroup = 256 pixels x up to 8 input-channel tiles;
+// wave w owns 64 pixels (4 MFMA column blocks) x all those tiles: 32 accumulators, every weight fragment feeds 4 MFMAs and every dc fragment 8.
+//   dc fragments come straight from global memory (a wave owns its pixel rows: nothing to share, 16 bytes per lane = 64-byte row pieces),
+//   requested one K step ahead; the weight fragments of a K stage (2 steps of 32) go through LDS once per workgroup, double-buffered.
+// wt_pack: [ci tile][K step of 32][lane][8] bf16 -- the A operand of mfma_f32_16x16x32_bf16 as frost_weight_prep lays it out.
+typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+#define DGW_NT 8        // input-channel tiles per workgroup
+#define DGW_KS 2        // K steps per LDS stage
+__global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
+                                                       int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate) {
+  __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t p0 = (int64_t)blockIdx.x * 256 + w * 64;
+  const int ct0 = blockIdx.y * per;                        // the tiles are dealt out evenly over gridDim.y (9 tiles -> 5 + 4, not 8 + 1)
+  int nct = CIT - ct0; if (nct > per) nct = per;
+  v4f acc[DGW_NT][4];
+#pragma unroll
+  for (int m = 0; m < DGW_NT; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+  // weight stage s: K steps [s*KS, s*KS+KS) of tiles ct0 .. ct0+nct-1 -> wl[buf][(ks * NT + m) * 1024 + lane * 16]; 256 threads x 4 x 16 bytes
+  const int nst = (KB + DGW_KS - 1) / DGW_KS;
+  uint4 wr[DGW_KS * DGW_NT / 4];
+  auto wfetch = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < DGW_KS * DGW_NT / 4; ++q) {
+      const int u = tid + 256 * q;                       // 16-byte unit: (ks, m, lane)
+      const int ln = u & 63, m = (u >> 6) % DGW_NT, ks = u / (64 * DGW_NT);
+      const int kb = st * DGW_KS + ks;
+      wr[q] = make_uint4(0, 0, 0, 0);
+      if (m < nct && kb < KB) wr[q] = *(const uint4*)(wt + ((((int64_t)(ct0 + m) * KB + kb) * 64 + ln) << 3));
+    }
+  };
+  auto wstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < DGW_KS * DGW_NT / 4; ++q) *(uint4*)(wl[buf] + (size_t)(tid + 256 * q) * 16) = wr[q];
+  };
+  // dc fragments of K step kb: lane (j, g) -> pixel p0 + 16 t + j, channels kb*32 + 8 g .. + 7
+  const int rowe = cout;
+  auto bfetch = [&](int kb, v4i* b) __attribute__((always_inline)) {
+    const int co = kb * 32 + 8 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t p = p0 + 16 * t + j;
+      b[t] = (v4i){0, 0, 0, 0};
+      if (p < npix && co < cout && kb < KB) b[t] = *(const v4i*)(dc + p * rowe + co);
+    }
+  };
+  v4i bcur[4], bnxt[4];
+  wfetch(0); wstore(0);
+  bfetch(0, bcur);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nst) wfetch(st + 1);
+#pragma unroll
+    for (int ks = 0; ks < DGW_KS; ++ks) {
+      const int kb = st * DGW_KS + ks;
+      bfetch(kb + 1, bnxt);                               // one K step ahead (zeros past the end)
+      if (kb < KB) {
+#pragma unroll
+        for (int m = 0; m < DGW_NT; ++m) {
+          if (m < nct) {
+            const v4i a = *(const v4i*)(wl[buf] + (size_t)((ks * DGW_NT + m) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, a), __builtin_bit_cast(v8bf16, bcur[t]), acc[m][t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bcur[t] = bnxt[t];
+    }
+    if (st + 1 < nst) wstore(buf ^ 1);
+    __syncthreads();
+  }
+  const float sw = qw ? qw[FROST_Q_SCALE] : 1.0f;
+#pragma unroll
+  for (int m = 0; m < DGW_NT; ++m) {
+    if (m >= nct) continue;
+    const int ci = (ct0 + m) * 16 + 4 * g;
+    if (ci >= cin) continue;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t p = p0 + 16 * t + j;
+      if (p >= npix) continue;
+      uint16_t* dst = dx + p * cin + ci;
+      float v[4] = {acc[m][t][0] * sw, acc[m][t][1] * sw, acc[m][t][2] * sw, acc[m][t][3] * sw};
+      if (accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
+      uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]);
+      *(uint2*)dst = o;
+    }
+  }
+}
+// 1 if the wide-layer data-gradient kernel takes this shape (FROST_DGRAD_WIDE = smallest Cout, 0 turns it off)
+extern "C" int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout) {
+  static const int minc = getenv("FROST_DGRAD_WIDE") ? atoi(getenv("FROST_DGRAD_WIDE")) : 1;      // smallest Cout it takes (measured: every non-fused layer gains); 0 = off
+  return minc > 0 && cout >= minc && (cout & 7) == 0 && (cin & 7) == 0 && npix >= 256;
+}
+extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
+                                   uint16_t* dx, int accumulate, void* stream) {
+  FROST_REQUIRE((cin & 7) == 0 && (cout & 7) == 0, "pw_dgrad_wide: channels must be multiples of 8");
+  const int cpad = round_up(cout, 16); const int KB = cpad / 32 + ((cpad % 32) ? 1 : 0);
+  const int CIT = round_up(cin, 16) / 16;
+  const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
+  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
+  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate);
+  return frost_check_launch("pw_dgrad_wide");
+}

@@ -551,8 +551,13 @@ class Engine:
                 self._side.wait_event(ev)
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
-                call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s,
-                     prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
+                if l.kind == "pw" and L.load_library().frost_pw_dgrad_wide_ok(x.npix, x.c, l.cout):
+                    # long dc rows (Cout > 128): a plain bf16 GEMM kernel of its own, dc fragments straight from memory, weight stages through LDS
+                    call("frost_pw_dgrad_wide", ptr(dc), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout, ptr(gx), acc, s,
+                         prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
+                else:
+                    call("frost_pw_conv_bwd", *args, 2, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), ptr(gx), acc, s,
+                         prof=("pw_dgrad", 2 * y.numel + 2 * x.numel))
             sw = s
             if self._side is not None and (_WG_STREAM & 1):      # dc (and x) stay referenced until the join
                 self._keep.append((dc, x.buf))

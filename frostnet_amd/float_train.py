@@ -405,6 +405,8 @@ class FloatRunner:
                 # resident weights, LDS-staged output) that also serves the fake-quant dgrad and the bf16 inference layers
                 if self.fp32:     # the same GEMM on the fp32 MFMA (mode 4 of the float pointwise kernel)
                     call("frost_float_pw_f32", None, ptr(dc), ptr(l.pack_t), npix_o, l.cout, a.c, 0, 4, None, 0, ptr(dx.buf), a.c, stream())
+                elif l.kind == 0 and L.load_library().frost_pw_dgrad_wide_ok(npix_o, a.c, l.cout):
+                    call("frost_pw_dgrad_wide", ptr(dc), ptr(l.pack_t), None, npix_o, a.c, l.cout, ptr(dx.buf), 0, stream())      # the stand-alone bf16 GEMM (frost_wgrad.hip)
                 else:
                     call("frost_infer_pw", ptr(dc), ptr(l.pack_t), None, npix_o, l.cout, a.c, 0, ptr(dx.buf), stream())
             if l.kind == 2:

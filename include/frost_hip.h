@@ -168,6 +168,12 @@ int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int
  * frost_pw_bwd_fused_ok() returns 1 when the shape is supported (npix a multiple of 128, LDS budget), else 0 (not an error code).
  * dx may be NULL (no data gradient wanted, e.g. the stem); dwq (fp32 [cout][cin]) is accumulated with atomics and must be pre-zeroed. */
 int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout);
+/* data gradient of a pointwise layer with long dc rows (Cout > 128) as a stand-alone bf16 GEMM: dx[p][ci] (+)= s_w * sum_co dc[p][co] * wq[co][ci]
+ * (replaces: the grad_input of F.conv2d inside ConvBn2d / ConvBnReLU2d, frostnet.py:124-145 through torch.ao's _forward_approximate; same result as
+ * pass 2 of frost_pw_conv_bwd).  wt_pack: the transposed bf16 pack of frost_weight_prep.  frost_pw_dgrad_wide_ok() = 1 if the shape qualifies. */
+int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout);
+int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
+                        uint16_t* dx, int accumulate, void* stream);
 int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
                             const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout, float* coef,
                             const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc_scratch, uint16_t* dx,
