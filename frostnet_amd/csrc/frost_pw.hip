@@ -874,6 +874,7 @@ static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   f.ok = 1;
   return f;
 }
+int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* bias, int64_t npix, int k, int n, int relu, uint16_t* y, hipStream_t s);      // frost_wgrad.hip
 extern "C" int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout) { return fuse_plan(npix, cin, cout, true).ok; }
 
 extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
@@ -966,6 +967,8 @@ extern "C" int frost_pw_conv_bwd(const int8_t* x, const float* qrec_x, const int
 extern "C" int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
                               uint16_t* y, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "infer_pw: channels must be multiples of 8");
+  static const int wide_min = getenv("FROST_INFER_WIDE") ? atoi(getenv("FROST_INFER_WIDE")) : 129;     // rows of more than 256 bytes: the stand-alone GEMM (0 = off)
+  if (wide_min > 0 && cin >= wide_min && npix >= 256) return frost_gemm_bf16_rows(x, pack, biasf, npix, cin, cout, relu, y, as_stream(stream));
   PwP d = {};
   d.T = (const uint8_t*)x; d.cout = cout; d.cpad = round_up(cout, 16); d.wpack = (const uint8_t*)pack;
   d.qw = nullptr; d.dx = y; d.accumulate = 0; d.bias = biasf; d.act_relu = relu;

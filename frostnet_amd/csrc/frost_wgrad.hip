@@ -277,9 +277,12 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
 // wt_pack: [ci tile][K step of 32][lane][8] bf16 -- the A operand of mfma_f32_16x16x32_bf16 as frost_weight_prep lays it out.
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 #define DGW_NT 8        // input-channel tiles per workgroup
+#ifndef DGW_KS
 #define DGW_KS 2        // K steps per LDS stage
+#endif
 __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
-                                                       int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate) {
+                                                       int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate,
+                                                       const float* __restrict__ bias, int relu) {
   __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,6 +362,8 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
       if (p >= npix) continue;
       uint16_t* dst = dx + p * cin + ci;
       float v[4] = {acc[m][t][0] * sw, acc[m][t][1] * sw, acc[m][t][2] * sw, acc[m][t][3] * sw};
+      if (bias) { const float4 b4 = *(const float4*)(bias + ci); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }      // the bf16 inference layers: + b'[co], ReLU
+      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       if (accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
       uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]);
       *(uint2*)dst = o;
@@ -377,6 +382,16 @@ extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, 
   const int CIT = round_up(cin, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate);
+  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
+                     (const float*)nullptr, 0);
   return frost_check_launch("pw_dgrad_wide");
+}
+// the same GEMM as a bf16 inference layer: y[p][n] = act(sum_k x[p][k] * W'[n][k] + b'[n]) (frost_infer_pw routes its long-row layers here)
+int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* bias, int64_t npix, int k, int n, int relu, uint16_t* y, hipStream_t s) {
+  const int kp = round_up(k, 16); const int KB = kp / 32 + ((kp % 32) ? 1 : 0);
+  const int CIT = round_up(n, 16) / 16;
+  const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
+  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
+  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu);
+  return frost_check_launch("gemm_bf16_rows");
 }
