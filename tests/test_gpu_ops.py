@@ -265,3 +265,31 @@ def test_gradboost_kernel(eng_mod, golden, name):
             v = st[key]
             v = v.cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             np.testing.assert_allclose(v, g[k], rtol=1e-4, atol=1e-12, err_msg=key)
+
+
+@pytest.mark.parametrize("npix,cin,cout,acc", [(25088, 288, 1728, 0), (1000, 104, 312, 1), (513, 56, 336, 0), (4096, 320, 1280, 1), (300, 24, 72, 0), (2048, 1440, 192, 0)])
+def test_dgrad_wide_kernel_vs_torch(eng_mod, npix, cin, cout, acc):
+    """frost_pw_dgrad_wide (k_dgrad_wide, frost_wgrad.hip) against a torch fp32 GEMM of the same bf16 operands: dx = s_w * dc . Wq (+ dx), rounded to
+    bf16 once.  Shapes: the 7x7 expand layer at full size, ragged pixel counts (not multiples of 256 / 16), Cout not a multiple of 32, Cin not a
+    multiple of 16, several input-channel chunks, accumulate on and off.  Tolerance: one bf16 ulp (the fp32 summation order differs)."""
+    from frostnet_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(npix + cin)
+    dc = (torch.randn(npix, cout, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    wq = torch.randint(-128, 128, (cout, cin), device="cuda", generator=g).float()          # integers: exact in bf16
+    sw = 0.0123
+    qw = torch.zeros(L.Q_STRIDE, device="cuda"); qw[L.Q_SCALE] = sw
+    cit, kb = (cin + 15) // 16, (cout + 31) // 32
+    wp = torch.zeros(cit * 16, kb * 32, device="cuda"); wp[:cin, :cout] = wq.t()
+    # wt_pack[cit][kb][lane][8] = W[co = kb*32 + 8*(lane>>4) + e][ci = cit*16 + (lane&15)]
+    pack = wp.view(cit, 16, kb, 4, 8).permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16)       # [cit][kb][g][i][e] -> lane = g*16 + i
+    prev = (torch.randn(npix, cin, device="cuda", generator=g)).to(torch.bfloat16)
+    dx = prev.clone() if acc else torch.full((npix, cin), float("nan"), device="cuda").to(torch.bfloat16)
+    assert L.load_library().frost_pw_dgrad_wide_ok(npix, cin, cout) == 1
+    L.call("frost_pw_dgrad_wide", L.ptr(dc.view(torch.int16)), L.ptr(pack.view(torch.int16)), L.ptr(qw), npix, cin, cout, L.ptr(dx.view(torch.int16)), acc, L.stream())
+    torch.cuda.synchronize()
+    ref = (dc.float() @ wq) * sw + (prev.float() if acc else 0.0)
+    got = dx.float()
+    assert bool(torch.isfinite(got).all())
+    err = (got - ref).abs() / (ref.abs() + 1e-3)
+    assert float(err.max()) <= 2.0 ** -7, float(err.max())
+    assert relerr(got, ref) <= 3e-3
