@@ -280,9 +280,10 @@ typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 #ifndef DGW_KS
 #define DGW_KS 2        // K steps per LDS stage
 #endif
+template <bool I8>      // I8: the same loop on int8 operands (64 k per step), epilogue = the integer conv output c[p][n] = acc - zpx * wsum[n] as int32
 __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
                                                        int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate,
-                                                       const float* __restrict__ bias, int relu) {
+                                                       const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint) {
   __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,14 +313,14 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
     for (int q = 0; q < DGW_KS * DGW_NT / 4; ++q) *(uint4*)(wl[buf] + (size_t)(tid + 256 * q) * 16) = wr[q];
   };
   // dc fragments of K step kb: lane (j, g) -> pixel p0 + 16 t + j, channels kb*32 + 8 g .. + 7
-  const int rowe = cout;
+  const int rowb = I8 ? cout : cout * 2;                   // bytes per operand row (K = cout elements); a K step is 64 bytes of it either way
   auto bfetch = [&](int kb, v4i* b) __attribute__((always_inline)) {
-    const int co = kb * 32 + 8 * g;
+    const int kbyte = kb * 64 + 16 * g;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int64_t p = p0 + 16 * t + j;
       b[t] = (v4i){0, 0, 0, 0};
-      if (p < npix && co < cout && kb < KB) b[t] = *(const v4i*)(dc + p * rowe + co);
+      if (p < npix && kbyte < rowb && kb < KB) b[t] = *(const v4i*)((const uint8_t*)dc + p * rowb + kbyte);
     }
   };
   v4i bcur[4], bnxt[4];
@@ -339,8 +340,10 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
           if (m < nct) {
             const v4i a = *(const v4i*)(wl[buf] + (size_t)((ks * DGW_NT + m) * 64 + lane) * 16);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, a), __builtin_bit_cast(v8bf16, bcur[t]), acc[m][t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {       // I8: the same registers hold the int32 accumulators (bit casts at the MFMA)
+              if constexpr (I8) acc[m][t] = __builtin_bit_cast(v4f, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bcur[t], __builtin_bit_cast(v4i, acc[m][t]), 0, 0, 0));
+              else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, a), __builtin_bit_cast(v8bf16, bcur[t]), acc[m][t], 0, 0, 0);
+            }
           }
         }
       }
@@ -349,6 +352,24 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
     }
     if (st + 1 < nst) wstore(buf ^ 1);
     __syncthreads();
+  }
+  if constexpr (I8) {
+    const int zpx = __float_as_int(qx[FROST_Q_ZP]) - 128;
+#pragma unroll
+    for (int m = 0; m < DGW_NT; ++m) {
+      if (m >= nct) continue;
+      const int ci = (ct0 + m) * 16 + 4 * g;
+      if (ci >= cin) continue;
+      const v4i ws = *(const v4i*)(wsum + ci);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t p = p0 + 16 * t + j;
+        if (p >= npix) continue;
+        const v4i a = __builtin_bit_cast(v4i, acc[m][t]);
+        *(v4i*)(cint + p * cin + ci) = (v4i){a[0] - zpx * ws[0], a[1] - zpx * ws[1], a[2] - zpx * ws[2], a[3] - zpx * ws[3]};
+      }
+    }
+    return;
   }
   const float sw = qw ? qw[FROST_Q_SCALE] : 1.0f;
 #pragma unroll
@@ -382,8 +403,8 @@ extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, 
   const int CIT = round_up(cin, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
-                     (const float*)nullptr, 0);
+  hipLaunchKernelGGL(k_dgrad_wide<false>, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
+                     (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr, (int32_t*)nullptr);
   return frost_check_launch("pw_dgrad_wide");
 }
 // the same GEMM as a bf16 inference layer: y[p][n] = act(sum_k x[p][k] * W'[n][k] + b'[n]) (frost_infer_pw routes its long-row layers here)
@@ -392,6 +413,117 @@ int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* b
   const int CIT = round_up(n, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu);
+  hipLaunchKernelGGL(k_dgrad_wide<false>, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu, (const int32_t*)nullptr,
+                     (const float*)nullptr, (int32_t*)nullptr);
   return frost_check_launch("gemm_bf16_rows");
+}
+
+// ---- the integer conv output of a pointwise layer, kept for element-wise passes: c[p][co] = sum_k xq[p][k] * wq[co][k] - (zp_x - 128) * wsum[co]
+// (x holds q - 128; wq_pack / wsum as frost_weight_prep lays them out).  The GEMM above on int8 operands: M = pixels, N = Cout, K = Cin.
+extern "C" int frost_pw_conv_int(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                                 int32_t* conv_out, void* stream) {
+  FROST_REQUIRE((cin & 7) == 0 && (cout & 3) == 0, "pw_conv_int: cin must be a multiple of 8, cout of 4");
+  const int KS = round_up(cin, 64) / 64;
+  const int CT = round_up(cout, 16) / 16;
+  const int nch = (CT + DGW_NT - 1) / DGW_NT, per = (CT + nch - 1) / nch;
+  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
+  // kernel arguments in its own (data-gradient) naming: K = "cout" = cin here, N = "cin" = cout here
+  hipLaunchKernelGGL(k_dgrad_wide<true>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
+                     (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out);
+  return frost_check_launch("pw_conv_int");
+}
+
+// ---- element-wise backward passes over a kept integer conv output (frost_pw_conv_int): the epilogues of k_pw's reduce / dc passes, same formulas
+//   t = fma(A, c, B) / s_y;  gy = g if t_lo < t <= t_hi else 0 (the STE window of the activation fake-quantise, ReLU included)
+//   mode 0: S1 += gy, S2 += gy * xhat (xhat = fma(c, R, -M*R)) -> coefficient rows S1 / S2        mode 1: dc = fma(gy, K1, fma(c, E, F)) -> bf16
+// thread = 4 channels (16 bytes of c) x strided pixels: coefficients and partial sums stay in registers.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint, int64_t npix, int cout, int cpad, float* __restrict__ coef, const float* qy,
+                                               int relu, float inv_count, const uint16_t* __restrict__ gout, uint16_t* __restrict__ dc, int sr) {
+  extern __shared__ float part[];                   // mode 0: [2][cout]
+  const int tid = threadIdx.x;
+  if (MODE == 0) { for (int i = tid; i < 2 * cout; i += 256) part[i] = 0.0f; __syncthreads(); }
+  const int c4n = cout >> 2;
+  const int64_t PP = ((int64_t)gridDim.x * 256) / c4n;
+  const int64_t tt = (int64_t)blockIdx.x * 256 + tid;
+  const int c4 = (int)(tt % c4n); const int64_t slot = tt / c4n;
+  const int ch = c4 * 4;
+  const float y_inv = 1.0f / qy[FROST_Q_SCALE];
+  const int zpy = __float_as_int(qy[FROST_Q_ZP]), qhi = q_hi(qy);
+  const float hi0 = (float)qhi + 0.5f - (float)zpy;                             // rint(hi0) ties to the even neighbour (as in k_pw)
+  const float t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+  float t_lo = 0.0f;
+  if (!relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  float A[4], B[4], R[4], MR[4], K1[4], E[4], F[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    A[r] = coef[FROST_COEF_A * cpad + ch + r]; B[r] = coef[FROST_COEF_B * cpad + ch + r];
+    const float Mv = coef[FROST_COEF_M * cpad + ch + r]; R[r] = coef[FROST_COEF_R * cpad + ch + r]; MR[r] = -Mv * R[r];
+    K1[r] = 0.f; E[r] = 0.f; F[r] = 0.f;
+    if (MODE == 1) {
+      K1[r] = coef[FROST_COEF_K1 * cpad + ch + r];
+      const float s1 = coef[FROST_COEF_S1 * cpad + ch + r], s2 = coef[FROST_COEF_S2 * cpad + ch + r];
+      E[r] = -K1[r] * (s2 * inv_count) * R[r]; F[r] = -K1[r] * (s1 * inv_count) - E[r] * Mv;
+    }
+  }
+  float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  if (slot < PP) {
+    for (int64_t p0 = slot; p0 < npix; p0 += 2 * PP) {          // two pixels per trip: their loads are in flight together
+      v4i cv[2]; uint2 gv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t p = p0 + u * PP;
+        cv[u] = (v4i){0, 0, 0, 0}; gv[u] = make_uint2(0, 0);
+        if (p < npix) { cv[u] = *(const v4i*)(cint + p * cout + ch); gv[u] = *(const uint2*)(gout + p * cout + ch); }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t p = p0 + u * PP;
+        if (p >= npix) continue;
+        const float gq[4] = {__uint_as_float(gv[u].x << 16), __uint_as_float(gv[u].x & 0xffff0000u), __uint_as_float(gv[u].y << 16), __uint_as_float(gv[u].y & 0xffff0000u)};
+        float dcv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float af = (float)cv[u][r];
+          const float tq = fmaf(A[r], af, B[r]) * y_inv;
+          const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+          if (MODE == 0) { r1[r] += gy; r2[r] = fmaf(gy, fmaf(af, R[r], MR[r]), r2[r]); }
+          else dcv[r] = fmaf(gy, K1[r], fmaf(af, E[r], F[r]));
+        }
+        if (MODE == 1) {
+          uint2 o;
+          if (sr) { o.x = sr_pk_bf16(dcv[0], dcv[1], rng); o.y = sr_pk_bf16(dcv[2], dcv[3], rng); }
+          else { o.x = cvt_pk_bf16(dcv[0], dcv[1]); o.y = cvt_pk_bf16(dcv[2], dcv[3]); }
+          *(uint2*)(dc + p * cout + ch) = o;
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    if (slot < PP) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { atomicAdd(&part[ch + r], r1[r]); atomicAdd(&part[cout + ch + r], r2[r]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < cout; i += 256) {
+      atomicAdd(coef + FROST_COEF_S1 * cpad + i, part[i]);
+      atomicAdd(coef + FROST_COEF_S2 * cpad + i, part[cout + i]);
+    }
+  }
+}
+extern "C" int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gout,
+                           uint16_t* dc, void* stream) {
+  FROST_REQUIRE((cout & 3) == 0, "pw_ew: cout must be a multiple of 4");
+  FROST_REQUIRE(mode == 0 || (mode == 1 && dc), "pw_ew: mode 0 (reduce) or 1 (dc, needs dc)");
+  const int cpad = round_up(cout, 16); const int c4n = cout >> 2;
+  const int64_t tot = npix * c4n;
+  static int rcap = -1;
+  if (rcap < 0) { const char* e = getenv("FROST_PWEW_CAP"); rcap = e ? atoi(e) : 256; if (rcap < 64) rcap = 64; }      // every workgroup ends with 2*cout float atomics into the coefficient rows: 256 measured best (512: +5 us, 2048: +40 us per launch)
+  int64_t grid = (tot + 255) / 256; const int64_t cap = mode == 0 ? rcap : 2048; if (grid > cap) grid = cap;
+  const int64_t gmin = (c4n + 255) / 256; if (grid < gmin) grid = gmin;
+  const float inv_count = 1.0f / (float)npix;
+  if (mode == 0) hipLaunchKernelGGL(k_pw_ew<0>, dim3((unsigned)grid), dim3(256), (size_t)2 * cout * 4, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, 0);
+  else hipLaunchKernelGGL(k_pw_ew<1>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, frost_sr_enabled());
+  return frost_check_launch("pw_ew");
 }

@@ -25,6 +25,7 @@ def round_up(a, b):
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
 _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
+_PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -529,9 +530,19 @@ class Engine:
             if l.kind == "stem":
                 l.dwq, dwq_final = l.dwq_col, l.dwq
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.wt_pack), ptr(l.qw), x.npix, x.c, l.cout)
-            # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
-            call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
-                 prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+            # wide-K layers (Cin > 256: x rows too long for k_pw's DMA tile): ONE recomputation of the integer conv output on the stand-alone GEMM kernel,
+            # then the reduce and dc passes element-wise over it (N << K here: the int32 output is smaller than x) instead of two chunked k_pw passes
+            cint = None
+            if _PW_KEEP and not fused and l.kind == "pw" and x.c > 256:
+                cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+                call("frost_pw_conv_int", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(cint), s,
+                     prof=("pw_bwd_reduce", x.numel + 4 * y.numel))
+                call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 0, ptr(gout), None, s,
+                     prof=("pw_bwd_reduce", 6 * y.numel))
+            else:
+                # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
+                call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
+                     prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
             if fused:
                 # dc pass + data gradient + weight gradient in one kernel: the dc tile never leaves LDS (layers with Cout*Cin <= ~19 k)
                 gx, acc = self._grad_slot(x) if x.needs_grad else (None, 0)
@@ -543,8 +554,12 @@ class Engine:
                 self._after_conv_backward(l, s)
                 y.grad = None
                 return
-            call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
-                 prof=("pw_bwd_dc", x.numel + 4 * y.numel))
+            if cint is not None:
+                call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 1, ptr(gout), ptr(dc), s,
+                     prof=("pw_bwd_dc", 8 * y.numel))
+            else:
+                call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
+                     prof=("pw_bwd_dc", x.numel + 4 * y.numel))
             if self._side is not None and (_WG_STREAM & 1):      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
                 ev = torch.cuda.Event()
                 ev.record()

@@ -171,6 +171,14 @@ int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout);
 /* data gradient of a pointwise layer with long dc rows (Cout > 128) as a stand-alone bf16 GEMM: dx[p][ci] (+)= s_w * sum_co dc[p][co] * wq[co][ci]
  * (replaces: the grad_input of F.conv2d inside ConvBn2d / ConvBnReLU2d, frostnet.py:124-145 through torch.ao's _forward_approximate; same result as
  * pass 2 of frost_pw_conv_bwd).  wt_pack: the transposed bf16 pack of frost_weight_prep.  frost_pw_dgrad_wide_ok() = 1 if the shape qualifies. */
+/* backward of a wide-K pointwise layer (Cin > 256) with ONE recomputation instead of two: frost_pw_conv_int stores the integer conv output
+ * c[p][co] = sum_k xq*wq - (zp_x - 128)*wsum[co] ([npix][cout] int32), frost_pw_ew runs the reduce pass (mode 0: S1 / S2 into the coefficient rows) and
+ * the dc pass (mode 1) element-wise over it -- the results of passes 0 and 1 of frost_pw_conv_bwd (replaces: autograd's BatchNorm + fake-quantise
+ * backward of ConvBn(ReLU)2d, frostnet.py:124-145 through torch.ao's _forward_approximate). */
+int frost_pw_conv_int(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                      int32_t* conv_out, void* stream);
+int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gout,
+                uint16_t* dc, void* stream);
 int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout);
 int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
                         uint16_t* dx, int accumulate, void* stream);
