@@ -87,6 +87,7 @@ _PROTOS = {
     "frost_pw_bwd_fused_ok": [L, I, I],
     "frost_pw_conv_int": [P, P, P, P, L, I, I, P, P],
     "frost_pw_ew": [P, L, I, P, P, I, I, P, P, P],
+    "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_pw_dgrad_wide_ok": [L, I, I],
     "frost_pw_dgrad_wide": [P, P, P, L, I, I, P, I, P],
     "frost_pw_conv_bwd_fused": [P, P, P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, P],

@@ -280,10 +280,14 @@ typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 #ifndef DGW_KS
 #define DGW_KS 2        // K steps per LDS stage
 #endif
-template <bool I8>      // I8: the same loop on int8 operands (64 k per step), epilogue = the integer conv output c[p][n] = acc - zpx * wsum[n] as int32
+// GM: 0 = bf16 operands (data gradient / inference layer); 1 = int8 operands (64 k per step), epilogue = the integer conv output c[p][n] = acc - zpx * wsum[n]
+// as int32; 2 = the same plus the forward statistics of c (sum, sum of squares, min, max per channel) and the conv finalize in the last workgroup
+template <int GM>
 __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
                                                        int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate,
-                                                       const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint) {
+                                                       const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint,
+                                                       uint8_t* __restrict__ stats, FrostFinDesc fin) {
+  constexpr bool I8 = GM != 0;
   __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -366,7 +370,60 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
         const int64_t p = p0 + 16 * t + j;
         if (p >= npix) continue;
         const v4i a = __builtin_bit_cast(v4i, acc[m][t]);
-        *(v4i*)(cint + p * cin + ci) = (v4i){a[0] - zpx * ws[0], a[1] - zpx * ws[1], a[2] - zpx * ws[2], a[3] - zpx * ws[3]};
+        const v4i c = (v4i){a[0] - zpx * ws[0], a[1] - zpx * ws[1], a[2] - zpx * ws[2], a[3] - zpx * ws[3]};
+        *(v4i*)(cint + p * cin + ci) = c;
+        acc[m][t] = __builtin_bit_cast(v4f, c);          // the statistics below read the finished values
+      }
+    }
+    if constexpr (GM == 2) {
+      // statistics of c over this workgroup's pixels: exact integer sums (c*c in 64 bits), folded over the 16 pixel lanes of a row group, then LDS
+      // (the four waves), then one set of global atomics per workgroup -- the table format of k_pw / conv_finalize_dev
+      __syncthreads();                                                     // the weight stages are done with: LDS is reused for the partial table
+      long long* l_s1 = (long long*)wl; unsigned long long* l_s2 = (unsigned long long*)(l_s1 + DGW_NT * 16);
+      int* l_mn = (int*)(l_s2 + DGW_NT * 16); int* l_mx = l_mn + DGW_NT * 16;
+      for (int i = tid; i < DGW_NT * 16; i += 256) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < DGW_NT; ++m) {
+        if (m >= nct) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          long long a1 = 0, a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (p0 + 16 * t + j < npix) {
+              const int v = __builtin_bit_cast(v4i, acc[m][t])[r];
+              a1 += v; a2 += (long long)v * v; mn = min(mn, v); mx = max(mx, v);
+            }
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {                               // the 16 lanes j of this g
+            a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); mn = min(mn, __shfl_xor(mn, o)); mx = max(mx, __shfl_xor(mx, o));
+          }
+          const int cl = m * 16 + 4 * g + r;
+          if (j == 0 && (ct0 + m) * 16 + 4 * g + r < cin && mn <= mx) {
+            atomicAdd((unsigned long long*)&l_s1[cl], (unsigned long long)a1); atomicAdd(&l_s2[cl], (unsigned long long)a2);
+            atomicMin(&l_mn[cl], mn); atomicMax(&l_mx[cl], mx);
+          }
+        }
+      }
+      __syncthreads();
+      const int cpadn = CIT * 16;
+      long long* g_s1 = (long long*)stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + cpadn);
+      int* g_mn = (int*)(g_s2 + cpadn); int* g_mx = g_mn + cpadn;
+      for (int i = tid; i < nct * 16; i += 256) {
+        const int c = ct0 * 16 + i;
+        if (c < cin && l_mn[i] <= l_mx[i]) {
+          atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[i]); atomicAdd(&g_s2[c], l_s2[i]);
+          atomicMin(&g_mn[c], l_mn[i]); atomicMax(&g_mx[c], l_mx[i]);
+        }
+      }
+      __shared__ int sflag;
+      if (last_block_done(fin.counter, gridDim.x * gridDim.y, &sflag)) {
+        float* sh = (float*)wl;
+        __syncthreads();
+        conv_finalize_dev(stats, npix, cin, cpadn, qx, fin.qrec_w, fin.wscale, fin.gamma, fin.beta, fin.rmean, fin.rvar, fin.nbt, fin.training, fin.relu, fin.observe, 1,
+                          fin.coef, fin.qrec_y, tid, 256, sh);
       }
     }
     return;
@@ -403,8 +460,8 @@ extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, 
   const int CIT = round_up(cin, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide<false>, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
-                     (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_dgrad_wide<0>, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
+                     (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("pw_dgrad_wide");
 }
 // the same GEMM as a bf16 inference layer: y[p][n] = act(sum_k x[p][k] * W'[n][k] + b'[n]) (frost_infer_pw routes its long-row layers here)
@@ -413,8 +470,8 @@ int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* b
   const int CIT = round_up(n, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide<false>, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu, (const int32_t*)nullptr,
-                     (const float*)nullptr, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_dgrad_wide<0>, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu, (const int32_t*)nullptr,
+                     (const float*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("gemm_bf16_rows");
 }
 
@@ -428,18 +485,33 @@ extern "C" int frost_pw_conv_int(const int8_t* x, const float* qrec_x, const int
   const int nch = (CT + DGW_NT - 1) / DGW_NT, per = (CT + nch - 1) / nch;
   dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
   // kernel arguments in its own (data-gradient) naming: K = "cout" = cin here, N = "cin" = cout here
-  hipLaunchKernelGGL(k_dgrad_wide<true>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
-                     (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out);
+  hipLaunchKernelGGL(k_dgrad_wide<1>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
+                     (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("pw_conv_int");
+}
+// the forward statistics pass of such a layer on the same kernel: stores the integer conv output, accumulates the statistics table and runs the conv
+// finalize in its last workgroup (what frost_pw_conv_fwd_fin does with k_pw); frost_pw_ew mode 2 then emits y from conv_out
+extern "C" int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                                      void* stats, const FrostFinDesc* fin, int32_t* conv_out, void* stream) {
+  FROST_REQUIRE((cin & 7) == 0 && (cout & 3) == 0, "pw_conv_fwd_keep: cin must be a multiple of 8, cout of 4");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y && conv_out && stats, "pw_conv_fwd_keep: incomplete arguments");
+  const int KS = round_up(cin, 64) / 64;
+  const int CT = round_up(cout, 16) / 16;
+  const int nch = (CT + DGW_NT - 1) / DGW_NT, per = (CT + nch - 1) / nch;
+  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
+  hipLaunchKernelGGL(k_dgrad_wide<2>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
+                     (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out, (uint8_t*)stats, *fin);
+  return frost_check_launch("pw_conv_fwd_keep");
 }
 
 // ---- element-wise backward passes over a kept integer conv output (frost_pw_conv_int): the epilogues of k_pw's reduce / dc passes, same formulas
 //   t = fma(A, c, B) / s_y;  gy = g if t_lo < t <= t_hi else 0 (the STE window of the activation fake-quantise, ReLU included)
 //   mode 0: S1 += gy, S2 += gy * xhat (xhat = fma(c, R, -M*R)) -> coefficient rows S1 / S2        mode 1: dc = fma(gy, K1, fma(c, E, F)) -> bf16
+//   mode 2 (forward): y = clamp(rint(fma(A, c, B) / s_y) + zp_y, 0, qmax) -> int8 (q - 128), the emit epilogue of k_pw
 // thread = 4 channels (16 bytes of c) x strided pixels: coefficients and partial sums stay in registers.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint, int64_t npix, int cout, int cpad, float* __restrict__ coef, const float* qy,
-                                               int relu, float inv_count, const uint16_t* __restrict__ gout, uint16_t* __restrict__ dc, int sr) {
+                                               int relu, float inv_count, const uint16_t* __restrict__ gout, uint16_t* __restrict__ dc, int sr, int8_t* __restrict__ yq) {
   extern __shared__ float part[];                   // mode 0: [2][cout]
   const int tid = threadIdx.x;
   if (MODE == 0) { for (int i = tid; i < 2 * cout; i += 256) part[i] = 0.0f; __syncthreads(); }
@@ -468,6 +540,31 @@ __global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint,
   }
   float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
   uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  if constexpr (MODE == 2) {
+    const float y_zpf = (float)zpy, qcap = (float)qhi; const bool lowq = qcap < 255.0f;
+    if (slot < PP) {
+      for (int64_t p0 = slot; p0 < npix; p0 += 4 * PP) {
+        v4i cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int64_t p = p0 + u * PP; cv[u] = (v4i){0, 0, 0, 0}; if (p < npix) cv[u] = *(const v4i*)(cint + p * cout + ch); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t p = p0 + u * PP;
+          if (p >= npix) continue;
+          uint32_t packed = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yv = fmaf(A[r], (float)cv[u][r], B[r]);
+            float qv = rintf(yv * y_inv) + y_zpf;
+            if (lowq) qv = fminf(qv, qcap);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);       // saturates at 0 (ReLU layers have zp == 0) and 255
+          }
+          *(uint32_t*)(yq + p * cout + ch) = packed ^ 0x80808080u;
+        }
+      }
+    }
+    return;
+  }
   if (slot < PP) {
     for (int64_t p0 = slot; p0 < npix; p0 += 2 * PP) {          // two pixels per trip: their loads are in flight together
       v4i cv[2]; uint2 gv[2];
@@ -513,9 +610,10 @@ __global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint,
   }
 }
 extern "C" int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gout,
-                           uint16_t* dc, void* stream) {
+                           void* out, void* stream) {
+  uint16_t* dc = (uint16_t*)out;
   FROST_REQUIRE((cout & 3) == 0, "pw_ew: cout must be a multiple of 4");
-  FROST_REQUIRE(mode == 0 || (mode == 1 && dc), "pw_ew: mode 0 (reduce) or 1 (dc, needs dc)");
+  FROST_REQUIRE(mode == 0 || ((mode == 1 || mode == 2) && out), "pw_ew: mode 0 (reduce), 1 (dc -> out) or 2 (emit -> out)");
   const int cpad = round_up(cout, 16); const int c4n = cout >> 2;
   const int64_t tot = npix * c4n;
   static int rcap = -1;
@@ -523,7 +621,8 @@ extern "C" int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, floa
   int64_t grid = (tot + 255) / 256; const int64_t cap = mode == 0 ? rcap : 2048; if (grid > cap) grid = cap;
   const int64_t gmin = (c4n + 255) / 256; if (grid < gmin) grid = gmin;
   const float inv_count = 1.0f / (float)npix;
-  if (mode == 0) hipLaunchKernelGGL(k_pw_ew<0>, dim3((unsigned)grid), dim3(256), (size_t)2 * cout * 4, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, 0);
-  else hipLaunchKernelGGL(k_pw_ew<1>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, frost_sr_enabled());
+  if (mode == 0) hipLaunchKernelGGL(k_pw_ew<0>, dim3((unsigned)grid), dim3(256), (size_t)2 * cout * 4, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, 0, (int8_t*)nullptr);
+  else if (mode == 1) hipLaunchKernelGGL(k_pw_ew<1>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, frost_sr_enabled(), (int8_t*)nullptr);
+  else hipLaunchKernelGGL(k_pw_ew<2>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, (uint16_t*)nullptr, 0, (int8_t*)out);
   return frost_check_launch("pw_ew");
 }

@@ -36,12 +36,13 @@ _DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
         self.grad = None
         self.needs_grad = True
+        self.cint = None          # wide-K pointwise layers: the integer conv output this activation was emitted from, kept for the backward
 
     @property
     def npix(self):
@@ -277,6 +278,19 @@ class Engine:
                                  l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0,
                                  l.wscale.data_ptr())
             nb = x.numel + l.wq_pack.numel()
+            if _PW_KEEP and l.kind == "pw" and x.c > 256:
+                # wide-K layer (x rows too long for k_pw's DMA tile, N << K): statistics + finalize on the stand-alone int8 GEMM kernel, which also stores the
+                # integer conv output (smaller than x); y is emitted element-wise from it and the backward's reduce / dc need no recomputation
+                cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+                call("frost_pw_conv_fwd_keep", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(cint),
+                     stream(), prof=("pw_fwd_stats", nb + 4 * y.numel))
+                call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 2, None, ptr(y.buf), stream(),
+                     prof=("pw_fwd_emit", 5 * y.numel))
+                if getattr(self, "trace", None) is not None:
+                    self.trace.append((l.name, y))
+                self.tape.append(("conv", l, x, y))
+                y.cint = cint if training else None
+                return y
             if l.kind in ("pw", "stem"):
                 call("frost_pw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin),
                      stream(), prof=(f"{l.kind}_fwd_stats", nb))
@@ -534,9 +548,12 @@ class Engine:
             # then the reduce and dc passes element-wise over it (N << K here: the int32 output is smaller than x) instead of two chunked k_pw passes
             cint = None
             if _PW_KEEP and not fused and l.kind == "pw" and x.c > 256:
-                cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
-                call("frost_pw_conv_int", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(cint), s,
-                     prof=("pw_bwd_reduce", x.numel + 4 * y.numel))
+                cint = getattr(y, "cint", None)          # kept by the training forward; otherwise (forward without statistics) one recomputation here
+                if cint is None:
+                    cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+                    call("frost_pw_conv_int", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(cint), s,
+                         prof=("pw_bwd_reduce", x.numel + 4 * y.numel))
+                y.cint = None
                 call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 0, ptr(gout), None, s,
                      prof=("pw_bwd_reduce", 6 * y.numel))
             else:

@@ -178,7 +178,7 @@ int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout);
 int frost_pw_conv_int(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
                       int32_t* conv_out, void* stream);
 int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gout,
-                uint16_t* dc, void* stream);
+                void* out, void* stream);          /* out: mode 1 dc (bf16), mode 2 y (int8, q - 128) */
 int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout);
 int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
                         uint16_t* dx, int accumulate, void* stream);
@@ -343,6 +343,10 @@ int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
                           void* stats, const FrostFinDesc* fin, void* stream);
 int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
                           int stride, void* stats, const FrostFinDesc* fin, void* stream);
+/* forward of a wide-K pointwise layer (see frost_pw_conv_int / frost_pw_ew) keeping the integer conv output: statistics pass + folded finalize (the job of frost_pw_conv_fwd_fin) on the stand-alone GEMM
+ * kernel, conv_out stored; frost_pw_ew mode 2 emits y from it, and the backward needs no recomputation at all */
+int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                           void* stats, const FrostFinDesc* fin, int32_t* conv_out, void* stream);
 
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
