@@ -282,7 +282,7 @@ typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
 #endif
 // GM: 0 = bf16 operands (data gradient / inference layer); 1 = int8 operands (64 k per step), epilogue = the integer conv output c[p][n] = acc - zpx * wsum[n]
 // as int32; 2 = the same plus the forward statistics of c (sum, sum of squares, min, max per channel) and the conv finalize in the last workgroup
-template <int GM>
+template <int GM, int NTP = 4>      // NTP: 16-pixel column blocks per wave (4: 256-pixel workgroup tile; 2: 128, for launches that would not fill the chip)
 __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
                                                        int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate,
                                                        const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint,
@@ -291,14 +291,14 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
   __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t p0 = (int64_t)blockIdx.x * 256 + w * 64;
+  const int64_t p0 = (int64_t)blockIdx.x * (64 * NTP) + w * (16 * NTP);
   const int ct0 = blockIdx.y * per;                        // the tiles are dealt out evenly over gridDim.y (9 tiles -> 5 + 4, not 8 + 1)
   int nct = CIT - ct0; if (nct > per) nct = per;
-  v4f acc[DGW_NT][4];
+  v4f acc[DGW_NT][NTP];
 #pragma unroll
   for (int m = 0; m < DGW_NT; ++m)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTP; ++t) acc[m][t] = (v4f){0.f, 0.f, 0.f, 0.f};
   // weight stage s: K steps [s*KS, s*KS+KS) of tiles ct0 .. ct0+nct-1 -> wl[buf][(ks * NT + m) * 1024 + lane * 16]; 256 threads x 4 x 16 bytes
   const int nst = (KB + DGW_KS - 1) / DGW_KS;
   uint4 wr[DGW_KS * DGW_NT / 4];
@@ -321,13 +321,13 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
   auto bfetch = [&](int kb, v4i* b) __attribute__((always_inline)) {
     const int kbyte = kb * 64 + 16 * g;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTP; ++t) {
       const int64_t p = p0 + 16 * t + j;
       b[t] = (v4i){0, 0, 0, 0};
       if (p < npix && kbyte < rowb && kb < KB) b[t] = *(const v4i*)((const uint8_t*)dc + p * rowb + kbyte);
     }
   };
-  v4i bcur[4], bnxt[4];
+  v4i bcur[NTP], bnxt[NTP];
   wfetch(0); wstore(0);
   bfetch(0, bcur);
   __syncthreads();
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
           if (m < nct) {
             const v4i a = *(const v4i*)(wl[buf] + (size_t)((ks * DGW_NT + m) * 64 + lane) * 16);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {       // I8: the same registers hold the int32 accumulators (bit casts at the MFMA)
+            for (int t = 0; t < NTP; ++t) {       // I8: the same registers hold the int32 accumulators (bit casts at the MFMA)
               if constexpr (I8) acc[m][t] = __builtin_bit_cast(v4f, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bcur[t], __builtin_bit_cast(v4i, acc[m][t]), 0, 0, 0));
               else acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, a), __builtin_bit_cast(v8bf16, bcur[t]), acc[m][t], 0, 0, 0);
             }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) bcur[t] = bnxt[t];
+      for (int t = 0; t < NTP; ++t) bcur[t] = bnxt[t];
     }
     if (st + 1 < nst) wstore(buf ^ 1);
     __syncthreads();
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
       if (ci >= cin) continue;
       const v4i ws = *(const v4i*)(wsum + ci);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NTP; ++t) {
         const int64_t p = p0 + 16 * t + j;
         if (p >= npix) continue;
         const v4i a = __builtin_bit_cast(v4i, acc[m][t]);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
         for (int r = 0; r < 4; ++r) {
           long long a1 = 0, a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < NTP; ++t) {
             if (p0 + 16 * t + j < npix) {
               const int v = __builtin_bit_cast(v4i, acc[m][t])[r];
               a1 += v; a2 += (long long)v * v; mn = min(mn, v); mx = max(mx, v);
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
     const int ci = (ct0 + m) * 16 + 4 * g;
     if (ci >= cin) continue;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTP; ++t) {
       const int64_t p = p0 + 16 * t + j;
       if (p >= npix) continue;
       uint16_t* dst = dx + p * cin + ci;
@@ -453,14 +453,21 @@ extern "C" int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout) {
   static const int minc = getenv("FROST_DGRAD_WIDE") ? atoi(getenv("FROST_DGRAD_WIDE")) : 1;      // smallest Cout it takes (measured: every non-fused layer gains); 0 = off
   return minc > 0 && cout >= minc && (cout & 7) == 0 && (cin & 7) == 0 && npix >= 256;
 }
+// 128-pixel tiles when 256-pixel ones would leave CUs without a workgroup (the 7x7 layers at B <= 512)
+template <int GM, typename... Args>
+static void launch_dgw(hipStream_t s, int64_t npix, int nch, Args... args) {
+  if (((npix + 255) / 256) * nch < 320)
+    hipLaunchKernelGGL((k_dgrad_wide<GM, 2>), dim3((unsigned)((npix + 127) / 128), (unsigned)nch), dim3(256), 0, s, args...);
+  else
+    hipLaunchKernelGGL((k_dgrad_wide<GM, 4>), dim3((unsigned)((npix + 255) / 256), (unsigned)nch), dim3(256), 0, s, args...);
+}
 extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
                                    uint16_t* dx, int accumulate, void* stream) {
   FROST_REQUIRE((cin & 7) == 0 && (cout & 7) == 0, "pw_dgrad_wide: channels must be multiples of 8");
   const int cpad = round_up(cout, 16); const int KB = cpad / 32 + ((cpad % 32) ? 1 : 0);
   const int CIT = round_up(cin, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
-  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide<0>, grid, dim3(256), 0, as_stream(stream), dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
+  launch_dgw<0>(as_stream(stream), npix, nch, dc, wt_pack, qrec_w, npix, cout, cin, KB, CIT, per, dx, accumulate,
                      (const float*)nullptr, 0, (const int32_t*)nullptr, (const float*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("pw_dgrad_wide");
 }
@@ -469,8 +476,7 @@ int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* b
   const int kp = round_up(k, 16); const int KB = kp / 32 + ((kp % 32) ? 1 : 0);
   const int CIT = round_up(n, 16) / 16;
   const int nch = (CIT + DGW_NT - 1) / DGW_NT, per = (CIT + nch - 1) / nch;
-  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide<0>, grid, dim3(256), 0, s, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu, (const int32_t*)nullptr,
+  launch_dgw<0>(s, npix, nch, x, pack, (const float*)nullptr, npix, k, n, KB, CIT, per, y, 0, bias, relu, (const int32_t*)nullptr,
                      (const float*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("gemm_bf16_rows");
 }
@@ -483,9 +489,8 @@ extern "C" int frost_pw_conv_int(const int8_t* x, const float* qrec_x, const int
   const int KS = round_up(cin, 64) / 64;
   const int CT = round_up(cout, 16) / 16;
   const int nch = (CT + DGW_NT - 1) / DGW_NT, per = (CT + nch - 1) / nch;
-  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
   // kernel arguments in its own (data-gradient) naming: K = "cout" = cin here, N = "cin" = cout here
-  hipLaunchKernelGGL(k_dgrad_wide<1>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
+  launch_dgw<1>(as_stream(stream), npix, nch, (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
                      (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out, (uint8_t*)nullptr, FrostFinDesc{});
   return frost_check_launch("pw_conv_int");
 }
@@ -498,8 +503,7 @@ extern "C" int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, cons
   const int KS = round_up(cin, 64) / 64;
   const int CT = round_up(cout, 16) / 16;
   const int nch = (CT + DGW_NT - 1) / DGW_NT, per = (CT + nch - 1) / nch;
-  dim3 grid((unsigned)((npix + 255) / 256), (unsigned)nch);
-  hipLaunchKernelGGL(k_dgrad_wide<2>, grid, dim3(256), 0, as_stream(stream), (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
+  launch_dgw<2>(as_stream(stream), npix, nch, (const uint16_t*)x, (const uint16_t*)wq_pack, (const float*)nullptr, npix, cin, cout, KS, CT, per,
                      (uint16_t*)nullptr, 0, (const float*)nullptr, 0, wsum, qrec_x, conv_out, (uint8_t*)stats, *fin);
   return frost_check_launch("pw_conv_fwd_keep");
 }

@@ -278,8 +278,8 @@ class Engine:
                                  l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0,
                                  l.wscale.data_ptr())
             nb = x.numel + l.wq_pack.numel()
-            if _PW_KEEP and l.kind == "pw" and x.c > 256:
-                # wide-K layer (x rows too long for k_pw's DMA tile, N << K): statistics + finalize on the stand-alone int8 GEMM kernel, which also stores the
+            if _PW_KEEP and l.kind == "pw" and x.c > 256 and l.cout < x.c:
+                # wide-K reduce layer (x rows too long for k_pw's DMA tile, Cout < Cin: the int32 output is smaller than the x re-reads it saves): statistics + finalize on the stand-alone int8 GEMM kernel, which also stores the
                 # integer conv output (smaller than x); y is emitted element-wise from it and the backward's reduce / dc need no recomputation
                 cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
                 call("frost_pw_conv_fwd_keep", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(cint),
@@ -547,7 +547,7 @@ class Engine:
             # wide-K layers (Cin > 256: x rows too long for k_pw's DMA tile): ONE recomputation of the integer conv output on the stand-alone GEMM kernel,
             # then the reduce and dc passes element-wise over it (N << K here: the int32 output is smaller than x) instead of two chunked k_pw passes
             cint = None
-            if _PW_KEEP and not fused and l.kind == "pw" and x.c > 256:
+            if _PW_KEEP and not fused and l.kind == "pw" and x.c > 256 and l.cout < x.c:
                 cint = getattr(y, "cint", None)          # kept by the training forward; otherwise (forward without statistics) one recomputation here
                 if cint is None:
                     cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
