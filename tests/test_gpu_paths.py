@@ -17,7 +17,9 @@ PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CS
              FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0")
 CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 32, 16, 1, 1, 112, 64), ("pw", 72, 24, 1, 1, 56, 128), ("pw", 144, 40, 1, 1, 28, 512), ("dw", 72, 72, 3, 1, 56, 64), ("pw", 56, 168, 1, 1, 28, 128), ("pw", 40, 16, 1, 1, 28, 64), ("pw", 56, 336, 1, 1, 28, 512), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
          ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
-         ("dw", 144, 144, 5, 2, 56, 64)]
+         ("dw", 144, 144, 5, 2, 56, 64),
+         # wide-K reduce layers on the kept-conv-output path (rows of 8 mod 16 bytes, a ragged pixel count, three channel chunks) vs all four passes through k_pw
+         ("pw", 312, 80, 1, 1, 14, 67), ("pw", 360, 96, 1, 1, 14, 33), ("pw", 1440, 192, 1, 1, 7, 70), ("pw", 624, 96, 1, 1, 14, 128)]
 
 
 def run(tmp, tag, case, env_extra):
