@@ -786,10 +786,16 @@ static int dispatch3(Dw3P& p, int k, int stride, int geo, int op, hipStream_t s)
 }
 static int geo_env(int geo) { static const int force = getenv("FROST_DW_GEO") ? atoi(getenv("FROST_DW_GEO")) : -1; return force == 0 ? GEO_A : geo; }
 
+// the matrix-core formulation (frost_dwm.hip) takes the layers it has an instance for
+int frost_dwm_ok(int k, int stride, int c);
+int frost_dwm_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k, int mode,
+                  void* stats, const float* coef, const float* qrec_y, int relu, int8_t* y, const FrostFinDesc* fin, hipStream_t s);
+
 extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n,
                                  int h, int w, int c, int k, int stride, int mode, void* stats, const float* coef,
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
+  if (frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, mode, stats, coef, qrec_y, relu, y, nullptr, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2);
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), mode == 0 ? 0 : 1, as_stream(stream));
@@ -798,6 +804,7 @@ extern "C" int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const
                                      int stride, void* stats, const FrostFinDesc* fin, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y, "dw_fwd_fin: incomplete finalize descriptor");
+  if (frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, 0, stats, nullptr, nullptr, 0, nullptr, fin, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = fin->coef; p.qy = fin->qrec_y; p.relu = fin->relu; p.fin = *fin; p.fin_on = 1;
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), 0, as_stream(stream));

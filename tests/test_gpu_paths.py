@@ -56,3 +56,23 @@ def test_fast_paths_match_plain_paths(case, tmp_path):
     for k in ("dw", "dgamma"):
         assert relerr(fast[k], plain[k]) <= 1e-2, k
     assert relerr(fast["dbeta"], plain["dbeta"]) <= 1e-3
+
+
+# The matrix-core depthwise formulation (csrc/frost_dwm.hip: Toeplitz bands on v_mfma_i32_16x16x64_i8) against the lane-=-channel stencil kernels:
+# 64- and 32-channel blocks, partial channel blocks, 3x3 and 5x5, maps that are / are not multiples of the 16 x 16 tile.  Same layer, same inputs;
+# the backward kernels are shared, so everything but the forward statistics' summation order is identical.
+DWM_CASES = [("dw", 72, 72, 3, 1, 56, 8), ("dw", 624, 624, 5, 1, 14, 16), ("dw", 32, 32, 3, 1, 112, 4), ("dw", 168, 168, 3, 1, 28, 8), ("dw", 360, 360, 5, 1, 14, 6),
+             ("dw", 1440, 1440, 5, 1, 7, 16)]
+
+
+@pytest.mark.parametrize("cb", ["32", "64"])
+@pytest.mark.parametrize("case", DWM_CASES, ids=lambda c: "_".join(str(v) for v in c))
+def test_dw_matrix_core_path_matches_stencil_path(case, cb, tmp_path):
+    mfma = run(str(tmp_path), "mfma", case, {"FROST_DW_MFMA": "1", "FROST_DWM_CB": cb})
+    sten = run(str(tmp_path), "sten", case, {"FROST_DW_MFMA": "0"})
+    d = np.abs(mfma["y"].astype(np.int16) - sten["y"].astype(np.int16))
+    assert d.max() <= 1 and float((d > 0).mean()) <= 1e-4, ("y", int(d.max()), float((d > 0).mean()))
+    np.testing.assert_allclose(mfma["qy"][:3], sten["qy"][:3], rtol=1e-6)
+    assert mfma["qy"][3].tobytes() == sten["qy"][3].tobytes()
+    np.testing.assert_allclose(mfma["rm"], sten["rm"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mfma["rv"], sten["rv"], rtol=1e-6, atol=1e-7)
