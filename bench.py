@@ -26,9 +26,10 @@ FLOPS_PER_IMG = FLOPS_I8_PER_IMG + FLOPS_BF16_PER_IMG                        # 2
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def cpu_baseline(res=224):
+def cpu_baseline(res=224, batch=64, timed=3):
     """Reference-path stand-in timed on the host cores: the CPU oracle (restated torch eager QAT graph, kind 'port').
-    Bounded sample: a 2-image probe step sizes the timed step to about 15 s of CPU work (2..128 images)."""
+    Bounded sample per SURVEY 8(d): batch 64, ONE warm-up step + THREE timed steps of fwd + bwd + GradBoost-SGD on the same state, median reported
+    (~25 s of CPU work on the GPU box's 32 usable threads; FROST_CPU_BASELINE_BATCH overrides the batch on small hosts)."""
     from oracle import frost_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -36,16 +37,19 @@ def cpu_baseline(res=224):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 32))          # more intra-op threads than usable cores makes the torch CPU kernels collapse
     torch.set_num_threads(cores)
+    batch = int(os.environ.get("FROST_CPU_BASELINE_BATCH", batch))
     cfg = O.net_cfg("large", 1.0)
     hp = dict(lr=5e-3, momentum=0.9, weight_decay=1e-5, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+    P, B = O.make_state(O.float_state_spec(cfg), 5000, True)
+    qs = O.QState(B)
+    x = torch.from_numpy(O.synth((batch, 3, res, res), 77))
+    tgt = torch.randint(0, 1000, (batch,))
+    states = {k: {} for k in P}
 
-    def one_step(batch):
-        P, B = O.make_state(O.float_state_spec(cfg), 5000, True)
-        qs = O.QState(B)
-        x = torch.from_numpy(O.synth((batch, 3, res, res), 77))
-        tgt = torch.randint(0, 1000, (batch,))
-        states = {k: {} for k in P}
+    def one_step():
         t0 = time.time()
+        for p in P.values():
+            p.grad = None
         y = O.frostnet_forward(P, qs, cfg, x, True, True)
         torch.nn.functional.cross_entropy(y, tgt).backward()
         with torch.no_grad():
@@ -54,12 +58,12 @@ def cpu_baseline(res=224):
                                  boost=True, noise=torch.empty_like(p).exponential_(), coin=torch.randint(0, 2, p.shape).float())
         return time.time() - t0
 
-    probe = one_step(2)
-    batch = int(max(2, min(128, 15.0 / (probe / 2))))
-    dt = one_step(batch)
+    warm = one_step()
+    ts = sorted(one_step() for _ in range(timed))
+    dt = ts[len(ts) // 2]
     return dict(value=batch / dt, unit="images/sec", cores=cores, kind="port",
-                sample=f"1 step, batch {batch} @ {res}x{res}, FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU "
-                       f"kernels via oracle/frost_oracle.py, {dt:.1f} s (after a 2-image probe step of {probe:.1f} s)")
+                sample=f"batch {batch} @ {res}x{res}, 1 warm-up + {timed} timed steps (median {dt:.2f} s; all {[round(t, 2) for t in ts]}, warm-up {warm:.2f} s), "
+                       f"FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU kernels via oracle/frost_oracle.py")
 
 
 def pmc_traffic(label, batch):
@@ -211,13 +215,55 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def _init_group(backend, dev, rank, world, args):
+    """Rendezvous + communicator bring-up with a HARD timeout and a readable failure: a stalled store or an RCCL init that never returns ends the
+    run with one message per rank instead of hanging the node (FROST_RDZV_TIMEOUT seconds, default 300)."""
+    import datetime
+    import torch.distributed as dist
+    tmo = int(os.environ.get("FROST_RDZV_TIMEOUT", "300"))
+    kw = dict(timeout=datetime.timedelta(seconds=tmo))
+    if dev is not None:
+        kw["device_id"] = dev
+    t0 = time.time()
+    try:
+        dist.init_process_group(backend, **kw)
+        if backend == "nccl":                 # communicators are created lazily: force it now, inside the timeout, with a one-element collective
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != dist.get_world_size():
+                raise RuntimeError(f"probe all-reduce returned {probe.item()} with world size {dist.get_world_size()}")
+    except Exception as e:
+        print(f"[bench] rank {rank}/{world}: process-group bring-up failed after {time.time() - t0:.0f} s (backend {backend}, MASTER_ADDR="
+              f"{os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, timeout {tmo} s): {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        sys.exit(3)
+    if dist.get_world_size() != world:
+        print(f"[bench] rank {rank}: process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
+def _check_distinct_devices(dev, rank, world):
+    """Every rank must drive its own GPU: gather (host, device index, PCI bus id / uuid) and refuse duplicates."""
+    import socket
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    ident = (socket.gethostname(), int(dev.index), str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", "")))
+    got = [None] * world
+    dist.all_gather_object(got, ident)
+    if len(set(got)) != world:
+        if rank == 0:
+            print(f"[bench] ranks do not see distinct devices: {got}", file=sys.stderr, flush=True)
+        sys.exit(3)
+    return got
+
+
 def dry_run(args):
     """Launcher check without GPUs (CPU test / any box): N gloo ranks rendezvous, all-reduce a rank-dependent vector, rank 0 prints
     one line.  Exercises exactly the spawn + env + rendezvous + single-line-output plumbing of the N>1 path."""
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if world > 1:
-        dist.init_process_group("gloo")
+        _init_group("gloo", None, rank, world, args)
     t = torch.full((4,), float(rank + 1))
     if world > 1:
         dist.all_reduce(t)
@@ -255,8 +301,10 @@ def main():
         sys.exit(_self_launch(args))
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} differs from --gpus {args.gpus}: reporting n_gpus={world}", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per requested GPU (torch.distributed.run --nproc-per-node {args.gpus})", file=sys.stderr, flush=True)
+        sys.exit(2)
     if args.dry_run_launcher:
         return dry_run(args)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
@@ -274,10 +322,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if args.share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        _init_group("gloo" if args.share_gpu else "nccl", None if args.share_gpu else dev, rank, world, args)
+        if not args.share_gpu:
+            _check_distinct_devices(dev, rank, world)
         if rank == 0:
             print(f"[bench] process group up: backend={dist.get_backend()} world={dist.get_world_size()} (one rank per GPU)", file=sys.stderr, flush=True)
 
@@ -323,13 +370,15 @@ def main():
         loss.backward()
         return loss
 
+    ctl = {"comm": True}                          # the exposed-communication measurement replays the step with the collectives switched off
+
     def eager_step():
         if seg is not None:
             seg.run_eager(x, tgt)
             seg.finish()
         else:
             fwd_bwd()
-            if dp:
+            if dp and ctl["comm"]:
                 dist.all_reduce(runner.grad_arena)
         opt.step()
 
@@ -338,6 +387,7 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
+    capture_fallback = None
     if not args.no_graph:
         try:
             if seg is not None:
@@ -357,11 +407,28 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
         except Exception as e:  # pragma: no cover
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
             graph = None
-            if seg is not None:
-                seg.graphs = None
             torch.cuda.synchronize()
+            if seg is not None:
+                # segment capture under a live RCCL watchdog failed: fall back to ONE graph + one post-backward all-reduce (the --single-allreduce form)
+                seg.graphs = None
+                seg = None
+                capture_fallback = f"segmented capture failed ({type(e).__name__}); fell back to one graph + single all-reduce"
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                            fwd_bwd()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                except Exception as e2:
+                    print(f"[bench] single-graph capture failed too ({type(e2).__name__}: {e2}); running eagerly", file=sys.stderr, flush=True)
+                    graph = None
+                    capture_fallback += "; that capture failed as well: eager launches"
+                    torch.cuda.synchronize()
 
     def step():
         if graph is None:
@@ -374,7 +441,8 @@ def main():
         else:
             graph.replay()
             if dp:
-                dist.all_reduce(runner.grad_arena)
+                if ctl["comm"]:
+                    dist.all_reduce(runner.grad_arena)
                 opt.launch(plan)
 
     for _ in range(args.warmup):
@@ -402,6 +470,52 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
+
+    comm = None
+    if dp:
+        # (a) every bucket's all-reduce alone on an otherwise idle GPU (median of 5); (b) the EXPOSED part of the exchange = step time with the
+        # collectives minus step time without them (the gradients of those extra steps stay un-reduced: they come after the timed region)
+        buckets = [(lo, hi) for _, lo, hi in seg.cuts] if seg is not None else [(0, runner.grad_arena.numel())]
+        per_bucket = []
+        for lo, hi in buckets:
+            ts = []
+            for _ in range(5):
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(runner.grad_arena[lo:hi])
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            per_bucket.append(dict(bytes=4 * (hi - lo), allreduce_us=round(sorted(ts)[2] * 1e3, 1)))
+        k = max(3, min(args.steps, 10))
+        ctl["comm"] = False
+        keep_reduce = seg._reduce if seg is not None else None
+        if seg is not None:
+            seg._reduce = lambda i: None
+        step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        dt_nc = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt_nc, op=dist.ReduceOp.MAX)
+        ctl["comm"] = True
+        if seg is not None:
+            seg._reduce = keep_reduce
+        ms_nc = float(dt_nc.item()) / k * 1e3
+        total_ar = sum(b["allreduce_us"] for b in per_bucket) / 1e3
+        comm = dict(mode=("single all-reduce after the backward" if seg is None else f"{len(seg.cuts)} buckets overlapped with the backward, one hipGraph segment per bucket"),
+                    buckets=per_bucket, allreduce_ms_sum=round(total_ar, 3), step_ms_without_collectives=round(ms_nc, 3),
+                    exposed_comm_ms_per_step=round(max(0.0, ms - ms_nc), 3), hidden_comm_ms_per_step=round(max(0.0, total_ar - max(0.0, ms - ms_nc)), 3),
+                    fallback=capture_fallback)
 
     roofline = None
     if rank == 0 and not args.no_roofline:
@@ -459,8 +573,7 @@ def main():
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
                                parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype="bf16",
                                ms_per_step_median_hip_events=round(ms_median, 3),
-                               grad_allreduce=(None if not dp else ("single, after backward" if seg is None else
-                                               f"{len(seg.cuts)} buckets overlapped with backward, one hipGraph segment per bucket"))),
+                               grad_allreduce=comm),
                    roofline=roofline, cpu_baseline=cpu)
     if dp:
         dist.destroy_process_group()

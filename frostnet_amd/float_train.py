@@ -344,7 +344,8 @@ class FloatRunner:
         drop = None
         if training and self.drop_rate > 0.0:
             keep = 1.0 - self.drop_rate
-            drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device).bernoulli_(keep).div_(keep)
+            from .runner import dropout_mask          # the same device Philox stream as the fake-quant runner (seed from torch + rank, resumable)
+            drop = dropout_mask(self, a.n * a.c, keep).view(a.n, a.c)
         pooled = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device)
         call(self._fn["frost_float_avgpool"], ptr(a.buf), a.n, a.h * a.w, a.c, ptr(drop), ptr(pooled), stream())
         nclass = self.fc.out_channels

@@ -6,6 +6,11 @@
   * `statassist_qat_switch` -- Classification/train.py:149-173 (StatAssist FP epoch(s) with the SAME optimizer, flip
     `is_warmup`, then fuse + prepare_qat keeping Parameter identity so optimizer state survives)
   * `train_one_iter` / `accuracy` -- helper_functions.py:32-46,118-155 (accuracy() fixed for torch>=1.7: reshape, not view)
+  * `train` / `val` -- the epoch loops, helper_functions.py:99-163 / 306-350: mean over the iterations of the per-batch loss / top-1 / top-5.  `val`
+    only switches to `model.eval()` -- as in the reference the observers stay live and keep moving with validation data.
+    The running sums stay on the device: ONE host read per epoch instead of the reference's three `.item()` per iteration.
+  * `checkpoint_state` / `save_checkpoint` / `load_checkpoint` -- Classification/train.py:193-223, helper_functions.py:400-407: the reference's
+    dictionary keys, plus `hip_rng` (dropout Philox seed + draw count; the GradBoost stream resumes from the optimizer's step count).
 """
 import math
 
@@ -105,3 +110,70 @@ def statassist_qat_switch(model, optimizer, qconfig_version=0, backend="qnnpack"
     qat_prepare(model, version=qconfig_version, backend=backend)
     assert before == [id(p) for p in model.parameters()], "prepare_qat must keep parameter identity"
     return model
+
+
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+def _epoch(loader, model, criterion, optimizer, epoch, args, grad_sync, train_mode):
+    dev = _device_of(model)
+    sums, n = torch.zeros(3, dtype=torch.float64, device=dev), 0
+    for i, (inp, target) in enumerate(loader):
+        inp, target = inp.to(dev, non_blocking=True), target.to(dev, non_blocking=True)
+        if train_mode:
+            if args is not None and getattr(args, "lrsch", "cos_lr") == "cos_lr" and hasattr(args, "dataset_len"):
+                adjust_learning_rate_cosine(optimizer, epoch, i, args.dataset_len, args)
+            loss, out = train_one_iter(model, criterion, optimizer, inp, target, grad_sync)
+        else:
+            with torch.no_grad():
+                out = model(inp)
+                loss = criterion(out, target)
+        acc1, acc5 = accuracy(out, target, topk=(1, min(5, out.shape[1])))
+        sums += torch.stack([loss.detach().double().reshape(()), acc1[0].double(), acc5[0].double()])
+        n += 1
+    if n == 0:
+        raise ValueError("empty loader")
+    loss, a1, a5 = (sums / n).tolist()           # the epoch's single device -> host read
+    return loss, a1, a5
+
+
+def train(train_loader, model, criterion, optimizer, epoch, total_ep=None, args=None, grad_sync=None):
+    """One training epoch (helper_functions.py:99-163): returns (mean loss, mean top-1, mean top-5) over the iterations."""
+    model.train()
+    return _epoch(train_loader, model, criterion, optimizer, epoch, args, grad_sync, True)
+
+
+def val(val_loader, model, criterion):
+    """One validation pass (helper_functions.py:306-350): `model.eval()` only -- BatchNorm uses its running statistics while every FakeQuantize
+    observer that has not been disabled explicitly keeps updating, exactly as the reference's val() leaves them."""
+    model.eval()
+    return _epoch(val_loader, model, criterion, None, 0, None, None, False)
+
+
+def checkpoint_state(model, optimizer, epoch, **scalars):
+    """The dictionary Classification/train.py:208-218 saves every epoch (same keys; `scalars` = lossTr, lossVal, acc1Tr, ... , lr, Max_name ...)."""
+    state = {"epoch": epoch + 1, "arch": str(type(model).__name__), "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}
+    state.update(scalars)
+    runner = getattr(model, "_hip_runner", None)
+    if runner is not None and hasattr(runner, "rng_state"):
+        state["hip_rng"] = runner.rng_state()
+    return state
+
+
+def save_checkpoint(state, filenameCheckpoint="checkpoint.pth.tar"):
+    torch.save(state, filenameCheckpoint)
+
+
+def load_checkpoint(model, optimizer, filenameCheckpoint="checkpoint.pth.tar", map_location=None):
+    """Resume: parameters / buffers (BN statistics, observer ranges, qparams), optimizer state (GradBoost statistics, step count = Philox offset)
+    and the dropout stream.  Returns the checkpoint dictionary (epoch, best accuracies ...)."""
+    ck = torch.load(filenameCheckpoint, map_location=map_location, weights_only=False)
+    model.load_state_dict(ck["state_dict"])
+    if optimizer is not None and "optimizer" in ck:
+        optimizer.load_state_dict(ck["optimizer"])
+    if "hip_rng" in ck and hasattr(model, "hip_runner"):
+        dev = _device_of(model)
+        if dev.type == "cuda":
+            model.hip_runner().set_rng_state(ck["hip_rng"])
+    return ck

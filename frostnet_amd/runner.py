@@ -52,6 +52,42 @@ class _QATFeatFunction(torch.autograd.Function):
         return None, None, None
 
 
+def dropout_seed():
+    """Philox key of the dropout masks: torch's seed (torch.manual_seed is honoured, Classification/train.py:38-39) mixed with the data-parallel
+    rank, so that the ranks of one job draw different masks for their shards."""
+    import os
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()
+    else:
+        rank = int(os.environ.get("RANK", "0"))
+    return (torch.initial_seed() + 0x9E3779B97F4A7C15 * (rank + 1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout_mask(runner, n, keep):
+    """nn.Dropout's mask (frostnet.py:297) for `n` pooled features: {0, 1/keep} floats drawn on the device (Philox4x32-10, counter = (index, draw)).
+    The draw counter lives in device memory (a captured hipGraph draws a fresh mask per replay) and, with the seed, is part of the runner's
+    `rng_state()` so that a resumed run continues the stream.  Shared by the fake-quant and the float runner."""
+    if getattr(runner, "_drop_ctr", None) is None:
+        runner._drop_ctr = torch.zeros(2, dtype=torch.int64, device=runner.device)        # {draw, arrival ticket}
+        runner._drop_seed = dropout_seed()
+    out = torch.empty(n, dtype=torch.float32, device=runner.device)
+    L.call("frost_dropout_mask", L.ptr(runner._drop_ctr), runner._drop_seed, n, keep, L.ptr(out), L.stream())
+    return out
+
+
+def rng_state(runner):
+    """{seed, draws} of the dropout stream (checkpointed by harness.save_checkpoint beside the optimizer's Philox offset = its step count)."""
+    if getattr(runner, "_drop_ctr", None) is None:
+        return {"seed": dropout_seed(), "draws": 0}
+    return {"seed": int(runner._drop_seed), "draws": int(runner._drop_ctr[0].item())}
+
+
+def set_rng_state(runner, state):
+    runner._drop_ctr = torch.tensor([int(state["draws"]), 0], dtype=torch.int64, device=runner.device)
+    runner._drop_seed = int(state["seed"]) & 0xFFFFFFFFFFFFFFFF
+
+
 def _is_fused_fq(fq):
     return type(fq).__name__ == "FusedMovingAvgObsFakeQuantize"
 
@@ -110,6 +146,12 @@ class FrostRunner:
         if not torch.cuda.is_current_stream_capturing():
             self._obs_cached = self.observe
         return getattr(self, "_obs_cached", True)
+
+    def rng_state(self):
+        return rng_state(self)
+
+    def set_rng_state(self, state):
+        set_rng_state(self, state)
 
     def still_valid(self):
         m = self.model
@@ -421,10 +463,7 @@ class FrostRunner:
         drop_rate = float(self.model.classifier[1].p)
         if training and drop_rate > 0.0:
             keep = 1.0 - drop_rate
-            if getattr(self, "_drop_ctr", None) is None:          # device-resident draw counter: a captured graph draws a fresh mask per replay
-                self._drop_ctr = torch.zeros(2, dtype=torch.int64, device=self.device)        # {draw, arrival ticket}
-            drop = torch.empty(a.n, a.c, dtype=torch.float32, device=self.device)
-            L.call("frost_dropout_mask", L.ptr(self._drop_ctr), 1882, a.n * a.c, keep, L.ptr(drop), L.stream())
+            drop = dropout_mask(self, a.n * a.c, keep).view(a.n, a.c)
         logits = self.E.head(self.cls, a, drop, self._obs)
         if not record:
             self.E.tape = []

@@ -222,6 +222,30 @@ def test_bench_launcher_dry_run_spawns_n_ranks():
     assert rec["n_gpus"] == 1
 
 
+def test_bench_launcher_dry_run_eight_ranks_and_failure_modes():
+    """the node-sized launch (8 ranks: spawn, rendezvous on 127.0.0.1, one all-reduce, ONE line from rank 0), a world size that
+    contradicts --gpus is refused with a message instead of silently re-labelled, and a rendezvous that cannot complete ends with exit code 3
+    after the hard timeout instead of hanging."""
+    import json
+    import subprocess
+    import time
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-launcher"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["allreduce_sum"] == rec["expected"] == 36.0
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29779")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run-launcher"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in out.stderr
+    # rank 0 of a 2-rank world whose peer never shows up: the bring-up times out (FROST_RDZV_TIMEOUT) and the rank exits with code 3
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29781", FROST_RDZV_TIMEOUT="5")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launcher"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 3 and "process-group bring-up failed" in out.stderr, (out.returncode, out.stderr[-500:])
+    assert time.time() - t0 < 200
+
+
 def _shard_oracle_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

@@ -6,8 +6,9 @@ depthwise geometries depend on the true map width, the split-K weight gradient o
 FrostNet-Large layer family runs at its true resolution with a batch that selects those variants, teacher-forced on the same
 seeded uint8 indices as the CPU oracle (oracle.convbn_qat, itself pinned to the reference by tests/test_oracle_golden.py).
 
-Stated tolerances: indices |delta| <= 1 with flip rate <= FLIP (integer-exact conv + one fma here, fp32 conv + divide +
-batch_norm there); observer scalars 2e-5; running statistics 1e-3; gradients norm-wise <= GRAD (bf16 gradient storage and
+Stated tolerances: indices equal to the reference's except (a) where the reference's own fp32 arithmetic is ambiguous -- its fp32 and fp64
+evaluations land on different indices: there either side, +-1, is accepted (all mismatches together <= FLIP_ANY) -- and (b) the device's own two
+fp32 roundings (integer-exact conv + one fma here, fp32 conv + divide + batch_norm there): <= FLIP_SOLID of the elements, |delta| <= 1; observer scalars 2e-5; running statistics 1e-3; gradients norm-wise <= GRAD (bf16 gradient storage and
 bf16 MFMA operands); the classifier head against the REFERENCE golden (tests/golden/g3_classifier.npz)."""
 import numpy as np
 import pytest
@@ -17,6 +18,8 @@ from oracle import frost_oracle as O
 
 pytestmark = pytest.mark.gpu
 FLIP = 5e-4
+FLIP_SOLID = 2e-4     # index mismatches where the reference's fp32 and fp64 evaluations agree (the device's own two fp32 roundings)
+FLIP_ANY = 3e-3       # all index mismatches, ties of the reference included
 GRAD = 2e-2
 
 
@@ -59,14 +62,33 @@ def _layer_state(cin, cout, k, groups, seed):
     return O.synth_state([k_ for k_, _ in spec], [s_ for _, s_ in spec], seed)
 
 
-@pytest.mark.parametrize("case", PROD, ids=[c[0] for c in PROD])
-def test_prod_layer_vs_oracle(engine, case):
-    name, cin, cout, k, s, groups, H, N, relu = case
+def device_int_weights(l):
+    """The layer's int8 weights as the kernels hold them (decoded from the MFMA / depthwise packs of frost_weight_prep), shape [cout, cin_g * k * k]."""
+    kk, cin_g = l.kk, l.cin_g
+    if l.kind == "dw":
+        pk = l.wq_pack[: kk * l.cpad].cpu().view(kk, l.cpad).numpy().astype(np.int32)
+        return pk[:, : l.cout].T.copy()
+    CT, KS = l.cpad // 16, l.kpad // 64
+    pk = l.wq_pack[: CT * KS * 1024].cpu().view(CT, KS, 64, 16).numpy().astype(np.int32)
+    full = np.zeros((l.cpad, l.kpad), np.int32)
+    for ln in range(64):
+        full[(np.arange(CT) * 16 + (ln & 15))[:, None, None], (np.arange(KS) * 64 + (ln >> 4) * 16)[None, :, None] + np.arange(16)[None, None, :]] = pk[:, :, ln, :]
+    if l.kind == "stem":                  # K index = tap * 4 + c  ->  OIHW order c * kk + tap
+        out = np.zeros((l.cout, cin_g * kk), np.int32)
+        for c in range(cin_g):
+            for tap in range(kk):
+                out[:, c * kk + tap] = full[: l.cout, tap * 4 + c]
+        return out
+    return full[: l.cout, : cin_g]
+
+
+def run_layer_case(engine, name, cin, cout, k, s, groups, H, N, relu, seed, in_zp, steps=2):
+    """One ConvBN(ReLU) layer, teacher-forced on seeded uint8 indices, `steps` training steps on the device (through the C ABI) and on the oracle
+    (fp32 = the reference's arithmetic; fp64 = the yardstick of the gradients); asserts the tolerances stated in the module docstring."""
     dev = "cuda"
     torch.set_num_threads(16)
-    seed = 7000 + 13 * PROD.index(case)
     sd = _layer_state(cin, cout, k, groups, seed)
-    in_scale, in_zp = 0.0231, (0 if PROD.index(case) % 2 == 0 else 117)
+    in_scale = 0.0231
     xi = np.clip(np.round(O.synth((N, cin, H, H), seed + 1) * 40 + 128 + (0 if in_zp else -60)), 0, 255).astype(np.uint8)
     # ---- oracle (CPU): fp32 = the reference's arithmetic (indices, observers, statistics); the SAME formulas evaluated in fp64 are the
     # yardstick for the gradients: at 263 k pixels dW / dgamma are sums with heavy cancellation (BatchNorm makes sum_p dc = 0) and the
@@ -90,19 +112,22 @@ def test_prod_layer_vs_oracle(engine, case):
     xi_t = T(xi)
     if kind == "stem":
         xi_t = torch.cat([xi_t, torch.full_like(xi_t[:, :1], in_zp)], 1)
-    for step in range(2):
+    for step in range(steps):
         xo.grad = None
         for p in P.values():
             p.grad = None
+        rv_before = qs.sd["L.conv.0.bn.running_var"].clone()          # the BN fold uses the running variance BEFORE this step's update
         yo = O.convbn_qat(P, qs, "L", xo, s, (k - 1) // 2, groups, bool(relu), True)
         gr = T(O.synth(tuple(yo.shape), seed + 2 + 50 * step))
         yo.backward(gr)
         xo64.grad = None
         for p in P64.values():
             p.grad = None
-        O.convbn_qat(P64, qs64, "L", xo64, s, (k - 1) // 2, groups, bool(relu), True).backward(gr.bfloat16().double())   # the device receives bf16 gradients
+        yo64 = O.convbn_qat(P64, qs64, "L", xo64, s, (k - 1) // 2, groups, bool(relu), True)
+        yo64.backward(gr.bfloat16().double())                                                                              # the device receives bf16 gradients
         a = "L.conv.0.activation_post_process"
         idx_o = O.fq_index(yo.detach(), qs.sd[a + ".scale"][0], qs.sd[a + ".zero_point"][0])
+        idx_64 = O.fq_index(yo64.detach(), qs64.sd[a + ".scale"][0], qs64.sd[a + ".zero_point"][0])
 
         E.begin_step()
         x = E.act_from_indices(xi_t, qx)
@@ -120,21 +145,98 @@ def test_prod_layer_vs_oracle(engine, case):
         e_db = relerr(l.beta.grad.cpu(), P64["L.conv.0.bn.bias"].grad)
         e_dx = relerr(engine.grad_to_float(x.grad, x.n, x.h, x.w, x.c).cpu(), xo64.grad) if kind != "stem" else 0.0
         r_dw, r_dg = relerr(P["L.conv.0.weight"].grad, P64["L.conv.0.weight"].grad), relerr(P["L.conv.0.bn.weight"].grad, P64["L.conv.0.bn.weight"].grad)
-        print(f"[{name} step {step}] idx max {mx} flip {rate:.2e} | vs fp64: dx {e_dx:.2e} dW {e_dw:.2e} dgamma {e_dg:.2e} dbeta {e_db:.2e} | ref32 vs fp64: dW {r_dw:.2e} dgamma {r_dg:.2e}")
-        assert mx <= 1 and rate <= FLIP, (name, step, mx, rate)
+        r_db, r_dx = relerr(P["L.conv.0.bn.bias"].grad, P64["L.conv.0.bn.bias"].grad), relerr(xo.grad, xo64.grad)
+        # three-way index comparison: `amb` = where the reference's own fp32 arithmetic and the exact (fp64) evaluation of the same formulas land on
+        # different indices (a value within fp32 round-off of a rounding boundary, or a channel whose batch variance is round-off).  The device sums
+        # exactly in integers: outside `amb` it must reproduce the reference's index (up to its own two fp32 roundings), inside it may take either side.
+        amb = (idx_o.to(torch.int16) - idx_64.to(torch.int16)).abs()
+        solid = amb == 0
+        # weight ties: the BN-folded weight w * gamma / sqrt(var + eps) of a channel can sit within one fp32 ulp of a rounding boundary of the weight
+        # quantiser; torch's vectorised CPU sqrt / divide are not bit-identical to IEEE (nor to themselves across CPUs: tests/devtools/dbg_solid_flips.py),
+        # the device's are -- such a weight may quantise one level apart, which moves every output of ITS channel by a fraction of a step.  Those
+        # channels (at most a handful of weights per layer, each verified to be a tie) are compared with |delta| <= 2 only.
+        with torch.no_grad():
+            sf32 = P["L.conv.0.bn.weight"] / torch.sqrt(rv_before + 1e-5)
+            wsc = (P["L.conv.0.weight"] * sf32.reshape(-1, 1, 1, 1)).reshape(cout, -1)
+            w_scale = float(qs.sd["L.conv.0.weight_fake_quant.scale"][0])
+            q_ref = torch.clamp(torch.round(wsc * float(np.float32(1.0) / np.float32(w_scale))), -128, 127).numpy().astype(np.int32)
+        q_dev = device_int_weights(l)
+        wdiff = np.argwhere(q_ref != q_dev)
+        tie_ch = sorted(set(int(a_) for a_, _ in wdiff))
+        for a_, b_ in wdiff:
+            t = float(wsc[a_, b_].double() / w_scale)
+            assert abs(q_ref[a_, b_] - q_dev[a_, b_]) == 1 and abs(abs(t - np.floor(t)) - 0.5) <= 2e-4, (name, "weight quantised differently away from a tie", int(a_), int(b_), t)
+        assert len(wdiff) <= 4, (name, "too many weight ties", len(wdiff))
+        if tie_ch:
+            keep = torch.ones(cout, dtype=torch.bool)
+            keep[tie_ch] = False
+            assert int(d[:, ~keep].max()) <= 2, (name, "tie channel", int(d[:, ~keep].max()))
+            d, amb, solid = d[:, keep], amb[:, keep], solid[:, keep]
+            mx, rate = int(d.max()), float((d > 0).float().mean())
+        rate_solid = float(((d > 0) & solid).float().mean())
+        excess = int((d.to(torch.int32) - amb.to(torch.int32)).max())
+        print(f"[{name} step {step}] weight ties {[(int(a_), int(b_)) for a_, b_ in wdiff]} idx max {mx} flip {rate:.2e} (off the reference's fp32/fp64-ambiguous set: {rate_solid:.2e}; that set: {float((~solid).float().mean()):.2e}) | vs fp64: dx {e_dx:.2e} dW {e_dw:.2e} dgamma {e_dg:.2e} dbeta {e_db:.2e} | ref32 vs fp64: dW {r_dw:.2e} dgamma {r_dg:.2e}")
+        assert excess <= 1 and rate_solid <= FLIP_SOLID and rate <= FLIP_ANY, (name, step, mx, excess, rate, rate_solid)
         np.testing.assert_allclose(qy["scale"], float(qs.sd[a + ".scale"][0]), rtol=2e-5)
         assert qy["zero_point"] == int(qs.sd[a + ".zero_point"][0])
         np.testing.assert_allclose(qy["min_val"], float(qs.sd[a + ".activation_post_process.min_val"]), rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(qy["max_val"], float(qs.sd[a + ".activation_post_process.max_val"]), rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(qw["scale"], float(qs.sd["L.conv.0.weight_fake_quant.scale"][0]), rtol=1e-6)
-        np.testing.assert_allclose(l.rmean.cpu().numpy(), qs.sd["L.conv.0.bn.running_mean"].numpy(), rtol=1e-3, atol=2e-4)
-        np.testing.assert_allclose(l.rvar.cpu().numpy(), qs.sd["L.conv.0.bn.running_var"].numpy(), rtol=1e-3, atol=2e-4)
+        # running statistics: against the fp32 reference, or -- for a channel where fp32 summation of the reference's conv output is ill-conditioned
+        # (BN-folded weights that quantise to a few levels: c = conv / scale_factor amplifies the round-off) -- against the fp64 evaluation
+        for key, dev_v in (("running_mean", l.rmean), ("running_var", l.rvar)):
+            v, r32, r64 = dev_v.cpu().numpy(), qs.sd["L.conv.0.bn." + key].numpy(), qs64.sd["L.conv.0.bn." + key].numpy()
+            ok = np.isclose(v, r32, rtol=1e-3, atol=2e-4) | np.isclose(v, r64, rtol=1e-3, atol=2e-4)
+            ok[tie_ch] |= np.isclose(v[tie_ch], r32[tie_ch], rtol=2e-2, atol=2e-3)          # a channel with one weight a level apart: its statistics move with it
+            assert ok.all(), (name, key, np.nonzero(~ok)[0][:8], v[~ok][:8], r32[~ok][:8], r64[~ok][:8])
         # All four gradients within GRAD of the fp64 evaluation of the reference's formulas.  (With round-to-nearest dc the 263 k-pixel cases
         # were 1.6e-2 / 4.5e-2 (dW / dgamma) off: a per-channel rounding bias amplified by sqrt(pixels); dc is now rounded stochastically,
         # frost_common.h, and sits at the bf16 floor.)  Where the reference's OWN fp32 evaluation is further than GRAD from fp64 (24->144 @56^2,
         # step 0: 2.4e-2 / 6.4e-2 -- an ill-conditioned channel), the bound is 1.5 x that distance: the device agrees with the fp32 reference there.
-        assert max(e_dx, e_db) <= GRAD, (name, step, e_dx, e_db)
+        assert e_dx <= max(GRAD, 1.5 * r_dx) and e_db <= max(GRAD, 1.5 * r_db), (name, step, e_dx, e_db, r_dx, r_db)
         assert e_dw <= max(GRAD, 1.5 * r_dw) and e_dg <= max(GRAD, 1.5 * r_dg), (name, step, e_dw, e_dg, r_dw, r_dg)
+
+
+
+@pytest.mark.parametrize("case", PROD, ids=[c[0] for c in PROD])
+def test_prod_layer_vs_oracle(engine, case):
+    name, cin, cout, k, s, groups, H, N, relu = case
+    run_layer_case(engine, name, cin, cout, k, s, groups, H, N, relu, 7000 + 13 * PROD.index(case), 0 if PROD.index(case) % 2 == 0 else 117)
+
+
+def _all_large_layers():
+    """Every conv of FrostNet-Large w=1.0 @224 (70 layers minus the classifier, which has its own golden) at its TRUE resolution,
+    with the batch that selects the kernel instance the B = 512 step runs: the instance is chosen by the pixel count (>= 2048 full 128-pixel tiles ->
+    resident-weight / shape-specialised instances; fewer tiles -> channel-group split, wide-K paths, depthwise geometry by map width), so the 112^2 /
+    56^2 / 28^2 layers get >= 2048 tiles and the 14^2 / 7^2 layers run at B = 512 itself."""
+    cfg = O.net_cfg("large")
+    batch = {112: 24, 56: 84, 28: 336, 14: 512, 7: 512}
+    out = [("conv1", 3, cfg["stem"], 3, 2, 1, 224, 4, 1, 0)]
+    H, prev_zp = 112, 0
+    for li, blocks in enumerate(cfg["layers"]):
+        for bi, bc in enumerate(blocks):
+            pre = f"layer{li + 1}.{bi}"
+            in_zp = prev_zp                       # block input: zp 0 after a ReLU layer (the stem), != 0 after a linear bottleneck / add
+            if bc["conv1"]:
+                if bc["squeeze"]:
+                    out.append((pre + ".squeeze_conv", bc["cin"], bc["r"], 1, 1, 1, H, batch[H], 1, in_zp))
+                out.append((pre + ".conv1", bc["n"], bc["hidden"], 1, 1, 1, H, batch[H], 1, in_zp))
+            out.append((pre + ".conv2", bc["hidden"], bc["hidden"], bc["k"], bc["s"], bc["hidden"], H, batch[H] if bc["hidden"] * H * H * batch[H] < 2.2e8 else max(4, batch[H] // 4), 1, 0 if bc["conv1"] else in_zp))
+            H = H // bc["s"]
+            out.append((pre + ".reduce_conv", bc["hidden"], bc["cout"], 1, 1, 1, H, batch[H], 0, 0))
+            prev_zp = 117
+    out.append(("last_layer", cfg["last_in"], cfg["last_out"], 1, 1, 1, H, batch[H], 1, 117))
+    return out
+
+
+ALL_LAYERS = _all_large_layers()
+
+
+@pytest.mark.parametrize("case", ALL_LAYERS, ids=[c[0] for c in ALL_LAYERS])
+def test_every_large_layer_at_true_resolution_vs_oracle(engine, case):
+    """the teacher-forced production-shape comparison over ALL layers of the headline model, one training step each."""
+    name, cin, cout, k, s, groups, H, N, relu, in_zp = case
+    run_layer_case(engine, name, cin, cout, k, s, groups, H, N, relu, 9100 + 7 * ALL_LAYERS.index(case), in_zp, steps=1)
 
 
 def test_classifier_head_vs_reference_golden(engine, golden):
