@@ -123,6 +123,9 @@ class FloatRunner:
     """Binds a float FrostNet (classification model or features backbone) to the float HIP kernels."""
 
     def __init__(self, model, precision=None):
+        if getattr(model, "act", "relu") != "relu":
+            raise NotImplementedError("the float (StatAssist warm-up) kernels implement the reference's ReLU network; act='hswish' runs on the device in "
+                                      "fake-quant (QAT-prepared) mode only")
         L.load_library()
         self._set_precision(precision or getattr(model, "float_precision", None))
         params = list(model.parameters())

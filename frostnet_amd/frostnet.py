@@ -59,6 +59,45 @@ class ConvBN(nn.Module):
         _fuse(self.conv, ['0', '1'])
 
 
+class Hswish(nn.Module):
+    """Quantizable hard-swish: the reference's `_Hswish` (Classification/models/imagenet/mobilenetv3.py:43-56) -- x * relu6(x + 3) / 6 written with
+    FloatFunctionals so that prepare_qat hangs FakeQuantize sites on it (two execute: nn.ReLU6's and quant_mul1's; add_scalar / mul_scalar are not
+    observed).  Same attribute names, so its state_dict keys are the reference's.  FrostNet itself uses ReLU (frostnet.py:21); this is the optional
+    activation BASELINE.json's north_star names, reachable through `act="hswish"`.  On the HIP device the op is `Engine.hswish`
+    (csrc/frost_convert.hip: presence bitmap -> observers -> 256-entry tables), bit-exact against the reference golden G10."""
+
+    def __init__(self, inplace=True):
+        super(Hswish, self).__init__()
+        self.relu6 = nn.ReLU6(inplace)
+        self.quant_mul1 = nn.quantized.FloatFunctional()
+        self.quant_mul2 = nn.quantized.FloatFunctional()
+        self.quant_add = nn.quantized.FloatFunctional()
+
+    def forward(self, x):
+        out = self.quant_add.add_scalar(x, 3.0)
+        out = self.relu6(out)
+        out = self.quant_mul1.mul(x, out)
+        out = self.quant_mul2.mul_scalar(out, 1 / 6)
+        return out
+
+
+class ConvBNHswish(nn.Module):
+    """Conv -> BatchNorm -> hard-swish: the reference's `_ConvBNHswish` (mobilenetv3.py:72-88) in FrostNet's layer vocabulary (`conv` = the fusable
+    Conv2d + BatchNorm2d pair, `act` = Hswish)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
+        super(ConvBNHswish, self).__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias=False),
+                                  nn.BatchNorm2d(out_channels))
+        self.act = Hswish(True)
+
+    def forward(self, x):
+        return self.act(self.conv(x))
+
+    def fuse_model(self):
+        _fuse(self.conv, ['0', '1'])
+
+
 def _make_divisible(v, divisor=8, min_value=None):
     """frostnet.py:62-79."""
     if min_value is None:
@@ -73,8 +112,11 @@ class CascadePreExBottleneck(nn.Module):
     """The Frost bottleneck (frostnet.py:81-145)."""
 
     def __init__(self, in_channels, out_channels, quantized=False, kernel_size=3, stride=1, dilation=1, expand_ratio=6,
-                 reduce_factor=4, block_type='CAS'):
+                 reduce_factor=4, block_type='CAS', act='relu'):
         super(CascadePreExBottleneck, self).__init__()
+        if act not in ('relu', 'hswish'):
+            raise ValueError("act must be 'relu' (the reference's FrostNet) or 'hswish'")
+        ConvBNReLU = {'relu': globals()['ConvBNReLU'], 'hswish': ConvBNHswish}[act]      # the activated-layer class of this block
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.kernel_size = kernel_size
@@ -148,8 +190,9 @@ class _FrostBase(nn.Module):
         layers = list()
         for k, c, e, r, s in block_setting:
             out_channels = _make_divisible(int(c * width_mult))
+            extra = {} if getattr(self, "act", "relu") == "relu" else {"act": self.act}
             layers.append(block(self.in_channels, out_channels, quantized=self.quantized, kernel_size=k, stride=s,
-                                dilation=dilation, expand_ratio=e, reduce_factor=r))
+                                dilation=dilation, expand_ratio=e, reduce_factor=r, **extra))
             self.in_channels = out_channels
         return nn.Sequential(*layers)
 
@@ -169,7 +212,7 @@ class _FrostBase(nn.Module):
 
     def fuse_model(self):
         for m in self.modules():
-            if type(m) in [ConvBNReLU, ConvBN]:
+            if type(m) in [ConvBNReLU, ConvBN, ConvBNHswish]:
                 m.fuse_model()
 
     # ---- HIP execution --------------------------------------------------------------------------------
@@ -189,10 +232,27 @@ class _FrostBase(nn.Module):
 
     def __getstate__(self):
         """copy.deepcopy / pickle (EMA or best-model snapshots, torch.save(model)): the device executors are per-instance caches
-        and stay behind; the copy builds its own on first use."""
+        and stay behind; the copy builds its own on first use.  The observer / qparam buffers a bound model aliases onto the runner's qrecord
+        arena (float, int32, uint8 and int64 views of ONE storage: torch.save refuses such a set) are replaced by detached copies in the
+        pickled state, module by module, so whole-module pickling works like state_dict() does."""
         d = self.__dict__.copy()
-        d.pop("_hip_runner", None)
+        r = d.pop("_hip_runner", None)
         d.pop("_bf16_infer", None)
+        d.pop("_hip_converted", None)
+        arena = getattr(getattr(r, "qa", None), "t", None)
+        if arena is not None:
+            import copy as _copy
+            base = arena.untyped_storage().data_ptr()
+
+            def detach_aliases(mod):
+                new = _copy.copy(mod)                                   # shallow: parameters stay shared with the live module (deepcopy / pickle copy them)
+                new._buffers = {k: (v.detach().clone() if torch.is_tensor(v) and v.device == arena.device and v.untyped_storage().data_ptr() == base else v)
+                                for k, v in mod._buffers.items()}
+                new._modules = {k: (detach_aliases(c) if c is not None else None) for k, c in mod._modules.items()}
+                return new
+            d["_modules"] = {k: (detach_aliases(c) if c is not None else None) for k, c in self._modules.items()}
+            d["_buffers"] = {k: (v.detach().clone() if torch.is_tensor(v) and v.device == arena.device and v.untyped_storage().data_ptr() == base else v)
+                             for k, v in self._buffers.items()}
         return d
 
     def _is_qat_prepared(self):
@@ -217,16 +277,25 @@ class _FrostBase(nn.Module):
                 r = FloatRunner(self)
             r.is_qat = qat
             self.__dict__["_hip_runner"] = r
+            if qat and self.__dict__.get("_hip_converted", False) and not getattr(r, "converted", False):
+                # the converted state (int8 packs frozen at convert time) lived on the runner that was just replaced: converting again would move the
+                # weight observers a second time, silently running the fake-quant eval graph would be a different model -- refuse instead
+                raise RuntimeError("this model was hip_convert()-ed and its device executor had to be rebuilt (parameters or buffers moved): the frozen int8 "
+                                   "weights are gone; rebuild the QAT model, load its state and call hip_convert() again")
         return r
 
 
 class FrostNet(_FrostBase):
     def __init__(self, nclass=1000, mode='large', width_mult=1.0, quantized=False, bottleneck=CascadePreExBottleneck,
-                 drop_rate=0.2, dilated=False, **kwargs):
+                 drop_rate=0.2, dilated=False, act='relu', **kwargs):
         super(FrostNet, self).__init__()
         self.quantized = quantized
         if mode not in _SETTINGS:
             raise ValueError('Unknown mode.')
+        if act not in ('relu', 'hswish'):
+            raise ValueError("act must be 'relu' (the reference's FrostNet, frostnet.py:21) or 'hswish' (the quantizable hard-swish of its MobileNetV3 zoo)")
+        self.act = act                          # 'hswish': every ConvBNReLU of the network becomes ConvBNHswish (SURVEY N4 / north_star wording)
+        ConvBNReLU = {'relu': globals()['ConvBNReLU'], 'hswish': ConvBNHswish}[act]
         l1, l2, l3, l4, l5 = _SETTINGS[mode]
         self.in_channels = _make_divisible(int(32 * min(1.0, width_mult)))
         self.conv1 = ConvBNReLU(3, self.in_channels, 3, 2, 1)
@@ -252,6 +321,7 @@ class FrostNet(_FrostBase):
             raise RuntimeError("hip_convert needs the QAT-prepared model (fuse_model + prepare_qat), like torch.quantization.convert")
         self.eval()
         self.hip_runner().convert()
+        self.__dict__["_hip_converted"] = True       # survives a rebuild of the runner (model.to(), a moved parameter): hip_runner() re-applies convert()
         return self
 
     def hip_infer_bf16(self, x):

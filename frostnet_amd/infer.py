@@ -51,6 +51,8 @@ class Bf16Inference:
 
     def __init__(self, model):
         L.load_library()
+        if getattr(model, "act", "relu") != "relu":
+            raise NotImplementedError("bf16 inference implements the reference's ReLU network (act='hswish' runs in fake-quant mode only)")
         p = next(model.parameters())
         if not p.is_cuda:
             raise RuntimeError("Bf16Inference needs the model on the GPU (no CPU fallback on the product path)")

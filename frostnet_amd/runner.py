@@ -237,7 +237,22 @@ class FrostRunner:
         if pc:
             self._bind_weight_per_channel(m.weight_fake_quant, qw, l)
         l.bn_mod = m.bn
+        l.hswish = None
+        act = getattr(blk, "act", None)
+        if act is not None and type(act).__name__ == "Hswish":
+            # ConvBNHswish (frostnet.py surface of the reference's `_ConvBNHswish`): the conv emits as a linear ConvBn2d with its own output FakeQuantize, then
+            # the quantizable hard-swish -- FakeQuantize records of nn.ReLU6 and of quant_mul1 (both observed), plus the derived record of the result
+            # after mul_scalar(1/6) (same indices, scale / 6: not a module buffer)
+            l.hswish = (self._bind_fq(act.relu6.activation_post_process, self.qa.alloc()),
+                        self._bind_fq(act.quant_mul1.activation_post_process, self.qa.alloc()), self.qa.alloc())
         return self.E.add_layer(l)
+
+    def _conv(self, l, x, training, obs):
+        """ConvBN(ReLU) / ConvBNHswish forward on the engine."""
+        y = self.E.conv(l, x, training, obs)
+        if l.hswish is not None:
+            y = self.E.hswish(y, l.hswish[0], l.hswish[1], l.hswish[2], obs)
+        return y
 
     def _bind_block(self, pre, b):
         d = dict(mod=b, squeeze=None, conv1=None, q_cat=None, q_add=None)
@@ -258,11 +273,11 @@ class FrostRunner:
         out = inp
         if d["conv1"] is not None:
             if d["squeeze"] is not None:
-                sq = E.conv(d["squeeze"], inp, training, obs)
+                sq = self._conv(d["squeeze"], inp, training, obs)
                 out = E.cat(sq, inp, d["q_cat"], obs)
-            out = E.conv(d["conv1"], out, training, obs)
-        out = E.conv(d["conv2"], out, training, obs)
-        out = E.conv(d["reduce"], out, training, obs)
+            out = self._conv(d["conv1"], out, training, obs)
+        out = self._conv(d["conv2"], out, training, obs)
+        out = self._conv(d["reduce"], out, training, obs)
         if d["q_add"] is not None:
             out = E.add(inp, out, d["q_add"], obs)
         return out
@@ -271,6 +286,7 @@ class FrostRunner:
         m = self.model
         blocks = [b for layer in (m.layer1, m.layer2, m.layer3, m.layer4, m.layer5) for b in layer]
         nsites = sum(1 for mod in m.modules() if hasattr(mod, "observer_enabled")) + 16     # every FakeQuantize of the tree + slack
+        nsites += sum(1 for mod in m.modules() if type(mod).__name__ == "Hswish")              # + the derived output record of every hard-swish
         self.qa = QArena(nsites, self.device)
         self.rule127 = False
         self.q_in = self._bind_fq(m.quant.activation_post_process, self.qa.alloc())
@@ -358,8 +374,13 @@ class FrostRunner:
         the converted model computes on the QNNPACK engine -- int8 weights frozen at convert time, integer bias, fp32 requantisation,
         QNNPACK's fixed-point add, rounding average pool -- instead of the fake-quant eval graph (whose observers keep moving and whose
         pooled features are not re-quantised; the two differ by 8-25 % of the activations' indices, see tests/test_gpu_convert.py)."""
+        if getattr(self, "converted", False):
+            return self                          # idempotent: a second convert() must not move the weight observers again
         if self.cls is None:
             raise NotImplementedError("convert() is implemented for the classification model")
+        if any(getattr(l, "hswish", None) is not None for l in self.E.layers):
+            raise NotImplementedError("convert() of a hard-swish network: the converted-inference kernels restate the QNNPACK ReLU graph; the "
+                                      "hard-swish variant runs the fake-quant graph (train / eval)")
         if any(l.per_channel for l in self.E.layers):
             raise NotImplementedError("convert() restates the QNNPACK kernels (per-tensor weights); a per-channel (fbgemm qconfig) model "
                                       "runs the fake-quant graph only")
@@ -426,7 +447,7 @@ class FrostRunner:
         self._obs = obs
         E.begin_step(observe=obs)
         a = E.quantize_input(x, self.q_in, observe=obs)
-        a = E.conv(self.stem, a, training, obs)
+        a = self._conv(self.stem, a, training, obs)
         feats = []
         for d in self.blocks:
             a = self.block_forward(d, a, training, obs)
@@ -458,7 +479,7 @@ class FrostRunner:
         if x.dtype != torch.float32:
             x = x.float()
         a, _ = self._trunk(x, training)
-        a = self.E.conv(self.last, a, training, self._obs)
+        a = self._conv(self.last, a, training, self._obs)
         drop = None
         drop_rate = float(self.model.classifier[1].p)
         if training and drop_rate > 0.0:

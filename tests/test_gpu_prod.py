@@ -18,8 +18,8 @@ from oracle import frost_oracle as O
 
 pytestmark = pytest.mark.gpu
 FLIP = 5e-4
-FLIP_SOLID = 2e-4     # index mismatches where the reference's fp32 and fp64 evaluations agree (the device's own two fp32 roundings)
-FLIP_ANY = 3e-3       # all index mismatches, ties of the reference included
+FLIP_SOLID = 2e-5     # index mismatches where the reference's fp32 and fp64 evaluations agree (the device's own two fp32 roundings): measured <= 6.0e-6 over 95 layer-steps
+FLIP_ANY = 1e-4       # all index mismatches, ties of the reference included: measured <= 1.6e-5
 GRAD = 2e-2
 
 

@@ -250,3 +250,118 @@ def test_epoch_loops_and_checkpoint_resume(engine, tmp_path):
     torch.cuda.synchronize()
     for (n, p), p3 in zip(model.named_parameters(), model3.parameters()):
         assert torch.equal(p, p3), n
+
+
+# ------------------------------------------------------------------------------------------------ quantizable hard-swish reachable from the module surface
+def test_hswish_bottleneck_device_vs_stock_modules(engine):
+    """`act="hswish"` puts the reference's quantizable `_Hswish` (Classification/models/imagenet/mobilenetv3.py:43-56, restated as
+    frostnet_amd.frostnet.Hswish with the same FloatFunctional attribute names) behind every activated layer of a Frost bottleneck.  CPU = the
+    stock torch QAT modules prepare_qat builds from it (what the reference's zoo executes); device = ConvBn2d emit + Engine.hswish.  Two training
+    steps, teacher-forced input: outputs within one quantisation step, input and parameter gradients at the bf16-storage level."""
+    import copy
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    from frostnet_amd import frostnet as F, runner as R
+    torch.manual_seed(3)
+    torch.set_num_threads(16)
+    m = F.CascadePreExBottleneck(80, 80, quantized=True, kernel_size=5, stride=1, expand_ratio=3, reduce_factor=4, act="hswish")
+    assert isinstance(m.conv1, F.ConvBNHswish) and isinstance(m.reduce_conv, F.ConvBN)
+    _randomize_bn(m, 21)
+    m.train()
+    for mod in m.modules():
+        if type(mod) in (F.ConvBNReLU, F.ConvBN, F.ConvBNHswish):
+            mod.fuse_model()
+    m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+    prepare_qat(m, inplace=True)
+    keys = list(m.state_dict().keys())
+    assert "conv1.act.quant_mul1.activation_post_process.scale" in keys and "conv1.act.relu6.activation_post_process.scale" in keys      # the reference's key names
+    ref = copy.deepcopy(m)
+    m.cuda()
+    run = R.FrostRunner.for_block(m)
+    qx = run.qa.alloc()
+    in_scale, in_zp, N, H = 0.0417, 117, 8, 14
+    run.qa.set_qparams(qx, in_scale, in_zp)
+    xi = torch.from_numpy(np.clip(np.round(O.synth((N, 80, H, H), 31) * 35 + 120), 0, 255).astype(np.uint8))
+    xf = (xi.float() - in_zp) * in_scale
+    qx[4], qx[5] = float(xf.min()), float(xf.max())
+
+    def relerr(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for step in range(2):
+        gr = torch.from_numpy(O.synth((N, 80, H, H), 60 + step))
+        xr = xf.clone().requires_grad_(True)
+        ref.zero_grad()
+        yr = ref(xr)
+        yr.backward(gr.bfloat16().float())
+        run.E.begin_step()
+        x = run.E.act_from_indices(xi, qx)
+        y = run.block_forward(run.block, x, True, True)
+        yd = y.dequant().cpu()
+        y.grad = engine.float_to_grad(gr.cuda())
+        run.bind_grads()
+        run.E.backward()
+        torch.cuda.synchronize()
+        ysc = float(ref.skip_add.activation_post_process.scale[0])
+        d = (yd - yr.detach()).abs() / ysc
+        e_dx = relerr(engine.grad_to_float(x.grad, x.n, x.h, x.w, x.c).cpu(), xr.grad)
+        worst = max((relerr(p.grad.cpu(), dict(ref.named_parameters())[n].grad), n) for n, p in m.named_parameters())
+        print(f"[hswish block step {step}] y: max {float(d.max()):.2f} steps, off by > 0.5 step {float((d > 0.5).float().mean()):.2e}; dx {e_dx:.2e}; worst parameter gradient {worst[0]:.2e} ({worst[1]})")
+        assert float(d.max()) <= 2.01 and float((d > 0.5).float().mean()) <= 2e-2
+        assert e_dx <= 5e-2 and worst[0] <= 5e-2, (e_dx, worst)
+        sd_d, sd_r = m.state_dict(), ref.state_dict()
+        for k in ("conv1.act.relu6.activation_post_process.scale", "conv1.act.quant_mul1.activation_post_process.scale", "conv2.act.quant_mul1.activation_post_process.scale",
+                  "squeeze_conv.act.quant_mul1.activation_post_process.activation_post_process.max_val"):
+            np.testing.assert_allclose(sd_d[k].float().cpu().numpy().reshape(-1), sd_r[k].float().numpy().reshape(-1), rtol=2e-3, atol=1e-6, err_msg=k)
+
+
+def test_hswish_network_builds_trains_and_refuses_unsupported_modes(engine):
+    """FrostNet(act='hswish'): a QAT training step on the device (finite loss, non-zero gradients everywhere), eval forward, and the documented refusals
+    (float warm-up kernels, bf16 inference and convert() implement the reference's ReLU network only)."""
+    from frostnet_amd import frostnet as F
+    torch.manual_seed(5)
+    model = F.FrostNet(nclass=1000, mode="small", quantized=True, drop_rate=0.0, act="hswish")
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    loss = torch.nn.functional.cross_entropy(model(x), torch.tensor([1, 2, 3, 4], device="cuda"))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    dead = [n for n, p in model.named_parameters() if p.grad is None or not np.isfinite(float(p.grad.norm())) or float(p.grad.norm()) == 0.0]
+    assert not dead, dead
+    model.eval()
+    with torch.no_grad():
+        assert model(x).shape == (4, 1000)
+    with pytest.raises(NotImplementedError):
+        model.hip_convert()
+    fm = F.FrostNet(mode="small", act="hswish").cuda()
+    with pytest.raises(NotImplementedError):
+        fm(x)
+
+
+def test_convert_is_idempotent_and_refuses_a_silent_revert(engine):
+    """the converted state lives on the device executor.  A second hip_convert() must not move the weight observers again, and a rebuilt
+    executor (parameters moved) must not silently fall back to the fake-quant eval graph -- a different model (tests/test_gpu_convert.py)."""
+    import copy
+    from frostnet_amd import frostnet as F
+    torch.manual_seed(11)
+    model = F.MODEL_REGISTRY["frostnet_quant_small_1_0"](drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    with torch.no_grad():
+        model(x)
+    model.hip_convert()
+    with torch.no_grad():
+        a = model(x).clone()
+    wmax = model.conv1.conv[0].weight_fake_quant.activation_post_process.max_val.clone()
+    model.hip_convert()                                   # no-op
+    with torch.no_grad():
+        b = model(x)
+    assert torch.equal(a, b) and torch.equal(wmax, model.conv1.conv[0].weight_fake_quant.activation_post_process.max_val)
+    snap = copy.deepcopy(model)                           # a copy is a fresh QAT model (its own executor, not converted)
+    with torch.no_grad():
+        assert snap.eval()(x).shape == a.shape
+    model.conv1.conv[0].weight.data = model.conv1.conv[0].weight.data.clone()        # a parameter moved: the executor must be rebuilt ...
+    with pytest.raises(RuntimeError, match="hip_convert"):
+        with torch.no_grad():
+            model(x)                                      # ... and refuses to serve the fake-quant graph in place of the converted model
