@@ -13,6 +13,7 @@ P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_QMAX, Q_OBS_EN, Q_FQ_EN, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12
 COEF_ROWS = 8
+COEF_A, COEF_B = 0, 1
 STATS_BYTES_PER_CH = 24
 
 
@@ -34,9 +35,13 @@ class FrostFDesc(C.Structure):
                 ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("fp32", C.c_int32)]
 
 
+TICKET_WORDS = 40      # FROST_TICKET_WORDS: zeroed uint32 words behind every last-workgroup-done ticket (main counter + 32 sub-counters)
+
+
 class FrostFinDesc(C.Structure):
     _fields_ = [("qrec_w", P), ("gamma", P), ("beta", P), ("rmean", P), ("rvar", P), ("nbt", P), ("coef", P), ("qrec_y", P), ("counter", P),
-                ("training", C.c_int32), ("relu", C.c_int32), ("observe", C.c_int32), ("reserved", C.c_int32), ("wscale", P)]
+                ("training", C.c_int32), ("relu", C.c_int32), ("observe", C.c_int32), ("reserved", C.c_int32), ("wscale", P),
+                ("cat_qrec_b", P), ("cat_qrec_y", P)]
 
 
 class FrostGDesc(C.Structure):
@@ -87,6 +92,7 @@ _PROTOS = {
     "frost_pw_bwd_fused_ok": [L, I, I],
     "frost_pw_conv_int": [P, P, P, P, L, I, I, P, P],
     "frost_pw_ew": [P, L, I, P, P, I, I, P, P, P],
+    "frost_pw_ew_emit_add": [P, L, I, P, P, I, P, P, P, P, P, I, P],
     "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_pw_dgrad_wide_ok": [L, I, I],
     "frost_pw_dgrad_wide": [P, P, P, L, I, I, P, I, P],

@@ -153,7 +153,8 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
 // with agent-scope loads.  sh: >= 2 * (nthr / 64) floats of shared memory.
 __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, int cout, int cpad, const float* qx, const float* qw, const float* wscale,
                                          const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
-                                         int relu, int observe, int have_stats, float* coef, float* qy, int tid, int nthr, float* sh) {
+                                         int relu, int observe, int have_stats, float* coef, float* qy, int tid, int nthr, float* sh,
+                                         const float* cat_qb = nullptr, float* cat_qy = nullptr) {
   const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
   const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
   const float sx = qx[FROST_Q_SCALE], sw0 = qw[FROST_Q_SCALE];
@@ -207,6 +208,8 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
     if (training && nbt) *nbt += 1;
     if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe);
     else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
+    // squeeze_conv of a Frost bottleneck: the cat's FakeQuantize sees min / max of the fake-quantised halves (k_cat_observe's expression)
+    if (cat_qy) observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_qb[FROST_Q_FQMIN]), fmaxf(qy[FROST_Q_FQMAX], cat_qb[FROST_Q_FQMAX]), 0, 0, observe);
   }
 }
 
@@ -222,6 +225,39 @@ __device__ __forceinline__ bool last_block_done(uint32_t* counter, unsigned tota
     const unsigned t = atomicAdd(counter, 1u);
     *sflag = (t == total - 1u) ? 1 : 0;
     if (t == total - 1u) *counter = 0u;    // re-armed for the next step
+  }
+  __syncthreads();
+  return *sflag != 0;
+}
+
+// Two-level ticket for launches of many workgroups that finish together.  Same-address device-scope atomics are serialised at the memory side
+// (~45 ns each, measured: 46 us for the 1024 equal workgroups of an element-wise pass), so the tail of a last-workgroup-done kernel grows with its
+// grid.  Here workgroup b takes a ticket of sub-counter 1 + (b mod 32) (32 addresses: 32 chains run in parallel), and the workgroup that completes a
+// sub-counter takes one of the main counter: 2 x ~total/32 serialised atomics instead of `total`.  counter: FROST_TICKET_WORDS zeroed uint32, left
+// zeroed.  Visibility argument as for last_block_done: every atomic is performed at the coherence point before its workgroup's ticket.
+__device__ __forceinline__ bool last_block_done2(uint32_t* counter, unsigned total, int* sflag) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int last = 0;
+#ifdef FROST_TICKET_SINGLE
+    if (true) {
+#else
+    if (total <= 64u) {
+#endif
+      const unsigned t = atomicAdd(counter, 1u);
+      if (t == total - 1u) { *counter = 0u; last = 1; }
+    } else {
+      const unsigned b = blockIdx.x + blockIdx.y * gridDim.x, s = b & 31u;
+      const unsigned mine = (total - s + 31u) >> 5;                   // workgroups with linear index = s (mod 32)
+      const unsigned t = atomicAdd(counter + 1 + s, 1u);
+      if (t == mine - 1u) {
+        counter[1 + s] = 0u;
+        const unsigned t2 = atomicAdd(counter, 1u);
+        if (t2 == 31u) { *counter = 0u; last = 1; }
+      }
+    }
+    *sflag = last;
   }
   __syncthreads();
   return *sflag != 0;

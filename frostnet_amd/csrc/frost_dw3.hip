@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
     }
     if (MODE == D_STATS && p.fin_on) {       // last workgroup done -> conv finalize in this launch (see frost_common.h)
       int* sflag = (int*)smem;
-      if (last_block_done(p.fin.counter, gridDim.x, sflag)) {
+      if (last_block_done2(p.fin.counter, gridDim.x, sflag)) {
         float* sh = (float*)(smem + 16);
         conv_finalize_dev(p.stats, (int64_t)p.n * p.ho * p.wo, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar,
                           p.fin.nbt, p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh);

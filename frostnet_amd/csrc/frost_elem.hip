@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a
   block_minmax_commit(lo, hi, out2);
   if (ticket) {        // last workgroup done: the range is complete -> observer update here (no launch of its own), range words re-armed for the next add
     __shared__ int sflag;
-    if (last_block_done(ticket, gridDim.x, &sflag) && threadIdx.x == 0) {
+    if (last_block_done2(ticket, gridDim.x, &sflag) && threadIdx.x == 0) {
       const float flo = __hip_atomic_load(out2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fhi = __hip_atomic_load(out2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       observer_update_dev(qy, flo, fhi, 0, 0, observe);
       __hip_atomic_store(out2, INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(out2 + 1, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -693,10 +693,10 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     }
     if (p.fin_on) {            // last workgroup done: the layer's statistics are complete -> conv finalize here instead of in its own launch
       int* sflag = (int*)smem;
-      if (last_block_done(p.fin.counter, p.fin_total, sflag)) {
+      if (last_block_done2(p.fin.counter, p.fin_total, sflag)) {
         float* sh = (float*)(smem + 16);
         conv_finalize_dev(p.stats, p.npix, p.cout, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
-                          p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 512, sh);
+                          p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 512, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
       }
     }
   } else if (MODE == M_BRED) {

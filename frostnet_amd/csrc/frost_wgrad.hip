@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
         }
       }
       __shared__ int sflag;
-      if (last_block_done(fin.counter, gridDim.x * gridDim.y, &sflag)) {
+      if (last_block_done2(fin.counter, gridDim.x * gridDim.y, &sflag)) {
         float* sh = (float*)wl;
         __syncthreads();
         conv_finalize_dev(stats, npix, cin, cpadn, qx, fin.qrec_w, fin.wscale, fin.gamma, fin.beta, fin.rmean, fin.rvar, fin.nbt, fin.training, fin.relu, fin.observe, 1,
@@ -629,4 +629,82 @@ extern "C" int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, floa
   else if (mode == 1) hipLaunchKernelGGL(k_pw_ew<1>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, dc, frost_sr_enabled(), (int8_t*)nullptr);
   else hipLaunchKernelGGL(k_pw_ew<2>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count, gout, (uint16_t*)nullptr, 0, (int8_t*)out);
   return frost_check_launch("pw_ew");
+}
+
+
+// ---- block-boundary fusion (first piece): the emit pass of a kept-conv-output reduce layer TOGETHER with the range pass of the residual add
+// that consumes it (frostnet.py:138-142: out = reduce_conv(out); out = skip_add.add(x, out)).  One sweep over the integer conv output writes the layer's
+// int8 output y AND accumulates min / max of (x + y) in the reference's fp32 arithmetic (k_add_minmax's expression, same operand order); the last
+// workgroup runs the MovingAverageMinMax update of the add's FakeQuantize.  Replaces frost_pw_ew(mode 2) + frost_add_minmax_observe: one launch and one
+// read of y fewer per residual block.  state3 = {lo, hi, ticket}: (+inf, -inf, 0) on entry and again on exit.
+__global__ __launch_bounds__(256) void k_pw_ew_emit_add(const int32_t* __restrict__ cint, int64_t npix, int cout, int cpad, const float* __restrict__ coef, const float* qy, int relu,
+                                                        const int8_t* __restrict__ a, const float* qa, int8_t* __restrict__ yq, float* state3, float* qsum, int observe) {
+  const int tid = threadIdx.x;
+  const int c4n = cout >> 2;
+  const int64_t PP = ((int64_t)gridDim.x * 256) / c4n;
+  const int64_t tt = (int64_t)blockIdx.x * 256 + tid;
+  const int c4 = (int)(tt % c4n); const int64_t slot = tt / c4n;
+  const int ch = c4 * 4;
+  const QP A = load_qp(qa), Y = load_qp(qy);
+  const float y_inv = 1.0f / qy[FROST_Q_SCALE];
+  const float y_zpf = (float)Y.zp, qcap = (float)q_hi(qy); const bool lowq = qcap < 255.0f;
+  float cA[4], cB[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { cA[r] = coef[FROST_COEF_A * cpad + ch + r]; cB[r] = coef[FROST_COEF_B * cpad + ch + r]; }
+  float lo = INFINITY, hi = -INFINITY;
+  if (slot < PP) {
+    for (int64_t p0 = slot; p0 < npix; p0 += 4 * PP) {
+      v4i cv[4]; uint32_t av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u * PP; cv[u] = (v4i){0, 0, 0, 0}; av[u] = 0;
+        if (p < npix) { cv[u] = *(const v4i*)(cint + p * cout + ch); av[u] = *(const uint32_t*)(a + p * cout + ch); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u * PP;
+        if (p >= npix) continue;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yv = fmaf(cA[r], (float)cv[u][r], cB[r]);
+          float qv = rintf(yv * y_inv) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);       // saturates at 0 and 255: the index the emit pass stores
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = (int)((packed >> (8 * r)) & 255u);
+          const float v = (float)((int)(int8_t)(av[u] >> (8 * r)) + 128 - A.zp) * A.scale + (float)(qi - Y.zp) * Y.scale;
+          lo = fminf(lo, v); hi = fmaxf(hi, v);
+        }
+        *(uint32_t*)(yq + p * cout + ch) = packed ^ 0x80808080u;
+      }
+    }
+  }
+  __shared__ float slo[4], shi[4]; __shared__ int sflag;
+  lo = wave_min(lo); hi = wave_max(hi);
+  if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
+    if (lo < __hip_atomic_load(state3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_f32(state3, lo);
+    if (hi > __hip_atomic_load(state3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_f32(state3 + 1, hi);
+  }
+  if (last_block_done2((uint32_t*)(state3 + 2), gridDim.x, &sflag) && tid == 0) {
+    const float flo = __hip_atomic_load(state3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fhi = __hip_atomic_load(state3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    observer_update_dev(qsum, flo, fhi, 0, 0, observe);
+    __hip_atomic_store(state3, INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(state3 + 1, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+extern "C" int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const int8_t* a,
+                                    const float* qrec_a, int8_t* y, float* state3, float* qrec_sum, int observe, void* stream) {
+  FROST_REQUIRE((cout & 3) == 0 && conv_out && a && y && state3 && qrec_sum, "pw_ew_emit_add: cout must be a multiple of 4, all buffers given");
+  const int cpad = round_up(cout, 16); const int c4n = cout >> 2;
+  const int64_t tot = npix * c4n;
+  int64_t grid = (tot + 255) / 256; if (grid > 1024) grid = 1024;           // few, fat workgroups: every one ends with two float atomics on ONE pair of words
+  const int64_t gmin = (c4n + 255) / 256; if (grid < gmin) grid = gmin;
+  hipLaunchKernelGGL(k_pw_ew_emit_add, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, a, qrec_a, y, state3,
+                     qrec_sum, observe);
+  return frost_check_launch("pw_ew_emit_add");
 }

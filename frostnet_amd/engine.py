@@ -27,6 +27,11 @@ _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B 
 _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
 _PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
+_BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary folds: the cat's observer update rides in the squeeze's finalize tail
+# reduce emit + residual-add range pass in one launch (frost_pw_ew_emit_add).  Bit-identical to the two launches it replaces, but NOT faster: measured 24.8-24.9 ms
+# per step with it vs 24.7-24.8 without (profiles/r03_block_fusion_ab.txt) -- the element-wise kernels' time is their single-workgroup observer tail, which
+# the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
+_BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 # depthwise weight gradients of maps no wider than this also go to the second stream.  Measured (two boxes, 2-3 runs each): 14 -> -0.2 ms, but
@@ -36,13 +41,15 @@ _DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
         self.grad = None
         self.needs_grad = True
         self.cint = None          # wide-K pointwise layers: the integer conv output this activation was emitted from, kept for the backward
+        self.cat_observed = False  # the cat consuming this activation already had its FakeQuantize record updated (folded into this layer's finalize)
+        self.sum_observed = False  # the residual add consuming this activation already had its range pass (fused into this layer's emit)
 
     @property
     def npix(self):
@@ -135,7 +142,7 @@ class ConvLayer:
         self.coef = torch.zeros(L.COEF_ROWS, self.cpad, dtype=torch.float32, device=dev)
         self.sigma = torch.ones(self.cout, dtype=torch.float32, device=dev)
         self.stats = None       # view into the engine's stats arena
-        self.fin_counter = torch.zeros(1, dtype=torch.int32, device=dev)     # last-workgroup-done ticket of the statistics pass
+        self.fin_counter = torch.zeros(L.TICKET_WORDS, dtype=torch.int32, device=dev)     # last-workgroup-done tickets of the statistics pass (two-level, frost_common.h)
         self.bn_mod = None      # the BatchNorm2d module (its .training flag is checked by the runner)
         self.dwq = None         # fp32 scratch for dL/d(fake-quantised weight)
 
@@ -260,8 +267,13 @@ class Engine:
         else:
             raise ValueError(l.kind)
 
-    def conv(self, l, x, training=True, observe=True):
-        """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute)."""
+    def conv(self, l, x, training=True, observe=True, residual=None, cat=None):
+        """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute).
+        residual = (a, q_sum): this layer is a bottleneck's reduce_conv whose output goes straight into skip_add.add(a, .) with FakeQuantize record
+        q_sum -- where the layer keeps its integer conv output, the emit pass and the add's range / observer pass are ONE launch
+        (frost_pw_ew_emit_add); the returned activation then carries `sum_observed = True` and Engine.add skips its own range pass.
+        cat = (q_b, q_cat): this layer is a squeeze_conv whose output is concatenated with an activation of record q_b under the FakeQuantize record
+        q_cat: that record is updated in this layer's finalize tail (`cat_observed = True` on the result; Engine.cat skips frost_cat_observe)."""
         pad = (l.k - 1) // 2
         ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
         if l.kind == "stem":      # im2col once (kept for the backward wgrad), then the pointwise int8-MFMA kernels
@@ -276,7 +288,10 @@ class Engine:
             # statistics pass with the finalize folded into its last workgroup (two launches per conv forward instead of three)
             fin = L.FrostFinDesc(l.qw.data_ptr(), l.gamma.data_ptr(), l.beta.data_ptr(), l.rmean.data_ptr(), l.rvar.data_ptr(), l.nbt.data_ptr(),
                                  l.coef.data_ptr(), l.qy.data_ptr(), l.fin_counter.data_ptr(), 1 if training else 0, int(l.relu), 1 if observe else 0, 0,
-                                 l.wscale.data_ptr())
+                                 l.wscale.data_ptr(), None, None)
+            cat_fold = cat is not None and _BLOCK_FUSE and l.kind == "pw" and not (_PW_KEEP and x.c > 256 and l.cout < x.c)
+            if cat_fold:                  # squeeze_conv: the cat's FakeQuantize record is updated in this layer's finalize tail (no frost_cat_observe launch)
+                fin.cat_qrec_b, fin.cat_qrec_y = cat[0].data_ptr(), cat[1].data_ptr()
             nb = x.numel + l.wq_pack.numel()
             if _PW_KEEP and l.kind == "pw" and x.c > 256 and l.cout < x.c:
                 # wide-K reduce layer (x rows too long for k_pw's DMA tile, Cout < Cin: the int32 output is smaller than the x re-reads it saves): statistics + finalize on the stand-alone int8 GEMM kernel, which also stores the
@@ -284,8 +299,14 @@ class Engine:
                 cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
                 call("frost_pw_conv_fwd_keep", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(cint),
                      stream(), prof=("pw_fwd_stats", nb + 4 * y.numel))
-                call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 2, None, ptr(y.buf), stream(),
-                     prof=("pw_fwd_emit", 5 * y.numel))
+                if residual is not None and observe and _BLOCK_EMIT_ADD:
+                    a, q_sum = residual
+                    call("frost_pw_ew_emit_add", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(a.buf), ptr(a.q), ptr(y.buf), ptr(self._add_state()),
+                         ptr(q_sum), 1, stream(), prof=("pw_fwd_emit_add", 6 * y.numel))
+                    y.sum_observed = True
+                else:
+                    call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 2, None, ptr(y.buf), stream(),
+                         prof=("pw_fwd_emit", 5 * y.numel))
                 if getattr(self, "trace", None) is not None:
                     self.trace.append((l.name, y))
                 self.tape.append(("conv", l, x, y))
@@ -304,6 +325,8 @@ class Engine:
                  ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
                  1 if observe else 0, ptr(l.coef), ptr(l.qy), ptr(l.wscale), stream())
         self._conv_launch(l, x, 1, y)
+        if need_stats and _FIN_FOLD and cat is not None and cat_fold:
+            y.cat_observed = True
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
         self.tape.append(("conv", l, x, y))
@@ -311,7 +334,8 @@ class Engine:
 
     def cat(self, a, b, q, observe=True):
         """FloatFunctional.cat + its FakeQuantize (frostnet.py:129)."""
-        call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
+        if not getattr(a, "cat_observed", False):
+            call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
         y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
         call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream(),
              prof=("cat_fwd", 2 * y.numel))
@@ -320,12 +344,15 @@ class Engine:
         self.tape.append(("cat", a, b, y))
         return y
 
+    def _add_state(self):
+        if not hasattr(self, "_add_mm"):      # {lo, hi, arrival ticket}: armed once, every launch leaves it armed again
+            self._add_mm = torch.tensor([float("inf"), float("-inf")] + [0.0] * L.TICKET_WORDS, dtype=torch.float32, device=self.device)
+        return self._add_mm
+
     def add(self, a, b, q, observe=True):
         """FloatFunctional.add + its FakeQuantize (frostnet.py:142)."""
-        if not hasattr(self, "_add_mm"):      # {lo, hi, arrival ticket}: armed once, every launch leaves it armed again
-            self._add_mm = torch.tensor([float("inf"), float("-inf"), 0.0], dtype=torch.float32, device=self.device)
-        if observe:                           # range of the sum + observer update in one launch (the update runs in the last workgroup)
-            call("frost_add_minmax_observe", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_mm), ptr(q), 1, stream(),
+        if observe and not getattr(b, "sum_observed", False):       # range of the sum + observer update in one launch (the update runs in the last workgroup)
+            call("frost_add_minmax_observe", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(self._add_state()), ptr(q), 1, stream(),
                  prof=("add_fwd_minmax", 2 * a.numel))
         y = self.new_act(a.n, a.h, a.w, a.c, q)
         call("frost_add_requant", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream(),

@@ -273,13 +273,18 @@ class FrostRunner:
         out = inp
         if d["conv1"] is not None:
             if d["squeeze"] is not None:
-                sq = self._conv(d["squeeze"], inp, training, obs)
+                if d["squeeze"].hswish is None:
+                    sq = E.conv(d["squeeze"], inp, training, obs, cat=(inp.q, d["q_cat"]))       # the cat's observer update rides in the squeeze's finalize tail
+                else:
+                    sq = self._conv(d["squeeze"], inp, training, obs)
                 out = E.cat(sq, inp, d["q_cat"], obs)
             out = self._conv(d["conv1"], out, training, obs)
         out = self._conv(d["conv2"], out, training, obs)
-        out = self._conv(d["reduce"], out, training, obs)
         if d["q_add"] is not None:
+            out = E.conv(d["reduce"], out, training, obs, residual=(inp, d["q_add"]))      # reduce_conv is linear (never hard-swish): straight to the engine
             out = E.add(inp, out, d["q_add"], obs)
+        else:
+            out = self._conv(d["reduce"], out, training, obs)
         return out
 
     def _build(self):

@@ -137,7 +137,7 @@ int frost_cat_requant(const int8_t* a, const float* qrec_a, int ca, const int8_t
 int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                      float* minmax2, void* stream);
 /* the same range pass with the MovingAverageMinMax update of the sum's FakeQuantize folded into its last workgroup (replaces frost_fill_minmax +
- * frost_add_minmax + frost_observer_update: one launch instead of three).  state3 = {lo, hi, arrival ticket}: (+inf, -inf, 0) on entry and again on exit. */
+ * frost_add_minmax + frost_observer_update: one launch instead of three).  state3 = {lo, hi, arrival ticket[FROST_TICKET_WORDS]}: (+inf, -inf, 0...) on entry and again on exit. */
 int frost_add_minmax_observe(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                              float* state3, float* qrec_y, int observe, void* stream);
 int frost_add_requant(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
@@ -331,13 +331,18 @@ int frost_gradboost_step(const FrostOptTensor* table, int ntensors, int64_t max_
 /* ---- statistics pass with the finalize folded into its tail --------------------------------------------------------------------------
  * frost_pw_conv_fwd / frost_dw_conv_fwd (mode 0) + frost_conv_finalize in ONE launch: the last workgroup to finish (device-scope ticket)
  * turns the integer statistics into the BN coefficients / running statistics / activation qparams, so a conv forward is two launches
- * (statistics+finalize, emit) instead of three.  `fin` is a HOST struct (copied into the kernel arguments); `counter` is one zeroed uint32
- * per layer in device memory (re-armed by the kernel). */
+ * (statistics+finalize, emit) instead of three.  `fin` is a HOST struct (copied into the kernel arguments); `counter` is FROST_TICKET_WORDS
+ * zeroed uint32 per layer in device memory (two-level arrival ticket: 32 sub-counters, re-armed by the kernel). */
+#define FROST_TICKET_WORDS 40
 typedef struct {
   const float* qrec_w; const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;
   float* coef; float* qrec_y; uint32_t* counter;
   int32_t training, relu, observe, reserved;
   const float* wscale;     /* [cpad] per-output-channel weight scale (FrostWDesc.wscale); NULL = qrec_w's scalar */
+  /* block-level fold: when this layer is a bottleneck's squeeze_conv, the FakeQuantize of quant_cat.cat([squeezed, x]) (frostnet.py:129)
+   * is updated right here, in the same last-workgroup tail, from the fake-quantised ranges of the two halves -- frost_cat_observe without its launch.
+   * cat_qrec_b = the qrecord of x (the second half), cat_qrec_y = the cat site's qrecord; both NULL = no fold. */
+  const float* cat_qrec_b; float* cat_qrec_y;
 } FrostFinDesc;
 int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
                           void* stats, const FrostFinDesc* fin, void* stream);
@@ -347,6 +352,14 @@ int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
  * kernel, conv_out stored; frost_pw_ew mode 2 emits y from it, and the backward needs no recomputation at all */
 int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
                            void* stats, const FrostFinDesc* fin, int32_t* conv_out, void* stream);
+
+/* ---- block-level fusion across the reduce_conv -> skip_add boundary of a Frost bottleneck -------------------------------------
+ * replaces: the activation FakeQuantize of reduce_conv (emit: frost_pw_ew mode 2) TOGETHER with the observer pass of FloatFunctional.add(x, out)
+ * (frostnet.py:138-142; frost_add_minmax_observe): y = emit(conv_out) is written and min / max of dequant(a) + dequant(y) -- the reference's fp32
+ * expression -- go through the MovingAverageMinMax update of `qrec_sum` in the kernel's last workgroup.  frost_add_requant then emits the sum.
+ * state3 = {lo, hi, ticket} as for frost_add_minmax_observe. */
+int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const int8_t* a,
+                         const float* qrec_a, int8_t* y, float* state3, float* qrec_sum, int observe, void* stream);
 
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).

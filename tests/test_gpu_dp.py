@@ -172,4 +172,5 @@ def test_bench_gpus2_spawns_two_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 64 and rec["config"]["hip_graph"] is True
-    assert "buckets overlapped" in rec["config"]["grad_allreduce"] and rec["value"] > 0
+    ga = rec["config"]["grad_allreduce"]
+    assert "buckets overlapped" in ga["mode"] and ga["fallback"] is None and len(ga["buckets"]) >= 2 and rec["value"] > 0

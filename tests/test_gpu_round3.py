@@ -365,3 +365,35 @@ def test_convert_is_idempotent_and_refuses_a_silent_revert(engine):
     with pytest.raises(RuntimeError, match="hip_convert"):
         with torch.no_grad():
             model(x)                                      # ... and refuses to serve the fake-quant graph in place of the converted model
+
+
+def test_fused_reduce_emit_and_add_range_pass_equals_the_two_launches(engine):
+    """frost_pw_ew_emit_add (block-boundary fusion) against frost_pw_ew(mode 2) + frost_add_minmax_observe on the same kept conv output:
+    the int8 output and every field of the add's qrecord (EMA'd min / max, scale, zero point, fake-quantised range) must be bit-identical, for both the
+    first observation (copy) and the moving average, and the {lo, hi, ticket} state must come back armed."""
+    from frostnet_amd import _lib as L
+    dev = "cuda"
+    g = torch.Generator().manual_seed(21)
+    for npix, cout in ((512 * 49, 192), (512 * 196, 80), (777, 96)):
+        cint = torch.randint(-60000, 60000, (npix * cout + 64,), generator=g, dtype=torch.int32).to(dev)
+        cpad = (cout + 15) // 16 * 16
+        coef = torch.zeros(L.COEF_ROWS, cpad, device=dev)
+        coef[L.COEF_A, :cout] = (torch.rand(cout, generator=g) * 4e-5 + 2e-5).to(dev)
+        coef[L.COEF_B, :cout] = (torch.rand(cout, generator=g) * 0.4 - 0.2).to(dev)
+        qa_, qy_ = engine.QArena(6, dev), None
+        qy, qa, qs1, qs2 = qa_.alloc(), qa_.alloc(), qa_.alloc(), qa_.alloc()
+        engine.QArena.set_qparams(qy, 0.0213, 121)
+        engine.QArena.set_qparams(qa, 0.0377, 109)
+        a = torch.randint(-128, 127, (npix * cout + 64,), generator=g, dtype=torch.int8).to(dev)
+        y1, y2 = torch.zeros(npix * cout + 64, dtype=torch.int8, device=dev), torch.zeros(npix * cout + 64, dtype=torch.int8, device=dev)
+        st1 = torch.tensor([float("inf"), float("-inf")] + [0.0] * L.TICKET_WORDS, device=dev)
+        st2 = st1.clone()
+        for rep in range(2):                                  # rep 0: first observation; rep 1: exponential moving average
+            L.call("frost_pw_ew", L.ptr(cint), npix, cout, L.ptr(coef), L.ptr(qy), 0, 2, None, L.ptr(y1), L.stream())
+            L.call("frost_add_minmax_observe", L.ptr(a), L.ptr(qa), L.ptr(y1), L.ptr(qy), npix * cout, L.ptr(st1), L.ptr(qs1), 1, L.stream())
+            L.call("frost_pw_ew_emit_add", L.ptr(cint), npix, cout, L.ptr(coef), L.ptr(qy), 0, L.ptr(a), L.ptr(qa), L.ptr(y2), L.ptr(st2), L.ptr(qs2), 1, L.stream())
+            torch.cuda.synchronize()
+            assert torch.equal(y1[: npix * cout], y2[: npix * cout])
+            assert torch.equal(qs1.view(torch.int32)[:8], qs2.view(torch.int32)[:8]), (qs1, qs2)
+            assert torch.equal(st1.view(torch.int32), st2.view(torch.int32)) and float(st2[0]) == float("inf") and int(st2.view(torch.int32)[2:].abs().sum()) == 0
+            cint = (cint // 2).contiguous()                   # different data for the second observation
