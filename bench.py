@@ -67,15 +67,18 @@ def cpu_baseline(res=224, batch=64, timed=3):
 
 
 def pmc_traffic(label, batch):
-    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r02_kernels_b<batch>.json, made by
+    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r03_kernels_b<batch>.json (or r02_), made by
     tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same step, gfx950 correction applied).
     Counters cannot be collected from inside this process, so the number is the committed one or null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_kernels_b{batch}.json")
-    try:
-        fam = json.load(open(path))["families"][label]
-        return int(fam["hbm_bytes_per_launch"]), os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
-    except (OSError, KeyError, ValueError):
-        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r03", "r02"):
+        path = os.path.join(here, "profiles", f"{tag}_kernels_b{batch}.json")
+        try:
+            fam = json.load(open(path))["families"][label]
+            return int(fam["hbm_bytes_per_launch"]), os.path.relpath(path, here)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def side_workload(args, dev):

@@ -146,11 +146,13 @@ _PROTOS = {
     "frost_softmax_ce": [P, P, I, I, F, P, P, P],
     "frost_dropout_mask": [P, C.c_uint64, L, F, P, P],
     "frost_conv_finalize_converted": [P, P, P, P, P, P, I, P, P, P],
+    "frost_conv_finalize_converted_fb": [P, P, P, P, P, P, I, P, P, P],
     "frost_add_qnnpack": [P, P, P, P, L, P, P, P],
     "frost_avgpool_q": [P, I, I, I, P, P],
     "frost_hswish_fwd": [P, P, L, P, P, P, P, I, P, P, P],
     "frost_hswish_bwd": [P, P, L, P, P, I, P],
     "frost_classifier_q": [P, P, P, P, I, I, I, P, P, P, P],
+    "frost_classifier_q_fb": [P, P, P, P, I, I, I, P, P, P, P],
 }
 SYMBOLS = sorted(list(_PROTOS) + ["frost_last_error"])
 

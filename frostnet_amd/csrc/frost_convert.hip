@@ -36,6 +36,33 @@ extern "C" int frost_conv_finalize_converted(const float* qrec_x, const float* q
   return frost_check_launch("conv_finalize_converted");
 }
 
+// The same coefficients for a model prepared with the per-channel 'fbgemm' qconfig and converted on the FBGEMM engine (Classification/latency_check.py:221-226;
+// aten qconv.cpp -> fbgemm::ReQuantizeOutput with a float bias): row A <- (s_x * s_w[c]) / s_y, row B <- b_fold[c] / (s_x * s_w[c]) as a FLOAT -- the emit
+// passes in mode 3 compute q = cvtps2dq((float(acc) + B) * A) + zp (oracle.fbgemm_conv, pinned by tests/golden/g13_convert_fbgemm_*).
+__global__ __launch_bounds__(256) void k_finalize_converted_fb(const float* qx, const float* wscale, const float* gamma, const float* beta, const float* rmean,
+                                                               const float* rvar, int cout, int cpad, float* coef, const float* qy) {
+  const float sx = qx[FROST_Q_SCALE], sy = qy[FROST_Q_SCALE];
+  for (int c = threadIdx.x; c < cpad; c += 256) {
+    float A = 0.0f, B = 0.0f;
+    if (c < cout) {
+      float b;
+      if (gamma) { const float rstd = 1.0f / sqrtf(rvar[c] + FROST_BN_EPS); b = (0.0f - rmean[c]) * rstd * gamma[c] + beta[c]; }
+      else b = beta ? beta[c] : 0.0f;
+      const float bs = sx * wscale[c];
+      A = bs / sy; B = b / bs;
+    }
+    coef[FROST_COEF_A * cpad + c] = A;
+    coef[FROST_COEF_B * cpad + c] = B;
+  }
+}
+extern "C" int frost_conv_finalize_converted_fb(const float* qrec_x, const float* wscale, const float* gamma, const float* beta, const float* rmean,
+                                                const float* rvar, int cout, float* coef, const float* qrec_y, void* stream) {
+  FROST_REQUIRE(wscale != nullptr, "conv_finalize_converted_fb: per-channel weight scales required");
+  const int cpad = round_up(cout, 16);
+  hipLaunchKernelGGL(k_finalize_converted_fb, dim3(1), dim3(256), 0, as_stream(stream), qrec_x, wscale, gamma, beta, rmean, rvar, cout, cpad, coef, qrec_y);
+  return frost_check_launch("conv_finalize_converted_fb");
+}
+
 // replaces: quantized::add on the QNNPACK engine (pytorch_qnnp_create_add_nc_q8 + q8vadd micro-kernel): integer fixed point.
 //   a_mul = lrint(s_a/s_y * 2^shift), shift = 21 - exponent(max(s_a/s_y, s_b/s_y));
 //   acc = a*a_mul + b*b_mul - (a_mul*zp_a + b_mul*zp_b);  y = clamp((acc >> shift) + (rem > thr) + zp_y, 0, 255), rem = (acc & mask) - (acc < 0)
@@ -95,7 +122,7 @@ extern "C" int frost_avgpool_q(const int8_t* x, int n, int hw, int c, int32_t* p
 // replaces: quantized::conv2d of the 1x1 classifier (nnq.Conv2d.from_float of nnqat.Conv2d, frostnet.py:298): one wave per output,
 // exact int32 accumulation, integer bias, fp32 requantisation; writes the dequantised logits (DeQuantStub) and, optionally, the indices.
 __global__ __launch_bounds__(256) void k_classifier_q(const int32_t* __restrict__ pooled, const float* qx, const int8_t* __restrict__ wq, const float* coef,
-                                                      int cpad, int n, int c, int cout, const float* qy, float* __restrict__ logits, uint8_t* __restrict__ idx) {
+                                                      int cpad, int n, int c, int cout, const float* qy, float* __restrict__ logits, uint8_t* __restrict__ idx, int fb) {
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= n * cout) return;
   const int img = wave / cout, co = wave - img * cout;
@@ -107,18 +134,27 @@ __global__ __launch_bounds__(256) void k_classifier_q(const int32_t* __restrict_
   if (lane == 0) {
     const float rs = coef[FROST_COEF_A * cpad + co]; const int bq = __float_as_int(coef[FROST_COEF_B * cpad + co]);
     const int zpy = __float_as_int(qy[FROST_Q_ZP]);
-    int q = (int)rintf((float)(acc + bq) * rs) + zpy;
+    int q = fb ? (int)rintf(((float)acc + coef[FROST_COEF_B * cpad + co]) * rs) + zpy        // FBGEMM form: float bias row, per-channel multiplier
+               : (int)rintf((float)(acc + bq) * rs) + zpy;
     q = min(max(q, 0), 255);
     logits[(int64_t)img * cout + co] = (float)(q - zpy) * qy[FROST_Q_SCALE];
     if (idx) idx[(int64_t)img * cout + co] = (uint8_t)q;
   }
 }
-extern "C" int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
-                                  const float* qrec_y, float* logits, uint8_t* idx, void* stream) {
+static int classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                        const float* qrec_y, float* logits, uint8_t* idx, int fb, void* stream) {
   const int64_t waves = (int64_t)n * cout;
   hipLaunchKernelGGL(k_classifier_q, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), pooled, qrec_x, wq, coef, round_up(cout, 16),
-                     n, c, cout, qrec_y, logits, idx);
+                     n, c, cout, qrec_y, logits, idx, fb);
   return frost_check_launch("classifier_q");
+}
+extern "C" int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                                  const float* qrec_y, float* logits, uint8_t* idx, void* stream) {
+  return classifier_q(pooled, qrec_x, wq, coef, n, c, cout, qrec_y, logits, idx, 0, stream);
+}
+extern "C" int frost_classifier_q_fb(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                                     const float* qrec_y, float* logits, uint8_t* idx, void* stream) {
+  return classifier_q(pooled, qrec_x, wq, coef, n, c, cout, qrec_y, logits, idx, 1, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ quantizable h-swish

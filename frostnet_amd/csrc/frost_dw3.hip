@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
     }
     if (MODE == D_EMIT && p.cvt) y_inv = 1.0f;
     // converted inference: y = float(acc + bias_q) * requant scale (row B carries the int32 bias bits); training / eval: y = fma(A, acc, B)
-    if (MODE == D_EMIT) { emit_add = p.cvt ? __float_as_int(cB) : 0; emit_b = p.cvt ? 0.0f : cB; }
+    if (MODE == D_EMIT) { emit_add = (p.cvt == 1) ? __float_as_int(cB) : 0; emit_b = (p.cvt == 1) ? 0.0f : cB; }
     if (MODE == D_EMIT) { qcap = (float)q_hi(p.qy); lowq = qcap < 255.0f; }        // row A already is the requantisation scale s_x*s_w/s_y
     if (MODE == D_BRED || MODE == D_BDC) {   // STE pass window in t = y/scale: t_lo < t <= t_hi (see frost_pw.hip)
       const int qhi = q_hi(p.qy);
@@ -397,6 +397,19 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
     const int oyb = DW_SEL(su.r0, L.sb) + wy * RH, oxb = DW_SEL(su.c0, L.sb) + (L.colo - L.sb * SUBW);
     const bool subok = chok && DW_SEL(su.ok, L.sb);
     int t1 = 0; double t2 = 0.0; int tmn = INT32_MAX, tmx = INT32_MIN;
+    const bool fbq = (MODE == D_EMIT) && p.cvt == 2;
+    if (fbq) {     // converted inference, FBGEMM form: q = cvtps2dq((float(acc) + b / (s_x s_w[c])) * (s_x s_w[c] / s_y)) + zp (rows B / A; oracle.fbgemm_conv)
+#pragma unroll
+      for (int o = 0; o < RH; ++o)
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int lp = (wy * RH + o) * TWT + L.colo + r;
+          float qv = rintf(fmaxf(((float)acc[o][r] + cB) * cA, relu_floor)) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          aux[lp * CBW + L.lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
+        }
+    }
+    if (!fbq)
 #pragma unroll
     for (int o = 0; o < RH; ++o) {
 #pragma unroll
@@ -795,9 +808,9 @@ extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int
                                  int h, int w, int c, int k, int stride, int mode, void* stats, const float* coef,
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
-  if (frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, mode, stats, coef, qrec_y, relu, y, nullptr, as_stream(stream));
+  if (mode != 3 && frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, mode, stats, coef, qrec_y, relu, y, nullptr, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
-  p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2);
+  p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2) ? 1 : ((mode == 3) ? 2 : 0);
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), mode == 0 ? 0 : 1, as_stream(stream));
 }
 extern "C" int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,

@@ -462,11 +462,29 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
           const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
           if (MODE == M_EMIT) {
             // converted inference: y = float(acc + bias_q) * requant scale (row B carries the int32 bias bits); training / eval: y = fma(A, acc, B)
-            const bool cvq = !SPC && p.cvt;
+            const bool cvq = !SPC && p.cvt == 1;
             int addq[4]; float Bq[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { addq[r] = cvq ? __float_as_int(B[r]) : 0; Bq[r] = cvq ? 0.0f : B[r]; }
             int8_t* base = p.y + p0 * p.cout;
+            if (!SPC && p.cvt == 2) {
+              // converted inference on the FBGEMM engine (per-channel 'fbgemm' qconfig): float bias, per-channel multiplier --
+              // q = cvtps2dq((float(acc) + b[c] / (s_x s_w[c])) * (s_x s_w[c] / s_y)) + zp, rows B / A (oracle.fbgemm_conv).  Uniform branch per channel tile.
+#pragma unroll
+              for (int t = 0; t < NT; ++t) {
+                const int prow = (wp * NT + t) * 16 + j;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float qv = rintf(((float)acci[m][t][r] + B[r]) * A[r]) + y_zpf;
+                  if (lowq) qv = fminf(qv, qcap);
+                  packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+                }
+                if (o_lds) { if (chok) *(uint32_t*)(gcur + prow * p.cout + ch0) = packed ^ 0x80808080u; }
+                else if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
+              }
+              continue;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const int prow = (wp * NT + t) * 16 + j;
@@ -745,6 +763,10 @@ static int launch_pw3(PwP& p, size_t lds, int64_t tile0, int64_t tile_end, hipSt
   const int64_t n = tile_end - tile0;
   int64_t grid = n < 256 * occ_cache ? n : 256 * occ_cache;
   if (grid < 1) return 0;
+  // statistics passes of wide layers: every workgroup ends with 4 global atomics per channel it touched, so the atomics per channel grow with the number of
+  // pixel-tile workgroups; FROST_PW_STATS_CAP (dev) caps those and lets the channel-group split fill the chip instead
+  static const int stats_cap = getenv("FROST_PW_STATS_CAP") ? atoi(getenv("FROST_PW_STATS_CAP")) : 0;
+  if (MODE == M_STATS && stats_cap > 0 && !q.io && grid > stats_cap && q.ngroups > 1) grid = stats_cap;
   static const int cs_on = getenv("FROST_PW_CSPLIT") ? atoi(getenv("FROST_PW_CSPLIT")) : 1;
   int cs = 1;
   static const int cs_mul = getenv("FROST_PW_CSMUL") ? atoi(getenv("FROST_PW_CSMUL")) : 1;
@@ -924,7 +946,7 @@ extern "C" int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int
   p.wsum = wsum; p.qx = qrec_x; p.qy = qrec_y; p.coef = (float*)coef; p.stats = (uint8_t*)stats; p.relu = relu; p.y = y;
   set_tiling(p, npix, cin);
   if (mode == 0) return dispatch_pw<M_STATS>(p, as_stream(stream));
-  p.cvt = (mode == 2);
+  p.cvt = (mode == 2) ? 1 : ((mode == 3) ? 2 : 0);          // 2: QNNPACK-form converted inference, 3: FBGEMM-form (float bias, per-channel multipliers)
   return dispatch_pw<M_EMIT>(p, as_stream(stream));
 }
 

@@ -256,7 +256,7 @@ class Engine:
         the activation bytes it must move at 1 B/element (+ the packed weights once)."""
         st = ptr(l.stats)
         nb = x.numel + l.wq_pack.numel() + (y.numel if y is not None else 0)
-        tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)      # mode 2 = emit with the converted-inference requantisation
+        tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)      # mode 2 / 3 = emit with the converted-inference requantisation (QNNPACK / FBGEMM form)
         if l.kind in ("pw", "stem"):
             call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
                  ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
@@ -405,8 +405,9 @@ class Engine:
         self._ensure_tables()
         call("frost_weight_prep", ptr(self._table), len(self.layers), self._max_elems, self.rule127, 1 if observe else 0, stream())
 
-    def conv_converted(self, l, x):
-        """quantized::conv2d(_relu) of the converted model: integer bias + fp32 requantisation in the emit epilogue (mode 2)."""
+    def conv_converted(self, l, x, fb=False):
+        """quantized::conv2d(_relu) of the converted model: integer bias + fp32 requantisation in the emit epilogue (mode 2); fb = the FBGEMM engine's form
+        for a per-channel ('fbgemm' qconfig) model: float bias + per-channel multipliers (mode 3)."""
         pad = (l.k - 1) // 2
         ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
         if l.kind == "stem":
@@ -414,9 +415,13 @@ class Engine:
             call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream())
             x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
-        call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
-             ptr(l.qy), stream())
-        self._conv_launch(l, x, 2, y)
+        if fb:
+            call("frost_conv_finalize_converted_fb", ptr(x.q), ptr(l.wscale), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
+                 ptr(l.qy), stream())
+        else:
+            call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
+                 ptr(l.qy), stream())
+        self._conv_launch(l, x, 3 if fb else 2, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
         return y
@@ -426,14 +431,17 @@ class Engine:
         call("frost_add_qnnpack", ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(q), ptr(y.buf), stream())
         return y
 
-    def head_converted(self, l, x):
+    def head_converted(self, l, x, fb=False):
         n, c = x.n, x.c
         pooled = torch.empty(n, c, dtype=torch.int32, device=self.device)
         call("frost_avgpool_q", ptr(x.buf), n, x.h * x.w, c, ptr(pooled), stream())
-        call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), None, ptr(l.bias), None, None, l.cout, ptr(l.coef), ptr(l.qy), stream())
+        if fb:
+            call("frost_conv_finalize_converted_fb", ptr(x.q), ptr(l.wscale), None, ptr(l.bias), None, None, l.cout, ptr(l.coef), ptr(l.qy), stream())
+        else:
+            call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), None, ptr(l.bias), None, None, l.cout, ptr(l.coef), ptr(l.qy), stream())
         logits = torch.empty(n, l.cout, dtype=torch.float32, device=self.device)
         self.last_logit_idx = torch.empty(n, l.cout, dtype=torch.uint8, device=self.device)
-        call("frost_classifier_q", ptr(pooled), ptr(x.q), ptr(l.wq_pack), ptr(l.coef), n, c, l.cout, ptr(l.qy), ptr(logits),
+        call("frost_classifier_q_fb" if fb else "frost_classifier_q", ptr(pooled), ptr(x.q), ptr(l.wq_pack), ptr(l.coef), n, c, l.cout, ptr(l.qy), ptr(logits),
              ptr(self.last_logit_idx), stream())
         return logits
 

@@ -386,35 +386,42 @@ class FrostRunner:
         if any(getattr(l, "hswish", None) is not None for l in self.E.layers):
             raise NotImplementedError("convert() of a hard-swish network: the converted-inference kernels restate the QNNPACK ReLU graph; the "
                                       "hard-swish variant runs the fake-quant graph (train / eval)")
-        if any(l.per_channel for l in self.E.layers):
-            raise NotImplementedError("convert() restates the QNNPACK kernels (per-tensor weights); a per-channel (fbgemm qconfig) model "
-                                      "runs the fake-quant graph only")
+        pcs = [l.per_channel for l in self.E.layers]
+        if any(pcs) and not all(pcs):
+            raise NotImplementedError("convert(): mixed per-tensor / per-channel weight quantisation")
+        # a per-channel model (the reference's 'fbgemm' qconfig, Classification/latency_check.py:221-226) converts to the FBGEMM engine's kernels:
+        # float-bias requantisation with per-channel multipliers and the float add; activations no longer clamp at the observers' 7-bit range
+        # (quantize_per_tensor / requantisation saturate at 255) -- the qrecords' index range is widened accordingly
+        self.converted_fb = all(pcs)
         with torch.cuda.device(self.device):
             self.E.prepare_converted(observe=True)         # per-site observer flags still decide on the device
+            if self.converted_fb:
+                self.qa.t[:, L.Q_QMAX] = 255.0
         self.converted = True
         return self
 
     def _forward_converted(self, x, taps=None):
-        E = self.E
+        E, fb = self.E, getattr(self, "converted_fb", False)
         if x.dtype != torch.float32:
             x = x.float()
         a = E.quantize_input(x, self.q_in, observe=False)
-        a = E.conv_converted(self.stem, a)
+        a = E.conv_converted(self.stem, a, fb)
         for d in self.blocks:
             inp, out = a, a
             if d["conv1"] is not None:
                 if d["squeeze"] is not None:
-                    out = E.cat(E.conv_converted(d["squeeze"], inp), inp, d["q_cat"], observe=False)
-                out = E.conv_converted(d["conv1"], out)
-            out = E.conv_converted(d["conv2"], out)
-            out = E.conv_converted(d["reduce"], out)
+                    out = E.cat(E.conv_converted(d["squeeze"], inp, fb), inp, d["q_cat"], observe=False)
+                out = E.conv_converted(d["conv1"], out, fb)
+            out = E.conv_converted(d["conv2"], out, fb)
+            out = E.conv_converted(d["reduce"], out, fb)
             if d["q_add"] is not None:
-                out = E.add_converted(inp, out, d["q_add"])
+                # QNNPACK: integer fixed-point q8add; FBGEMM: dequantise, add in fp32, quantise -- the fake-quant graph's own add arithmetic
+                out = E.add(inp, out, d["q_add"], observe=False) if fb else E.add_converted(inp, out, d["q_add"])
             a = out
             if taps is not None:
                 taps.append(a)
-        a = E.conv_converted(self.last, a)
-        logits = E.head_converted(self.cls, a)
+        a = E.conv_converted(self.last, a, fb)
+        logits = E.head_converted(self.cls, a, fb)
         E.tape = []
         return logits
 

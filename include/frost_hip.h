@@ -109,7 +109,8 @@ int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int r
 /* reset the per-layer integer stats scratch (sum=0,sumsq=0,min=INT_MAX,max=INT_MIN); cpads/offs are device arrays */
 int frost_stats_init_table(void* stats, const int32_t* cpads, const int64_t* offs, int nlayers, void* stream);
 /* replaces: F.conv2d of a 1x1 conv on fake-quantised operands (conv_fused.py:152) -- int8 MFMA.
- * mode 0: accumulate per-channel stats only.  mode 1: emit y=fq(relu?(A*acc+B)) as offset-binary int8. */
+ * mode 0: accumulate per-channel stats only.  mode 1: emit y=fq(relu?(A*acc+B)) as offset-binary int8.
+ * mode 2 / 3: emit in converted-inference form (QNNPACK integer bias / FBGEMM float bias + per-channel multiplier), see frost_conv_finalize_converted[_fb]. */
 int frost_pw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix,
                       int cin, int cout, int mode, void* stats, const float* coef, const float* qrec_y, int relu,
                       int8_t* y, void* stream);
@@ -377,6 +378,14 @@ int frost_dropout_mask(void* draw_counter, uint64_t seed, int64_t n, float keep,
  * weights are prepared once by frost_weight_prep with FrostWDesc.reserved0 = 1. */
 int frost_conv_finalize_converted(const float* qrec_x, const float* qrec_w, const float* gamma, const float* beta,
                                   const float* rmean, const float* rvar, int cout, float* coef, const float* qrec_y, void* stream);
+/* the same for a model prepared with the per-channel 'fbgemm' qconfig and converted on the FBGEMM engine (Classification/latency_check.py:221-226):
+ * row A = (s_x * s_w[c]) / s_y, row B = b_fold[c] / (s_x * s_w[c]) (float) -- the emit kernels in mode 3 then compute
+ * q = cvtps2dq((float(acc) + B) * A) + zp  (aten qconv.cpp -> fbgemm::ReQuantizeOutput with a float bias).  The residual add of that engine is the
+ * float add frost_add_requant already computes; cat / average pool are shared with the QNNPACK form. */
+int frost_conv_finalize_converted_fb(const float* qrec_x, const float* wscale, const float* gamma, const float* beta, const float* rmean,
+                                     const float* rvar, int cout, float* coef, const float* qrec_y, void* stream);
+int frost_classifier_q_fb(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
+                          const float* qrec_y, float* logits, uint8_t* idx, void* stream);
 /* replaces: quantized::add (QNNPACK q8add, integer fixed point) -- FloatFunctional.add of a converted model (frostnet.py:142) */
 int frost_add_qnnpack(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y,
                       int8_t* y, void* stream);

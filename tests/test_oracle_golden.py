@@ -367,6 +367,34 @@ def test_g9_converted_inference(golden, mode):
     assert np.array_equal(y.numpy(), g["logits"])
 
 
+def convert_case_fbgemm(g, mode):
+    B, R, tseed, xseed, wseed = [int(v) for v in g["spec"]]
+    cfg = O.net_cfg(mode, 1.0)
+    P, _ = O.make_state(O.float_state_spec(cfg), wseed, True)
+    qs = O.QState(unpack_state(g, "pre_sd/"), qconfig="fbgemm")
+    return cfg, P, qs, T(O.synth((B, 3, R, R), xseed))
+
+
+@pytest.mark.parametrize("mode", ["small", "large"])
+def test_g13_converted_inference_fbgemm(golden, mode):
+    """oracle.converted_forward(engine='fbgemm') == the reference's model prepared with the 'fbgemm' qconfig and converted on the FBGEMM engine
+    (Classification/latency_check.py:221-226): per-channel weights, float-bias requantisation, float add -- every block output and the logits bit-exact."""
+    import zlib
+    g = golden(f"g13_convert_fbgemm_{mode}")
+    cfg, P, qs, x = convert_case_fbgemm(g, mode)
+    trace = []
+    with torch.no_grad():
+        y = O.converted_forward(P, qs, cfg, x, True, trace, engine="fbgemm")
+    for name, q, s, z in trace:
+        key = "blk/" + name.replace(".", "/")
+        assert [s, float(z)] == g[key + "/qp"].tolist(), name
+        idx = q.to(torch.uint8).numpy()
+        assert np.uint32(zlib.crc32(np.ascontiguousarray(idx).tobytes())) == g[key + "/crc"], name
+        ref = g[key + "/idx"]
+        assert np.array_equal(idx if idx.size <= 40000 else idx[:, :8, :6, :6], ref), name
+    assert np.array_equal(y.numpy(), g["logits"])
+
+
 # ------------------------------------------------------------------------------------------ G10 quantizable hard-swish (SURVEY N4)
 def test_g10_hswish(golden):
     g = golden("g10_hswish")

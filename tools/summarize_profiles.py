@@ -14,16 +14,20 @@ import json
 import re
 import sys
 
-FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- kernel-name regex
-    ("pw_fwd_stats", r"k_pw<0,|k_dgrad_wide<2>"), ("pw_fwd_emit", r"k_pw<1,|k_pw_ew<2>"), ("pw_bwd_reduce", r"k_pw<2,|k_pw_ew<0>|k_dgrad_wide<1>"),
-    ("pw_bwd_fused", r"k_pw<3, \d+, \w+, \w+, [1-9]\d*[,>]"), ("pw_bwd_dc", r"k_pw<3,|k_pw_ew<1>"), ("pw_dgrad", r"k_pw<4,|k_dgrad_wide<0>"), ("pw_wgrad", r"k_pw_wgrad"),
-    ("dw_fwd_stats", r"k_dw3<DwGeo<[^>]*>, 0[,>]"), ("dw_fwd_emit", r"k_dw3<DwGeo<[^>]*>, 1[,>]"),
+FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- kernel-name regex; first match wins
+    ("stem_fwd_stats", r"k_pw<0, 8, true, true, 0, 2>"), ("stem_fwd_emit", r"k_pw<1, 8, true, true, 0, 2>"),        # SP = 2 (32 channels, 40-byte rows) is the stem's instance only
+    ("pw_fwd_stats", r"k_pw<0,|k_dgrad_wide<2,"), ("pw_fwd_emit_add", r"k_pw_ew_emit_add"), ("pw_fwd_emit", r"k_pw<1,|k_pw_ew<2>"),
+    ("pw_bwd_reduce", r"k_pw<2,|k_pw_ew<0>|k_dgrad_wide<1,"),
+    ("pw_bwd_fused", r"k_pw<3, \d+, \w+, \w+, [1-9]\d*[,>]"), ("pw_bwd_dc", r"k_pw<3,|k_pw_ew<1>"), ("pw_dgrad", r"k_pw<4,|k_dgrad_wide<0,"), ("pw_wgrad", r"k_pw_wgrad"),
+    ("dw_fwd_stats", r"k_dw3<DwGeo<[^>]*>, 0[,>]|k_dwm<\d, \d+, 0>"), ("dw_fwd_emit", r"k_dw3<DwGeo<[^>]*>, 1[,>]|k_dwm<\d, \d+, [14]>"),
     ("dw_bwd_reduce", r"k_dw3<DwGeo<[^>]*>, 2[,>]"), ("dw_bwd_dc", r"k_dw3<DwGeo<[^>]*>, [34][,>]"),
     ("dw_wgrad", r"k_dw3_wgrad"), ("dw_dgrad", r"k_dw3_dgrad"),
-    ("conv_finalize", r"k_conv_finalize"), ("wgrad_finalize", r"k_wgrad_finalize"),
-    ("cat_fwd", r"k_cat_requant"), ("cat_bwd", r"k_cat_bwd"), ("add_fwd_minmax", r"k_add_minmax"),
-    ("add_fwd_emit", r"k_add_requant"), ("add_bwd", r"k_add_bwd"), ("stem_im2col", r"k_stem_im2col"),
-    ("gradboost", r"k_gradboost"), ("weight_prep", r"k_wprep"),
+    ("conv_finalize", r"k_conv_finalize"), ("wgrad_finalize", r"k_wgrad_finalize|k_weight_grad_finalize"),
+    ("cat_fwd", r"k_cat_requant|k_cat_observe"), ("cat_bwd", r"k_cat_bwd"), ("add_fwd_minmax", r"k_add_minmax"),
+    ("add_fwd_emit", r"k_add_requant"), ("add_bwd", r"k_add_bwd"), ("stem_im2col", r"k_stem_im2col|k_stem_wgrad_remap"),
+    ("gradboost", r"k_gradboost"), ("weight_prep", r"k_wprep|k_save_sigma|k_stats_init"),
+    ("head", r"k_avgpool|k_classifier|k_head|k_sgemm|k_mask_logits|k_softmax_ce|k_dropout|k_fake_quant|k_minmax|k_fill_minmax|k_observer_update|k_quantize_input|k_pool"),
+    ("torch_elementwise", r"at::native|elementwise_kernel|vectorized_elementwise|__amd_rocclr_(fill|copy)Buffer|reduce_kernel"),
 ]
 
 
