@@ -94,6 +94,8 @@ _PROTOS = {
     "frost_pw_ew": [P, L, I, P, P, I, I, P, P, P],
     "frost_pw_ew_emit_add": [P, L, I, P, P, I, P, P, P, P, P, I, P],
     "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
+    "frost_block_supported": [I, I, I, I, I, I],
+    "frost_block_expand_dw_stats": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
     "frost_pw_dgrad_wide_ok": [L, I, I],
     "frost_pw_dgrad_wide": [P, P, P, L, I, I, P, I, P],
     "frost_pw_conv_bwd_fused": [P, P, P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, P],

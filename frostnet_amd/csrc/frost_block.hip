@@ -1,0 +1,319 @@
+// Block-level fused forward kernels of a Frost bottleneck at the 14 x 14 and 7 x 7 stages (CascadePreExBottleneck.forward,
+// /root/reference/frostnet.py:124-145: squeeze -> cat -> conv1 (1x1 expand) -> conv2 (depthwise) -> reduce_conv (1x1) -> skip add).
+//
+// Every ConvBN(ReLU) of the block needs two global reductions before its output exists (BatchNorm batch statistics + the activation observer's
+// min / max), so a block forward keeps its synchronisation points whatever is fused.  What fusion removes at these stages is a full read / write of
+// the EXPANDED tensor (6 x the block input) and one latency-bound launch per boundary:
+//
+//   A  k_blk_expand_dw      conv1's emit pass  +  conv2's statistics pass (+ its folded finalize)
+//        a workgroup owns ONE image (49 / 196 pixels): the block-internal input x (cat) is staged in LDS once; per 64-channel chunk the int8 MFMA
+//        GEMM produces conv1's accumulators, the epilogue quantises them (same expression as k_pw's emit) straight into a zero-point-haloed
+//        [row][col][64 ch] LDS plane, and the depthwise stencil runs on that plane with lane = channel (ds_read_b64_tr_b8 + v_dot4_i32_i8, the core of
+//        k_dw3) accumulating conv2's exact integer statistics.  y1 leaves for HBM once (the backward and conv2's emit pass read it), never re-read here.
+//   B  k_blk_dw_reduce      conv2's emit pass  +  reduce_conv's int8 GEMM / statistics pass (+ folded finalize), K-split over the same chunks
+//        y1 chunk -> plane -> depthwise -> quantise y2 (LDS, and out to HBM for the backward) -> MFMA partial sums of the reduce conv stay in
+//        registers across the chunks; the integer conv output is stored once (the element-wise emit / backward of the kept-output path use it).
+//
+// Results are bit-identical to the layer-by-layer kernels: same integer accumulators, same quantisation expression, exact integer statistics.
+#include "frost_common.h"
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+struct BlkAP {
+  const int8_t* x; const float* qx;                 // conv1's input (offset-binary bytes, [n*map][cin]) and its record
+  const int8_t* w1; const int32_t* wsum1;           // conv1: MFMA-fragment weight pack [CT][KS][64][16 B], per-channel weight sums
+  const float* coef1; const float* qy1; int8_t* y1; // conv1: coefficient rows (finalized), output record, output tensor [n*map][c]
+  const int8_t* wq2; const int32_t* wsum2;          // conv2 (depthwise): taps [k*k][cpad], weight sums
+  uint8_t* stats2; FrostFinDesc fin;                // conv2: statistics table and the finalize descriptor
+  int n, cin, c, cpad, KS, kstr, nchunk, csplit, imgs;
+};
+
+template <int K, int HW, int NW>
+struct BlkGeo {
+  static constexpr int MAP = HW * HW, NPT = (MAP + 15) / 16;      // pixels of one image, 16-pixel MFMA tiles
+  static constexpr int NPH = NW / 4, NPTW = (NPT + NPH - 1) / NPH;  // pixel-tile halves over the waves, tiles per wave
+  static constexpr int PAD = (K - 1) / 2, NRG = (HW + 1) / 2;     // depthwise: 2 output rows per wave unit
+  static constexpr int PHA = 2 * NRG + K - 1;                      // plane rows (incl. the rows an odd map's last unit reads past the halo)
+  static constexpr int NSEG = (HW + 7) / 8, PITCH = NSEG * 8 + 8;  // 8-column output segments; plane columns (16 read per segment)
+  static constexpr int PLANE = PHA * PITCH * 64;
+  static constexpr int NT = NW * 64;
+  // input rows + plane + ticket flag + per channel of the chunk range: statistics 24 B, conv1 rows 12 B, conv2 weight sum 4 B, taps k*k B
+  __host__ __device__ static constexpr int lds(int kstr, int nch) { return NPT * 16 * kstr + PLANE + 64 + nch * 64 * (24 + 12 + 4 + K * K); }
+};
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would serialise every barrier behind the
+// weight-fragment prefetch and the y stores in flight (an L2 / HBM round trip per chunk)
+__device__ __forceinline__ void blk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ v2i blk_tr8(const uint8_t* row, int col0, int lane) {     // 8 consecutive pixels of channel `lane` of a [col][64 ch] row
+  const int jp = lane & 15, G = lane >> 4;
+  return __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(row + (col0 + (jp >> 1)) * 64 + 16 * G + 8 * (jp & 1)));
+}
+
+// depthwise accumulators of one wave unit: output rows r0, r0 + 1, columns seg*8 .. +8 of channel `lane`, from the plane (signed bytes q - 128)
+template <int K, int PITCH>
+__device__ __forceinline__ void blk_dw_unit(const uint8_t* pl, int r0, int seg, int lane, const int (&wpk)[K][2], int acc0, int (&acc)[2][8]) {
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[o][r] = acc0;
+  constexpr int NWIN = (K == 3) ? 8 : 12;
+#pragma unroll
+  for (int jr = 0; jr < K + 1; ++jr) {
+    const uint8_t* rowp = pl + (r0 + jr) * PITCH * 64;
+    int d[5];
+    const v2i a = blk_tr8(rowp, seg * 8, lane), b = blk_tr8(rowp, seg * 8 + 8, lane);
+    d[0] = a[0]; d[1] = a[1]; d[2] = b[0]; d[3] = b[1]; d[4] = 0;
+    int win[NWIN];
+#pragma unroll
+    for (int i = 0; i < NWIN; ++i) win[i] = (i % 4 == 0) ? d[i / 4] : __builtin_amdgcn_alignbyte(d[i / 4 + 1], d[i / 4], i % 4);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      if ((jr - ky) >= 0 && (jr - ky) < 2) {
+        const int o = jr - ky;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          acc[o][r] = __builtin_amdgcn_sdot4(win[r], wpk[ky][0], acc[o][r], false);
+          if (K == 5) acc[o][r] = __builtin_amdgcn_sdot4(win[r + 4], wpk[ky][1], acc[o][r], false);
+        }
+      }
+    }
+  }
+}
+
+template <int K, int HW, int NW, int KSM>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 3 : 4) void k_blk_expand_dw(const BlkAP p) {
+  using G = BlkGeo<K, HW, NW>;
+  constexpr int MAP = G::MAP, NPT = G::NPT, NPTW = G::NPTW, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                                     // [NPT*16][kstr]
+  uint8_t* const pl = smem + NPT * 16 * p.kstr;                 // [PHA][PITCH][64]
+  int* const sflag = (int*)(pl + G::PLANE);
+  // per-channel rows of the workgroup's chunk range (cw channels), resident for all its images:
+  //   conv2 statistics s1, s2 (8 B each), min, max | conv1 A, B, weight sum | conv2 weight sum | conv2 taps [chunk][k*k][64]
+  const int cs = (int)blockIdx.x % p.csplit, ig = (int)blockIdx.x / p.csplit;
+  const int chunk_lo = (cs * p.nchunk) / p.csplit, chunk_hi = ((cs + 1) * p.nchunk) / p.csplit;
+  const int cw = (chunk_hi - chunk_lo) * 64;
+  unsigned long long* const l_s1 = (unsigned long long*)(sflag + 16);
+  unsigned long long* const l_s2 = l_s1 + cw;
+  int* const l_mn = (int*)(l_s2 + cw); int* const l_mx = l_mn + cw;
+  float* const tabA = (float*)(l_mx + cw); float* const tabB = tabA + cw;
+  int* const tabW = (int*)(tabB + cw); int* const tabW2 = tabW + cw;
+  uint8_t* const taps = (uint8_t*)(tabW2 + cw);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int CT = p.cpad >> 4;
+  const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+
+  // ---- prologue: the plane's zero-point fill, identity statistics, the chunk range's per-channel rows and taps
+  const int zp1 = __float_as_int(p.qy1[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zp1 - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)pl)[i] = make_uint4(zf, zf, zf, zf);
+    for (int i = tid; i < cw; i += NT) {
+      const int c2 = chunk_lo * 64 + i; const bool ok = c2 < p.c;
+      l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN;
+      tabA[i] = ok ? p.coef1[FROST_COEF_A * p.cpad + c2] : 0.0f; tabB[i] = ok ? p.coef1[FROST_COEF_B * p.cpad + c2] : 0.0f;
+      tabW[i] = ok ? p.wsum1[c2] : 0; tabW2[i] = ok ? p.wsum2[c2] : 0;
+    }
+    const int ntap = (chunk_hi - chunk_lo) * K * K * 16;                          // 4 channels of one tap per thread, in batches of 4 loads
+    for (int i0 = tid; i0 < ntap; i0 += 4 * NT) {
+      uint32_t tv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * NT; const int cl = i / (K * K * 16), rem = i - cl * (K * K * 16), t = rem >> 4, c4 = (rem & 15) * 4;
+        const int c2 = (chunk_lo + cl) * 64 + c4;
+        tv[q] = (i < ntap && c2 < p.c) ? *(const uint32_t*)(p.wq2 + t * p.cpad + c2) : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q * NT; const int cl = i / (K * K * 16), rem = i - cl * (K * K * 16), t = rem >> 4, c4 = (rem & 15) * 4;
+        if (i < ntap) *(uint32_t*)(taps + (cl * K * K + t) * 64 + c4) = tv[q];
+      }
+    }
+  }
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  const float y_inv = 1.0f / p.qy1[FROST_Q_SCALE], y_zpf = (float)zp1;
+  const float qcap = (float)q_hi(p.qy1); const bool lowq = qcap < 255.0f;
+  // this lane's pixel of each of the wave's pixel tiles -> byte offset of the pixel inside the plane (-1: padding pixel)
+  const int ph = (NW == 8) ? (w >> 2) : 0, wct = w & 3;
+  int off[NPTW];
+#pragma unroll
+  for (int t = 0; t < NPTW; ++t) {
+    const int pi = (ph * NPTW + t) * 16 + j;
+    const int r = pi / HW, cc = pi - r * HW;
+    off[t] = (pi < MAP) ? ((r + PAD) * PITCH + cc + PAD) * 64 : -1;
+  }
+  auto load_w1 = [&](int chunk, v4i (&dst)[KSM]) __attribute__((always_inline)) {
+    const int ct = min(chunk * 4 + wct, CT - 1);          // a partial last chunk recomputes the last tile (its bytes are never used)
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks)
+      dst[ks] = *(const v4i*)(p.w1 + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+  };
+  v4i afr[KSM];
+  if (chunk_lo < chunk_hi) load_w1(chunk_lo, afr);
+
+  for (int img = img_lo; img < img_hi; ++img) {
+    {   // the image's input rows (the previous image's last barrier freed the buffer)
+      const int8_t* src = p.x + (int64_t)img * MAP * p.cin;
+      const int upr = p.cin >> 3, total = MAP * upr;
+      constexpr int XB = (MAP * KSM * 8 + NT - 1) / NT;           // 8-byte units per thread: all loads in flight before the first LDS store
+      uint2 xv[XB];
+#pragma unroll
+      for (int i = 0; i < XB; ++i) { const int u = tid + i * NT; xv[i] = (u < total) ? *(const uint2*)(src + (int64_t)u * 8) : make_uint2(0, 0); }
+#pragma unroll
+      for (int i = 0; i < XB; ++i) {
+        const int u = tid + i * NT; const int row = u / upr, col = u - row * upr;
+        if (u < total) *(uint2*)(xs + row * p.kstr + col * 8) = xv[i];
+      }
+    }
+    blk_barrier();
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+      const int cl = chunk - chunk_lo;
+      const int ti = cl * 64 + wct * 16 + 4 * g;       // GEMM epilogue: 4 consecutive channels of this lane (index into the resident rows)
+      const bool chok = (chunk * 64 + lane) < p.c;     // depthwise: this lane's channel
+      // ---- conv1: int8 MFMA GEMM of the wave's channel tile over its pixel tiles
+      v4i acc[NPTW];
+      float A[4], B[4];
+      {
+        const int4 ws = *(const int4*)(tabW + ti); const v4i init = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w};
+        const float4 A4 = *(const float4*)(tabA + ti), B4 = *(const float4*)(tabB + ti);
+        A[0] = A4.x; A[1] = A4.y; A[2] = A4.z; A[3] = A4.w; B[0] = B4.x; B[1] = B4.y; B[2] = B4.z; B[3] = B4.w;
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) acc[t] = init;
+      }
+      {
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+#pragma unroll
+          for (int t = 0; t < NPTW; ++t) {       // (the second half's last tile may lie past the image: it reads on into the plane and is dropped)
+            const v4i bfr = *(const v4i*)(xs + ((ph * NPTW + t) * 16 + j) * p.kstr + ks * 64 + g * 16);
+            acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, acc[t], 0, 0, 0);          // D[chan][pix]
+          }
+        }
+        // emit: q = clamp(rint(fma(A, acc, B) / s) + zp, 0, hi) -- k_pw's expression -- into the plane
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) {
+          uint32_t packed = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yv = fmaf(A[r], (float)acc[t][r], B[r]);
+            float qv = rintf(yv * y_inv) + y_zpf;
+            if (lowq) qv = fminf(qv, qcap);
+            packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+          }
+          if (off[t] >= 0) *(uint32_t*)(pl + off[t] + wct * 16 + 4 * g) = packed ^ 0x80808080u;
+        }
+      }
+      blk_barrier();                                           // the chunk's y1 plane is complete
+      {   // the next (image, chunk)'s weight fragments travel under the depthwise phase
+        const int nxt = (chunk + 1 < chunk_hi) ? chunk + 1 : chunk_lo;
+        if (chunk + 1 < chunk_hi || img + 1 < img_hi) load_w1(nxt, afr);
+      }
+      // ---- y1 chunk out to HBM (8-byte pieces, 64 contiguous bytes per pixel)
+      {
+        int8_t* dst = p.y1 + (int64_t)img * MAP * p.c + chunk * 64;
+        for (int u = tid; u < MAP * 8; u += NT) {
+          const int px = u >> 3, part = u & 7;
+          const int r = px / HW, cc = px - r * HW;
+          if (chunk * 64 + part * 8 < p.c) *(uint2*)(dst + (int64_t)px * p.c + part * 8) = *(const uint2*)(pl + ((r + PAD) * PITCH + cc + PAD) * 64 + part * 8);
+        }
+      }
+      // ---- conv2 statistics: wave w = output rows 2w, 2w + 1 of the map, lane = channel
+      if (w < G::NRG) {
+        const uint8_t* tapb = taps + cl * K * K * 64;
+        int wpk[K][2];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          uint32_t lo = 0, hi = 0;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) { const uint32_t b = tapb[(ky * K + kx) * 64 + lane]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+          wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+        }
+        const int acc0 = (128 - zp1) * tabW2[cl * 64 + lane];
+        int t1 = 0; double t2 = 0.0; int tmn = INT32_MAX, tmx = INT32_MIN;
+#pragma unroll 1
+        for (int seg = 0; seg < G::NSEG; ++seg) {
+          int a[2][8];
+          blk_dw_unit<K, PITCH>(pl, 2 * w, seg, lane, wpk, acc0, a);
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
+                const int vi = a[o][r]; const float v = (float)vi;
+                t1 += vi; t2 = fma((double)v, (double)v, t2); tmn = min(tmn, vi); tmx = max(tmx, vi);
+              }
+            }
+        }
+        if (chok) {
+          const int li = cl * 64 + lane;
+          atomicAdd(&l_s1[li], (unsigned long long)(long long)t1); atomicAdd(&l_s2[li], (unsigned long long)t2);
+          atomicMin(&l_mn[li], tmn); atomicMax(&l_mx[li], tmx);
+        }
+      }
+      blk_barrier();                                           // plane (and, after the last chunk, the input rows) free again
+    }
+  }
+  // ---- one set of global atomics per channel of the range, then: last workgroup done -> conv2's finalize in this launch
+  {
+    long long* g_s1 = (long long*)p.stats2; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+    for (int i = tid; i < cw; i += NT) {
+      const int c2 = chunk_lo * 64 + i;
+      if (c2 < p.c && l_mn[i] <= l_mx[i]) {
+        atomicAdd((unsigned long long*)&g_s1[c2], l_s1[i]); atomicAdd(&g_s2[c2], l_s2[i]);
+        atomicMin(&g_mn[c2], l_mn[i]); atomicMax(&g_mx[c2], l_mx[i]);
+      }
+    }
+  }
+  if (last_block_done2(p.fin.counter, gridDim.x, sflag)) {
+    float* sh = (float*)smem;
+    conv_finalize_dev(p.stats2, (int64_t)p.n * MAP, p.c, p.cpad, p.qy1, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+                      p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, NT, sh);
+  }
+}
+
+template <int K, int HW, int NW, int KSM>
+static int launch_blk_a(BlkAP& p, hipStream_t s) {
+  using G = BlkGeo<K, HW, NW>;
+  const size_t lds = (size_t)G::lds(p.kstr, (p.nchunk + p.csplit - 1) / p.csplit);
+  FROST_REQUIRE(lds <= 160 * 1024, "block_expand_dw: LDS budget exceeded");
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_expand_dw<K, HW, NW, KSM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_blk_expand_dw<K, HW, NW, KSM>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.csplit)), dim3(NW * 64), lds, s, p);
+  return frost_check_launch("block_expand_dw");
+}
+
+extern "C" int frost_block_supported(int h, int w, int k, int stride, int cin, int c) {
+  return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (cin % 8) == 0 && cin > (h == 7 ? 64 : 0) && cin <= (h == 7 ? 320 : 192) && (c % 8) == 0) ? 1 : 0;
+}
+
+extern "C" int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x, const int8_t* w1_pack, const int32_t* wsum1, const float* coef1,
+                                           const float* qrec_y1, int8_t* y1, int n, int h, int w, int cin, int c, const int8_t* wq2,
+                                           const int32_t* wsum2, int k, void* stats2, const FrostFinDesc* fin2, void* stream) {
+  FROST_REQUIRE(frost_block_supported(h, w, k, 1, cin, c), "block_expand_dw: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1, cin <= 320 / 192)");
+  FROST_REQUIRE(fin2 && fin2->counter && fin2->coef && fin2->qrec_y, "block_expand_dw: incomplete finalize descriptor");
+  BlkAP p = {};
+  p.x = x; p.qx = qrec_x; p.w1 = w1_pack; p.wsum1 = wsum1; p.coef1 = coef1; p.qy1 = qrec_y1; p.y1 = y1; p.wq2 = wq2; p.wsum2 = wsum2;
+  p.stats2 = (uint8_t*)stats2; p.fin = *fin2; p.n = n; p.cin = cin; p.c = c; p.cpad = round_up(c, 16); p.KS = (cin + 63) / 64; p.kstr = p.KS * 64 + 16;
+  p.nchunk = (c + 63) / 64;
+  // work split: a workgroup takes `imgs` images x a range of channel chunks.  Per-channel state of the range stays in LDS across the images and is
+  // flushed once (4 atomics per channel per workgroup); the split keeps >= ~4 workgroups per CU in flight at the training batch.
+  static const int cpw_env = getenv("FROST_BLK_CPW") ? atoi(getenv("FROST_BLK_CPW")) : 0, imgs_env = getenv("FROST_BLK_IMGS") ? atoi(getenv("FROST_BLK_IMGS")) : 0;
+  int cpw = cpw_env > 0 ? cpw_env : 2;                 // chunks per workgroup
+  if (cpw > p.nchunk) cpw = p.nchunk;
+  p.csplit = (p.nchunk + cpw - 1) / cpw;
+  const int want = 1400;                // measured on 240->1440 @ 7x7 and 104->624 @ 14x14, B = 512: (2 chunks, 4 images) and (2 chunks, 2 images) per workgroup
+  int imgs = imgs_env > 0 ? imgs_env : (int)(((int64_t)n * p.csplit + want / 2) / want);
+  if (imgs < 1) imgs = 1;
+  if (imgs > 16) imgs = 16;
+  p.imgs = imgs;
+  hipStream_t s = as_stream(stream);
+#define BLK_A(KK, HH, NWW, KSS) if (k == KK && h == HH && p.KS == KSS) return launch_blk_a<KK, HH, NWW, KSS>(p, s);
+  BLK_A(3, 7, 4, 2) BLK_A(3, 7, 4, 3) BLK_A(3, 7, 4, 4) BLK_A(3, 7, 4, 5) BLK_A(5, 7, 4, 2) BLK_A(5, 7, 4, 3) BLK_A(5, 7, 4, 4) BLK_A(5, 7, 4, 5)
+  BLK_A(3, 14, 8, 1) BLK_A(3, 14, 8, 2) BLK_A(3, 14, 8, 3) BLK_A(5, 14, 8, 1) BLK_A(5, 14, 8, 2) BLK_A(5, 14, 8, 3)
+#undef BLK_A
+  FROST_REQUIRE(false, "block_expand_dw: no instance");
+  return 1;
+}

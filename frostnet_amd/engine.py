@@ -31,6 +31,7 @@ _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary 
 # reduce emit + residual-add range pass in one launch (frost_pw_ew_emit_add).  Bit-identical to the two launches it replaces, but NOT faster: measured 24.8-24.9 ms
 # per step with it vs 24.7-24.8 without (profiles/r03_block_fusion_ab.txt) -- the element-wise kernels' time is their single-workgroup observer tail, which
 # the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
+_BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit + conv2 statistics in one launch at the 14x14 / 7x7 stages (csrc/frost_block.hip)
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -331,6 +332,34 @@ class Engine:
             self.trace.append((l.name, y))
         self.tape.append(("conv", l, x, y))
         return y
+
+    def pair_fusable(self, l1, l2, x, training, observe):
+        """conv1 -> conv2 of a bottleneck at the 14x14 / 7x7 stages: conv1's emit pass and conv2's statistics pass run as ONE launch (csrc/frost_block.hip)."""
+        return bool(_BLOCK_PAIR and _FIN_FOLD and training and observe and l1.kind == "pw" and l2.kind == "dw" and l1.k == 1
+                    and getattr(l1, "hswish", None) is None and getattr(l2, "hswish", None) is None
+                    and L.load_library().frost_block_supported(x.h, x.w, l2.k, l2.stride, x.c, l1.cout))
+
+    def conv_pair(self, l1, l2, x, training=True, observe=True):
+        """`conv2(conv1(x))` of CascadePreExBottleneck.forward (frostnet.py:134-137) with the expanded tensor kept on chip between conv1's activation
+        FakeQuantize and conv2's batch statistics: conv1 statistics + finalize (k_pw) -> frost_block_expand_dw_stats -> conv2 emit (k_dw3).
+        Tape and saved tensors are those of two Engine.conv calls: the backward is unchanged."""
+        y1 = self.new_act(x.n, x.h, x.w, l1.cout, l1.qy)
+        fin1 = L.FrostFinDesc(l1.qw.data_ptr(), l1.gamma.data_ptr(), l1.beta.data_ptr(), l1.rmean.data_ptr(), l1.rvar.data_ptr(), l1.nbt.data_ptr(),
+                              l1.coef.data_ptr(), l1.qy.data_ptr(), l1.fin_counter.data_ptr(), 1, int(l1.relu), 1, 0, l1.wscale.data_ptr(), None, None)
+        call("frost_pw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l1.wq_pack), ptr(l1.wsum), x.npix, x.c, l1.cout, ptr(l1.stats), C.byref(fin1),
+             stream(), prof=("pw_fwd_stats", x.numel + l1.wq_pack.numel()))
+        fin2 = L.FrostFinDesc(l2.qw.data_ptr(), l2.gamma.data_ptr(), l2.beta.data_ptr(), l2.rmean.data_ptr(), l2.rvar.data_ptr(), l2.nbt.data_ptr(),
+                              l2.coef.data_ptr(), l2.qy.data_ptr(), l2.fin_counter.data_ptr(), 1, int(l2.relu), 1, 0, l2.wscale.data_ptr(), None, None)
+        call("frost_block_expand_dw_stats", ptr(x.buf), ptr(x.q), ptr(l1.wq_pack), ptr(l1.wsum), ptr(l1.coef), ptr(l1.qy), ptr(y1.buf), x.n, x.h, x.w, x.c,
+             l1.cout, ptr(l2.wq_pack), ptr(l2.wsum), l2.k, ptr(l2.stats), C.byref(fin2), stream(),
+             prof=("blk_expand_dw", x.numel + l1.wq_pack.numel() + y1.numel))
+        y2 = self.new_act(x.n, x.h, x.w, l2.cout, l2.qy)
+        self._conv_launch(l2, y1, 1, y2)
+        if getattr(self, "trace", None) is not None:
+            self.trace.append((l1.name, y1)); self.trace.append((l2.name, y2))
+        self.tape.append(("conv", l1, x, y1))
+        self.tape.append(("conv", l2, y1, y2))
+        return y2
 
     def cat(self, a, b, q, observe=True):
         """FloatFunctional.cat + its FakeQuantize (frostnet.py:129)."""

@@ -278,8 +278,12 @@ class FrostRunner:
                 else:
                     sq = self._conv(d["squeeze"], inp, training, obs)
                 out = E.cat(sq, inp, d["q_cat"], obs)
-            out = self._conv(d["conv1"], out, training, obs)
-        out = self._conv(d["conv2"], out, training, obs)
+            if E.pair_fusable(d["conv1"], d["conv2"], out, training, obs):
+                out = E.conv_pair(d["conv1"], d["conv2"], out, training, obs)
+            else:
+                out = self._conv(d["conv2"], self._conv(d["conv1"], out, training, obs), training, obs)
+        else:
+            out = self._conv(d["conv2"], out, training, obs)
         if d["q_add"] is not None:
             out = E.conv(d["reduce"], out, training, obs, residual=(inp, d["q_add"]))      # reduce_conv is linear (never hard-swish): straight to the engine
             out = E.add(inp, out, d["q_add"], obs)

@@ -362,6 +362,19 @@ int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* w
 int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const int8_t* a,
                          const float* qrec_a, int8_t* y, float* state3, float* qrec_sum, int observe, void* stream);
 
+/* ---- whole-bottleneck forward fusion at the 14x14 / 7x7 stages (CascadePreExBottleneck.forward, frostnet.py:124-145) ------------
+ * frost_block_supported: 1 when the fused kernels have an instance for a (conv1 -> conv2) pair: square 7x7 / 14x14 maps, depthwise k in {3,5} at
+ * stride 1, conv1 input rows of <= 320 (7x7) / 192 (14x14) bytes.
+ * frost_block_expand_dw_stats replaces: conv1's emit pass (frost_pw_conv_fwd mode 1: BN + ReLU + activation FakeQuantize of `self.conv1`, frostnet.py:134)
+ * TOGETHER with conv2's statistics pass and folded finalize (frost_dw_conv_fwd_fin: batch statistics, running-stat update and observer update of
+ * `self.conv2`, frostnet.py:137).  One workgroup per image: conv1's quantised output goes through an LDS plane straight into the depthwise stencil
+ * and leaves for HBM once (y1: conv2's emit pass and the backward read it).  conv1 must be finalized (coef1 / qrec_y1 final); results are
+ * bit-identical to the two separate launches. */
+int frost_block_supported(int h, int w, int k, int stride, int cin, int c);
+int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x, const int8_t* w1_pack, const int32_t* wsum1, const float* coef1,
+                                const float* qrec_y1, int8_t* y1, int n, int h, int w, int cin, int c, const int8_t* wq2, const int32_t* wsum2,
+                                int k, void* stats2, const FrostFinDesc* fin2, void* stream);
+
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
  * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */
