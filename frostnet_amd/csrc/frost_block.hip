@@ -285,6 +285,255 @@ static int launch_blk_a(BlkAP& p, hipStream_t s) {
   return frost_check_launch("block_expand_dw");
 }
 
+// ================================================================================================ kernel B: conv2 emit + reduce_conv GEMM / statistics
+struct BlkBP {
+  const int8_t* y1; const float* qy1;               // conv2's input (conv1's output) and its record
+  const int8_t* wq2; const int32_t* wsum2;          // conv2 (depthwise): taps [k*k][cpad], weight sums
+  const float* coef2; const float* qy2; int8_t* y2; // conv2: coefficient rows (finalized), output record, output tensor [n*map][c]
+  const int8_t* w3; const int32_t* wsum3;           // reduce_conv: MFMA-fragment weight pack [CT3][nchunk][64][16 B], weight sums
+  int32_t* cint; uint8_t* stats3; FrostFinDesc fin; // reduce_conv: integer conv output [n*map][cout], statistics table, finalize descriptor
+  int n, c, cpad, cout, cpad3, nchunk, imgs, relu2;
+};
+
+template <int K, int HW, int NW>
+struct BlkGeoB : BlkGeo<K, HW, NW> {
+  using G = BlkGeo<K, HW, NW>;
+  static constexpr int Y2 = G::NPH * G::NPTW * 16 * 64;                  // conv2's quantised output of one chunk, [pixel][64 ch]: the GEMM's B operand as it lies
+  __host__ __device__ static constexpr int lds(int cpad3) { return G::PLANE + Y2 + 2 * K * K * 64 + 64 + cpad3 * 24; }
+};
+
+// NCTW: reduce_conv output-channel tiles per wave (tiles wct, wct + 4, ...)
+template <int K, int HW, int NW, int NCTW>
+__global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
+  using G = BlkGeoB<K, HW, NW>;
+  constexpr int MAP = G::MAP, NPTW = G::NPTW, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  constexpr int YU = (MAP * 8 + NT - 1) / NT;                    // 8-byte units of a y chunk per thread
+  constexpr int NTAPW = (K * K * 16 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const pl = smem;                                      // [PHA][PITCH][64]  y1 chunk with its zero-point halo
+  uint8_t* const y2t = smem + G::PLANE;                          // [NPT*16][64]      y2 chunk
+  uint8_t* const taps = y2t + G::Y2;                             // [2][k*k][64]
+  int* const sflag = (int*)(taps + 2 * K * K * 64);
+  unsigned long long* const l_s1 = (unsigned long long*)(sflag + 16);
+  unsigned long long* const l_s2 = l_s1 + p.cpad3;
+  int* const l_mn = (int*)(l_s2 + p.cpad3); int* const l_mx = l_mn + p.cpad3;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int ph = (NW == 8) ? (w >> 2) : 0, wct = w & 3;
+  const int CT3 = p.cpad3 >> 4;
+  const int img_lo = (int)blockIdx.x * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+  const int nit = (img_hi - img_lo) * p.nchunk;
+
+  const int zp1 = __float_as_int(p.qy1[FROST_Q_ZP]), zp2 = __float_as_int(p.qy2[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zp1 - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)pl)[i] = make_uint4(zf, zf, zf, zf);
+    for (int i = tid; i < (G::Y2 >> 4); i += NT) ((uint4*)y2t)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < p.cpad3; i += NT) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }
+  }
+  const float y_inv = 1.0f / p.qy2[FROST_Q_SCALE], y_zpf = (float)zp2;
+  const float qcap = (float)q_hi(p.qy2); const bool lowq = qcap < 255.0f;
+  const float relu_floor = p.relu2 ? 0.0f : -INFINITY;
+  const int zpx3 = zp2 - 128;
+  // the plane / tensor position of the y units this thread moves (the same for every chunk)
+  int uoff[YU]; int upx[YU];
+#pragma unroll
+  for (int i = 0; i < YU; ++i) {
+    const int u = tid + i * NT, px = u >> 3, part = u & 7;
+    const int r = px / HW, cc = px - r * HW;
+    upx[i] = (u < MAP * 8) ? px : -1;
+    uoff[i] = ((r + PAD) * PITCH + cc + PAD) * 64 + part * 8;
+  }
+  const int upart = (tid & 7) * 8;                                // NT is a multiple of 8: every unit of a thread has the same channel part
+  const int tap_c = (tid & 15) * 4;
+  auto load_y1 = [&](int img, int chunk, uint2 (&dst)[YU]) __attribute__((always_inline)) {
+    const int8_t* src = p.y1 + (int64_t)img * MAP * p.c + chunk * 64 + upart;
+    const bool cok = (chunk * 64 + upart) < p.c;
+#pragma unroll
+    for (int i = 0; i < YU; ++i) dst[i] = (upx[i] >= 0 && cok) ? *(const uint2*)(src + (int64_t)upx[i] * p.c) : make_uint2(0, 0);
+  };
+  auto load_taps = [&](int chunk, uint32_t (&dst)[NTAPW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NTAPW; ++i) {
+      const int t = (tid + i * NT) >> 4;
+      dst[i] = (t < K * K && (chunk * 64 + tap_c) < p.c) ? *(const uint32_t*)(p.wq2 + t * p.cpad + chunk * 64 + tap_c) : 0u;
+    }
+  };
+  struct ChRow { float A, B; int ws; };
+  auto load_row = [&](int chunk) __attribute__((always_inline)) {
+    ChRow r; const int c2 = chunk * 64 + lane; const bool ok = c2 < p.c;
+    r.A = ok ? p.coef2[FROST_COEF_A * p.cpad + c2] : 0.0f; r.B = ok ? p.coef2[FROST_COEF_B * p.cpad + c2] : 0.0f; r.ws = ok ? p.wsum2[c2] : 0;
+    return r;
+  };
+  uint2 yv[YU]; uint32_t tv[NTAPW]; ChRow row_n;
+  if (nit > 0) { load_y1(img_lo, 0, yv); load_taps(0, tv); row_n = load_row(0); }
+  v4i acc[NCTW][NPTW];
+  __syncthreads();
+
+  for (int it = 0; it < nit; ++it) {
+    const int img = img_lo + it / p.nchunk, chunk = it - (it / p.nchunk) * p.nchunk;
+    uint8_t* const tapb = taps + (it & 1) * K * K * 64;
+    if (chunk == 0) {
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
+    }
+    // ---- 1. this chunk's y1 rows into the plane, its taps into LDS; 2. the next chunk's come into registers under the arithmetic
+#pragma unroll
+    for (int i = 0; i < YU; ++i) if (upx[i] >= 0) *(uint2*)(pl + uoff[i]) = yv[i];
+#pragma unroll
+    for (int i = 0; i < NTAPW; ++i) { const int t = (tid + i * NT) >> 4; if (t < K * K) *(uint32_t*)(tapb + t * 64 + tap_c) = tv[i]; }
+    const ChRow row = row_n;
+    v4i afr[NCTW];
+#pragma unroll
+    for (int m = 0; m < NCTW; ++m) {       // reduce_conv weight fragments of this K step (one chunk = 64 input channels), consumed after the depthwise phase
+      const int ct = min(wct + 4 * m, CT3 - 1);
+      afr[m] = *(const v4i*)(p.w3 + ((((int64_t)ct * p.nchunk + chunk) * 64 + lane) << 4));
+    }
+    if (it + 1 < nit) {
+      const int it2 = it + 1; const int img2 = img_lo + it2 / p.nchunk, chunk2 = it2 - (it2 / p.nchunk) * p.nchunk;
+      load_y1(img2, chunk2, yv); load_taps(chunk2, tv); row_n = load_row(chunk2);
+    }
+    blk_barrier();
+    // ---- conv2: depthwise conv + emit (k_dw3's expression) of output rows 2w, 2w + 1, lane = channel -> y2 chunk [pixel][64]
+    if (w < G::NRG) {
+      int wpk[K][2];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) { const uint32_t b = tapb[(ky * K + kx) * 64 + lane]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+        wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+      }
+      const int acc0 = (128 - zp1) * row.ws;
+#pragma unroll 1
+      for (int seg = 0; seg < G::NSEG; ++seg) {
+        int a[2][8];
+        blk_dw_unit<K, PITCH>(pl, 2 * w, seg, lane, wpk, acc0, a);
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
+              const float yf = fmaf(row.A, (float)a[o][r], row.B);
+              float qv = rintf(fmaxf(yf, relu_floor) * y_inv) + y_zpf;
+              if (lowq) qv = fminf(qv, qcap);
+              y2t[((2 * w + o) * HW + seg * 8 + r) * 64 + lane] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
+            }
+          }
+      }
+    }
+    blk_barrier();
+    // ---- y2 chunk out to HBM; reduce_conv: acc[cout tile][pixel tile] += W3[:, chunk] * y2 chunk
+    {
+      int8_t* dst = p.y2 + (int64_t)img * MAP * p.c + chunk * 64 + upart;
+      if ((chunk * 64 + upart) < p.c) {
+#pragma unroll
+        for (int i = 0; i < YU; ++i) if (upx[i] >= 0) *(uint2*)(dst + (int64_t)upx[i] * p.c) = *(const uint2*)(y2t + upx[i] * 64 + upart);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NPTW; ++t) {
+      const v4i bfr = *(const v4i*)(y2t + ((ph * NPTW + t) * 16 + j) * 64 + g * 16);
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m) acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[m], bfr, acc[m][t], 0, 0, 0);        // D[chan][pix]
+    }
+    if (chunk == p.nchunk - 1) {
+      // ---- the image's integer conv output c = acc - (zp - 128) * wsum and its exact statistics (table format of k_pw / conv_finalize_dev)
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m) {
+        const int ct = wct + 4 * m;
+        if (ct >= CT3) continue;
+        const int ch0 = ct * 16 + 4 * g;
+        const v4i ws = *(const v4i*)(p.wsum3 + ch0);
+        long long a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}; int mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) {
+          const int px = (ph * NPTW + t) * 16 + j;
+          if (px < MAP && ch0 < p.cout) {
+            const v4i cv = (v4i){acc[m][t][0] - zpx3 * ws[0], acc[m][t][1] - zpx3 * ws[1], acc[m][t][2] - zpx3 * ws[2], acc[m][t][3] - zpx3 * ws[3]};
+            *(v4i*)(p.cint + ((int64_t)img * MAP + px) * p.cout + ch0) = cv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int v = cv[r]; a1[r] += v; a2[r] += (long long)v * v; mn[r] = min(mn[r], v); mx[r] = max(mx[r], v); }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {                               // the 16 pixel lanes j of this g
+            a1[r] += __shfl_xor(a1[r], o); a2[r] += __shfl_xor(a2[r], o); mn[r] = min(mn[r], __shfl_xor(mn[r], o)); mx[r] = max(mx[r], __shfl_xor(mx[r], o));
+          }
+          if (j == 0 && (ch0 + r) < p.cout && mn[r] <= mx[r]) {
+            atomicAdd(&l_s1[ch0 + r], (unsigned long long)a1[r]); atomicAdd(&l_s2[ch0 + r], (unsigned long long)a2[r]);
+            atomicMin(&l_mn[ch0 + r], mn[r]); atomicMax(&l_mx[ch0 + r], mx[r]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    long long* g_s1 = (long long*)p.stats3; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
+    int* g_mn = (int*)(g_s2 + p.cpad3); int* g_mx = g_mn + p.cpad3;
+    for (int i = tid; i < p.cout; i += NT) {
+      if (l_mn[i] <= l_mx[i]) {
+        atomicAdd((unsigned long long*)&g_s1[i], l_s1[i]); atomicAdd(&g_s2[i], l_s2[i]);
+        atomicMin(&g_mn[i], l_mn[i]); atomicMax(&g_mx[i], l_mx[i]);
+      }
+    }
+  }
+  if (last_block_done2(p.fin.counter, gridDim.x, sflag)) {
+    float* sh = (float*)smem;
+    conv_finalize_dev(p.stats3, (int64_t)p.n * MAP, p.cout, p.cpad3, p.qy2, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+                      p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, NT, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
+  }
+}
+
+template <int K, int HW, int NW, int NCTW>
+static int launch_blk_b(BlkBP& p, hipStream_t s) {
+  using G = BlkGeoB<K, HW, NW>;
+  const size_t lds = (size_t)G::lds(p.cpad3);
+  FROST_REQUIRE(lds <= 160 * 1024, "block_dw_reduce: LDS budget exceeded");
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_reduce<K, HW, NW, NCTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_blk_dw_reduce<K, HW, NW, NCTW>), dim3((unsigned)((p.n + p.imgs - 1) / p.imgs)), dim3(NW * 64), lds, s, p);
+  return frost_check_launch("block_dw_reduce");
+}
+
+extern "C" int frost_block_dw_reduce_supported(int h, int w, int k, int stride, int c, int cout) {
+  const int ct3 = (cout + 15) / 16;
+  return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (c % 8) == 0 && (cout % 4) == 0 && ct3 <= (h == 7 ? 20 : 8)) ? 1 : 0;
+}
+
+extern "C" int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, const int8_t* wq2, const int32_t* wsum2, const float* coef2, const float* qrec_y2,
+                                     int relu2, int8_t* y2, int n, int h, int w, int c, int k, const int8_t* w3_pack, const int32_t* wsum3, int cout,
+                                     int32_t* conv_out, void* stats3, const FrostFinDesc* fin3, void* stream) {
+  FROST_REQUIRE(frost_block_dw_reduce_supported(h, w, k, 1, c, cout), "block_dw_reduce: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1, cout <= 320 / 128)");
+  FROST_REQUIRE(fin3 && fin3->counter && fin3->coef && fin3->qrec_y && conv_out && stats3, "block_dw_reduce: incomplete arguments");
+  BlkBP p = {};
+  p.y1 = y1; p.qy1 = qrec_y1; p.wq2 = wq2; p.wsum2 = wsum2; p.coef2 = coef2; p.qy2 = qrec_y2; p.y2 = y2; p.w3 = w3_pack; p.wsum3 = wsum3; p.cint = conv_out;
+  p.stats3 = (uint8_t*)stats3; p.fin = *fin3; p.n = n; p.c = c; p.cpad = round_up(c, 16); p.cout = cout; p.cpad3 = round_up(cout, 16); p.nchunk = (c + 63) / 64;
+  p.relu2 = relu2;
+  static const int imgs_env = getenv("FROST_BLK_IMGS_B") ? atoi(getenv("FROST_BLK_IMGS_B")) : 0;
+  int imgs = imgs_env > 0 ? imgs_env : (n + 1023) / 1024;          // the K split keeps an image in one workgroup: one image each up to 1024 workgroups
+  if (imgs < 1) imgs = 1;
+  p.imgs = imgs;
+  hipStream_t s = as_stream(stream);
+  const int ct3 = p.cpad3 >> 4;
+  if (h == 7) {
+    const int nctw = (ct3 + 3) / 4;
+#define BLK_B(KK, NN) if (k == KK && nctw <= NN) return launch_blk_b<KK, 7, 4, NN>(p, s);
+    BLK_B(3, 3) BLK_B(3, 5) BLK_B(5, 3) BLK_B(5, 5)
+#undef BLK_B
+  } else {
+    if (k == 3) return launch_blk_b<3, 14, 8, 2>(p, s);
+    return launch_blk_b<5, 14, 8, 2>(p, s);
+  }
+  FROST_REQUIRE(false, "block_dw_reduce: no instance");
+  return 1;
+}
+
 extern "C" int frost_block_supported(int h, int w, int k, int stride, int cin, int c) {
   return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (cin % 8) == 0 && cin > (h == 7 ? 64 : 0) && cin <= (h == 7 ? 320 : 192) && (c % 8) == 0) ? 1 : 0;
 }

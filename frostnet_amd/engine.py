@@ -32,6 +32,7 @@ _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary 
 # per step with it vs 24.7-24.8 without (profiles/r03_block_fusion_ab.txt) -- the element-wise kernels' time is their single-workgroup observer tail, which
 # the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
 _BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit + conv2 statistics in one launch at the 14x14 / 7x7 stages (csrc/frost_block.hip)
+_BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -42,7 +43,7 @@ _DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
@@ -50,6 +51,7 @@ class Act:
         self.needs_grad = True
         self.cint = None          # wide-K pointwise layers: the integer conv output this activation was emitted from, kept for the backward
         self.cat_observed = False  # the cat consuming this activation already had its FakeQuantize record updated (folded into this layer's finalize)
+        self.kept_next = None      # set by conv_pair: the integer conv output of the reduce_conv consuming this activation (its statistics pass already ran)
         self.sum_observed = False  # the residual add consuming this activation already had its range pass (fused into this layer's emit)
 
     @property
@@ -297,9 +299,12 @@ class Engine:
             if _PW_KEEP and l.kind == "pw" and x.c > 256 and l.cout < x.c:
                 # wide-K reduce layer (x rows too long for k_pw's DMA tile, Cout < Cin: the int32 output is smaller than the x re-reads it saves): statistics + finalize on the stand-alone int8 GEMM kernel, which also stores the
                 # integer conv output (smaller than x); y is emitted element-wise from it and the backward's reduce / dc need no recomputation
-                cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
-                call("frost_pw_conv_fwd_keep", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(cint),
-                     stream(), prof=("pw_fwd_stats", nb + 4 * y.numel))
+                cint = getattr(x, "kept_next", None)          # conv_pair ran this layer's GEMM / statistics / finalize inside the block kernel
+                if cint is None:
+                    cint = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+                    call("frost_pw_conv_fwd_keep", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(cint),
+                         stream(), prof=("pw_fwd_stats", nb + 4 * y.numel))
+                x.kept_next = None
                 if residual is not None and observe and _BLOCK_EMIT_ADD:
                     a, q_sum = residual
                     call("frost_pw_ew_emit_add", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(a.buf), ptr(a.q), ptr(y.buf), ptr(self._add_state()),
@@ -339,7 +344,13 @@ class Engine:
                     and getattr(l1, "hswish", None) is None and getattr(l2, "hswish", None) is None
                     and L.load_library().frost_block_supported(x.h, x.w, l2.k, l2.stride, x.c, l1.cout))
 
-    def conv_pair(self, l1, l2, x, training=True, observe=True):
+    def reduce_fusable(self, l2, l3, y1):
+        """conv2 -> reduce_conv: conv2's emit pass and reduce_conv's GEMM / statistics (kept-output path) as one launch."""
+        return bool(_BLOCK_DWRED and _PW_KEEP and l3 is not None and l3.kind == "pw" and l3.k == 1 and l2.cout > 256 and l3.cout < l2.cout
+                    and getattr(l3, "hswish", None) is None
+                    and L.load_library().frost_block_dw_reduce_supported(y1.h, y1.w, l2.k, l2.stride, l2.cout, l3.cout))
+
+    def conv_pair(self, l1, l2, x, training=True, observe=True, l3=None):
         """`conv2(conv1(x))` of CascadePreExBottleneck.forward (frostnet.py:134-137) with the expanded tensor kept on chip between conv1's activation
         FakeQuantize and conv2's batch statistics: conv1 statistics + finalize (k_pw) -> frost_block_expand_dw_stats -> conv2 emit (k_dw3).
         Tape and saved tensors are those of two Engine.conv calls: the backward is unchanged."""
@@ -354,7 +365,17 @@ class Engine:
              l1.cout, ptr(l2.wq_pack), ptr(l2.wsum), l2.k, ptr(l2.stats), C.byref(fin2), stream(),
              prof=("blk_expand_dw", x.numel + l1.wq_pack.numel() + y1.numel))
         y2 = self.new_act(x.n, x.h, x.w, l2.cout, l2.qy)
-        self._conv_launch(l2, y1, 1, y2)
+        if self.reduce_fusable(l2, l3, y1):
+            # the block's third boundary: y2 goes from the depthwise stencil through LDS into reduce_conv's K-split GEMM; Engine.conv(l3, y2, kept=...) emits
+            cint = torch.empty(x.npix * l3.cout + 64, dtype=torch.int32, device=self.device)
+            fin3 = L.FrostFinDesc(l3.qw.data_ptr(), l3.gamma.data_ptr(), l3.beta.data_ptr(), l3.rmean.data_ptr(), l3.rvar.data_ptr(), l3.nbt.data_ptr(),
+                                  l3.coef.data_ptr(), l3.qy.data_ptr(), l3.fin_counter.data_ptr(), 1, int(l3.relu), 1, 0, l3.wscale.data_ptr(), None, None)
+            call("frost_block_dw_reduce", ptr(y1.buf), ptr(y1.q), ptr(l2.wq_pack), ptr(l2.wsum), ptr(l2.coef), ptr(l2.qy), int(l2.relu), ptr(y2.buf), x.n, x.h, x.w,
+                 l2.cout, l2.k, ptr(l3.wq_pack), ptr(l3.wsum), l3.cout, ptr(cint), ptr(l3.stats), C.byref(fin3), stream(),
+                 prof=("blk_dw_reduce", y1.numel + y2.numel + l3.wq_pack.numel() + 4 * x.npix * l3.cout))
+            y2.kept_next = cint
+        else:
+            self._conv_launch(l2, y1, 1, y2)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l1.name, y1)); self.trace.append((l2.name, y2))
         self.tape.append(("conv", l1, x, y1))

@@ -279,7 +279,7 @@ class FrostRunner:
                     sq = self._conv(d["squeeze"], inp, training, obs)
                 out = E.cat(sq, inp, d["q_cat"], obs)
             if E.pair_fusable(d["conv1"], d["conv2"], out, training, obs):
-                out = E.conv_pair(d["conv1"], d["conv2"], out, training, obs)
+                out = E.conv_pair(d["conv1"], d["conv2"], out, training, obs, l3=d["reduce"])
             else:
                 out = self._conv(d["conv2"], self._conv(d["conv1"], out, training, obs), training, obs)
         else:

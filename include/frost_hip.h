@@ -375,6 +375,17 @@ int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x, const int8
                                 const float* qrec_y1, int8_t* y1, int n, int h, int w, int cin, int c, const int8_t* wq2, const int32_t* wsum2,
                                 int k, void* stats2, const FrostFinDesc* fin2, void* stream);
 
+/* frost_block_dw_reduce replaces: conv2's emit pass (frost_dw_conv_fwd mode 1: BN + ReLU + activation FakeQuantize of `self.conv2`, frostnet.py:137)
+ * TOGETHER with reduce_conv's statistics pass on the kept-output path (frost_pw_conv_fwd_keep: int8 GEMM, integer conv output stored, batch statistics,
+ * folded finalize of `self.reduce_conv`, frostnet.py:138).  One workgroup per image, K-split over 64-channel chunks: y1 chunk -> LDS plane ->
+ * depthwise -> quantised y2 chunk (LDS; out to HBM once for the backward) -> MFMA partial sums of reduce_conv in registers across the chunks.
+ * conv2 must be finalized; conv_out / stats3 / fin3 as for frost_pw_conv_fwd_keep (frost_pw_ew mode 2 then emits reduce_conv's y).  Bit-identical
+ * to the two separate launches.  frost_block_dw_reduce_supported: 7x7 / 14x14 maps, k in {3,5}, stride 1, cout <= 320 (7x7) / 128 (14x14). */
+int frost_block_dw_reduce_supported(int h, int w, int k, int stride, int c, int cout);
+int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, const int8_t* wq2, const int32_t* wsum2, const float* coef2, const float* qrec_y2,
+                          int relu2, int8_t* y2, int n, int h, int w, int c, int k, const int8_t* w3_pack, const int32_t* wsum3, int cout,
+                          int32_t* conv_out, void* stats3, const FrostFinDesc* fin3, void* stream);
+
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
  * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */
