@@ -1,0 +1,79 @@
+"""Block-level fused forward kernels (csrc/frost_block.hip) against the layer-by-layer launches they replace.
+
+conv1 -> conv2 -> reduce_conv of a CascadePreExBottleneck (/root/reference/frostnet.py:134-138) at the 14x14 / 7x7 stages runs as
+  conv1 statistics (k_pw) -> frost_block_expand_dw_stats -> frost_block_dw_reduce -> reduce emit (frost_pw_ew)
+instead of six launches.  Same integer accumulators, same quantisation expressions, exact integer statistics: EVERY result must be bit-identical --
+conv1 / conv2 / reduce outputs, the kept integer conv output, BN coefficient rows, running statistics and the observers' records.  The layer-by-layer
+kernels themselves are held to the oracle and the reference goldens in test_gpu_ops / test_gpu_prod / test_gpu_model; the whole-network tests
+(test_gpu_model, test_gpu_prod) run with the block kernels on (default), so they cover the composition too."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (cin, cexp, H, k, cout, batch): FrostNet-Large's 7x7 / 14x14 bottlenecks, a partial last 64-channel chunk (1440 = 22.5 x 64, 360 = 5.6 x 64),
+# 8-mod-16 input rows (104, 120), batches that are not multiples of the images-per-workgroup split, and the widest reduce (1728 -> 320)
+CASES = [(240, 1440, 7, 5, 192, 5), (192, 1152, 7, 3, 192, 64), (288, 1728, 7, 5, 320, 9), (104, 624, 14, 5, 96, 3), (120, 360, 14, 3, 96, 33),
+         (160, 960, 14, 5, 96, 6), (104, 312, 14, 5, 80, 17)]
+
+
+def _build(cin, cexp, k, cout, seed):
+    from frostnet_amd import engine
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    E, qa = engine.Engine(dev), engine.QArena(10, dev)
+
+    def layer(name, kind, ci, co, kk, relu):
+        fan = ci if kind == "pw" else kk * kk
+        w = (torch.randn(co, 1 if kind == "dw" else ci, kk, kk, generator=g) * (2.0 / fan) ** 0.5).to(dev).requires_grad_(True)
+        gamma = (torch.rand(co, generator=g) * 0.5 + 0.75).to(dev).requires_grad_(True)
+        beta = (torch.rand(co, generator=g) * 0.2 - 0.05).to(dev).requires_grad_(True)
+        return E.add_layer(engine.ConvLayer(name, kind, w, gamma, beta, torch.zeros(co, device=dev), torch.ones(co, device=dev),
+                                            torch.zeros((), dtype=torch.int64, device=dev), None, kk, 1, relu, qa.alloc(), qa.alloc()))
+    l1, l2, l3 = layer("conv1", "pw", cin, cexp, 1, True), layer("conv2", "dw", cexp, cexp, k, True), layer("reduce", "pw", cexp, cout, 1, False)
+    qx = qa.alloc()
+    qa.set_qparams(qx, 0.02, 3)
+    return E, l1, l2, l3, qx
+
+
+def _run(case, fused, steps=2):
+    cin, cexp, H, k, cout, n = case
+    E, l1, l2, l3, qx = _build(cin, cexp, k, cout, 11)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    out = []
+    for _ in range(steps):            # the second step starts from moved running statistics / observer records
+        x = E.new_act(n, H, H, cin, qx)
+        x.buf[: x.numel] = torch.randint(-128, 128, (x.numel,), dtype=torch.int16, generator=g).to(torch.int8).to("cuda")
+        E.begin_step()
+        if fused:
+            assert E.pair_fusable(l1, l2, x, True, True)
+            y2 = E.conv_pair(l1, l2, x, l3=l3)
+            assert y2.kept_next is not None, "reduce_conv was expected on the fused path"
+        else:
+            y2 = E.conv(l2, E.conv(l1, x))
+        y3 = E.conv(l3, y2)
+        torch.cuda.synchronize()
+        y1 = E.tape[0][3]
+        out.append(dict(y1=y1.buf[: y1.numel].clone(), y2=y2.buf[: y2.numel].clone(), y3=y3.buf[: y3.numel].clone(), cint=y3.cint[: y3.numel].clone(),
+                        **{f"{nm}{i}": getattr(l, nm).clone() for i, l in enumerate((l1, l2, l3), 1) for nm in ("qy", "coef", "rmean", "rvar", "nbt")}))
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "_".join(str(v) for v in c))
+def test_block_kernels_bit_identical_to_layer_launches(case):
+    ref, got = _run(case, False), _run(case, True)
+    for step, (a, b) in enumerate(zip(ref, got)):
+        for key in a:
+            assert torch.equal(a[key].reshape(-1).view(torch.uint8), b[key].reshape(-1).view(torch.uint8)), (step, key)
+
+
+def test_block_kernels_refuse_unsupported_shapes():
+    from frostnet_amd import _lib as L
+    lib = L.load_library()
+    assert lib.frost_block_supported(14, 14, 5, 1, 104, 624) == 1 and lib.frost_block_supported(7, 7, 3, 1, 192, 1152) == 1
+    assert lib.frost_block_supported(28, 28, 3, 1, 56, 168) == 0          # 28x28: layer-by-layer
+    assert lib.frost_block_supported(14, 14, 5, 2, 104, 624) == 0          # stride 2: layer-by-layer
+    assert lib.frost_block_supported(7, 7, 5, 1, 328, 1968) == 0           # input rows beyond the resident tile
+    assert lib.frost_block_dw_reduce_supported(7, 7, 5, 1, 1728, 320) == 1 and lib.frost_block_dw_reduce_supported(14, 14, 5, 1, 624, 160) == 0
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        L.call("frost_block_expand_dw_stats", None, None, None, None, None, None, None, 1, 28, 28, 56, 168, None, None, 3, None, None, None)
