@@ -213,6 +213,16 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
   }
 }
 
+// Memory-model note.  The hand-off below (statistics written ONLY by agent-scope atomics, read back ONLY by agent-scope loads, the ticket ordered after
+// them by s_waitcnt vmcnt(0)) is what gfx942 / gfx950 guarantee for device-scope atomics, which are performed at the memory side; it is not a
+// release / acquire pair in the HIP / LLVM memory model.  This library is built for gfx950 only (__graft_entry__.FLAGS); on any other target the ticket is
+// bracketed by agent-scope fences (1.7 us each on the critical path of every layer on MI355X, measured -- hence not there).  tests/test_gpu_round3.py
+// runs the finalize stress (tests/devtools/stress_finalize.py) so that a compiler or architecture change that breaks the hand-off fails a test.
+#if defined(__gfx950__) || defined(__gfx942__) || !defined(__HIP_DEVICE_COMPILE__)
+#define FROST_TICKET_FENCE() ((void)0)
+#else
+#define FROST_TICKET_FENCE() __threadfence()
+#endif
 // Last-workgroup-done tail of a statistics kernel: every thread has issued its atomics; returns true in ALL threads of the one workgroup
 // that arrives last (its view of the other workgroups' atomics is then complete).  sflag: one int of shared memory.
 __device__ __forceinline__ bool last_block_done(uint32_t* counter, unsigned total, int* sflag) {
@@ -222,9 +232,10 @@ __device__ __forceinline__ bool last_block_done(uint32_t* counter, unsigned tota
     // No release / acquire fence (1.7 us each on the critical path of every layer): the statistics are written ONLY by agent-scope atomics and
     // read back ONLY by agent-scope (sc1) loads -- "agent atomics on both sides" needs no cache maintenance (MI355X guide, cross-XCD hand-off
     // forms); the vmcnt(0) above orders this workgroup's atomics before its ticket.
+    FROST_TICKET_FENCE();
     const unsigned t = atomicAdd(counter, 1u);
     *sflag = (t == total - 1u) ? 1 : 0;
-    if (t == total - 1u) *counter = 0u;    // re-armed for the next step
+    if (t == total - 1u) { FROST_TICKET_FENCE(); __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }    // re-armed for the next step
   }
   __syncthreads();
   return *sflag != 0;
@@ -245,16 +256,18 @@ __device__ __forceinline__ bool last_block_done2(uint32_t* counter, unsigned tot
 #else
     if (total <= 64u) {
 #endif
+      FROST_TICKET_FENCE();
       const unsigned t = atomicAdd(counter, 1u);
-      if (t == total - 1u) { *counter = 0u; last = 1; }
+      if (t == total - 1u) { FROST_TICKET_FENCE(); __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
     } else {
       const unsigned b = blockIdx.x + blockIdx.y * gridDim.x, s = b & 31u;
       const unsigned mine = (total - s + 31u) >> 5;                   // workgroups with linear index = s (mod 32)
+      FROST_TICKET_FENCE();
       const unsigned t = atomicAdd(counter + 1 + s, 1u);
       if (t == mine - 1u) {
-        counter[1 + s] = 0u;
+        __hip_atomic_store(counter + 1 + s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned t2 = atomicAdd(counter, 1u);
-        if (t2 == 31u) { *counter = 0u; last = 1; }
+        if (t2 == 31u) { FROST_TICKET_FENCE(); __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
       }
     }
     *sflag = last;

@@ -258,6 +258,23 @@ class _FrostBase(nn.Module):
     def _is_qat_prepared(self):
         return hasattr(self.conv1.conv[0], "weight_fake_quant")
 
+    def _flags_changed(self):
+        r = self.__dict__.get("_hip_runner")
+        if r is not None and hasattr(r, "flags_dirty"):
+            r.flags_dirty = True
+
+    def apply(self, fn):
+        """nn.Module.apply; `model.apply(torch.quantization.disable_observer)` and friends write the per-site enable flags on the device, so the
+        runner's host-side summary of them is re-read before the next forward (no per-forward device -> host read otherwise)."""
+        out = super().apply(fn)
+        self._flags_changed()
+        return out
+
+    def train(self, mode=True):
+        out = super().train(mode)
+        self._flags_changed()
+        return out
+
     def hip_runner(self):
         """The device executor bound to this module tree (built lazily, rebuilt if parameters were moved)."""
         if getattr(self, "_is_replica", False):

@@ -96,6 +96,7 @@ class FrostRunner:
     def __init__(self, model):
         L.load_library()   # raises if the HIP library is missing: no CPU fallback on the device path
         self.model = model
+        self.flags_dirty = True      # host summary of the per-site enable flags: re-read before the next forward (see _observe_hint)
         if not model._is_qat_prepared():
             raise NotImplementedError(
                 "FrostRunner binds the fake-quantised (QAT-prepared) FrostNet; the float model runs through "
@@ -128,24 +129,33 @@ class FrostRunner:
             off += p.numel()
         return r
 
-    @property
-    def observe(self):
-        """True iff any site's observer is enabled: ONE device->host read of the flag column of the qrecord arena (the torch
-        `observer_enabled` buffers are views into it).  Also the place where a disabled fake-quantizer is refused."""
+    def read_flags(self):
+        """ONE device -> host read of the enable-flag columns of the qrecord arena (the torch `observer_enabled` / `fake_quant_enabled` buffers are
+        views into it): refuses a disabled fake-quantizer, returns True iff any site's observer is enabled."""
         flags = self.qa.t.view(torch.int32)[: self.qa.next][:, [L.Q_OBS_EN, L.Q_FQ_EN]].cpu()
         if bool((flags[:, 1] == 0).any()):
             raise NotImplementedError("fake_quant_enabled == 0 (torch.quantization.disable_fake_quant): the int8 engine has no float "
                                       "activation mode; run the float model (FloatRunner) instead")
         return bool((flags[:, 0] != 0).any())
 
+    @property
+    def observe(self):
+        """True iff any site's observer is enabled (reads the device flags now)."""
+        self._obs_cached = self.read_flags()
+        self.flags_dirty = False
+        return self._obs_cached
+
     def _observe_hint(self, training):
-        """What the host passes as `observe`: 1 = run the statistics passes and let every site's own device flag decide.  Training
-        needs the statistics anyway (BatchNorm); eval reads the flags once per forward so that a fully frozen network skips them."""
-        if training:
-            return True
-        if not torch.cuda.is_current_stream_capturing():
-            self._obs_cached = self.observe
-        return getattr(self, "_obs_cached", True)
+        """What the host passes as `observe`: 1 = run the statistics passes and let every site's own device flag decide.  Training needs the
+        statistics anyway (BatchNorm); a fully frozen network in eval skips them.  The flags live on the device (per-site switches without a host
+        round trip); the host keeps a summary that is re-read only when it may have changed -- after `model.train()` / `.eval()`,
+        `model.apply(...)` (how torch.quantization.enable/disable_observer/fake_quant are applied) or `runner.flags_dirty = True` -- not on every
+        forward, and for training as well as eval (a disabled fake-quantizer is refused in both).  A flag written straight into a sub-module's
+        buffer without any of these is honoured per site on the device at once and reaches the summary at the next mode switch."""
+        if getattr(self, "flags_dirty", True) and not torch.cuda.is_current_stream_capturing():
+            self._obs_cached = self.read_flags()
+            self.flags_dirty = False
+        return True if training else getattr(self, "_obs_cached", True)
 
     def rng_state(self):
         return rng_state(self)

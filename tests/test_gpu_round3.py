@@ -397,3 +397,47 @@ def test_fused_reduce_emit_and_add_range_pass_equals_the_two_launches(engine):
             assert torch.equal(qs1.view(torch.int32)[:8], qs2.view(torch.int32)[:8]), (qs1, qs2)
             assert torch.equal(st1.view(torch.int32), st2.view(torch.int32)) and float(st2[0]) == float("inf") and int(st2.view(torch.int32)[2:].abs().sum()) == 0
             cint = (cint // 2).contiguous()                   # different data for the second observation
+
+
+def test_statistics_finalize_handoff_stress():
+    """The statistics -> finalize hand-off of every conv layer (last-workgroup-done ticket, agent-scope atomics read back by agent-scope loads, no fences on
+    gfx950: csrc/frost_common.h) under a stress run: two copies of FrostNet-Large run 60 training-mode forwards on the same inputs; the forward is
+    bit-reproducible, so one stale statistic anywhere shows up as a differing logit or state entry (keep this as a test, not a devtool)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "devtools", "stress_finalize.py"), "60", "16"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "0 steps with differing logits, 0 state entries differ" in out.stdout, out.stdout[-1000:]
+
+
+def test_flag_summary_is_host_side_and_follows_apply():
+    """The runner's `observe` summary is read from the device only after train() / eval() / model.apply(...) (no per-forward device -> host read),
+    a disabled fake-quantizer is refused in training as well as in eval, and per-site flags keep working without any host involvement."""
+    import torch
+    from frostnet_amd import frostnet as F
+    torch.manual_seed(0)
+    m = F.MODEL_REGISTRY["frostnet_quant_small_0_5"](nclass=10)
+    F.qat_prepare(m, version=0)
+    m.cuda().train()
+    x = torch.randn(4, 3, 64, 64, device="cuda")
+    m(x)
+    r = m.hip_runner()
+    assert r.flags_dirty is False
+    reads = []
+    orig = r.read_flags
+    r.read_flags = lambda: (reads.append(1), orig())[1]
+    m(x); m(x)
+    assert not reads, "a training forward read the flags although nothing changed"
+    m.eval()
+    with torch.no_grad():
+        m(x); m(x)
+    assert len(reads) == 1, reads                      # once after the mode switch
+    m.apply(torch.quantization.disable_observer)
+    with torch.no_grad():
+        m(x)
+    assert len(reads) == 2 and r._obs_cached is False
+    m.apply(torch.quantization.enable_observer)
+    m.apply(torch.quantization.disable_fake_quant)
+    m.train()
+    with pytest.raises(NotImplementedError, match="fake_quant_enabled"):
+        m(x)
+    m.apply(torch.quantization.enable_fake_quant)
+    m(x)
