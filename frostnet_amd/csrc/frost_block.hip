@@ -534,6 +534,263 @@ extern "C" int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, con
   return 1;
 }
 
+// ================================================================================================ kernel C: depthwise backward -- dc + weight gradient + data gradient
+// conv2's backward after its reduce pass (S1 / S2 in the coefficient rows): today three launches (dc pass, weight gradient, data gradient: 12 bytes per
+// element through HBM, the dc tensor written once and read twice).  Here a workgroup holds one image's 64-channel chunk: x plane (int8, zero-point halo)
+// and gout tile in LDS -> recomputed conv, STE window, dc = fma(gy, K1, fma(acc, E, F)) rounded to bf16 (k_dw3's expressions) -> dc plane in LDS (zero
+// halo) -> weight-gradient sums (lane-local, 25 accumulators across the workgroup's images) and the data gradient straight from the plane: the whole map
+// is resident, so the data gradient needs no halo recomputation and dc never reaches HBM.  5 bytes per element.
+struct BlkCP {
+  const int8_t* x; const float* qx;                 // conv2's input (y1) and its record
+  const int8_t* wq; const int32_t* wsum; const float* qw; const float* wscale;   // taps [k*k][cpad], weight sums, weight record, per-channel scales (or NULL)
+  const float* coef; const float* qy;               // coefficient rows after the reduce pass (S1 / S2 filled), output record
+  const uint16_t* gout; uint16_t* dx; float* dwq;   // gradient w.r.t. conv2's output (bf16), w.r.t. its input (bf16, or NULL), raw weight-gradient sums [c][k*k]
+  int n, c, cpad, nchunk, imgs, relu, sr; float inv_count;
+};
+
+template <int K, int HW, int NW>
+struct BlkGeoC : BlkGeo<K, HW, NW> {
+  using G = BlkGeo<K, HW, NW>;
+  static constexpr int DPL = G::PLANE * 2;                                // dc plane, bf16, same [row][col][64] geometry as the x plane
+  static constexpr int GT = (G::MAP + 8) * 64 * 2;                        // gout tile bf16 [pixel][64] (+ slack: the last row's 4-pixel reads run past it)
+  static constexpr int RED = NW * K * K * 64 * 4;                         // weight-gradient partials of the waves (reuses the planes after the loop)
+  __host__ __device__ static constexpr int lds() { return (G::PLANE + DPL + GT > RED ? G::PLANE + DPL + GT : RED) + 64; }
+};
+
+__device__ __forceinline__ void blk_tr16(const uint8_t* row, int col0, int lane, float* out4) {     // 4 consecutive pixels of channel `lane` of a bf16 [col][64 ch] row
+  typedef short v4s_ __attribute__((ext_vector_type(4)));
+  const int jp = lane & 15, G = lane >> 4;
+  const v4s_ raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(row + ((col0 + (jp >> 2)) * 64 + 16 * G + 4 * (jp & 3)) * 2));
+  out4[0] = bf2f((uint16_t)raw[0]); out4[1] = bf2f((uint16_t)raw[1]); out4[2] = bf2f((uint16_t)raw[2]); out4[3] = bf2f((uint16_t)raw[3]);
+}
+
+template <int K, int HW, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
+  using G = BlkGeoC<K, HW, NW>;
+  constexpr int MAP = G::MAP, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  constexpr int XU = (MAP * 8 + NT - 1) / NT, GU = (MAP * 8 + NT - 1) / NT;       // 8-byte units of x, 16-byte units of gout per thread (8 per pixel each)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
+  uint8_t* const dpl = smem + G::PLANE;                         // [PHA][PITCH][64] bf16
+  uint8_t* const gt = dpl + G::DPL;                             // [MAP][64] bf16
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+  const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
+
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
+    for (int i = tid; i < ((G::DPL + G::GT) >> 4); i += NT) ((uint4*)dpl)[i] = make_uint4(0, 0, 0, 0);
+  }
+  // per-lane (= per-channel) constants
+  int wpk[K][2]; float wf[K * K];         // (the taps as floats in LDS instead, to fit 3 waves per SIMD: 28 spilled registers, 20 % slower -- measured)
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int8_t wv = chok ? p.wq[(ky * K + kx) * p.cpad + ch] : (int8_t)0;
+      wf[ky * K + kx] = (float)wv;
+      const uint32_t b = (uint32_t)(uint8_t)wv; if (kx < 4) lo |= b << (8 * kx); else hi |= b;
+    }
+    wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+  }
+  const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;
+  const float sw = (p.wscale && chok) ? p.wscale[ch] : p.qw[FROST_Q_SCALE];
+  float cA = 0, cB = 0, cK1 = 0, cE = 0, cF = 0;
+  if (chok) {
+    cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
+    const float m = p.coef[FROST_COEF_M * p.cpad + ch], cR = p.coef[FROST_COEF_R * p.cpad + ch];
+    cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
+    cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
+    cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+  }
+  const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
+  float t_lo = 0.0f, t_hi;
+  {
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
+    const float hi0 = (float)qhi + 0.5f - (float)zpy;
+    t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  const bool sr_on = p.sr != 0;
+  float wacc[K * K]; float sdc = 0.0f;
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wacc[t] = 0.0f;
+  // staging plan (the same for every image): unit u -> pixel u >> 3, 8-byte (x) / 16-byte (gout) part u & 7
+  int upx[XU], uoff[XU];
+#pragma unroll
+  for (int i = 0; i < XU; ++i) {
+    const int u = tid + i * NT, px = u >> 3;
+    const int r = px / HW, cc = px - r * HW;
+    upx[i] = (u < MAP * 8) ? px : -1;
+    uoff[i] = ((r + PAD) * PITCH + cc + PAD) * 64;
+  }
+  const int part = tid & 7;
+  const bool pok = (chunk * 64 + part * 8) < p.c;
+  uint2 xv[XU]; uint4 gv[GU];
+  auto prefetch = [&](int img) __attribute__((always_inline)) {
+    const int8_t* xs = p.x + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
+    const uint16_t* gs = p.gout + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const bool ok = upx[i] >= 0 && pok;
+      xv[i] = ok ? *(const uint2*)(xs + (int64_t)upx[i] * p.c) : make_uint2(0, 0);
+      gv[i] = ok ? *(const uint4*)(gs + (int64_t)upx[i] * p.c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (img_lo < img_hi) prefetch(img_lo);
+  __syncthreads();
+
+  for (int img = img_lo; img < img_hi; ++img) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      if (upx[i] >= 0) { if (pok) *(uint2*)(xpl + uoff[i] + part * 8) = xv[i]; *(uint4*)(gt + (upx[i] * 64 + part * 8) * 2) = gv[i]; }
+    }
+    if (img + 1 < img_hi) prefetch(img + 1);
+    blk_barrier();
+    // ---- dc of output rows 2w, 2w + 1 (lane = channel) -> dc plane; weight-gradient sums over the same rows
+    if (w < G::NRG) {
+#pragma unroll 1
+      for (int seg = 0; seg < G::NSEG; ++seg) {
+        int a[2][8];
+        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+        float dcv[2][8];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          float gq[8];
+          const uint8_t* grow = gt + ((2 * w + o) * HW) * 64 * 2;
+          blk_tr16(grow, seg * 8, lane, gq); blk_tr16(grow, seg * 8 + 4, lane, gq + 4);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const bool valid = (2 * w + o) < HW && (seg * 8 + r) < HW && chok;
+            const float v = (float)a[o][r];
+            const float tq = fmaf(cA, v, cB) * y_inv;
+            const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+            const float dcf = fmaf(gy, cK1, fmaf(v, cE, cF));
+            const uint32_t db = __float_as_uint(dcf), dr = sr_next16(rng);
+            const uint32_t hb = (db + (sr_on ? dr : 0x7fffu + ((db >> 16) & 1u))) >> 16;
+            if (valid) *(uint16_t*)(dpl + (((2 * w + o + PAD) * PITCH + seg * 8 + r + PAD) * 64 + lane) * 2) = (uint16_t)hb;
+            dcv[o][r] = valid ? __uint_as_float(hb << 16) : 0.0f;
+            sdc += dcv[o][r];
+          }
+        }
+        // wacc[ky][kx] += dc[o][r] * q[o + ky][r + kx]  (q = unsigned index; the zero point comes off through sdc at the end)
+#pragma unroll
+        for (int jr = 0; jr < K + 1; ++jr) {
+          const uint8_t* rowp = xpl + (2 * w + jr) * PITCH * 64;
+          const v2i ra = blk_tr8(rowp, seg * 8, lane), rb = blk_tr8(rowp, seg * 8 + 8, lane);
+          const uint32_t u[4] = {(uint32_t)ra[0] ^ 0x80808080u, (uint32_t)ra[1] ^ 0x80808080u, (uint32_t)rb[0] ^ 0x80808080u, (uint32_t)rb[1] ^ 0x80808080u};
+          float xr[12];
+#pragma unroll
+          for (int i = 0; i < 12; ++i) xr[i] = (float)((u[i >> 2] >> (8 * (i & 3))) & 255u);
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            if ((jr - ky) >= 0 && (jr - ky) < 2) {
+              const int o = jr - ky;
+#pragma unroll
+              for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) wacc[ky * K + kx] = fmaf(dcv[o][r], xr[r + kx], wacc[ky * K + kx]);
+            }
+          }
+        }
+      }
+    }
+    blk_barrier();
+    // ---- data gradient of input rows 2w, 2w + 1 from the dc plane: dx[iy][ix] = s_w * sum dc[iy + pad - ky][ix + pad - kx] * wq[ky][kx]  (k_dw3_dgrad's order)
+    if (p.dx && w < G::NRG) {
+#pragma unroll 1
+      for (int seg = 0; seg < G::NSEG; ++seg) {
+        float acc[2][8];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) acc[o][r] = 0.0f;
+#pragma unroll
+        for (int jr = 0; jr < K + 1; ++jr) {
+          float dcr[12];
+          const uint8_t* rowp = dpl + ((2 * w + jr) * PITCH) * 64 * 2;
+          blk_tr16(rowp, seg * 8, lane, dcr); blk_tr16(rowp, seg * 8 + 4, lane, dcr + 4); blk_tr16(rowp, seg * 8 + 8, lane, dcr + 8);
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            const int ky = o + K - 1 - jr;
+            if (ky >= 0 && ky < K) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[o][r] = fmaf(dcr[r + K - 1 - kx], wf[ky * K + kx], acc[o][r]);
+            }
+          }
+        }
+        uint16_t* dst = p.dx + (int64_t)img * MAP * p.c + ch;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if ((2 * w + o) < HW && (seg * 8 + r) < HW && chok) dst[(int64_t)((2 * w + o) * HW + seg * 8 + r) * p.c] = (uint16_t)cvt_pk_bf16(acc[o][r] * sw, 0.0f);
+      }
+    }
+    blk_barrier();
+  }
+  // ---- dW[c][tap] += s_x * (sum dc*q - zp * sum dc): the waves' partials through LDS, one atomic per (channel, tap) and workgroup
+  __syncthreads();
+  float* red = (float*)smem;                       // [NW][K*K][64]
+  const float zpf = (float)zpx;
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) red[(w * K * K + t) * 64 + lane] = (w < G::NRG) ? wacc[t] - zpf * sdc : 0.0f;
+  __syncthreads();
+  const float sx = p.qx[FROST_Q_SCALE];
+  for (int i = tid; i < K * K * 64; i += NT) {
+    const int t = i >> 6, l2 = i & 63; const int c2 = chunk * 64 + l2;
+    float sum = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * K * K + t) * 64 + l2];
+    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
+  }
+}
+
+template <int K, int HW, int NW>
+static int launch_blk_c(BlkCP& p, hipStream_t s) {
+  using G = BlkGeoC<K, HW, NW>;
+  const size_t lds = (size_t)G::lds();
+  FROST_REQUIRE(lds <= 160 * 1024, "block_dw_bwd: LDS budget exceeded");
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_bwd<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_blk_dw_bwd<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
+  return frost_check_launch("block_dw_bwd");
+}
+
+extern "C" int frost_block_dw_bwd_supported(int h, int w, int k, int stride, int c) {
+  return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (c % 8) == 0) ? 1 : 0;
+}
+
+extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                                  int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                                  float* dwq, void* stream) {
+  FROST_REQUIRE(frost_block_dw_bwd_supported(h, w, k, 1, c), "block_dw_bwd: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1)");
+  FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout && dwq, "block_dw_bwd: incomplete arguments");
+  BlkCP p = {};
+  p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.qw = qrec_w; p.wscale = wscale; p.coef = coef; p.qy = qrec_y; p.gout = gout; p.dx = dx; p.dwq = dwq;
+  p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu; p.sr = frost_sr_enabled();
+  p.inv_count = 1.0f / (float)((int64_t)n * h * w);
+  static const int imgs_env = getenv("FROST_BLK_IMGS_C") ? atoi(getenv("FROST_BLK_IMGS_C")) : 0;
+  static const int wgs_env = getenv("FROST_BLK_WGS_C") ? atoi(getenv("FROST_BLK_WGS_C")) : 0;
+  // images per workgroup: the k*k weight-gradient sums stay in registers across them and every workgroup ends with 64 * k*k float atomics, so the launch
+  // is sized to ONE round of resident workgroups (2 per CU at ~200 VGPRs), not to many small ones
+  const int want = wgs_env > 0 ? wgs_env : (h == 7 ? 768 : 512);          // measured over FrostNet-Large's eleven eligible layers at B = 512
+  int imgs = imgs_env > 0 ? imgs_env : (int)(((int64_t)n * p.nchunk + want - 1) / want);
+  if (imgs < 1) imgs = 1;
+  if (imgs > n) imgs = n;
+  p.imgs = imgs;
+  hipStream_t s = as_stream(stream);
+  if (h == 7) return (k == 3) ? launch_blk_c<3, 7, 4>(p, s) : launch_blk_c<5, 7, 4>(p, s);
+  return (k == 3) ? launch_blk_c<3, 14, 8>(p, s) : launch_blk_c<5, 14, 8>(p, s);
+}
+
 extern "C" int frost_block_supported(int h, int w, int k, int stride, int cin, int c) {
   return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (cin % 8) == 0 && cin > (h == 7 ? 64 : 0) && cin <= (h == 7 ? 320 : 192) && (c % 8) == 0) ? 1 : 0;
 }

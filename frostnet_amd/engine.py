@@ -33,6 +33,7 @@ _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary 
 # the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
 _BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit + conv2 statistics in one launch at the 14x14 / 7x7 stages (csrc/frost_block.hip)
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
+_BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -688,6 +689,15 @@ class Engine:
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                  prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
+            gslot = self._grad_slot(x) if x.needs_grad else (None, 0)
+            if _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and not gslot[1] and L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c):
+                # 14x14 / 7x7 maps: the image's dc lives in an LDS plane; weight gradient and data gradient come from it (csrc/frost_block.hip)
+                call("frost_block_dw_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
+                     l.k, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]) if x.needs_grad else None, ptr(l.dwq), s,
+                     prof=("blk_dw_bwd", x.numel + 2 * y.numel + (2 * x.numel if x.needs_grad else 0)))
+                self._after_conv_backward(l, s)
+                y.grad = None
+                return
             # dc pass + weight gradient in one sweep where the kernel's register state allows it (the library applies the same
             # rule and would otherwise run the two kernels itself; calling them separately keeps the profiler tags per kernel)
             if _DW_FUSE and l.stride == 1 and (l.k == 3 or (l.k == 5 and y.w <= 8 and _DW_FUSE_K5)):
@@ -707,7 +717,7 @@ class Engine:
                 call("frost_dw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(l.dwq), sw,
                      prof=("dw_wgrad", 2 * y.numel + x.numel))
             if x.needs_grad:
-                gx, acc = self._grad_slot(x)
+                gx, acc = gslot
                 call("frost_dw_dgrad", ptr(dc), ptr(l.wq_pack), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride, ptr(gx), acc,
                      ptr(l.wscale) if l.per_channel else None, s,
                      prof=("dw_dgrad", 2 * y.numel + 2 * x.numel))

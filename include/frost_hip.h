@@ -386,6 +386,16 @@ int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, const int8_t* 
                           int relu2, int8_t* y2, int n, int h, int w, int c, int k, const int8_t* w3_pack, const int32_t* wsum3, int cout,
                           int32_t* conv_out, void* stats3, const FrostFinDesc* fin3, void* stream);
 
+/* frost_block_dw_bwd replaces, for conv2 of such a block: frost_dw_conv_bwd pass 1 (dc) + frost_dw_wgrad + frost_dw_dgrad -- the backward of
+ * nniqat.ConvBnReLU2d (depthwise) after its reduce pass (frost_dw_conv_bwd pass 0 filled the S1 / S2 coefficient rows): dc is assembled in an LDS plane
+ * per image and 64-channel chunk, the raw weight-gradient sums (dwq[c][k*k], as frost_dw_wgrad) and the data gradient (dx, bf16, overwritten; may be
+ * NULL) come straight from it; dc is not written to HBM.  wscale: per-channel weight scales or NULL (qrec_w's scalar).  Same expressions and, for the
+ * data gradient, the same summation order as the separate kernels; dc's stochastic rounding draws differ (generator seeded per workgroup / thread). */
+int frost_block_dw_bwd_supported(int h, int w, int k, int stride, int c);
+int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                       int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                       float* dwq, void* stream);
+
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
  * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */

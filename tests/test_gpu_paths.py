@@ -14,10 +14,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CSPLIT="0", FROST_DW_GEO="0", FROST_DW_FUSE="0", FROST_PW_FUSE="0", FROST_DW_XCD="0", FROST_WG_XCD="0",
-             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0")
+             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0")
+FAST = dict()
 CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 32, 16, 1, 1, 112, 64), ("pw", 72, 24, 1, 1, 56, 128), ("pw", 144, 40, 1, 1, 28, 512), ("dw", 72, 72, 3, 1, 56, 64), ("pw", 56, 168, 1, 1, 28, 128), ("pw", 40, 16, 1, 1, 28, 64), ("pw", 56, 336, 1, 1, 28, 512), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
          ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
          ("dw", 144, 144, 5, 2, 56, 64),
+         # 14x14 / 7x7 depthwise layers: the fused backward (dc + weight gradient + data gradient from an LDS plane, csrc/frost_block.hip) vs the three separate kernels;
+         # partial last 64-channel chunks (360, 1440), batches that do not divide by the images-per-workgroup split
+         ("dw", 624, 624, 5, 1, 14, 19), ("dw", 360, 360, 3, 1, 14, 33), ("dw", 1152, 1152, 3, 1, 7, 45), ("dw", 312, 312, 5, 1, 14, 64),
          # wide-K reduce layers on the kept-conv-output path (rows of 8 mod 16 bytes, a ragged pixel count, three channel chunks) vs all four passes through k_pw
          ("pw", 312, 80, 1, 1, 14, 67), ("pw", 360, 96, 1, 1, 14, 33), ("pw", 1440, 192, 1, 1, 7, 70), ("pw", 624, 96, 1, 1, 14, 128)]
 
@@ -41,7 +45,7 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "_".join(str(v) for v in c))
 def test_fast_paths_match_plain_paths(case, tmp_path):
-    fast = run(str(tmp_path), "fast", case, {})
+    fast = run(str(tmp_path), "fast", case, FAST)
     plain = run(str(tmp_path), "plain", case, PLAIN)
     d = np.abs(fast["y"].astype(np.int16) - plain["y"].astype(np.int16))
     assert d.max() <= 1 and float((d > 0).mean()) <= 1e-4, ("y", int(d.max()), float((d > 0).mean()))
@@ -76,3 +80,20 @@ def test_dw_matrix_core_path_matches_stencil_path(case, cb, tmp_path):
     assert mfma["qy"][3].tobytes() == sten["qy"][3].tobytes()
     np.testing.assert_allclose(mfma["rm"], sten["rm"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(mfma["rv"], sten["rv"], rtol=1e-6, atol=1e-7)
+
+
+# Fused depthwise backward with round-to-nearest dc (FROST_SR=0: no random draws): dc is then a deterministic function of the inputs, the data gradient is
+# summed in k_dw3_dgrad's order, so dx must be BIT-IDENTICAL to the three-kernel path; the weight gradient differs by the order of its fp32 atomics only.
+@pytest.mark.parametrize("case", [("dw", 1440, 1440, 5, 1, 7, 21), ("dw", 624, 624, 5, 1, 14, 10), ("dw", 360, 360, 3, 1, 14, 7), ("dw", 1152, 1152, 3, 1, 7, 16)],
+                         ids=lambda c: "_".join(str(v) for v in c))
+def test_fused_depthwise_backward_exact_without_stochastic_rounding(case, tmp_path):
+    fused = run(str(tmp_path), "fused", case, {"FROST_SR": "0", "FROST_BLOCK_DWBWD": "2"})
+    sep = run(str(tmp_path), "sep", case, {"FROST_SR": "0", "FROST_BLOCK_DWBWD": "0"})
+    assert fused["y"].tobytes() == sep["y"].tobytes()
+    # S1 / S2 of the reduce pass are float atomics (order differs from run to run at the 1e-7 level), so a dc exactly on a bf16 rounding boundary may fall
+    # either way and moves the up to k*k data-gradient elements it feeds: everything else is identical
+    a, b = bf16_to_f32(fused["dx"]).astype(np.float64), bf16_to_f32(sep["dx"]).astype(np.float64)
+    differ = a != b
+    assert float(differ.mean()) <= 2e-3, float(differ.mean())
+    assert relerr(a, b) <= 2e-4
+    assert relerr(fused["dw"], sep["dw"]) <= 2e-5 and relerr(fused["dgamma"], sep["dgamma"]) <= 2e-5 and relerr(fused["dbeta"], sep["dbeta"]) <= 2e-5
