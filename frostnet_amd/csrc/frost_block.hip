@@ -791,6 +791,144 @@ extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const in
   return (k == 3) ? launch_blk_c<3, 14, 8>(p, s) : launch_blk_c<5, 14, 8>(p, s);
 }
 
+// ================================================================================================ kernel R: depthwise backward, reduce pass
+// S1 = sum gy, S2 = sum gy * xhat per channel (k_dw3's reduce pass) in the image-resident scheme of k_blk_dw_bwd: lane = channel, the two sums stay in registers
+// across the workgroup's images, ONE pair of float atomics per channel and workgroup.
+template <int K, int HW, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
+  using G = BlkGeoC<K, HW, NW>;
+  constexpr int MAP = G::MAP, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  constexpr int XU = (MAP * 8 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
+  uint8_t* const gt = smem + G::PLANE;                          // [MAP][64] bf16
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+  const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
+    for (int i = tid; i < (G::GT >> 4); i += NT) ((uint4*)gt)[i] = make_uint4(0, 0, 0, 0);
+  }
+  int wpk[K][2];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) { const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+    wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+  }
+  const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;
+  float cA = 0, cB = 0, cR = 0, cMR = 0;
+  if (chok) {
+    cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
+    cR = p.coef[FROST_COEF_R * p.cpad + ch]; cMR = -p.coef[FROST_COEF_M * p.cpad + ch] * cR;
+  }
+  const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
+  float t_lo = 0.0f, t_hi;
+  {
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
+    const float hi0 = (float)qhi + 0.5f - (float)zpy;
+    t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+  float r1 = 0.0f, r2 = 0.0f;
+  int upx[XU], uoff[XU];
+#pragma unroll
+  for (int i = 0; i < XU; ++i) {
+    const int u = tid + i * NT, px = u >> 3;
+    const int r = px / HW, cc = px - r * HW;
+    upx[i] = (u < MAP * 8) ? px : -1;
+    uoff[i] = ((r + PAD) * PITCH + cc + PAD) * 64;
+  }
+  const int part = tid & 7;
+  const bool pok = (chunk * 64 + part * 8) < p.c;
+  uint2 xv[XU]; uint4 gv[XU];
+  auto prefetch = [&](int img) __attribute__((always_inline)) {
+    const int8_t* xs = p.x + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
+    const uint16_t* gs = p.gout + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const bool ok = upx[i] >= 0 && pok;
+      xv[i] = ok ? *(const uint2*)(xs + (int64_t)upx[i] * p.c) : make_uint2(0, 0);
+      gv[i] = ok ? *(const uint4*)(gs + (int64_t)upx[i] * p.c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if (img_lo < img_hi) prefetch(img_lo);
+  __syncthreads();
+  for (int img = img_lo; img < img_hi; ++img) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      if (upx[i] >= 0) { if (pok) *(uint2*)(xpl + uoff[i] + part * 8) = xv[i]; *(uint4*)(gt + (upx[i] * 64 + part * 8) * 2) = gv[i]; }
+    }
+    if (img + 1 < img_hi) prefetch(img + 1);
+    blk_barrier();
+    if (w < G::NRG) {
+#pragma unroll 1
+      for (int seg = 0; seg < G::NSEG; ++seg) {
+        int a[2][8];
+        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          float gq[8];
+          const uint8_t* grow = gt + ((2 * w + o) * HW) * 64 * 2;
+          blk_tr16(grow, seg * 8, lane, gq); blk_tr16(grow, seg * 8 + 4, lane, gq + 4);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const bool valid = (2 * w + o) < HW && (seg * 8 + r) < HW && chok;
+            const float v = (float)a[o][r];
+            const float tq = fmaf(cA, v, cB) * y_inv;
+            const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+            r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2);
+          }
+        }
+      }
+    }
+    blk_barrier();
+  }
+  __syncthreads();
+  float* red = (float*)smem;                       // [NW][2][64]
+  red[(w * 2) * 64 + lane] = r1; red[(w * 2 + 1) * 64 + lane] = r2;
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6, l2 = tid & 63, c2 = chunk * 64 + l2;
+    float sum = 0.0f;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * 2 + which) * 64 + l2];
+    if (c2 < p.c) atomicAdd((float*)p.coef + (which ? FROST_COEF_S2 : FROST_COEF_S1) * p.cpad + c2, sum);
+  }
+}
+
+template <int K, int HW, int NW>
+static int launch_blk_r(BlkCP& p, hipStream_t s) {
+  using G = BlkGeoC<K, HW, NW>;
+  const size_t lds = (size_t)(G::PLANE + G::GT + 64);
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_bred<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_blk_dw_bred<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
+  return frost_check_launch("block_dw_bwd_reduce");
+}
+
+extern "C" int frost_block_dw_bwd_reduce(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
+                                         float* coef, const float* qrec_y, int relu, const uint16_t* gout, void* stream) {
+  FROST_REQUIRE((h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && (c % 8) == 0), "block_dw_bwd_reduce: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1)");
+  FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout, "block_dw_bwd_reduce: incomplete arguments");
+  BlkCP p = {};
+  p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.coef = coef; p.qy = qrec_y; p.gout = gout;
+  p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu;
+  static const int wgs_env = getenv("FROST_BLK_WGS_R") ? atoi(getenv("FROST_BLK_WGS_R")) : 0;
+  const int want = wgs_env > 0 ? wgs_env : 1024;
+  int imgs = (int)(((int64_t)n * p.nchunk + want - 1) / want);
+  if (imgs < 1) imgs = 1;
+  if (imgs > n) imgs = n;
+  p.imgs = imgs;
+  hipStream_t s = as_stream(stream);
+  if (h == 7) return (k == 3) ? launch_blk_r<3, 7, 4>(p, s) : launch_blk_r<5, 7, 4>(p, s);
+  return (k == 3) ? launch_blk_r<3, 14, 8>(p, s) : launch_blk_r<5, 14, 8>(p, s);
+}
+
 extern "C" int frost_block_supported(int h, int w, int k, int stride, int cin, int c) {
   return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (cin % 8) == 0 && cin > (h == 7 ? 64 : 0) && cin <= (h == 7 ? 320 : 192) && (c % 8) == 0) ? 1 : 0;
 }

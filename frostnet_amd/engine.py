@@ -34,6 +34,7 @@ _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary 
 _BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit + conv2 statistics in one launch at the 14x14 / 7x7 stages (csrc/frost_block.hip)
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
+_BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -687,10 +688,15 @@ class Engine:
                 call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), sw)
         elif l.kind == "dw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
-            call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
-                 prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
+            blk = _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)
+            if blk and _BLOCK_DWBRED:
+                call("frost_block_dw_bwd_reduce", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, x.c, l.k, ptr(l.coef), ptr(l.qy), int(l.relu),
+                     ptr(gout), s, prof=("blk_dw_bred", x.numel + 2 * y.numel))
+            else:
+                call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
+                     prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
             gslot = self._grad_slot(x) if x.needs_grad else (None, 0)
-            if _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and not gslot[1] and L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c):
+            if blk and not gslot[1]:
                 # 14x14 / 7x7 maps: the image's dc lives in an LDS plane; weight gradient and data gradient come from it (csrc/frost_block.hip)
                 call("frost_block_dw_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
                      l.k, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]) if x.needs_grad else None, ptr(l.dwq), s,

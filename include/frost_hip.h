@@ -392,6 +392,10 @@ int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, const int8_t* 
  * NULL) come straight from it; dc is not written to HBM.  wscale: per-channel weight scales or NULL (qrec_w's scalar).  Same expressions and, for the
  * data gradient, the same summation order as the separate kernels; dc's stochastic rounding draws differ (generator seeded per workgroup / thread). */
 int frost_block_dw_bwd_supported(int h, int w, int k, int stride, int c);
+/* the reduce pass of the same layers (replaces frost_dw_conv_bwd pass 0): S1 = sum gy, S2 = sum gy * xhat accumulated into the coefficient rows, image-resident
+ * like frost_block_dw_bwd (lane = channel, the sums in registers across a workgroup's images, one pair of float atomics per channel and workgroup) */
+int frost_block_dw_bwd_reduce(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
+                              float* coef, const float* qrec_y, int relu, const uint16_t* gout, void* stream);
 int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
                        int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
                        float* dwq, void* stream);

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CSPLIT="0", FROST_DW_GEO="0", FROST_DW_FUSE="0", FROST_PW_FUSE="0", FROST_DW_XCD="0", FROST_WG_XCD="0",
-             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0")
+             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0", FROST_BLOCK_DWBRED="0")
 FAST = dict()
 CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 32, 16, 1, 1, 112, 64), ("pw", 72, 24, 1, 1, 56, 128), ("pw", 144, 40, 1, 1, 28, 512), ("dw", 72, 72, 3, 1, 56, 64), ("pw", 56, 168, 1, 1, 28, 128), ("pw", 40, 16, 1, 1, 28, 64), ("pw", 56, 336, 1, 1, 28, 512), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
          ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
@@ -88,7 +88,7 @@ def test_dw_matrix_core_path_matches_stencil_path(case, cb, tmp_path):
                          ids=lambda c: "_".join(str(v) for v in c))
 def test_fused_depthwise_backward_exact_without_stochastic_rounding(case, tmp_path):
     fused = run(str(tmp_path), "fused", case, {"FROST_SR": "0", "FROST_BLOCK_DWBWD": "2"})
-    sep = run(str(tmp_path), "sep", case, {"FROST_SR": "0", "FROST_BLOCK_DWBWD": "0"})
+    sep = run(str(tmp_path), "sep", case, {"FROST_SR": "0", "FROST_BLOCK_DWBWD": "0", "FROST_BLOCK_DWBRED": "0"})
     assert fused["y"].tobytes() == sep["y"].tobytes()
     # S1 / S2 of the reduce pass are float atomics (order differs from run to run at the 1e-7 level), so a dc exactly on a bf16 rounding boundary may fall
     # either way and moves the up to k*k data-gradient elements it feeds: everything else is identical
