@@ -94,6 +94,8 @@ _PROTOS = {
     "frost_pw_ew": [P, L, I, P, P, I, I, P, P, P],
     "frost_pw_ew_emit_add": [P, L, I, P, P, I, P, P, P, P, P, I, P],
     "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
+    "frost_pwc_bwd_ok": [L, I, I],
+    "frost_pwc_conv_bwd": [P, P, P, P, L, I, I, I, P, P, I, P, P, P],
     "frost_block_supported": [I, I, I, I, I, I],
     "frost_block_expand_dw_stats": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
     "frost_block_dw_reduce_supported": [I, I, I, I, I, I],

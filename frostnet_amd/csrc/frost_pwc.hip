@@ -1,0 +1,218 @@
+// Reduce and dc passes of the backward of WIDE pointwise ConvBN(ReLU) layers (the expand convs of the 14 x 14 / 7 x 7 bottlenecks, last_layer): the same
+// arithmetic as k_pw's BRED / BDC passes (frost_pw.hip; replaces the torch stages frost_pw_conv_bwd pass 0 / 1 cite) in the chunked layout of the block
+// kernels (frost_block.hip).
+//
+// Why a second kernel: k_pw keeps a 128-pixel tile and walks ALL output channels of it; with Cout = 624 .. 1728 the gout / dc rows of a tile (2 * Cout bytes per
+// pixel) do not fit LDS, so its epilogue reads gout and writes dc from registers in 8-byte pieces at a 2 * Cout-byte stride (16 + 30 us of the 90 us dc pass of
+// 240 -> 1440 @ 7 x 7, profiles/r02_pw_ablation.txt).  Here a workgroup owns a 64-pixel tile and walks 64-channel CHUNKS: the chunk's gout window is 64 x 128
+// contiguous bytes per pixel row -> staged through LDS with full-line loads (register prefetch one chunk ahead), dc is written in place over it and leaves
+// with full-line stores; the x tile is staged once per workgroup, the chunk's weight fragments come from L2 one chunk ahead, the per-channel coefficient
+// rows of the workgroup's chunk range sit in LDS (E / F folded once).
+#include "frost_common.h"
+
+struct PwcP {
+  const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum;
+  float* coef; const float* qy; const uint16_t* gout; uint16_t* dc;
+  int64_t npix; int cin, c, cpad, kstr, nchunk, csplit, relu, sr; float inv_count;
+};
+
+__device__ __forceinline__ void pwc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int CTRL>
+__device__ __forceinline__ float pwc_dpp_add(float v) { return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+// sum over the 16 lanes of a row (lanes j = 0..15 of one g): the total lands in lane 15 (row_shr 1, 2, 4, 8 -- k_pw's row_sum_f)
+__device__ __forceinline__ float pwc_row_sum(float v) { v = pwc_dpp_add<0x111>(v); v = pwc_dpp_add<0x112>(v); v = pwc_dpp_add<0x114>(v); v = pwc_dpp_add<0x118>(v); return v; }
+
+#define PWC_PX 64
+// MODE 0: reduce pass (S1 += gy, S2 += gy * xhat into the coefficient rows); MODE 1: dc pass.  KSM: K steps of 64 input channels (exact).
+template <int MODE, int KSM>
+__global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                                   // [64][kstr]
+  uint8_t* const gwin = smem + PWC_PX * p.kstr;               // [2][64 px][64 ch] bf16: gout window, dc in place
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int cs = (int)blockIdx.x % p.csplit; const int64_t tile = (int64_t)blockIdx.x / p.csplit;
+  const int chunk_lo = (cs * p.nchunk) / p.csplit, chunk_hi = ((cs + 1) * p.nchunk) / p.csplit;
+  const int cw = (chunk_hi - chunk_lo) * 64;
+  // per-channel rows of the chunk range: A, B, R, MR (= -M R) [, K1, E, F] [, the two sums]
+  float* const tA = (float*)(gwin + 2 * PWC_PX * 64 * 2); float* const tB = tA + cw; float* const tR = tB + cw; float* const tMR = tR + cw;
+  float* const tK1 = tMR + cw; float* const tE = tK1 + cw; float* const tF = tE + cw;
+  int* const tW = (int*)(tF + cw);
+  float* const l_f1 = (float*)(tW + cw); float* const l_f2 = l_f1 + cw;
+  const int64_t p0 = tile * PWC_PX;
+  const int CT = p.cpad >> 4;
+
+  for (int i = tid; i < cw; i += 256) {
+    const int c2 = chunk_lo * 64 + i; const bool ok = c2 < p.c;
+    const float A = ok ? p.coef[FROST_COEF_A * p.cpad + c2] : 0.0f, B = ok ? p.coef[FROST_COEF_B * p.cpad + c2] : 0.0f;
+    const float M = ok ? p.coef[FROST_COEF_M * p.cpad + c2] : 0.0f, R = ok ? p.coef[FROST_COEF_R * p.cpad + c2] : 0.0f;
+    tA[i] = A; tB[i] = B; tR[i] = R; tMR[i] = -M * R; tW[i] = ok ? p.wsum[c2] : 0;
+    if (MODE == 1) {
+      const float K1 = ok ? p.coef[FROST_COEF_K1 * p.cpad + c2] : 0.0f;
+      const float s1 = ok ? p.coef[FROST_COEF_S1 * p.cpad + c2] : 0.0f, s2 = ok ? p.coef[FROST_COEF_S2 * p.cpad + c2] : 0.0f;
+      const float E = -K1 * (s2 * p.inv_count) * R;
+      tK1[i] = K1; tE[i] = E; tF[i] = -K1 * (s1 * p.inv_count) - E * M;
+    } else { l_f1[i] = 0.0f; l_f2[i] = 0.0f; }
+  }
+  {   // the tile's input rows: contiguous in HBM; rows past the tensor stay zero
+    const int upr = p.cin >> 3; const int64_t rows = p.npix - p0 < PWC_PX ? p.npix - p0 : PWC_PX; const int total = (int)rows * upr;
+    constexpr int XB = (PWC_PX * KSM * 8 + 255) / 256;
+    const int8_t* src = p.x + p0 * p.cin;
+    uint2 xv[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) { const int u = tid + i * 256; xv[i] = (u < total) ? *(const uint2*)(src + (int64_t)u * 8) : make_uint2(0, 0); }
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int u = tid + i * 256; const int row = u / upr, col = u - row * upr;
+      if (u < PWC_PX * upr) *(uint2*)(xs + row * p.kstr + col * 8) = xv[i];
+    }
+  }
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
+  float t_lo = 0.0f, t_hi;
+  {
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
+    const float hi0 = (float)qhi + 0.5f - (float)zpy;
+    t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  // gout window units: pixel u >> 3, 16-byte part u & 7 (two per thread)
+  const int part = tid & 7, upx0 = tid >> 3, upx1 = (tid + 256) >> 3;
+  const bool pv0 = (p0 + upx0) < p.npix, pv1 = (p0 + upx1) < p.npix;
+  auto load_g = [&](int chunk, uint4 (&dst)[2]) __attribute__((always_inline)) {
+    const bool cok = (chunk * 64 + part * 8) < p.c;
+    const uint16_t* gs = p.gout + p0 * p.c + chunk * 64 + part * 8;
+    dst[0] = (pv0 && cok) ? *(const uint4*)(gs + (int64_t)upx0 * p.c) : make_uint4(0, 0, 0, 0);
+    dst[1] = (pv1 && cok) ? *(const uint4*)(gs + (int64_t)upx1 * p.c) : make_uint4(0, 0, 0, 0);
+  };
+  auto load_w = [&](int chunk, v4i (&dst)[KSM]) __attribute__((always_inline)) {
+    const int ct = min(chunk * 4 + w, CT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) dst[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+  };
+  uint4 gv[2]; v4i afr[KSM];
+  if (chunk_lo < chunk_hi) { load_g(chunk_lo, gv); load_w(chunk_lo, afr); }
+  __syncthreads();
+
+  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+    uint8_t* const gw = gwin + ((chunk - chunk_lo) & 1) * (PWC_PX * 64 * 2);
+    *(uint4*)(gw + (upx0 * 64 + part * 8) * 2) = gv[0];
+    *(uint4*)(gw + (upx1 * 64 + part * 8) * 2) = gv[1];
+    // conv recomputation: wave = channel tile w of the chunk, 4 pixel tiles
+    const int ti = (chunk - chunk_lo) * 64 + w * 16 + 4 * g;
+    v4i acc[4];
+    {
+      const int4 ws = *(const int4*)(tW + ti); const v4i init = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = init;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const v4i bfr = *(const v4i*)(xs + (t * 16 + j) * p.kstr + ks * 64 + g * 16);
+        acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, acc[t], 0, 0, 0);          // D[chan][pix]
+      }
+    if (chunk + 1 < chunk_hi) { load_g(chunk + 1, gv); load_w(chunk + 1, afr); }
+    pwc_barrier();                                             // the gout window is complete
+    const float4 A4 = *(const float4*)(tA + ti), B4 = *(const float4*)(tB + ti);
+    const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
+    if (MODE == 0) {
+      const float4 R4 = *(const float4*)(tR + ti), M4 = *(const float4*)(tMR + ti);
+      const float R[4] = {R4.x, R4.y, R4.z, R4.w}, MR[4] = {M4.x, M4.y, M4.z, M4.w};
+      float r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint2 gq2 = *(const uint2*)(gw + ((t * 16 + j) * 64 + w * 16 + 4 * g) * 2);
+        const float gq[4] = {__uint_as_float(gq2.x << 16), __uint_as_float(gq2.x & 0xffff0000u), __uint_as_float(gq2.y << 16), __uint_as_float(gq2.y & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float af = (float)acc[t][r];
+          const float tq = fmaf(A[r], af, B[r]) * y_inv;
+          const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;        // rows past the tensor carry gout = 0
+          r1[r] += gy; r2[r] = fmaf(gy, fmaf(af, R[r], MR[r]), r2[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = pwc_row_sum(r1[r]), b = pwc_row_sum(r2[r]);
+        if (j == 15) { atomicAdd(&l_f1[ti + r], a); atomicAdd(&l_f2[ti + r], b); }
+      }
+    } else {
+      const float4 K4 = *(const float4*)(tK1 + ti), E4 = *(const float4*)(tE + ti), F4 = *(const float4*)(tF + ti);
+      const float K1[4] = {K4.x, K4.y, K4.z, K4.w}, E[4] = {E4.x, E4.y, E4.z, E4.w}, F[4] = {F4.x, F4.y, F4.z, F4.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint8_t* const gp = gw + ((t * 16 + j) * 64 + w * 16 + 4 * g) * 2;
+        const uint2 gq2 = *(const uint2*)gp;
+        const float gq[4] = {__uint_as_float(gq2.x << 16), __uint_as_float(gq2.x & 0xffff0000u), __uint_as_float(gq2.y << 16), __uint_as_float(gq2.y & 0xffff0000u)};
+        float dcv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float af = (float)acc[t][r];
+          const float tq = fmaf(A[r], af, B[r]) * y_inv;
+          const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+          dcv[r] = fmaf(gy, K1[r], fmaf(af, E[r], F[r]));
+        }
+        uint2 o;
+        if (p.sr) { o.x = sr_pk_bf16(dcv[0], dcv[1], rng); o.y = sr_pk_bf16(dcv[2], dcv[3], rng); }
+        else { o.x = cvt_pk_bf16(dcv[0], dcv[1]); o.y = cvt_pk_bf16(dcv[2], dcv[3]); }
+        *(uint2*)gp = o;                                        // dc in place over the gout window
+      }
+      pwc_barrier();
+      // the dc window out: full 128-byte lines per pixel
+      const bool cok = (chunk * 64 + part * 8) < p.c;
+      uint16_t* dd = p.dc + p0 * p.c + chunk * 64 + part * 8;
+      if (pv0 && cok) *(uint4*)(dd + (int64_t)upx0 * p.c) = *(const uint4*)(gw + (upx0 * 64 + part * 8) * 2);
+      if (pv1 && cok) *(uint4*)(dd + (int64_t)upx1 * p.c) = *(const uint4*)(gw + (upx1 * 64 + part * 8) * 2);
+    }
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    for (int i = tid; i < cw; i += 256) {
+      const int c2 = chunk_lo * 64 + i;
+      if (c2 < p.c) { atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c2, l_f1[i]); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c2, l_f2[i]); }
+    }
+  }
+}
+
+template <int MODE, int KSM>
+static int launch_pwc(PwcP& p, hipStream_t s) {
+  const int cwmax = ((p.nchunk + p.csplit - 1) / p.csplit) * 64;
+  const size_t lds = (size_t)PWC_PX * p.kstr + 2 * PWC_PX * 64 * 2 + (size_t)cwmax * 4 * 10 + 64;
+  FROST_REQUIRE(lds <= 64 * 1024, "pwc: LDS budget exceeded");
+  const int64_t tiles = (p.npix + PWC_PX - 1) / PWC_PX;
+  hipLaunchKernelGGL((k_pwc<MODE, KSM>), dim3((unsigned)(tiles * p.csplit)), dim3(256), lds, s, p);
+  return frost_check_launch("pwc");
+}
+
+// 1 if the chunked kernel takes this layer: wide output (the rows k_pw cannot stage), input rows of at most 320 bytes
+extern "C" int frost_pwc_bwd_ok(int64_t npix, int cin, int cout) {
+  static const int minc = getenv("FROST_PWC") ? atoi(getenv("FROST_PWC")) : 256;        // smallest Cout it takes; 0 = off
+  return (minc > 0 && cout >= minc && (cin % 8) == 0 && cin <= 320 && (cout % 8) == 0 && npix >= 1024) ? 1 : 0;
+}
+
+// pass 0: reduce, pass 1: dc -- the contract of frost_pw_conv_bwd passes 0 / 1
+extern "C" int frost_pwc_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout, int pass,
+                                  float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream) {
+  FROST_REQUIRE(frost_pwc_bwd_ok(npix, cin, cout) && (pass == 0 || (pass == 1 && dc)), "pwc_conv_bwd: unsupported layer or pass");
+  PwcP p = {};
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = coef; p.qy = qrec_y; p.gout = gout; p.dc = dc; p.npix = npix; p.cin = cin; p.c = cout;
+  p.cpad = round_up(cout, 16); const int KS = (cin + 63) / 64; p.kstr = KS * 64 + 16; p.nchunk = (cout + 63) / 64; p.relu = relu; p.sr = frost_sr_enabled();
+  p.inv_count = 1.0f / (float)npix;
+  static const int cpw_env = getenv("FROST_PWC_CPW") ? atoi(getenv("FROST_PWC_CPW")) : 0;
+  // chunks per workgroup: the x tile is staged once per workgroup, so more chunks amortise it; fewer keep >= ~2000 workgroups in the launch
+  const int64_t tiles = (npix + PWC_PX - 1) / PWC_PX;
+  int cpw = cpw_env > 0 ? cpw_env : (int)((tiles * p.nchunk + 2047) / 2048);
+  if (cpw < 2) cpw = 2;
+  if (cpw > p.nchunk) cpw = p.nchunk;
+  if (cpw > 12) cpw = 12;
+  p.csplit = (p.nchunk + cpw - 1) / cpw;
+  hipStream_t s = as_stream(stream);
+#define PWC_GO(KK) if (KS == KK) return pass == 0 ? launch_pwc<0, KK>(p, s) : launch_pwc<1, KK>(p, s);
+  PWC_GO(1) PWC_GO(2) PWC_GO(3) PWC_GO(4) PWC_GO(5)
+#undef PWC_GO
+  FROST_REQUIRE(false, "pwc_conv_bwd: no instance");
+  return 1;
+}

@@ -645,8 +645,13 @@ class Engine:
                      prof=("pw_bwd_reduce", 6 * y.numel))
             else:
                 # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
-                call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
-                     prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+                pwc = (not fused) and l.kind == "pw" and bool(L.load_library().frost_pwc_bwd_ok(x.npix, x.c, l.cout))      # wide layers: chunked kernel, full-line gout / dc I/O
+                if pwc:
+                    call("frost_pwc_conv_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
+                         prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+                else:
+                    call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
+                         prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
             if fused:
                 # dc pass + data gradient + weight gradient in one kernel: the dc tile never leaves LDS (layers with Cout*Cin <= ~19 k)
                 gx, acc = self._grad_slot(x) if x.needs_grad else (None, 0)
@@ -661,6 +666,9 @@ class Engine:
             if cint is not None:
                 call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 1, ptr(gout), ptr(dc), s,
                      prof=("pw_bwd_dc", 8 * y.numel))
+            elif pwc:
+                call("frost_pwc_conv_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), s,
+                     prof=("pw_bwd_dc", x.numel + 4 * y.numel))
             else:
                 call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                      prof=("pw_bwd_dc", x.numel + 4 * y.numel))

@@ -362,6 +362,14 @@ int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* w
 int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const int8_t* a,
                          const float* qrec_a, int8_t* y, float* state3, float* qrec_sum, int observe, void* stream);
 
+/* ---- reduce / dc passes of WIDE pointwise layers in the chunked layout (csrc/frost_pwc.hip) -----------------------------------------------------
+ * replaces: what frost_pw_conv_bwd passes 0 / 1 replace (the backward of nniqat.ConvBn(ReLU)2d up to dc), for layers whose gout / dc rows are too long for k_pw's
+ * LDS-staged tile I/O (Cout >= 256, input rows <= 320 bytes): a workgroup owns a 64-pixel tile and walks 64-channel chunks, so the gout window is read and the dc
+ * window written with full 128-byte lines.  Same expressions as k_pw; pass 0 accumulates S1 / S2 into the coefficient rows, pass 1 writes dc (bf16). */
+int frost_pwc_bwd_ok(int64_t npix, int cin, int cout);
+int frost_pwc_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout, int pass,
+                       float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream);
+
 /* ---- whole-bottleneck forward fusion at the 14x14 / 7x7 stages (CascadePreExBottleneck.forward, frostnet.py:124-145) ------------
  * frost_block_supported: 1 when the fused kernels have an instance for a (conv1 -> conv2) pair: square 7x7 / 14x14 maps, depthwise k in {3,5} at
  * stride 1, conv1 input rows of <= 320 (7x7) / 192 (14x14) bytes.
