@@ -35,6 +35,7 @@ _BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit +
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
+_PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # largest pixel count whose reduce pass runs on the chunked kernel (the dc pass always does)
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -646,7 +647,7 @@ class Engine:
             else:
                 # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
                 pwc = (not fused) and l.kind == "pw" and bool(L.load_library().frost_pwc_bwd_ok(x.npix, x.c, l.cout))      # wide layers: chunked kernel, full-line gout / dc I/O
-                if pwc:
+                if pwc and x.npix <= _PWC_RED_MAXPIX:       # (per 64-pixel tile a pair of float atomics per channel: above ~100 k pixels k_pw's fatter tiles win -- measured 98 vs 186 us at 28 x 28)
                     call("frost_pwc_conv_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                          prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
                 else:
