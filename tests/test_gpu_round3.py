@@ -414,7 +414,7 @@ def test_flag_summary_is_host_side_and_follows_apply():
     import torch
     from frostnet_amd import frostnet as F
     torch.manual_seed(0)
-    m = F.MODEL_REGISTRY["frostnet_quant_small_0_5"](nclass=10)
+    m = F.MODEL_REGISTRY["frostnet_quant_small_0_5"]()
     F.qat_prepare(m, version=0)
     m.cuda().train()
     x = torch.randn(4, 3, 64, 64, device="cuda")
