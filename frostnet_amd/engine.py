@@ -36,6 +36,7 @@ _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit +
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
 _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # largest pixel count whose reduce pass runs on the chunked kernel (the dc pass always does)
+_PW_FUSE_MINPIX = int(os.environ.get("FROST_PW_FUSE_MINPIX", "150000"))   # fused pointwise backward only from this pixel count up; below (the 14x14 / 7x7 squeeze convs): dc + data gradient, weight gradient on the second stream (-0.08 ms)
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -623,8 +624,10 @@ class Engine:
         self._ensure_grad(l)
         gout = y.grad
         s = stream()
-        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout))
-        dc = None if fused else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
+        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.npix >= _PW_FUSE_MINPIX)
+        blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)
+                  and bool(L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)))      # dc stays in LDS there: no buffer
+        dc = None if (fused or blk_dw) else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
         if getattr(self, "_dbg", False):
             self._last_dc = dc
         if l.kind in ("pw", "stem"):
