@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
                                                        const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint,
                                                        uint8_t* __restrict__ stats, FrostFinDesc fin) {
   constexpr bool I8 = GM != 0;
-  __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024];
+  __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024 + 1024];          // (+ the slack the staged output tile needs, see the epilogue)
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t p0 = (int64_t)blockIdx.x * (64 * NTP) + w * (16 * NTP);
@@ -429,6 +429,39 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
     return;
   }
   const float sw = qw ? qw[FROST_Q_SCALE] : 1.0f;
+  if (!bias && !relu && !accumulate && (cin & 7) == 0) {
+    // data gradient of a layer with long output rows (reduce_conv: Cin = 312 .. 1728): the lane's results are 8-byte pieces at a 2*Cin-byte stride; staged
+    // through a wave-private LDS tile [32 pixels][128 channels] (pitch 264 B, two pixel blocks at a time) they leave as 256 contiguous bytes per pixel, four
+    // pixel rows per store instruction
+    constexpr int OP = DGW_NT * 32 + 8;
+    static_assert(4 * 32 * OP <= (int)sizeof(wl), "output staging tile does not fit the weight buffers");
+    __syncthreads();                                       // every wave is done with the weight stages
+    uint8_t* const ot = &wl[0][0] + (size_t)w * (32 * OP);
+    const int c8 = lane & 15, rsub = lane >> 4;             // 16-byte piece (8 channels) of the row, row within a group of four
+    const int cch = ct0 * 16 + c8 * 8;
+#pragma unroll
+    for (int t0 = 0; t0 < NTP; t0 += 2) {
+#pragma unroll
+      for (int m = 0; m < DGW_NT; ++m) {
+        if (m >= nct) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          uint2 o; o.x = cvt_pk_bf16(acc[m][t0 + t][0] * sw, acc[m][t0 + t][1] * sw); o.y = cvt_pk_bf16(acc[m][t0 + t][2] * sw, acc[m][t0 + t][3] * sw);
+          *(uint2*)(ot + (16 * t + j) * OP + (m * 16 + 4 * g) * 2) = o;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private tile: no barrier, the wave's own writes have landed
+      if (c8 < nct * 2 && cch < cin) {
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+          const int64_t p = p0 + 16 * t0 + r0 + rsub;
+          if (p < npix) *(uint4*)(dx + p * cin + cch) = *(const uint4*)(ot + (r0 + rsub) * OP + c8 * 16);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is read out before the next pair of pixel blocks overwrites it
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < DGW_NT; ++m) {
     if (m >= nct) continue;
