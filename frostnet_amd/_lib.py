@@ -96,6 +96,7 @@ _PROTOS = {
     "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_pwc_bwd_ok": [L, I, I],
     "frost_pwc_conv_bwd": [P, P, P, P, L, I, I, I, P, P, I, P, P, P],
+    "frost_pwc_conv_fwd_emit": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_block_supported": [I, I, I, I, I, I],
     "frost_block_expand_dw_stats": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
     "frost_block_dw_reduce_supported": [I, I, I, I, I, I],

@@ -12,7 +12,7 @@
 
 struct PwcP {
   const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum;
-  float* coef; const float* qy; const uint16_t* gout; uint16_t* dc;
+  float* coef; const float* qy; const uint16_t* gout; uint16_t* dc; int8_t* y;
   int64_t npix; int cin, c, cpad, kstr, nchunk, csplit, relu, sr; float inv_count;
 };
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
       const float s1 = ok ? p.coef[FROST_COEF_S1 * p.cpad + c2] : 0.0f, s2 = ok ? p.coef[FROST_COEF_S2 * p.cpad + c2] : 0.0f;
       const float E = -K1 * (s2 * p.inv_count) * R;
       tK1[i] = K1; tE[i] = E; tF[i] = -K1 * (s1 * p.inv_count) - E * M;
-    } else { l_f1[i] = 0.0f; l_f2[i] = 0.0f; }
+    } else if (MODE == 0) { l_f1[i] = 0.0f; l_f2[i] = 0.0f; }
   }
   {   // the tile's input rows: contiguous in HBM; rows past the tensor stay zero
     const int upr = p.cin >> 3; const int64_t rows = p.npix - p0 < PWC_PX ? p.npix - p0 : PWC_PX; const int total = (int)rows * upr;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
   }
   const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
   const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
+  const float y_zpf = (float)__float_as_int(p.qy[FROST_Q_ZP]), qcap = (float)q_hi(p.qy); const bool lowq = qcap < 255.0f;
   float t_lo = 0.0f, t_hi;
   {
     const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
@@ -92,13 +93,15 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
     for (int ks = 0; ks < KSM; ++ks) dst[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
   };
   uint4 gv[2]; v4i afr[KSM];
-  if (chunk_lo < chunk_hi) { load_g(chunk_lo, gv); load_w(chunk_lo, afr); }
+  if (chunk_lo < chunk_hi) { if (MODE != 2) load_g(chunk_lo, gv); load_w(chunk_lo, afr); }
   __syncthreads();
 
   for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
     uint8_t* const gw = gwin + ((chunk - chunk_lo) & 1) * (PWC_PX * 64 * 2);
-    *(uint4*)(gw + (upx0 * 64 + part * 8) * 2) = gv[0];
-    *(uint4*)(gw + (upx1 * 64 + part * 8) * 2) = gv[1];
+    if (MODE != 2) {
+      *(uint4*)(gw + (upx0 * 64 + part * 8) * 2) = gv[0];
+      *(uint4*)(gw + (upx1 * 64 + part * 8) * 2) = gv[1];
+    }
     // conv recomputation: wave = channel tile w of the chunk, 4 pixel tiles
     const int ti = (chunk - chunk_lo) * 64 + w * 16 + 4 * g;
     v4i acc[4];
@@ -114,10 +117,33 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
         const v4i bfr = *(const v4i*)(xs + (t * 16 + j) * p.kstr + ks * 64 + g * 16);
         acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, acc[t], 0, 0, 0);          // D[chan][pix]
       }
-    if (chunk + 1 < chunk_hi) { load_g(chunk + 1, gv); load_w(chunk + 1, afr); }
-    pwc_barrier();                                             // the gout window is complete
+    if (chunk + 1 < chunk_hi) { if (MODE != 2) load_g(chunk + 1, gv); load_w(chunk + 1, afr); }
+    if (MODE != 2) pwc_barrier();                              // the gout window is complete
     const float4 A4 = *(const float4*)(tA + ti), B4 = *(const float4*)(tB + ti);
     const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
+    if (MODE == 2) {
+      // forward emit (k_pw's expression): q = clamp(rint(fma(A, acc, B) / s) + zp, 0, hi) -> int8 window [64 px][64 ch] -> 64-byte rows out
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yv = fmaf(A[r], (float)acc[t][r], B[r]);
+          float qv = rintf(yv * y_inv) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+        }
+        *(uint32_t*)(gw + (t * 16 + j) * 64 + w * 16 + 4 * g) = packed ^ 0x80808080u;
+      }
+      pwc_barrier();
+      const int px = tid >> 2, q16 = tid & 3;                  // 64 pixels x 4 pieces of 16 bytes
+      if ((p0 + px) < p.npix && (chunk * 64 + q16 * 16) < p.c) {
+        int8_t* dst = p.y + (p0 + px) * p.c + chunk * 64 + q16 * 16;
+        if ((p.c & 15) == 0) *(uint4*)dst = *(const uint4*)(gw + px * 64 + q16 * 16);
+        else { *(uint2*)dst = *(const uint2*)(gw + px * 64 + q16 * 16); if ((chunk * 64 + q16 * 16 + 8) < p.c) *(uint2*)(dst + 8) = *(const uint2*)(gw + px * 64 + q16 * 16 + 8); }
+      }
+      continue;
+    }
     if (MODE == 0) {
       const float4 R4 = *(const float4*)(tR + ti), M4 = *(const float4*)(tMR + ti);
       const float R[4] = {R4.x, R4.y, R4.z, R4.w}, MR[4] = {M4.x, M4.y, M4.z, M4.w};
@@ -214,5 +240,27 @@ extern "C" int frost_pwc_conv_bwd(const int8_t* x, const float* qrec_x, const in
   PWC_GO(1) PWC_GO(2) PWC_GO(3) PWC_GO(4) PWC_GO(5)
 #undef PWC_GO
   FROST_REQUIRE(false, "pwc_conv_bwd: no instance");
+  return 1;
+}
+
+// the forward emit pass of the same layers (the contract of frost_pw_conv_fwd mode 1: training / eval form, not the converted-inference forms): the quantised
+// output leaves through an LDS window with 64-byte row pieces instead of 4-byte pieces at a Cout-byte stride
+extern "C" int frost_pwc_conv_fwd_emit(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                                       const float* coef, const float* qrec_y, int8_t* y, void* stream) {
+  FROST_REQUIRE(frost_pwc_bwd_ok(npix, cin, cout) && y, "pwc_conv_fwd_emit: unsupported layer");
+  PwcP p = {};
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = (float*)coef; p.qy = qrec_y; p.y = y; p.npix = npix; p.cin = cin; p.c = cout;
+  p.cpad = round_up(cout, 16); const int KS = (cin + 63) / 64; p.kstr = KS * 64 + 16; p.nchunk = (cout + 63) / 64;
+  const int64_t tiles = (npix + PWC_PX - 1) / PWC_PX;
+  int cpw = (int)((tiles * p.nchunk + 2047) / 2048);
+  if (cpw < 2) cpw = 2;
+  if (cpw > p.nchunk) cpw = p.nchunk;
+  if (cpw > 12) cpw = 12;
+  p.csplit = (p.nchunk + cpw - 1) / cpw;
+  hipStream_t s = as_stream(stream);
+#define PWC_GO(KK) if (KS == KK) return launch_pwc<2, KK>(p, s);
+  PWC_GO(1) PWC_GO(2) PWC_GO(3) PWC_GO(4) PWC_GO(5)
+#undef PWC_GO
+  FROST_REQUIRE(false, "pwc_conv_fwd_emit: no instance");
   return 1;
 }

@@ -37,6 +37,7 @@ _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise bac
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
 _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # largest pixel count whose reduce pass runs on the chunked kernel (the dc pass always does)
 _PW_FUSE_MINPIX = int(os.environ.get("FROST_PW_FUSE_MINPIX", "150000"))   # fused pointwise backward only from this pixel count up; below (the 14x14 / 7x7 squeeze convs): dc + data gradient, weight gradient on the second stream (-0.08 ms)
+_PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -264,7 +265,10 @@ class Engine:
         st = ptr(l.stats)
         nb = x.numel + l.wq_pack.numel() + (y.numel if y is not None else 0)
         tag = (f"{l.kind}_fwd_{'emit' if mode else 'stats'}", nb)      # mode 2 / 3 = emit with the converted-inference requantisation (QNNPACK / FBGEMM form)
-        if l.kind in ("pw", "stem"):
+        if l.kind == "pw" and mode == 1 and _PWC_EMIT and L.load_library().frost_pwc_bwd_ok(x.npix, x.c, l.cout):
+            # wide layers outside a conv1 -> conv2 pair (last_layer, the stride-2 blocks' conv1): chunked emit, y leaves as 64-byte row pieces (csrc/frost_pwc.hip)
+            call("frost_pwc_conv_fwd_emit", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.coef), ptr(l.qy), ptr(y.buf), stream(), prof=tag)
+        elif l.kind in ("pw", "stem"):
             call("frost_pw_conv_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, mode, st,
                  ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.buf) if y is not None else None, stream(), prof=tag)
         elif l.kind == "dw":

@@ -367,6 +367,9 @@ int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const 
  * LDS-staged tile I/O (Cout >= 256, input rows <= 320 bytes): a workgroup owns a 64-pixel tile and walks 64-channel chunks, so the gout window is read and the dc
  * window written with full 128-byte lines.  Same expressions as k_pw; pass 0 accumulates S1 / S2 into the coefficient rows, pass 1 writes dc (bf16). */
 int frost_pwc_bwd_ok(int64_t npix, int cin, int cout);
+/* the forward emit pass of the same layers (frost_pw_conv_fwd mode 1; the converted-inference modes stay on k_pw): y leaves through an LDS window as 64-byte row pieces */
+int frost_pwc_conv_fwd_emit(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
+                            const float* coef, const float* qrec_y, int8_t* y, void* stream);
 int frost_pwc_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout, int pass,
                        float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream);
 
