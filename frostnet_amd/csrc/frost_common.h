@@ -113,10 +113,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // observer EMA + qparams, shared by every finalize-type kernel (Appendix B of SURVEY.md).
 // cur_lo/cur_hi: min/max of the current tensor. Writes all qrecord fields. One thread.
+// the record fields the update reads, fetched ahead of the dependent chain that produces cur_lo / cur_hi (a finalize tail is a chain of global round trips:
+// ticket -> statistics -> this record; loaded early the record travels with the statistics)
+struct ObsPre { float mn, mx, en, qmax; };
+__device__ __forceinline__ ObsPre observer_prefetch(const float* q) { ObsPre p; p.mn = q[FROST_Q_MIN]; p.mx = q[FROST_Q_MAX]; p.en = q[FROST_Q_OBS_EN]; p.qmax = q[FROST_Q_QMAX]; return p; }
 __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi, int symmetric, int rule127,
-                                           int observe) {
-  float mn = q[FROST_Q_MIN], mx = q[FROST_Q_MAX];
-  observe = observe && (__float_as_int(q[FROST_Q_OBS_EN]) != 0);       // the site's own observer_enabled buffer (device resident)
+                                           int observe, const ObsPre* pre = nullptr) {
+  float mn = pre ? pre->mn : q[FROST_Q_MIN], mx = pre ? pre->mx : q[FROST_Q_MAX];
+  observe = observe && (__float_as_int(pre ? pre->en : q[FROST_Q_OBS_EN]) != 0);       // the site's own observer_enabled buffer (device resident)
+  float fscale = 1.0f; int fzp = 0; bool have = false;
+  const int qhi = pre ? ((pre->qmax > 0.0f) ? (int)pre->qmax : 255) : q_hi(q);
   if (observe) {
     if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = cur_lo; mx = cur_hi; }
     else { mn = mn + FROST_OBS_C * (cur_lo - mn); mx = mx + FROST_OBS_C * (cur_hi - mx); }
@@ -130,18 +136,19 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
         else scale = fmaxf(-mn_neg, mx_pos) / 127.5f;
         scale = fmaxf(scale, FROST_F32_EPS);
       } else {
-        scale = (mx_pos - mn_neg) / (float)q_hi(q);          // (qmax - qmin): 255, or 127 with reduce_range
+        scale = (mx_pos - mn_neg) / (float)qhi;          // (qmax - qmin): 255, or 127 with reduce_range
         scale = fmaxf(scale, FROST_F32_EPS);
         zp = 0 - (int)rintf(mn_neg / scale);
-        zp = min(max(zp, 0), q_hi(q));
+        zp = min(max(zp, 0), qhi);
       }
     }
     q[FROST_Q_SCALE] = scale; q[FROST_Q_ZP] = __int_as_float(zp);
+    fscale = scale; fzp = zp; have = true;
   }
-  float scale = q[FROST_Q_SCALE]; int zp = __float_as_int(q[FROST_Q_ZP]);
+  const float scale = have ? fscale : q[FROST_Q_SCALE]; const int zp = have ? fzp : __float_as_int(q[FROST_Q_ZP]);
   float inv = 1.0f / scale;
   q[FROST_Q_INV] = inv;
-  int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : q_hi(q);
+  int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : qhi;
   int ilo = fq_index(cur_lo, inv, zp, lo, hi), ihi = fq_index(cur_hi, inv, zp, lo, hi);
   q[FROST_Q_FQMIN] = (float)(ilo - zp) * scale;
   q[FROST_Q_FQMAX] = (float)(ihi - zp) * scale;
@@ -158,6 +165,11 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
   const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
   const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
   const float sx = qx[FROST_Q_SCALE], sw0 = qw[FROST_Q_SCALE];
+  ObsPre pre_y = {}, pre_cat = {}; float cat_b_lo = 0.0f, cat_b_hi = 0.0f;
+  if (tid == 0 && have_stats) {      // the records thread 0 updates at the end: requested now, they arrive with the statistics
+    pre_y = observer_prefetch(qy);
+    if (cat_qy) { pre_cat = observer_prefetch(cat_qy); cat_b_lo = cat_qb[FROST_Q_FQMIN]; cat_b_hi = cat_qb[FROST_Q_FQMAX]; }
+  }
   float lo = INFINITY, hi = -INFINITY;
   for (int c = tid; c < cpad; c += nthr) {
     float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
@@ -206,10 +218,13 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
   if (tid == 0) {
     for (int i = 1; i < nw; ++i) { lo = fminf(lo, sh[i]); hi = fmaxf(hi, sh[nw + i]); }
     if (training && nbt) *nbt += 1;
-    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe);
+    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe, &pre_y);
     else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
     // squeeze_conv of a Frost bottleneck: the cat's FakeQuantize sees min / max of the fake-quantised halves (k_cat_observe's expression)
-    if (cat_qy) observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_qb[FROST_Q_FQMIN]), fmaxf(qy[FROST_Q_FQMAX], cat_qb[FROST_Q_FQMAX]), 0, 0, observe);
+    if (cat_qy) {
+      if (have_stats) observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_b_lo), fmaxf(qy[FROST_Q_FQMAX], cat_b_hi), 0, 0, observe, &pre_cat);
+      else observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_qb[FROST_Q_FQMIN]), fmaxf(qy[FROST_Q_FQMAX], cat_qb[FROST_Q_FQMAX]), 0, 0, observe);
+    }
   }
 }
 
