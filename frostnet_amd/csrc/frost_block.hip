@@ -25,7 +25,7 @@ struct BlkAP {
   const float* coef1; const float* qy1; int8_t* y1; // conv1: coefficient rows (finalized), output record, output tensor [n*map][c]
   const int8_t* wq2; const int32_t* wsum2;          // conv2 (depthwise): taps [k*k][cpad], weight sums
   uint8_t* stats2; FrostFinDesc fin;                // conv2: statistics table and the finalize descriptor
-  int n, cin, c, cpad, KS, kstr, nchunk, csplit, imgs;
+  int n, cin, c, cpad, KS, kstr, nchunk, csplit, imgs, rounds;
 };
 
 template <int K, int HW, int NW>
@@ -279,8 +279,16 @@ static int launch_blk_a(BlkAP& p, hipStream_t s) {
   using G = BlkGeo<K, HW, NW>;
   const size_t lds = (size_t)G::lds(p.kstr, (p.nchunk + p.csplit - 1) / p.csplit);
   FROST_REQUIRE(lds <= 160 * 1024, "block_expand_dw: LDS budget exceeded");
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_expand_dw<K, HW, NW, KSM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static bool attr_set = false; static int occ = 0; static size_t occ_lds = 0;
+  if (!attr_set || occ_lds != lds) {
+    hipFuncSetAttribute((const void*)k_blk_expand_dw<K, HW, NW, KSM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; occ_lds = lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_expand_dw<K, HW, NW, KSM>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  }
+  if (p.imgs <= 0) {       // whole rounds of resident workgroups: image groups = floor(rounds * slots / chunk ranges)
+    const int rounds = p.rounds > 0 ? p.rounds : 1;
+    int groups = (256 * occ * rounds) / p.csplit; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
+    p.imgs = (p.n + groups - 1) / groups;
+  }
   hipLaunchKernelGGL((k_blk_expand_dw<K, HW, NW, KSM>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.csplit)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_expand_dw");
 }
@@ -545,7 +553,7 @@ struct BlkCP {
   const int8_t* wq; const int32_t* wsum; const float* qw; const float* wscale;   // taps [k*k][cpad], weight sums, weight record, per-channel scales (or NULL)
   const float* coef; const float* qy;               // coefficient rows after the reduce pass (S1 / S2 filled), output record
   const uint16_t* gout; uint16_t* dx; float* dwq;   // gradient w.r.t. conv2's output (bf16), w.r.t. its input (bf16, or NULL), raw weight-gradient sums [c][k*k]
-  int n, c, cpad, nchunk, imgs, relu, sr; float inv_count;
+  int n, c, cpad, nchunk, imgs, rounds, relu, sr; float inv_count;
 };
 
 template <int K, int HW, int NW>
@@ -758,8 +766,17 @@ static int launch_blk_c(BlkCP& p, hipStream_t s) {
   using G = BlkGeoC<K, HW, NW>;
   const size_t lds = (size_t)G::lds();
   FROST_REQUIRE(lds <= 160 * 1024, "block_dw_bwd: LDS budget exceeded");
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_bwd<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static bool attr_set = false; static int occ = 0;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_blk_dw_bwd<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_dw_bwd<K, HW, NW>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  }
+  if (p.imgs <= 0) {
+    // one round of RESIDENT workgroups (queried, not guessed): a launch of 1.5 rounds costs two -- image groups = floor(slots / chunks), images per group to match
+    const int rounds = p.rounds > 0 ? p.rounds : 1;
+    int groups = (256 * occ * rounds) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
+    p.imgs = (p.n + groups - 1) / groups;
+  }
   hipLaunchKernelGGL((k_blk_dw_bwd<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_dw_bwd");
 }
@@ -781,11 +798,10 @@ extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const in
   static const int wgs_env = getenv("FROST_BLK_WGS_C") ? atoi(getenv("FROST_BLK_WGS_C")) : 0;
   // images per workgroup: the k*k weight-gradient sums stay in registers across them and every workgroup ends with 64 * k*k float atomics, so the launch
   // is sized to ONE round of resident workgroups (2 per CU at ~200 VGPRs), not to many small ones
-  const int want = wgs_env > 0 ? wgs_env : (h == 7 ? 768 : 512);          // measured over FrostNet-Large's eleven eligible layers at B = 512
-  int imgs = imgs_env > 0 ? imgs_env : (int)(((int64_t)n * p.nchunk + want - 1) / want);
-  if (imgs < 1) imgs = 1;
+  static const int rounds_env = getenv("FROST_BLK_ROUNDS_C") ? atoi(getenv("FROST_BLK_ROUNDS_C")) : 0;
+  int imgs = imgs_env > 0 ? imgs_env : (wgs_env > 0 ? (int)(((int64_t)n * p.nchunk + wgs_env - 1) / wgs_env) : 0);      // 0: sized from the kernel's residency at launch
   if (imgs > n) imgs = n;
-  p.imgs = imgs;
+  p.imgs = imgs; p.rounds = rounds_env;
   hipStream_t s = as_stream(stream);
   if (h == 7) return (k == 3) ? launch_blk_c<3, 7, 4>(p, s) : launch_blk_c<5, 7, 4>(p, s);
   return (k == 3) ? launch_blk_c<3, 14, 8>(p, s) : launch_blk_c<5, 14, 8>(p, s);
@@ -905,8 +921,16 @@ template <int K, int HW, int NW>
 static int launch_blk_r(BlkCP& p, hipStream_t s) {
   using G = BlkGeoC<K, HW, NW>;
   const size_t lds = (size_t)(G::PLANE + G::GT + 64);
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_bred<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static bool attr_set = false; static int occ = 0;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_blk_dw_bred<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_dw_bred<K, HW, NW>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  }
+  if (p.imgs <= 0) {       // one round of resident workgroups (see launch_blk_c)
+    const int rounds = p.rounds > 0 ? p.rounds : 1;
+    int groups = (256 * occ * rounds) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
+    p.imgs = (p.n + groups - 1) / groups;
+  }
   hipLaunchKernelGGL((k_blk_dw_bred<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_dw_bwd_reduce");
 }
@@ -919,11 +943,10 @@ extern "C" int frost_block_dw_bwd_reduce(const int8_t* x, const float* qrec_x, c
   p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.coef = coef; p.qy = qrec_y; p.gout = gout;
   p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu;
   static const int wgs_env = getenv("FROST_BLK_WGS_R") ? atoi(getenv("FROST_BLK_WGS_R")) : 0;
-  const int want = wgs_env > 0 ? wgs_env : 1024;
-  int imgs = (int)(((int64_t)n * p.nchunk + want - 1) / want);
-  if (imgs < 1) imgs = 1;
+  static const int rounds_env = getenv("FROST_BLK_ROUNDS_R") ? atoi(getenv("FROST_BLK_ROUNDS_R")) : 0;
+  int imgs = wgs_env > 0 ? (int)(((int64_t)n * p.nchunk + wgs_env - 1) / wgs_env) : 0;       // 0: sized from the kernel's residency at launch
   if (imgs > n) imgs = n;
-  p.imgs = imgs;
+  p.imgs = imgs; p.rounds = rounds_env;
   hipStream_t s = as_stream(stream);
   if (h == 7) return (k == 3) ? launch_blk_r<3, 7, 4>(p, s) : launch_blk_r<5, 7, 4>(p, s);
   return (k == 3) ? launch_blk_r<3, 14, 8>(p, s) : launch_blk_r<5, 14, 8>(p, s);
@@ -948,11 +971,9 @@ extern "C" int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x,
   int cpw = cpw_env > 0 ? cpw_env : 2;                 // chunks per workgroup
   if (cpw > p.nchunk) cpw = p.nchunk;
   p.csplit = (p.nchunk + cpw - 1) / cpw;
-  const int want = 1400;                // measured on 240->1440 @ 7x7 and 104->624 @ 14x14, B = 512: (2 chunks, 4 images) and (2 chunks, 2 images) per workgroup
-  int imgs = imgs_env > 0 ? imgs_env : (int)(((int64_t)n * p.csplit + want / 2) / want);
-  if (imgs < 1) imgs = 1;
-  if (imgs > 16) imgs = 16;
-  p.imgs = imgs;
+  static const int rounds_env = getenv("FROST_BLK_ROUNDS_A") ? atoi(getenv("FROST_BLK_ROUNDS_A")) : 0;
+  p.imgs = imgs_env > 0 ? imgs_env : 0;          // 0: sized from the kernel's residency at launch (whole rounds of resident workgroups)
+  p.rounds = rounds_env > 0 ? rounds_env : (h == 14 ? 2 : 1);      // measured: two rounds at 14 x 14 (72 vs 82 us), one at 7 x 7
   hipStream_t s = as_stream(stream);
 #define BLK_A(KK, HH, NWW, KSS) if (k == KK && h == HH && p.KS == KSS) return launch_blk_a<KK, HH, NWW, KSS>(p, s);
   BLK_A(3, 7, 4, 2) BLK_A(3, 7, 4, 3) BLK_A(3, 7, 4, 4) BLK_A(3, 7, 4, 5) BLK_A(5, 7, 4, 2) BLK_A(5, 7, 4, 3) BLK_A(5, 7, 4, 4) BLK_A(5, 7, 4, 5)
