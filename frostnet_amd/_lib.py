@@ -44,6 +44,19 @@ class FrostFinDesc(C.Structure):
                 ("cat_qrec_b", P), ("cat_qrec_y", P)]
 
 
+class FrostBlockLayer(C.Structure):
+    _fields_ = [("wq_pack", P), ("wsum", P), ("stats", P), ("fin", FrostFinDesc), ("wt_pack", P), ("dwq", P), ("cout", C.c_int32), ("k", C.c_int32)]
+
+
+class FrostBlockDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("cin", C.c_int32), ("x", P), ("qrec_x", P),
+                ("conv1", FrostBlockLayer), ("conv2", FrostBlockLayer), ("reduce", FrostBlockLayer), ("y1", P), ("y2", P), ("conv_out3", P), ("y3", P)]
+
+
+class FrostBlockBwd(C.Structure):
+    _fields_ = [("gout3", P), ("dc3", P), ("g2", P), ("g1", P), ("dc1", P), ("dx", P), ("side_stream", P)]
+
+
 class FrostGDesc(C.Structure):
     _fields_ = [("dwq", P), ("w", P), ("gamma", P), ("sigma_r", P), ("qw", P), ("coef", P), ("dw", P), ("dgamma", P), ("dbeta", P),
                 ("cout", C.c_int32), ("per", C.c_int32), ("cpad", C.c_int32), ("reserved", C.c_int32), ("wscale", P)]
@@ -98,6 +111,8 @@ _PROTOS = {
     "frost_pwc_conv_bwd": [P, P, P, P, L, I, I, I, P, P, I, P, P, P],
     "frost_pwc_conv_fwd_emit": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_block_supported": [I, I, I, I, I, I],
+    "frost_block_fwd": [P, P],
+    "frost_block_bwd": [P, P, P],
     "frost_block_expand_dw_stats": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
     "frost_block_dw_reduce_supported": [I, I, I, I, I, I],
     "frost_block_dw_bwd_supported": [I, I, I, I, I],

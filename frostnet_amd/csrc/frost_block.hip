@@ -982,3 +982,73 @@ extern "C" int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x,
   FROST_REQUIRE(false, "block_expand_dw: no instance");
   return 1;
 }
+
+// ================================================================================================ frost_block_fwd / frost_block_bwd: host composites
+extern "C" int frost_pw_conv_fwd_fin(const int8_t*, const float*, const int8_t*, const int32_t*, int64_t, int, int, void*, const FrostFinDesc*, void*);
+extern "C" int frost_pw_ew(const int32_t*, int64_t, int, float*, const float*, int, int, const uint16_t*, void*, void*);
+extern "C" int frost_pw_dgrad_wide(const uint16_t*, const uint16_t*, const float*, int64_t, int, int, uint16_t*, int, void*);
+extern "C" int frost_pw_wgrad(const uint16_t*, const int8_t*, const float*, int64_t, int, int, float*, void*);
+extern "C" int frost_pw_conv_bwd(const int8_t*, const float*, const int8_t*, const int32_t*, const uint16_t*, const float*, int64_t, int, int, int, float*, const float*, int,
+                                 const uint16_t*, uint16_t*, uint16_t*, int, void*);
+extern "C" int frost_pwc_bwd_ok(int64_t, int, int);
+extern "C" int frost_pwc_conv_bwd(const int8_t*, const float*, const int8_t*, const int32_t*, int64_t, int, int, int, float*, const float*, int, const uint16_t*, uint16_t*, void*);
+
+static int blk_desc_check(const FrostBlockDesc* d) {
+  FROST_REQUIRE(d && d->x && d->y1 && d->y2 && d->y3 && d->conv_out3, "block: incomplete descriptor");
+  FROST_REQUIRE(d->conv2.cout == d->conv1.cout && d->conv1.k == 1 && d->reduce.k == 1, "block: conv1 / reduce_conv are 1x1, conv2 is depthwise over conv1's channels");
+  FROST_REQUIRE(frost_block_supported(d->h, d->w, d->conv2.k, 1, d->cin, d->conv1.cout) && frost_block_dw_reduce_supported(d->h, d->w, d->conv2.k, 1, d->conv1.cout, d->reduce.cout)
+                && d->reduce.cout < d->conv1.cout, "block: unsupported shape (14x14 / 7x7 maps, depthwise stride 1, reduce_conv narrower than the expanded tensor)");
+  return 0;
+}
+
+extern "C" int frost_block_fwd(const FrostBlockDesc* d, void* stream) {
+  if (int rc = blk_desc_check(d)) return rc;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const FrostBlockLayer &l1 = d->conv1, &l2 = d->conv2, &l3 = d->reduce;
+  int rc = frost_pw_conv_fwd_fin(d->x, d->qrec_x, l1.wq_pack, l1.wsum, npix, d->cin, l1.cout, l1.stats, &l1.fin, stream);
+  if (rc) return rc;
+  rc = frost_block_expand_dw_stats(d->x, d->qrec_x, l1.wq_pack, l1.wsum, l1.fin.coef, l1.fin.qrec_y, d->y1, d->n, d->h, d->w, d->cin, l1.cout, l2.wq_pack, l2.wsum, l2.k, l2.stats,
+                                   &l2.fin, stream);
+  if (rc) return rc;
+  rc = frost_block_dw_reduce(d->y1, l1.fin.qrec_y, l2.wq_pack, l2.wsum, l2.fin.coef, l2.fin.qrec_y, l2.fin.relu, d->y2, d->n, d->h, d->w, l1.cout, l2.k, l3.wq_pack, l3.wsum, l3.cout,
+                             d->conv_out3, l3.stats, &l3.fin, stream);
+  if (rc) return rc;
+  return frost_pw_ew(d->conv_out3, npix, l3.cout, l3.fin.coef, l3.fin.qrec_y, l3.fin.relu, 2, nullptr, d->y3, stream);
+}
+
+extern "C" int frost_block_bwd(const FrostBlockDesc* d, const FrostBlockBwd* b, void* stream) {
+  if (int rc = blk_desc_check(d)) return rc;
+  FROST_REQUIRE(b && b->gout3 && b->dc3 && b->g2 && b->g1 && b->dc1, "block_bwd: incomplete gradient buffers");
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const FrostBlockLayer &l1 = d->conv1, &l2 = d->conv2, &l3 = d->reduce;
+  hipStream_t ms = as_stream(stream), ss = b->side_stream ? as_stream(b->side_stream) : ms;
+  hipEvent_t ev = nullptr;
+  auto fork = [&]() { if (ss != ms) { if (!ev) hipEventCreateWithFlags(&ev, hipEventDisableTiming); hipEventRecord(ev, ms); hipStreamWaitEvent(ss, ev, 0); } };
+  int rc;
+  // reduce_conv (kept integer conv output: element-wise reduce and dc)
+  if ((rc = frost_pw_ew(d->conv_out3, npix, l3.cout, l3.fin.coef, l3.fin.qrec_y, l3.fin.relu, 0, b->gout3, nullptr, stream))) return rc;
+  if ((rc = frost_pw_ew(d->conv_out3, npix, l3.cout, l3.fin.coef, l3.fin.qrec_y, l3.fin.relu, 1, b->gout3, b->dc3, stream))) return rc;
+  fork();
+  if ((rc = frost_pw_dgrad_wide(b->dc3, l3.wt_pack, l3.fin.qrec_w, npix, l1.cout, l3.cout, b->g2, 0, stream))) return rc;
+  if ((rc = frost_pw_wgrad(b->dc3, d->y2, l2.fin.qrec_y, npix, l1.cout, l3.cout, l3.dwq, (void*)ss))) return rc;
+  // conv2 (depthwise): reduce pass, then dc + weight gradient + data gradient in one launch
+  if ((rc = frost_block_dw_bwd_reduce(d->y1, l1.fin.qrec_y, l2.wq_pack, l2.wsum, d->n, d->h, d->w, l1.cout, l2.k, l2.fin.coef, l2.fin.qrec_y, l2.fin.relu, b->g2, stream))) return rc;
+  if ((rc = frost_block_dw_bwd(d->y1, l1.fin.qrec_y, l2.wq_pack, l2.wsum, l2.fin.qrec_w, l2.fin.wscale, d->n, d->h, d->w, l1.cout, l2.k, l2.fin.coef, l2.fin.qrec_y, l2.fin.relu,
+                               b->g2, b->g1, l2.dwq, stream))) return rc;
+  // conv1
+  const bool pwc = frost_pwc_bwd_ok(npix, d->cin, l1.cout) != 0;
+  if (pwc && npix <= 131072) rc = frost_pwc_conv_bwd(d->x, d->qrec_x, l1.wq_pack, l1.wsum, npix, d->cin, l1.cout, 0, l1.fin.coef, l1.fin.qrec_y, l1.fin.relu, b->g1, nullptr, stream);
+  else rc = frost_pw_conv_bwd(d->x, d->qrec_x, l1.wq_pack, l1.wsum, l1.wt_pack, l1.fin.qrec_w, npix, d->cin, l1.cout, 0, l1.fin.coef, l1.fin.qrec_y, l1.fin.relu, b->g1, nullptr, nullptr, 0, stream);
+  if (rc) return rc;
+  if (pwc) rc = frost_pwc_conv_bwd(d->x, d->qrec_x, l1.wq_pack, l1.wsum, npix, d->cin, l1.cout, 1, l1.fin.coef, l1.fin.qrec_y, l1.fin.relu, b->g1, b->dc1, stream);
+  else rc = frost_pw_conv_bwd(d->x, d->qrec_x, l1.wq_pack, l1.wsum, l1.wt_pack, l1.fin.qrec_w, npix, d->cin, l1.cout, 1, l1.fin.coef, l1.fin.qrec_y, l1.fin.relu, b->g1, b->dc1, nullptr, 0, stream);
+  if (rc) return rc;
+  fork();
+  if (b->dx && (rc = frost_pw_dgrad_wide(b->dc1, l1.wt_pack, l1.fin.qrec_w, npix, d->cin, l1.cout, b->dx, 0, stream))) return rc;
+  if ((rc = frost_pw_wgrad(b->dc1, d->x, d->qrec_x, npix, d->cin, l1.cout, l1.dwq, (void*)ss))) return rc;
+  if (ss != ms) {          // join: what follows on the main stream may reuse dc1 / dc3
+    hipEventRecord(ev, ss); hipStreamWaitEvent(ms, ev, 0);
+  }
+  if (ev) hipEventDestroy(ev);
+  return frost_check_launch("block_bwd");
+}

@@ -411,6 +411,36 @@ int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pa
                        int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
                        float* dwq, void* stream);
 
+/* ---- frost_block_fwd / frost_block_bwd: the conv1 -> conv2 -> reduce_conv chain of one bottleneck as ONE call each (SURVEY 8(b) "frost_block_fwd/bwd") ------
+ * replaces: `out = self.reduce_conv(self.conv2(self.conv1(out)))` of CascadePreExBottleneck.forward (frostnet.py:134-138) in training mode with observers on, and
+ * its backward.  Host-side composites over the entries above (what Engine.conv_pair / Engine._conv_backward sequence): every launch goes to `stream`, nothing is
+ * allocated -- all buffers are the caller's.  Supported where frost_block_supported and frost_block_dw_reduce_supported hold (14x14 / 7x7 maps, depthwise
+ * stride 1, reduce_conv narrower than the expanded tensor); other blocks run layer by layer.
+ *   forward : frost_pw(c)_conv_fwd_fin(conv1) -> frost_block_expand_dw_stats -> frost_block_dw_reduce -> frost_pw_ew mode 2 (y3)
+ *   backward: reduce_conv [frost_pw_ew 0, 1 -> frost_pw_dgrad_wide -> frost_pw_wgrad]; conv2 [frost_block_dw_bwd_reduce -> frost_block_dw_bwd];
+ *             conv1 [reduce pass -> frost_pwc_conv_bwd / frost_pw_conv_bwd pass 1 -> frost_pw_dgrad_wide -> frost_pw_wgrad].  Raw weight-gradient sums land in
+ *             `dwq` of each layer (zeroed by the caller; frost_weight_grad_finalize[_table] turns them into dW / dgamma / dbeta as for any layer).
+ *             side_stream (may be NULL): the two pointwise weight gradients run there, forked / joined with events inside the call. */
+typedef struct {
+  const int8_t* wq_pack; const int32_t* wsum; void* stats; FrostFinDesc fin;     /* forward operands of one ConvBN(ReLU) layer; fin.coef / fin.qrec_y are its rows / output record */
+  const uint16_t* wt_pack; float* dwq;                                           /* backward: transposed bf16 pack (pointwise layers; unused for conv2), raw weight-gradient sums */
+  int32_t cout, k;
+} FrostBlockLayer;
+typedef struct {
+  int32_t n, h, w, cin;                        /* conv1's input: n images of h x w x cin */
+  const int8_t* x; const float* qrec_x;
+  FrostBlockLayer conv1, conv2, reduce;
+  int8_t* y1; int8_t* y2; int32_t* conv_out3; int8_t* y3;       /* conv1 / conv2 outputs (kept for the backward), reduce_conv's integer output and emitted output */
+} FrostBlockDesc;
+typedef struct {
+  const uint16_t* gout3;                       /* gradient w.r.t. y3 (bf16, [n*h*w][cout3]) */
+  uint16_t* dc3; uint16_t* g2; uint16_t* g1; uint16_t* dc1;     /* work buffers: dc of reduce_conv, gradients w.r.t. y2 and y1, dc of conv1 (bf16, sized like the tensors) */
+  uint16_t* dx;                                /* gradient w.r.t. x (bf16, overwritten); NULL = not needed */
+  void* side_stream;
+} FrostBlockBwd;
+int frost_block_fwd(const FrostBlockDesc* d, void* stream);
+int frost_block_bwd(const FrostBlockDesc* d, const FrostBlockBwd* b, void* stream);
+
 /* ---- loss and dropout mask of the training step -------------------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(reduction='mean') forward + backward (Classification/train.py:147, helper_functions.py:140-142).
  * loss: one float (caller zeroes it; accumulated with atomics); dlogits = (softmax - onehot) * inv_n (may be NULL); target < 0 ignored. */

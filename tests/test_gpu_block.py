@@ -135,3 +135,73 @@ def test_block_backward_without_stochastic_rounding(case, tmp_path):
     assert float((a != b).mean()) <= 4e-2 and _rel(a, b) <= 3e-3          # (run-to-run order of the float atomics in the reduce passes moves a few dc roundings)
     for i in (1, 2, 3):
         assert _rel(blk[f"dw{i}"], lay[f"dw{i}"]) <= 2e-3 and _rel(blk[f"dgamma{i}"], lay[f"dgamma{i}"]) <= 3e-2, i       # d-gamma: a cancelling sum (see above)
+
+
+# ---- frost_block_fwd / frost_block_bwd: the chain as ONE C-ABI call each -----------------------------------------------------------------
+def _block_desc(E, l1, l2, l3, x, y1, y2, y3, cint):
+    import ctypes as C
+    from frostnet_amd import _lib as L
+
+    def fin(l):
+        return L.FrostFinDesc(l.qw.data_ptr(), l.gamma.data_ptr(), l.beta.data_ptr(), l.rmean.data_ptr(), l.rvar.data_ptr(), l.nbt.data_ptr(), l.coef.data_ptr(),
+                              l.qy.data_ptr(), l.fin_counter.data_ptr(), 1, int(l.relu), 1, 0, l.wscale.data_ptr(), None, None)
+
+    def layer(l):
+        return L.FrostBlockLayer(l.wq_pack.data_ptr(), l.wsum.data_ptr(), l.stats.data_ptr(), fin(l), l.wt_pack.data_ptr() if l.wt_pack is not None else None,
+                                 l.dwq.data_ptr(), l.cout, l.k)
+    return L.FrostBlockDesc(x.n, x.h, x.w, x.c, x.buf.data_ptr(), x.q.data_ptr(), layer(l1), layer(l2), layer(l3), y1.data_ptr(), y2.data_ptr(), cint.data_ptr(), y3.data_ptr())
+
+
+@pytest.mark.parametrize("case", [(240, 1440, 7, 5, 192, 13), (104, 624, 14, 5, 96, 6), (192, 1152, 7, 3, 192, 32)], ids=lambda c: "_".join(str(v) for v in c))
+def test_frost_block_fwd_bwd_entries_match_engine_sequence(case):
+    """frost_block_fwd / frost_block_bwd called through ctypes on caller-owned buffers against Engine.conv_pair + Engine.conv + Engine.backward on an identical
+    copy of the layers: the forward bit for bit; the backward runs the same kernels on the same grids (same stochastic-rounding draws), so the data gradient and
+    the raw weight-gradient sums agree up to the order of float atomics."""
+    import ctypes as C
+    from frostnet_amd import _lib as L, engine as EN
+    cin, cexp, H, k, cout, n = case
+    res = {}
+    for mode in ("engine", "entry"):
+        E, l1, l2, l3, qx = _build(cin, cexp, k, cout, 23)
+        g = torch.Generator(device="cpu").manual_seed(9)
+        x = E.new_act(n, H, H, cin, qx)
+        x.buf[: x.numel] = torch.randint(-128, 128, (x.numel,), dtype=torch.int16, generator=g).to(torch.int8).to("cuda")
+        gy = (torch.randn(n * H * H * cout, generator=g) * 1e-3).to("cuda").to(torch.bfloat16).view(torch.int16)
+        gy = torch.cat([gy, torch.zeros(64, dtype=torch.int16, device="cuda")])
+        E.begin_step()
+        if mode == "engine":
+            x.needs_grad = True
+            y3 = E.conv(l3, E.conv_pair(l1, l2, x, l3=l3))
+            y1, y2 = E.tape[0][3], E.tape[1][3]
+            fwd = dict(y1=y1.buf[: y1.numel].clone(), y2=y2.buf[: y2.numel].clone(), y3=y3.buf[: y3.numel].clone(), cint=y3.cint[: y3.numel].clone())
+            y3.grad = gy
+            E._prepare_dwq(); E._pending = []; E._side = None; E._keep = []       # Engine.backward's set-up without its weight-gradient finalize (the raw sums are compared)
+            for op in reversed(E.tape):
+                E._conv_backward(op[1], op[2], op[3])
+            torch.cuda.synchronize()
+            bwd = dict(dx=x.grad[: x.numel].clone(), **{f"dwq{i}": l.dwq.clone() for i, l in enumerate((l1, l2, l3), 1)})
+        else:
+            npix = n * H * H
+            E._prepare_dwq()                                  # allocates and zeroes the raw weight-gradient sums
+            y1 = torch.empty(npix * cexp + 64, dtype=torch.int8, device="cuda"); y2 = torch.empty_like(y1)
+            y3 = torch.empty(npix * cout + 64, dtype=torch.int8, device="cuda"); cint = torch.empty(npix * cout + 64, dtype=torch.int32, device="cuda")
+            d = _block_desc(E, l1, l2, l3, x, y1, y2, y3, cint)
+            L.call("frost_block_fwd", C.byref(d), L.stream())
+            fwd = dict(y1=y1[: npix * cexp].clone(), y2=y2[: npix * cexp].clone(), y3=y3[: npix * cout].clone(), cint=cint[: npix * cout].clone())
+            bf = lambda m: torch.empty(m + 64, dtype=torch.int16, device="cuda")
+            dc3, g2, g1, dc1, dx = bf(npix * cout), bf(npix * cexp), bf(npix * cexp), bf(npix * cexp), bf(npix * cin)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            b = L.FrostBlockBwd(gy.data_ptr(), dc3.data_ptr(), g2.data_ptr(), g1.data_ptr(), dc1.data_ptr(), dx.data_ptr(), C.c_void_p(side.cuda_stream))
+            L.call("frost_block_bwd", C.byref(d), C.byref(b), L.stream())
+            torch.cuda.synchronize()
+            bwd = dict(dx=dx[: npix * cin].clone(), **{f"dwq{i}": l.dwq.clone() for i, l in enumerate((l1, l2, l3), 1)})
+        res[mode] = (fwd, bwd)
+    (fa, ba), (fb, bb) = res["engine"], res["entry"]
+    for key in fa:
+        assert torch.equal(fa[key].reshape(-1).view(torch.uint8), fb[key].reshape(-1).view(torch.uint8)), key
+    dxa, dxb = ba["dx"].view(torch.bfloat16).double(), bb["dx"].view(torch.bfloat16).double()
+    assert float((dxa != dxb).double().mean()) <= 4e-2 and float((dxa - dxb).norm() / dxa.norm()) <= 3e-3
+    for i in (1, 2, 3):
+        a, b = ba[f"dwq{i}"].double(), bb[f"dwq{i}"].double()
+        assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-3, i
