@@ -416,7 +416,7 @@ int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pa
  * its backward.  Host-side composites over the entries above (what Engine.conv_pair / Engine._conv_backward sequence): every launch goes to `stream`, nothing is
  * allocated -- all buffers are the caller's.  Supported where frost_block_supported and frost_block_dw_reduce_supported hold (14x14 / 7x7 maps, depthwise
  * stride 1, reduce_conv narrower than the expanded tensor); other blocks run layer by layer.
- *   forward : frost_pw(c)_conv_fwd_fin(conv1) -> frost_block_expand_dw_stats -> frost_block_dw_reduce -> frost_pw_ew mode 2 (y3)
+ *   forward : frost_pw_conv_fwd_fin on conv1 -> frost_block_expand_dw_stats -> frost_block_dw_reduce -> frost_pw_ew mode 2 (y3)
  *   backward: reduce_conv [frost_pw_ew 0, 1 -> frost_pw_dgrad_wide -> frost_pw_wgrad]; conv2 [frost_block_dw_bwd_reduce -> frost_block_dw_bwd];
  *             conv1 [reduce pass -> frost_pwc_conv_bwd / frost_pw_conv_bwd pass 1 -> frost_pw_dgrad_wide -> frost_pw_wgrad].  Raw weight-gradient sums land in
  *             `dwq` of each layer (zeroed by the caller; frost_weight_grad_finalize[_table] turns them into dW / dgamma / dbeta as for any layer).
