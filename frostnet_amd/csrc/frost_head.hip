@@ -6,7 +6,7 @@
 // fp32 operands on the f32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation, the VALU fmaf chain's
 // numerics at 16x its rate).  64x64 tile per workgroup, each of the 4 waves a 32x32 quadrant; 16-deep K stages through
 // LDS with the next stage register-prefetched.  TB = int8_t: the fake-quantised classifier weight, dequantised on load.
-template <typename TA, typename TB, int KD>
+template <typename TA, typename TB, int KD, int AM = 0, int BM = 0>      // AM 1: A moves as float4 along K; BM 1 / 2: int8 B moves as 16 bytes along K / along N
 __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t ars, int64_t acs, const TB* __restrict__ b,
                                                int64_t brs, int64_t bcs, int M, int N, int K, const float* alpha_ptr,
                                                float alpha, const float* __restrict__ bias, float* __restrict__ c, int accumulate,
@@ -28,27 +28,87 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
   // staging roles: 1024 elements per operand per stage = 4 per thread; walk the operand along its unit-stride dimension
-  int ar[NQ], ak[NQ], br[NQ], bk[NQ];
+  int ar[AM ? 1 : NQ], ak[AM ? 1 : NQ], br[BM ? 1 : NQ], bk[BM ? 1 : NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int i = tid + q * 256;
-    if (acs == 1) { ak[q] = i % KD; ar[q] = i / KD; } else { ar[q] = i & 63; ak[q] = i >> 6; }
-    if (brs == 1) { bk[q] = i % KD; br[q] = i / KD; } else { br[q] = i & 63; bk[q] = i >> 6; }
+    if constexpr (AM == 0) { if (acs == 1) { ak[q] = i % KD; ar[q] = i / KD; } else { ar[q] = i & 63; ak[q] = i >> 6; } }
+    if constexpr (BM == 0) { if (brs == 1) { bk[q] = i % KD; br[q] = i / KD; } else { br[q] = i & 63; bk[q] = i >> 6; } }
   }
-  float pa[NQ], pb[NQ];
+  // Vector staging (the 64-deep instance; the classifier GEMMs): an operand whose K dimension has unit stride moves as 16-byte pieces along K, an int8 B with
+  // unit stride along N as 16-byte pieces along N -- 4 + 1 loads per thread and stage instead of 32 scalar ones (the forward GEMM was 114 us for 1.3 GFLOP).
+  // Pieces that would cross the end of a row / the K range take the scalar path below.
+  constexpr bool va = (AM == 1), vbk = (BM == 1), vbn = (BM == 2);        // (the host checks strides and alignment, see launch_sgemm)
+  static_assert((AM == 0 && BM == 0) || KD == 64, "vector staging is laid out for the 64-deep stages");
+  float pa[va ? 1 : NQ], pb[(vbk || vbn) ? 1 : NQ];
+  float4 va4[va ? 4 : 1]; uint4 vb16 = make_uint4(0, 0, 0, 0);
   auto fetch = [&](int k0) {
+    if constexpr (va) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + q * 256, row = i >> 4, k4 = (i & 15) * 4;
+        va4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + row < M) {
+          const TA* src = a + (int64_t)(m0 + row) * ars + k0 + k4;
+          if (k0 + k4 + 3 < kend) va4[q] = *(const float4*)src;
+          else { float t[4] = {0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 4; ++e) if (k0 + k4 + e < kend) t[e] = (float)src[e]; va4[q] = make_float4(t[0], t[1], t[2], t[3]); }
+        }
+      }
+    }
+    if constexpr (vbk || vbn) {
+      vb16 = make_uint4(0, 0, 0, 0);
+      if constexpr (vbk) { const int col = tid >> 2, ku = (tid & 3) * 16; if (n0 + col < N && k0 + ku + 15 < kend) vb16 = *(const uint4*)((const int8_t*)b + (int64_t)(n0 + col) * bcs + k0 + ku); }
+      else { const int kk = tid >> 2, nu = (tid & 3) * 16; if (k0 + kk < kend && n0 + nu + 15 < N) vb16 = *(const uint4*)((const int8_t*)b + (int64_t)(k0 + kk) * brs + n0 + nu); }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      pa[q] = (m0 + ar[q] < M && k0 + ak[q] < kend) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
-      pb[q] = (n0 + br[q] < N && k0 + bk[q] < kend) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
-      if (kscale && k0 + bk[q] < kend) pb[q] *= kscale[k0 + bk[q]];
+      if constexpr (!va) pa[q] = (m0 + ar[q] < M && k0 + ak[q] < kend) ? (float)a[(int64_t)(m0 + ar[q]) * ars + (int64_t)(k0 + ak[q]) * acs] : 0.0f;
+      if constexpr (!(vbk || vbn)) {
+        pb[q] = (n0 + br[q] < N && k0 + bk[q] < kend) ? (float)b[(int64_t)(k0 + bk[q]) * brs + (int64_t)(n0 + br[q]) * bcs] : 0.0f;
+        if (kscale && k0 + bk[q] < kend) pb[q] *= kscale[k0 + bk[q]];
+      }
+    }
+  };
+  auto stage = [&](int k0) {
+    if constexpr (va) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int i = tid + q * 256, row = i >> 4, k4 = (i & 15) * 4; as[row][k4] = va4[q].x; as[row][k4 + 1] = va4[q].y; as[row][k4 + 2] = va4[q].z; as[row][k4 + 3] = va4[q].w; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) as[ar[q]][ak[q]] = pa[q];
+    }
+    if constexpr (vbk || vbn) {
+      const uint32_t wv[4] = {vb16.x, vb16.y, vb16.z, vb16.w};
+      if constexpr (vbk) {          // 16 consecutive k of column col; the pieces the vector load skipped (row / K tail) come one by one
+        const int col = tid >> 2, ku = (tid & 3) * 16;
+        const bool whole = n0 + col < N && k0 + ku + 15 < kend;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = (float)(int)(int8_t)(wv[e >> 2] >> (8 * (e & 3)));
+          if (!whole) v = (n0 + col < N && k0 + ku + e < kend) ? (float)((const int8_t*)b)[(int64_t)(n0 + col) * bcs + k0 + ku + e] : 0.0f;
+          if (kscale && k0 + ku + e < kend) v *= kscale[k0 + ku + e];
+          bs[ku + e][col] = v;
+        }
+      } else {            // 16 consecutive n of row kk
+        const int kk = tid >> 2, nu = (tid & 3) * 16;
+        const bool whole = k0 + kk < kend && n0 + nu + 15 < N;
+        const float ksc = (kscale && k0 + kk < kend) ? kscale[k0 + kk] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = (float)(int)(int8_t)(wv[e >> 2] >> (8 * (e & 3)));
+          if (!whole) v = (k0 + kk < kend && n0 + nu + e < N) ? (float)((const int8_t*)b)[(int64_t)(k0 + kk) * brs + n0 + nu + e] : 0.0f;
+          bs[kk][nu + e] = v * ksc;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bs[bk[q]][br[q]] = pb[q];
     }
   };
   fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += KD) {
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { as[ar[q]][ak[q]] = pa[q]; bs[bk[q]][br[q]] = pb[q]; }
+    stage(k0);
     __syncthreads();
     if (k0 + KD < kend) fetch(k0 + KD);
 #pragma unroll
@@ -87,7 +147,17 @@ static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, c
   int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible)
   while (split_ok && ks < 8 && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
   if (ks > 1) (void)hipMemsetAsync(c, 0, (size_t)M * N * sizeof(float), s);
-  if (K / ks >= 256) hipLaunchKernelGGL((k_sgemm<TA, TB, 64>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, ks);
+  if constexpr (sizeof(TA) == 4 && sizeof(TB) == 1) {
+    // the classifier GEMMs: fp32 activations x int8 weights, both with a unit-stride dimension -> 16-byte staging pieces
+    const bool va = acs == 1 && (ars & 3) == 0 && (((uintptr_t)a) & 15) == 0;
+    const bool al_b = (((uintptr_t)b) & 15) == 0;
+    if (K / ks >= 256 && va && al_b && brs == 1 && (bcs & 15) == 0) {
+      hipLaunchKernelGGL((k_sgemm<TA, TB, 64, 1, 1>), grid, dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale); return; }
+    if (K / ks >= 256 && va && al_b && bcs == 1 && (brs & 15) == 0) {
+      hipLaunchKernelGGL((k_sgemm<TA, TB, 64, 1, 2>), grid, dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale); return; }
+  }
+  if (K / ks >= 256) hipLaunchKernelGGL((k_sgemm<TA, TB, 64>), grid, dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
   else hipLaunchKernelGGL((k_sgemm<TA, TB, 16>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
 }
 extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
