@@ -1,14 +1,19 @@
 #!/bin/bash
+# End-of-round job: profiles (rocprofv3 kernel stats + PMC passes), default bench line, per-layer table, side workloads, other batch sizes, full GPU suite, smoke.
+# Every step runs under `timeout` and reads nothing from stdin.
+exec < /dev/null
 mkdir -p gpurun_out
-bash tools/collect_profiles.sh r03 512 > gpurun_out/collect_r03.log 2>&1
-cp gpurun_out/prof_r03/summary.json profiles/r03_kernels_b512.json 2>/dev/null
+timeout 1500 bash tools/collect_profiles.sh r03 512 > gpurun_out/collect_r03.log 2>&1
+[ -f gpurun_out/prof_r03/summary.json ] && cp gpurun_out/prof_r03/summary.json profiles/r03_kernels_b512.json
 timeout 900 python bench.py > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err
 timeout 900 python tests/devtools/layer_times.py 512 > gpurun_out/layer_times_r03_b512.txt 2>&1
-find gpurun_out/prof_r03/stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/r03_kernel_stats.csv \;
-find gpurun_out/prof_r03 -name "*kernel_trace.csv" -size +20M -delete
-find gpurun_out/prof_r03 -name "*counter_collection.csv" -size +20M -delete
+f=$(find gpurun_out/prof_r03/stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_kernel_stats.csv
+find gpurun_out/prof_r03 -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+find gpurun_out/prof_r03 -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
 : > gpurun_out/r03_side_workloads.jsonl
 for wl in infer int8 detect float; do timeout 600 python bench.py --workload $wl 2>/dev/null | tail -1 >> gpurun_out/r03_side_workloads.jsonl; done
-( timeout 3400 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r03.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_r03.log 2>&1
-tail -c 400 gpurun_out/bench_r03.json; tail -4 gpurun_out/gpu_suite_r03.log; tail -1 gpurun_out/smoke_r03.log; tail -1 gpurun_out/layer_times_r03_b512.txt
+: > gpurun_out/r03_other_batches.jsonl
+for b in 64 200 256; do timeout 600 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r03_other_batches.jsonl; done
+( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r03.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_r03.log 2>&1
+tail -c 300 gpurun_out/bench_r03.json; echo; tail -3 gpurun_out/gpu_suite_r03.log; tail -1 gpurun_out/smoke_r03.log; cut -c1-200 gpurun_out/r03_other_batches.jsonl
