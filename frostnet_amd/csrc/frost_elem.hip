@@ -310,12 +310,15 @@ __global__ __launch_bounds__(256) void k_wprep_wsum(const FrostWDesc* descs) {
 extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe,
                                  void* stream) {
   hipStream_t s = as_stream(stream);
-  int gx = grid_for(max_elems, 1024, 64);
+  // grid.x = workgroups per layer: the launch is as long as its largest layers (classifier 1.28 M, last_layer 0.41 M, layer5.0.conv1 0.5 M weights), which at 64 / 32 workgroups
+  // each kept the three big launches at 38 + 53 + 63 us; the small layers' extra workgroups exit at once
+  static const int wcap = getenv("FROST_WPREP_WGS") ? atoi(getenv("FROST_WPREP_WGS")) : 256;
+  int gx = grid_for(max_elems, 1024, wcap);
   if (observe) hipLaunchKernelGGL(k_wprep_minmax, dim3(gx, nlayers), dim3(256), 0, s, descs);
   hipLaunchKernelGGL(k_wprep_observe, dim3((nlayers + 63) / 64), dim3(64), 0, s, descs, nlayers, rule127, observe);
   hipLaunchKernelGGL(k_wprep_scales, dim3(nlayers), dim3(256), 0, s, descs, rule127, observe);
   hipLaunchKernelGGL(k_wprep_pack, dim3(gx, nlayers), dim3(256), 0, s, descs);
-  hipLaunchKernelGGL(k_wprep_wsum, dim3(32, nlayers), dim3(256), 0, s, descs);
+  hipLaunchKernelGGL(k_wprep_wsum, dim3(wcap >= 128 ? 128 : 32, nlayers), dim3(256), 0, s, descs);
   return frost_check_launch("weight_prep");
 }
 
