@@ -114,6 +114,7 @@ _PROTOS = {
     "frost_block_fwd": [P, P],
     "frost_block_bwd": [P, P, P],
     "frost_block_expand_dw_stats": [P, P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P],
+    "frost_block_dw_stats": [P, P, P, P, I, I, I, I, I, P, P, P],
     "frost_block_dw_reduce_supported": [I, I, I, I, I, I],
     "frost_block_dw_bwd_supported": [I, I, I, I, I],
     "frost_block_dw_bwd_reduce": [P, P, P, P, I, I, I, I, I, P, P, I, P, P],

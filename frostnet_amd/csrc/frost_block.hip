@@ -917,6 +917,138 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
   }
 }
 
+// ================================================================================================ kernel S: depthwise forward, statistics pass
+// conv2's exact integer statistics (sum, sum of squares, min, max of the conv output per channel: k_dw3's statistics pass) in the image-resident scheme of the
+// backward kernels: lane = channel, the four values stay in registers across the workgroup's images, one set of atomics per channel and workgroup, finalize folded
+// into the last workgroup.  With frost_pwc_conv_fwd_emit in front it is the two-launch alternative to k_blk_expand_dw (y1 makes one HBM round trip more, both
+// kernels are simpler: no chunk-range re-staging of x, no per-chunk barriers around a GEMM).
+template <int K, int HW, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_stats(const BlkCP p, uint8_t* __restrict__ stats, const FrostFinDesc fin) {
+  using G = BlkGeoC<K, HW, NW>;
+  constexpr int MAP = G::MAP, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  constexpr int XU = (MAP * 8 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+  const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
+  }
+  int wpk[K][2];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) { const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+    wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+  }
+  const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;
+  long long st1 = 0; double st2 = 0.0; int smn = INT32_MAX, smx = INT32_MIN;
+  int upx[XU], uoff[XU];
+#pragma unroll
+  for (int i = 0; i < XU; ++i) {
+    const int u = tid + i * NT, px = u >> 3;
+    const int r = px / HW, cc = px - r * HW;
+    upx[i] = (u < MAP * 8) ? px : -1;
+    uoff[i] = ((r + PAD) * PITCH + cc + PAD) * 64;
+  }
+  const int part = tid & 7;
+  const bool pok = (chunk * 64 + part * 8) < p.c;
+  uint2 xv[XU];
+  auto prefetch = [&](int img) __attribute__((always_inline)) {
+    const int8_t* xs = p.x + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const bool ok = upx[i] >= 0 && pok;
+      xv[i] = ok ? *(const uint2*)(xs + (int64_t)upx[i] * p.c) : make_uint2(0, 0);
+    }
+  };
+  if (img_lo < img_hi) prefetch(img_lo);
+  __syncthreads();
+  for (int img = img_lo; img < img_hi; ++img) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      if (upx[i] >= 0 && pok) *(uint2*)(xpl + uoff[i] + part * 8) = xv[i];
+    }
+    if (img + 1 < img_hi) prefetch(img + 1);
+    blk_barrier();
+    if (w < G::NRG) {
+#pragma unroll 1
+      for (int seg = 0; seg < G::NSEG; ++seg) {
+        int a[2][8];
+        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+        int t1 = 0; double t2 = 0.0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
+              const int vi = a[o][r]; const float v = (float)vi;
+              t1 += vi; t2 = fma((double)v, (double)v, t2); smn = min(smn, vi); smx = max(smx, vi);
+            }
+          }
+        st1 += t1; st2 += t2;
+      }
+    }
+    blk_barrier();
+  }
+  __syncthreads();
+  // the waves' lane-local partials through LDS, one set of global atomics per channel and workgroup; then the folded finalize
+  double* red_d = (double*)smem;                    // [NW][2][64]
+  int* red_i = (int*)(red_d + NW * 2 * 64);         // [NW][2][64]
+  red_d[(w * 2) * 64 + lane] = (double)st1; red_d[(w * 2 + 1) * 64 + lane] = st2; red_i[(w * 2) * 64 + lane] = smn; red_i[(w * 2 + 1) * 64 + lane] = smx;
+  __syncthreads();
+  if (tid < 64) {
+    const int c2 = chunk * 64 + tid;
+    double a1 = 0, a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) { a1 += red_d[(w2 * 2) * 64 + tid]; a2 += red_d[(w2 * 2 + 1) * 64 + tid]; mn = min(mn, red_i[(w2 * 2) * 64 + tid]); mx = max(mx, red_i[(w2 * 2 + 1) * 64 + tid]); }
+    if (c2 < p.c && mn <= mx) {
+      long long* g_s1 = (long long*)stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+      int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+      atomicAdd((unsigned long long*)&g_s1[c2], (unsigned long long)(long long)a1); atomicAdd(&g_s2[c2], (unsigned long long)a2);
+      atomicMin(&g_mn[c2], mn); atomicMax(&g_mx[c2], mx);
+    }
+  }
+  int* sflag = (int*)(smem + NW * 2 * 64 * 12);
+  if (last_block_done2(fin.counter, gridDim.x, sflag)) {
+    float* sh = (float*)smem;
+    conv_finalize_dev(stats, (int64_t)p.n * MAP, p.c, p.cpad, p.qx, fin.qrec_w, fin.wscale, fin.gamma, fin.beta, fin.rmean, fin.rvar, fin.nbt, fin.training, fin.relu, fin.observe, 1,
+                      fin.coef, fin.qrec_y, tid, NT, sh);
+  }
+}
+
+template <int K, int HW, int NW>
+static int launch_blk_s(BlkCP& p, uint8_t* stats, const FrostFinDesc& fin, hipStream_t s) {
+  using G = BlkGeoC<K, HW, NW>;
+  const size_t lds = (size_t)(G::PLANE > NW * 2 * 64 * 12 + 64 ? G::PLANE : NW * 2 * 64 * 12 + 64) + 64;
+  static bool attr_set = false; static int occ = 0;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_blk_dw_stats<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_dw_stats<K, HW, NW>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+  }
+  int groups = (256 * occ) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;       // one round of resident workgroups
+  p.imgs = (p.n + groups - 1) / groups;
+  hipLaunchKernelGGL((k_blk_dw_stats<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p, stats, fin);
+  return frost_check_launch("block_dw_stats");
+}
+
+// conv2's statistics pass + folded finalize on 14x14 / 7x7 maps (the contract of frost_dw_conv_fwd_fin)
+extern "C" int frost_block_dw_stats(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k, void* stats,
+                                    const FrostFinDesc* fin, void* stream) {
+  FROST_REQUIRE((h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && (c % 8) == 0), "block_dw_stats: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1)");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y && stats, "block_dw_stats: incomplete finalize descriptor");
+  BlkCP p = {};
+  p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64;
+  hipStream_t s = as_stream(stream);
+  if (h == 7) return (k == 3) ? launch_blk_s<3, 7, 4>(p, (uint8_t*)stats, *fin, s) : launch_blk_s<5, 7, 4>(p, (uint8_t*)stats, *fin, s);
+  return (k == 3) ? launch_blk_s<3, 14, 8>(p, (uint8_t*)stats, *fin, s) : launch_blk_s<5, 14, 8>(p, (uint8_t*)stats, *fin, s);
+}
+
 template <int K, int HW, int NW>
 static int launch_blk_r(BlkCP& p, hipStream_t s) {
   using G = BlkGeoC<K, HW, NW>;

@@ -31,7 +31,7 @@ _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary 
 # reduce emit + residual-add range pass in one launch (frost_pw_ew_emit_add).  Bit-identical to the two launches it replaces, but NOT faster: measured 24.8-24.9 ms
 # per step with it vs 24.7-24.8 without (profiles/r03_block_fusion_ab.txt) -- the element-wise kernels' time is their single-workgroup observer tail, which
 # the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
-_BLOCK_PAIR = os.environ.get("FROST_BLOCK_PAIR", "1") != "0"      # conv1 emit + conv2 statistics in one launch at the 14x14 / 7x7 stages (csrc/frost_block.hip)
+_BLOCK_PAIR = int(os.environ.get("FROST_BLOCK_PAIR", "3"))         # conv1 emit + conv2 statistics at the 14x14 / 7x7 stages: 1 = one launch (k_blk_expand_dw), 2 = chunked emit + image-resident statistics, 3 = whichever measured faster per shape (2 for 5x5 on 14x14: 103 vs 120 us), 0 = layer kernels
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
@@ -369,9 +369,14 @@ class Engine:
              stream(), prof=("pw_fwd_stats", x.numel + l1.wq_pack.numel()))
         fin2 = L.FrostFinDesc(l2.qw.data_ptr(), l2.gamma.data_ptr(), l2.beta.data_ptr(), l2.rmean.data_ptr(), l2.rvar.data_ptr(), l2.nbt.data_ptr(),
                               l2.coef.data_ptr(), l2.qy.data_ptr(), l2.fin_counter.data_ptr(), 1, int(l2.relu), 1, 0, l2.wscale.data_ptr(), None, None)
-        call("frost_block_expand_dw_stats", ptr(x.buf), ptr(x.q), ptr(l1.wq_pack), ptr(l1.wsum), ptr(l1.coef), ptr(l1.qy), ptr(y1.buf), x.n, x.h, x.w, x.c,
-             l1.cout, ptr(l2.wq_pack), ptr(l2.wsum), l2.k, ptr(l2.stats), C.byref(fin2), stream(),
-             prof=("blk_expand_dw", x.numel + l1.wq_pack.numel() + y1.numel))
+        if _BLOCK_PAIR == 2 or (_BLOCK_PAIR == 3 and x.h == 14 and l2.k == 5):
+            self._conv_launch(l1, x, 1, y1)
+            call("frost_block_dw_stats", ptr(y1.buf), ptr(y1.q), ptr(l2.wq_pack), ptr(l2.wsum), x.n, x.h, x.w, l2.cout, l2.k, ptr(l2.stats), C.byref(fin2), stream(),
+                 prof=("blk_dw_stats", y1.numel))
+        else:
+            call("frost_block_expand_dw_stats", ptr(x.buf), ptr(x.q), ptr(l1.wq_pack), ptr(l1.wsum), ptr(l1.coef), ptr(l1.qy), ptr(y1.buf), x.n, x.h, x.w, x.c,
+                 l1.cout, ptr(l2.wq_pack), ptr(l2.wsum), l2.k, ptr(l2.stats), C.byref(fin2), stream(),
+                 prof=("blk_expand_dw", x.numel + l1.wq_pack.numel() + y1.numel))
         y2 = self.new_act(x.n, x.h, x.w, l2.cout, l2.qy)
         if self.reduce_fusable(l2, l3, y1):
             # the block's third boundary: y2 goes from the depthwise stencil through LDS into reduce_conv's K-split GEMM; Engine.conv(l3, y2, kept=...) emits

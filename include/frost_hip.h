@@ -382,6 +382,10 @@ int frost_pwc_conv_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pa
  * and leaves for HBM once (y1: conv2's emit pass and the backward read it).  conv1 must be finalized (coef1 / qrec_y1 final); results are
  * bit-identical to the two separate launches. */
 int frost_block_supported(int h, int w, int k, int stride, int cin, int c);
+/* conv2's statistics pass + folded finalize alone, image-resident (the contract of frost_dw_conv_fwd_fin on 14x14 / 7x7 maps, stride 1): with frost_pwc_conv_fwd_emit in
+ * front of it the two-launch alternative to frost_block_expand_dw_stats */
+int frost_block_dw_stats(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k, void* stats,
+                         const FrostFinDesc* fin, void* stream);
 int frost_block_expand_dw_stats(const int8_t* x, const float* qrec_x, const int8_t* w1_pack, const int32_t* wsum1, const float* coef1,
                                 const float* qrec_y1, int8_t* y1, int n, int h, int w, int cin, int c, const int8_t* wq2, const int32_t* wsum2,
                                 int k, void* stats2, const FrostFinDesc* fin2, void* stream);
