@@ -551,7 +551,7 @@ extern "C" int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, con
 struct BlkCP {
   const int8_t* x; const float* qx;                 // conv2's input (y1) and its record
   const int8_t* wq; const int32_t* wsum; const float* qw; const float* wscale;   // taps [k*k][cpad], weight sums, weight record, per-channel scales (or NULL)
-  const float* coef; const float* qy;               // coefficient rows after the reduce pass (S1 / S2 filled), output record
+  float* coef; const float* qy;                     // coefficient rows (the reduce pass accumulates S1 / S2 into them; the dc pass reads them), output record
   const uint16_t* gout; uint16_t* dx; float* dwq;   // gradient w.r.t. conv2's output (bf16), w.r.t. its input (bf16, or NULL), raw weight-gradient sums [c][k*k]
   int n, c, cpad, nchunk, imgs, rounds, relu, sr; float inv_count;
 };
@@ -791,7 +791,7 @@ extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const in
   FROST_REQUIRE(frost_block_dw_bwd_supported(h, w, k, 1, c), "block_dw_bwd: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1)");
   FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout && dwq, "block_dw_bwd: incomplete arguments");
   BlkCP p = {};
-  p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.qw = qrec_w; p.wscale = wscale; p.coef = coef; p.qy = qrec_y; p.gout = gout; p.dx = dx; p.dwq = dwq;
+  p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.qw = qrec_w; p.wscale = wscale; p.coef = (float*)coef /* read-only in this pass */; p.qy = qrec_y; p.gout = gout; p.dx = dx; p.dwq = dwq;
   p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu; p.sr = frost_sr_enabled();
   p.inv_count = 1.0f / (float)((int64_t)n * h * w);
   static const int imgs_env = getenv("FROST_BLK_IMGS_C") ? atoi(getenv("FROST_BLK_IMGS_C")) : 0;
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
     float sum = 0.0f;
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * 2 + which) * 64 + l2];
-    if (c2 < p.c) atomicAdd((float*)p.coef + (which ? FROST_COEF_S2 : FROST_COEF_S1) * p.cpad + c2, sum);
+    if (c2 < p.c) atomicAdd(p.coef + (which ? FROST_COEF_S2 : FROST_COEF_S1) * p.cpad + c2, sum);
   }
 }
 
