@@ -92,9 +92,33 @@ __global__ __launch_bounds__(256) void k_quantize_input(const float* __restrict_
     }
   }
 }
+// channels_last RGB input (the reference's loaders after .to(memory_format=channels_last); bench.py): the tensor is one dense [pixel][3] fp32 array -- four pixels =
+// three 16-byte loads and one 16-byte store per thread (the generic kernel: three 4-byte loads, one 4-byte store and 64-bit divisions per pixel)
+__global__ __launch_bounds__(256) void k_quantize_input_nhwc3(const float* __restrict__ x, int64_t npix4, const float* __restrict__ qrec, int8_t* __restrict__ out) {
+  const QP q = load_qp(qrec);
+  const uint32_t padb = (uint32_t)((q.zp - 128) & 255) << 24;
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < npix4; i += (int64_t)gridDim.x * 256) {
+    const float4 a = ((const float4*)x)[3 * i], b = ((const float4*)x)[3 * i + 1], c = ((const float4*)x)[3 * i + 2];
+    const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int pxl = 0; pxl < 4; ++pxl) {
+      uint32_t packed = padb;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) packed |= ((uint32_t)((fq_index(v[3 * pxl + ch], q.inv, q.zp, 0, q.hi) - 128) & 255)) << (8 * ch);
+      o[pxl] = packed;
+    }
+    ((uint4*)out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
 extern "C" int frost_quantize_input(const float* x, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
                                     int64_t sw, const float* qrec, int8_t* out, int cpad, void* stream) {
   FROST_REQUIRE(cpad % 4 == 0 && cpad >= c, "quantize_input: cpad must be a multiple of 4 and >= c");
+  const int64_t npix = (int64_t)n * h * w;
+  if (c == 3 && cpad == 4 && sc == 1 && sw == 3 && sh == (int64_t)w * 3 && sn == (int64_t)h * w * 3 && (npix & 3) == 0 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(k_quantize_input_nhwc3, dim3(grid_for(npix / 4, 256, 8192)), dim3(256), 0, as_stream(stream), x, npix / 4, qrec, out);
+    return frost_check_launch("quantize_input");
+  }
   hipLaunchKernelGGL(k_quantize_input, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0, as_stream(stream), x, n,
                      c, h, w, sn, sc, sh, sw, qrec, out, cpad);
   return frost_check_launch("quantize_input");

@@ -441,3 +441,18 @@ def test_flag_summary_is_host_side_and_follows_apply():
         m(x)
     m.apply(torch.quantization.enable_fake_quant)
     m(x)
+
+
+def test_input_quantisation_channels_last_fast_path_equals_generic():
+    """QuantStub on a channels_last RGB batch takes the vectorised kernel (four pixels per thread); an NCHW-contiguous copy of the same values takes the generic
+    strided kernel: identical bytes, including the zero-point pad channel."""
+    from frostnet_amd import engine as EN
+    torch.manual_seed(3)
+    E, qa = EN.Engine("cuda"), EN.QArena(4, "cuda")
+    q = qa.alloc()
+    qa.set_qparams(q, 0.0187, 117)
+    x = torch.randn(6, 3, 32, 20, device="cuda") * 2.0
+    a = E.quantize_input(x.contiguous(), q, observe=False)
+    b = E.quantize_input(x.contiguous(memory_format=torch.channels_last), q, observe=False)
+    torch.cuda.synchronize()
+    assert a.c == 4 and torch.equal(a.buf[: a.numel], b.buf[: b.numel])
