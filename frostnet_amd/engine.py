@@ -337,7 +337,7 @@ class Engine:
                 self._conv_launch(l, x, 0, None)
             call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
                  ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
-                 1 if observe else 0, ptr(l.coef), ptr(l.qy), ptr(l.wscale), stream())
+                 1 if observe else 0, ptr(l.coef), ptr(l.qy), ptr(l.wscale), stream(), prof=("conv_finalize", 48 * l.cout))
         self._conv_launch(l, x, 1, y)
         if need_stats and _FIN_FOLD and cat is not None and cat_fold:
             y.cat_observed = True
