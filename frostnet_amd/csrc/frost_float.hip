@@ -460,6 +460,23 @@ extern "C" int frost_float_pw_f32(const FrostFDesc* desc, const float* x, const 
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise passes (fp32 FMA)
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <typename ET> struct FdwRaw;          // two adjacent channels as loaded (conversion deferred to the arithmetic phase)
+template <> struct FdwRaw<uint16_t> {
+  using T = uint32_t;
+  static __device__ __forceinline__ T ld(const uint16_t* p) { return *(const uint32_t*)p; }
+  static __device__ __forceinline__ v2f cv(T v) { return (v2f){__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)}; }
+};
+template <> struct FdwRaw<float> {
+  using T = v2f;
+  static __device__ __forceinline__ T ld(const float* p) { return *(const v2f*)p; }
+  static __device__ __forceinline__ v2f cv(T v) { return v; }
+};
+__device__ __forceinline__ v2f fdw_ld2(const uint16_t* p) { const uint32_t v = *(const uint32_t*)p; return (v2f){__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)}; }
+__device__ __forceinline__ v2f fdw_ld2(const float* p) { return *(const v2f*)p; }
+template <typename ET> struct FdwOut;
+template <> struct FdwOut<uint16_t> { static __device__ __forceinline__ void st(uint16_t* p, v2f v) { *(uint32_t*)p = cvt_pk_bf16(v[0], v[1]); } };
+template <> struct FdwOut<float> { static __device__ __forceinline__ void st(float* p, v2f v) { *(v2f*)p = v; } };
 // one thread = 8 channels (fixed for the thread's whole life, so statistics stay in registers) x a strided set of output-pixel PAIRS
 // (two horizontally adjacent outputs share the S + K input columns of a kernel row and every tap's weights: 1.5-1.7x fewer loads)
 #define FDW_WO 2
@@ -588,6 +605,127 @@ static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const
   switch (mode) { case F_STATS: FDW_LAUNCH(F_STATS); break; case F_EMIT: FDW_LAUNCH(F_EMIT); break; case F_BRED: FDW_LAUNCH(F_BRED); break; default: FDW_LAUNCH(F_BDC); }
 #undef FDW_LAUNCH
 }
+// Row-walking form of the forward passes (F_STATS: conv output + statistics, F_EMIT: y = [relu](c*scale + bias)) -- the default: a wave owns 2 * GW channels of
+// 64 / GW output rows and walks along them with the k x k input window and its channels' weights in registers (see k_f_dw_wgrad_row for the rotation of the
+// window slots); per output pixel S*k loads of 4 bytes, k*k packed FMAs in the same (ky, kx) order as k_f_dw -- the conv output is bit-identical --, one store.
+template <int MODE, int K, int S, int GW, typename ET>
+__global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu,
+                                                  ET* __restrict__ y) {
+  constexpr int PAD = (K - 1) / 2, RPW = 64 / GW;
+  using SA = typename std::conditional<sizeof(ET) == 4, double, float>::type;     // fp32 mode: statistics partials in double
+  __shared__ SA sred[2][2 * GW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cl = (lane % GW) * 2, rsub = lane / GW;
+  const int ch = blockIdx.y * (2 * GW) + cl; const bool live = ch < c;
+  if (MODE == F_STATS) { for (int i = tid; i < 4 * GW; i += 256) (&sred[0][0])[i] = (SA)0; __syncthreads(); }
+  SA s0 = 0, s1 = 0, q0 = 0, q1 = 0;
+  if (live) {
+    const float* wf = (const float*)dp->pack;
+    v2f wt[K][K];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) wt[ky][kx] = *(const v2f*)(wf + (ky * K + kx) * cpad + ch);
+    v2f sc = (v2f){1.0f, 1.0f}, bi = (v2f){0.0f, 0.0f};
+    if (MODE == F_EMIT) { sc = *(const v2f*)(dp->coef + FC_SCALE * cpad + ch); bi = *(const v2f*)(dp->coef + FC_BIAS * cpad + ch); }
+    const float lo = relu ? 0.0f : -INFINITY;
+    const int rows = n * ho;
+    for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
+      const int in = r / ho, oy = r - in * ho;
+      const ET* xr[K]; bool rv[K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - PAD + ky; rv[ky] = (unsigned)iy < (unsigned)h;
+        xr[ky] = x + ((int64_t)(in * h + (rv[ky] ? iy : 0)) * w) * c + ch;
+      }
+      ET* orow = y ? y + (int64_t)r * wo * c + ch : nullptr;
+      v2f win[K][K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) win[ky][kx] = (v2f){0.0f, 0.0f};
+#pragma unroll
+      for (int kx = 0; kx < K - S; ++kx) {
+        const int ix = kx - PAD;
+        const bool cv = (unsigned)ix < (unsigned)w; const int64_t off = (int64_t)(cv ? ix : 0) * c;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) { const v2f v = fdw_ld2(xr[ky] + off); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
+      }
+      for (int ox0 = 0; ox0 < wo; ox0 += K) {
+        typename FdwRaw<ET>::T raw[K][S][K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int ox = ox0 + u;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const int ix = ox * S - PAD + (K - S + j);
+            const int64_t off = (int64_t)(((unsigned)ix < (unsigned)w) ? ix : 0) * c;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) raw[u][j][ky] = FdwRaw<ET>::ld(xr[ky] + off);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int ox = ox0 + u;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const int kx = K - S + j, ix = ox * S - PAD + kx, slot = (u * S + kx) % K;
+            const bool cv = (unsigned)ix < (unsigned)w;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? FdwRaw<ET>::cv(raw[u][j][ky]) : (v2f){0.0f, 0.0f};
+          }
+          v2f acc = (v2f){0.0f, 0.0f};
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc = __builtin_elementwise_fma(win[ky][(u * S + kx) % K], wt[ky][kx], acc);
+          if (ox < wo) {
+            if (MODE == F_STATS) {
+              s0 += (SA)acc[0]; s1 += (SA)acc[1]; q0 += (SA)acc[0] * (SA)acc[0]; q1 += (SA)acc[1] * (SA)acc[1];
+              if (orow) FdwOut<ET>::st(orow + (int64_t)ox * c, acc);
+            } else {
+              const v2f o = (v2f){fmaxf(fmaf(acc[0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[1], sc[1], bi[1]), lo)};
+              FdwOut<ET>::st(orow + (int64_t)ox * c, o);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (MODE == F_STATS) {
+    if (live) { atomicAdd(&sred[0][cl], s0); atomicAdd(&sred[0][cl + 1], s1); atomicAdd(&sred[1][cl], q0); atomicAdd(&sred[1][cl + 1], q1); }
+    __syncthreads();
+    double* st = dp->stat + (size_t)((blockIdx.x + blockIdx.y) & (FST_SLOTS - 1)) * 4 * cpad;
+    for (int i = tid; i < 4 * GW; i += 256) {
+      const int which = i / (2 * GW), cc = blockIdx.y * (2 * GW) + i % (2 * GW);
+      const SA v = sred[which][i % (2 * GW)];
+      if (cc < c && v != (SA)0) atomicAdd(st + which * cpad + cc, (double)v);
+    }
+  }
+}
+template <int MODE, int K, int S, int GW, typename ET>
+static void launch_f_dw_row2(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s) {
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("FROST_FDW_ROW_WGS"); wgs = e ? atoi(e) : (K == 3 ? 2048 : 1024); }
+  constexpr int RPW = 64 / GW;
+  const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
+  int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
+  hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out);
+}
+template <int MODE, int K, int S, typename ET>
+static void launch_f_dw_row(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s) {
+  if (c > 64) launch_f_dw_row2<MODE, K, S, 64, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+  else if (c > 32) launch_f_dw_row2<MODE, K, S, 32, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+  else launch_f_dw_row2<MODE, K, S, 16, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+}
+template <int MODE, typename ET>
+static void launch_f_dw_row_ks(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int k, int stride, int ho, int wo, int relu, ET* out, hipStream_t s) {
+  if (k == 3 && stride == 1) launch_f_dw_row<MODE, 3, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+  else if (k == 3) launch_f_dw_row<MODE, 3, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+  else if (stride == 1) launch_f_dw_row<MODE, 5, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+  else launch_f_dw_row<MODE, 5, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+}
 template <typename ET>
 static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int k, int stride, int relu, int mode, const ET* gy, ET* out, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0, "float_dw: channels must be a multiple of 8");
@@ -595,6 +733,13 @@ static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w
   FROST_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "float_dw: 3x3 / 5x5, stride 1 / 2");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
+  static int row_form = -1;
+  if (row_form < 0) { const char* e = getenv("FROST_FDW_ROW"); row_form = e ? atoi(e) : 1; }
+  if (row_form && (mode == F_STATS || mode == F_EMIT)) {
+    if (mode == F_STATS) launch_f_dw_row_ks<F_STATS, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s);
+    else launch_f_dw_row_ks<F_EMIT, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s);
+    return frost_check_launch("float_dw");
+  }
   const int64_t tot = (int64_t)n * ho * ((wo + FDW_WO - 1) / FDW_WO) * c8n;
   const bool red = (mode == F_STATS || mode == F_BRED);
   int64_t grid = (tot + 255) / 256; const int64_t cap = red ? f_red_cap() : 8192; if (grid > cap) grid = cap;
@@ -753,10 +898,112 @@ __global__ __launch_bounds__(256) void k_f_dw_dgrad(const FrostFDesc* dp, const 
     FEl<ET>::st8(dx + (((int64_t)in * h + iy) * w + ix) * c + ch, acc);
   }
 }
+// Row-walking form (the default for k = 3 / 5, stride 1 / 2), the data-gradient sibling of k_f_dw_wgrad_row: a wave owns 2 * GW channels of 64 / GW input rows and
+// walks along them with a k x k window of dc in registers and the (flipped) weights of its channels in registers -- per input pixel k new loads, k*k packed
+// FMAs, one store.  Stride 2 runs the same walk over the zero-inserted gradient (dcu[2 oy][2 ox] = dc[oy][ox]): odd columns load nothing (the walk is unrolled
+// 2k times so that the column parity is a compile-time constant), odd rows contribute zeros.
+template <int K, int S, int GW, typename ET>
+__global__ __launch_bounds__(256) void k_f_dw_dgrad_row(const FrostFDesc* dp, const ET* __restrict__ dc, int n, int h, int w, int c, int cpad, int ho, int wo,
+                                                        ET* __restrict__ dx) {
+  constexpr int PAD = (K - 1) / 2, RPW = 64 / GW, UNR = (S == 2) ? 2 * K : K;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cl = (lane % GW) * 2, rsub = lane / GW;
+  const int ch = blockIdx.y * (2 * GW) + cl;
+  if (ch >= c) return;
+  const float* wf = (const float*)dp->pack;
+  v2f wt[K][K];                                   // wt[a][b] = w[K-1-a][K-1-b]: out[iy][ix] = sum_ab dcu[iy - PAD + a][ix - PAD + b] * wt[a][b]
+#pragma unroll
+  for (int a = 0; a < K; ++a)
+#pragma unroll
+    for (int b = 0; b < K; ++b) wt[a][b] = *(const v2f*)(wf + ((K - 1 - a) * K + (K - 1 - b)) * cpad + ch);
+  const int rows = n * h;
+  for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
+    const int in = r / h, iy = r - in * h;
+    const ET* dr[K]; bool rv[K];
+#pragma unroll
+    for (int a = 0; a < K; ++a) {
+      const int ty = iy - PAD + a;                  // row of the (zero-inserted) gradient
+      const int oy = (S == 2) ? (ty >> 1) : ty;
+      rv[a] = ty >= 0 && oy < ho && (S == 1 || (ty & 1) == 0);
+      dr[a] = dc + ((int64_t)(in * ho + (rv[a] ? oy : 0)) * wo) * c + ch;
+    }
+    ET* orow = dx + (int64_t)r * w * c + ch;
+    v2f win[K][K];
+#pragma unroll
+    for (int a = 0; a < K; ++a)
+#pragma unroll
+      for (int b = 0; b < K; ++b) win[a][b] = (v2f){0.0f, 0.0f};
+#pragma unroll
+    for (int b = PAD; b < K - 1; ++b) {             // columns tx = 0 .. PAD - 1 of the first pixel's window (tx < 0: zeros)
+      const int tx = b - PAD;
+      if (S == 2 && (tx & 1)) continue;
+      const int ox = (S == 2) ? (tx >> 1) : tx;
+      const bool cv = ox < wo; const int64_t off = (int64_t)(cv ? ox : 0) * c;
+#pragma unroll
+      for (int a = 0; a < K; ++a) { const v2f v = fdw_ld2(dr[a] + off); win[a][b] = (cv && rv[a]) ? v : (v2f){0.0f, 0.0f}; }
+    }
+    for (int ix0 = 0; ix0 < w; ix0 += UNR) {
+      typename FdwRaw<ET>::T raw[UNR][K];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int tx = ix0 + u + PAD;                // the window column that enters at pixel ix0 + u (parity known at compile time: ix0 is even for S = 2)
+        if (S == 2 && ((u + PAD) & 1)) continue;
+        const int ox = (S == 2) ? (tx >> 1) : tx;
+        const int64_t off = (int64_t)((ox < wo) ? ox : 0) * c;
+#pragma unroll
+        for (int a = 0; a < K; ++a) raw[u][a] = FdwRaw<ET>::ld(dr[a] + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int ix = ix0 + u, tx = ix + PAD, slot = (u + K - 1) % K;
+        if (S == 2 && ((u + PAD) & 1)) {
+#pragma unroll
+          for (int a = 0; a < K; ++a) win[a][slot] = (v2f){0.0f, 0.0f};
+        } else {
+          const int ox = (S == 2) ? (tx >> 1) : tx;
+          const bool cv = ox < wo;
+#pragma unroll
+          for (int a = 0; a < K; ++a) win[a][slot] = (cv && rv[a]) ? FdwRaw<ET>::cv(raw[u][a]) : (v2f){0.0f, 0.0f};
+        }
+        v2f acc = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < K; ++a)
+#pragma unroll
+          for (int b = 0; b < K; ++b) acc = __builtin_elementwise_fma(win[a][(u + b) % K], wt[a][b], acc);
+        if (ix < w) FdwOut<ET>::st(orow + (int64_t)ix * c, acc);
+      }
+    }
+  }
+}
+template <int K, int S, int GW, typename ET>
+static void launch_f_dw_dgrad_row2(const FrostFDesc* desc, const ET* dc, int n, int h, int w, int c, int ho, int wo, ET* dx, hipStream_t s) {
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("FROST_FDW_DGRAD_WGS"); wgs = e ? atoi(e) : 4096; }
+  constexpr int RPW = 64 / GW;
+  const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * h;
+  int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
+  hipLaunchKernelGGL((k_f_dw_dgrad_row<K, S, GW, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, dc, n, h, w, c, round_up(c, 16), ho, wo, dx);
+}
+template <int K, int S, typename ET>
+static void launch_f_dw_dgrad_row(const FrostFDesc* desc, const ET* dc, int n, int h, int w, int c, int ho, int wo, ET* dx, hipStream_t s) {
+  if (c > 64) launch_f_dw_dgrad_row2<K, S, 64, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+  else if (c > 32) launch_f_dw_dgrad_row2<K, S, 32, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+  else launch_f_dw_dgrad_row2<K, S, 16, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+}
 template <typename ET>
 static int float_dw_dgrad_any(const FrostFDesc* desc, const ET* dc, int n, int h, int w, int c, int k, int stride, ET* dx, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0, "float_dw_dgrad: channels must be a multiple of 8");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+  static int row_form = -1;
+  if (row_form < 0) { const char* e = getenv("FROST_FDW_DGRAD_ROW"); row_form = e ? atoi(e) : 1; }
+  if (row_form && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    if (k == 3 && stride == 1) launch_f_dw_dgrad_row<3, 1, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+    else if (k == 3) launch_f_dw_dgrad_row<3, 2, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+    else if (stride == 1) launch_f_dw_dgrad_row<5, 1, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+    else launch_f_dw_dgrad_row<5, 2, ET>(desc, dc, n, h, w, c, ho, wo, dx, s);
+    return frost_check_launch("float_dw_dgrad");
+  }
   const int64_t tot = (int64_t)n * h * w * (c >> 3); int64_t grid = (tot + 255) / 256; if (grid > 16384) grid = 16384;
   grid = (grid + 7) & ~(int64_t)7;
   hipLaunchKernelGGL(k_f_dw_dgrad<ET>, dim3((unsigned)grid), dim3(256), 0, s, desc, dc, n, h, w, c, round_up(c, 16), k, stride, ho, wo, dx);
@@ -822,10 +1069,126 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const ET* __restrict__ dc, c
     if (cc < c) atomicAdd(dw + (int64_t)cc * k * k + ky * k + kx, red[cl * 5 + kx]);
   }
 }
+// Row-walking form (the default for k = 3 / 5): a wave owns 128 channels (lane = 2 adjacent channels: one 256-byte segment per pixel and wave) and walks
+// along output rows with the k x k input window in registers -- per output pixel it loads the S new window columns (k loads of 4 bytes) and one dc value and
+// runs k*k packed FMAs, so dc and x are read ONCE (the form above reads both once per kernel row, in 64-byte segments).  The window's column slots rotate
+// with the output column ((ox*S + kx) mod k; the ox loop is unrolled k times so that every slot index is a compile-time constant: no register moves).
+template <int K, int S, int GW, typename ET>
+__global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ dc, const ET* __restrict__ x, int n, int h, int w, int c, int ho, int wo,
+                                                        float* __restrict__ dw) {
+  // GW lanes (2 * GW channels) per output row, 64 / GW rows per wave: narrow layers (the biggest maps) keep every lane busy
+  constexpr int PAD = (K - 1) / 2, KK = K * K, RPW = 64 / GW;
+  __shared__ float red[2 * GW * KK];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cl = (lane % GW) * 2, rsub = lane / GW;
+  const int ch = blockIdx.y * (2 * GW) + cl; const bool live = ch < c;
+  v2f acc[K][K];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) acc[ky][kx] = (v2f){0.0f, 0.0f};
+  const int rows = n * ho;
+  if (live) {
+    for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
+      const int in = r / ho, oy = r - in * ho;
+      const ET* xr[K]; bool rv[K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - PAD + ky; rv[ky] = (unsigned)iy < (unsigned)h;
+        xr[ky] = x + ((int64_t)(in * h + (rv[ky] ? iy : 0)) * w) * c + ch;
+      }
+      const ET* dr = dc + (int64_t)r * wo * c + ch;
+      v2f win[K][K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) win[ky][kx] = (v2f){0.0f, 0.0f};
+#pragma unroll
+      for (int kx = 0; kx < K - S; ++kx) {              // the columns of pixel 0 that no later step loads
+        const int ix = kx - PAD;                        // (every load unconditional from a clamped address, zeroed afterwards: a conditional load ends in a wait at its join)
+        const bool cv = (unsigned)ix < (unsigned)w; const int64_t off = (int64_t)(cv ? ix : 0) * c;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) { const v2f v = fdw_ld2(xr[ky] + off); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
+      }
+      for (int ox0 = 0; ox0 < wo; ox0 += K) {
+        // phase 1: every load of the next K output pixels (no branch on ox: past the row end dc counts as zero), phase 2: the arithmetic
+        typename FdwRaw<ET>::T raw[K][S][K], graw[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int ox = ox0 + u;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const int ix = ox * S - PAD + (K - S + j);
+            const int64_t off = (int64_t)(((unsigned)ix < (unsigned)w) ? ix : 0) * c;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) raw[u][j][ky] = FdwRaw<ET>::ld(xr[ky] + off);
+          }
+          graw[u] = FdwRaw<ET>::ld(dr + (int64_t)(ox < wo ? ox : wo - 1) * c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const int ox = ox0 + u;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const int kx = K - S + j, ix = ox * S - PAD + kx, slot = (u * S + kx) % K;
+            const bool cv = (unsigned)ix < (unsigned)w;
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? FdwRaw<ET>::cv(raw[u][j][ky]) : (v2f){0.0f, 0.0f};
+          }
+          const v2f g = (ox < wo) ? FdwRaw<ET>::cv(graw[u]) : (v2f){0.0f, 0.0f};
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[ky][kx] = __builtin_elementwise_fma(g, win[ky][(u * S + kx) % K], acc[ky][kx]);
+        }
+      }
+    }
+  }
+  for (int i = tid; i < 2 * GW * KK; i += 256) red[i] = 0.0f;
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) { atomicAdd(&red[cl * KK + ky * K + kx], acc[ky][kx][0]); atomicAdd(&red[(cl + 1) * KK + ky * K + kx], acc[ky][kx][1]); }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * GW * KK; i += 256) {
+    const int cc = blockIdx.y * (2 * GW) + i / KK;
+    if (cc < c && red[i] != 0.0f) atomicAdd(dw + (int64_t)cc * KK + (i % KK), red[i]);
+  }
+}
+template <int K, int S, int GW, typename ET>
+static void launch_f_dw_wgrad_row2(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s) {
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("FROST_FDW_WGRAD_WGS"); wgs = e ? atoi(e) : (K == 3 ? 2048 : 1024); }
+  constexpr int RPW = 64 / GW;
+  const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
+  int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
+  hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw);
+}
+template <int K, int S, typename ET>
+static void launch_f_dw_wgrad_row(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s) {
+  // lanes per row: 64 (256-byte segments) unless the layer is so narrow that most of them would idle -- measured: 96 channels on 64 lanes (25 % idle) beat
+  // three 16-lane groups of 64-byte segments (547 vs 717 us, layer1.1), 32 channels on 16 lanes beat 64 (202 vs 462 us, layer1.0)
+  if (c > 64) launch_f_dw_wgrad_row2<K, S, 64, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+  else if (c > 32) launch_f_dw_wgrad_row2<K, S, 32, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+  else launch_f_dw_wgrad_row2<K, S, 16, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+}
 template <typename ET>
 static int float_dw_wgrad_any(const ET* dc, const ET* x, int n, int h, int w, int c, int k, int stride, float* dw, hipStream_t s) {
   FROST_REQUIRE(c % 8 == 0 && k <= 5, "float_dw_wgrad: channels must be a multiple of 8, k <= 5");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
+  static int row_form = -1;
+  if (row_form < 0) { const char* e = getenv("FROST_FDW_WGRAD_ROW"); row_form = e ? atoi(e) : 1; }
+  if (row_form && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    if (k == 3 && stride == 1) launch_f_dw_wgrad_row<3, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+    else if (k == 3) launch_f_dw_wgrad_row<3, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+    else if (stride == 1) launch_f_dw_wgrad_row<5, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+    else launch_f_dw_wgrad_row<5, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+    return frost_check_launch("float_dw_wgrad");
+  }
   const int64_t npix = (int64_t)n * ho * wo;
   const int units = ((c + 31) / 32) * k;
   int64_t gx = (npix + 63) / 64; int64_t cap = 4096 / units; if (cap < 1) cap = 1; if (gx > cap) gx = cap;

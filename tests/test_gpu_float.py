@@ -392,3 +392,68 @@ def test_fp32_mode_train_step_end_to_end(F, name, res, batch):
     assert _rel(e, e_ref) <= 3e-5, _rel(e, e_ref)
     model.float_precision = "bf16"                 # switching the precision rebinds
     assert model.hip_runner().precision == "bf16"
+
+
+@pytest.mark.parametrize("case", [(3, 1, 14, 96, 5), (3, 2, 28, 144, 3), (5, 1, 7, 1440, 4), (5, 2, 14, 672, 3), (5, 1, 14, 360, 2), (3, 1, 9, 40, 2), (5, 2, 11, 200, 2)],
+                         ids=lambda c: "k%d_s%d_h%d_c%d_n%d" % c)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_float_dw_wgrad_row_form_vs_fp64(case, prec):
+    """frost_float_dw_wgrad(_f32) -- the row-walking kernel (window in registers, dc and x read once) -- against an fp64 conv2d weight gradient of the SAME
+    (bf16-rounded, for the bf16 mode) operands: odd sizes, channel counts that leave a partial 128-channel group, both strides and kernel sizes.
+    Products are exact in fp32; what is left is the summation order (fp32 partials + float atomics): <= 2e-5 of the gradient norm."""
+    from frostnet_amd import _lib as L
+    k, s, h, c, n = case
+    g = torch.Generator().manual_seed(1000 * k + 100 * s + h + c)
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    x = torch.randn(n, c, h, h, generator=g)
+    dc = torch.randn(n, c, ho, ho, generator=g) * 0.1
+    if prec == "bf16":
+        x, dc = x.bfloat16().float(), dc.bfloat16().float()
+    xw = x.double().requires_grad_(False)
+    wt = torch.zeros(c, 1, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xw, wt, stride=s, padding=pad, groups=c).backward(dc.double())
+    ref = wt.grad.reshape(c, k * k)
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    dd = dc.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    dw = torch.zeros(c, k * k, device="cuda")
+    L.call("frost_float_dw_wgrad" + ("" if prec == "bf16" else "_f32"), L.ptr(dd), L.ptr(xd), n, h, h, c, k, s, L.ptr(dw), L.stream())
+    torch.cuda.synchronize()
+    assert _rel(dw.cpu(), ref) <= 2e-5, _rel(dw.cpu(), ref)
+
+
+@pytest.mark.parametrize("case", [(3, 1, 14, 96, 5), (3, 2, 28, 144, 3), (5, 1, 7, 1440, 4), (5, 2, 14, 672, 3), (5, 1, 14, 360, 2), (3, 1, 9, 40, 2), (5, 2, 11, 200, 2),
+                                  (3, 2, 13, 32, 3), (5, 1, 5, 24, 3)], ids=lambda c: "k%d_s%d_h%d_c%d_n%d" % c)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_float_dw_dgrad_row_form_vs_fp64(case, prec):
+    """frost_float_dw_dgrad(_f32) -- the row-walking kernel (window of dc and the flipped weights in registers; stride 2 walks the zero-inserted gradient) --
+    against the fp64 input gradient of conv2d on the same (bf16-rounded) dc and the same fp32 weights: odd and even map sizes, partial channel groups, every
+    lanes-per-row variant.  bf16 mode: the output is rounded to bf16 once (<= 2^-9 relative per element: 3e-3 norm-wise); fp32 mode: summation order only."""
+    import ctypes as C
+    from frostnet_amd import _lib as L
+    k, s, h, c, n = case
+    g = torch.Generator().manual_seed(7000 + 1000 * k + 100 * s + h + c)
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    wgt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    dc = torch.randn(n, c, ho, ho, generator=g)
+    if prec == "bf16":
+        dc = dc.bfloat16().float()
+    xin = torch.zeros(n, c, h, h, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xin, wgt.double(), stride=s, padding=pad, groups=c).backward(dc.double())
+    ref = xin.grad.permute(0, 2, 3, 1).contiguous()
+    cpad = (c + 15) // 16 * 16
+    pack = torch.zeros(k * k, cpad)
+    pack[:, :c] = wgt.reshape(c, k * k).t()
+    pack = pack.cuda()
+    desc = L.FrostFDesc()
+    desc.pack, desc.cout, desc.cin_g, desc.kk, desc.kind, desc.cpad = pack.data_ptr(), c, 1, k * k, 1, cpad
+    dtab = L.struct_to_tensor(desc, "cuda")
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    dd = dc.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    dx = torch.full((n, h, h, c), float("nan"), dtype=dt, device="cuda")
+    L.call("frost_float_dw_dgrad" + ("" if prec == "bf16" else "_f32"), L.ptr(dtab), L.ptr(dd), n, h, h, c, k, s, L.ptr(dx), L.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx.float()).all()
+    assert _rel(dx.float().cpu(), ref) <= (3e-3 if prec == "bf16" else 2e-6), _rel(dx.float().cpu(), ref)
