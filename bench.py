@@ -163,8 +163,8 @@ def side_workload(args, dev):
         for _ in range(3):                       # tables / optimizer state exist before the capture
             step()
         torch.cuda.synchronize()
-        # (the float warm-up step is GPU-bound with its weight gradients on a second stream: 33.5 ms eager, 34.4 ms replayed -- left eager)
-        if not args.no_graph and args.workload == "detect":
+        # (the float warm-up step is GPU-bound with its weight gradients on a second stream: 17.0 ms eager, 17.6 ms replayed (FROST_FLOAT_GRAPH=1) -- left eager)
+        if not args.no_graph and (args.workload == "detect" or (args.workload == "float" and os.environ.get("FROST_FLOAT_GRAPH", "0") == "1")):
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())

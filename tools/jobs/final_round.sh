@@ -12,6 +12,10 @@ find gpurun_out/prof_r03 -name "*kernel_trace.csv" -size +20M -delete 2>/dev/nul
 find gpurun_out/prof_r03 -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
 : > gpurun_out/r03_side_workloads.jsonl
 for wl in infer int8 detect float; do timeout 600 python bench.py --workload $wl 2>/dev/null | tail -1 >> gpurun_out/r03_side_workloads.jsonl; done
+FROST_FLOAT_PRECISION=fp32 timeout 600 python bench.py --workload float 2>/dev/null | tail -1 >> gpurun_out/r03_side_workloads.jsonl
+( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03_float -o s -- python bench.py --workload float --steps 10 --warmup 3 > gpurun_out/prof_r03_float.log 2>&1 )
+f=$(find gpurun_out/prof_r03_float -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r03_float_b256_kernel_stats.csv
+find gpurun_out/prof_r03_float -name "*kernel_trace.csv" -delete 2>/dev/null
 : > gpurun_out/r03_other_batches.jsonl
 for b in 64 200 256; do timeout 600 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r03_other_batches.jsonl; done
 ( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r03.log
