@@ -594,12 +594,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   }
   // per-lane (= per-channel) constants
   int wpk[K][2]; float wf[K * K];         // (the taps as floats in LDS instead, to fit 3 waves per SIMD: 28 spilled registers, 20 % slower -- measured)
+  int8_t taps[K * K];
+  load_taps_i8<K * K>(p.wq, p.cpad, ch, chok, taps);
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-      const int8_t wv = chok ? p.wq[(ky * K + kx) * p.cpad + ch] : (int8_t)0;
+      const int8_t wv = taps[ky * K + kx];
       wf[ky * K + kx] = (float)wv;
       const uint32_t b = (uint32_t)(uint8_t)wv; if (kx < 4) lo |= b << (8 * kx); else hi |= b;
     }
@@ -829,11 +831,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
     for (int i = tid; i < (G::GT >> 4); i += NT) ((uint4*)gt)[i] = make_uint4(0, 0, 0, 0);
   }
   int wpk[K][2];
+  int8_t taps[K * K];
+  load_taps_i8<K * K>(p.wq, p.cpad, ch, chok, taps);
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) { const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+    for (int kx = 0; kx < K; ++kx) { const uint32_t b = (uint32_t)(uint8_t)taps[ky * K + kx]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
     wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
   }
   const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;
@@ -939,11 +943,13 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_stats(const BlkCP p, uint
     for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
   }
   int wpk[K][2];
+  int8_t taps[K * K];
+  load_taps_i8<K * K>(p.wq, p.cpad, ch, chok, taps);
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) { const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+    for (int kx = 0; kx < K; ++kx) { const uint32_t b = (uint32_t)(uint8_t)taps[ky * K + kx]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
     wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
   }
   const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;

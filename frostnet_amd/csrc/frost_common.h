@@ -79,6 +79,16 @@ __device__ __forceinline__ uint32_t sr_pk_bf16(float lo, float hi, uint32_t& st)
 }
 static inline int frost_sr_enabled() { static const int on = getenv("FROST_SR") ? atoi(getenv("FROST_SR")) : 1; return on; }
 
+// The k x k int8 taps of channel `ch` (row pitch cpad): every load unconditional from a clamped channel, the lanes past the last channel zeroed afterwards.
+// (`chok ? w[..] : 0` per tap puts every load into its own exec-masked block with its wait behind it: 25 memory latencies in a row -- ~17 us -- at the head of
+// every depthwise workgroup, seen in the ISA as global_load_sbyte / s_waitcnt vmcnt(0) pairs.)
+template <int KK> __device__ __forceinline__ void load_taps_i8(const int8_t* __restrict__ wq, int cpad, int ch, bool chok, int8_t (&t)[KK]) {
+  const int chc = chok ? ch : 0;
+#pragma unroll
+  for (int i = 0; i < KK; ++i) t[i] = wq[i * cpad + chc];
+#pragma unroll
+  for (int i = 0; i < KK; ++i) t[i] = chok ? t[i] : (int8_t)0;
+}
 // ---- ordered float atomics ---------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
   if (v >= 0.0f) atomicMin((int*)addr, __float_as_int(v));

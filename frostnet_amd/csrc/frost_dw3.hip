@@ -298,12 +298,14 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
   // acc starts at (128 - zp) * sum(w), so acc = sum w * (q - zp) exactly (zero padding = zero-point fill).
   constexpr int NPK = (K == 3) ? 1 : 2;
   int wpk[K][NPK];
+  int8_t taps[K * K];
+  load_taps_i8<K * K>(p.wq, p.cpad, ch, chok, taps);
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-      const uint32_t b = chok ? (uint32_t)(uint8_t)p.wq[(ky * K + kx) * p.cpad + ch] : 0u;
+      const uint32_t b = (uint32_t)(uint8_t)taps[ky * K + kx];
       if (kx < 4) lo |= b << (8 * kx); else hi |= b;
     }
     wpk[ky][0] = (int)lo; if (NPK > 1) wpk[ky][NPK - 1] = (int)hi;
@@ -631,8 +633,12 @@ __global__ __launch_bounds__(256, 2) void k_dw3_dgrad(const Dw3P pin) {
   const int ch = cb * CBW + L.lc; const bool chok = ch < p.c;
   const float sw = (p.wscale && chok) ? p.wscale[ch] : p.qw[FROST_Q_SCALE];     // lane = channel: the per-channel weight scale is a per-lane scalar
   float wf[K * K];
+  {
+    int8_t taps[K * K];
+    load_taps_i8<K * K>(p.wq, p.cpad, ch, chok, taps);
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) wf[t] = chok ? (float)p.wq[t * p.cpad + ch] : 0.0f;
+    for (int t = 0; t < K * K; ++t) wf[t] = (float)taps[t];
+  }
   const int rb = (S == 1) ? wy * RH : wy * (RH / 2);
   const int cin_sub = L.colo - L.sb * SUBW;                                // patch column inside its sub-tile (multiple of 8)
   const int cbase = L.sb * DWS + ((S == 1) ? cin_sub : cin_sub / 2);

@@ -462,20 +462,42 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
     }
     return;
   }
+  // accumulate (the gradient slot already holds a gradient: squeeze_conv behind the skip connection): every old value is requested BEFORE the first one is
+  // used -- loaded where it is consumed, each load sits in its own block with its wait behind it (up to 16 memory latencies in a row per tile, seen in the ISA)
+  uint2 prev[DGW_NT][NTP];
+#pragma unroll
+  for (int m = 0; m < DGW_NT; ++m)
+#pragma unroll
+    for (int t = 0; t < NTP; ++t) prev[m][t] = make_uint2(0u, 0u);
+  if (accumulate) {
+#pragma unroll
+    for (int m = 0; m < DGW_NT; ++m) {
+      const int ci = (ct0 + m) * 16 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < NTP; ++t) {
+        const int64_t p = p0 + 16 * t + j;
+        const bool ok = m < nct && ci < cin && p < npix;
+        const uint2 o = *(const uint2*)(dx + (ok ? p * cin + ci : 0));          // unconditional from a clamped address
+        prev[m][t] = ok ? o : make_uint2(0u, 0u);
+      }
+    }
+  }
 #pragma unroll
   for (int m = 0; m < DGW_NT; ++m) {
     if (m >= nct) continue;
     const int ci = (ct0 + m) * 16 + 4 * g;
     if (ci >= cin) continue;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *(const float4*)(bias + ci);                                 // the bf16 inference layers: + b'[co], ReLU
 #pragma unroll
     for (int t = 0; t < NTP; ++t) {
       const int64_t p = p0 + 16 * t + j;
       if (p >= npix) continue;
       uint16_t* dst = dx + p * cin + ci;
       float v[4] = {acc[m][t][0] * sw, acc[m][t][1] * sw, acc[m][t][2] * sw, acc[m][t][3] * sw};
-      if (bias) { const float4 b4 = *(const float4*)(bias + ci); v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }      // the bf16 inference layers: + b'[co], ReLU
+      if (bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
       if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      if (accumulate) { const uint2 o = *(const uint2*)dst; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
+      if (accumulate) { const uint2 o = prev[m][t]; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
       uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]);
       *(uint2*)dst = o;
     }

@@ -1,8 +1,12 @@
 #!/bin/bash
-# A/B of two library builds on ONE box: build/ab/libfrost_old.so (reference build) vs the in-tree library, interleaved.
+# A/B of two library builds on ONE box: build/ab/libfrost_old.so (reference build) vs the in-tree library, interleaved; optional parity subset first.
 exec < /dev/null
 mkdir -p gpurun_out/ab
 O=gpurun_out/ab
+if [ "$1" = "tests" ]; then
+  timeout 1800 python -m pytest tests/test_gpu_paths.py tests/test_gpu_block.py tests/test_gpu_prod.py -q -x > $O/tests.log 2>&1
+  tail -3 $O/tests.log
+fi
 for rep in 1 2 3; do
   for v in new old; do
     if [ $v = old ]; then export FROST_HIP_LIB=$PWD/build/ab/libfrost_old.so; else unset FROST_HIP_LIB; fi
