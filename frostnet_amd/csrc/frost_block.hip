@@ -113,8 +113,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 3 : 4) void k_blk_expand_dw(co
     for (int i = tid; i < cw; i += NT) {
       const int c2 = chunk_lo * 64 + i; const bool ok = c2 < p.c;
       l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN;
-      tabA[i] = ok ? p.coef1[FROST_COEF_A * p.cpad + c2] : 0.0f; tabB[i] = ok ? p.coef1[FROST_COEF_B * p.cpad + c2] : 0.0f;
-      tabW[i] = ok ? p.wsum1[c2] : 0; tabW2[i] = ok ? p.wsum2[c2] : 0;
+      const int cc = ok ? c2 : 0;          // unconditional from a clamped channel, zeroed afterwards (a load under `ok ?` waits at its own join)
+      const float rA = p.coef1[FROST_COEF_A * p.cpad + cc], rB = p.coef1[FROST_COEF_B * p.cpad + cc]; const int rW = p.wsum1[cc], rW2 = p.wsum2[cc];
+      tabA[i] = ok ? rA : 0.0f; tabB[i] = ok ? rB : 0.0f; tabW[i] = ok ? rW : 0; tabW2[i] = ok ? rW2 : 0;
     }
     const int ntap = (chunk_hi - chunk_lo) * K * K * 16;                          // 4 channels of one tap per thread, in batches of 4 loads
     for (int i0 = tid; i0 < ntap; i0 += 4 * NT) {
@@ -370,7 +371,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
   struct ChRow { float A, B; int ws; };
   auto load_row = [&](int chunk) __attribute__((always_inline)) {
     ChRow r; const int c2 = chunk * 64 + lane; const bool ok = c2 < p.c;
-    r.A = ok ? p.coef2[FROST_COEF_A * p.cpad + c2] : 0.0f; r.B = ok ? p.coef2[FROST_COEF_B * p.cpad + c2] : 0.0f; r.ws = ok ? p.wsum2[c2] : 0;
+    const int cc = ok ? c2 : 0;
+    const float rA = p.coef2[FROST_COEF_A * p.cpad + cc], rB = p.coef2[FROST_COEF_B * p.cpad + cc]; const int rW = p.wsum2[cc];
+    r.A = ok ? rA : 0.0f; r.B = ok ? rB : 0.0f; r.ws = ok ? rW : 0;
     return r;
   };
   uint2 yv[YU]; uint32_t tv[NTAPW]; ChRow row_n;

@@ -44,12 +44,14 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
 
   for (int i = tid; i < cw; i += 256) {
     const int c2 = chunk_lo * 64 + i; const bool ok = c2 < p.c;
-    const float A = ok ? p.coef[FROST_COEF_A * p.cpad + c2] : 0.0f, B = ok ? p.coef[FROST_COEF_B * p.cpad + c2] : 0.0f;
-    const float M = ok ? p.coef[FROST_COEF_M * p.cpad + c2] : 0.0f, R = ok ? p.coef[FROST_COEF_R * p.cpad + c2] : 0.0f;
-    tA[i] = A; tB[i] = B; tR[i] = R; tMR[i] = -M * R; tW[i] = ok ? p.wsum[c2] : 0;
+    const int cc = ok ? c2 : 0;                  // every row unconditional from a clamped channel (a load under `ok ?` waits at its own join), zeroed afterwards
+    float A = p.coef[FROST_COEF_A * p.cpad + cc], B = p.coef[FROST_COEF_B * p.cpad + cc], M = p.coef[FROST_COEF_M * p.cpad + cc], R = p.coef[FROST_COEF_R * p.cpad + cc];
+    int ws = p.wsum[cc];
+    float K1 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (MODE == 1) { K1 = p.coef[FROST_COEF_K1 * p.cpad + cc]; s1 = p.coef[FROST_COEF_S1 * p.cpad + cc]; s2 = p.coef[FROST_COEF_S2 * p.cpad + cc]; }
+    if (!ok) { A = 0.0f; B = 0.0f; M = 0.0f; R = 0.0f; ws = 0; K1 = 0.0f; s1 = 0.0f; s2 = 0.0f; }
+    tA[i] = A; tB[i] = B; tR[i] = R; tMR[i] = -M * R; tW[i] = ws;
     if (MODE == 1) {
-      const float K1 = ok ? p.coef[FROST_COEF_K1 * p.cpad + c2] : 0.0f;
-      const float s1 = ok ? p.coef[FROST_COEF_S1 * p.cpad + c2] : 0.0f, s2 = ok ? p.coef[FROST_COEF_S2 * p.cpad + c2] : 0.0f;
       const float E = -K1 * (s2 * p.inv_count) * R;
       tK1[i] = K1; tE[i] = E; tF[i] = -K1 * (s1 * p.inv_count) - E * M;
     } else if (MODE == 0) { l_f1[i] = 0.0f; l_f2[i] = 0.0f; }
