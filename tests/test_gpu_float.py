@@ -457,3 +457,49 @@ def test_float_dw_dgrad_row_form_vs_fp64(case, prec):
     torch.cuda.synchronize()
     assert torch.isfinite(dx.float()).all()
     assert _rel(dx.float().cpu(), ref) <= (3e-3 if prec == "bf16" else 2e-6), _rel(dx.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("case", [(3, 1, 14, 96, 5), (3, 2, 28, 144, 3), (5, 1, 7, 1440, 4), (5, 2, 14, 672, 3), (3, 2, 13, 32, 3), (5, 1, 5, 24, 3), (5, 2, 11, 200, 2)],
+                         ids=lambda c: "k%d_s%d_h%d_c%d_n%d" % c)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_float_dw_forward_row_form_vs_fp64(case, prec):
+    """frost_float_dw(_f32) modes 0 / 1 -- the row-walking forward (conv output + per-channel sum / sum of squares; y = relu(c * scale + bias)) -- against an fp64
+    conv2d of the same operands.  bf16 mode stores the outputs as bf16 (one rounding: 3e-3 norm-wise); the statistics are taken from the fp32 accumulators."""
+    from frostnet_amd import _lib as L
+    k, s, h, c, n = case
+    sfx = "" if prec == "bf16" else "_f32"
+    g = torch.Generator().manual_seed(4200 + 100 * k + 10 * s + h + c)
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    cpad = (c + 15) // 16 * 16
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    wgt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    x = torch.randn(n, c, h, h, generator=g)
+    if prec == "bf16":
+        x = x.bfloat16().float()
+    ref = torch.nn.functional.conv2d(x.double(), wgt.double(), stride=s, padding=pad, groups=c).permute(0, 2, 3, 1).contiguous()
+    pack = torch.zeros(k * k, cpad)
+    pack[:, :c] = wgt.reshape(c, k * k).t()
+    pack = pack.cuda()
+    coef = torch.zeros(8, cpad)
+    coef[0, :c] = torch.rand(c, generator=g) + 0.5
+    coef[1, :c] = torch.randn(c, generator=g) * 0.3
+    coef = coef.cuda()
+    stat = torch.zeros(8 * 4 * cpad, dtype=torch.float64, device="cuda")
+    d = L.FrostFDesc()
+    d.pack, d.coef, d.stat, d.cout, d.cin_g, d.kk, d.kind, d.cpad, d.fp32 = pack.data_ptr(), coef.data_ptr(), stat.data_ptr(), c, 1, k * k, 1, cpad, int(prec == "fp32")
+    tab = L.struct_to_tensor(d, "cuda")
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    cv = torch.full((n, ho, ho, c), float("nan"), dtype=dt, device="cuda")
+    y = torch.full((n, ho, ho, c), float("nan"), dtype=dt, device="cuda")
+    L.call("frost_float_dw" + sfx, L.ptr(tab), L.ptr(xd), n, h, h, c, k, s, 1, 0, None, L.ptr(cv), L.stream())          # mode 0: statistics + conv output
+    L.call("frost_float_dw" + sfx, L.ptr(tab), L.ptr(xd), n, h, h, c, k, s, 1, 1, None, L.ptr(y), L.stream())           # mode 1: emit
+    torch.cuda.synchronize()
+    tol = 3e-3 if prec == "bf16" else 2e-6
+    assert _rel(cv.float().cpu(), ref) <= tol
+    yref = torch.relu(ref * coef[0, :c].cpu().double() + coef[1, :c].cpu().double())
+    assert _rel(y.float().cpu(), yref) <= tol
+    sums = stat.view(8, 4, cpad).sum(0).cpu()
+    flat = ref.reshape(-1, c)
+    assert _rel(sums[0, :c], flat.sum(0)) <= 1e-4 and _rel(sums[1, :c], (flat * flat).sum(0)) <= 1e-4
+    assert float(sums[2:].abs().max()) == 0.0
