@@ -146,6 +146,8 @@ _PROTOS = {
     "frost_float_ew": [P, P, L, I, I, I, P, I, P, I, P],
     "frost_float_ew_f32": [P, P, L, I, I, I, P, I, P, I, P],
     "frost_float_dw_dgrad": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_dw_src": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_float_dw_wgrad_src": [P, P, P, I, I, I, I, I, I, I, P, P],
     "frost_float_dw_wgrad": [P, P, I, I, I, I, I, I, P, P],
     "frost_float_pw_wgrad": [P, P, L, I, I, I, P, I, P],
     "frost_float_stem_wscatter": [P, I, P, P],
@@ -155,6 +157,8 @@ _PROTOS = {
     "frost_float_pw_f32": [P, P, P, L, I, I, I, I, P, I, P, I, P],
     "frost_float_dw_f32": [P, P, I, I, I, I, I, I, I, I, P, P, P],
     "frost_float_dw_dgrad_f32": [P, P, I, I, I, I, I, I, P, P],
+    "frost_float_dw_src_f32": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_float_dw_wgrad_src_f32": [P, P, P, I, I, I, I, I, I, I, P, P],
     "frost_float_dw_wgrad_f32": [P, P, I, I, I, I, I, I, P, P],
     "frost_float_pw_wgrad_f32": [P, P, L, I, I, I, P, I, P],
     "frost_float_grad_merge_f32": [P, P, I, I, P, L, I, P, P],

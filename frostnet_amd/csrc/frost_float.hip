@@ -608,9 +608,11 @@ static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const
 // Row-walking form of the forward passes (F_STATS: conv output + statistics, F_EMIT: y = [relu](c*scale + bias)) -- the default: a wave owns 2 * GW channels of
 // 64 / GW output rows and walks along them with the k x k input window and its channels' weights in registers (see k_f_dw_wgrad_row for the rotation of the
 // window slots); per output pixel S*k loads of 4 bytes, k*k packed FMAs in the same (ky, kx) order as k_f_dw -- the conv output is bit-identical --, one store.
-template <int MODE, int K, int S, int GW, typename ET>
+// SRC: x holds the KEPT CONV OUTPUT of the layer in front (conv1 of the bottleneck) instead of its activation: y1 = [relu](c1 * scale + bias) is applied as the
+// window is loaded (padding stays zero), so conv1's element-wise emit pass -- one read of c1 and one write of y1 -- never runs in training.
+template <int MODE, int K, int S, int GW, bool SRC, typename ET>
 __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu,
-                                                  ET* __restrict__ y) {
+                                                  ET* __restrict__ y, const FrostFDesc* dsrc, int relu_src) {
   constexpr int PAD = (K - 1) / 2, RPW = 64 / GW;
   using SA = typename std::conditional<sizeof(ET) == 4, double, float>::type;     // fp32 mode: statistics partials in double
   __shared__ SA sred[2][2 * GW];
@@ -628,6 +630,9 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
       for (int kx = 0; kx < K; ++kx) wt[ky][kx] = *(const v2f*)(wf + (ky * K + kx) * cpad + ch);
     v2f sc = (v2f){1.0f, 1.0f}, bi = (v2f){0.0f, 0.0f};
     if (MODE == F_EMIT) { sc = *(const v2f*)(dp->coef + FC_SCALE * cpad + ch); bi = *(const v2f*)(dp->coef + FC_BIAS * cpad + ch); }
+    v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY;
+    if (SRC) { ssc = *(const v2f*)(dsrc->coef + FC_SCALE * cpad + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * cpad + ch); slo = relu_src ? 0.0f : -INFINITY; }
+    auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){fmaxf(fmaf(v[0], ssc[0], sbi[0]), slo), fmaxf(fmaf(v[1], ssc[1], sbi[1]), slo)} : v; };
     const float lo = relu ? 0.0f : -INFINITY;
     const int rows = n * ho;
     for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
         const int ix = kx - PAD;
         const bool cv = (unsigned)ix < (unsigned)w; const int64_t off = (int64_t)(cv ? ix : 0) * c;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) { const v2f v = fdw_ld2(xr[ky] + off); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
+        for (int ky = 0; ky < K; ++ky) { const v2f v = xf(fdw_ld2(xr[ky] + off)); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
       }
       for (int ox0 = 0; ox0 < wo; ox0 += K) {
         typename FdwRaw<ET>::T raw[K][S][K];
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
             const int kx = K - S + j, ix = ox * S - PAD + kx, slot = (u * S + kx) % K;
             const bool cv = (unsigned)ix < (unsigned)w;
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? FdwRaw<ET>::cv(raw[u][j][ky]) : (v2f){0.0f, 0.0f};
+            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? xf(FdwRaw<ET>::cv(raw[u][j][ky])) : (v2f){0.0f, 0.0f};
           }
           v2f acc = (v2f){0.0f, 0.0f};
 #pragma unroll
@@ -705,29 +710,34 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
   }
 }
 template <int MODE, int K, int S, int GW, typename ET>
-static void launch_f_dw_row2(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s) {
+static void launch_f_dw_row2(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s,
+                             const FrostFDesc* dsrc, int relu_src) {
   static int wgs = -1;
   if (wgs < 0) { const char* e = getenv("FROST_FDW_ROW_WGS"); wgs = e ? atoi(e) : (K == 3 ? 2048 : 1024); }
   constexpr int RPW = 64 / GW;
   const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
   int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
-  hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out);
+  if (dsrc) hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, true, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
+  else hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, false, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
 }
 template <int MODE, int K, int S, typename ET>
-static void launch_f_dw_row(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s) {
-  if (c > 64) launch_f_dw_row2<MODE, K, S, 64, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
-  else if (c > 32) launch_f_dw_row2<MODE, K, S, 32, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
-  else launch_f_dw_row2<MODE, K, S, 16, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+static void launch_f_dw_row(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s,
+                            const FrostFDesc* dsrc, int relu_src) {
+  if (c > 64) launch_f_dw_row2<MODE, K, S, 64, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
+  else if (c > 32) launch_f_dw_row2<MODE, K, S, 32, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
+  else launch_f_dw_row2<MODE, K, S, 16, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
 }
 template <int MODE, typename ET>
-static void launch_f_dw_row_ks(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int k, int stride, int ho, int wo, int relu, ET* out, hipStream_t s) {
-  if (k == 3 && stride == 1) launch_f_dw_row<MODE, 3, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
-  else if (k == 3) launch_f_dw_row<MODE, 3, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
-  else if (stride == 1) launch_f_dw_row<MODE, 5, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
-  else launch_f_dw_row<MODE, 5, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s);
+static void launch_f_dw_row_ks(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int k, int stride, int ho, int wo, int relu, ET* out, hipStream_t s,
+                               const FrostFDesc* dsrc, int relu_src) {
+  if (k == 3 && stride == 1) launch_f_dw_row<MODE, 3, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
+  else if (k == 3) launch_f_dw_row<MODE, 3, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
+  else if (stride == 1) launch_f_dw_row<MODE, 5, 1, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
+  else launch_f_dw_row<MODE, 5, 2, ET>(desc, x, n, h, w, c, cpad, ho, wo, relu, out, s, dsrc, relu_src);
 }
 template <typename ET>
-static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int k, int stride, int relu, int mode, const ET* gy, ET* out, hipStream_t s) {
+static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int k, int stride, int relu, int mode, const ET* gy, ET* out, hipStream_t s,
+                        const FrostFDesc* dsrc = nullptr, int relu_src = 0) {
   FROST_REQUIRE(c % 8 == 0, "float_dw: channels must be a multiple of 8");
   FROST_REQUIRE(mode >= 0 && mode <= 3, "float_dw: mode 0..3");
   FROST_REQUIRE((k == 3 || k == 5) && (stride == 1 || stride == 2), "float_dw: 3x3 / 5x5, stride 1 / 2");
@@ -735,9 +745,10 @@ static int float_dw_any(const FrostFDesc* desc, const ET* x, int n, int h, int w
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
   static int row_form = -1;
   if (row_form < 0) { const char* e = getenv("FROST_FDW_ROW"); row_form = e ? atoi(e) : 1; }
-  if (row_form && (mode == F_STATS || mode == F_EMIT)) {
-    if (mode == F_STATS) launch_f_dw_row_ks<F_STATS, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s);
-    else launch_f_dw_row_ks<F_EMIT, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s);
+  FROST_REQUIRE(!dsrc || mode == F_STATS || mode == F_EMIT, "float_dw_src: forward modes only (0: statistics + conv output, 1: emit)");
+  if ((row_form || dsrc) && (mode == F_STATS || mode == F_EMIT)) {
+    if (mode == F_STATS) launch_f_dw_row_ks<F_STATS, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s, dsrc, relu_src);
+    else launch_f_dw_row_ks<F_EMIT, ET>(desc, x, n, h, w, c, cpad, k, stride, ho, wo, relu, out, s, dsrc, relu_src);
     return frost_check_launch("float_dw");
   }
   const int64_t tot = (int64_t)n * ho * ((wo + FDW_WO - 1) / FDW_WO) * c8n;
@@ -759,6 +770,17 @@ extern "C" int frost_float_dw(const FrostFDesc* desc, const uint16_t* x, int n, 
 extern "C" int frost_float_dw_f32(const FrostFDesc* desc, const float* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
                                   const float* gy, float* out, void* stream) {
   return float_dw_any<float>(desc, x, n, h, w, c, k, stride, relu, mode, gy, out, as_stream(stream));
+}
+// forward modes with the input given as the kept conv output of the layer in front (descriptor desc_src, ReLU flag relu_src): see k_f_dw_row<SRC>
+extern "C" int frost_float_dw_src(const FrostFDesc* desc, const uint16_t* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                                  int relu, int mode, uint16_t* out, void* stream) {
+  FROST_REQUIRE(desc_src && conv_src, "float_dw_src: descriptor and kept conv output of the layer in front");
+  return float_dw_any<uint16_t>(desc, conv_src, n, h, w, c, k, stride, relu, mode, nullptr, out, as_stream(stream), desc_src, relu_src);
+}
+extern "C" int frost_float_dw_src_f32(const FrostFDesc* desc, const float* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                                      int relu, int mode, float* out, void* stream) {
+  FROST_REQUIRE(desc_src && conv_src, "float_dw_src: descriptor and kept conv output of the layer in front");
+  return float_dw_any<float>(desc, conv_src, n, h, w, c, k, stride, relu, mode, nullptr, out, as_stream(stream), desc_src, relu_src);
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise passes over a kept conv output
@@ -1073,9 +1095,9 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const ET* __restrict__ dc, c
 // along output rows with the k x k input window in registers -- per output pixel it loads the S new window columns (k loads of 4 bytes) and one dc value and
 // runs k*k packed FMAs, so dc and x are read ONCE (the form above reads both once per kernel row, in 64-byte segments).  The window's column slots rotate
 // with the output column ((ox*S + kx) mod k; the ox loop is unrolled k times so that every slot index is a compile-time constant: no register moves).
-template <int K, int S, int GW, typename ET>
+template <int K, int S, int GW, bool SRC, typename ET>
 __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ dc, const ET* __restrict__ x, int n, int h, int w, int c, int ho, int wo,
-                                                        float* __restrict__ dw) {
+                                                        float* __restrict__ dw, const FrostFDesc* dsrc, int relu_src) {
   // GW lanes (2 * GW channels) per output row, 64 / GW rows per wave: narrow layers (the biggest maps) keep every lane busy
   constexpr int PAD = (K - 1) / 2, KK = K * K, RPW = 64 / GW;
   __shared__ float red[2 * GW * KK];
@@ -1087,6 +1109,9 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
   for (int ky = 0; ky < K; ++ky)
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) acc[ky][kx] = (v2f){0.0f, 0.0f};
+  v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY;          // SRC: x is the kept conv output of the layer in front (see k_f_dw_row<SRC>)
+  if (SRC && live) { const int scp = dsrc->cpad; ssc = *(const v2f*)(dsrc->coef + FC_SCALE * scp + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * scp + ch); slo = relu_src ? 0.0f : -INFINITY; }
+  auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){fmaxf(fmaf(v[0], ssc[0], sbi[0]), slo), fmaxf(fmaf(v[1], ssc[1], sbi[1]), slo)} : v; };
   const int rows = n * ho;
   if (live) {
     for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
@@ -1108,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
         const int ix = kx - PAD;                        // (every load unconditional from a clamped address, zeroed afterwards: a conditional load ends in a wait at its join)
         const bool cv = (unsigned)ix < (unsigned)w; const int64_t off = (int64_t)(cv ? ix : 0) * c;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) { const v2f v = fdw_ld2(xr[ky] + off); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
+        for (int ky = 0; ky < K; ++ky) { const v2f v = xf(fdw_ld2(xr[ky] + off)); win[ky][kx] = (cv && rv[ky]) ? v : (v2f){0.0f, 0.0f}; }
       }
       for (int ox0 = 0; ox0 < wo; ox0 += K) {
         // phase 1: every load of the next K output pixels (no branch on ox: past the row end dc counts as zero), phase 2: the arithmetic
@@ -1134,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
             const int kx = K - S + j, ix = ox * S - PAD + kx, slot = (u * S + kx) % K;
             const bool cv = (unsigned)ix < (unsigned)w;
 #pragma unroll
-            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? FdwRaw<ET>::cv(raw[u][j][ky]) : (v2f){0.0f, 0.0f};
+            for (int ky = 0; ky < K; ++ky) win[ky][slot] = (cv && rv[ky]) ? xf(FdwRaw<ET>::cv(raw[u][j][ky])) : (v2f){0.0f, 0.0f};
           }
           const v2f g = (ox < wo) ? FdwRaw<ET>::cv(graw[u]) : (v2f){0.0f, 0.0f};
 #pragma unroll
@@ -1160,33 +1185,35 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
   }
 }
 template <int K, int S, int GW, typename ET>
-static void launch_f_dw_wgrad_row2(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s) {
+static void launch_f_dw_wgrad_row2(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s, const FrostFDesc* dsrc, int relu_src) {
   static int wgs = -1;
   if (wgs < 0) { const char* e = getenv("FROST_FDW_WGRAD_WGS"); wgs = e ? atoi(e) : (K == 3 ? 2048 : 1024); }
   constexpr int RPW = 64 / GW;
   const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
   int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
-  hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw);
+  if (dsrc) hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, true, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
+  else hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, false, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
 }
 template <int K, int S, typename ET>
-static void launch_f_dw_wgrad_row(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s) {
+static void launch_f_dw_wgrad_row(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s, const FrostFDesc* dsrc, int relu_src) {
   // lanes per row: 64 (256-byte segments) unless the layer is so narrow that most of them would idle -- measured: 96 channels on 64 lanes (25 % idle) beat
   // three 16-lane groups of 64-byte segments (547 vs 717 us, layer1.1), 32 channels on 16 lanes beat 64 (202 vs 462 us, layer1.0)
-  if (c > 64) launch_f_dw_wgrad_row2<K, S, 64, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
-  else if (c > 32) launch_f_dw_wgrad_row2<K, S, 32, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
-  else launch_f_dw_wgrad_row2<K, S, 16, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+  if (c > 64) launch_f_dw_wgrad_row2<K, S, 64, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
+  else if (c > 32) launch_f_dw_wgrad_row2<K, S, 32, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
+  else launch_f_dw_wgrad_row2<K, S, 16, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
 }
 template <typename ET>
-static int float_dw_wgrad_any(const ET* dc, const ET* x, int n, int h, int w, int c, int k, int stride, float* dw, hipStream_t s) {
+static int float_dw_wgrad_any(const ET* dc, const ET* x, int n, int h, int w, int c, int k, int stride, float* dw, hipStream_t s, const FrostFDesc* dsrc = nullptr, int relu_src = 0) {
   FROST_REQUIRE(c % 8 == 0 && k <= 5, "float_dw_wgrad: channels must be a multiple of 8, k <= 5");
   const int pad = (k - 1) / 2; const int ho = (h + 2 * pad - k) / stride + 1, wo = (w + 2 * pad - k) / stride + 1;
   static int row_form = -1;
   if (row_form < 0) { const char* e = getenv("FROST_FDW_WGRAD_ROW"); row_form = e ? atoi(e) : 1; }
-  if (row_form && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
-    if (k == 3 && stride == 1) launch_f_dw_wgrad_row<3, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
-    else if (k == 3) launch_f_dw_wgrad_row<3, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
-    else if (stride == 1) launch_f_dw_wgrad_row<5, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
-    else launch_f_dw_wgrad_row<5, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s);
+  FROST_REQUIRE(!dsrc || ((k == 3 || k == 5) && (stride == 1 || stride == 2)), "float_dw_wgrad_src: 3x3 / 5x5, stride 1 / 2");
+  if ((row_form || dsrc) && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+    if (k == 3 && stride == 1) launch_f_dw_wgrad_row<3, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
+    else if (k == 3) launch_f_dw_wgrad_row<3, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
+    else if (stride == 1) launch_f_dw_wgrad_row<5, 1, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
+    else launch_f_dw_wgrad_row<5, 2, ET>(dc, x, n, h, w, c, ho, wo, dw, s, dsrc, relu_src);
     return frost_check_launch("float_dw_wgrad");
   }
   const int64_t npix = (int64_t)n * ho * wo;
@@ -1201,6 +1228,17 @@ extern "C" int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n
 }
 extern "C" int frost_float_dw_wgrad_f32(const float* dc, const float* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream) {
   return float_dw_wgrad_any<float>(dc, x, n, h, w, c, k, stride, dw, as_stream(stream));
+}
+// weight gradient with the layer's input given as the kept conv output of the layer in front (see frost_float_dw_src)
+extern "C" int frost_float_dw_wgrad_src(const uint16_t* dc, const uint16_t* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                                        float* dw, void* stream) {
+  FROST_REQUIRE(desc_src && conv_src, "float_dw_wgrad_src: descriptor and kept conv output of the layer in front");
+  return float_dw_wgrad_any<uint16_t>(dc, conv_src, n, h, w, c, k, stride, dw, as_stream(stream), desc_src, relu_src);
+}
+extern "C" int frost_float_dw_wgrad_src_f32(const float* dc, const float* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                                            float* dw, void* stream) {
+  FROST_REQUIRE(desc_src && conv_src, "float_dw_wgrad_src: descriptor and kept conv output of the layer in front");
+  return float_dw_wgrad_any<float>(dc, conv_src, n, h, w, c, k, stride, dw, as_stream(stream), desc_src, relu_src);
 }
 
 // ------------------------------------------------------------------------------------------------ pointwise weight gradient (bf16 MFMA, K = pixels)

@@ -34,10 +34,11 @@ def round_up(a, b):
 
 class FAct:
     """NHWC activation, bf16 (int16 storage) or fp32; 64 elements of slack for the 16-byte tail loads."""
-    __slots__ = ("buf", "n", "h", "w", "c")
+    __slots__ = ("buf", "n", "h", "w", "c", "src")
 
-    def __init__(self, buf, n, h, w, c):
+    def __init__(self, buf, n, h, w, c, src=None):
         self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+        self.src = src          # (descriptor pointer, relu) of the producing layer when `buf` holds its CONV OUTPUT (the consumer applies BN + ReLU on load)
 
     @property
     def npix(self):
@@ -51,6 +52,7 @@ class FAct:
 
 _KEEP_CONV = os.environ.get("FROST_FLOAT_KEEP_CONV", "1") != "0"        # training keeps each layer's conv output for element-wise passes (A/B knob)
 _WGRAD_SIDE = os.environ.get("FROST_FLOAT_WGRAD_SIDE", "1") != "0"      # weight gradients on a second stream (A/B knob)
+_LAZY_EMIT = os.environ.get("FROST_FLOAT_LAZY_EMIT", "1") != "0"        # training: conv1's activation is never written -- the depthwise kernels apply BN + ReLU to its kept conv output on load (A/B knob)
 
 
 class _FLayer:
@@ -155,7 +157,7 @@ class FloatRunner:
         self.precision, self.fp32 = precision, precision == "fp32"
         self._adt = torch.float32 if self.fp32 else torch.int16          # activation / activation-gradient storage
         sfx = "_f32" if self.fp32 else ""
-        self._fn = {n: n + sfx for n in ("frost_float_pw", "frost_float_dw", "frost_float_ew", "frost_float_dw_dgrad", "frost_float_dw_wgrad", "frost_float_pw_wgrad",
+        self._fn = {n: n + sfx for n in ("frost_float_pw", "frost_float_dw", "frost_float_ew", "frost_float_dw_dgrad", "frost_float_dw_wgrad", "frost_float_pw_wgrad", "frost_float_dw_src", "frost_float_dw_wgrad_src",
                                          "frost_float_grad_merge", "frost_float_avgpool", "frost_float_head_bwd")}
         self._fn["cat"] = "frost_float_cat_f32" if self.fp32 else "frost_infer_cat"
         self._fn["add"] = "frost_float_add_f32" if self.fp32 else "frost_infer_add"
@@ -257,26 +259,35 @@ class FloatRunner:
         return FAct(torch.empty(n * h * w * c + 64, dtype=self._adt, device=self.device), n, h, w, c)
 
     # ------------------------------------------------------------------------------------------ forward
-    def _conv(self, l, a, training, record, out=None, ldy=None):
-        """Conv -> BN -> [ReLU] (frostnet.py:14-60).  `out`/`ldy`: write into a slice of a wider buffer (the cat)."""
+    def _conv(self, l, a, training, record, out=None, ldy=None, lazy=False):
+        """Conv -> BN -> [ReLU] (frostnet.py:14-60).  `out`/`ldy`: write into a slice of a wider buffer (the cat).
+        lazy (training, kept conv output): no emit pass -- the returned activation carries the conv output and `src`, its only consumer (the depthwise layer)
+        applies BN + ReLU on load (frost_float_dw_src / frost_float_dw_wgrad_src)."""
         if l.kind == 1:
             pad = (l.k - 1) // 2
             ho, wo = (a.h + 2 * pad - l.k) // l.stride + 1, (a.w + 2 * pad - l.k) // l.stride + 1
         else:
             ho, wo = a.h, a.w
-        y = self._new(a.n, ho, wo, l.cout) if out is None else None
+        lazy = bool(lazy and out is None and training and _KEEP_CONV)
+        y = self._new(a.n, ho, wo, l.cout) if (out is None and not lazy) else None
         npix_o = a.n * ho * wo
-        dst, ld = (ptr(y.buf), l.cout) if out is None else (out, ldy)
+        dst, ld = (ptr(y.buf) if y is not None else None, l.cout) if out is None else (out, ldy)
         if training and _KEEP_CONV:
             # training: ONE convolution per layer.  The statistics pass stores the conv output c; y = [relu](c*scale + bias) is an element-wise pass
             # over c, and so are the backward's statistics and dc (frost_float_ew) -- c is kept until the layer's backward
             cbuf = torch.empty(npix_o * l.cout + 64, dtype=self._adt, device=self.device)
             if l.kind == 1:
-                call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, ptr(cbuf), stream())
+                if a.src is not None:
+                    call(self._fn["frost_float_dw_src"], l.desc_ptr, ptr(a.buf), a.src[0], a.src[1], a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, ptr(cbuf), stream())
+                else:
+                    call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, ptr(cbuf), stream())
             else:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, ptr(cbuf), l.cout, stream())
             call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
-            call(self._fn["frost_float_ew"], l.desc_ptr, ptr(cbuf), npix_o, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
+            if lazy:
+                y = FAct(cbuf, a.n, ho, wo, l.cout, src=(l.desc_ptr, int(l.relu)))
+            else:
+                call(self._fn["frost_float_ew"], l.desc_ptr, ptr(cbuf), npix_o, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
             if record:
                 l.c = cbuf
         elif l.kind == 1:
@@ -303,7 +314,9 @@ class FloatRunner:
                 sq = self._conv(ent["squeeze"], a, training, record)
                 call(self._fn["cat"], ptr(sq.buf), cs, ptr(a.buf), a.c, a.npix, ptr(cat.buf), stream())     # cat([squeezed, x], 1)
                 a = cat
-            a = self._conv(ent["conv1"], a, training, record)
+            c2 = ent["conv2"]
+            a = self._conv(ent["conv1"], a, training, record,
+                           lazy=bool(training and _KEEP_CONV and _LAZY_EMIT and c2.kind == 1 and c2.k in (3, 5) and c2.stride in (1, 2)))
         a = self._conv(ent["conv2"], a, training, record)
         a = self._conv(ent["reduce"], a, training, record)
         if not blk.reduction:
@@ -397,7 +410,10 @@ class FloatRunner:
             if need_dx:
                 dx = self._new(a.n, a.h, a.w, a.c)
                 call(self._fn["frost_float_dw_dgrad"], l.desc_ptr, ptr(dc), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(dx.buf), stream())
-            self._on_side(lambda: call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream()), dc, a)
+            if a.src is not None:
+                self._on_side(lambda: call(self._fn["frost_float_dw_wgrad_src"], ptr(dc), ptr(a.buf), a.src[0], a.src[1], a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream()), dc, a)
+            else:
+                self._on_side(lambda: call(self._fn["frost_float_dw_wgrad"], ptr(dc), ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, ptr(gw), stream()), dc, a)
         else:
             if kept is None:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), BRED, gy, ldg, None, 0, stream())

@@ -283,6 +283,15 @@ int frost_float_ew(const FrostFDesc* desc, const uint16_t* conv, int64_t npix, i
                    uint16_t* out, int ldy, void* stream);
 int frost_float_ew_f32(const FrostFDesc* desc, const float* conv, int64_t npix, int c, int relu, int mode, const float* gy, int ldg,
                        float* out, int ldy, void* stream);
+/* The depthwise layer of a bottleneck fed from the KEPT CONV OUTPUT of the layer in front (conv1) instead of its activation: y1 = [relu](c1 * scale + bias)
+ * (BatchNorm2d + ReLU of frostnet.py:14-30, coefficient rows of desc_src) is applied as the input window is loaded, so the element-wise emit pass of conv1
+ * (frost_float_ew mode 1: one read of c1, one write of y1) never runs in training.  frost_float_dw_src: forward modes 0 / 1 of frost_float_dw;
+ * frost_float_dw_wgrad_src: the weight gradient of the same layer (it needs the same input).  fp32 mode: identical values to the two-pass form; bf16 mode: the
+ * input is not rounded to bf16 on the way (closer to the reference's fp32). */
+int frost_float_dw_src(const FrostFDesc* desc, const uint16_t* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                       int relu, int mode, uint16_t* out, void* stream);
+int frost_float_dw_wgrad_src(const uint16_t* dc, const uint16_t* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                             float* dw, void* stream);
 int frost_float_dw_dgrad(const FrostFDesc* desc, const uint16_t* dc, int n, int h, int w, int c, int k, int stride, uint16_t* dx, void* stream);
 int frost_float_dw_wgrad(const uint16_t* dc, const uint16_t* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream);
 int frost_float_pw_wgrad(const uint16_t* dc, const uint16_t* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream);
@@ -298,6 +307,10 @@ int frost_float_pw_f32(const FrostFDesc* desc, const float* x, const float* pack
                        const float* gy, int ldg, float* out, int ldy, void* stream);
 int frost_float_dw_f32(const FrostFDesc* desc, const float* x, int n, int h, int w, int c, int k, int stride, int relu, int mode,
                        const float* gy, float* out, void* stream);
+int frost_float_dw_src_f32(const FrostFDesc* desc, const float* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                           int relu, int mode, float* out, void* stream);
+int frost_float_dw_wgrad_src_f32(const float* dc, const float* conv_src, const FrostFDesc* desc_src, int relu_src, int n, int h, int w, int c, int k, int stride,
+                                 float* dw, void* stream);
 int frost_float_dw_dgrad_f32(const FrostFDesc* desc, const float* dc, int n, int h, int w, int c, int k, int stride, float* dx, void* stream);
 int frost_float_dw_wgrad_f32(const float* dc, const float* x, int n, int h, int w, int c, int k, int stride, float* dw, void* stream);
 int frost_float_pw_wgrad_f32(const float* dc, const float* x, int64_t npix, int cin, int ldx, int cout, float* dw, int ldw, void* stream);

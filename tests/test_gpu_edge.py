@@ -104,8 +104,8 @@ def test_float_ragged(F, batch, res):
     model.cuda().train()
     run = model.hip_runner()
     dev, orig_conv, orig_block = {}, run._conv, run._block
-    def conv(l, a, training, record, out=None, ldy=None):
-        o = orig_conv(l, a, training, record, out, ldy)
+    def conv(l, a, training, record, out=None, ldy=None, **kw):
+        o = orig_conv(l, a, training, record, out, ldy, **kw)
         if l.name == "conv1":
             dev["stem"] = o
         return o

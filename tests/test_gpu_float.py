@@ -160,8 +160,8 @@ def test_float_train_step_vs_fp32_definition(F, name, res, batch):
     run = model.hip_runner()
     assert type(run).__name__ == "FloatRunner"
     dev_caps, orig_conv, orig_block = {}, run._conv, run._block
-    def conv(l, a, training, record, out=None, ldy=None):
-        o = orig_conv(l, a, training, record, out, ldy)
+    def conv(l, a, training, record, out=None, ldy=None, **kw):
+        o = orig_conv(l, a, training, record, out, ldy, **kw)
         if l.name == "conv1":
             dev_caps["stem"] = o
         return o
@@ -503,3 +503,64 @@ def test_float_dw_forward_row_form_vs_fp64(case, prec):
     flat = ref.reshape(-1, c)
     assert _rel(sums[0, :c], flat.sum(0)) <= 1e-4 and _rel(sums[1, :c], (flat * flat).sum(0)) <= 1e-4
     assert float(sums[2:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(3, 1, 14, 96, 5, 1), (5, 2, 14, 672, 3, 1), (5, 1, 7, 1440, 4, 0), (3, 2, 13, 32, 3, 1), (5, 1, 14, 360, 2, 1)],
+                         ids=lambda c: "k%d_s%d_h%d_c%d_n%d_relu%d" % c)
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_float_dw_fed_from_kept_conv_output_equals_emit_then_conv(case, prec):
+    """frost_float_dw_src / frost_float_dw_wgrad_src (BN + ReLU of the layer in front applied to its kept conv output as the window is loaded) against
+    frost_float_ew mode 1 followed by frost_float_dw / frost_float_dw_wgrad on the emitted activation.  fp32 mode: the same values enter the same arithmetic --
+    conv output bit-identical, statistics and weight gradient to the summation order.  bf16 mode: the two-pass form rounds the activation to bf16 on the way
+    (2^-9 relative per element); both are held to the fp64 definition instead."""
+    from frostnet_amd import _lib as L
+    k, s, h, c, n, relu_src = case
+    sfx = "" if prec == "bf16" else "_f32"
+    g = torch.Generator().manual_seed(5300 + 100 * k + 10 * s + h + c)
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // s + 1
+    cpad = (c + 15) // 16 * 16
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    wgt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    pack = torch.zeros(k * k, cpad)
+    pack[:, :c] = wgt.reshape(c, k * k).t()
+    pack = pack.cuda()
+    scoef = torch.zeros(8, cpad)
+    scoef[0, :c] = torch.rand(c, generator=g) + 0.5
+    scoef[1, :c] = torch.randn(c, generator=g) * 0.3
+    scoef = scoef.cuda()
+    c1 = torch.randn(n, h, h, c, generator=g).to(dt).cuda()
+    dcg = (torch.randn(n, ho, ho, c, generator=g) * 0.1).to(dt).cuda()
+
+    def desc(**kw):
+        d = L.FrostFDesc()
+        for key, v in kw.items():
+            setattr(d, key, v)
+        return L.struct_to_tensor(d, "cuda")
+    stats = [torch.zeros(8 * 4 * cpad, dtype=torch.float64, device="cuda") for _ in range(2)]
+    src_tab = desc(coef=scoef.data_ptr(), cout=c, cpad=cpad, fp32=int(prec == "fp32"))
+    tabs = [desc(pack=pack.data_ptr(), stat=st.data_ptr(), cout=c, cin_g=1, kk=k * k, kind=1, cpad=cpad, fp32=int(prec == "fp32")) for st in stats]
+    y1 = torch.empty(n, h, h, c, dtype=dt, device="cuda")
+    cv = [torch.full((n, ho, ho, c), float("nan"), dtype=dt, device="cuda") for _ in range(2)]
+    dw = [torch.zeros(c, k * k, device="cuda") for _ in range(2)]
+    L.call("frost_float_ew" + sfx, L.ptr(src_tab), L.ptr(c1), n * h * h, c, relu_src, 1, None, 0, L.ptr(y1), c, L.stream())
+    L.call("frost_float_dw" + sfx, L.ptr(tabs[0]), L.ptr(y1), n, h, h, c, k, s, 1, 0, None, L.ptr(cv[0]), L.stream())
+    L.call("frost_float_dw_wgrad" + sfx, L.ptr(dcg), L.ptr(y1), n, h, h, c, k, s, L.ptr(dw[0]), L.stream())
+    L.call("frost_float_dw_src" + sfx, L.ptr(tabs[1]), L.ptr(c1), L.ptr(src_tab), relu_src, n, h, h, c, k, s, 1, 0, L.ptr(cv[1]), L.stream())
+    L.call("frost_float_dw_wgrad_src" + sfx, L.ptr(dcg), L.ptr(c1), L.ptr(src_tab), relu_src, n, h, h, c, k, s, L.ptr(dw[1]), L.stream())
+    torch.cuda.synchronize()
+    sums = [st.view(8, 4, cpad).sum(0)[:2, :c] for st in stats]
+    if prec == "fp32":
+        assert torch.equal(cv[0].view(torch.int32), cv[1].view(torch.int32))
+        assert _rel(sums[1], sums[0]) <= 1e-9 and _rel(dw[1], dw[0]) <= 2e-6
+    else:
+        y64 = c1.float().cpu().double() * scoef[0, :c].cpu().double() + scoef[1, :c].cpu().double()
+        if relu_src:
+            y64 = torch.relu(y64)
+        xin = y64.permute(0, 3, 1, 2).contiguous()
+        wt = wgt.double().clone().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xin, wt, stride=s, padding=pad, groups=c)
+        ref.backward(dcg.float().cpu().double().permute(0, 3, 1, 2))
+        refo = ref.detach().permute(0, 2, 3, 1)
+        assert _rel(cv[1].float().cpu(), refo) <= 3e-3 and _rel(cv[0].float().cpu(), refo) <= 5e-3
+        assert _rel(dw[1].cpu(), wt.grad.reshape(c, k * k)) <= 1e-4 and _rel(dw[0].cpu(), wt.grad.reshape(c, k * k)) <= 4e-3
