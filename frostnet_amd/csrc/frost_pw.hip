@@ -114,6 +114,14 @@ __device__ __forceinline__ void pw_dma_tile(const uint8_t* src, uint8_t* dst, in
   const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)dst);
   for (int u = w; u < nunits; u += 8) pw_glds16(src + u * 1024 + lane * 16, lbase + u * 1024);
 }
+// DMA of `nbytes` (multiple of 16) contiguous bytes, 16-byte aligned on both sides; the last unit may be partial (lanes past the end are masked off)
+__device__ __forceinline__ void pw_dma_bytes(const uint8_t* src, uint8_t* dst, int nbytes, int tid) {
+  const int lane = tid & 63; const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nunits = (nbytes + 1023) >> 10;
+  const uint32_t lbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)dst);
+  for (int u = w; u < nunits; u += 8)
+    if (u * 1024 + lane * 16 < nbytes) pw_glds16(src + u * 1024 + lane * 16, lbase + u * 1024);
+}
 #define PW_WB_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
 __device__ __forceinline__ void pw_wait_barrier(int n_younger) {      // n_younger: wave-uniform lower bound, see above
   switch (n_younger) {
@@ -199,9 +207,13 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   } else if (MODE == M_BRED) {
     for (int c = tid; c < p.cpad; c += 512) { l_f1[c] = 0.0f; l_f2[c] = 0.0f; }
   }
-  if (RES) for (int i = tid; i < (wl_bytes >> 4); i += 512) ((uint4*)wl)[i] = ((const uint4*)p.wpack)[i];
+  // resident weights / weight sums / (emit) coefficient rows go to LDS by DMA: issued from inline asm they put no wait into the code that follows, so every
+  // prologue copy travels in ONE memory round trip (as register copies each loop ended in a wait for its own loads: 3 - 4 round trips at the head of every launch);
+  // the __syncthreads() below (vmcnt(0) + barrier) is their completion point
+  if (RES) pw_dma_tile(p.wpack, (uint8_t*)wl, wl_bytes, tid);
+  if (RES && MODE != M_DGRAD) pw_dma_bytes((const uint8_t*)p.wsum, (uint8_t*)wsl, p.cpad * 4, tid);
   if (cres) {
-    if (MODE == M_EMIT) for (int i = tid; i < 2 * p.cpad; i += 512) ((float*)cl)[i] = p.coef[i];        // rows A, B
+    if (MODE == M_EMIT) pw_dma_bytes((const uint8_t*)p.coef, (uint8_t*)cl, 2 * p.cpad * 4, tid);        // rows A, B
     if (MODE == M_BRED || MODE == M_BDC) {     // folded rows (see the backward epilogue): M row <- -M*R, S1 row <- E, S2 row <- F
       float* c2 = (float*)cl;
       for (int c = tid; c < p.cpad; c += 512) {
@@ -213,7 +225,6 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       }
     }
   }
-  if (RES && MODE != M_DGRAD) for (int i = tid; i < p.cpad; i += 512) ((int*)wsl)[i] = p.wsum[i];
   // the data gradient's K tail reads past a dc row (next row / other buffer / the 64-byte pad): stale LDS bytes x zero weights must not be NaN
   if (FUSE) {
     for (int i = tid; i < (p.io_bytes >> 4); i += 512) ((uint4*)(smem + xs_bytes))[i] = make_uint4(0, 0, 0, 0);
@@ -796,6 +807,7 @@ static int pw_spec(const PwP& p, bool io_std) {
 }
 template <int MODE, int WP>
 static int launch_pw(PwP& p, hipStream_t s) {
+  FROST_REQUIRE((((uintptr_t)p.wpack | (uintptr_t)p.wsum | (uintptr_t)p.coef) & 15) == 0, "pw: weight pack, weight sums and coefficient rows must be 16-byte aligned (LDS DMA)");
   size_t lds = p.gl ? (size_t)2 * p.tile_bytes + 64 : (size_t)BP * p.kstr + 64;
   if (MODE == M_STATS) lds += (size_t)p.cpad * 24;
   if (MODE == M_BRED) lds += (size_t)p.cpad * 8;
