@@ -16,6 +16,8 @@
  *    fake-quantised tensor min/max, 1/scale, observer_enabled / fake_quant_enabled.  torch's module buffers are views
  *    into these records.
  *  - gradients of activations: bf16, NHWC.  Parameter gradients: fp32.
+ *  - alignment: tensors, weight packs, weight sums and coefficient rows are 16-byte aligned (vector loads and LDS DMA; the pointwise entries check
+ *    the three tables and return an argument error otherwise).
  */
 #ifndef FROST_HIP_H
 #define FROST_HIP_H
