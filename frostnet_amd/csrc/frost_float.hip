@@ -872,7 +872,7 @@ static int float_ew_any(const FrostFDesc* desc, const ET* cv, int64_t npix, int 
   const int cpad = round_up(c, 16); const int c8n = c >> 3;
   const int64_t tot = npix * c8n;
   static int rcap = -1;
-  if (rcap < 0) { const char* e = getenv("FROST_FEW_CAP"); rcap = e ? atoi(e) : 512; }
+  if (rcap < 0) { const char* e = getenv("FROST_FEW_CAP"); rcap = e ? atoi(e) : 256; }      // (512 -> 256: -0.23 ms per step; 128: +0.2)
   int64_t grid = (tot + 255) / 256; const int64_t cap = (mode == F_BRED) ? rcap : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;
   const size_t lds = (mode == F_BRED) ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
