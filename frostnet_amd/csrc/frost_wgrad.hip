@@ -250,7 +250,7 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
   if (cin > 64 && cout > 64) {      // wide layers: 128x128 tiles, quadrant-per-wave
     const int ntile = ((cout + BT - 1) / BT) * ((cin + BT - 1) / BT);
-    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 256;     // one 8-wave workgroup per CU: the kernel runs beside the main stream (512 = full residency measured 0.6 % slower end to end, 128 also slower)
+    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 128;     // the kernel runs beside the main stream and competes with it for bandwidth: step 22.05 / 21.99 / 21.91 / 21.94 / 21.87 / 22.1 / 22.18 ms at 256 / 224 / 192 / 160 / 128 / 96 / 64 (end of round 3, interleaved runs; 512 = full residency: 22.3)
     int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
     int xmap; nsplit = xcd_round(nsplit, nblk, &xmap);
     hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(512), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit, xmap);
