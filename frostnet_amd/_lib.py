@@ -234,12 +234,15 @@ class Profiler:
 
 
 PROFILER = None
+CALL_LOG = None      # tests: set to a list to record the name of every C-ABI entry launched (which kernel family a case engaged)
 
 
 def call(name, *args, prof=None):
     """Launch one C-ABI entry on the current stream. prof=(label, algorithmic_bytes) tags it for the Profiler."""
     lib = load_library()
     p = PROFILER
+    if CALL_LOG is not None:
+        CALL_LOG.append(name)
     if p is not None and prof is not None and (p.only is None or p.only == prof[0]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

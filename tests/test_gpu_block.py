@@ -4,8 +4,10 @@ conv1 -> conv2 -> reduce_conv of a CascadePreExBottleneck (/root/reference/frost
   conv1 statistics (k_pw) -> frost_block_expand_dw_stats -> frost_block_dw_reduce -> reduce emit (frost_pw_ew)
 instead of six launches.  Same integer accumulators, same quantisation expressions, exact integer statistics: EVERY result must be bit-identical --
 conv1 / conv2 / reduce outputs, the kept integer conv output, BN coefficient rows, running statistics and the observers' records.  The layer-by-layer
-kernels themselves are held to the oracle and the reference goldens in test_gpu_ops / test_gpu_prod / test_gpu_model; the whole-network tests
-(test_gpu_model, test_gpu_prod) run with the block kernels on (default), so they cover the composition too."""
+kernels themselves are held to the oracle and the reference goldens in test_gpu_ops / test_gpu_prod / test_gpu_model.  The block kernels engage only in
+training mode with live observers on 14x14 / 7x7 maps, i.e. NOT in the 64-97 px training tests nor in the 224-px eval tests; their direct comparisons with
+the reference / the oracle are tests/test_gpu_model.py::test_g4_block_true_shapes (reference goldens g4t_* at the true shapes, forward + backward, engagement
+asserted) and tests/test_gpu_prod.py::test_large224_train_forward_block_by_block (Large @224 training forward against the oracle)."""
 import pytest
 import torch
 

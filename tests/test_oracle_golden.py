@@ -196,6 +196,43 @@ def test_g4_block(golden, name, tag):
                                        atol=1e-7, err_msg=key)
 
 
+G4T = ["l31", "l33", "l36", "l41", "l43", "l50"]
+
+
+@pytest.mark.parametrize("name", G4T)
+def test_g4_block_true_shapes(golden, name):
+    """The bottlenecks of FrostNet-Large's 14x14 / 7x7 stages at their TRUE shapes (the shapes the device's block kernels take): the
+    oracle's indices are the reference's except on ties of the reference's own fp32 sums (<= 1 step on <= 1e-4 of the elements)."""
+    g = golden(f"g4t_{name}_q")
+    cin, cout, k, s, e, r, H, N, xseed, gseed, wseed = [int(v) for v in g["spec"]]
+    bc = O.block_cfg(cin, cout, k, e, r, s)
+    P, B = init_from_fixture(g, wseed, True)
+    P = {"B." + k_: v for k_, v in P.items()}
+    qs = O.QState({"B." + k_: v for k_, v in B.items()})
+    x = ((T(g["x_idx"].astype(np.float32)) - float(g["in_qp"][1])) * float(g["in_qp"][0])).requires_grad_(True)
+    for step in range(2):
+        x.grad = None
+        for p in P.values():
+            p.grad = None
+        y = O.block_forward(P, qs, "B", x, bc, True, True)
+        y.backward(T(O.synth(tuple(y.shape), gseed + 50 * step)))
+        sc, zp = float(g[f"s{step}_yqp"][0]), float(g[f"s{step}_yqp"][1])
+        idx = torch.round(y.detach() / sc + zp).to(torch.int16)
+        d = (idx - T(g[f"s{step}_yidx"]).to(torch.int16)).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 1e-4, (name, step, int(d.max()), float((d > 0).float().mean()))
+        np.testing.assert_allclose(x.grad.numpy(), g[f"s{step}_dx"], rtol=1e-3, atol=1e-5 * float(np.abs(g[f"s{step}_dx"]).max()))
+        for key in g.files:
+            if key.startswith(f"s{step}_grad/"):
+                pn = "B." + key[len(f"s{step}_grad/"):].replace("/", ".")
+                check_pack(P[pn].grad, g[key], rtol=1e-3)
+        for key, v in unpack_state(g, f"s{step}_sd/").items():
+            mine = qs.sd.get("B." + key)
+            if mine is None:
+                continue
+            np.testing.assert_allclose(mine.reshape(-1).double().numpy(), v.reshape(-1).double().numpy(), rtol=1e-6,
+                                       atol=1e-7, err_msg=key)
+
+
 # ------------------------------------------------------------------------------------------ G5
 def _net(mode, quantized, seed0=5000):
     cfg = O.net_cfg(mode, 1.0)

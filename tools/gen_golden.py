@@ -238,6 +238,52 @@ def g4_blocks():
                  init_keys=keys, init_shapes=shapes, init_ndims=ndims, **outs)
 
 
+
+# ------------------------------------------------------------------------------------------ G4 at true shapes
+def g4_true_shapes():
+    """G4 at the TRUE shapes of FrostNet-Large's 14x14 / 7x7 bottlenecks (frostnet.py:176-198 rows 11, 13, 17, 19, 21, 23), where the
+    device's block kernels (csrc/frost_block.hip) engage: N = 4 ... 7 images, two training steps, forward indices + dx + every parameter
+    gradient + state.  y is stored as uint8 indices + (scale, zero_point) (y = (idx - zp) * scale exactly)."""
+    ref, _ = refshim.load_frostnet()
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat
+    specs = [  # name, cin, cout, k, s, e, r, H, N
+        ("l31", 80, 80, 5, 1, 3, 4, 14, 4),
+        ("l33", 80, 96, 5, 1, 6, 4, 14, 4),
+        ("l36", 96, 96, 3, 1, 3, 4, 14, 5),
+        ("l41", 192, 192, 5, 1, 6, 4, 7, 6),
+        ("l43", 192, 192, 5, 1, 3, 4, 7, 7),
+        ("l50", 192, 320, 5, 1, 6, 2, 7, 6),
+    ]
+    for i, (name, cin, cout, k, s, e, r, H, N) in enumerate(specs):
+        m = ref.CascadePreExBottleneck(cin, cout, quantized=True, kernel_size=k, stride=s, expand_ratio=e, reduce_factor=r)
+        keys, shapes, ndims = load_synth(m, 4600 + 100 * i)
+        m.train()
+        for mod in m.modules():
+            if type(mod) in (ref.ConvBNReLU, ref.ConvBN):
+                mod.fuse_model()
+        m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+        prepare_qat(m, inplace=True)
+        in_scale, in_zp = 0.0187, 109
+        xi = np.clip(np.round(synth((N, cin, H, H), 480 + i) * 45 + 120), 0, 255).astype(np.uint8)
+        x = ((T(xi.astype(np.float32)) - in_zp) * in_scale).requires_grad_(True)
+        outs = {}
+        last = m.skip_add if (s == 1 and cin == cout) else m.reduce_conv.conv[0]
+        for step in range(2):
+            x.grad = None
+            m.zero_grad()
+            y = m(x)
+            g = T(synth(tuple(y.shape), 490 + i + 50 * step))
+            y.backward(g)
+            fq = last.activation_post_process
+            outs[f"s{step}_yidx"] = fq_idx(y, fq).to(torch.uint8)
+            outs[f"s{step}_yqp"] = np.array([float(fq.scale[0]), float(fq.zero_point[0])])
+            outs[f"s{step}_dx"] = x.grad.clone()
+            for pn, p in m.named_parameters():
+                outs[f"s{step}_grad/" + pn.replace(".", "/")] = grad_pack(p.grad)
+            outs.update(sd_np(m.state_dict(), f"s{step}_sd/"))
+        save(f"g4t_{name}_q", spec=np.array([cin, cout, k, s, e, r, H, N, 480 + i, 490 + i, 4600 + 100 * i]),
+             in_qp=np.array([in_scale, in_zp]), x_idx=xi, init_keys=keys, init_shapes=shapes, init_ndims=ndims, **outs)
+
 # ------------------------------------------------------------------------------------------ G5
 def _pgrads(net):
     ps = list(net.named_parameters())
@@ -607,8 +653,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g4t"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection, g12=g12_fbgemm, g13=g13_convert_fbgemm)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection, g12=g12_fbgemm, g13=g13_convert_fbgemm, g4t=g4_true_shapes)
     for w in which:
         fns[w]()
