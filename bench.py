@@ -66,19 +66,48 @@ def cpu_baseline(res=224, batch=64, timed=3):
                        f"FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU kernels via oracle/frost_oracle.py")
 
 
-def pmc_traffic(label, batch):
-    """HBM bytes per launch of one kernel family from the committed PMC passes (profiles/r03_kernels_b<batch>.json (or r02_), made by
-    tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same step, gfx950 correction applied).
-    Counters cannot be collected from inside this process, so the number is the committed one or null."""
+PMC_TAGS = ("r04", "r03", "r02")
+
+
+def pmc_table(batch):
+    """The committed PMC family table of this same step (profiles/r0N_kernels_b<batch>.json, made by tools/collect_profiles.sh: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied).  Counters cannot be collected from inside this process, so traffic numbers are the
+    committed ones or null.  Returns (document, relative path) or (None, None)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r03", "r02"):
+    for tag in PMC_TAGS:
         path = os.path.join(here, "profiles", f"{tag}_kernels_b{batch}.json")
         try:
-            fam = json.load(open(path))["families"][label]
-            return int(fam["hbm_bytes_per_launch"]), os.path.relpath(path, here)
-        except (OSError, KeyError, ValueError):
+            return json.load(open(path)), os.path.relpath(path, here)
+        except (OSError, ValueError):
             continue
     return None, None
+
+
+def pmc_traffic(label, batch):
+    """HBM bytes per launch of one kernel family from the committed PMC passes."""
+    doc, path = pmc_table(batch)
+    try:
+        return int(doc["families"][label]["hbm_bytes_per_launch"]), path
+    except (TypeError, KeyError, ValueError):
+        return None, None
+
+
+def pmc_step_traffic(batch):
+    """Whole-step HBM bytes (sum over every kernel family of the committed table) and the launches per step of that pass."""
+    doc, path = pmc_table(batch)
+    if doc is None:
+        return None, None, None
+    if "hbm_bytes_per_step" in doc:
+        return int(doc["hbm_bytes_per_step"]), doc.get("kernel_launches_per_step"), path
+    fams = doc.get("families", {})
+    steps = None
+    if "gradboost" in fams and fams["gradboost"].get("FETCH_SIZE_launches"):
+        steps = fams["gradboost"]["FETCH_SIZE_launches"]            # one optimizer launch per step of the counter pass
+    if not steps:
+        return None, None, path
+    tot = sum(v["hbm_bytes_per_launch"] * v.get("FETCH_SIZE_launches", 0) / steps for v in fams.values() if "hbm_bytes_per_launch" in v)
+    n = sum(v.get("FETCH_SIZE_launches", 0) / steps for k, v in fams.items() if k != "torch_elementwise")
+    return int(tot), round(n, 1), path
 
 
 def side_workload(args, dev):
@@ -536,14 +565,23 @@ def main():
         s2 = L.PROFILER.summary()[dom]
         L.PROFILER = None
         achieved = s2["bytes_per_launch"] / (s2["avg_ms"] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom, args.batch if args.res == 224 and args.mode == "large" else -1)
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
-                        avg_launch_ms=round(s2["avg_ms"], 4), launches_per_step=s2["launches"] // 3,
-                        algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),
-                        whole_step=dict(achieved=round(value / world * ALGO_BYTES_PER_IMG / 1e9, 1), unit="GB/s",
-                                        frac=round(value / world * ALGO_BYTES_PER_IMG / 1e9 / HBM_PEAK_GBS, 4),
-                                        algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG),
+        pmc_batch = args.batch if args.res == 224 and args.mode == "large" else -1
+        traffic, traffic_src = pmc_traffic(dom, pmc_batch)
+        step_traffic, step_launches, step_src = pmc_step_traffic(pmc_batch)
+        algo_step = ALGO_BYTES_PER_IMG * args.batch
+        step_gbs = value / world * ALGO_BYTES_PER_IMG / 1e9
+        # The headline roofline figure is the WHOLE STEP: algorithmic bytes of one image (layer-granular) x images / s over the
+        # 8 TB/s HBM peak; `traffic` = HBM bytes of one step summed over every kernel family of the committed counter passes.  The dominant kernel family
+        # (the contract's per-kernel figure: algorithmic bytes per launch / average launch duration by HIP events on the launch stream) is `dominant_kernel`.
+        roofline = dict(bound="hbm", kernel="whole step", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(step_gbs / HBM_PEAK_GBS, 4), traffic=step_traffic, traffic_source=step_src,
+                        traffic_total_bytes_per_step=step_traffic, algorithmic_bytes_per_step=algo_step,
+                        traffic_ratio=(round(step_traffic / algo_step, 3) if step_traffic else None),
+                        kernel_launches_per_step=step_launches, algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG,
+                        dominant_kernel=dict(kernel=dom, achieved=round(achieved, 1), unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                                             traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(s2["avg_ms"], 4),
+                                             launches_per_step=s2["launches"] // 3, algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),
+                                             share_of_step=round(summ[dom]["total_ms"] / max(1e-9, sum(v["total_ms"] for v in summ.values())), 3)),
                         # secondary roof (north_star's "MFMA utilisation"): fwd convs on the int8 MFMA (861.6 MFLOP/img), dgrad + wgrad on
                         # the bf16 MFMA (1701.6 MFLOP/img); dense peaks 5 POP/s int8, 2.5 PFLOP/s bf16.  The path is HBM-bound.
                         mfma=dict(achieved=round(value / world * FLOPS_PER_IMG / 1e12, 2), unit="TFLOP/s",

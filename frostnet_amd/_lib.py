@@ -35,6 +35,7 @@ class FrostFDesc(C.Structure):
                 ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("fp32", C.c_int32)]
 
 
+ABI_VERSION = 3
 TICKET_WORDS = 40      # FROST_TICKET_WORDS: zeroed uint32 words behind every last-workgroup-done ticket (main counter + 32 sub-counters)
 
 
@@ -76,6 +77,8 @@ class FrostOptHyper(C.Structure):
 
 _PROTOS = {
     "frost_abi_version": [],
+    "frost_ticket_words": [],
+    "frost_fin_desc_bytes": [],
     "frost_minmax_f32": [P, L, P, P],
     "frost_fill_minmax": [P, I, P],
     "frost_minmax_input": [P, I, I, I, I, L, L, L, L, P, P],
@@ -201,6 +204,10 @@ def load_library():
         fn.argtypes = args
         fn.restype = C.c_int       # (frost_pw_bwd_fused_ok / frost_abi_version return a value, not a status)
     lib.frost_last_error.restype = C.c_char_p
+    # the sizes a binding must agree on with the library (the ticket buffers grew from 1 to 40 words, FrostFinDesc gained two fields)
+    if lib.frost_abi_version() != ABI_VERSION or lib.frost_ticket_words() != TICKET_WORDS or lib.frost_fin_desc_bytes() != C.sizeof(FrostFinDesc):
+        raise RuntimeError(f"{LIB_PATH}: ABI mismatch (library abi {lib.frost_abi_version()} / ticket words {lib.frost_ticket_words()} / FrostFinDesc "
+                           f"{lib.frost_fin_desc_bytes()} B, binding {ABI_VERSION} / {TICKET_WORDS} / {C.sizeof(FrostFinDesc)} B): rebuild with `python __graft_entry__.py`")
     _lib = lib
     return lib
 

@@ -7,6 +7,8 @@ static thread_local char g_err[256] = "";
 extern "C" void frost_set_error(const char* msg) { strncpy(g_err, msg, sizeof(g_err) - 1); }
 extern "C" const char* frost_last_error(void) { return g_err; }
 extern "C" int frost_abi_version(void) { return FROST_ABI_VERSION; }
+extern "C" int frost_ticket_words(void) { return FROST_TICKET_WORDS; }
+extern "C" int frost_fin_desc_bytes(void) { return (int)sizeof(FrostFinDesc); }
 int frost_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -36,7 +36,9 @@ _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit +
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
 _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # largest pixel count whose reduce pass runs on the chunked kernel (the dc pass always does)
-_PW_FUSE_MINPIX = int(os.environ.get("FROST_PW_FUSE_MINPIX", "150000"))   # fused pointwise backward only from this pixel count up; below (the 14x14 / 7x7 squeeze convs): dc + data gradient, weight gradient on the second stream (-0.08 ms)
+# fused pointwise backward only on maps of at least this many pixels PER IMAGE (28 x 28 and up); below -- the squeeze convs of the 14 x 14 / 7 x 7 stages -- dc + data gradient,
+# weight gradient on the second stream (-0.08 ms at B = 512).  A per-image rule: the decision is about which STAGE a layer belongs to and must not flip with the batch size
+_PW_FUSE_MINMAP = int(os.environ.get("FROST_PW_FUSE_MINMAP", "400"))
 _PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
@@ -633,7 +635,7 @@ class Engine:
         self._ensure_grad(l)
         gout = y.grad
         s = stream()
-        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.npix >= _PW_FUSE_MINPIX)
+        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)
                   and bool(L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)))      # dc stays in LDS there: no buffer
         dc = None if (fused or blk_dw) else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)

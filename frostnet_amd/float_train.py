@@ -234,6 +234,16 @@ class FloatRunner:
         self.layers.append(l)
         return l
 
+    def rng_state(self):
+        """Dropout Philox stream {seed, draws}: the float warm-up shares the device generator of the fake-quant runner (runner.dropout_mask),
+        so harness.save_checkpoint / load_checkpoint resume it the same way."""
+        from .runner import rng_state
+        return rng_state(self)
+
+    def set_rng_state(self, state):
+        from .runner import set_rng_state
+        set_rng_state(self, state)
+
     def still_valid(self):
         m = self.model
         return self._sig == tuple(p.data_ptr() for p in m.parameters()) + tuple(b.data_ptr() for b in m.buffers())

@@ -20,6 +20,18 @@ except Exception:  # pragma: no cover
         return fn
 
 MODEL_REGISTRY = {}
+_FLAG_EPOCH = [0]      # bumped by every `.apply(fn)` on a module of this file: the runners compare it with the epoch of their host-side summary of the per-site enable flags
+
+
+class _FlagNotify(nn.Module):
+    """`model.layer3.apply(torch.quantization.disable_observer)` (or on a single block / ConvBNReLU) writes the per-site `observer_enabled` /
+    `fake_quant_enabled` flags -- device memory on the HIP path.  The write itself is honoured per site at once; the host-side summary a runner keeps of
+    them (frostnet_amd.runner.FrostRunner._observe_hint) is invalidated here, whichever sub-module the call was made on."""
+
+    def apply(self, fn):
+        out = super().apply(fn)
+        _FLAG_EPOCH[0] += 1
+        return out
 
 
 def _fuse(seq, names):
@@ -31,7 +43,7 @@ def _fuse(seq, names):
         aoq.fuse_modules(seq, names, inplace=True)
 
 
-class ConvBNReLU(nn.Module):
+class ConvBNReLU(_FlagNotify):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
         super(ConvBNReLU, self).__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
@@ -45,7 +57,7 @@ class ConvBNReLU(nn.Module):
         _fuse(self.conv, ['0', '1', '2'])
 
 
-class ConvBN(nn.Module):
+class ConvBN(_FlagNotify):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1):
         super(ConvBN, self).__init__()
         self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
@@ -81,7 +93,7 @@ class Hswish(nn.Module):
         return out
 
 
-class ConvBNHswish(nn.Module):
+class ConvBNHswish(_FlagNotify):
     """Conv -> BatchNorm -> hard-swish: the reference's `_ConvBNHswish` (mobilenetv3.py:72-88) in FrostNet's layer vocabulary (`conv` = the fusable
     Conv2d + BatchNorm2d pair, `act` = Hswish)."""
 
@@ -108,7 +120,7 @@ def _make_divisible(v, divisor=8, min_value=None):
     return new_v
 
 
-class CascadePreExBottleneck(nn.Module):
+class CascadePreExBottleneck(_FlagNotify):
     """The Frost bottleneck (frostnet.py:81-145)."""
 
     def __init__(self, in_channels, out_channels, quantized=False, kernel_size=3, stride=1, dilation=1, expand_ratio=6,
@@ -185,7 +197,7 @@ _SETTINGS = {
 }
 
 
-class _FrostBase(nn.Module):
+class _FrostBase(_FlagNotify):
     def _make_layer(self, block, block_setting, width_mult, dilation=1):
         layers = list()
         for k, c, e, r, s in block_setting:
@@ -238,7 +250,7 @@ class _FrostBase(nn.Module):
         d = self.__dict__.copy()
         r = d.pop("_hip_runner", None)
         d.pop("_bf16_infer", None)
-        d.pop("_hip_converted", None)
+        # `_hip_converted` stays: a copy of a converted model has no frozen int8 weights; its forward raises (hip_runner) rather than computing the QAT eval graph
         arena = getattr(getattr(r, "qa", None), "t", None)
         if arena is not None:
             import copy as _copy
@@ -286,6 +298,13 @@ class _FrostBase(nn.Module):
         if r is not None and not qat and want is not None and getattr(r, "precision", want) != want:
             r = None
         if r is None or r.model is not self or r.is_qat != qat or not r.still_valid():
+            if qat and self.__dict__.get("_hip_converted", False):
+                # the converted state (int8 packs frozen at convert time) lived on the runner that is gone (parameters or buffers moved, or this is a
+                # deepcopy / unpickled copy of a converted model): converting again would move the weight observers a second time, silently running the
+                # fake-quant eval graph would be a different model.  Refuse -- on EVERY call: no runner is cached while the flag is set.
+                self.__dict__.pop("_hip_runner", None)
+                raise RuntimeError("this model was hip_convert()-ed and its device executor is gone (parameters or buffers moved, or the model was copied / "
+                                   "unpickled): the frozen int8 weights went with it; rebuild the QAT model, load its state and call hip_convert() again")
             if qat:
                 from .runner import FrostRunner
                 r = FrostRunner(self)
@@ -294,11 +313,6 @@ class _FrostBase(nn.Module):
                 r = FloatRunner(self)
             r.is_qat = qat
             self.__dict__["_hip_runner"] = r
-            if qat and self.__dict__.get("_hip_converted", False) and not getattr(r, "converted", False):
-                # the converted state (int8 packs frozen at convert time) lived on the runner that was just replaced: converting again would move the
-                # weight observers a second time, silently running the fake-quant eval graph would be a different model -- refuse instead
-                raise RuntimeError("this model was hip_convert()-ed and its device executor had to be rebuilt (parameters or buffers moved): the frozen int8 "
-                                   "weights are gone; rebuild the QAT model, load its state and call hip_convert() again")
         return r
 
 
@@ -338,7 +352,9 @@ class FrostNet(_FrostBase):
             raise RuntimeError("hip_convert needs the QAT-prepared model (fuse_model + prepare_qat), like torch.quantization.convert")
         self.eval()
         self.hip_runner().convert()
-        self.__dict__["_hip_converted"] = True       # survives a rebuild of the runner (model.to(), a moved parameter): hip_runner() re-applies convert()
+        # marks the module tree: if the runner holding the frozen int8 weights is ever lost (model.to(), a moved parameter, a deepcopy / pickle of the
+        # model -- __getstate__ keeps this flag and drops the runner), hip_runner() raises on every call instead of running the fake-quant eval graph
+        self.__dict__["_hip_converted"] = True
         return self
 
     def hip_infer_bf16(self, x):

@@ -175,5 +175,7 @@ def load_checkpoint(model, optimizer, filenameCheckpoint="checkpoint.pth.tar", m
     if "hip_rng" in ck and hasattr(model, "hip_runner"):
         dev = _device_of(model)
         if dev.type == "cuda":
-            model.hip_runner().set_rng_state(ck["hip_rng"])
+            r = model.hip_runner()
+            if hasattr(r, "set_rng_state"):
+                r.set_rng_state(ck["hip_rng"])
     return ck

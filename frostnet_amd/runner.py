@@ -72,6 +72,8 @@ def dropout_mask(runner, n, keep):
         runner._drop_ctr = torch.zeros(2, dtype=torch.int64, device=runner.device)        # {draw, arrival ticket}
         runner._drop_seed = dropout_seed()
     out = torch.empty(n, dtype=torch.float32, device=runner.device)
+    if torch.cuda.is_current_stream_capturing():
+        runner._drop_captured = True
     L.call("frost_dropout_mask", L.ptr(runner._drop_ctr), runner._drop_seed, n, keep, L.ptr(out), L.stream())
     return out
 
@@ -84,7 +86,15 @@ def rng_state(runner):
 
 
 def set_rng_state(runner, state):
-    runner._drop_ctr = torch.tensor([int(state["draws"]), 0], dtype=torch.int64, device=runner.device)
+    """Restore the dropout stream.  The draw counter is written IN PLACE: a hipGraph captured earlier holds the counter's address and keeps drawing from
+    the restored position (a replaced tensor would leave the graph advancing the old one)."""
+    new = torch.tensor([int(state["draws"]), 0], dtype=torch.int64, device=runner.device)
+    if getattr(runner, "_drop_ctr", None) is None:
+        runner._drop_ctr = new
+    else:
+        runner._drop_ctr.copy_(new)
+    if getattr(runner, "_drop_seed", None) is not None and int(runner._drop_seed) != (int(state["seed"]) & 0xFFFFFFFFFFFFFFFF) and getattr(runner, "_drop_captured", False):
+        raise RuntimeError("set_rng_state: the dropout seed is a launch argument baked into the captured hipGraph; re-capture the step after restoring a different seed")
     runner._drop_seed = int(state["seed"]) & 0xFFFFFFFFFFFFFFFF
 
 
@@ -148,13 +158,18 @@ class FrostRunner:
     def _observe_hint(self, training):
         """What the host passes as `observe`: 1 = run the statistics passes and let every site's own device flag decide.  Training needs the
         statistics anyway (BatchNorm); a fully frozen network in eval skips them.  The flags live on the device (per-site switches without a host
-        round trip); the host keeps a summary that is re-read only when it may have changed -- after `model.train()` / `.eval()`,
-        `model.apply(...)` (how torch.quantization.enable/disable_observer/fake_quant are applied) or `runner.flags_dirty = True` -- not on every
-        forward, and for training as well as eval (a disabled fake-quantizer is refused in both).  A flag written straight into a sub-module's
-        buffer without any of these is honoured per site on the device at once and reaches the summary at the next mode switch."""
-        if getattr(self, "flags_dirty", True) and not torch.cuda.is_current_stream_capturing():
-            self._obs_cached = self.read_flags()
-            self.flags_dirty = False
+        round trip); the host keeps a summary.  Eval forwards re-read it every time (outside hipGraph capture); training forwards re-read it after
+        any `.apply(...)` (how torch.quantization.enable/disable_observer/fake_quant are applied) on the model OR ANY OF ITS SUB-MODULES
+        (frostnet._FLAG_EPOCH), after `model.train()` / `.eval()`, or after `runner.flags_dirty = True`.  A disabled fake-quantizer is refused in both modes.  A flag written
+        straight into a FakeQuantize buffer of a training model without any of these is honoured per site on the device at once."""
+        from . import frostnet as _F
+        if not torch.cuda.is_current_stream_capturing():
+            # eval re-reads the flags on every forward (one small device -> host read; a flag written straight into a sub-module's buffer is seen at once);
+            # training re-reads when a `.apply()` / `.train()` ran anywhere in the tree since the last read (`_FLAG_EPOCH`) or `flags_dirty` was set
+            if (not training) or getattr(self, "flags_dirty", True) or getattr(self, "_flag_epoch", -1) != _F._FLAG_EPOCH[0]:
+                self._obs_cached = self.read_flags()
+                self.flags_dirty = False
+                self._flag_epoch = _F._FLAG_EPOCH[0]
         return True if training else getattr(self, "_obs_cached", True)
 
     def rng_state(self):

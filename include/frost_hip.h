@@ -27,7 +27,12 @@
 extern "C" {
 #endif
 
-#define FROST_ABI_VERSION 2
+/* ABI history (a caller built against an older header MUST NOT call a newer library, and vice versa: check frost_abi_version() at load time)
+ *   2 -> 3 (round 3/4): every last-workgroup-done ticket buffer grew from 1 to FROST_TICKET_WORDS (40) zeroed uint32 words -- FrostFinDesc.counter, and
+ *          the state of frost_add_minmax_observe / frost_pw_ew_emit_add is {lo, hi, ticket[FROST_TICKET_WORDS]} (was {lo, hi, ticket}); FrostFinDesc gained
+ *          cat_qrec_b / cat_qrec_y.  A 1-word ticket under the new kernels is an out-of-bounds device atomic: frost_ticket_words() and
+ *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does). */
+#define FROST_ABI_VERSION 3
 
 /* qrecord field indices (floats) */
 #define FROST_Q_MIN 0
@@ -60,6 +65,8 @@ extern "C" {
 #define FROST_STATS_BYTES_PER_CH 24
 
 int frost_abi_version(void);
+int frost_ticket_words(void);      /* == FROST_TICKET_WORDS of the library that was loaded */
+int frost_fin_desc_bytes(void);    /* == sizeof(FrostFinDesc) of the library that was loaded */
 const char* frost_last_error(void);
 
 /* ---- element-wise / observer -------------------------------------------------------------------------- */

@@ -358,13 +358,17 @@ def test_convert_is_idempotent_and_refuses_a_silent_revert(engine):
     with torch.no_grad():
         b = model(x)
     assert torch.equal(a, b) and torch.equal(wmax, model.conv1.conv[0].weight_fake_quant.activation_post_process.max_val)
-    snap = copy.deepcopy(model)                           # a copy is a fresh QAT model (its own executor, not converted)
-    with torch.no_grad():
-        assert snap.eval()(x).shape == a.shape
+    snap = copy.deepcopy(model)                           # a copy carries the module tree and the "converted" mark, not the frozen int8 weights (they live on the
+    for _ in range(2):                                    # executor): it refuses to run -- on every call -- instead of serving the fake-quant eval graph
+        with pytest.raises(RuntimeError, match="hip_convert"):
+            with torch.no_grad():
+                snap.eval()(x)
     model.conv1.conv[0].weight.data = model.conv1.conv[0].weight.data.clone()        # a parameter moved: the executor must be rebuilt ...
-    with pytest.raises(RuntimeError, match="hip_convert"):
-        with torch.no_grad():
-            model(x)                                      # ... and refuses to serve the fake-quant graph in place of the converted model
+    for _ in range(3):                                    # ... and every later call still refuses (the guard used to fire only once)
+        with pytest.raises(RuntimeError, match="hip_convert"):
+            with torch.no_grad():
+                model(x)
+    assert "_hip_runner" not in model.__dict__
 
 
 def test_fused_reduce_emit_and_add_range_pass_equals_the_two_launches(engine):

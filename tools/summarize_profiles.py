@@ -66,9 +66,12 @@ def main():
             lab = family(r["Kernel_Name"])
             if lab:
                 per[lab][0].add(r["Dispatch_Id"]); per[lab][1] += float(r["Counter_Value"])
+        steps = max(1, len(per["gradboost"][0])) if "gradboost" in per else 1          # one optimizer launch per step of the pass
         for lab, (ids, kib) in per.items():
             out[lab][f"{ctr}_KiB_per_launch"] = round(kib / len(ids), 1)
             out[lab][f"{ctr}_launches"] = len(ids)
+            out[lab][f"{ctr}_KiB_per_step"] = round(kib / steps, 1)
+            out[lab]["launches_per_step"] = round(len(ids) / steps, 2)
     # MFMA / VALU counters (separate --pmc passes): per family totals per launch
     for d_ in sorted(glob.glob(f"{root}/mfma_*")):
         f = glob.glob(f"{d_}/**/*counter_collection.csv", recursive=True)
@@ -99,8 +102,12 @@ def main():
     for lab, d in out.items():
         if "FETCH_SIZE_KiB_per_launch" in d and "WRITE_SIZE_KiB_per_launch" in d:
             d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KiB_per_launch"] + d["WRITE_SIZE_KiB_per_launch"]) * 1024)
+            d["hbm_bytes_per_step"] = int((2 * d["FETCH_SIZE_KiB_per_step"] + d["WRITE_SIZE_KiB_per_step"]) * 1024)
+    hbm_step = sum(d.get("hbm_bytes_per_step", 0) for d in out.values())
+    launches_step = sum(d.get("launches_per_step", 0) for lab, d in out.items() if lab != "torch_elementwise")
     doc = dict(batch=batch, fetch_calibration=cal, correction="hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950; separate --pmc passes, eager step)",
-               stats_total_ms=round(total_ns / 1e6, 3), families=out)
+               stats_total_ms=round(total_ns / 1e6, 3), hbm_bytes_per_step=hbm_step, kernel_launches_per_step=round(launches_step, 1),
+               algorithmic_bytes_per_step=45593016 * batch, traffic_ratio=round(hbm_step / (45593016.0 * batch), 3), families=out)
     json.dump(doc, open(f"{root}/summary.json", "w"), indent=1, sort_keys=True)
     for lab, d in sorted(out.items(), key=lambda kv: -kv[1].get("total_ms", 0)):
         print(f"{lab:16s} {d}")
