@@ -289,6 +289,12 @@ class Engine:
         q_cat: that record is updated in this layer's finalize tail (`cat_observed = True` on the result; Engine.cat skips frost_cat_observe)."""
         pad = (l.k - 1) // 2
         ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
+        # frozen BatchNorm (`_freeze_stages`, frostnet_features.py:354-359: bn.eval() inside a training forward): this layer normalises with its running
+        # statistics (finalize in eval form, nothing updated); its backward is the batch-statistics one minus the S1 / S2 terms (Engine._frozen_after_reduce)
+        net_training = training
+        l.frozen = bool(training and l.bn_mod is not None and not l.bn_mod.training)
+        if l.frozen:
+            training = False
         if l.kind == "stem":      # im2col once (kept for the backward wgrad), then the pointwise int8-MFMA kernels
             xc = self.new_act(x.n, ho, wo, 40, x.q)
             call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream(),
@@ -326,7 +332,7 @@ class Engine:
                 if getattr(self, "trace", None) is not None:
                     self.trace.append((l.name, y))
                 self.tape.append(("conv", l, x, y))
-                y.cint = cint if training else None
+                y.cint = cint if net_training else None
                 return y
             if l.kind in ("pw", "stem"):
                 call("frost_pw_conv_fwd_fin", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin),
@@ -350,12 +356,16 @@ class Engine:
 
     def pair_fusable(self, l1, l2, x, training, observe):
         """conv1 -> conv2 of a bottleneck at the 14x14 / 7x7 stages: conv1's emit pass and conv2's statistics pass run as ONE launch (csrc/frost_block.hip)."""
+        if any(l.bn_mod is not None and not l.bn_mod.training for l in (l1, l2)):
+            return False          # a frozen BatchNorm (eval-form finalize) takes the layer path
         return bool(_BLOCK_PAIR and _FIN_FOLD and training and observe and l1.kind == "pw" and l2.kind == "dw" and l1.k == 1
                     and getattr(l1, "hswish", None) is None and getattr(l2, "hswish", None) is None
                     and L.load_library().frost_block_supported(x.h, x.w, l2.k, l2.stride, x.c, l1.cout))
 
     def reduce_fusable(self, l2, l3, y1):
         """conv2 -> reduce_conv: conv2's emit pass and reduce_conv's GEMM / statistics (kept-output path) as one launch."""
+        if l3 is not None and l3.bn_mod is not None and not l3.bn_mod.training:
+            return False
         return bool(_BLOCK_DWRED and _PW_KEEP and l3 is not None and l3.kind == "pw" and l3.k == 1 and l2.cout > 256 and l3.cout < l2.cout
                     and getattr(l3, "hswish", None) is None
                     and L.load_library().frost_block_dw_reduce_supported(y1.h, y1.w, l2.k, l2.stride, l2.cout, l3.cout))
@@ -364,6 +374,9 @@ class Engine:
         """`conv2(conv1(x))` of CascadePreExBottleneck.forward (frostnet.py:134-137) with the expanded tensor kept on chip between conv1's activation
         FakeQuantize and conv2's batch statistics: conv1 statistics + finalize (k_pw) -> frost_block_expand_dw_stats -> conv2 emit (k_dw3).
         Tape and saved tensors are those of two Engine.conv calls: the backward is unchanged."""
+        l1.frozen = l2.frozen = False
+        if l3 is not None:
+            l3.frozen = False
         y1 = self.new_act(x.n, x.h, x.w, l1.cout, l1.qy)
         fin1 = L.FrostFinDesc(l1.qw.data_ptr(), l1.gamma.data_ptr(), l1.beta.data_ptr(), l1.rmean.data_ptr(), l1.rvar.data_ptr(), l1.nbt.data_ptr(),
                               l1.coef.data_ptr(), l1.qy.data_ptr(), l1.fin_counter.data_ptr(), 1, int(l1.relu), 1, 0, l1.wscale.data_ptr(), None, None)
@@ -622,7 +635,11 @@ class Engine:
                                       l.coef.data_ptr(), l.w.grad.data_ptr(), l.gamma.grad.data_ptr(), l.beta.grad.data_ptr(),
                                       l.cout, l.cin_g * l.kk, l.cpad, 0, l.wscale.data_ptr())
             cache[slot] = (key, L.struct_to_tensor(arr, self.device))
+        for l in self._pending:
+            self._frozen_restore(l)
         call("frost_weight_grad_finalize_table", ptr(cache[slot][1]), len(self._pending), stream())
+        for l in self._pending:
+            self._frozen_fix_dgamma(l)
         self._pending = []
 
     @staticmethod
@@ -667,6 +684,7 @@ class Engine:
                 else:
                     call("frost_pw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, None, 0, s,
                          prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
+            self._frozen_after_reduce(l)
             if fused:
                 # dc pass + data gradient + weight gradient in one kernel: the dc tile never leaves LDS (layers with Cout*Cin <= ~19 k)
                 gx, acc = self._grad_slot(x) if x.needs_grad else (None, 0)
@@ -718,6 +736,7 @@ class Engine:
             else:
                 call("frost_dw_conv_bwd", *args, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                      prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
+            self._frozen_after_reduce(l)
             gslot = self._grad_slot(x) if x.needs_grad else (None, 0)
             if blk and not gslot[1]:
                 # 14x14 / 7x7 maps: the image's dc lives in an LDS plane; weight gradient and data gradient come from it (csrc/frost_block.hip)
@@ -753,12 +772,38 @@ class Engine:
         self._after_conv_backward(l, s)
         y.grad = None
 
+    def _frozen_after_reduce(self, l):
+        """Backward of a layer whose BatchNorm is frozen (eval form, running statistics): y = c + (beta - rm * gamma / sigma_r), so dc = gy -- the
+        batch-statistics expression dc = K1 (gy - S1/n - xhat S2/n) with K1 = 1 (what the eval-form finalize wrote) and without the S1 / S2 terms.  The dc
+        kernels (every variant) read those terms from the coefficient rows, so the rows are set aside and zeroed between the reduce pass and the dc pass;
+        _frozen_restore puts them back for the parameter-gradient finalize (dbeta = S1) and corrects dgamma."""
+        if not getattr(l, "frozen", False):
+            return
+        rows = l.coef[L.COEF_S1: L.COEF_S2 + 1]
+        l._s12 = rows.clone()
+        rows.zero_()
+
+    def _frozen_restore(self, l):
+        if getattr(l, "frozen", False) and getattr(l, "_s12", None) is not None:
+            l.coef[L.COEF_S1: L.COEF_S2 + 1].copy_(l._s12)
+
+    def _frozen_fix_dgamma(self, l):
+        """dgamma of a frozen layer: BatchNorm's own gamma path sum gy (c0 - rm)/sigma_r and the un-scaling c0 = c / (gamma/sigma_r) cancel to
+        -(rm / sigma_r) * S1; the finalize kernel computed S2 * VFRAC (the batch-statistics form) in its place -- swapped here (the fold term dot / sigma_r stays)."""
+        if getattr(l, "frozen", False) and getattr(l, "_s12", None) is not None:
+            c = l.cout
+            s1, s2 = l._s12[0][:c], l._s12[1][:c]
+            l.gamma.grad.sub_(s2 * l.coef[L.COEF_VFRAC][:c] + s1 * l.rmean / l.sigma)
+            l._s12 = None
+
     def _after_conv_backward(self, l, s):
         if self.on_layer_grads is None:
             self._pending.append(l)        # single GPU: all layers finalized by one table launch at the end of the backward
         else:
+            self._frozen_restore(l)
             call("frost_weight_grad_finalize", ptr(l.dwq), ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.coef), l.cout,
                  l.cin_g, l.kk, l.cpad, ptr(l.w.grad), ptr(l.gamma.grad), ptr(l.beta.grad), 0, ptr(l.wscale), s)
+            self._frozen_fix_dgamma(l)
 
 
 def grad_to_float(g, n, h, w, c):

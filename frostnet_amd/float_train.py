@@ -345,6 +345,11 @@ class FloatRunner:
         if x.dtype != torch.float32:
             x = x.float()
         n, _, h, w = x.shape
+        if training:
+            for l in self.layers:
+                if not l.bn.training:
+                    raise NotImplementedError(f"{l.name}: BatchNorm in eval mode inside a training forward of the FLOAT model (_freeze_stages): the float HIP "
+                                              "backward implements the batch-statistics gradient only; the QAT-prepared model supports frozen BatchNorm")
         call("frost_float_weight_prep", ptr(self._table), len(self.layers), stream())
         if not training:
             call("frost_float_bn_eval", ptr(self._table), len(self.layers), stream())

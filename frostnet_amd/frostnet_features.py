@@ -99,7 +99,7 @@ class FrostNet(_FrostBase):
 
     def _freeze_stages(self):
         """frostnet_features.py:354-359: every BatchNorm2d (also the `.bn` of a fused QAT conv) goes to eval mode, i.e. normalises
-        with its running statistics and stops updating them.  On the HIP path a *training* forward with frozen BatchNorm is refused
-        (runner._trunk): the hand-written backward implements the batch-statistics gradient only."""
+        with its running statistics and stops updating them.  The QAT-prepared model honours this per layer on the HIP path (training forward in eval
+        form + the frozen-statistics backward, engine.Engine._frozen_after_reduce; tests/test_gpu_round4.py); the float HIP path refuses it."""
         for bn in (m for m in self.modules() if isinstance(m, nn.BatchNorm2d)):
             bn.eval()

@@ -479,11 +479,8 @@ class FrostRunner:
             raise ValueError("expected an (N,3,H,W) tensor")
         if x.numel() == 0:
             raise ValueError("empty batch")
-        if training:
-            for l in self.E.layers:
-                if l.bn_mod is not None and not l.bn_mod.training:
-                    raise NotImplementedError(f"{l.name}: BatchNorm in eval mode inside a training forward (_freeze_stages): the HIP backward "
-                                              "implements the batch-statistics BatchNorm gradient only")
+        # a BatchNorm in eval mode inside a training forward (`_freeze_stages`, frostnet_features.py:354-359; mmdet's norm_eval) is honoured per layer:
+        # Engine.conv normalises with the running statistics and the backward drops the batch-statistics terms (Engine._frozen_after_reduce)
         E, obs = self.E, self._observe_hint(training)
         self._obs = obs
         E.begin_step(observe=obs)

@@ -231,11 +231,19 @@ def test_guards(fa):
     l2.backward()
     with pytest.raises(NotImplementedError):
         m(x.clone().requires_grad_(True))
-    # frozen BatchNorm inside a training forward is refused, not silently normalised with batch statistics
-    m.layer2[0].conv1.conv[0].bn.eval()
-    with pytest.raises(NotImplementedError, match="BatchNorm"):
-        m(x)
+    # frozen BatchNorm inside a training forward (`_freeze_stages`) is honoured per layer on the fake-quant path -- its running statistics do not move
+    # (parity with the oracle: tests/test_gpu_round4.py) -- and refused, not silently normalised with batch statistics, on the float path
+    bn = m.layer2[0].conv1.conv[0].bn
+    bn.eval()
+    rm, nbt = bn.running_mean.clone(), int(bn.num_batches_tracked)
+    other = m.layer2[0].conv2.conv[0].bn.running_mean.clone()
+    m(x).sum().backward()
+    assert torch.equal(rm, bn.running_mean) and int(bn.num_batches_tracked) == nbt and not torch.equal(other, m.layer2[0].conv2.conv[0].bn.running_mean)
     m.train()
+    fm = fa["F"].MODEL_REGISTRY["frostnet_small_1_0"]().cuda().train()
+    fm.layer2[0].conv1.conv[1].eval()
+    with pytest.raises(NotImplementedError, match="BatchNorm"):
+        fm(x)
     # a DataParallel replica (shares the original's runner and pointers) is refused
     rep = m._replicate_for_data_parallel()
     with pytest.raises(RuntimeError, match="one process per"):
