@@ -788,12 +788,9 @@ class Engine:
             l.coef[L.COEF_S1: L.COEF_S2 + 1].copy_(l._s12)
 
     def _frozen_fix_dgamma(self, l):
-        """dgamma of a frozen layer: BatchNorm's own gamma path sum gy (c0 - rm)/sigma_r and the un-scaling c0 = c / (gamma/sigma_r) cancel to
-        -(rm / sigma_r) * S1; the finalize kernel computed S2 * VFRAC (the batch-statistics form) in its place -- swapped here (the fold term dot / sigma_r stays)."""
-        if getattr(l, "frozen", False) and getattr(l, "_s12", None) is not None:
-            c = l.cout
-            s1, s2 = l._s12[0][:c], l._s12[1][:c]
-            l.gamma.grad.sub_(s2 * l.coef[L.COEF_VFRAC][:c] + s1 * l.rmean / l.sigma)
+        """Nothing to correct: the parameter-gradient finalize evaluates dgamma = S2 + (quantisation-residual sum) / sigma_r, which is the frozen-BatchNorm
+        gradient as well as the batch-statistics one (csrc/frost_head.hip, k_wgrad_finalize); only the stash is dropped."""
+        if getattr(l, "frozen", False):
             l._s12 = None
 
     def _after_conv_backward(self, l, s):
