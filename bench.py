@@ -289,6 +289,14 @@ def _check_distinct_devices(dev, rank, world):
     return got
 
 
+def _rank_devices(dev, world):
+    """[device index per rank] (all ranks call this)."""
+    import torch.distributed as dist
+    got = [None] * world
+    dist.all_gather_object(got, int(dev.index))
+    return got
+
+
 def dry_run(args):
     """Launcher check without GPUs (CPU test / any box): N gloo ranks rendezvous, all-reduce a rank-dependent vector, rank 0 prints
     one line.  Exercises exactly the spawn + env + rendezvous + single-line-output plumbing of the N>1 path."""
@@ -327,6 +335,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="dev/test: all ranks on cuda:0 with the gloo backend (checks launcher + segmented step + a real 2-rank all-reduce on a 1-GPU box)")
     ap.add_argument("--dry-run-launcher", action="store_true", help="no GPU: N gloo ranks, one all-reduce, one JSON line")
+    ap.add_argument("--check-allreduce", action="store_true",
+                    help="N>1: before timing, verify on the live process group that the bucketed all-reduce leaves the MEAN of the ranks' own shard gradients in every rank's arena")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -417,6 +427,38 @@ def main():
     for _ in range(max(1, min(args.warmup, 3))):      # first steps build tables / state before any capture
         eager_step()
     torch.cuda.synchronize()
+
+    allreduce_check = None
+    if dp and args.check_allreduce:
+        # same state, same shard, twice: once with the collectives switched off (the rank's own gradient, gathered from every rank), once with the
+        # bucketed exchange -> the arena must hold sum_r (g_r / world) = the mean.  Forward state (BN statistics, observers) is restored in between.
+        sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if seg is not None:
+            keep = seg._reduce
+            seg._reduce = lambda i: None
+            seg.run_eager(x, tgt)
+            seg._reduce = keep
+        else:
+            fwd_bwd()
+        torch.cuda.synchronize()
+        mine = runner.grad_arena.clone()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        want = torch.stack(parts).sum(0)
+        model.load_state_dict(sd0)
+        if seg is not None:
+            seg.run_eager(x, tgt)
+            seg.finish()
+        else:
+            fwd_bwd()
+            dist.all_reduce(runner.grad_arena)
+        torch.cuda.synchronize()
+        rel = float((runner.grad_arena - want).norm() / (want.norm() + 1e-30))
+        own = float((mine * world - want).norm() / (want.norm() + 1e-30))            # how far a single rank's gradient is from the mean: the check is not vacuous
+        model.load_state_dict(sd0)
+        allreduce_check = dict(rel_err_vs_mean_of_rank_gradients=rel, single_rank_vs_mean=own, ok=bool(rel <= 2e-2), devices=_rank_devices(dev, world))
+        if rank == 0:
+            print(f"[bench] all-reduce check: arena vs mean of the ranks' own gradients {rel:.2e} (one rank alone: {own:.2e})", file=sys.stderr, flush=True)
 
     graph = None
     capture_fallback = None
@@ -547,7 +589,7 @@ def main():
         comm = dict(mode=("single all-reduce after the backward" if seg is None else f"{len(seg.cuts)} buckets overlapped with the backward, one hipGraph segment per bucket"),
                     buckets=per_bucket, allreduce_ms_sum=round(total_ar, 3), step_ms_without_collectives=round(ms_nc, 3),
                     exposed_comm_ms_per_step=round(max(0.0, ms - ms_nc), 3), hidden_comm_ms_per_step=round(max(0.0, total_ar - max(0.0, ms - ms_nc)), 3),
-                    fallback=capture_fallback)
+                    fallback=capture_fallback, allreduce_check=allreduce_check)
 
     roofline = None
     if rank == 0 and not args.no_roofline:

@@ -166,7 +166,7 @@ def test_bench_gpus2_spawns_two_ranks():
     """The launcher contract: `python bench.py --gpus 2` (no torchrun around it) must run TWO ranks and report n_gpus = 2."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--batch", "32", "--steps", "3", "--warmup", "2",
-           "--no-roofline", "--no-cpu-baseline"]
+           "--check-allreduce", "--no-roofline", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -174,3 +174,26 @@ def test_bench_gpus2_spawns_two_ranks():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 64 and rec["config"]["hip_graph"] is True
     ga = rec["config"]["grad_allreduce"]
     assert "buckets overlapped" in ga["mode"] and ga["fallback"] is None and len(ga["buckets"]) >= 2 and rec["value"] > 0
+    chk = ga["allreduce_check"]        # the live two-rank reduction leaves the mean of the ranks' own gradients (and one rank's gradient alone is far from it)
+    assert chk["ok"] and chk["single_rank_vs_mean"] > 10 * chk["rel_err_vs_mean_of_rank_gradients"], chk
+
+
+def test_bench_two_physical_gpus_rccl():
+    """first contact with more than one physical GPU must be boring.  When >= 2 devices are visible, `python bench.py --gpus 2` (RCCL, one rank
+    per GPU, no --share-gpu) must come up on distinct devices, capture the segmented step without falling back, and leave the MEAN of the two ranks'
+    own shard gradients in the arena (checked on the live process group by --check-allreduce); the exposed communication per step is recorded."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (the round-end 8-GPU node); the one-GPU boxes run the same path as --share-gpu / --force-dp")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "5", "--warmup", "3", "--check-allreduce",
+           "--no-roofline", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    ga = rec["config"]["grad_allreduce"]
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 128
+    assert ga["fallback"] is None and "buckets overlapped" in ga["mode"], ga
+    chk = ga["allreduce_check"]
+    assert chk["ok"] and sorted(chk["devices"]) == [0, 1] and chk["single_rank_vs_mean"] > 10 * chk["rel_err_vs_mean_of_rank_gradients"], chk
+    assert ga["exposed_comm_ms_per_step"] is not None and rec["value"] > 0
+    print(f"[2 GPUs] {rec['value']:.0f} img/s, exposed communication {ga['exposed_comm_ms_per_step']} ms / step, all-reduce check {chk}")
