@@ -213,6 +213,27 @@ def side_workload(args, dev):
             except Exception as e:  # pragma: no cover
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
                 torch.cuda.synchronize()
+    elif not args.no_graph and args.workload in ("infer", "int8"):
+        # inference: the whole forward (static input buffer) replayed as ONE hipGraph -- the ~100 launches of a forward are 10-40 us each
+        eager = step
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    static_out = eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            step = graph.replay
+            graphed = True
+        except Exception as e:  # pragma: no cover
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

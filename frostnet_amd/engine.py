@@ -479,6 +479,7 @@ class Engine:
         resulting int8 packs.  After this the weights are frozen: converted forwards do not touch them again."""
         for l in self.layers:
             l.fold_rsqrt = True
+            l._cfin_key = None
         self._table = None
         self._ensure_tables()
         call("frost_weight_prep", ptr(self._table), len(self.layers), self._max_elems, self.rule127, 1 if observe else 0, stream())
@@ -493,16 +494,26 @@ class Engine:
             call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream())
             x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
-        if fb:
-            call("frost_conv_finalize_converted_fb", ptr(x.q), ptr(l.wscale), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
-                 ptr(l.qy), stream())
-        else:
-            call("frost_conv_finalize_converted", ptr(x.q), ptr(l.qw), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
-                 ptr(l.qy), stream())
+        self._converted_coef(l, x.q, fb)
         self._conv_launch(l, x, 3 if fb else 2, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
         return y
+
+    def _converted_coef(self, l, qx, fb):
+        """Requantisation coefficients of a converted conv (integer bias at scale s_x * s_w, multiplier s_x * s_w / s_y): functions of records that are
+        frozen after convert(), so they are computed ONCE per (layer, input record) -- not per forward (70 launches of a few microseconds each)."""
+        key = (qx.data_ptr(), bool(fb))
+        if getattr(l, "_cfin_key", None) == key:
+            return
+        if fb:
+            call("frost_conv_finalize_converted_fb", ptr(qx), ptr(l.wscale), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
+                 ptr(l.qy), stream())
+        else:
+            call("frost_conv_finalize_converted", ptr(qx), ptr(l.qw), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
+                 ptr(l.qy), stream())
+        if not torch.cuda.is_current_stream_capturing():
+            l._cfin_key = key
 
     def add_converted(self, a, b, q):
         y = self.new_act(a.n, a.h, a.w, a.c, q)
