@@ -171,6 +171,8 @@ _PROTOS = {
     "frost_float_cat_f32": [P, I, P, I, L, P, P],
     "frost_float_add_f32": [P, P, L, P, P],
     "frost_float_stem_im2col_f32": [P, I, I, I, L, L, L, L, P, P],
+    "frost_infer_block_ok": [I, I, I, I, I, I, I, I, I, I],
+    "frost_infer_block": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

@@ -8,6 +8,7 @@ weights and activations (the c2 configuration asks for bf16); the parity test ho
 tolerance.  No CPU / torch-eager fallback: a missing library raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -17,6 +18,36 @@ from ._lib import call, ptr, stream
 
 def round_up(a, b):
     return (a + b - 1) // b * b
+
+
+# Whole-bottleneck fused kernel (csrc/frost_iblock.hip): True = every bottleneck the kernel takes, False = layer-by-layer launches, "auto" (default) = where the
+# fused launch measured faster at B = 256 (tools/bench_iblock.py, profiles/r04_infer_blocks.txt): bottlenecks without an expansion conv (layer1.0: 415 vs 540 us)
+# and CAS bottlenecks with a 3 x 3 depthwise conv (layer2.1: 109 vs 133 us; layer3.5 / 3.6: 100 vs 108).  Elsewhere the one-workgroup-per-tile kernel is
+# latency-bound (three barrier-separated phases per 64-channel chunk at 2 workgroups per CU) and loses to the HBM-bound layer kernels by 1.3 - 2 x.
+_FUSED = {"0": False, "1": True}.get(os.environ.get("FROST_INFER_FUSED", "auto"), "auto")
+
+
+def pick_tile(lib, h, w, cin, r, cexp, cout, k, stride):
+    """Spatial output tile (th, tw) of one workgroup of frost_infer_block for a bottleneck geometry: the largest candidate whose staging fits (fewer halo
+    pixels recomputed by conv1), preferring tiles that divide the output map.  None: the fused kernel does not take this geometry."""
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    cands = [(ho, wo), ((ho + 1) // 2, wo), (7, 14), (8, 16), (7, 7), (8, 8), (4, 8), (4, 4)]
+    if os.environ.get("FROST_IB_TILE"):
+        cands = [tuple(int(v) for v in os.environ["FROST_IB_TILE"].split(","))] + cands[-1:]
+    best = None
+    for th, tw in cands:
+        th, tw = min(th, ho), min(tw, wo)
+        lds = lib.frost_infer_block_ok(h, w, cin, r, cexp, cout, k, stride, th, tw) if th * tw <= 256 else 0
+        if lds <= 0:
+            continue
+        waste = (-(-ho // th) * th) * (-(-wo // tw) * tw) / float(ho * wo)            # ragged edge tiles
+        halo = ((th - 1) * stride + k) * ((tw - 1) * stride + k) / float(th * tw * stride * stride)      # region pixels conv1 computes per useful pixel
+        wgs = min(4, (160 * 1024) // lds)                                                 # resident workgroups per CU by LDS: the phases of one workgroup are serial
+        score = waste * halo * (1.0 + 0.6 * (4 - wgs))
+        if best is None or score < best[0] - 1e-9:
+            best = (score, th, tw)
+    return None if best is None else (best[1], best[2])
 
 
 class _ILayer:
@@ -111,6 +142,23 @@ class Bf16Inference:
         for ent in self.blocks:
             blk = ent["blk"]
             x_in, c_in, npix = a, c, n * h * w
+            l2, l3, sq, l1 = ent["conv2"], ent["reduce"], ent["squeeze"], ent["conv1"]
+            if _FUSED is True or (_FUSED == "auto" and (l1 is None or (sq is not None and l2.k == 3))):
+                r = sq.cout if sq is not None else 0
+                key = ("tile", h, w)
+                if key not in ent:
+                    ent[key] = pick_tile(L.load_library(), h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride)
+                tile = ent[key]
+                if tile is not None:
+                    pad = (l2.k - 1) // 2
+                    h2, w2 = (h + 2 * pad - l2.k) // l2.stride + 1, (w + 2 * pad - l2.k) // l2.stride + 1
+                    out = torch.empty(n * h2 * w2 * l3.cout + 64, dtype=torch.int16, device=self.device)
+                    call("frost_infer_block", ptr(a), ptr(sq.pack) if sq is not None else None, ptr(sq.biasf) if sq is not None else None,
+                         ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
+                         ptr(l3.pack), ptr(l3.biasf), n, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride, 0 if blk.reduction else 1, tile[0], tile[1],
+                         ptr(out), stream())
+                    a, c, h, w = out, l3.cout, h2, w2
+                    continue
             if ent["conv1"] is not None:
                 if ent["squeeze"] is not None:
                     s = self._pw(ent["squeeze"], a, npix, c)

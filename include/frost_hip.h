@@ -255,6 +255,16 @@ int frost_infer_dw(const uint16_t* x, const float* wf, const float* biasf, int n
 int frost_infer_cat(const uint16_t* a, int ca, const uint16_t* b, int cb, int64_t npix, uint16_t* y, void* stream);
 int frost_infer_add(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* y, void* stream);
 int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void* stream);
+/* ---- whole-bottleneck fused bf16 inference (csrc/frost_iblock.hip) -----------------------------------------------------------
+ * replaces (eval mode, BatchNorm folded): CascadePreExBottleneck.forward, frostnet.py:124-145 -- [squeeze_conv -> cat] -> conv1 -> conv2 (depthwise) ->
+ * reduce_conv [-> + x] as ONE launch per bottleneck; the expanded tensors stay in LDS, only the block input and output touch HBM.
+ * wsq / w1 / w3: bf16 A-fragment packs of frost_infer_weight_prep (kpad = round_up(K, 32)), bsq / b1 / bdw / b3 the folded biases, wdw fp32 taps
+ * [k*k][round_up(cexp,16)].  wsq == NULL (r = 0): no squeeze / cat;  w1 == NULL (cexp == cin): the depthwise conv reads the block input (frostnet.py:105-108).
+ * (th, tw): spatial output tile of one workgroup; frost_infer_block_ok says whether the geometry / tile fits (LDS <= 160 KB, register budgets). */
+int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int cout, int k, int stride, int th, int tw);
+int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const float* bsq, const uint16_t* w1, const float* b1, const float* wdw,
+                      const float* bdw, const uint16_t* w3, const float* b3, int n, int h, int w, int cin, int r, int cexp, int cout, int k,
+                      int stride, int residual, int th, int tw, uint16_t* y, void* stream);
 /* y[n][o] = sum_k x[n][k] * w[o][k] + bias[o], fp32 on the f32 MFMA (classifier of the float model) */
 int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream);
 

@@ -39,3 +39,42 @@ def test_bf16_inference_vs_fp32_definition(name, res, batch):
     assert agree >= batch - max(1, batch // 8), (agree, batch)
     with pytest.raises(RuntimeError):
         model.train(); model.hip_infer_bf16(x.cuda())
+
+
+@pytest.mark.parametrize("name,res,batch", [("frostnet_large_1_0", 224, 6), ("frostnet_large_1_0", 160, 3), ("frostnet_small_1_0", 97, 5), ("frostnet_base_1_25", 128, 2)])
+def test_fused_block_inference_equals_layer_by_layer(name, res, batch):
+    """frost_infer_block (csrc/frost_iblock.hip: squeeze -> cat -> conv1 -> depthwise -> reduce_conv -> + x in ONE launch per bottleneck, expanded tensors in LDS)
+    against the layer-by-layer kernels it replaces: same rounding points (every layer output rounded to bf16 once), so the logits agree to the summation order of
+    the GEMMs -- held to 1e-2 norm-wise (one bf16 step is 4e-3) -- and both meet the fp32 definition's tolerance.  224 px exercises whole-image, half-image and
+    8 x 16 / 8 x 8 / 7 x 7 tiles with stride 1 and 2; 160 / 97 / 128 px ragged edge tiles and odd maps; base_1_25 other channel counts (partial 64-channel chunks)."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, infer as I, _lib as L
+    torch.manual_seed(17)
+    model = F.MODEL_REGISTRY[name]()
+    _randomize_bn(model, 23)
+    model.eval()
+    x = torch.randn(batch, 3, res, res)
+    with torch.no_grad():
+        ref = model(x)
+    model.cuda()
+    xg = x.cuda()
+    old = I._FUSED
+    try:
+        I._FUSED = True                                   # every bottleneck the kernel takes (the default, "auto", fuses only where it measured faster)
+        L.CALL_LOG = []
+        fused = model.hip_infer_bf16(xg).cpu()
+        log = list(L.CALL_LOG)
+        L.CALL_LOG = None
+        I._FUSED = False
+        model.__dict__.pop("_bf16_infer", None)
+        plain = model.hip_infer_bf16(xg).cpu()
+    finally:
+        I._FUSED = old
+        L.CALL_LOG = None
+    nblocks = sum(len(getattr(model, f"layer{i}")) for i in range(1, 6))
+    nfused = log.count("frost_infer_block")
+    assert nfused == nblocks if name.endswith("1_0") else nfused >= nblocks // 2, (nfused, nblocks)      # (other widths: the widest blocks exceed the kernel's K budget)
+    r_fp, r_pl, r_ref = float((fused - plain).norm() / plain.norm()), float((plain - ref).norm() / ref.norm()), float((fused - ref).norm() / ref.norm())
+    print(f"[{name}@{res}] fused vs layer-by-layer {r_fp:.2e}; vs the fp32 definition: fused {r_ref:.2e}, layer-by-layer {r_pl:.2e}")
+    assert r_fp <= 1e-2 and r_ref <= 3e-2, (r_fp, r_ref, r_pl)
