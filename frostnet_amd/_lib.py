@@ -173,6 +173,15 @@ _PROTOS = {
     "frost_float_stem_im2col_f32": [P, I, I, I, L, L, L, L, P, P],
     "frost_infer_block_ok": [I, I, I, I, I, I, I, I, I, I],
     "frost_infer_block": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_g32_wq": [P, P, P, P, P, I, I, P, P],
+    "frost_g32_conv_acc": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_g32_reduce": [P, L, I, P, P, I, P, P],
+    "frost_g32_dc": [P, L, I, P, P, I, P, P, P],
+    "frost_g32_dgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
+    "frost_g32_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_g32_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],
+    "frost_g32_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
+    "frost_g32_pool_bwd": [P, P, I, I, I, P, P],
     "frost_save_sigma": [P, P, I, P],
     "frost_mask_logits": [P, P, P, L, P, P],
     "frost_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

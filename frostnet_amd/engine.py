@@ -181,6 +181,9 @@ class Engine:
         self._table = None
         self.on_layer_grads = None     # callback(layer) after a layer's parameter gradients are final (DP overlap)
         self._side, self._keep = None, []
+        # fp32-GRADIENT parity mode (csrc/frost_g32.hip; `model.grad_precision = "fp32"` / FROST_GRAD=fp32): activation gradients and dc in fp32, long sums in
+        # fp64, plain kernels -- the reference's fp32 autograd precision instead of bf16 storage.  10-30 x slower; for parity statements, not for training runs.
+        self.grad_fp32 = os.environ.get("FROST_GRAD", "bf16").lower() == "fp32"
 
     # ------------------------------------------------------------------------------------------ plan
     def add_layer(self, layer):
@@ -233,11 +236,10 @@ class Engine:
         a.buf[: a.numel].copy_(v.view(-1))
         return a
 
-    @staticmethod
-    def _grad_slot(a):
-        """bf16 gradient buffer of an Act: returns (tensor, accumulate_flag)."""
+    def _grad_slot(self, a):
+        """Gradient buffer of an Act (bf16 bits, or fp32 in the fp32-gradient mode): returns (tensor, accumulate_flag)."""
         if a.grad is None:
-            a.grad = torch.empty(a.numel + 64, dtype=torch.int16, device=a.buf.device)
+            a.grad = torch.empty(a.numel + 64, dtype=torch.float32 if self.grad_fp32 else torch.int16, device=a.buf.device)
             return a.grad, 0
         return a.grad, 1
 
@@ -544,6 +546,8 @@ class Engine:
         bucket's all-reduce) while the rest of the backward is still to run."""
         self._prepare_dwq()
         self._pending = []          # conv layers whose weight-gradient finalize is deferred to one table launch
+        if self.grad_fp32:
+            return self._backward_g32(dlogits, boundaries, on_bucket)
         # Pointwise weight gradients run on a second stream: nothing downstream needs them until the finalize at the end of the
         # backward, and the short low-resolution kernels leave launch gaps and tails that an independent kernel can fill.
         # Off when per-layer gradients are awaited (data parallel) and while the per-kernel profiler times the main stream.
@@ -604,6 +608,79 @@ class Engine:
         self._finalize_pending()
         self._keep = []
         self.tape = []
+
+    # ------------------------------------------------------------------------------------------ fp32-gradient parity mode
+    def _backward_g32(self, dlogits, boundaries, on_bucket):
+        """The tape replayed with the plain fp32 kernels of csrc/frost_g32.hip (same formulas, fp32 storage, fp64 sums)."""
+        self._side = None
+        s = stream()
+        for entry in reversed(self.tape):
+            kind = entry[0]
+            if kind == "head":
+                _, l, x, pooled, raw, drop = entry
+                g = torch.empty_like(raw)
+                call("frost_mask_logits", ptr(dlogits.contiguous()), ptr(raw), ptr(l.qy), raw.numel(), ptr(g), s)
+                dwq = torch.empty(l.cout, l.cin_g, dtype=torch.float32, device=self.device)
+                gx, _ = self._grad_slot(x)
+                dpool = torch.empty_like(pooled)
+                scratch = torch.empty(x.numel + 64, dtype=torch.int16, device=self.device)          # (the fp32 GEMMs of the head are shared; its bf16 gx is discarded)
+                self._ensure_grad(l)
+                call("frost_head_bwd", ptr(g), ptr(pooled), ptr(l.wq_pack), ptr(l.qw), x.n, x.c, l.cout, x.h * x.w, ptr(drop), ptr(dwq), ptr(l.bias.grad),
+                     ptr(scratch), ptr(dpool), ptr(l.wscale) if l.per_channel else None, s)
+                call("frost_g32_pool_bwd", ptr(dpool), ptr(drop), x.n, x.h * x.w, x.c, ptr(gx), s)
+                call("frost_weight_grad_finalize", ptr(dwq), ptr(l.w), None, None, ptr(l.qw), ptr(l.coef), l.cout, l.cin_g, 1, l.cpad, ptr(l.w.grad), None, None, 0,
+                     ptr(l.wscale), s)
+            elif kind == "conv":
+                _, l, x, y = entry
+                self._conv_backward_g32(l, x, y)
+            elif kind == "cat":
+                _, a, b, y = entry
+                ga, fa = self._grad_slot(a)
+                gb, fb = self._grad_slot(b)
+                call("frost_g32_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q), ptr(ga), fa, ptr(gb), fb, s)
+                y.grad = None
+            elif kind == "add":
+                _, a, b, y = entry
+                ga, fa = self._grad_slot(a)
+                gb, fb = self._grad_slot(b)
+                call("frost_g32_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga), fa, ptr(gb), fb, s)
+                y.grad = None
+            else:
+                raise NotImplementedError(f"fp32-gradient mode: no plain kernel for the '{kind}' node")
+            if kind in ("head", "conv"):
+                l = entry[1]
+                if self.on_layer_grads is not None:
+                    self.on_layer_grads(l)
+                if boundaries is not None and id(l) in boundaries:
+                    self._close_bucket(boundaries[id(l)], on_bucket)
+        self._finalize_pending()
+        self.tape = []
+
+    def _conv_backward_g32(self, l, x, y):
+        self._ensure_grad(l)
+        s = stream()
+        kind = {"pw": 0, "dw": 1, "stem": 2}[l.kind]
+        per = l.cin_g * l.kk
+        if getattr(l, "_g32_qw", None) is None:
+            l._g32_qw = torch.empty(l.cout * per + 64, dtype=torch.int8, device=self.device)
+        qw = l._g32_qw
+        call("frost_g32_wq", ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, l.cout, per, ptr(qw), s)
+        cin_g = 1 if kind == 1 else l.cin_g
+        geo = (kind, x.n, x.h, x.w, x.c, cin_g, l.cout, l.k, l.stride)
+        acc = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+        call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s)
+        call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), s)
+        self._frozen_after_reduce(l)
+        dc = torch.empty(y.numel + 64, dtype=torch.float32, device=self.device)
+        call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
+        if getattr(self, "_dbg", False):
+            self._last_dc = dc
+        if x.needs_grad:
+            gx, accf = self._grad_slot(x)
+            call("frost_g32_dgrad", ptr(dc), ptr(qw), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, *geo, ptr(gx), accf, s)
+        call("frost_g32_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), *geo, ptr(l.dwq), s)
+        self._after_conv_backward(l, s)
+        y.grad = None
 
     def _prepare_dwq(self):
         """One fp32 scratch arena for every layer's dL/d(fake-quantised weight) (the wgrad kernels accumulate with atomics):
@@ -815,13 +892,16 @@ class Engine:
 
 
 def grad_to_float(g, n, h, w, c):
-    """bf16 gradient buffer -> fp32 NCHW (tests)."""
-    return g[: n * h * w * c].view(torch.bfloat16).float().view(n, h, w, c).permute(0, 3, 1, 2)
+    """gradient buffer (bf16 bits, or fp32 in the fp32-gradient mode) -> fp32 NCHW (tests)."""
+    g = g[: n * h * w * c]
+    g = g if g.dtype == torch.float32 else g.view(torch.bfloat16).float()
+    return g.view(n, h, w, c).permute(0, 3, 1, 2)
 
 
-def float_to_grad(t_nchw):
-    """fp32 NCHW -> bf16 NHWC buffer with slack (tests)."""
-    v = t_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).view(torch.int16).reshape(-1)
-    out = torch.zeros(v.numel() + 64, dtype=torch.int16, device=t_nchw.device)
+def float_to_grad(t_nchw, fp32=False):
+    """fp32 NCHW -> NHWC gradient buffer with slack: bf16 bits, or fp32 (`fp32=True`: the fp32-gradient mode, Engine.grad_fp32)."""
+    v = t_nchw.permute(0, 2, 3, 1).contiguous()
+    v = v.float().reshape(-1) if fp32 else v.to(torch.bfloat16).view(torch.int16).reshape(-1)
+    out = torch.zeros(v.numel() + 64, dtype=v.dtype, device=t_nchw.device)
     out[: v.numel()] = v
     return out

@@ -47,7 +47,7 @@ class _QATFeatFunction(torch.autograd.Function):
         for a, g in zip(ctx.acts, grads):     # tap gradients first; later layers' dgrads accumulate on top
             if g is None:
                 g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
-            a.grad = float_to_grad(g)
+            a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_fp32)
         ctx.runner._backward_impl(None)
         return None, None, None
 
@@ -483,6 +483,11 @@ class FrostRunner:
         # Engine.conv normalises with the running statistics and the backward drops the batch-statistics terms (Engine._frozen_after_reduce)
         E, obs = self.E, self._observe_hint(training)
         self._obs = obs
+        gp = getattr(self.model, "grad_precision", None)          # "fp32": the fp32-gradient parity mode of the backward (csrc/frost_g32.hip); default bf16 storage
+        if gp is not None:
+            if gp not in ("bf16", "fp32"):
+                raise ValueError("model.grad_precision must be 'bf16' or 'fp32'")
+            E.grad_fp32 = gp == "fp32"
         E.begin_step(observe=obs)
         a = E.quantize_input(x, self.q_in, observe=obs)
         a = self._conv(self.stem, a, training, obs)
@@ -556,7 +561,7 @@ class _QATMapsFunction(torch.autograd.Function):
             for a, g in zip(ctx.acts, grads):
                 if g is None:
                     g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
-                a.grad = float_to_grad(g)
+                a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_fp32)
             ctx.runner._backward_impl(None)
         return None, None, None
 
