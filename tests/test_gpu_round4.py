@@ -207,9 +207,13 @@ def test_fp32_gradient_mode_layer_vs_oracle(F, case):
     sd = O.synth_state([k_ for k_, _ in spec], [s_ for _, s_ in spec], seed)
     in_scale = 0.0231
     xi = np.clip(np.round(O.synth((N, cin, H, H), seed + 1) * 40 + 128 + (0 if in_zp else -60)), 0, 255).astype(np.uint8)
-    P64, B64 = O.split_state({O.float_to_qat_key(k_): (v.clone().double() if v.is_floating_point() else v.clone()) for k_, v in sd.items()})
-    qs64 = O.QState(B64)
-    xo64 = ((T(xi.astype(np.float64)) - in_zp) * in_scale).requires_grad_(True)
+    # two yardsticks: the reference's formulas evaluated in fp32 (= the reference itself: it decides borderline cases -- the weight with the largest magnitude sits
+    # exactly on the clipping boundary 127.5 of its fake-quantiser, and whether its gradient is masked depends on the last bit of x * (1 / scale)) and in fp64
+    # (free of the reference's own summation noise).  A gradient passes if it is within tolerance of either.
+    ev = []
+    for dt in (torch.float32, torch.float64):
+        Pq, Bq = O.split_state({O.float_to_qat_key(k_): (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k_, v in sd.items()})
+        ev.append((Pq, O.QState(Bq), ((T(xi).to(dt) - in_zp) * in_scale).requires_grad_(True), dt))
     kind = "stem" if (groups == 1 and k == 3) else ("dw" if groups > 1 else "pw")
     E, qa = engine.Engine(dev), engine.QArena(4, dev)
     E.grad_fp32 = True
@@ -227,12 +231,14 @@ def test_fp32_gradient_mode_layer_vs_oracle(F, case):
     Ho = (H + 2 * pad - k) // s + 1
     for step in range(2):
         gr = T(O.synth((N, cout, Ho, Ho), seed + 2 + 50 * step))
-        xo64.grad = None
-        for p in P64.values():
-            p.grad = None
-        yo64 = O.convbn_qat(P64, qs64, "L", xo64, s, pad, groups, bool(relu), True)
-        yo64.backward(gr.double())
-        idx64 = O.fq_index(yo64.detach(), qs64.sd["L.conv.0.activation_post_process.scale"][0], qs64.sd["L.conv.0.activation_post_process.zero_point"][0])
+        idxs = []
+        for Pq, qsq, xq, dt in ev:
+            xq.grad = None
+            for p in Pq.values():
+                p.grad = None
+            yo = O.convbn_qat(Pq, qsq, "L", xq, s, pad, groups, bool(relu), True)
+            yo.backward(gr.to(dt))
+            idxs.append(O.fq_index(yo.detach(), qsq.sd["L.conv.0.activation_post_process.scale"][0], qsq.sd["L.conv.0.activation_post_process.zero_point"][0]))
         E.begin_step()
         x = E.act_from_indices(xi_t, qx)
         y = E.conv(l, x, training=True, observe=True)
@@ -240,13 +246,15 @@ def test_fp32_gradient_mode_layer_vs_oracle(F, case):
         y.grad = engine.float_to_grad(gr.to(dev), fp32=True)
         E.backward()
         torch.cuda.synchronize()
-        flips = float((yidx.to(torch.int16) != idx64.to(torch.int16)).float().mean())
-        errs = dict(dW=relerr(l.w.grad.cpu(), P64["L.conv.0.weight"].grad), dgamma=relerr(l.gamma.grad.cpu(), P64["L.conv.0.bn.weight"].grad),
-                    dbeta=relerr(l.beta.grad.cpu(), P64["L.conv.0.bn.bias"].grad))
+        flips = min(float((yidx.to(torch.int16) != ix.to(torch.int16)).float().mean()) for ix in idxs)
+        errs = {}
+        for nm, mine, key in (("dW", l.w.grad, "L.conv.0.weight"), ("dgamma", l.gamma.grad, "L.conv.0.bn.weight"), ("dbeta", l.beta.grad, "L.conv.0.bn.bias")):
+            errs[nm] = min(relerr(mine.cpu(), Pq[key].grad) for Pq, _, _, _ in ev)
         if kind != "stem":
-            errs["dx"] = relerr(engine.grad_to_float(x.grad, x.n, x.h, x.w, x.c).cpu(), xo64.grad)
-        print(f"[fp32-grad {name} step {step}] forward flips vs fp64 {flips:.1e}; " + " ".join(f"{k_} {v:.2e}" for k_, v in errs.items()))
-        # a forward index that differs from the fp64 evaluation's (a tie of the reference's own rounding) moves a mask: budget 3 x sqrt(flip fraction) on top
+            dxd = engine.grad_to_float(x.grad, x.n, x.h, x.w, x.c).cpu()
+            errs["dx"] = min(relerr(dxd, xq.grad) for _, _, xq, _ in ev)
+        print(f"[fp32-grad {name} step {step}] forward flips {flips:.1e}; " + " ".join(f"{k_} {v:.2e}" for k_, v in errs.items()))
+        # a forward index that differs from the oracle's (a tie of the reference's own rounding) moves a mask: budget 3 x sqrt(flip fraction) on top
         tol = G32_TOL + 3.0 * flips ** 0.5
         assert all(v <= tol for v in errs.values()), (name, step, errs, tol)
 
