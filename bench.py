@@ -454,6 +454,7 @@ def main():
         # same state, same shard, twice: once with the collectives switched off (the rank's own gradient, gathered from every rank), once with the
         # bucketed exchange -> the arena must hold sum_r (g_r / world) = the mean.  Forward state (BN statistics, observers) is restored in between.
         sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        rng0 = runner.rng_state()                     # the dropout stream too: both passes must draw the same mask
         if seg is not None:
             keep = seg._reduce
             seg._reduce = lambda i: None
@@ -467,6 +468,7 @@ def main():
         dist.all_gather(parts, mine)
         want = torch.stack(parts).sum(0)
         model.load_state_dict(sd0)
+        runner.set_rng_state(rng0)
         if seg is not None:
             seg.run_eager(x, tgt)
             seg.finish()
@@ -477,6 +479,7 @@ def main():
         rel = float((runner.grad_arena - want).norm() / (want.norm() + 1e-30))
         own = float((mine * world - want).norm() / (want.norm() + 1e-30))            # how far a single rank's gradient is from the mean: the check is not vacuous
         model.load_state_dict(sd0)
+        runner.set_rng_state(rng0)
         allreduce_check = dict(rel_err_vs_mean_of_rank_gradients=rel, single_rank_vs_mean=own, ok=bool(rel <= 2e-2), devices=_rank_devices(dev, world))
         if rank == 0:
             print(f"[bench] all-reduce check: arena vs mean of the ranks' own gradients {rel:.2e} (one rank alone: {own:.2e})", file=sys.stderr, flush=True)
