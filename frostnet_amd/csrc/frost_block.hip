@@ -1193,3 +1193,108 @@ extern "C" int frost_block_bwd(const FrostBlockDesc* d, const FrostBlockBwd* b, 
   if (ev) hipEventDestroy(ev);
   return frost_check_launch("block_bwd");
 }
+
+// ================================================================================================ squeeze_conv emit + cat in one launch
+// out = quant_cat.cat([squeeze_conv(x), x], 1) (frostnet.py:127-129): the emit pass of the squeeze conv (k_pw's expression on the int8 MFMA) and the cat's
+// requantisation of BOTH halves (k_cat_requant's two 256-entry tables) from one staged x tile -- the squeezed activation and the input are not re-read, one launch
+// instead of two per CAS bottleneck.  The cat's FakeQuantize record must already be final (it is updated in the squeeze's statistics / finalize tail).
+// Results are bit-identical to frost_pw_conv_fwd(mode 1) + frost_cat_requant.
+struct SqCatP {
+  const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum; const float* coef; const float* qsq; const float* qcat;
+  int8_t* ysq; int8_t* ycat; int64_t npix; int cin, r, cpad, kstr;
+};
+template <int KSM>
+__global__ __launch_bounds__(256) void k_sq_emit_cat(const SqCatP p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                          // [128][kstr]
+  uint8_t* const lut = smem + 128 * p.kstr;          // [2][256]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  {
+    const QP A = load_qp(p.qsq), B = load_qp(p.qx), Y = load_qp(p.qcat);
+    const int q = (int)(int8_t)tid + 128;
+    lut[tid] = (uint8_t)((fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
+    lut[256 + tid] = (uint8_t)((fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
+  }
+  {
+    const int upr = p.cin >> 3; const int total = 128 * upr;
+    for (int u = tid; u < total; u += 256) {
+      const int row = u / upr, col = u - row * upr;
+      const int64_t px = p0 + row;
+      uint2 v = make_uint2(0, 0);
+      if (px < p.npix) v = *(const uint2*)(p.x + px * p.cin + col * 8);
+      *(uint2*)(xs + row * p.kstr + col * 8) = v;
+    }
+  }
+  __syncthreads();
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  const int zps = __float_as_int(p.qsq[FROST_Q_ZP]);
+  const float y_inv = 1.0f / p.qsq[FROST_Q_SCALE], y_zpf = (float)zps;
+  const float qcap = (float)q_hi(p.qsq); const bool lowq = qcap < 255.0f;
+  const int cy = p.r + p.cin;
+  const int CT = p.cpad >> 4;
+  for (int ct = 0; ct < CT; ++ct) {
+    const int ch = ct * 16 + 4 * g;
+    v4i afr[KSM];
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) afr[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+    const int4 ws = *(const int4*)(p.wsum + ch);
+    const float4 A4 = *(const float4*)(p.coef + FROST_COEF_A * p.cpad + ch), B4 = *(const float4*)(p.coef + FROST_COEF_B * p.cpad + ch);
+    const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = (wv * 2 + t) * 16 + j;
+      v4i acc = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w};
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) {
+        const v4i bfr = *(const v4i*)(xs + row * p.kstr + ks * 64 + g * 16);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, acc, 0, 0, 0);
+      }
+      uint32_t packed = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float yv = fmaf(A[r], (float)acc[r], B[r]);
+        float qv = rintf(yv * y_inv) + y_zpf;
+        if (lowq) qv = fminf(qv, qcap);
+        packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+      }
+      packed ^= 0x80808080u;
+      const int64_t px = p0 + row;
+      if (px < p.npix && ch < p.r) {
+        *(uint32_t*)(p.ysq + px * p.r + ch) = packed;
+        const uint32_t o = (uint32_t)lut[packed & 255] | ((uint32_t)lut[(packed >> 8) & 255] << 8) | ((uint32_t)lut[(packed >> 16) & 255] << 16) | ((uint32_t)lut[packed >> 24] << 24);
+        *(uint32_t*)(p.ycat + px * cy + ch) = o;
+      }
+    }
+  }
+  {   // the input half of the cat, from the staged tile
+    const int dpp = p.cin >> 2; const int total = 128 * dpp;
+    const uint8_t* l1 = lut + 256;
+    for (int u = tid; u < total; u += 256) {
+      const int row = u / dpp, c0 = (u - row * dpp) * 4;
+      const int64_t px = p0 + row;
+      if (px >= p.npix) continue;
+      const uint32_t src = *(const uint32_t*)(xs + row * p.kstr + c0);
+      const uint32_t o = (uint32_t)l1[src & 255] | ((uint32_t)l1[(src >> 8) & 255] << 8) | ((uint32_t)l1[(src >> 16) & 255] << 16) | ((uint32_t)l1[src >> 24] << 24);
+      *(uint32_t*)(p.ycat + px * cy + p.r + c0) = o;
+    }
+  }
+}
+extern "C" int frost_sq_emit_cat_ok(int cin, int r) { return (cin % 8 == 0) && (r % 4 == 0) && cin <= 192 && r <= 128; }
+extern "C" int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, const float* coef,
+                                 const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, void* stream) {
+  FROST_REQUIRE(frost_sq_emit_cat_ok(cin, r), "sq_emit_cat: cin <= 192 (multiple of 8), r <= 128 (multiple of 4)");
+  SqCatP p = {};
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = coef; p.qsq = qrec_sq; p.qcat = qrec_cat; p.ysq = y_sq; p.ycat = y_cat;
+  p.npix = npix; p.cin = cin; p.r = r; p.cpad = round_up(r, 16);
+  const int ksm = round_up(cin, 64) / 64;
+  p.kstr = ksm * 64 + 16;
+  const size_t lds = (size_t)128 * p.kstr + 512;
+  const dim3 grid((unsigned)((npix + 127) / 128));
+  hipStream_t s = as_stream(stream);
+  if (ksm == 1) hipLaunchKernelGGL(k_sq_emit_cat<1>, grid, dim3(256), lds, s, p);
+  else if (ksm == 2) hipLaunchKernelGGL(k_sq_emit_cat<2>, grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(k_sq_emit_cat<3>, grid, dim3(256), lds, s, p);
+  return frost_check_launch("sq_emit_cat");
+}

@@ -41,6 +41,7 @@ _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # larg
 _PW_FUSE_MINMAP = int(os.environ.get("FROST_PW_FUSE_MINMAP", "400"))
 _PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
+_BLOCK_SQCAT = os.environ.get("FROST_BLOCK_SQCAT", "1") != "0"      # squeeze_conv emit + cat requantisation in one launch (frost_sq_emit_cat), bit-identical to the two it replaces
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 # depthwise weight gradients of maps no wider than this also go to the second stream.  Measured (two boxes, 2-3 runs each): 14 -> -0.2 ms, but
@@ -50,7 +51,7 @@ _DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
@@ -60,6 +61,7 @@ class Act:
         self.cat_observed = False  # the cat consuming this activation already had its FakeQuantize record updated (folded into this layer's finalize)
         self.kept_next = None      # set by conv_pair: the integer conv output of the reduce_conv consuming this activation (its statistics pass already ran)
         self.sum_observed = False  # the residual add consuming this activation already had its range pass (fused into this layer's emit)
+        self.cat_done = None       # the cat consuming this (squeeze) activation was already written by frost_sq_emit_cat: Engine.cat returns it
 
     @property
     def npix(self):
@@ -348,7 +350,15 @@ class Engine:
             call("frost_conv_finalize", ptr(l.stats) if need_stats else None, y.npix, l.cout, ptr(x.q), ptr(l.qw),
                  ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), ptr(l.nbt), 1 if training else 0, int(l.relu),
                  1 if observe else 0, ptr(l.coef), ptr(l.qy), ptr(l.wscale), stream(), prof=("conv_finalize", 48 * l.cout))
-        self._conv_launch(l, x, 1, y)
+        if (need_stats and _FIN_FOLD and cat is not None and cat_fold and _BLOCK_SQCAT and l.kind == "pw" and l.relu and getattr(l, "hswish", None) is None
+                and L.load_library().frost_sq_emit_cat_ok(x.c, l.cout)):
+            # squeeze_conv of a CAS bottleneck: emit + both halves of the cat from one staged x tile (the cat's record was finalized in the statistics launch's tail)
+            ycat = self.new_act(x.n, ho, wo, l.cout + x.c, cat[1])
+            call("frost_sq_emit_cat", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.coef), ptr(l.qy), ptr(cat[1]), ptr(y.buf), ptr(ycat.buf),
+                 stream(), prof=("pw_fwd_emit", x.numel + l.wq_pack.numel() + y.numel + ycat.numel))
+            y.cat_done = ycat
+        else:
+            self._conv_launch(l, x, 1, y)
         if need_stats and _FIN_FOLD and cat is not None and cat_fold:
             y.cat_observed = True
         if getattr(self, "trace", None) is not None:
@@ -414,11 +424,15 @@ class Engine:
 
     def cat(self, a, b, q, observe=True):
         """FloatFunctional.cat + its FakeQuantize (frostnet.py:129)."""
-        if not getattr(a, "cat_observed", False):
-            call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
-        y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
-        call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream(),
-             prof=("cat_fwd", 2 * y.numel))
+        y = getattr(a, "cat_done", None)
+        if y is not None:                  # written by the squeeze's emit launch (frost_sq_emit_cat)
+            a.cat_done = None
+        else:
+            if not getattr(a, "cat_observed", False):
+                call("frost_cat_observe", ptr(a.q), ptr(b.q), ptr(q), 1 if observe else 0, stream())
+            y = self.new_act(a.n, a.h, a.w, a.c + b.c, q)
+            call("frost_cat_requant", ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(q), ptr(y.buf), stream(),
+                 prof=("cat_fwd", 2 * y.numel))
         if getattr(self, "trace", None) is not None:
             self.trace.append(("cat", y))
         self.tape.append(("cat", a, b, y))

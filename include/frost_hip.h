@@ -255,6 +255,36 @@ int frost_infer_dw(const uint16_t* x, const float* wf, const float* biasf, int n
 int frost_infer_cat(const uint16_t* a, int ca, const uint16_t* b, int cb, int64_t npix, uint16_t* y, void* stream);
 int frost_infer_add(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* y, void* stream);
 int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void* stream);
+/* ---- fp32-GRADIENT parity mode of the fake-quant backward (csrc/frost_g32.hip) --------------------------------------------------------------
+ * replaces: the reference's fp32 autograd (loss.backward(), Classification/utils/helper_functions.py:139-143) for one ConvBn(ReLU)2d + activation FakeQuantize, with
+ * the production backward's formulas but fp32 gradient storage and fp64 sums (plain one-thread-per-output kernels; 10-30 x slower -- a parity instrument).
+ *   frost_g32_wq        fake-quantised weight INDICES [cout][per] (OIHW), q = clamp(rint(W * gamma/sigma_r / s_w), -128, 127)
+ *   frost_g32_conv_acc  exact int32 conv output acc[p][co] = sum (q_x - zp_x) q_w;  kind 0 pointwise / 2 stem-on-im2col: (n, h, w) = the OUTPUT map, x = [npix][xc];
+ *                       kind 1 depthwise: (n, h, w) = the input map
+ *   frost_g32_reduce    S1 / S2 rows of `coef` from fp32 gout (STE window on fma(A, acc, B)/s_y, ReLU included);  frost_g32_dc: dc = K1 (gy - S1/n - xhat S2/n), fp32
+ *   frost_g32_dgrad     gx (+)= sum dc * q_w * s_w   (kind 0 / 1);   frost_g32_wgrad: dwq[co][j] = s_x sum dc (q_x - zp_x)  -> frost_weight_grad_finalize as usual
+ *   frost_g32_cat_bwd / _add_bwd / _pool_bwd: the block wiring and the head's pooled gradient in fp32 */
+int frost_g32_wq(const float* w, const float* gamma, const float* sigma, const float* qrec_w, const float* wscale, int cout, int per, int8_t* out, void* stream);
+int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride,
+                       int32_t* acc, void* stream);
+int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* stream);
+int frost_g32_dc(const int32_t* acc, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const float* gout, float* dc, void* stream);
+int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* qrec_w, const float* wscale, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k,
+                    int stride, float* gx, int accumulate, void* stream);
+int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qrec_x, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride, float* dwq,
+                    void* stream);
+int frost_g32_cat_bwd(const float* gy, const int8_t* a, const float* qrec_a, int ca, const int8_t* b, const float* qrec_b, int cb, int64_t npix, const float* qrec_y,
+                      float* ga, int acc_a, float* gb, int acc_b, void* stream);
+int frost_g32_add_bwd(const float* gy, const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y, float* ga, int acc_a,
+                      float* gb, int acc_b, void* stream);
+int frost_g32_pool_bwd(const float* dpool, const float* drop, int n, int hw, int c, float* gx, void* stream);
+
+/* squeeze_conv emit + cat in ONE launch (frostnet.py:127-129: out = quant_cat.cat([squeeze_conv(x), x], 1)): replaces frost_pw_conv_fwd(mode 1) of the squeeze conv +
+ * frost_cat_requant, bit-identical; the cat's record qrec_cat must be final (FrostFinDesc.cat_qrec_y of the squeeze's statistics launch).  y_sq: [npix][r], y_cat: [npix][r + cin]. */
+int frost_sq_emit_cat_ok(int cin, int r);
+int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, const float* coef,
+                      const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, void* stream);
+
 /* ---- whole-bottleneck fused bf16 inference (csrc/frost_iblock.hip) -----------------------------------------------------------
  * replaces (eval mode, BatchNorm folded): CascadePreExBottleneck.forward, frostnet.py:124-145 -- [squeeze_conv -> cat] -> conv1 -> conv2 (depthwise) ->
  * reduce_conv [-> + x] as ONE launch per bottleneck; the expanded tensors stay in LDS, only the block input and output touch HBM.

@@ -305,3 +305,48 @@ def test_fp32_gradient_mode_block_vs_reference_golden(F, golden):
         top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
         print(f"[fp32-grad block l31 step {step}] output index flips vs the reference {flips:.1e}; worst gradients vs the reference: " + ", ".join(f"{k_} {v:.2e}" for k_, v in top))
         assert all(v <= 2e-3 + 3.0 * flips ** 0.5 for v in worst.values()), top
+
+
+# ------------------------------------------------------------------------------------------ squeeze emit + cat in one launch
+@pytest.mark.parametrize("cin,r,H,n", [(40, 16, 28, 5), (80, 24, 14, 7), (96, 24, 14, 33), (192, 48, 7, 9), (192, 96, 7, 3), (120, 32, 9, 2)])
+def test_squeeze_emit_cat_fused_is_bit_identical(F, cin, r, H, n):
+    """frost_sq_emit_cat (squeeze_conv emit + quant_cat.cat requantisation from one staged tile, frostnet.py:127-129) against the two launches it replaces
+    (frost_pw_conv_fwd mode 1 + frost_cat_requant): squeezed activation, cat output and the cat's record bit-identical over two steps (the second from moved
+    observers), ragged last tiles included."""
+    from frostnet_amd import engine, _lib as L
+    dev = "cuda"
+
+    def run(fused):
+        old = engine._BLOCK_SQCAT
+        engine._BLOCK_SQCAT = fused
+        try:
+            g = torch.Generator(device="cpu").manual_seed(31)
+            E, qa = engine.Engine(dev), engine.QArena(8, dev)
+            w = (torch.randn(r, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(dev).requires_grad_(True)
+            gamma = (torch.rand(r, generator=g) * 0.5 + 0.75).to(dev).requires_grad_(True)
+            beta = (torch.rand(r, generator=g) * 0.2 - 0.05).to(dev).requires_grad_(True)
+            l = E.add_layer(engine.ConvLayer("sq", "pw", w, gamma, beta, torch.zeros(r, device=dev), torch.ones(r, device=dev), torch.zeros((), dtype=torch.int64, device=dev),
+                                             None, 1, 1, True, qa.alloc(), qa.alloc()))
+            qx, qcat = qa.alloc(), qa.alloc()
+            qa.set_qparams(qx, 0.021, 117)
+            qx[4], qx[5] = -2.4, 2.9
+            outs = []
+            for step in range(2):
+                x = E.new_act(n, H, H, cin, qx)
+                x.buf[: x.numel] = torch.randint(-128, 128, (x.numel,), dtype=torch.int16, generator=g).to(torch.int8).to(dev)
+                E.begin_step()
+                L.CALL_LOG = []
+                sq = E.conv(l, x, True, True, cat=(x.q, qcat))
+                y = E.cat(sq, x, qcat, True)
+                torch.cuda.synchronize()
+                log, L.CALL_LOG = list(L.CALL_LOG), None
+                assert ("frost_sq_emit_cat" in log) == fused and ("frost_cat_requant" in log) == (not fused), log
+                outs.append((sq.buf[: sq.numel].clone(), y.buf[: y.numel].clone(), qcat.clone(), l.qy.clone()))
+            return outs
+        finally:
+            engine._BLOCK_SQCAT = old
+            L.CALL_LOG = None
+    a, b = run(True), run(False)
+    for sa, sb in zip(a, b):
+        for ta, tb in zip(sa, sb):
+            assert torch.equal(ta, tb)
