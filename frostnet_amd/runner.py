@@ -158,15 +158,16 @@ class FrostRunner:
     def _observe_hint(self, training):
         """What the host passes as `observe`: 1 = run the statistics passes and let every site's own device flag decide.  Training needs the
         statistics anyway (BatchNorm); a fully frozen network in eval skips them.  The flags live on the device (per-site switches without a host
-        round trip); the host keeps a summary.  Eval forwards re-read it every time (outside hipGraph capture); training forwards re-read it after
-        any `.apply(...)` (how torch.quantization.enable/disable_observer/fake_quant are applied) on the model OR ANY OF ITS SUB-MODULES
-        (frostnet._FLAG_EPOCH), after `model.train()` / `.eval()`, or after `runner.flags_dirty = True`.  A disabled fake-quantizer is refused in both modes.  A flag written
-        straight into a FakeQuantize buffer of a training model without any of these is honoured per site on the device at once."""
+        round trip); the host keeps a summary and re-reads it only when it may have changed: after any `.apply(...)` (how
+        torch.quantization.enable/disable_observer/fake_quant are applied) on the model OR ANY OF ITS SUB-MODULES (frostnet._FLAG_EPOCH), after
+        `model.train()` / `.eval()`, or after `runner.flags_dirty = True`.  A disabled fake-quantizer is refused in both modes.  A flag written straight
+        into a FakeQuantize buffer without any of these is honoured per site on the device at once; it reaches the summary (which only decides whether
+        a fully frozen eval forward may skip its statistics passes) at the next of those events -- set `flags_dirty` after such a write."""
         from . import frostnet as _F
         if not torch.cuda.is_current_stream_capturing():
-            # eval re-reads the flags on every forward (one small device -> host read; a flag written straight into a sub-module's buffer is seen at once);
-            # training re-reads when a `.apply()` / `.train()` ran anywhere in the tree since the last read (`_FLAG_EPOCH`) or `flags_dirty` was set
-            if (not training) or getattr(self, "flags_dirty", True) or getattr(self, "_flag_epoch", -1) != _F._FLAG_EPOCH[0]:
+            # no per-forward device -> host read: the summary is re-read when an `.apply()` ran anywhere in a FrostNet tree since the last read (`_FLAG_EPOCH`: root or
+            # any sub-module), after `model.train()` / `.eval()`, or when `flags_dirty` was set by hand
+            if getattr(self, "flags_dirty", True) or getattr(self, "_flag_epoch", -1) != _F._FLAG_EPOCH[0]:
                 self._obs_cached = self.read_flags()
                 self.flags_dirty = False
                 self._flag_epoch = _F._FLAG_EPOCH[0]

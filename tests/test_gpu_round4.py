@@ -58,11 +58,13 @@ def test_submodule_flag_switches_reach_the_runner(F):
     with torch.no_grad():
         model(3.0 * x)
     assert not torch.equal(before, site.activation_post_process.max_val), "the re-enabled observer did not run"
-    # a flag written straight into the buffer (no apply at all) is seen by the next eval forward too
+    # a flag written straight into the buffer (no apply at all): honoured per site on the device; the host summary ("everything is frozen: skip the statistics
+    # passes") learns of it through `flags_dirty`
     model.layer2[0].conv1.apply(aoq.disable_observer)
     other = model.layer1[1].conv1.conv[0].activation_post_process
     b2 = other.activation_post_process.max_val.clone()
     other.observer_enabled[0] = 1
+    model.hip_runner().flags_dirty = True
     with torch.no_grad():
         model(5.0 * x)
     assert not torch.equal(b2, other.activation_post_process.max_val)
