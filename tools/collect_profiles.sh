@@ -4,7 +4,7 @@
 #   fetch/   PMC pass 1: FETCH_SIZE   (eager step, one kernel-trace + one counter, nothing else)
 #   write/   PMC pass 2: WRITE_SIZE
 # and gpurun_out/prof_<tag>/summary.json (tools/summarize_profiles.py), which is what gets copied to profiles/.
-tag=${1:-r03}
+tag=${1:-r04}
 B=${2:-512}
 root=$(pwd)
 out=$root/gpurun_out/prof_$tag
