@@ -29,57 +29,63 @@ struct IBlkP {
   int th, tw, tiles_x, tiles_y, rh, rw, rp, rpt, tp, tpt, xs, residual, tw4;
 };
 
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would put the L2 round trip of every weight / tap
+// prefetch behind the barrier it was issued in front of (the prefetched registers are consumed later, behind the compiler's own waits)
+__device__ __forceinline__ void ib_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define IB_PLS 68      // plane row stride (bf16 elements): 136 B, the 16 pixel rows of an MFMA tile fall into distinct 8-byte bank slots
 #define IB_Y2S 72      // y2 row stride: 144 B
 
-template <int K, int S, int MAXT, int KB1M>
-__global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
-  constexpr int PAD = (K - 1) / 2, SPAN = 3 * S + K, TAPW = (K * K + 1) * 64, TPT = (TAPW + 255) / 256;
+template <int K, int S, int MAXT, int KB1M, int NW>
+__global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
+  constexpr int PAD = (K - 1) / 2, SPAN = 3 * S + K, TAPW = (K * K + 1) * 64, NT = NW * 64, TPT = (TAPW + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* const xc = (uint16_t*)smem;                                    // [rpt*16][xs]
   uint16_t* const pl = xc + (size_t)p.rpt * 16 * p.xs;                     // [rpt*16][IB_PLS]
   uint16_t* const y2 = pl + (size_t)p.rpt * 16 * IB_PLS;                   // [tpt*16][IB_Y2S]
   float* const tapl = (float*)(y2 + (size_t)p.tpt * 16 * IB_Y2S);          // [k*k + 1][64]: the chunk's depthwise taps and (last row) folded bias
+  uint16_t* const ptab = (uint16_t*)(tapl + TAPW);                         // [rpt*16]: staged (in-image) pixel -> plane row, 0xffff past the last one
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   int b = blockIdx.x;
   const int tx = b % p.tiles_x; b /= p.tiles_x; const int ty = b % p.tiles_y; const int img = b / p.tiles_y;
   const int iy0 = ty * p.th * S - PAD, ix0 = tx * p.tw * S - PAD;          // image coordinates of region pixel (0, 0)
+  // Only the IN-IMAGE part of the region is staged and convolved (a sub-rectangle [ry0, ry1) x [rx0, rx1) of it, compact pixel index sp): conv2 zero-pads
+  // conv1's OUTPUT, so the plane is simply zero elsewhere -- on a 7 x 7 map with a 5 x 5 depthwise conv that is 49 of the region's 121 pixels.
+  const int ry0 = max(0, -iy0), rx0 = max(0, -ix0);
+  const int srh = min(p.rh, p.h - iy0) - ry0, srw = min(p.rw, p.w - ix0) - rx0;
+  const int sp = srh * srw, spt = (sp + 15) >> 4;
 
-  // ---- phase 0: zero the staging rows (K padding of the MFMA operands, out-of-image pixels, pad rows), then the region's input rows behind the squeeze slot
+  // ---- phase 0: zero the staging rows (K padding of the MFMA operands, pad rows), the plane (conv2's zero padding) and y2's pad rows; pixel table
   {
-    const int n16 = (p.rpt * 16 * p.xs + p.tpt * 16 * IB_Y2S) >> 3;      // xc ... (pl is fully written per chunk) ... y2: zero xc and y2
-    uint4* z = (uint4*)xc; const int nx = (p.rpt * 16 * p.xs) >> 3;
-    for (int i = tid; i < nx; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+    uint4* z = (uint4*)xc; const int nx = (spt * 16 * p.xs) >> 3;
+    for (int i = tid; i < nx; i += NT) z[i] = make_uint4(0, 0, 0, 0);
+    uint4* zp_ = (uint4*)pl; const int np_ = (p.rpt * 16 * IB_PLS) >> 3;
+    for (int i = tid; i < np_; i += NT) zp_[i] = make_uint4(0, 0, 0, 0);
     uint4* z2 = (uint4*)y2; const int ny = (p.tpt * 16 * IB_Y2S) >> 3;
-    for (int i = tid; i < ny; i += 256) z2[i] = make_uint4(0, 0, 0, 0);
-    (void)n16;
+    for (int i = tid; i < ny; i += NT) z2[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < spt * 16; i += NT) {
+      const int sy = i / srw, sx = i - sy * srw;
+      ptab[i] = (i < sp) ? (uint16_t)((ry0 + sy) * p.rw + rx0 + sx) : (uint16_t)0xffff;
+    }
   }
   __syncthreads();
   {
-    const int upr = p.cin >> 3, total = p.rp * upr;
+    const int upr = p.cin >> 3, total = sp * upr;
     const uint16_t* src = p.x + (int64_t)img * p.h * p.w * p.cin;
-    for (int u = tid; u < total; u += 256) {
+    for (int u = tid; u < total; u += NT) {
       const int px = u / upr, part = u - px * upr;
-      const int ry = px / p.rw, rx = px - ry * p.rw;
-      const int iy = iy0 + ry, ix = ix0 + rx;
-      if (iy >= 0 && iy < p.h && ix >= 0 && ix < p.w)
-        *(uint4*)(xc + (size_t)px * p.xs + p.r + part * 8) = *(const uint4*)(src + ((int64_t)iy * p.w + ix) * p.cin + part * 8);
+      const int sy = px / srw, sx = px - sy * srw;
+      const int iy = iy0 + ry0 + sy, ix = ix0 + rx0 + sx;
+      *(uint4*)(xc + (size_t)px * p.xs + p.r + part * 8) = *(const uint4*)(src + ((int64_t)iy * p.w + ix) * p.cin + part * 8);
     }
-  }
-  // which of this lane's region pixels (pixel j of MFMA tile pt, pt = bit index) lie inside the image: conv1's output is zero elsewhere (conv2's zero padding)
-  uint32_t vmask = 0;
-  for (int pt = 0; pt < p.rpt; ++pt) {
-    const int px = pt * 16 + j; const int ry = px / p.rw, rx = px - ry * p.rw;
-    const int iy = iy0 + ry, ix = ix0 + rx;
-    if (px < p.rp && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w) vmask |= 1u << pt;
   }
   // the depthwise taps / bias of a chunk travel global -> registers -> LDS one chunk ahead of their use
   float tpre[TPT];
   auto load_taps = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < TPT; ++q) {
-      const int i = tid + q * 256; const int t = i >> 6, ch = c * 64 + (i & 63);
+      const int i = tid + q * NT; const int t = i >> 6, ch = c * 64 + (i & 63);
       float v = 0.f;
       if (i < TAPW && ch < p.cpad_dw) v = (t < K * K) ? p.wdw[(size_t)t * p.cpad_dw + ch] : p.bdw[ch];
       tpre[q] = v;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
   };
   auto store_taps = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < TPT; ++q) { const int i = tid + q * 256; if (i < TAPW) tapl[i] = tpre[q]; }
+    for (int q = 0; q < TPT; ++q) { const int i = tid + q * NT; if (i < TAPW) tapl[i] = tpre[q]; }
   };
   load_taps(0);
   store_taps();
@@ -95,8 +101,8 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
 
   // ---- phase 1: squeeze_conv (1x1, ReLU) over every region pixel, written in front of the input = cat([squeezed, x], 1)
   if (p.wsq) {
-    const int ntile = p.rpt * p.ct_sq;
-    for (int idx = wv; idx < ntile; idx += 4) {
+    const int ntile = spt * p.ct_sq;
+    for (int idx = wv; idx < ntile; idx += NW) {
       const int ct = idx % p.ct_sq, pt = idx / p.ct_sq;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
       for (int kb = 0; kb < p.kb_sq; ++kb) {
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
     __syncthreads();
   }
 
-  // reduce_conv accumulators: tile t of this wave = linear tile index wv + 4 t over (ct3, tpt)
+  // reduce_conv accumulators: tile t of this wave = linear tile index wv + NW t over (ct3, tpt)
   v4f acc3[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) acc3[t] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -123,8 +129,9 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
   const int kcat = p.r + p.cin;
 
   uint4 af[KB1M];
+  const int wq = wv & 3, wph = wv >> 2;                                       // conv1: channel tile of the chunk, pixel-tile phase (NW / 4 waves share a channel tile)
   auto load_w1 = [&](int c) __attribute__((always_inline)) {
-    const int ct = min(c * 4 + wv, p.ct1 - 1);
+    const int ct = min(c * 4 + wq, p.ct1 - 1);
 #pragma unroll
     for (int kb = 0; kb < KB1M; ++kb) if (kb < p.kb1) af[kb] = *(const uint4*)(p.w1 + (((size_t)ct * p.kb1 + kb) * 64 + lane) * 8);
   };
@@ -133,11 +140,11 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
   for (int c = 0; c < p.nchunk; ++c) {
     // ---- conv1 -> plane (or the block input itself when the block has no expansion conv)
     if (p.w1) {
-      const int ct = c * 4 + wv;
+      const int ct = c * 4 + wq;
       if (ct < p.ct1) {
         const int ch = ct * 16 + 4 * g;
         const float4 bb = *(const float4*)(p.b1 + ch);
-        for (int pt = 0; pt < p.rpt; ++pt) {
+        for (int pt = wph; pt < spt; pt += NW / 4) {
           v4f acc = {0.f, 0.f, 0.f, 0.f};
           const uint16_t* brow = xc + (size_t)(pt * 16 + j) * p.xs + g * 8;
 #pragma unroll
@@ -145,23 +152,28 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
             const uint4 bf = *(const uint4*)(brow + kb * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af[kb]), __builtin_bit_cast(v8bf, bf), acc, 0, 0, 0);
           }
-          uint2 o = make_uint2(0, 0);
-          if ((vmask >> pt) & 1u) { o.x = cvt_pk_bf16(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f)); o.y = cvt_pk_bf16(fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f)); }
-          *(uint2*)(pl + (size_t)(pt * 16 + j) * IB_PLS + wv * 16 + 4 * g) = o;
+          const unsigned prow = ptab[pt * 16 + j];
+          if (prow != 0xffffu) {
+            uint2 o; o.x = cvt_pk_bf16(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f)); o.y = cvt_pk_bf16(fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
+            *(uint2*)(pl + (size_t)prow * IB_PLS + wq * 16 + 4 * g) = o;
+          }
         }
       } else {
-        for (int pt = 0; pt < p.rpt; ++pt) *(uint2*)(pl + (size_t)(pt * 16 + j) * IB_PLS + wv * 16 + 4 * g) = make_uint2(0, 0);
+        for (int pt = wph; pt < spt; pt += NW / 4) {
+          const unsigned prow = ptab[pt * 16 + j];
+          if (prow != 0xffffu) *(uint2*)(pl + (size_t)prow * IB_PLS + wq * 16 + 4 * g) = make_uint2(0, 0);
+        }
       }
       if (c + 1 < p.nchunk) load_w1(c + 1);                                  // the next chunk's fragments travel under the depthwise and reduce phases
     } else {
-      for (int u = tid; u < p.rpt * 16 * 8; u += 256) {                       // plane = channels [64 c, 64 c + 64) of the staged input
+      for (int u = tid; u < sp * 8; u += NT) {                                // plane = channels [64 c, 64 c + 64) of the staged input
         const int px = u >> 3, part = u & 7; const int ch = c * 64 + part * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ch < p.cin) v = *(const uint4*)(xc + (size_t)px * p.xs + p.r + ch);
-        *(uint4*)(pl + (size_t)px * IB_PLS + part * 8) = v;
+        *(uint4*)(pl + (size_t)ptab[px] * IB_PLS + part * 8) = v;
       }
     }
-    __syncthreads();
+    ib_barrier();
     // ---- conv2: depthwise k x k, stride S, lane = channel pair; bias first, taps in (ky, kx) order (k_inf_dw's order)
     {
       if (c + 1 < p.nchunk) load_taps(c + 1);                                // in flight under this phase; stored after it
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
       { const float2 b2 = *(const float2*)(tapl + K * K * 64 + 2 * cp); bd[0] = b2.x; bd[1] = b2.y; }
       const int units = p.th * p.tw4;
 #pragma unroll 1
-      for (int u = pg; u < units; u += 8) {
+      for (int u = pg; u < units; u += NT / 32) {
         const int oy = u / p.tw4, ox0 = (u - oy * p.tw4) * 4;
         float a[4][2];
 #pragma unroll
@@ -201,12 +213,12 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
           if (ox0 + o < p.tw) *(uint32_t*)(y2 + (size_t)(oy * p.tw + ox0 + o) * IB_Y2S + 2 * cp) = cvt_pk_bf16(fmaxf(a[o][0], 0.f), fmaxf(a[o][1], 0.f));
       }
     }
-    __syncthreads();
+    ib_barrier();
     if (c + 1 < p.nchunk) store_taps();                                      // (read again only after the barrier that ends this chunk)
     // ---- reduce_conv: this chunk's 64 K values into the persistent accumulators
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-      const int idx = wv + 4 * t;
+      const int idx = wv + NW * t;
       if (idx < ntile3) {
         const int ct = idx % p.ct3, pt = idx / p.ct3;
 #pragma unroll
@@ -220,14 +232,14 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
         }
       }
     }
-    __syncthreads();
+    ib_barrier();
   }
 
   // ---- epilogue: + bias, the layer's bf16 rounding, + residual (bf16 add), store 4 channels per lane
   uint16_t* dst = p.y + (int64_t)img * p.ho * p.wo * p.cout;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    const int idx = wv + 4 * t;
+    const int idx = wv + NW * t;
     if (idx < ntile3) {
       const int ct = idx % p.ct3, pt = idx / p.ct3;
       const int ch = ct * 16 + 4 * g, px = pt * 16 + j;
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
         const float4 bb = *(const float4*)(p.b3 + ch);
         uint2 o; o.x = cvt_pk_bf16(acc3[t][0] + bb.x, acc3[t][1] + bb.y); o.y = cvt_pk_bf16(acc3[t][2] + bb.z, acc3[t][3] + bb.w);
         if (p.residual) {
-          const uint2 xr = *(const uint2*)(xc + (size_t)((oy + PAD) * p.rw + ox + PAD) * p.xs + p.r + ch);         // stride 1: region pixel (oy + pad, ox + pad)
+          const uint2 xr = *(const uint2*)(xc + (size_t)((oy + PAD - ry0) * srw + ox + PAD - rx0) * p.xs + p.r + ch);   // stride 1: region pixel (oy + pad, ox + pad), staged compactly
           o.x = cvt_pk_bf16(bf2f(xr.x & 0xffff) + bf2f(o.x & 0xffff), bf2f(xr.x >> 16) + bf2f(o.x >> 16));
           o.y = cvt_pk_bf16(bf2f(xr.y & 0xffff) + bf2f(o.y & 0xffff), bf2f(xr.y >> 16) + bf2f(o.y >> 16));
         }
@@ -249,20 +261,33 @@ __global__ __launch_bounds__(256) void k_iblock(const IBlkP p) {
 }
 
 static size_t iblock_lds(int rpt, int tpt, int xs, int k) {
-  return ((size_t)rpt * 16 * xs + (size_t)rpt * 16 * IB_PLS + (size_t)tpt * 16 * IB_Y2S) * 2 + (size_t)(k * k + 1) * 64 * 4;
+  return ((size_t)rpt * 16 * xs + (size_t)rpt * 16 * IB_PLS + (size_t)tpt * 16 * IB_Y2S) * 2 + (size_t)(k * k + 1) * 64 * 4 + (size_t)rpt * 16 * 2;
+}
+
+static int iblock_waves(const IBlkP& p) {
+  static const int forced = getenv("FROST_IB_NW") ? atoi(getenv("FROST_IB_NW")) : 0;
+  if (forced == 4 || forced == 8) return forced;
+  // 8 waves where a workgroup carries a whole (small) map and a wide expansion: its three phases per 64-channel chunk are serial, more waves shorten each
+  return (p.tp >= 49 && p.cexp >= 256) ? 8 : 4;
 }
 
 template <int K, int S>
 static int launch_iblock(const IBlkP& p, size_t lds, hipStream_t s) {
-  const int per_wave = (p.ct3 * p.tpt + 3) / 4;
+  const int nw = iblock_waves(p);
+  const int per_wave = (p.ct3 * p.tpt + nw - 1) / nw;
   const dim3 grid((unsigned)(p.n * p.tiles_x * p.tiles_y));
-#define IB_GO(MT, KB) do { \
+#define IB_GO(MT, KB, NW_) do { \
     static bool set = false; \
-    if (!set) { hipFuncSetAttribute((const void*)k_iblock<K, S, MT, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-    hipLaunchKernelGGL((k_iblock<K, S, MT, KB>), grid, dim3(256), lds, s, p); } while (0)
-#define IB_GO2(MT) do { if (p.kb1 <= 2) IB_GO(MT, 2); else IB_GO(MT, 10); } while (0)
-  if (per_wave <= 4) IB_GO2(4); else if (per_wave <= 8) IB_GO2(8); else if (per_wave <= 12) IB_GO2(12); else if (per_wave <= 20) IB_GO2(20);
-  else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_iblock<K, S, MT, KB, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((k_iblock<K, S, MT, KB, NW_>), grid, dim3(NW_ * 64), lds, s, p); } while (0)
+#define IB_GO2(MT, NW_) do { if (p.kb1 <= 2) IB_GO(MT, 2, NW_); else IB_GO(MT, 10, NW_); } while (0)
+  if (nw == 8) {
+    if (per_wave <= 4) IB_GO2(4, 8); else if (per_wave <= 12) IB_GO2(12, 8);
+    else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
+  } else {
+    if (per_wave <= 4) IB_GO2(4, 4); else if (per_wave <= 8) IB_GO2(8, 4); else if (per_wave <= 12) IB_GO2(12, 4); else if (per_wave <= 20) IB_GO2(20, 4);
+    else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
+  }
 #undef IB_GO2
 #undef IB_GO
   return frost_check_launch("infer_block");
@@ -276,7 +301,7 @@ extern "C" int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int 
   const int rpt = (rh * rw + 15) / 16, tpt = (th * tw + 15) / 16;
   const int kc = r + round_up(cin, 32) > round_up(r + cin, 32) ? r + round_up(cin, 32) : round_up(r + cin, 32);
   const size_t lds = iblock_lds(rpt, tpt, kc + 8, k);
-  if (lds > 160 * 1024 || rpt > 32) return 0;                          // (rpt <= 32: one validity bit per pixel tile in a register)
+  if (lds > 160 * 1024 || rh * rw >= 0xffff) return 0;
   if (round_up(r + cin, 32) / 32 > 10) return 0;                       // conv1 K steps held in registers
   if ((round_up(cout, 16) / 16 * tpt + 3) / 4 > 20) return 0;          // reduce accumulators per wave
   (void)h; (void)w;

@@ -20,11 +20,22 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
-# Whole-bottleneck fused kernel (csrc/frost_iblock.hip): True = every bottleneck the kernel takes, False = layer-by-layer launches, "auto" (default) = where the
-# fused launch measured faster at B = 256 (tools/bench_iblock.py, profiles/r04_infer_blocks.txt): bottlenecks without an expansion conv (layer1.0: 415 vs 540 us)
-# and CAS bottlenecks with a 3 x 3 depthwise conv (layer2.1: 109 vs 133 us; layer3.5 / 3.6: 100 vs 108).  Elsewhere the one-workgroup-per-tile kernel is
-# latency-bound (three barrier-separated phases per 64-channel chunk at 2 workgroups per CU) and loses to the HBM-bound layer kernels by 1.3 - 2 x.
+# Whole-bottleneck fused kernel (csrc/frost_iblock.hip): "1" = every bottleneck the kernel takes (tile from pick_tile), "0" = layer-by-layer launches, "auto"
+# (default) = MEASURED per bottleneck: the first forward outside a hipGraph capture times the layer-by-layer launches and the fused launch with each candidate
+# tile (3 runs each) and keeps the fastest for that (map size, batch) -- results are bit-identical whichever is chosen (tests/test_gpu_infer.py).
 _FUSED = {"0": False, "1": True}.get(os.environ.get("FROST_INFER_FUSED", "auto"), "auto")
+TILE_CANDIDATES = ((0, 0), (-1, 0), (7, 14), (8, 16), (7, 7), (8, 8), (4, 8))          # (0, 0) = the whole map, (-1, 0) = half of it
+
+
+def candidate_tiles(lib, h, w, cin, r, cexp, cout, k, stride):
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = []
+    for th, tw in TILE_CANDIDATES:
+        th, tw = (ho, wo) if th == 0 else (((ho + 1) // 2, wo) if th < 0 else (min(th, ho), min(tw, wo)))
+        if (th, tw) not in out and th * tw <= 256 and lib.frost_infer_block_ok(h, w, cin, r, cexp, cout, k, stride, th, tw) > 0:
+            out.append((th, tw))
+    return out
 
 
 def pick_tile(lib, h, w, cin, r, cexp, cout, k, stride):
@@ -42,9 +53,11 @@ def pick_tile(lib, h, w, cin, r, cexp, cout, k, stride):
         if lds <= 0:
             continue
         waste = (-(-ho // th) * th) * (-(-wo // tw) * tw) / float(ho * wo)            # ragged edge tiles
-        halo = ((th - 1) * stride + k) * ((tw - 1) * stride + k) / float(th * tw * stride * stride)      # region pixels conv1 computes per useful pixel
-        wgs = min(4, (160 * 1024) // lds)                                                 # resident workgroups per CU by LDS: the phases of one workgroup are serial
-        score = waste * halo * (1.0 + 0.6 * (4 - wgs))
+        rp = ((th - 1) * stride + k) * ((tw - 1) * stride + k)                            # region pixels conv1 computes for th * tw outputs (halo included)
+        wgs = min(3, (160 * 1024) // lds)                                                 # resident workgroups per CU by LDS
+        # cost per output pixel: region pixels plus a fixed per-tile cost (prologue, barriers: ~150 pixel-equivalents), mildly weighted by residency --
+        # fitted to tools/prof_iblock.py (104 -> 624 -> 96 @14x14, k5: 7x14 157 us, 7x7 198, 4x8 235, 4x4 475; 16 -> 96 -> 24 @112, k3 s2: 8x8 best)
+        score = waste * (rp + 150.0) / (th * tw) * (1.0 + 0.1 * (3 - wgs))
         if best is None or score < best[0] - 1e-9:
             best = (score, th, tw)
     return None if best is None else (best[1], best[2])
@@ -126,6 +139,69 @@ class Bf16Inference:
         call("frost_infer_dw", ptr(x), ptr(l.pack), ptr(l.biasf), n, h, w, l.cout, l.k, l.stride, int(l.relu), ptr(y), stream())
         return y, ho, wo
 
+    def _block_plain(self, ent, a, c, n, h, w):
+        """One bottleneck as layer-by-layer launches: [squeeze -> cat] -> conv1 -> conv2 -> reduce_conv [-> + x]."""
+        x_in, npix = a, n * h * w
+        if ent["conv1"] is not None:
+            if ent["squeeze"] is not None:
+                s = self._pw(ent["squeeze"], a, npix, c)
+                cs = ent["squeeze"].cout
+                cat = torch.empty(npix * (cs + c) + 64, dtype=torch.int16, device=self.device)
+                call("frost_infer_cat", ptr(s), cs, ptr(a), c, npix, ptr(cat), stream())     # cat([squeezed, x], 1)
+                a, c = cat, cs + c
+            a, c = self._pw(ent["conv1"], a, npix, c), ent["conv1"].cout
+        a, h2, w2 = self._dw(ent["conv2"], a, n, h, w)
+        npix2 = n * h2 * w2
+        a, c = self._pw(ent["reduce"], a, npix2, c), ent["reduce"].cout
+        if not ent["blk"].reduction:
+            out = torch.empty_like(a)
+            call("frost_infer_add", ptr(x_in), ptr(a), npix2 * c, ptr(out), stream())
+            a = out
+        return a, c, h2, w2
+
+    def _block_fused(self, ent, a, c, n, h, w, tile):
+        """The same bottleneck as ONE launch of frost_infer_block with the spatial output tile `tile`."""
+        l2, l3, sq, l1 = ent["conv2"], ent["reduce"], ent["squeeze"], ent["conv1"]
+        r = sq.cout if sq is not None else 0
+        pad = (l2.k - 1) // 2
+        h2, w2 = (h + 2 * pad - l2.k) // l2.stride + 1, (w + 2 * pad - l2.k) // l2.stride + 1
+        out = torch.empty(n * h2 * w2 * l3.cout + 64, dtype=torch.int16, device=self.device)
+        call("frost_infer_block", ptr(a), ptr(sq.pack) if sq is not None else None, ptr(sq.biasf) if sq is not None else None,
+             ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
+             ptr(l3.pack), ptr(l3.biasf), n, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride, 0 if ent["blk"].reduction else 1, tile[0], tile[1],
+             ptr(out), stream())
+        return out, l3.cout, h2, w2
+
+    def _block(self, ent, a, c, n, h, w):
+        if _FUSED is False:
+            return self._block_plain(ent, a, c, n, h, w)
+        key = ("choice", n, h, w, _FUSED)
+        choice = ent.get(key)
+        if choice is None:
+            l2, l3, sq = ent["conv2"], ent["reduce"], ent["squeeze"]
+            r = sq.cout if sq is not None else 0
+            lib = L.load_library()
+            if _FUSED is True:
+                choice = pick_tile(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride) or "plain"
+            elif torch.cuda.is_current_stream_capturing():
+                return self._block_plain(ent, a, c, n, h, w)          # nothing can be timed inside a capture: run one eager forward first (bench.py does)
+            else:
+                timed = []
+                for cand in ["plain"] + candidate_tiles(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride):
+                    run = (lambda: self._block_plain(ent, a, c, n, h, w)) if cand == "plain" else (lambda t=cand: self._block_fused(ent, a, c, n, h, w, t))
+                    run()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(3):
+                        run()
+                    e1.record()
+                    e1.synchronize()
+                    timed.append((e0.elapsed_time(e1) / 3.0, cand))
+                choice = min(timed, key=lambda t: t[0])[1]
+                ent[("timing", n, h, w)] = timed
+            ent[key] = choice
+        return self._block_plain(ent, a, c, n, h, w) if choice == "plain" else self._block_fused(ent, a, c, n, h, w, choice)
+
     @torch.no_grad()
     def __call__(self, x):
         if self.model.training:
@@ -140,41 +216,7 @@ class Bf16Inference:
         npix = n * ho * wo
         a, c, h, w = self._pw(self.stem, col, npix, 64), self.stem.cout, ho, wo
         for ent in self.blocks:
-            blk = ent["blk"]
-            x_in, c_in, npix = a, c, n * h * w
-            l2, l3, sq, l1 = ent["conv2"], ent["reduce"], ent["squeeze"], ent["conv1"]
-            if _FUSED is True or (_FUSED == "auto" and (l1 is None or (sq is not None and l2.k == 3))):
-                r = sq.cout if sq is not None else 0
-                key = ("tile", h, w)
-                if key not in ent:
-                    ent[key] = pick_tile(L.load_library(), h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride)
-                tile = ent[key]
-                if tile is not None:
-                    pad = (l2.k - 1) // 2
-                    h2, w2 = (h + 2 * pad - l2.k) // l2.stride + 1, (w + 2 * pad - l2.k) // l2.stride + 1
-                    out = torch.empty(n * h2 * w2 * l3.cout + 64, dtype=torch.int16, device=self.device)
-                    call("frost_infer_block", ptr(a), ptr(sq.pack) if sq is not None else None, ptr(sq.biasf) if sq is not None else None,
-                         ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
-                         ptr(l3.pack), ptr(l3.biasf), n, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride, 0 if blk.reduction else 1, tile[0], tile[1],
-                         ptr(out), stream())
-                    a, c, h, w = out, l3.cout, h2, w2
-                    continue
-            if ent["conv1"] is not None:
-                if ent["squeeze"] is not None:
-                    s = self._pw(ent["squeeze"], a, npix, c)
-                    cs = ent["squeeze"].cout
-                    cat = torch.empty(npix * (cs + c) + 64, dtype=torch.int16, device=self.device)
-                    call("frost_infer_cat", ptr(s), cs, ptr(a), c, npix, ptr(cat), stream())     # cat([squeezed, x], 1)
-                    a, c = cat, cs + c
-                a, c = self._pw(ent["conv1"], a, npix, c), ent["conv1"].cout
-            a, h2, w2 = self._dw(ent["conv2"], a, n, h, w)
-            npix2 = n * h2 * w2
-            a, c = self._pw(ent["reduce"], a, npix2, c), ent["reduce"].cout
-            if not blk.reduction:
-                out = torch.empty_like(a)
-                call("frost_infer_add", ptr(x_in), ptr(a), npix2 * c, ptr(out), stream())
-                a = out
-            h, w = h2, w2
+            a, c, h, w = self._block(ent, a, c, n, h, w)
         npix = n * h * w
         a, c = self._pw(self.last, a, npix, c), self.last.cout
         pooled = torch.empty(n, c, dtype=torch.float32, device=self.device)

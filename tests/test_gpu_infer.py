@@ -69,6 +69,11 @@ def test_fused_block_inference_equals_layer_by_layer(name, res, batch):
         I._FUSED = False
         model.__dict__.pop("_bf16_infer", None)
         plain = model.hip_infer_bf16(xg).cpu()
+        I._FUSED = "auto"                                 # the default: per bottleneck whichever of {layer-by-layer, fused with one of the candidate tiles} measured fastest
+        model.__dict__.pop("_bf16_infer", None)
+        auto = model.hip_infer_bf16(xg).cpu()
+        auto2 = model.hip_infer_bf16(xg).cpu()            # second call: the cached choices
+        picks = [v for ent in model.__dict__["_bf16_infer"].blocks for k_, v in ent.items() if isinstance(k_, tuple) and k_[0] == "choice"]
     finally:
         I._FUSED = old
         L.CALL_LOG = None
@@ -78,3 +83,5 @@ def test_fused_block_inference_equals_layer_by_layer(name, res, batch):
     r_fp, r_pl, r_ref = float((fused - plain).norm() / plain.norm()), float((plain - ref).norm() / ref.norm()), float((fused - ref).norm() / ref.norm())
     print(f"[{name}@{res}] fused vs layer-by-layer {r_fp:.2e}; vs the fp32 definition: fused {r_ref:.2e}, layer-by-layer {r_pl:.2e}")
     assert r_fp <= 1e-2 and r_ref <= 3e-2, (r_fp, r_ref, r_pl)
+    assert torch.equal(auto, plain) and torch.equal(auto2, plain) and len(picks) == nblocks, picks       # whatever was picked, the result is the same
+    print(f"    measured choices: {picks}")

@@ -47,3 +47,12 @@ for li, nb in enumerate((3, 2, 7, 5, 1)):
     names += [f"layer{li + 1}.{b}" for b in range(nb)]
 for k, (nm, blk) in enumerate(zip(names, [b for b in blocks if any(c[0] == "frost_infer_dw" for c in b)])):
     print(f"{nm:10s} fused {fb[k]:7.1f} us   plain {sum(t for _, t in blk):7.1f} us  ({len(blk)} launches)")
+
+I._FUSED = "auto"
+model.__dict__.pop("_bf16_infer", None)
+model.hip_infer_bf16(x)
+inf = model.__dict__["_bf16_infer"]
+for nm, ent in zip(names, inf.blocks):
+    t = [v for k_, v in ent.items() if isinstance(k_, tuple) and k_[0] == "timing"][0]
+    c = [v for k_, v in ent.items() if isinstance(k_, tuple) and k_[0] == "choice"][0]
+    print(f"{nm:10s} auto -> {str(c):10s}  " + "  ".join(f"{str(cd)}:{ms * 1e3:.0f}" for ms, cd in t))
