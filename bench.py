@@ -678,7 +678,7 @@ def main():
                                         f"(noise on; StatAssist FP epoch is a one-off before it), batch={args.batch}/GPU, "
                                         f"{args.res}x{args.res} NHWC, qnnpack qconfig v0 (per-tensor)",
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
-                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype="bf16",
+                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype=("fp32" if runner.E.grad_fp32 else "bf16"),
                                ms_per_step_median_hip_events=round(ms_median, 3),
                                grad_allreduce=comm),
                    roofline=roofline, cpu_baseline=cpu)
