@@ -78,6 +78,7 @@ class FrostOptHyper(C.Structure):
 
 _PROTOS = {
     "frost_abi_version": [],
+    "frost_add_state_floats": [],
     "frost_ticket_words": [],
     "frost_fin_desc_bytes": [],
     "frost_minmax_f32": [P, L, P, P],

@@ -301,4 +301,34 @@ __device__ __forceinline__ bool last_block_done2(uint32_t* counter, unsigned tot
   return *sflag != 0;
 }
 
+// Range (min / max) of a launch WITHOUT same-address float atomics: every workgroup stores its pair into its own slot of `part` (agent-scope stores: written
+// through, like the statistics atomics), the last workgroup to arrive (ticket) folds the gridDim.x pairs.  The same-address atomics this replaces serialise at
+// the memory side (~45 ns each): a range pass of 150-500 workgroups spent 15-40 us in them for 2-5 us of work.  Returns true in thread 0 of the last workgroup
+// with the full range in lo / hi.  part: 2 * gridDim.x floats; sh: 8 floats + one int of shared memory.
+#define FROST_MM_SLOTS 1024
+__device__ __forceinline__ bool range_fold_last(float& lo, float& hi, float* part, uint32_t* ticket, float* sh, int* sflag) {
+  lo = wave_min(lo); hi = wave_max(hi);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w] = lo; sh[4 + w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < nw; ++i) { lo = fminf(lo, sh[i]); hi = fmaxf(hi, sh[4 + i]); }
+    __hip_atomic_store(part + 2 * blockIdx.x, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 2 * blockIdx.x + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!last_block_done2(ticket, gridDim.x, sflag)) return false;
+  lo = INFINITY; hi = -INFINITY;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) {
+    lo = fminf(lo, __hip_atomic_load(part + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    hi = fmaxf(hi, __hip_atomic_load(part + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  lo = wave_min(lo); hi = wave_max(hi);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sh[w] = lo; sh[4 + w] = hi; }
+  __syncthreads();
+  if (threadIdx.x != 0) return false;
+  for (int i = 1; i < nw; ++i) { lo = fminf(lo, sh[i]); hi = fmaxf(hi, sh[4 + i]); }
+  return true;
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

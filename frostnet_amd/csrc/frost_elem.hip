@@ -450,22 +450,21 @@ __global__ __launch_bounds__(256) void k_add_minmax(const int8_t* __restrict__ a
   for (int64_t i = (n16 << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {     // tail (n % 16)
     const float v = add_val((int)a[i], (int)b[i], A, B); lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
-  block_minmax_commit(lo, hi, out2);
-  if (ticket) {        // last workgroup done: the range is complete -> observer update here (no launch of its own), range words re-armed for the next add
-    __shared__ int sflag;
-    if (last_block_done2(ticket, gridDim.x, &sflag) && threadIdx.x == 0) {
-      const float flo = __hip_atomic_load(out2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fhi = __hip_atomic_load(out2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      observer_update_dev(qy, flo, fhi, 0, 0, observe);
-      __hip_atomic_store(out2, INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(out2 + 1, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (ticket) {        // fused form: per-workgroup slots, the last workgroup folds them and runs the observer update (no launch of its own, no same-address float atomics)
+    __shared__ int sflag; __shared__ float shr[8];
+    if (range_fold_last(lo, hi, out2 + 2 + FROST_TICKET_WORDS, ticket, shr, &sflag)) observer_update_dev(qy, lo, hi, 0, 0, observe);
+    return;
   }
+  block_minmax_commit(lo, hi, out2);
 }
-// range pass + MovingAverageMinMax update of the sum's FakeQuantize in one launch.  state3: {lo, hi, arrival ticket}; lo / hi must hold (+inf, -inf) on
-// entry (frost_fill_minmax once) and hold them again on exit, the ticket 0.
+// range pass + MovingAverageMinMax update of the sum's FakeQuantize in one launch.  state: frost_add_state_floats() floats = {2 unused, arrival ticket
+// [FROST_TICKET_WORDS] (zeroed once, left zeroed), 2 * FROST_MM_SLOTS per-workgroup range slots}.
+extern "C" int frost_add_state_floats(void) { return 2 + FROST_TICKET_WORDS + 2 * FROST_MM_SLOTS; }
 extern "C" int frost_add_minmax_observe(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                                         float* state3, float* qrec_y, int observe, void* stream) {
   FROST_REQUIRE(n % 4 == 0, "add: n must be a multiple of 4");
-  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 32768, 512)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, state3, qrec_y,
+  // (with per-workgroup slots the tail no longer grows with the grid: more, thinner workgroups than the atomics form could afford)
+  hipLaunchKernelGGL(k_add_minmax, dim3(grid_for(n, 8192, FROST_MM_SLOTS)), dim3(256), 0, as_stream(stream), a, qrec_a, b, qrec_b, n, state3, qrec_y,
                      (uint32_t*)(state3 + 2), observe);
   return frost_check_launch("add_minmax_observe");
 }

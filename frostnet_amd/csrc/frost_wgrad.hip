@@ -737,27 +737,15 @@ __global__ __launch_bounds__(256) void k_pw_ew_emit_add(const int32_t* __restric
       }
     }
   }
-  __shared__ float slo[4], shi[4]; __shared__ int sflag;
-  lo = wave_min(lo); hi = wave_max(hi);
-  if ((tid & 63) == 0) { slo[tid >> 6] = lo; shi[tid >> 6] = hi; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int i = 1; i < 4; ++i) { lo = fminf(lo, slo[i]); hi = fmaxf(hi, shi[i]); }
-    if (lo < __hip_atomic_load(state3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_min_f32(state3, lo);
-    if (hi > __hip_atomic_load(state3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomic_max_f32(state3 + 1, hi);
-  }
-  if (last_block_done2((uint32_t*)(state3 + 2), gridDim.x, &sflag) && tid == 0) {
-    const float flo = __hip_atomic_load(state3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), fhi = __hip_atomic_load(state3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    observer_update_dev(qsum, flo, fhi, 0, 0, observe);
-    __hip_atomic_store(state3, INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(state3 + 1, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  __shared__ int sflag; __shared__ float shr[8];
+  if (range_fold_last(lo, hi, state3 + 2 + FROST_TICKET_WORDS, (uint32_t*)(state3 + 2), shr, &sflag)) observer_update_dev(qsum, lo, hi, 0, 0, observe);
 }
 extern "C" int frost_pw_ew_emit_add(const int32_t* conv_out, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const int8_t* a,
                                     const float* qrec_a, int8_t* y, float* state3, float* qrec_sum, int observe, void* stream) {
   FROST_REQUIRE((cout & 3) == 0 && conv_out && a && y && state3 && qrec_sum, "pw_ew_emit_add: cout must be a multiple of 4, all buffers given");
   const int cpad = round_up(cout, 16); const int c4n = cout >> 2;
   const int64_t tot = npix * c4n;
-  int64_t grid = (tot + 255) / 256; if (grid > 1024) grid = 1024;           // few, fat workgroups: every one ends with two float atomics on ONE pair of words
+  int64_t grid = (tot + 1023) / 1024; if (grid > FROST_MM_SLOTS) grid = FROST_MM_SLOTS;           // one range slot per workgroup (range_fold_last)
   const int64_t gmin = (c4n + 255) / 256; if (grid < gmin) grid = gmin;
   hipLaunchKernelGGL(k_pw_ew_emit_add, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, a, qrec_a, y, state3,
                      qrec_sum, observe);

@@ -28,9 +28,9 @@ _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-ima
 _PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
 _BLOCK_FUSE = os.environ.get("FROST_BLOCK_FUSE", "1") != "0"   # block-boundary folds: the cat's observer update rides in the squeeze's finalize tail
-# reduce emit + residual-add range pass in one launch (frost_pw_ew_emit_add).  Bit-identical to the two launches it replaces, but NOT faster: measured 24.8-24.9 ms
-# per step with it vs 24.7-24.8 without (profiles/r03_block_fusion_ab.txt) -- the element-wise kernels' time is their single-workgroup observer tail, which
-# the fusion keeps.  Off by default; kept as an entry point and as the measurement behind DESIGN (f).
+# reduce emit + residual-add range pass in one launch (frost_pw_ew_emit_add), bit-identical to the two launches it replaces.  Slower than them in round 3 (both ended in
+# same-address float atomics, one pair per workgroup, ~45 ns each); since the range passes keep per-workgroup slots and the last workgroup folds them
+# (range_fold_last, csrc/frost_common.h: add_fwd_minmax 18-39 -> 13-28 us) the fused launch is 19-23 us against 12 + 17: on by default (round 4; -9 launches).
 _BLOCK_PAIR = int(os.environ.get("FROST_BLOCK_PAIR", "3"))         # conv1 emit + conv2 statistics at the 14x14 / 7x7 stages: 1 = one launch (k_blk_expand_dw), 2 = chunked emit + image-resident statistics, 3 = whichever measured faster per shape (2 for 5x5 on 14x14: 103 vs 120 us), 0 = layer kernels
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
@@ -40,7 +40,7 @@ _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # larg
 # weight gradient on the second stream (-0.08 ms at B = 512).  A per-image rule: the decision is about which STAGE a layer belongs to and must not flip with the batch size
 _PW_FUSE_MINMAP = int(os.environ.get("FROST_PW_FUSE_MINMAP", "400"))
 _PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
-_BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "0") != "0"
+_BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "1") != "0"
 _BLOCK_SQCAT = os.environ.get("FROST_BLOCK_SQCAT", "1") != "0"      # squeeze_conv emit + cat requantisation in one launch (frost_sq_emit_cat), bit-identical to the two it replaces
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -439,8 +439,8 @@ class Engine:
         return y
 
     def _add_state(self):
-        if not hasattr(self, "_add_mm"):      # {lo, hi, arrival ticket}: armed once, every launch leaves it armed again
-            self._add_mm = torch.tensor([float("inf"), float("-inf")] + [0.0] * L.TICKET_WORDS, dtype=torch.float32, device=self.device)
+        if not hasattr(self, "_add_mm"):      # {2 unused, arrival ticket, per-workgroup range slots}: zeroed once, every launch leaves the ticket zeroed again
+            self._add_mm = torch.zeros(L.load_library().frost_add_state_floats(), dtype=torch.float32, device=self.device)
         return self._add_mm
 
     def add(self, a, b, q, observe=True):

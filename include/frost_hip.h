@@ -29,7 +29,8 @@ extern "C" {
 
 /* ABI history (a caller built against an older header MUST NOT call a newer library, and vice versa: check frost_abi_version() at load time)
  *   2 -> 3 (round 3/4): every last-workgroup-done ticket buffer grew from 1 to FROST_TICKET_WORDS (40) zeroed uint32 words -- FrostFinDesc.counter, and
- *          the state of frost_add_minmax_observe / frost_pw_ew_emit_add is {lo, hi, ticket[FROST_TICKET_WORDS]} (was {lo, hi, ticket}); FrostFinDesc gained
+ *          the state of frost_add_minmax_observe / frost_pw_ew_emit_add is frost_add_state_floats() floats: {2 unused, ticket[FROST_TICKET_WORDS], per-workgroup
+ *          range slots} (was {lo, hi, ticket}); FrostFinDesc gained
  *          cat_qrec_b / cat_qrec_y.  A 1-word ticket under the new kernels is an out-of-bounds device atomic: frost_ticket_words() and
  *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does). */
 #define FROST_ABI_VERSION 3
@@ -148,6 +149,7 @@ int frost_add_minmax(const int8_t* a, const float* qrec_a, const int8_t* b, cons
                      float* minmax2, void* stream);
 /* the same range pass with the MovingAverageMinMax update of the sum's FakeQuantize folded into its last workgroup (replaces frost_fill_minmax +
  * frost_add_minmax + frost_observer_update: one launch instead of three).  state3 = {lo, hi, arrival ticket[FROST_TICKET_WORDS]}: (+inf, -inf, 0...) on entry and again on exit. */
+int frost_add_state_floats(void);      /* floats of the `state` buffer of frost_add_minmax_observe / frost_pw_ew_emit_add: {2 unused, ticket[FROST_TICKET_WORDS], 2 * 1024 per-workgroup range slots}, zero-filled once */
 int frost_add_minmax_observe(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
                              float* state3, float* qrec_y, int observe, void* stream);
 int frost_add_requant(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n,
