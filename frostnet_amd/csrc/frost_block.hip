@@ -1202,7 +1202,8 @@ extern "C" int frost_block_bwd(const FrostBlockDesc* d, const FrostBlockBwd* b, 
 struct SqCatP {
   const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum; const float* coef; const float* qsq; const float* qcat;
   int8_t* ysq; int8_t* ycat; int64_t npix; int cin, r, cpad, kstr;
-};
+  int cvt;       // 0: fake-quant emit q = rint(fma(A, acc, B) / s_y) + zp;  1: converted QNNPACK form q = rint(float(acc + b_q) * A) + zp (row B = int32 bias bits);
+};               // 2: converted FBGEMM form q = rint((float(acc) + B) * A) + zp   (k_pw's emit flavours, csrc/frost_pw.hip)
 template <int KSM>
 __global__ __launch_bounds__(256) void k_sq_emit_cat(const SqCatP p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1254,8 +1255,12 @@ __global__ __launch_bounds__(256) void k_sq_emit_cat(const SqCatP p) {
       uint32_t packed = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float yv = fmaf(A[r], (float)acc[r], B[r]);
-        float qv = rintf(yv * y_inv) + y_zpf;
+        float qv;
+        if (p.cvt == 2) qv = rintf(((float)acc[r] + B[r]) * A[r]) + y_zpf;
+        else {
+          const float yv = (p.cvt == 1) ? fmaf(A[r], (float)(acc[r] + __float_as_int(B[r])), 0.0f) : fmaf(A[r], (float)acc[r], B[r]);
+          qv = rintf(yv * (p.cvt == 1 ? 1.0f : y_inv)) + y_zpf;
+        }
         if (lowq) qv = fminf(qv, qcap);
         packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
       }
@@ -1283,9 +1288,11 @@ __global__ __launch_bounds__(256) void k_sq_emit_cat(const SqCatP p) {
 }
 extern "C" int frost_sq_emit_cat_ok(int cin, int r) { return (cin % 8 == 0) && (r % 4 == 0) && cin <= 192 && r <= 128; }
 extern "C" int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, const float* coef,
-                                 const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, void* stream) {
+                                 const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, int mode, void* stream) {
   FROST_REQUIRE(frost_sq_emit_cat_ok(cin, r), "sq_emit_cat: cin <= 192 (multiple of 8), r <= 128 (multiple of 4)");
+  FROST_REQUIRE(mode >= 1 && mode <= 3, "sq_emit_cat: mode 1 (fake-quant emit), 2 / 3 (converted QNNPACK / FBGEMM form), as frost_pw_conv_fwd");
   SqCatP p = {};
+  p.cvt = mode - 1;
   p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = coef; p.qsq = qrec_sq; p.qcat = qrec_cat; p.ysq = y_sq; p.ycat = y_cat;
   p.npix = npix; p.cin = cin; p.r = r; p.cpad = round_up(r, 16);
   const int ksm = round_up(cin, 64) / 64;

@@ -355,7 +355,7 @@ class Engine:
             # squeeze_conv of a CAS bottleneck: emit + both halves of the cat from one staged x tile (the cat's record was finalized in the statistics launch's tail)
             ycat = self.new_act(x.n, ho, wo, l.cout + x.c, cat[1])
             call("frost_sq_emit_cat", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.coef), ptr(l.qy), ptr(cat[1]), ptr(y.buf), ptr(ycat.buf),
-                 stream(), prof=("pw_fwd_emit", x.numel + l.wq_pack.numel() + y.numel + ycat.numel))
+                 1, stream(), prof=("pw_fwd_emit", x.numel + l.wq_pack.numel() + y.numel + ycat.numel))
             y.cat_done = ycat
         else:
             self._conv_launch(l, x, 1, y)
@@ -500,7 +500,7 @@ class Engine:
         self._ensure_tables()
         call("frost_weight_prep", ptr(self._table), len(self.layers), self._max_elems, self.rule127, 1 if observe else 0, stream())
 
-    def conv_converted(self, l, x, fb=False):
+    def conv_converted(self, l, x, fb=False, cat=None):
         """quantized::conv2d(_relu) of the converted model: integer bias + fp32 requantisation in the emit epilogue (mode 2); fb = the FBGEMM engine's form
         for a per-channel ('fbgemm' qconfig) model: float bias + per-channel multipliers (mode 3)."""
         pad = (l.k - 1) // 2
@@ -511,6 +511,14 @@ class Engine:
             x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
         self._converted_coef(l, x.q, fb)
+        if cat is not None and _BLOCK_SQCAT and l.kind == "pw" and L.load_library().frost_sq_emit_cat_ok(x.c, l.cout):
+            # squeeze_conv of a CAS bottleneck: the converted emit and both halves of the cat (records frozen) in one launch
+            ycat = self.new_act(x.n, ho, wo, l.cout + x.c, cat)
+            call("frost_sq_emit_cat", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.coef), ptr(l.qy), ptr(cat), ptr(y.buf), ptr(ycat.buf),
+                 3 if fb else 2, stream())
+            if getattr(self, "trace", None) is not None:
+                self.trace.append((l.name, y)); self.trace.append(("cat", ycat))
+            return ycat
         self._conv_launch(l, x, 3 if fb else 2, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))

@@ -440,7 +440,9 @@ class FrostRunner:
             inp, out = a, a
             if d["conv1"] is not None:
                 if d["squeeze"] is not None:
-                    out = E.cat(E.conv_converted(d["squeeze"], inp, fb), inp, d["q_cat"], observe=False)
+                    out = E.conv_converted(d["squeeze"], inp, fb, cat=d["q_cat"])          # returns the cat when the fused launch applies ...
+                    if out.c != d["squeeze"].cout + inp.c:                                  # ... else the squeezed activation
+                        out = E.cat(out, inp, d["q_cat"], observe=False)
                 out = E.conv_converted(d["conv1"], out, fb)
             out = E.conv_converted(d["conv2"], out, fb)
             out = E.conv_converted(d["reduce"], out, fb)

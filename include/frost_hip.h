@@ -285,7 +285,7 @@ int frost_g32_pool_bwd(const float* dpool, const float* drop, int n, int hw, int
  * frost_cat_requant, bit-identical; the cat's record qrec_cat must be final (FrostFinDesc.cat_qrec_y of the squeeze's statistics launch).  y_sq: [npix][r], y_cat: [npix][r + cin]. */
 int frost_sq_emit_cat_ok(int cin, int r);
 int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, const float* coef,
-                      const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, void* stream);
+                      const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, int mode, void* stream);   /* mode 1 / 2 / 3 as frost_pw_conv_fwd's emit modes */
 
 /* ---- whole-bottleneck fused bf16 inference (csrc/frost_iblock.hip) -----------------------------------------------------------
  * replaces (eval mode, BatchNorm folded): CascadePreExBottleneck.forward, frostnet.py:124-145 -- [squeeze_conv -> cat] -> conv1 -> conv2 (depthwise) ->
