@@ -4,8 +4,8 @@
 // Inference has no batch-statistics barrier between the layers, so the EXPANDED tensors (conv1 / conv2 outputs, 3-6 x the block input) never leave the chip:
 // only the block input and the block output touch HBM (2.28 M instead of 13.07 M elements per image over the network).
 //
-// Work decomposition.  A workgroup (4 waves) owns one spatial OUTPUT tile th x tw of one image.  The input region the tile's depthwise windows cover
-// ((th-1)*s + k) x ((tw-1)*s + k) pixels, out-of-image pixels = 0) is staged in LDS once as rows [pixel][r + cin] bf16 -- the squeeze conv writes its r
+// Work decomposition.  A workgroup (4 or 8 waves) owns one spatial OUTPUT tile th x tw of one image.  The in-image part of the input region the tile's depthwise
+// windows cover ((th-1)*s + k) x ((tw-1)*s + k) pixels) is staged in LDS once as rows [pixel][r + cin] bf16 -- the squeeze conv writes its r
 // channels in front of the copied input, which IS the cat.  Then, per 64-channel chunk of the expanded width:
 //   conv1   bf16 MFMA 16x16x32, D[channel][pixel]; wave = one 16-channel tile, all region pixels; + bias, ReLU, bf16 -> plane [pixel][64] (zero outside the image:
 //           the depthwise conv zero-pads conv1's OUTPUT)
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
   for (int t = 0; t < MAXT; ++t) acc3[t] = (v4f){0.f, 0.f, 0.f, 0.f};
   const int ntile3 = p.ct3 * p.tpt;
   const int cp = tid & 31, pg = tid >> 5;                                    // depthwise: channel pair, pixel group
-  const int kcat = p.r + p.cin;
 
   uint4 af[KB1M];
   const int wq = wv & 3, wph = wv >> 2;                                       // conv1: channel tile of the chunk, pixel-tile phase (NW / 4 waves share a channel tile)
@@ -257,7 +256,6 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
       }
     }
   }
-  (void)kcat;
 }
 
 static size_t iblock_lds(int rpt, int tpt, int xs, int k) {

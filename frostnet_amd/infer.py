@@ -39,8 +39,9 @@ def candidate_tiles(lib, h, w, cin, r, cexp, cout, k, stride):
 
 
 def pick_tile(lib, h, w, cin, r, cexp, cout, k, stride):
-    """Spatial output tile (th, tw) of one workgroup of frost_infer_block for a bottleneck geometry: the largest candidate whose staging fits (fewer halo
-    pixels recomputed by conv1), preferring tiles that divide the output map.  None: the fused kernel does not take this geometry."""
+    """Spatial output tile (th, tw) of one workgroup of frost_infer_block by a cost model (FROST_INFER_FUSED=1; the default mode "auto" measures the candidates
+    instead, Bf16Inference._block): region pixels conv1 computes per output pixel plus a fixed per-tile cost, mildly weighted by the residency the tile's LDS
+    footprint allows.  None: the fused kernel does not take this geometry."""
     pad = (k - 1) // 2
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     cands = [(ho, wo), ((ho + 1) // 2, wo), (7, 14), (8, 16), (7, 7), (8, 8), (4, 8), (4, 4)]
