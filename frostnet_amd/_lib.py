@@ -136,6 +136,8 @@ _PROTOS = {
     "frost_weight_grad_finalize_table": [P, I, P],
     "frost_infer_weight_prep": [P, I, P],
     "frost_infer_stem_im2col": [P, I, I, I, L, L, L, L, P, P],
+    "frost_infer_stem_ok": [I],
+    "frost_infer_stem": [P, I, I, I, L, L, L, L, P, P, I, I, P, P],
     "frost_infer_pw": [P, P, P, L, I, I, I, P, P],
     "frost_infer_dw": [P, P, P, I, I, I, I, I, I, I, P, P],
     "frost_infer_cat": [P, I, P, I, L, P, P],

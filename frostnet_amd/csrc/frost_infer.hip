@@ -70,6 +70,102 @@ extern "C" int frost_infer_stem_im2col(const float* x, int n, int h, int w, int6
   return frost_check_launch("infer_stem_im2col");
 }
 
+// ------------------------------------------------------------------------------------------------ stem without the im2col round trip
+// conv1 of the network (frostnet.py:250: ConvBNReLU(3, 32, 3, 2)) straight from the fp32 image: the im2col path above writes and re-reads 128 bytes per output
+// pixel (411 MB at B = 256) around a GEMM whose real input is 12 bytes per INPUT pixel.  Here a workgroup stages the input rows of a 4-row x 128-column output
+// tile in LDS as bf16 [row][column][c0 c1 c2 0] (8 bytes per input pixel: one tap of the im2col row), a lane builds its MFMA B operand with two 8-byte LDS
+// reads per K block, and the same two bf16 MFMAs per 16 x 16 tile as the GEMM path run on it (K index = tap * 4 + c, K blocks 0 and 1 in that order, then
+// + bias, ReLU, one bf16 rounding) -- bit-identical to im2col + frost_infer_pw.  HBM traffic: the image once (+ 1/8 halo rows) and the output once.
+#define IS_TH 4
+#define IS_XT 8                                   // 16-pixel MFMA tiles along x per workgroup
+#define IS_LW (IS_XT * 32 + 2)                    // staged columns: 2 * 128 + 1, rounded up to even
+template <int CT>
+__global__ __launch_bounds__(256) void k_inf_stem(const float* __restrict__ x, int h, int w, int ho, int wo, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                                  const uint16_t* __restrict__ pack, const float* __restrict__ biasf, int cout, int relu, int tiles_x,
+                                                  int tiles_y, uint16_t* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) uint2 img[(2 * IS_TH + 1) * IS_LW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x; const int ty = b % tiles_y; const int in = b / tiles_y;
+  const int oy0 = ty * IS_TH, ox0 = tx * IS_XT * 16;
+  const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;                       // image coordinates of staged (row 0, column 0)
+  const int ncol = min(IS_LW, (wo - ox0) * 2 + 1);                      // staged columns that a valid output pixel can touch
+  const float* src = x + (int64_t)in * sn;
+  // staging: a thread converts 2 adjacent columns x 3 channels per step (consecutive threads walk a row: coalesced for unit sw)
+  const int cpairs = (ncol + 1) >> 1;
+  for (int u = tid; u < (2 * IS_TH + 1) * cpairs; u += 256) {
+    const int r = u / cpairs, cp = u - r * cpairs;
+    const int iy = iy0 + r;
+    float v[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (iy >= 0 && iy < h) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ix = ix0 + 2 * cp + q;
+        if (ix >= 0 && ix < w) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[q][c] = src[c * sc + iy * sh + ix * sw];
+        }
+      }
+    }
+    uint4 o; o.x = cvt_pk_bf16(v[0][0], v[0][1]); o.y = cvt_pk_bf16(v[0][2], 0.0f); o.z = cvt_pk_bf16(v[1][0], v[1][1]); o.w = cvt_pk_bf16(v[1][2], 0.0f);
+    *(uint4*)(img + r * IS_LW + 2 * cp) = o;
+  }
+  // A fragments (K blocks 0 and 1 of every channel tile) and this lane's biases
+  uint4 af[CT][2]; float4 bb[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) af[ct][kb] = *(const uint4*)(pack + (((size_t)ct * 2 + kb) * 64 + lane) * 8);
+    bb[ct] = *(const float4*)(biasf + ct * 16 + 4 * g);
+  }
+  // K block 0: k = 8 g .. 8 g + 7 = taps 2 g and 2 g + 1; K block 1: tap 8 in group 0, zero elsewhere
+  const int t0 = 2 * g, t1 = 2 * g + 1;
+  const int off0 = (t0 / 3) * IS_LW + t0 % 3, off1 = (t1 / 3) * IS_LW + t1 % 3, off8 = 2 * IS_LW + 2;
+  const float flo = relu ? 0.0f : -INFINITY;
+  __syncthreads();
+  const int nxt = min(IS_XT, (wo - ox0 + 15) >> 4);
+  uint16_t* dst = y + (int64_t)in * ho * wo * cout;
+  for (int t = wv; t < IS_TH * nxt; t += 4) {
+    const int r = t / nxt, xt = t - r * nxt;
+    const int oy = oy0 + r, ox = ox0 + xt * 16 + j;
+    const uint2* bp = img + (2 * r) * IS_LW + (xt * 16 + j) * 2;
+    const uint2 a0 = bp[off0], a1 = bp[off1];
+    uint2 a8 = make_uint2(0, 0);
+    if (g == 0) a8 = bp[off8];
+    const uint4 b0 = make_uint4(a0.x, a0.y, a1.x, a1.y), b1 = make_uint4(a8.x, a8.y, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, af[ct][0]), __builtin_bit_cast(v8bf16, b0), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf16, af[ct][1]), __builtin_bit_cast(v8bf16, b1), acc, 0, 0, 0);
+      const int ch = ct * 16 + 4 * g;
+      if (oy < ho && ox < wo && ch < cout) {
+        uint2 o;
+        o.x = cvt_pk_bf16(fmaxf(acc[0] + bb[ct].x, flo), fmaxf(acc[1] + bb[ct].y, flo));
+        o.y = cvt_pk_bf16(fmaxf(acc[2] + bb[ct].z, flo), fmaxf(acc[3] + bb[ct].w, flo));
+        *(uint2*)(dst + ((int64_t)oy * wo + ox) * cout + ch) = o;
+      }
+    }
+  }
+}
+extern "C" int frost_infer_stem_ok(int cout) { return (cout % 8 == 0 && cout >= 8 && cout <= 64) ? 1 : 0; }
+/* The stem conv (3 x 3, stride 2, pad 1, 3 input channels) of the bf16 inference graph in one launch.  x: logical (N,3,H,W) fp32 with element strides
+ * (sn, sc, sh, sw); pack / biasf: the stem's FrostIDesc.pack (kind 2: K index = tap * 4 + c, kpad = 64) and folded bias; y: [N][ho][wo][cout] bf16. */
+extern "C" int frost_infer_stem(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const uint16_t* pack,
+                                const float* biasf, int cout, int relu, uint16_t* y, void* stream) {
+  FROST_REQUIRE(frost_infer_stem_ok(cout), "infer_stem: cout must be a multiple of 8 in 8..64");
+  FROST_REQUIRE(x && pack && biasf && y && n > 0 && h > 0 && w > 0, "infer_stem: incomplete arguments");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int tiles_x = (wo + IS_XT * 16 - 1) / (IS_XT * 16), tiles_y = (ho + IS_TH - 1) / IS_TH;
+  const dim3 grid((unsigned)((int64_t)n * tiles_x * tiles_y));
+  hipStream_t s = as_stream(stream);
+  const int ct = (cout + 15) / 16;
+#define IS_GO(C) hipLaunchKernelGGL((k_inf_stem<C>), grid, dim3(256), 0, s, x, h, w, ho, wo, sn, sc, sh, sw, pack, biasf, cout, relu, tiles_x, tiles_y, y)
+  if (ct == 1) IS_GO(1); else if (ct == 2) IS_GO(2); else if (ct == 3) IS_GO(3); else IS_GO(4);
+#undef IS_GO
+  return frost_check_launch("infer_stem");
+}
+
 // the 1x1 layers (and the im2col'd stem) run on the pointwise skeleton of frost_pw.hip (frost_infer_pw is defined there)
 
 // ------------------------------------------------------------------------------------------------ depthwise (fp32 FMA)

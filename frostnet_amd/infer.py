@@ -24,6 +24,8 @@ def round_up(a, b):
 # (default) = MEASURED per bottleneck: the first forward outside a hipGraph capture times the layer-by-layer launches and the fused launch with each candidate
 # tile (3 runs each) and keeps the fastest for that (map size, batch) -- results are bit-identical whichever is chosen (tests/test_gpu_infer.py).
 _FUSED = {"0": False, "1": True}.get(os.environ.get("FROST_INFER_FUSED", "auto"), "auto")
+# the stem straight from the fp32 image (frost_infer_stem) instead of im2col + GEMM: bit-identical, no 128-byte-per-pixel patch buffer
+_STEM_DIRECT = os.environ.get("FROST_INFER_STEM", "direct") != "im2col"
 TILE_CANDIDATES = ((0, 0), (-1, 0), (7, 14), (8, 16), (7, 7), (8, 8), (4, 8))          # (0, 0) = the whole map, (-1, 0) = half of it
 
 
@@ -212,10 +214,16 @@ class Bf16Inference:
         n, _, h, w = x.shape
         call("frost_infer_weight_prep", ptr(self._table), len(self.layers), stream())
         ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-        col = torch.empty(n * ho * wo * 64 + 64, dtype=torch.int16, device=self.device)
-        call("frost_infer_stem_im2col", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col), stream())
         npix = n * ho * wo
-        a, c, h, w = self._pw(self.stem, col, npix, 64), self.stem.cout, ho, wo
+        if _STEM_DIRECT and L.load_library().frost_infer_stem_ok(self.stem.cout):
+            a = torch.empty(npix * self.stem.cout, dtype=torch.int16, device=self.device)
+            call("frost_infer_stem", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(self.stem.pack), ptr(self.stem.biasf),
+                 self.stem.cout, 1, ptr(a), stream())
+        else:
+            col = torch.empty(npix * 64 + 64, dtype=torch.int16, device=self.device)
+            call("frost_infer_stem_im2col", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col), stream())
+            a = self._pw(self.stem, col, npix, 64)
+        c, h, w = self.stem.cout, ho, wo
         for ent in self.blocks:
             a, c, h, w = self._block(ent, a, c, n, h, w)
         npix = n * h * w

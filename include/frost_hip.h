@@ -250,6 +250,10 @@ typedef struct FrostIDesc {
 int frost_infer_weight_prep(const FrostIDesc* descs, int nlayers, void* stream);
 int frost_infer_stem_im2col(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, uint16_t* out,
                             void* stream);
+/* the stem in ONE launch, no im2col buffer (bit-identical to frost_infer_stem_im2col + frost_infer_pw): pack / biasf = the stem's FrostIDesc.pack / .biasf */
+int frost_infer_stem_ok(int cout);
+int frost_infer_stem(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const uint16_t* pack,
+                     const float* biasf, int cout, int relu, uint16_t* y, void* stream);
 int frost_infer_pw(const uint16_t* x, const uint16_t* pack, const float* biasf, int64_t npix, int cin, int cout, int relu,
                    uint16_t* y, void* stream);
 int frost_infer_dw(const uint16_t* x, const float* wf, const float* biasf, int n, int h, int w, int c, int k, int stride, int relu,

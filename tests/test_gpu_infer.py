@@ -85,3 +85,33 @@ def test_fused_block_inference_equals_layer_by_layer(name, res, batch):
     assert r_fp <= 1e-2 and r_ref <= 3e-2, (r_fp, r_ref, r_pl)
     assert torch.equal(auto, plain) and torch.equal(auto2, plain) and len(picks) == nblocks, picks       # whatever was picked, the result is the same
     print(f"    measured choices: {picks}")
+
+
+@pytest.mark.parametrize("name,n,h,w", [("frostnet_large_1_0", 3, 224, 224), ("frostnet_small_1_0", 2, 97, 131), ("frostnet_base_0_75", 1, 600, 520), ("frostnet_large_1_0", 2, 31, 17)])
+def test_direct_stem_is_bit_identical_to_im2col_gemm(name, n, h, w):
+    """frost_infer_stem (conv1 straight from the fp32 image, tile staged in LDS) against frost_infer_stem_im2col + frost_infer_pw on the same packs: the same
+    bf16 operands enter the same two MFMAs per tile in the same order, so every output element must match bit for bit -- NCHW and channels_last inputs, odd sizes,
+    maps wider than one 128-column tile, maps smaller than one tile."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, infer as I, _lib as L
+    from frostnet_amd._lib import call, ptr, stream
+    torch.manual_seed(3)
+    model = F.MODEL_REGISTRY[name]()
+    _randomize_bn(model, 5)
+    model.eval().cuda()
+    inf = I.Bf16Inference(model)
+    st = inf.stem
+    assert L.load_library().frost_infer_stem_ok(st.cout)
+    call("frost_infer_weight_prep", ptr(inf._table), len(inf.layers), stream())
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    npix = n * ho * wo
+    for x in (torch.randn(n, 3, h, w, device="cuda"), torch.randn(n, 3, h, w, device="cuda").contiguous(memory_format=torch.channels_last) * 3.0):
+        col = torch.empty(npix * 64 + 64, dtype=torch.int16, device="cuda")
+        call("frost_infer_stem_im2col", ptr(x), n, h, w, *x.stride(), ptr(col), stream())
+        want = inf._pw(st, col, npix, 64)[: npix * st.cout]
+        got = torch.full((npix * st.cout,), 0x7fc0, dtype=torch.int16, device="cuda")
+        call("frost_infer_stem", ptr(x), n, h, w, *x.stride(), ptr(st.pack), ptr(st.biasf), st.cout, 1, ptr(got), stream())
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), int((got != want).sum())
+        assert float(got.view(torch.bfloat16).float().abs().max()) > 0
