@@ -199,6 +199,8 @@ _PROTOS = {
     "frost_conv_finalize_converted_fb": [P, P, P, P, P, P, I, P, P, P],
     "frost_add_qnnpack": [P, P, P, P, L, P, P, P],
     "frost_avgpool_q": [P, I, I, I, P, P],
+    "frost_stem_converted_ok": [I],
+    "frost_stem_converted": [P, I, I, I, L, L, L, L, P, P, P, P, P, I, I, P, P],
     "frost_hswish_fwd": [P, P, L, P, P, P, P, I, P, P, P],
     "frost_hswish_bwd": [P, P, L, P, P, I, P],
     "frost_classifier_q": [P, P, P, P, I, I, I, P, P, P, P],

@@ -7,6 +7,7 @@
 //   * the quantised adaptive average pool (mean index rounded half-to-even, input qparams kept),
 //   * the classifier as an exact int32 GEMV with requantisation.
 #include "frost_common.h"
+typedef int v4i_c __attribute__((ext_vector_type(4)));
 
 // replaces: nniqat.ConvBn(ReLU)2d.to_float -> fuse_conv_bn_weights (bias) + nnq.Conv2d.from_float + aten qconv.cpp (QNNPACK path):
 //   bias_q = nearbyint(b_fold / (s_x*s_w)),  requant scale = s_w*s_x/s_y  (all fp32, this op order).
@@ -141,8 +142,60 @@ __global__ __launch_bounds__(256) void k_classifier_q(const int32_t* __restrict_
     if (idx) idx[(int64_t)img * cout + co] = (uint8_t)q;
   }
 }
+// The same integer GEMM on the int8 MFMA: a wave owns 16 output channels x 16 images and walks K in steps of 64 (one v_mfma_i32_16x16x64_i8 each); both
+// operands come straight from global memory in fragment layout (A = 16 bytes of a weight row, B = 16 pooled indices re-packed as offset-binary bytes), the
+// zero-point term -(zp_x - 128) * sum_k w[co][k] from dot4 sums of the A bytes the wave loads anyway.  Integer accumulation is exact in any order, the
+// epilogue is the one above: bit-identical logits.  (One wave per OUTPUT, as above, is 256 000 waves of 20 dependent byte loads: 134 us at B = 256.)
+__global__ __launch_bounds__(256) void k_classifier_q_mfma(const int32_t* __restrict__ pooled, const float* qx, const int8_t* __restrict__ wq, const float* coef,
+                                                           int cpad, int n, int c, int cout, const float* qy, float* __restrict__ logits, uint8_t* __restrict__ idx,
+                                                           int fb, int tiles_co) {
+  const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tco = wave % tiles_co, timg = wave / tiles_co;
+  if (timg * 16 >= n) return;
+  const int i = lane & 15, g = lane >> 4;
+  const int8_t* wrow = wq + (int64_t)min(tco * 16 + i, cout - 1) * c + g * 16;
+  const int32_t* prow = pooled + (int64_t)min(timg * 16 + i, n - 1) * c + g * 16;
+  v4i_c acc = {0, 0, 0, 0};
+  int ws = 0;
+  for (int k0 = 0; k0 < c; k0 += 64) {
+    const v4i_c a = *(const v4i_c*)(wrow + k0);
+    v4i_c b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 v = *(const int4*)(prow + k0 + 4 * q);
+      b[q] = (int)((uint32_t)((v.x - 128) & 255) | ((uint32_t)((v.y - 128) & 255) << 8) | ((uint32_t)((v.z - 128) & 255) << 16) | ((uint32_t)((v.w - 128) & 255) << 24));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ws = __builtin_amdgcn_sdot4(a[q], 0x01010101, ws, false);
+    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+  }
+  ws += __shfl_xor(ws, 16); ws += __shfl_xor(ws, 32);                        // every lane: sum_k w of channel tco * 16 + (lane & 15)
+  const int zpx = __float_as_int(qx[FROST_Q_ZP]), zpy = __float_as_int(qy[FROST_Q_ZP]);
+  const float sy = qy[FROST_Q_SCALE];
+  const int img = timg * 16 + i;                                             // D: lane (j = image, g) holds channels 4 g + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = tco * 16 + 4 * g + r;
+    const int wsr = __shfl(ws, 4 * g + r);
+    if (co < cout && img < n) {
+      const int a = acc[r] + (128 - zpx) * wsr;
+      const float rs = coef[FROST_COEF_A * cpad + co];
+      int q = fb ? (int)rintf(((float)a + coef[FROST_COEF_B * cpad + co]) * rs) + zpy : (int)rintf((float)(a + __float_as_int(coef[FROST_COEF_B * cpad + co])) * rs) + zpy;
+      q = min(max(q, 0), 255);
+      logits[(int64_t)img * cout + co] = (float)(q - zpy) * sy;
+      if (idx) idx[(int64_t)img * cout + co] = (uint8_t)q;
+    }
+  }
+}
 static int classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
                         const float* qrec_y, float* logits, uint8_t* idx, int fb, void* stream) {
+  static const int mfma_on = getenv("FROST_CLS_MFMA") ? atoi(getenv("FROST_CLS_MFMA")) : 1;
+  if (mfma_on && (c & 63) == 0 && ((((uintptr_t)pooled) | ((uintptr_t)wq)) & 15) == 0) {
+    const int tiles_co = (cout + 15) / 16, tiles_img = (n + 15) / 16;
+    hipLaunchKernelGGL(k_classifier_q_mfma, dim3((unsigned)((tiles_co * tiles_img + 3) / 4)), dim3(256), 0, as_stream(stream), pooled, qrec_x, wq, coef,
+                       round_up(cout, 16), n, c, cout, qrec_y, logits, idx, fb, tiles_co);
+    return frost_check_launch("classifier_q");
+  }
   const int64_t waves = (int64_t)n * cout;
   hipLaunchKernelGGL(k_classifier_q, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, as_stream(stream), pooled, qrec_x, wq, coef, round_up(cout, 16),
                      n, c, cout, qrec_y, logits, idx, fb);
@@ -155,6 +208,120 @@ extern "C" int frost_classifier_q(const int32_t* pooled, const float* qrec_x, co
 extern "C" int frost_classifier_q_fb(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,
                                      const float* qrec_y, float* logits, uint8_t* idx, void* stream) {
   return classifier_q(pooled, qrec_x, wq, coef, n, c, cout, qrec_y, logits, idx, 1, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ converted stem in one launch
+// QuantStub + quantized::conv2d_relu of conv1 (frostnet.py:250, 319-320 after convert) straight from the fp32 image: today three launches (frost_quantize_input
+// -> 4 bytes per input pixel, frost_stem_im2col -> 40 bytes per OUTPUT pixel, the int8 GEMM on those rows: 173 us at B = 256).  Here a workgroup quantises the
+// input rows of a 4-row x 128-column output tile into LDS ([row][column] dwords c0 c1 c2 zp, offset-binary, padding = the zero point), a lane builds the
+// K = 64 MFMA operand (k = tap * 4 + c, the pack's order) from four of those dwords, and the emit epilogue is k_pw's converted one.  The integer accumulators are
+// exact and the epilogue expressions identical, so the output indices are those of the three-launch path bit for bit.
+#define CS_TH 4
+#define CS_XT 8
+#define CS_LW (CS_XT * 32 + 2)
+template <int CT>
+__global__ __launch_bounds__(256) void k_stem_converted(const float* __restrict__ x, int h, int w, int ho, int wo, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                                        const float* qx, const int8_t* __restrict__ wpack, const int32_t* __restrict__ wsum,
+                                                        const float* __restrict__ coef, int cpad, const float* qy, int cout, int cvt, int tiles_x, int tiles_y,
+                                                        int8_t* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) uint32_t img[(2 * CS_TH + 1) * CS_LW];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x; const int ty = b % tiles_y; const int in = b / tiles_y;
+  const int oy0 = ty * CS_TH, ox0 = tx * CS_XT * 16;
+  const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;
+  const int ncol = min(CS_LW, (wo - ox0) * 2 + 1);
+  const QP X = load_qp(qx);
+  const uint32_t zb = (uint32_t)((X.zp - 128) & 255), zfill = zb * 0x01010101u;
+  const float* src = x + (int64_t)in * sn;
+  const int cpairs = (ncol + 1) >> 1;
+  for (int u = tid; u < (2 * CS_TH + 1) * cpairs; u += 256) {
+    const int r = u / cpairs, cp = u - r * cpairs;
+    const int iy = iy0 + r;
+    uint32_t o[2] = {zfill, zfill};
+    if (iy >= 0 && iy < h) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ix = ix0 + 2 * cp + q;
+        if (ix >= 0 && ix < w) {
+          uint32_t packed = zb << 24;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) packed |= ((uint32_t)((fq_index(src[c * sc + iy * sh + ix * sw], X.inv, X.zp, 0, X.hi) - 128) & 255)) << (8 * c);
+          o[q] = packed;
+        }
+      }
+    }
+    *(uint2*)(img + r * CS_LW + 2 * cp) = make_uint2(o[0], o[1]);
+  }
+  // A fragments, weight sums, requantisation rows of this lane's 4 channels per channel tile
+  v4i_c af[CT]; int4 ws[CT]; float A[CT][4], B[CT][4];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    af[ct] = *(const v4i_c*)(wpack + (((int64_t)ct * 64 + lane) << 4));
+    const int ch = ct * 16 + 4 * g;
+    ws[ct] = *(const int4*)(wsum + ch);
+    const float4 a4 = *(const float4*)(coef + FROST_COEF_A * cpad + ch), b4 = *(const float4*)(coef + FROST_COEF_B * cpad + ch);
+    A[ct][0] = a4.x; A[ct][1] = a4.y; A[ct][2] = a4.z; A[ct][3] = a4.w; B[ct][0] = b4.x; B[ct][1] = b4.y; B[ct][2] = b4.z; B[ct][3] = b4.w;
+  }
+  // k = 16 g .. 16 g + 15 = taps 4 g .. 4 g + 3; taps past the ninth carry zero weights
+  int off[4]; bool tv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int t = 4 * g + q; tv[q] = t < 9; off[q] = tv[q] ? (t / 3) * CS_LW + t % 3 : 0; }
+  const int zpx = X.zp - 128;
+  const float y_zpf = (float)__float_as_int(qy[FROST_Q_ZP]);
+  const float y_inv = 1.0f / qy[FROST_Q_SCALE];
+  const float qcap = (float)q_hi(qy); const bool lowq = qcap < 255.0f;
+  __syncthreads();
+  const int nxt = min(CS_XT, (wo - ox0 + 15) >> 4);
+  int8_t* dst = y + (int64_t)in * ho * wo * cout;
+  for (int t = wv; t < CS_TH * nxt; t += 4) {
+    const int r = t / nxt, xt = t - r * nxt;
+    const int oy = oy0 + r, ox = ox0 + xt * 16 + j;
+    const uint32_t* bp = img + (2 * r) * CS_LW + (xt * 16 + j) * 2;
+    v4i_c bf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bf[q] = tv[q] ? (int)bp[off[q]] : 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      v4i_c acc = {-zpx * ws[ct].x, -zpx * ws[ct].y, -zpx * ws[ct].z, -zpx * ws[ct].w};
+      acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[ct], bf, acc, 0, 0, 0);
+      uint32_t packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float qv;
+        if (cvt == 2) qv = rintf(((float)acc[e] + B[ct][e]) * A[ct][e]) + y_zpf;
+        else {
+          const float yv = (cvt == 1) ? fmaf(A[ct][e], (float)(acc[e] + __float_as_int(B[ct][e])), 0.0f) : fmaf(A[ct][e], (float)acc[e], B[ct][e]);
+          qv = rintf(yv * (cvt == 1 ? 1.0f : y_inv)) + y_zpf;
+        }
+        if (lowq) qv = fminf(qv, qcap);
+        packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, e, packed);
+      }
+      const int ch = ct * 16 + 4 * g;
+      if (oy < ho && ox < wo && ch < cout) *(uint32_t*)(dst + ((int64_t)oy * wo + ox) * cout + ch) = packed ^ 0x80808080u;
+    }
+  }
+}
+extern "C" int frost_stem_converted_ok(int cout) { return (cout % 4 == 0 && cout >= 4 && cout <= 64) ? 1 : 0; }
+/* x: logical (N,3,H,W) fp32 with element strides; qrec_x: the QuantStub's (frozen) record; wq_pack / wsum / coef: the stem layer's pack (kind 2), weight sums
+ * and coefficient rows after frost_conv_finalize_converted(_fb); mode 2 / 3 = QNNPACK / FBGEMM requantisation (as frost_pw_conv_fwd), 1 = fake-quant emit;
+ * y: [N][ho][wo][cout] offset-binary indices under qrec_y. */
+extern "C" int frost_stem_converted(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* qrec_x,
+                                    const int8_t* wq_pack, const int32_t* wsum, const float* coef, const float* qrec_y, int cout, int mode, int8_t* y,
+                                    void* stream) {
+  FROST_REQUIRE(frost_stem_converted_ok(cout), "stem_converted: cout must be a multiple of 4 in 4..64");
+  FROST_REQUIRE(mode >= 1 && mode <= 3, "stem_converted: mode 1 (fake-quant emit), 2 / 3 (converted QNNPACK / FBGEMM form)");
+  FROST_REQUIRE(x && qrec_x && wq_pack && wsum && coef && qrec_y && y && n > 0, "stem_converted: incomplete arguments");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  const int tiles_x = (wo + CS_XT * 16 - 1) / (CS_XT * 16), tiles_y = (ho + CS_TH - 1) / CS_TH;
+  const dim3 grid((unsigned)((int64_t)n * tiles_x * tiles_y));
+  hipStream_t s = as_stream(stream);
+  const int ct = (cout + 15) / 16, cpad = round_up(cout, 16);
+#define CS_GO(C) hipLaunchKernelGGL((k_stem_converted<C>), grid, dim3(256), 0, s, x, h, w, ho, wo, sn, sc, sh, sw, qrec_x, wq_pack, wsum, coef, cpad, qrec_y, cout, \
+                                    mode - 1, tiles_x, tiles_y, y)
+  if (ct == 1) CS_GO(1); else if (ct == 2) CS_GO(2); else if (ct == 3) CS_GO(3); else CS_GO(4);
+#undef CS_GO
+  return frost_check_launch("stem_converted");
 }
 
 // ------------------------------------------------------------------------------------------------ quantizable h-swish

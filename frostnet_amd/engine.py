@@ -41,6 +41,7 @@ _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # larg
 _PW_FUSE_MINMAP = int(os.environ.get("FROST_PW_FUSE_MINMAP", "400"))
 _PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "1") != "0"
+_STEM_FUSED_CVT = os.environ.get("FROST_STEM_CONVERTED", "1") != "0"   # converted inference: QuantStub + stem conv in one launch from the fp32 image (frost_stem_converted), bit-identical
 _BLOCK_SQCAT = os.environ.get("FROST_BLOCK_SQCAT", "1") != "0"      # squeeze_conv emit + cat requantisation in one launch (frost_sq_emit_cat), bit-identical to the two it replaces
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
@@ -522,6 +523,20 @@ class Engine:
         self._conv_launch(l, x, 3 if fb else 2, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
+        return y
+
+    def stem_converted(self, l, x, q_in, fb=False):
+        """QuantStub (frozen record) + the converted stem conv from the fp32 image in ONE launch; None when the fused launch does not apply (a site trace
+        wants the quantised image, the switch is off, an unusual stem width) -- the caller then runs quantize_input + conv_converted."""
+        if not _STEM_FUSED_CVT or getattr(self, "trace", None) is not None or l.kind != "stem" or x.shape[1] != 3 \
+                or not L.load_library().frost_stem_converted_ok(l.cout):
+            return None
+        n, _, h, w = x.shape
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        self._converted_coef(l, q_in, fb)
+        y = self.new_act(n, ho, wo, l.cout, l.qy)
+        call("frost_stem_converted", ptr(x), n, h, w, *x.stride(), ptr(q_in), ptr(l.wq_pack), ptr(l.wsum), ptr(l.coef), ptr(l.qy), l.cout, 3 if fb else 2,
+             ptr(y.buf), stream())
         return y
 
     def _converted_coef(self, l, qx, fb):

@@ -119,10 +119,25 @@ class Bf16Inference:
                 self.blocks.append(ent)
         self.last = self._add(model.last_layer.conv, True)
         self.fc = model.classifier[2]
-        arr = (L.FrostIDesc * len(self.layers))()
-        for i, l in enumerate(self.layers):
-            arr[i] = l.desc()
-        self._table = L.struct_to_tensor(arr, self.device)
+        self._table, self._ptrs, self._versions = None, None, None
+
+    def _prepare_weights(self):
+        """BatchNorm folding + fragment packing (frost_infer_weight_prep) once per state of the parameters, as the reference folds once before it evaluates
+        (Classification/evaluate.py:131-143): the descriptor table follows re-assigned tensors (data pointers), the packs follow in-place updates (tensor
+        version counters).  `refresh()` forces it (for writes the counters do not see, e.g. through a raw pointer)."""
+        ts = [t for l in self.layers for t in (l.conv.weight, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var)]
+        ptrs, versions = [t.data_ptr() for t in ts], [t._version for t in ts]
+        if ptrs != self._ptrs:
+            arr = (L.FrostIDesc * len(self.layers))()
+            for i, l in enumerate(self.layers):
+                arr[i] = l.desc()
+            self._table, self._ptrs, self._versions = L.struct_to_tensor(arr, self.device), ptrs, None
+        if versions != self._versions:
+            call("frost_infer_weight_prep", ptr(self._table), len(self.layers), stream())
+            self._versions = versions
+
+    def refresh(self):
+        self._versions = None
 
     def _add(self, seq, relu, stem=False):
         l = _ILayer(seq, relu, self.device, stem)
@@ -212,7 +227,7 @@ class Bf16Inference:
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32 or x.device != self.device:
             raise ValueError("expected an fp32 (N,3,H,W) tensor on the model's device")
         n, _, h, w = x.shape
-        call("frost_infer_weight_prep", ptr(self._table), len(self.layers), stream())
+        self._prepare_weights()
         ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
         npix = n * ho * wo
         if _STEM_DIRECT and L.load_library().frost_infer_stem_ok(self.stem.cout):

@@ -434,8 +434,10 @@ class FrostRunner:
         E, fb = self.E, getattr(self, "converted_fb", False)
         if x.dtype != torch.float32:
             x = x.float()
-        a = E.quantize_input(x, self.q_in, observe=False)
-        a = E.conv_converted(self.stem, a, fb)
+        a = E.stem_converted(self.stem, x, self.q_in, fb)
+        if a is None:
+            a = E.quantize_input(x, self.q_in, observe=False)
+            a = E.conv_converted(self.stem, a, fb)
         for d in self.blocks:
             inp, out = a, a
             if d["conv1"] is not None:

@@ -541,6 +541,12 @@ int frost_classifier_q_fb(const int32_t* pooled, const float* qrec_x, const int8
 int frost_add_qnnpack(const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y,
                       int8_t* y, void* stream);
 /* replaces: adaptive_avg_pool2d(1) on a quantised tensor: int32 index rint_half_even(mean), input qparams kept (frostnet.py:296) */
+/* QuantStub + the converted stem conv in ONE launch from the fp32 image (replaces frost_quantize_input + frost_stem_im2col + frost_pw_conv_fwd mode 2 / 3,
+ * bit-identical indices): frostnet.py:250, 319-320 after torch.quantization.convert */
+int frost_stem_converted_ok(int cout);
+int frost_stem_converted(const float* x, int n, int h, int w, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* qrec_x,
+                         const int8_t* wq_pack, const int32_t* wsum, const float* coef, const float* qrec_y, int cout, int mode, int8_t* y,
+                         void* stream);
 int frost_avgpool_q(const int8_t* x, int n, int hw, int c, int32_t* pooled, void* stream);
 /* replaces: quantized::conv2d of the classifier (frostnet.py:298) + DeQuantStub: exact int32 GEMV, coefficient rows as above */
 int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t* wq, const float* coef, int n, int c, int cout,

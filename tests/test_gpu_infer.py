@@ -103,7 +103,7 @@ def test_direct_stem_is_bit_identical_to_im2col_gemm(name, n, h, w):
     inf = I.Bf16Inference(model)
     st = inf.stem
     assert L.load_library().frost_infer_stem_ok(st.cout)
-    call("frost_infer_weight_prep", ptr(inf._table), len(inf.layers), stream())
+    inf._prepare_weights()
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     npix = n * ho * wo
     for x in (torch.randn(n, 3, h, w, device="cuda"), torch.randn(n, 3, h, w, device="cuda").contiguous(memory_format=torch.channels_last) * 3.0):
@@ -115,3 +115,41 @@ def test_direct_stem_is_bit_identical_to_im2col_gemm(name, n, h, w):
         torch.cuda.synchronize()
         assert torch.equal(got, want), int((got != want).sum())
         assert float(got.view(torch.bfloat16).float().abs().max()) > 0
+
+
+def test_weight_prep_is_cached_and_follows_updates():
+    """The folded packs are rebuilt when a parameter changes in place (version counter), when a tensor is re-assigned (data pointer), on refresh() -- and not otherwise."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, _lib as L
+    torch.manual_seed(5)
+    model = F.MODEL_REGISTRY["frostnet_small_1_0"]()
+    _randomize_bn(model, 9)
+    model.eval().cuda()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    y0 = model.hip_infer_bf16(x).clone()
+    L.CALL_LOG = []
+    try:
+        y1 = model.hip_infer_bf16(x)
+        assert "frost_infer_weight_prep" not in L.CALL_LOG and torch.equal(y0, y1)
+        with torch.no_grad():
+            model.classifier[2].bias.add_(1.0)                         # not a folded tensor: no re-prep, but the head reads it live
+            model.conv1.conv[1].weight.mul_(1.5)                            # in place
+        del L.CALL_LOG[:]
+        y2 = model.hip_infer_bf16(x)
+        assert "frost_infer_weight_prep" in L.CALL_LOG and not torch.equal(y2, y1 + 1.0)
+        model.last_layer.conv[0].weight.data = model.last_layer.conv[0].weight.data * 0.5      # re-assigned
+        del L.CALL_LOG[:]
+        y3 = model.hip_infer_bf16(x)
+        assert "frost_infer_weight_prep" in L.CALL_LOG and not torch.equal(y3, y2)
+        ref = F.MODEL_REGISTRY["frostnet_small_1_0"]()
+        ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        ref.eval()
+        with torch.no_grad():
+            want = ref(x.cpu())
+        assert float((y3.cpu() - want).norm() / want.norm()) <= 3e-2
+        del L.CALL_LOG[:]
+        model.__dict__["_bf16_infer"].refresh()
+        assert torch.equal(model.hip_infer_bf16(x), y3) and "frost_infer_weight_prep" in L.CALL_LOG
+    finally:
+        L.CALL_LOG = None

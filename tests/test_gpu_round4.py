@@ -352,3 +352,41 @@ def test_squeeze_emit_cat_fused_is_bit_identical(F, cin, r, H, n):
     for sa, sb in zip(a, b):
         for ta, tb in zip(sa, sb):
             assert torch.equal(ta, tb)
+
+
+@pytest.mark.parametrize("shape,cl", [((5, 3, 97, 131), False), ((3, 3, 64, 64), True), ((2, 3, 300, 520), True), ((1, 3, 31, 17), False)])
+def test_converted_stem_in_one_launch_is_bit_identical(shape, cl):
+    """frost_stem_converted (QuantStub + quantized conv1 from the fp32 image) against frost_quantize_input + frost_stem_im2col + the int8 GEMM emit: every block
+    output and the logits of the converted model must be identical -- odd sizes, NCHW and channels_last, a map wider than one 128-column tile, a map smaller
+    than one tile, a batch that is not a multiple of the classifier's 16-image MFMA tile.  (The reference fixtures pin both to torch: tests/test_gpu_convert.py.)"""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, engine as E, _lib as L
+    torch.manual_seed(11)
+    model = F.MODEL_REGISTRY["frostnet_quant_small_1_0"](drop_rate=0.0)
+    F.qat_prepare(model, version=0)
+    model.cuda().train()
+    for _ in range(2):                                     # observers and running statistics see data before convert()
+        model(torch.randn(4, 3, 64, 64, device="cuda") * 1.5)
+    model.hip_convert()
+    r = model.hip_runner()
+    x = torch.randn(*shape, device="cuda") * 1.5
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for fused in (True, False):
+        E._STEM_FUSED_CVT = fused
+        L.CALL_LOG = []
+        try:
+            taps = []
+            with torch.no_grad():
+                y = r._forward_converted(x, taps)
+            torch.cuda.synchronize()
+            assert ("frost_stem_converted" in L.CALL_LOG) == fused and ("frost_stem_im2col" in L.CALL_LOG) == (not fused)
+            outs[fused] = (y.clone(), [t.indices().clone() for t in taps], r.E.last_logit_idx.clone())
+        finally:
+            L.CALL_LOG = None
+            E._STEM_FUSED_CVT = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][2], outs[False][2])
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(a, b)
