@@ -26,7 +26,7 @@ struct IBlkP {
   const uint16_t* w3; const float* b3;          // reduce_conv
   int n, h, w, ho, wo, cin, r, cexp, cout;
   int kb_sq, ct_sq, kb1, ct1, kb3, ct3, cpad_dw, nchunk;
-  int th, tw, tiles_x, tiles_y, rh, rw, rp, rpt, tp, tpt, xs, residual, tw4;
+  int th, tw, tiles_x, tiles_y, rh, rw, rp, rpt, tp, tpt, xs, residual, tw4, waves;
 };
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would put the L2 round trip of every weight / tap
@@ -265,6 +265,7 @@ static size_t iblock_lds(int rpt, int tpt, int xs, int k) {
 static int iblock_waves(const IBlkP& p) {
   static const int forced = getenv("FROST_IB_NW") ? atoi(getenv("FROST_IB_NW")) : 0;
   if (forced == 4 || forced == 8) return forced;
+  if (p.waves == 4 || p.waves == 8) return p.waves;                    // the caller measured (frostnet_amd/infer.py "auto")
   // 8 waves where a workgroup carries a whole (small) map and a wide expansion: its three phases per 64-channel chunk are serial, more waves shorten each
   return (p.tp >= 49 && p.cexp >= 256) ? 8 : 4;
 }
@@ -308,10 +309,11 @@ extern "C" int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int 
 
 /* One Frost bottleneck, bf16 inference, as ONE launch.  x: [n][h][w][cin] bf16 NHWC; y: [n][ho][wo][cout].  Packs / folded biases are those of
  * frost_infer_weight_prep (FrostIDesc.pack / .biasf): wsq / w1 / w3 = bf16 A-fragment packs with kpad = round_up(K, 32) (NULL = layer absent), wdw = fp32 taps
- * [k*k][round_up(cexp,16)].  r = squeeze width (0 without squeeze), cexp = depthwise width (= r + cin ... when conv1 is absent: = cin).  residual: + x. */
+ * [k*k][round_up(cexp,16)].  r = squeeze width (0 without squeeze), cexp = depthwise width (= r + cin ... when conv1 is absent: = cin).  residual: + x.
+ * waves: 4 or 8 waves per workgroup, 0 = the kernel's own rule (8 for a whole small map with a wide expansion). */
 extern "C" int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const float* bsq, const uint16_t* w1, const float* b1, const float* wdw,
                                  const float* bdw, const uint16_t* w3, const float* b3, int n, int h, int w, int cin, int r, int cexp, int cout, int k,
-                                 int stride, int residual, int th, int tw, uint16_t* y, void* stream) {
+                                 int stride, int residual, int th, int tw, int waves, uint16_t* y, void* stream) {
   FROST_REQUIRE(frost_infer_block_ok(h, w, cin, r, cexp, cout, k, stride, th, tw), "infer_block: unsupported geometry / tile");
   FROST_REQUIRE(!residual || (stride == 1 && cin == cout), "infer_block: residual needs stride 1 and cin == cout");
   FROST_REQUIRE((wsq != nullptr) == (r > 0) && (w1 != nullptr || cexp == cin), "infer_block: inconsistent layer set");
@@ -327,7 +329,7 @@ extern "C" int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const f
   p.rh = (th - 1) * stride + k; p.rw = (tw - 1) * stride + k; p.rp = p.rh * p.rw; p.rpt = (p.rp + 15) / 16;
   p.tp = th * tw; p.tpt = (p.tp + 15) / 16; p.tw4 = (tw + 3) / 4;
   const int kc = (r + round_up(cin, 32) > round_up(r + cin, 32)) ? r + round_up(cin, 32) : round_up(r + cin, 32);
-  p.xs = kc + 8; p.residual = residual;
+  p.xs = kc + 8; p.residual = residual; p.waves = waves;
   const size_t lds = iblock_lds(p.rpt, p.tpt, p.xs, k);
   hipStream_t s = as_stream(stream);
   if (k == 3 && stride == 1) return launch_iblock<3, 1>(p, lds, s);

@@ -187,7 +187,7 @@ class Bf16Inference:
         call("frost_infer_block", ptr(a), ptr(sq.pack) if sq is not None else None, ptr(sq.biasf) if sq is not None else None,
              ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
              ptr(l3.pack), ptr(l3.biasf), n, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride, 0 if ent["blk"].reduction else 1, tile[0], tile[1],
-             ptr(out), stream())
+             tile[2] if len(tile) > 2 else 0, ptr(out), stream())
         return out, l3.cout, h2, w2
 
     def _block(self, ent, a, c, n, h, w):
@@ -205,9 +205,13 @@ class Bf16Inference:
                 return self._block_plain(ent, a, c, n, h, w)          # nothing can be timed inside a capture: run one eager forward first (bench.py does)
             else:
                 timed = []
-                for cand in ["plain"] + candidate_tiles(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride):
+                tiles = candidate_tiles(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride)
+                for cand in ["plain"] + [(th, tw, nw) for th, tw in tiles for nw in (4, 8)]:          # every tile with 4 and with 8 waves per workgroup
                     run = (lambda: self._block_plain(ent, a, c, n, h, w)) if cand == "plain" else (lambda t=cand: self._block_fused(ent, a, c, n, h, w, t))
-                    run()
+                    try:
+                        run()
+                    except RuntimeError:              # this wave count does not hold the tile's reduce_conv accumulators
+                        continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(3):
