@@ -26,24 +26,28 @@ struct IBlkP {
   const uint16_t* w3; const float* b3;          // reduce_conv
   int n, h, w, ho, wo, cin, r, cexp, cout;
   int kb_sq, ct_sq, kb1, ct1, kb3, ct3, cpad_dw, nchunk;
-  int th, tw, tiles_x, tiles_y, rh, rw, rp, rpt, tp, tpt, xs, residual, tw4, waves;
+  int th, tw, tiles_x, tiles_y, rh, rw, rp, rpt, tp, tpt, xs, residual, tw4, waves, chunk;
 };
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would put the L2 round trip of every weight / tap
 // prefetch behind the barrier it was issued in front of (the prefetched registers are consumed later, behind the compiler's own waits)
 __device__ __forceinline__ void ib_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#define IB_PLS 68      // plane row stride (bf16 elements): 136 B, the 16 pixel rows of an MFMA tile fall into distinct 8-byte bank slots
-#define IB_Y2S 72      // y2 row stride: 144 B
+// plane row stride (bf16 elements) CH + 4: 136 B (72 B), the 16 pixel rows of an MFMA tile fall into distinct 8-byte bank slots; y2 row stride CH + 8
+#define IB_PLS(CH) ((CH) + 4)
+#define IB_Y2S(CH) ((CH) + 8)
 
-template <int K, int S, int MAXT, int KB1M, int NW>
+// CH = channels of the expanded width per chunk: 64, or 32 for the narrow high-resolution blocks (cexp = 32 / 72 / 96 / 144: a 64-wide chunk leaves 25-50 % of the
+// depthwise lanes on padding channels there, and the smaller planes let more workgroups share a CU)
+template <int K, int S, int MAXT, int KB1M, int NW, int CH>
 __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
-  constexpr int PAD = (K - 1) / 2, SPAN = 3 * S + K, TAPW = (K * K + 1) * 64, NT = NW * 64, TPT = (TAPW + NT - 1) / NT;
+  constexpr int PAD = (K - 1) / 2, SPAN = 3 * S + K, TAPW = (K * K + 1) * CH, NT = NW * 64, TPT = (TAPW + NT - 1) / NT;
+  constexpr int PLS = IB_PLS(CH), Y2S = IB_Y2S(CH), LCH = (CH == 64) ? 6 : 5, TPC = CH / 16, KSC = CH / 32, CPN = CH / 2;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint16_t* const xc = (uint16_t*)smem;                                    // [rpt*16][xs]
-  uint16_t* const pl = xc + (size_t)p.rpt * 16 * p.xs;                     // [rpt*16][IB_PLS]
-  uint16_t* const y2 = pl + (size_t)p.rpt * 16 * IB_PLS;                   // [tpt*16][IB_Y2S]
-  float* const tapl = (float*)(y2 + (size_t)p.tpt * 16 * IB_Y2S);          // [k*k + 1][64]: the chunk's depthwise taps and (last row) folded bias
+  uint16_t* const pl = xc + (size_t)p.rpt * 16 * p.xs;                     // [rpt*16][PLS]
+  uint16_t* const y2 = pl + (size_t)p.rpt * 16 * PLS;                      // [tpt*16][Y2S]
+  float* const tapl = (float*)(y2 + (size_t)p.tpt * 16 * Y2S);             // [k*k + 1][CH]: the chunk's depthwise taps and (last row) folded bias
   uint16_t* const ptab = (uint16_t*)(tapl + TAPW);                         // [rpt*16]: staged (in-image) pixel -> plane row, 0xffff past the last one
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -60,9 +64,9 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
   {
     uint4* z = (uint4*)xc; const int nx = (spt * 16 * p.xs) >> 3;
     for (int i = tid; i < nx; i += NT) z[i] = make_uint4(0, 0, 0, 0);
-    uint4* zp_ = (uint4*)pl; const int np_ = (p.rpt * 16 * IB_PLS) >> 3;
+    uint4* zp_ = (uint4*)pl; const int np_ = (p.rpt * 16 * PLS) >> 3;
     for (int i = tid; i < np_; i += NT) zp_[i] = make_uint4(0, 0, 0, 0);
-    uint4* z2 = (uint4*)y2; const int ny = (p.tpt * 16 * IB_Y2S) >> 3;
+    uint4* z2 = (uint4*)y2; const int ny = (p.tpt * 16 * Y2S) >> 3;
     for (int i = tid; i < ny; i += NT) z2[i] = make_uint4(0, 0, 0, 0);
     for (int i = tid; i < spt * 16; i += NT) {
       const int sy = i / srw, sx = i - sy * srw;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
   auto load_taps = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < TPT; ++q) {
-      const int i = tid + q * NT; const int t = i >> 6, ch = c * 64 + (i & 63);
+      const int i = tid + q * NT; const int t = i >> LCH, ch = c * CH + (i & (CH - 1));
       float v = 0.f;
       if (i < TAPW && ch < p.cpad_dw) v = (t < K * K) ? p.wdw[(size_t)t * p.cpad_dw + ch] : p.bdw[ch];
       tpre[q] = v;
@@ -125,12 +129,12 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) acc3[t] = (v4f){0.f, 0.f, 0.f, 0.f};
   const int ntile3 = p.ct3 * p.tpt;
-  const int cp = tid & 31, pg = tid >> 5;                                    // depthwise: channel pair, pixel group
+  const int cp = tid & (CPN - 1), pg = tid / CPN;                            // depthwise: channel pair, pixel group
 
   uint4 af[KB1M];
-  const int wq = wv & 3, wph = wv >> 2;                                       // conv1: channel tile of the chunk, pixel-tile phase (NW / 4 waves share a channel tile)
+  const int wq = wv % TPC, wph = wv / TPC;                                    // conv1: channel tile of the chunk, pixel-tile phase (NW / TPC waves share a channel tile)
   auto load_w1 = [&](int c) __attribute__((always_inline)) {
-    const int ct = min(c * 4 + wq, p.ct1 - 1);
+    const int ct = min(c * TPC + wq, p.ct1 - 1);
 #pragma unroll
     for (int kb = 0; kb < KB1M; ++kb) if (kb < p.kb1) af[kb] = *(const uint4*)(p.w1 + (((size_t)ct * p.kb1 + kb) * 64 + lane) * 8);
   };
@@ -139,11 +143,11 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
   for (int c = 0; c < p.nchunk; ++c) {
     // ---- conv1 -> plane (or the block input itself when the block has no expansion conv)
     if (p.w1) {
-      const int ct = c * 4 + wq;
+      const int ct = c * TPC + wq;
       if (ct < p.ct1) {
         const int ch = ct * 16 + 4 * g;
         const float4 bb = *(const float4*)(p.b1 + ch);
-        for (int pt = wph; pt < spt; pt += NW / 4) {
+        for (int pt = wph; pt < spt; pt += NW / TPC) {
           v4f acc = {0.f, 0.f, 0.f, 0.f};
           const uint16_t* brow = xc + (size_t)(pt * 16 + j) * p.xs + g * 8;
 #pragma unroll
@@ -154,22 +158,23 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
           const unsigned prow = ptab[pt * 16 + j];
           if (prow != 0xffffu) {
             uint2 o; o.x = cvt_pk_bf16(fmaxf(acc[0] + bb.x, 0.f), fmaxf(acc[1] + bb.y, 0.f)); o.y = cvt_pk_bf16(fmaxf(acc[2] + bb.z, 0.f), fmaxf(acc[3] + bb.w, 0.f));
-            *(uint2*)(pl + (size_t)prow * IB_PLS + wq * 16 + 4 * g) = o;
+            *(uint2*)(pl + (size_t)prow * PLS + wq * 16 + 4 * g) = o;
           }
         }
       } else {
-        for (int pt = wph; pt < spt; pt += NW / 4) {
+        for (int pt = wph; pt < spt; pt += NW / TPC) {
           const unsigned prow = ptab[pt * 16 + j];
-          if (prow != 0xffffu) *(uint2*)(pl + (size_t)prow * IB_PLS + wq * 16 + 4 * g) = make_uint2(0, 0);
+          if (prow != 0xffffu) *(uint2*)(pl + (size_t)prow * PLS + wq * 16 + 4 * g) = make_uint2(0, 0);
         }
       }
       if (c + 1 < p.nchunk) load_w1(c + 1);                                  // the next chunk's fragments travel under the depthwise and reduce phases
     } else {
-      for (int u = tid; u < sp * 8; u += NT) {                                // plane = channels [64 c, 64 c + 64) of the staged input
-        const int px = u >> 3, part = u & 7; const int ch = c * 64 + part * 8;
+      for (int u = tid; u < sp * (CH / 8); u += NT) {                         // plane = channels [CH c, CH c + CH) of the staged input
+        const int px = u / (CH / 8), part = u % (CH / 8); const int ch = c * CH + part * 8;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ch < p.cin) v = *(const uint4*)(xc + (size_t)px * p.xs + p.r + ch);
-        *(uint4*)(pl + (size_t)ptab[px] * IB_PLS + part * 8) = v;
+        *(uint2*)(pl + (size_t)ptab[px] * PLS + part * 8) = make_uint2(v.x, v.y);          // (rows are 8-byte aligned: stride CH + 4 elements)
+        *(uint2*)(pl + (size_t)ptab[px] * PLS + part * 8 + 4) = make_uint2(v.z, v.w);
       }
     }
     ib_barrier();
@@ -177,10 +182,10 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
     {
       if (c + 1 < p.nchunk) load_taps(c + 1);                                // in flight under this phase; stored after it
       float bd[2];
-      { const float2 b2 = *(const float2*)(tapl + K * K * 64 + 2 * cp); bd[0] = b2.x; bd[1] = b2.y; }
+      { const float2 b2 = *(const float2*)(tapl + K * K * CH + 2 * cp); bd[0] = b2.x; bd[1] = b2.y; }
       const int units = p.th * p.tw4;
 #pragma unroll 1
-      for (int u = pg; u < units; u += NT / 32) {
+      for (int u = pg; u < units; u += NT / CPN) {
         const int oy = u / p.tw4, ox0 = (u - oy * p.tw4) * 4;
         float a[4][2];
 #pragma unroll
@@ -188,15 +193,15 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
 #pragma unroll 1
         for (int ky = 0; ky < K; ++ky) {                                     // (not unrolled: unrolled, all k*k taps are hoisted into 2 k*k registers and the kernel drops to one wave per SIMD)
           const int row = oy * S + ky;
-          const uint16_t* rp_ = pl + ((size_t)row * p.rw + ox0 * S) * IB_PLS + 2 * cp;
+          const uint16_t* rp_ = pl + ((size_t)row * p.rw + ox0 * S) * PLS + 2 * cp;
           float wt[K][2];                                                     // this kernel row's taps (LDS: 8-byte reads, the lanes of a pixel group share none)
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) { const float2 w2 = *(const float2*)(tapl + (ky * K + kx) * 64 + 2 * cp); wt[kx][0] = w2.x; wt[kx][1] = w2.y; }
+          for (int kx = 0; kx < K; ++kx) { const float2 w2 = *(const float2*)(tapl + (ky * K + kx) * CH + 2 * cp); wt[kx][0] = w2.x; wt[kx][1] = w2.y; }
           float col[SPAN][2];
 #pragma unroll
           for (int q = 0; q < SPAN; ++q) {
             uint32_t v = 0;
-            if (ox0 * S + q < p.rw) v = *(const uint32_t*)(rp_ + (size_t)q * IB_PLS);
+            if (ox0 * S + q < p.rw) v = *(const uint32_t*)(rp_ + (size_t)q * PLS);
             col[q][0] = __uint_as_float(v << 16); col[q][1] = __uint_as_float(v & 0xffff0000u);
           }
 #pragma unroll
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o)
-          if (ox0 + o < p.tw) *(uint32_t*)(y2 + (size_t)(oy * p.tw + ox0 + o) * IB_Y2S + 2 * cp) = cvt_pk_bf16(fmaxf(a[o][0], 0.f), fmaxf(a[o][1], 0.f));
+          if (ox0 + o < p.tw) *(uint32_t*)(y2 + (size_t)(oy * p.tw + ox0 + o) * Y2S + 2 * cp) = cvt_pk_bf16(fmaxf(a[o][0], 0.f), fmaxf(a[o][1], 0.f));
       }
     }
     ib_barrier();
@@ -221,11 +226,11 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
       if (idx < ntile3) {
         const int ct = idx % p.ct3, pt = idx / p.ct3;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int kb = 2 * c + k2;
+        for (int k2 = 0; k2 < KSC; ++k2) {
+          const int kb = KSC * c + k2;
           if (kb < p.kb3) {
             const uint4 af = *(const uint4*)(p.w3 + (((size_t)ct * p.kb3 + kb) * 64 + lane) * 8);
-            const uint4 bf = *(const uint4*)(y2 + (size_t)(pt * 16 + j) * IB_Y2S + k2 * 32 + g * 8);
+            const uint4 bf = *(const uint4*)(y2 + (size_t)(pt * 16 + j) * Y2S + k2 * 32 + g * 8);
             acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af), __builtin_bit_cast(v8bf, bf), acc3[t], 0, 0, 0);
           }
         }
@@ -258,8 +263,8 @@ __global__ __launch_bounds__(NW * 64) void k_iblock(const IBlkP p) {
   }
 }
 
-static size_t iblock_lds(int rpt, int tpt, int xs, int k) {
-  return ((size_t)rpt * 16 * xs + (size_t)rpt * 16 * IB_PLS + (size_t)tpt * 16 * IB_Y2S) * 2 + (size_t)(k * k + 1) * 64 * 4 + (size_t)rpt * 16 * 2;
+static size_t iblock_lds(int rpt, int tpt, int xs, int k, int ch) {
+  return ((size_t)rpt * 16 * xs + (size_t)rpt * 16 * IB_PLS(ch) + (size_t)tpt * 16 * IB_Y2S(ch)) * 2 + (size_t)(k * k + 1) * ch * 4 + (size_t)rpt * 16 * 2;
 }
 
 static int iblock_waves(const IBlkP& p) {
@@ -275,11 +280,11 @@ static int launch_iblock(const IBlkP& p, size_t lds, hipStream_t s) {
   const int nw = iblock_waves(p);
   const int per_wave = (p.ct3 * p.tpt + nw - 1) / nw;
   const dim3 grid((unsigned)(p.n * p.tiles_x * p.tiles_y));
-#define IB_GO(MT, KB, NW_) do { \
+#define IB_GO(MT, KB, NW_, CH_) do { \
     static bool set = false; \
-    if (!set) { (void)hipFuncSetAttribute((const void*)k_iblock<K, S, MT, KB, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-    hipLaunchKernelGGL((k_iblock<K, S, MT, KB, NW_>), grid, dim3(NW_ * 64), lds, s, p); } while (0)
-#define IB_GO2(MT, NW_) do { if (p.kb1 <= 2) IB_GO(MT, 2, NW_); else IB_GO(MT, 10, NW_); } while (0)
+    if (!set) { (void)hipFuncSetAttribute((const void*)k_iblock<K, S, MT, KB, NW_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((k_iblock<K, S, MT, KB, NW_, CH_>), grid, dim3(NW_ * 64), lds, s, p); } while (0)
+#define IB_GO2(MT, NW_) do { if (p.chunk == 32) IB_GO(MT, 2, NW_, 32); else if (p.kb1 <= 2) IB_GO(MT, 2, NW_, 64); else IB_GO(MT, 10, NW_, 64); } while (0)
   if (nw == 8) {
     if (per_wave <= 4) IB_GO2(4, 8); else if (per_wave <= 12) IB_GO2(12, 8);
     else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
@@ -299,7 +304,7 @@ extern "C" int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int 
   const int rh = (th - 1) * stride + k, rw = (tw - 1) * stride + k;
   const int rpt = (rh * rw + 15) / 16, tpt = (th * tw + 15) / 16;
   const int kc = r + round_up(cin, 32) > round_up(r + cin, 32) ? r + round_up(cin, 32) : round_up(r + cin, 32);
-  const size_t lds = iblock_lds(rpt, tpt, kc + 8, k);
+  const size_t lds = iblock_lds(rpt, tpt, kc + 8, k, 64);
   if (lds > 160 * 1024 || rh * rw >= 0xffff) return 0;
   if (round_up(r + cin, 32) / 32 > 10) return 0;                       // conv1 K steps held in registers
   if ((round_up(cout, 16) / 16 * tpt + 3) / 4 > 20) return 0;          // reduce accumulators per wave
@@ -310,11 +315,14 @@ extern "C" int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int 
 /* One Frost bottleneck, bf16 inference, as ONE launch.  x: [n][h][w][cin] bf16 NHWC; y: [n][ho][wo][cout].  Packs / folded biases are those of
  * frost_infer_weight_prep (FrostIDesc.pack / .biasf): wsq / w1 / w3 = bf16 A-fragment packs with kpad = round_up(K, 32) (NULL = layer absent), wdw = fp32 taps
  * [k*k][round_up(cexp,16)].  r = squeeze width (0 without squeeze), cexp = depthwise width (= r + cin ... when conv1 is absent: = cin).  residual: + x.
- * waves: 4 or 8 waves per workgroup, 0 = the kernel's own rule (8 for a whole small map with a wide expansion). */
+ * waves: 4 or 8 waves per workgroup, 0 = the kernel's own rule (8 for a whole small map with a wide expansion).  chunk: channels of the expanded width per
+ * pass, 64 (= 0) or 32 (the narrow high-resolution blocks, conv1 K <= 64). */
 extern "C" int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const float* bsq, const uint16_t* w1, const float* b1, const float* wdw,
                                  const float* bdw, const uint16_t* w3, const float* b3, int n, int h, int w, int cin, int r, int cexp, int cout, int k,
-                                 int stride, int residual, int th, int tw, int waves, uint16_t* y, void* stream) {
+                                 int stride, int residual, int th, int tw, int waves, int chunk, uint16_t* y, void* stream) {
   FROST_REQUIRE(frost_infer_block_ok(h, w, cin, r, cexp, cout, k, stride, th, tw), "infer_block: unsupported geometry / tile");
+  if (chunk == 0) chunk = 64;
+  FROST_REQUIRE(chunk == 64 || (chunk == 32 && round_up(r + cin, 32) <= 64), "infer_block: chunk = 64, or 32 for blocks whose conv1 has K <= 64");
   FROST_REQUIRE(!residual || (stride == 1 && cin == cout), "infer_block: residual needs stride 1 and cin == cout");
   FROST_REQUIRE((wsq != nullptr) == (r > 0) && (w1 != nullptr || cexp == cin), "infer_block: inconsistent layer set");
   IBlkP p = {};
@@ -324,13 +332,13 @@ extern "C" int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const f
   p.cin = cin; p.r = r; p.cexp = cexp; p.cout = cout;
   p.kb_sq = round_up(cin, 32) / 32; p.ct_sq = round_up(r, 16) / 16;
   p.kb1 = round_up(r + cin, 32) / 32; p.ct1 = round_up(cexp, 16) / 16;
-  p.kb3 = round_up(cexp, 32) / 32; p.ct3 = round_up(cout, 16) / 16; p.cpad_dw = round_up(cexp, 16); p.nchunk = (cexp + 63) / 64;
+  p.kb3 = round_up(cexp, 32) / 32; p.ct3 = round_up(cout, 16) / 16; p.cpad_dw = round_up(cexp, 16); p.nchunk = (cexp + chunk - 1) / chunk; p.chunk = chunk;
   p.th = th; p.tw = tw; p.tiles_x = (p.wo + tw - 1) / tw; p.tiles_y = (p.ho + th - 1) / th;
   p.rh = (th - 1) * stride + k; p.rw = (tw - 1) * stride + k; p.rp = p.rh * p.rw; p.rpt = (p.rp + 15) / 16;
   p.tp = th * tw; p.tpt = (p.tp + 15) / 16; p.tw4 = (tw + 3) / 4;
   const int kc = (r + round_up(cin, 32) > round_up(r + cin, 32)) ? r + round_up(cin, 32) : round_up(r + cin, 32);
   p.xs = kc + 8; p.residual = residual; p.waves = waves;
-  const size_t lds = iblock_lds(p.rpt, p.tpt, p.xs, k);
+  const size_t lds = iblock_lds(p.rpt, p.tpt, p.xs, k, chunk);
   hipStream_t s = as_stream(stream);
   if (k == 3 && stride == 1) return launch_iblock<3, 1>(p, lds, s);
   if (k == 3) return launch_iblock<3, 2>(p, lds, s);

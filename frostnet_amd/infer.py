@@ -26,7 +26,7 @@ def round_up(a, b):
 _FUSED = {"0": False, "1": True}.get(os.environ.get("FROST_INFER_FUSED", "auto"), "auto")
 # the stem straight from the fp32 image (frost_infer_stem) instead of im2col + GEMM: bit-identical, no 128-byte-per-pixel patch buffer
 _STEM_DIRECT = os.environ.get("FROST_INFER_STEM", "direct") != "im2col"
-TILE_CANDIDATES = ((0, 0), (-1, 0), (7, 14), (8, 16), (7, 7), (8, 8), (4, 8))          # (0, 0) = the whole map, (-1, 0) = half of it
+TILE_CANDIDATES = ((0, 0), (-1, 0), (7, 14), (8, 16), (16, 16), (7, 7), (8, 8), (4, 16), (4, 8))          # (0, 0) = the whole map, (-1, 0) = half of it
 
 
 def candidate_tiles(lib, h, w, cin, r, cexp, cout, k, stride):
@@ -187,7 +187,7 @@ class Bf16Inference:
         call("frost_infer_block", ptr(a), ptr(sq.pack) if sq is not None else None, ptr(sq.biasf) if sq is not None else None,
              ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
              ptr(l3.pack), ptr(l3.biasf), n, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride, 0 if ent["blk"].reduction else 1, tile[0], tile[1],
-             tile[2] if len(tile) > 2 else 0, ptr(out), stream())
+             tile[2] if len(tile) > 2 else 0, tile[3] if len(tile) > 3 else 0, ptr(out), stream())
         return out, l3.cout, h2, w2
 
     def _block(self, ent, a, c, n, h, w):
@@ -206,7 +206,9 @@ class Bf16Inference:
             else:
                 timed = []
                 tiles = candidate_tiles(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride)
-                for cand in ["plain"] + [(th, tw, nw) for th, tw in tiles for nw in (4, 8)]:          # every tile with 4 and with 8 waves per workgroup
+                narrow = -(-(r + c) // 32) <= 2                       # conv1 K <= 64 (the high-resolution blocks): 32-channel chunks are an option
+                # every tile with 4 and with 8 waves per workgroup (and, for the narrow blocks, with 64- and 32-channel chunks of the expanded width)
+                for cand in ["plain"] + [(th, tw, nw, ch) for th, tw in tiles for nw in (4, 8) for ch in ((64, 32) if narrow else (64,))]:
                     run = (lambda: self._block_plain(ent, a, c, n, h, w)) if cand == "plain" else (lambda t=cand: self._block_fused(ent, a, c, n, h, w, t))
                     try:
                         run()

@@ -300,7 +300,7 @@ int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pac
 int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int cout, int k, int stride, int th, int tw);
 int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const float* bsq, const uint16_t* w1, const float* b1, const float* wdw,
                       const float* bdw, const uint16_t* w3, const float* b3, int n, int h, int w, int cin, int r, int cexp, int cout, int k,
-                      int stride, int residual, int th, int tw, int waves, uint16_t* y, void* stream);
+                      int stride, int residual, int th, int tw, int waves, int chunk, uint16_t* y, void* stream);
 /* y[n][o] = sum_k x[n][k] * w[o][k] + bias[o], fp32 on the f32 MFMA (classifier of the float model) */
 int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream);
 

@@ -22,7 +22,7 @@ Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
 y = torch.empty(n * Ho * Ho * cout + 64, dtype=torch.int16, device=dev)
 def run():
     L.call("frost_infer_block", L.ptr(x), L.ptr(wsq), L.ptr(bsq), L.ptr(w1), L.ptr(b1), L.ptr(wdw), L.ptr(bdw), L.ptr(w3), L.ptr(b3), n, H, H, cin, r, cexp, cout, k, s,
-           1 if (s == 1 and cin == cout) else 0, tile[0], tile[1], 0, L.ptr(y), L.stream())
+           1 if (s == 1 and cin == cout) else 0, tile[0], tile[1], 0, 0, L.ptr(y), L.stream())
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
