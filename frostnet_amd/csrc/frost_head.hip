@@ -142,10 +142,12 @@ __global__ __launch_bounds__(256) void k_sgemm(const TA* __restrict__ a, int64_t
 // split K so that >= 256 workgroups run (C is zeroed by a memset node first)
 template <typename TA, typename TB>
 static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, const TB* b, int64_t brs, int64_t bcs, int M, int N, int K,
-                         const float* alpha_ptr, const float* bias, float* c, bool split_ok, const float* nscale = nullptr, const float* kscale = nullptr) {
+                         const float* alpha_ptr, const float* bias, float* c, bool split_ok, const float* nscale = nullptr, const float* kscale = nullptr,
+                         int max_split = 8) {
   const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
-  int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible)
-  while (split_ok && ks < 8 && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
+  int ks = 1;      // forward GEMMs stay unsplit: their result must not depend on atomic order (the forward is bit-reproducible) -- or split in TWO:
+                   // 0 + a + b and 0 + b + a are the same float, whichever half arrives first
+  while (split_ok && ks < max_split && tiles * ks < 256 && K / (ks * 2) >= 64) ks *= 2;
   if (ks > 1) (void)hipMemsetAsync(c, 0, (size_t)M * N * sizeof(float), s);
   const dim3 grid((N + 63) / 64, (M + 63) / 64, ks);
   if constexpr (sizeof(TA) == 4 && sizeof(TB) == 1) {
@@ -161,7 +163,8 @@ static void launch_sgemm(hipStream_t s, const TA* a, int64_t ars, int64_t acs, c
   else hipLaunchKernelGGL((k_sgemm<TA, TB, 16>), dim3((N + 63) / 64, (M + 63) / 64, ks), dim3(256), 0, s, a, ars, acs, b, brs, bcs, M, N, K, alpha_ptr, 1.0f, bias, c, 0, nscale, kscale);
 }
 extern "C" int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream) {
-  launch_sgemm<float, float>(as_stream(stream), x, (int64_t)k, (int64_t)1, w, (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, bias, y, false);
+  static const int split2 = getenv("FROST_LINEAR_SPLIT2") ? atoi(getenv("FROST_LINEAR_SPLIT2")) : 1;
+  launch_sgemm<float, float>(as_stream(stream), x, (int64_t)k, (int64_t)1, w, (int64_t)1, (int64_t)k, n, o, k, (const float*)nullptr, bias, y, split2 != 0, nullptr, nullptr, 2);
   return frost_check_launch("linear_f32");
 }
 // classifier forward: y[n][o] = s_w * sum_k x[n][k] * wq[o][k] + bias[o]   (frostnet.py:299 on fake-quantised weights)

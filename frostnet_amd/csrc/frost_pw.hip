@@ -478,6 +478,33 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) { addq[r] = cvq ? __float_as_int(B[r]) : 0; Bq[r] = cvq ? 0.0f : B[r]; }
             int8_t* base = p.y + p0 * p.cout;
+            if (SPC) {
+              // specialised instances: the requantisation flavour is a uniform branch around the tile loop, so the training emit pays nothing for the converted
+              // forms (expressions = the generic path's below, term for term)
+              auto emit_tiles = [&](auto cv_tag) __attribute__((always_inline)) {
+                constexpr int CV = decltype(cv_tag)::value;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                  const int prow = (wp * NT + t) * 16 + j;
+                  uint32_t packed = 0;
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    float qv;
+                    if (CV == 2) qv = rintf(((float)acci[m][t][r] + B[r]) * A[r]) + y_zpf;
+                    else if (CV == 1) qv = rintf(fmaf(A[r], (float)(acci[m][t][r] + __float_as_int(B[r])), 0.0f) * y_inv) + y_zpf;
+                    else qv = rintf(fmaf(A[r], (float)acci[m][t][r], B[r]) * y_inv) + y_zpf;
+                    if (lowq) qv = fminf(qv, qcap);
+                    packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+                  }
+                  if (o_lds) { if (chok) *(uint32_t*)(gcur + prow * p.cout + ch0) = packed ^ 0x80808080u; }
+                  else if ((FULL || (p0 + prow) < p.npix) && chok) *(uint32_t*)(base + prow * p.cout + ch0) = packed ^ 0x80808080u;
+                }
+              };
+              if (p.cvt == 1) emit_tiles(std::integral_constant<int, 1>{});
+              else if (p.cvt == 2) emit_tiles(std::integral_constant<int, 2>{});
+              else emit_tiles(std::integral_constant<int, 0>{});
+              continue;
+            }
             if (!SPC && p.cvt == 2) {
               // converted inference on the FBGEMM engine (per-channel 'fbgemm' qconfig): float bias, per-channel multiplier --
               // q = cvtps2dq((float(acc) + b[c] / (s_x s_w[c])) * (s_x s_w[c] / s_y)) + zp, rows B / A (oracle.fbgemm_conv).  Uniform branch per channel tile.
@@ -793,7 +820,7 @@ template <int WP>
 static int pw_spec(const PwP& p, bool io_std) {
   static const int on = getenv("FROST_PW_SPEC") ? atoi(getenv("FROST_PW_SPEC")) : 1;
   constexpr int WC = 8 / WP;
-  if (!on || WP == 2 || !io_std || p.cvt || p.ngroups != 1 || (p.cpad >> 4) != WC * p.mi_eff || !p.gl) return 0;
+  if (!on || WP == 2 || !io_std || p.ngroups != 1 || (p.cpad >> 4) != WC * p.mi_eff || !p.gl) return 0;
   const bool al = (p.kstr & 15) == 0;
   if (p.cout != p.cpad) {                  // partial last channel tile: 24 and 40 output channels (96->24, 72->24, 144->40, 168->40)
     if (WP == 8 && p.mi_eff == 2) return 18;
