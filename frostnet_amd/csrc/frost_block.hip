@@ -18,6 +18,18 @@
 #include "frost_common.h"
 
 typedef int v2i __attribute__((ext_vector_type(2)));
+#include <stdlib.h>
+
+// XCD-aware block index (speed only): workgroup b runs on XCD b % 8, and the (image group, chunk) kernels below read 64-byte (int8) / 128-byte (bf16) pieces of
+// pixel rows whose length is no multiple of a cache line (c = 312 ... 1728 channels), so a neighbouring chunk's workgroup on ANOTHER XCD fetches the shared lines
+// again (counters: 1.7 - 2.9x the algorithmic bytes).  Runs of 4 consecutive work items (= neighbouring chunks of one image group) are therefore dealt to ONE XCD,
+// resident together.  Bijective on [0, total): the last total % 32 items keep their index.  FROST_BLK_XCD=0: the plain map (A/B runs).
+__device__ __forceinline__ int blk_xcd_item(int b, int total, int on) {
+  if (!on || b >= (total & ~31)) return b;
+  const int xcd = b & 7, j = b >> 3;
+  return (j >> 2) * 32 + xcd * 4 + (j & 3);
+}
+static int blk_xcd_on() { static const int on = getenv("FROST_BLK_XCD") ? atoi(getenv("FROST_BLK_XCD")) : 1; return on; }
 
 struct BlkAP {
   const int8_t* x; const float* qx;                 // conv1's input (offset-binary bytes, [n*map][cin]) and its record
@@ -556,7 +568,7 @@ struct BlkCP {
   const int8_t* wq; const int32_t* wsum; const float* qw; const float* wscale;   // taps [k*k][cpad], weight sums, weight record, per-channel scales (or NULL)
   float* coef; const float* qy;                     // coefficient rows (the reduce pass accumulates S1 / S2 into them; the dc pass reads them), output record
   const uint16_t* gout; uint16_t* dx; float* dwq;   // gradient w.r.t. conv2's output (bf16), w.r.t. its input (bf16, or NULL), raw weight-gradient sums [c][k*k]
-  int n, c, cpad, nchunk, imgs, rounds, relu, sr; float inv_count;
+  int n, c, cpad, nchunk, imgs, rounds, relu, sr; float inv_count; int xmap;
 };
 
 template <int K, int HW, int NW>
@@ -585,7 +597,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   uint8_t* const dpl = smem + G::PLANE;                         // [PHA][PITCH][64] bf16
   uint8_t* const gt = dpl + G::DPL;                             // [MAP][64] bf16
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int bi = blk_xcd_item((int)blockIdx.x, (int)gridDim.x, p.xmap);
+  const int chunk = bi % p.nchunk, ig = bi / p.nchunk;
   const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
   const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
 
@@ -782,6 +795,7 @@ static int launch_blk_c(BlkCP& p, hipStream_t s) {
     int groups = (256 * occ * rounds) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
     p.imgs = (p.n + groups - 1) / groups;
   }
+  p.xmap = blk_xcd_on();
   hipLaunchKernelGGL((k_blk_dw_bwd<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_dw_bwd");
 }
@@ -824,7 +838,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
   uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
   uint8_t* const gt = smem + G::PLANE;                          // [MAP][64] bf16
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int bi = blk_xcd_item((int)blockIdx.x, (int)gridDim.x, p.xmap);
+  const int chunk = bi % p.nchunk, ig = bi / p.nchunk;
   const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
   const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
   const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
@@ -937,7 +952,8 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_stats(const BlkCP p, uint
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = (int)blockIdx.x % p.nchunk, ig = (int)blockIdx.x / p.nchunk;
+  const int bi = blk_xcd_item((int)blockIdx.x, (int)gridDim.x, p.xmap);
+  const int chunk = bi % p.nchunk, ig = bi / p.nchunk;
   const int img_lo = ig * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
   const int ch = chunk * 64 + lane; const bool chok = ch < p.c;
   const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
@@ -1042,6 +1058,7 @@ static int launch_blk_s(BlkCP& p, uint8_t* stats, const FrostFinDesc& fin, hipSt
   }
   int groups = (256 * occ) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;       // one round of resident workgroups
   p.imgs = (p.n + groups - 1) / groups;
+  p.xmap = blk_xcd_on();
   hipLaunchKernelGGL((k_blk_dw_stats<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p, stats, fin);
   return frost_check_launch("block_dw_stats");
 }
@@ -1072,6 +1089,7 @@ static int launch_blk_r(BlkCP& p, hipStream_t s) {
     int groups = (256 * occ * rounds) / p.nchunk; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
     p.imgs = (p.n + groups - 1) / groups;
   }
+  p.xmap = blk_xcd_on();
   hipLaunchKernelGGL((k_blk_dw_bred<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_dw_bwd_reduce");
 }

@@ -405,6 +405,9 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         if (MODE == M_STATS) {
+#ifdef PW_ABL_NOSTATEPI
+          return;
+#endif
           // lane: channel ct*16+j; register r of tile t: pixel p0 + (wp*NT+t)*16 + 4g + r.  Per element: one int add (sum),
           // cvt + fma (sum of squares, fp32 within the tile -> double across tiles), half a min3 and half a max3.
 #pragma unroll
@@ -740,6 +743,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     __syncthreads();
     long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+#ifndef PW_ABL_NOGATOM
     for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {
       if (l_mn[c] <= l_mx[c]) {
         atomicAdd((unsigned long long*)&g_s1[c], (unsigned long long)l_s1[c]);
@@ -747,6 +751,8 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
         atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
       }
     }
+#endif
+#ifndef PW_ABL_NOFIN
     if (p.fin_on) {            // last workgroup done: the layer's statistics are complete -> conv finalize here instead of in its own launch
       int* sflag = (int*)smem;
       if (last_block_done2(p.fin.counter, p.fin_total, sflag)) {
@@ -755,6 +761,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
                           p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 512, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
       }
     }
+#endif
   } else if (MODE == M_BRED) {
     if (defer) {
       const int ct0 = (cg_lo * WC + wc) * mi_eff;
@@ -860,7 +867,9 @@ static int launch_pw(PwP& p, hipStream_t s) {
   int rc = 0;
   if (nfull > 0) {
     const size_t cres_bytes = (size_t)p.cpad * FROST_COEF_ROWS * 4;
-    if (res_ok && res_on && res_bytes <= 40 * 1024 && lds_f + res_bytes <= 80 * 1024 && nfull >= 2048) {
+    static const int res_mint = getenv("FROST_PW_RES_MINTILES") ? atoi(getenv("FROST_PW_RES_MINTILES")) : 64;      // (was 2048: the squeeze convs of the 14 x 14 stage run 2 - 5 us faster per pass resident, measured per layer)
+    static const int res_maxb = getenv("FROST_PW_RES_MAXKB") ? atoi(getenv("FROST_PW_RES_MAXKB")) : 40;
+    if (res_ok && res_on && res_bytes <= (size_t)res_maxb * 1024 && lds_f + res_bytes <= (size_t)(res_maxb + 40) * 1024 && nfull >= res_mint) {
       const int sp = (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED) ? pw_spec<WP>(pf, MODE == M_STATS || pf.io != 0) : 0;
       if constexpr (WP == 8 && (MODE == M_STATS || MODE == M_EMIT || MODE == M_BRED)) {
         if (sp == 2) rc = launch_pw3<MODE, 8, true, true, 0, 2>(pf, lds_f + res_bytes, 0, nfull, s);

@@ -286,13 +286,17 @@ template <int GM, int NTP = 4>      // NTP: 16-pixel column blocks per wave (4: 
 __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restrict__ dc, const uint16_t* __restrict__ wt, const float* qw, int64_t npix,
                                                        int cout, int cin, int KB, int CIT, int per, uint16_t* __restrict__ dx, int accumulate,
                                                        const float* __restrict__ bias, int relu, const int32_t* __restrict__ wsum, const float* qx, int32_t* __restrict__ cint,
-                                                       uint8_t* __restrict__ stats, FrostFinDesc fin) {
+                                                       uint8_t* __restrict__ stats, FrostFinDesc fin, int xmap, int nchy) {
   constexpr bool I8 = GM != 0;
   __shared__ __attribute__((aligned(16))) uint8_t wl[2][DGW_KS * DGW_NT * 1024 + 1024];          // (+ the slack the staged output tile needs, see the epilogue)
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t p0 = (int64_t)blockIdx.x * (64 * NTP) + w * (16 * NTP);
-  const int ct0 = blockIdx.y * per;                        // the tiles are dealt out evenly over gridDim.y (9 tiles -> 5 + 4, not 8 + 1)
+  // XCD-aware map (speed only, 1-D grid): the `nchy` input-channel groups of one pixel tile re-read the same dc rows, so they are dealt to ONE XCD back to back
+  // (workgroup b runs on XCD b % 8) and the re-reads hit that XCD's L2; pixel tiles past the tensor (grid padding) find every access predicated off
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xmap) { const int b = blockIdx.x, xcd = b & 7, jb = b >> 3; bx = (jb / nchy) * 8 + xcd; by = jb % nchy; }
+  const int64_t p0 = (int64_t)bx * (64 * NTP) + w * (16 * NTP);
+  const int ct0 = by * per;                        // the tiles are dealt out evenly over the channel groups (9 tiles -> 5 + 4, not 8 + 1)
   int nct = CIT - ct0; if (nct > per) nct = per;
   v4f acc[DGW_NT][NTP];
 #pragma unroll
@@ -511,10 +515,13 @@ extern "C" int frost_pw_dgrad_wide_ok(int64_t npix, int cin, int cout) {
 // 128-pixel tiles when 256-pixel ones would leave CUs without a workgroup (the 7x7 layers at B <= 512)
 template <int GM, typename... Args>
 static void launch_dgw(hipStream_t s, int64_t npix, int nch, Args... args) {
-  if (((npix + 255) / 256) * nch < 320)
-    hipLaunchKernelGGL((k_dgrad_wide<GM, 2>), dim3((unsigned)((npix + 127) / 128), (unsigned)nch), dim3(256), 0, s, args...);
-  else
-    hipLaunchKernelGGL((k_dgrad_wide<GM, 4>), dim3((unsigned)((npix + 255) / 256), (unsigned)nch), dim3(256), 0, s, args...);
+  static const int xon = getenv("FROST_DGW_XCD") ? atoi(getenv("FROST_DGW_XCD")) : 1;
+  const bool small = ((npix + 255) / 256) * nch < 320;
+  const int64_t nx = small ? (npix + 127) / 128 : (npix + 255) / 256;
+  const bool xm = xon && nch > 1;
+  const dim3 grid = xm ? dim3((unsigned)(((nx + 7) / 8) * 8 * nch)) : dim3((unsigned)nx, (unsigned)nch);
+  if (small) hipLaunchKernelGGL((k_dgrad_wide<GM, 2>), grid, dim3(256), 0, s, args..., xm ? 1 : 0, nch);
+  else hipLaunchKernelGGL((k_dgrad_wide<GM, 4>), grid, dim3(256), 0, s, args..., xm ? 1 : 0, nch);
 }
 extern "C" int frost_pw_dgrad_wide(const uint16_t* dc, const uint16_t* wt_pack, const float* qrec_w, int64_t npix, int cin, int cout,
                                    uint16_t* dx, int accumulate, void* stream) {
