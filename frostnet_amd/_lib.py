@@ -263,9 +263,14 @@ PROFILER = None
 CALL_LOG = None      # tests: set to a list to record the name of every C-ABI entry launched (which kernel family a case engaged)
 
 
+_ABL_SKIP = frozenset(v for v in os.environ.get("FROST_ABL_SKIP", "").split(",") if v)   # dev, TIMING ONLY: entries not launched at all (wrong results) -- what a family costs inside the real step
+
+
 def call(name, *args, prof=None):
     """Launch one C-ABI entry on the current stream. prof=(label, algorithmic_bytes) tags it for the Profiler."""
     lib = load_library()
+    if _ABL_SKIP and name in _ABL_SKIP:
+        return
     p = PROFILER
     if CALL_LOG is not None:
         CALL_LOG.append(name)

@@ -13,8 +13,14 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 #define WT 64
 #define KPIX 128
+#ifndef WG_PFD
+#define WG_PFD 1      // prefetch depth (128-pixel blocks) of the 64 x 64-tile kernel (deeper: measured no faster -- the loop was LDS-bank bound, not latency bound)
+#endif
+#ifndef WGB_PFD
+#define WGB_PFD 1     // ... of the 128 x 128-tile kernel
+#endif
 #ifndef RSD
-#define RSD 136   // dc LDS row stride (bytes): 64 bf16 + 8
+#define RSD 160   // dc LDS row stride (bytes): 64 bf16 + 32 -- 40 dwords = 8 x odd: the 4 (8) rows a 16-lane group (half wave) reads land on disjoint 8-bank ranges
 #endif
 #ifndef RSX
 #define RSX 72    // x  LDS row stride (bytes): 64 int8 + 8  (8-byte aligned rows for the 8-byte transpose reads)
@@ -24,7 +30,7 @@ __device__ __forceinline__ uint32_t pack_trunc_bf16(float lo, float hi) {   // e
   return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
 }
 
-__global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+__global__ __launch_bounds__(256, (WG_PFD > 1) ? 2 : 3) void k_pw_wgrad(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
                                                   int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD + KPIX * RSX];   // 26.6 KB: staging, then the 16 KB reduction tile
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD;
@@ -49,44 +55,52 @@ __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict_
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  // transpose-read source addresses (fixed per lane): this wave's 32 pixels = rows w*32 + 8g + e
-  const int pb = w * 32 + g * 8;
-  const uint8_t* a_src = dcs + (pb + (i16 >> 2)) * RSD + (i16 & 3) * 8;          // + a*32 bytes, second read + 4 rows
-  const uint8_t* b_src = xs + (pb + (i16 >> 1)) * RSX + (i16 & 1) * 8;           // + b*16 bytes
+  // transpose-read source addresses (fixed per lane): this wave's 32 pixels = rows w*32 + ..; lane group g holds K slots {4g .. 4g+3} (first read) and
+  // {16+4g .. 16+4g+3} (second read) of the 32 -- any K order serves as long as both operands use it, and with this one a half wave reads 8 CONSECUTIVE rows,
+  // which the row strides above spread over all 64 banks (rows 8g .. 8g+3 per group: 4-way conflicts on the dc reads, LDS_BANK_CONFLICT ~ the kernel's duration)
+  const int pb = w * 32 + g * 4;
+  const uint8_t* a_src = dcs + (pb + (i16 >> 2)) * RSD + (i16 & 3) * 8;          // + a*32 bytes, second read + 16 rows
+  const int r8 = i16 >> 1;
+  const uint8_t* b_src = xs + (pb + r8 + ((r8 >= 4) ? 12 : 0)) * RSX + (i16 & 1) * 8;           // + b*16 bytes
 
   int na = (cout - co0 + 15) / 16; if (na > 4) na = 4;     // live 16-channel tiles of this workgroup's 64x64 output tile
   int nb = (cin - ci0 + 15) / 16; if (nb > 4) nb = 4;
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
-  // register prefetch of the next 128-pixel block (24 VGPRs) so its HBM latency overlaps the MFMAs of the current one
-  uint4 pd[4]; uint2 px[4];
-#define WG_PREFETCH(BLK_)                                                                                             \
+  // register prefetch, WG_PFD 128-pixel blocks deep (24 VGPRs each): the kernel runs on few workgroups beside the main stream, so what hides the HBM round
+  // trip is the bytes each workgroup keeps in flight, not residency (one block ahead: ~4 us per block and workgroup, i.e. one round trip per block)
+  uint4 pd[WG_PFD][4]; uint2 px[WG_PFD][4];
+#define WG_PREFETCH(S_, BLK_)                                                                                         \
   {                                                                                                                   \
     const int64_t q0_ = (BLK_) * KPIX;                                                                                \
     _Pragma("unroll") for (int jn = 0; jn < 4; ++jn) {                                                                \
       const int u_ = tid + jn * 256; const int pix_ = u_ >> 3, c8_ = u_ & 7; const int64_t gp_ = q0_ + pix_;          \
-      pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint2(zfill, zfill);                                             \
-      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);            \
-      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);               \
+      pd[S_][jn] = make_uint4(0, 0, 0, 0); px[S_][jn] = make_uint2(zfill, zfill);                                     \
+      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[S_][jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);        \
+      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[S_][jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);           \
     }                                                                                                                 \
   }
-  if (split < nblk) WG_PREFETCH((int64_t)split)
-  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+#pragma unroll
+  for (int s = 0; s < WG_PFD; ++s) { const int64_t b_ = (int64_t)split + (int64_t)s * nsplit; if (b_ < nblk) WG_PREFETCH(s, b_) }
+  for (int64_t blk0 = split; blk0 < nblk; blk0 += (int64_t)nsplit * WG_PFD) {
+#pragma unroll
+   for (int s = 0; s < WG_PFD; ++s) {
+    const int64_t blk = blk0 + (int64_t)s * nsplit;
+    if (blk >= nblk) break;                               // workgroup-uniform
     __syncthreads();
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int u = tid + jn * 256; const int pix = u >> 3, c8 = u & 7;
-      *(uint2*)(dcs + pix * RSD + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y);
-      *(uint2*)(dcs + pix * RSD + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
-      *(uint2*)(xs + pix * RSX + c8 * 8) = px[jn];
+      *(uint4*)(dcs + pix * RSD + c8 * 16) = pd[s][jn];
+      *(uint2*)(xs + pix * RSX + c8 * 8) = px[s][jn];
     }
     __syncthreads();
-    if (blk + nsplit < nblk) WG_PREFETCH(blk + nsplit)
+    if (blk + (int64_t)nsplit * WG_PFD < nblk) WG_PREFETCH(s, blk + (int64_t)nsplit * WG_PFD)
     v4i afr[4], bfr[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {                         // A: dc^T, rows = co; lane i16 gets channel a*16+i16, 8 pixels
       if (a < na) {
         const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + a * 32));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + a * 32 + 4 * RSD));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + a * 32 + 16 * RSD));
         afr[a] = (v4i){(int)((uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16)), (int)((uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16)),
                        (int)((uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16)), (int)((uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16))};
       }
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict_
       for (int b = 0; b < 4; ++b)
         if (a < na && b < nb)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
+   }
   }
   // cross-wave reduction through LDS float atomics into one 64x64 tile
   __syncthreads();
@@ -135,14 +150,15 @@ __global__ __launch_bounds__(256, 3) void k_pw_wgrad(const uint16_t* __restrict_
 // version needed 224 VGPRs: 8 waves per CU, latency-bound).
 #define BT 128
 #ifndef RSD2
-#define RSD2 264   // 128 bf16 + 8 bytes
+#define RSD2 288   // 128 bf16 + 32 bytes (72 dwords = 8 x 9, see RSD)
 #endif
 #ifndef RSX2
-#define RSX2 136   // 128 int8 + 8 bytes
+#define RSX2 288   // the x tile lives in LDS as bf16 (q - zp, exact): converted ONCE per element while staging -- as int8 every wave converted its own B fragments
+                   // (the two co-halves twice over): 280 of the loop's ~330 VALU instructions per block, on 1 - 2 waves per SIMD with no MFMA overlap
 #endif
-__global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+__global__ __launch_bounds__(512, (WGB_PFD > 1) ? 1 : 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
                                                          int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 51 KB
+  __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 72 KB
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD2;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,33 +179,45 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
-  const uint8_t* a_src = dcs + (g * 8 + (i16 >> 2)) * RSD2 + qa * 128 + (i16 & 3) * 8;
-  const uint8_t* b_src = xs + (g * 8 + (i16 >> 1)) * RSX2 + qb * 32 + (i16 & 1) * 8;
+  const uint8_t* a_src = dcs + (g * 4 + (i16 >> 2)) * RSD2 + qa * 128 + (i16 & 3) * 8;         // K slot order: see k_pw_wgrad
+  const uint8_t* b_src = xs + (g * 4 + (i16 >> 2)) * RSX2 + qb * 64 + (i16 & 3) * 8;           // bf16 like the dc tile: + b*32 bytes, second read + 16 rows
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
-  uint4 pd[4]; uint2 px[4];         // register prefetch of the next block: HBM/L2 latency overlaps the MFMAs
-#define WGB_PREFETCH(BLK_)                                                                                            \
+  uint4 pd[WGB_PFD][4]; uint2 px[WGB_PFD][4];         // register prefetch, WGB_PFD blocks deep (see k_pw_wgrad)
+#define WGB_PREFETCH(S_, BLK_)                                                                                        \
   {                                                                                                                   \
     const int64_t q0_ = (BLK_) * KPIX;                                                                                \
     _Pragma("unroll") for (int jn = 0; jn < 4; ++jn) {                                                                \
       const int u_ = tid + jn * 512; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;         \
-      pd[jn] = make_uint4(0, 0, 0, 0); px[jn] = make_uint2(zfill, zfill);                                             \
-      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);            \
-      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);               \
+      pd[S_][jn] = make_uint4(0, 0, 0, 0); px[S_][jn] = make_uint2(zfill, zfill);                                     \
+      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[S_][jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);        \
+      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[S_][jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);           \
     }                                                                                                                 \
   }
-  if (split < nblk) WGB_PREFETCH((int64_t)split)
-  for (int64_t blk = split; blk < nblk; blk += nsplit) {
+#pragma unroll
+  for (int s = 0; s < WGB_PFD; ++s) { const int64_t b_ = (int64_t)split + (int64_t)s * nsplit; if (b_ < nblk) WGB_PREFETCH(s, b_) }
+  for (int64_t blk0 = split; blk0 < nblk; blk0 += (int64_t)nsplit * WGB_PFD) {
+#pragma unroll
+   for (int s = 0; s < WGB_PFD; ++s) {
+    const int64_t blk = blk0 + (int64_t)s * nsplit;
+    if (blk >= nblk) break;                               // workgroup-uniform
     __syncthreads();
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int u = tid + jn * 512; const int pix = u >> 4, c8 = u & 15;
-      *(uint2*)(dcs + pix * RSD2 + c8 * 16) = make_uint2(pd[jn].x, pd[jn].y);
-      *(uint2*)(dcs + pix * RSD2 + c8 * 16 + 8) = make_uint2(pd[jn].z, pd[jn].w);
-      *(uint2*)(xs + pix * RSX2 + c8 * 8) = px[jn];
+      *(uint4*)(dcs + pix * RSD2 + c8 * 16) = pd[s][jn];
+      const uint32_t u0 = px[s][jn].x ^ 0x80808080u, u1 = px[s][jn].y ^ 0x80808080u;          // offset-binary -> unsigned index
+      *(uint4*)(xs + pix * RSX2 + c8 * 16) = make_uint4(pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
+                                                         pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                                                         pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
+                                                         pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf));
     }
     __syncthreads();
-    if (blk + nsplit < nblk) WGB_PREFETCH(blk + nsplit)
+    if (blk + (int64_t)nsplit * WGB_PFD < nblk) WGB_PREFETCH(s, blk + (int64_t)nsplit * WGB_PFD)
+#if defined(WGB_ABL) && WGB_ABL >= 2
+    if (na > 99) {
+#else
     if (na > 0 && nb > 0) {
+#endif
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         v4i afr[4], bfr[2];
@@ -197,19 +225,16 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
         for (int a = 0; a < 4; ++a) {
           if (a < na) {
             const v2i lo = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32)));
-            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32 + 4 * RSD2)));
+            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(a_src + ks * 32 * RSD2 + a * 32 + 16 * RSD2)));
             afr[a] = (v4i){lo[0], lo[1], hi[0], hi[1]};
           }
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           if (b < nb) {
-            const v2i raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32((v2i __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 16));
-            const uint32_t u0 = (uint32_t)raw[0] ^ 0x80808080u, u1 = (uint32_t)raw[1] ^ 0x80808080u;
-            bfr[b] = (v4i){(int)pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
-                           (int)pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
-                           (int)pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
-                           (int)pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf)};
+            const v2i lo = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 32)));
+            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 32 + 16 * RSX2)));
+            bfr[b] = (v4i){lo[0], lo[1], hi[0], hi[1]};
           }
         }
 #pragma unroll
@@ -220,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
       }
     }
+   }
   }
   const float sx = qx[FROST_Q_SCALE];
 #pragma unroll
@@ -230,7 +256,11 @@ __global__ __launch_bounds__(512, 2) void k_pw_wgrad_big(const uint16_t* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * 32 + b * 16 + i16;
+#if defined(WGB_ABL) && WGB_ABL >= 1
+          if (co < cout && ci < cin && acc[a][b][r] == 12345.678f) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
+#else
           if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
+#endif
         }
       }
 }
