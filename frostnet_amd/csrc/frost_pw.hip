@@ -46,6 +46,7 @@ struct PwP {
   float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
   int dxo_off, dx_bytes;             // LDS offset / size of the dx output tile [128][cin] bf16
   int wtl_off, wtl_bytes;            // LDS-resident copy of the transposed weight pack
+  int xb_off;                        // fused backward: the x tile as bf16 (q - zp) [128][cin], converted once per tile for the weight gradient's B operand
   FrostFinDesc fin; int fin_on; unsigned fin_total;   // statistics pass: finalize folded into the last workgroup's tail
   int sr;                            // dc is rounded to bf16 stochastically (unbiased; see sr_pk_bf16 in frost_common.h)
   int cvt;                           // emit pass in converted-inference form: q = rint(float(acc + b_q) * rs) + zp (QNNPACK requantisation)
@@ -161,6 +162,10 @@ __device__ __forceinline__ uint32_t pw_trunc_bf2(float lo, float hi) {   // exac
 template <int MODE, int WP, bool RES, bool FULLT, int FTW = 0, int SP = 0>
 __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) void k_pw(const PwP p) {
   constexpr bool FUSE = FTW > 0;
+  // XB: the fused backward's weight gradient takes its B operand from a bf16 copy of the x tile made once per tile (in the dx tile's LDS, weight gradient BEFORE the data
+  // gradient).  Measured per shape: it wins where a wave owns <= 2 weight-gradient tiles (16 -> 96 @112: 655 -> 612 us, 24 -> 72 @56: 192 -> 179) and loses where it owns 6 - 11
+  // (the per-fragment conversions hide under the MFMA / LDS latencies of the long unrolled tile loop; the extra phase and barrier do not): 24 -> 144 418 -> 451, 168 -> 40 166 -> 194
+  constexpr bool XB = FTW == 2;
   constexpr bool SPC = SP > 0;
   constexpr bool SPF = SPC && !(SP & 16);        // every channel tile full
   constexpr int MIE = SP & 7;
@@ -616,10 +621,46 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       epilogue(std::integral_constant<bool, FULLT>{});
     }
     if (FUSE) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the dc tile [128][cout] bf16 is complete in LDS
+      if (XB) {                                                                         // x tile (linear, [128][cin] offset-binary bytes) -> xb [128][cin] bf16 of (q - zp)
+        const float zpf = (float)(zpx + 128);
+        uint8_t* xbw = smem + p.xb_off;
+        for (int u = tid; u < 16 * p.rowbytes; u += 512) {
+          const uint2 rv = *(const uint2*)(xs + u * 8);
+          const uint32_t u0 = rv.x ^ 0x80808080u, u1 = rv.y ^ 0x80808080u;      // offset-binary -> unsigned index
+          *(uint4*)(xbw + u * 16) = make_uint4(pw_trunc_bf2((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf), pw_trunc_bf2((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                                               pw_trunc_bf2((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf), pw_trunc_bf2((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the dc tile [128][cout] bf16 (and xb) is complete in LDS
       const uint8_t* dct = io_base + buf * p.g_bytes;
       const int rbd = p.cout * 2, cin = p.rowbytes;
       uint8_t* dxo = smem + p.dxo_off;
+      if (XB) {                                                                   // ---- weight gradient: 16x16 (co x ci) tiles, K = the 128 pixels
+        // B operand = the x tile as bf16, converted ONCE per tile by the whole workgroup (xb, filled before the barrier above): as transposed int8 reads every
+        // wave converted the fragments of each of its tiles itself -- ~35 VALU per K step and tile, up to 40 % of the kernel's VALU on the 24 -> 144 / 56 -> 168 layers
+        const int nbw = (cin + 15) >> 4, ntw = CT * nbw;
+        const uint8_t* xb = smem + p.xb_off; const int rbx = cin * 2;
+#pragma unroll
+        for (int i = 0; i < FTW; ++i) {
+          const int tt = w + 8 * i;
+          if (tt < ntw) {
+            const int a = tt / nbw, b = tt - a * nbw;
+            const uint8_t* a_src = dct + (g * 8 + (j >> 2)) * rbd + (j & 3) * 8 + a * 32;
+            const uint8_t* b_src = xb + (g * 8 + (j >> 2)) * rbx + (j & 3) * 8 + b * 32;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const v2i_ lo = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(a_src + ks * 32 * rbd)));
+              const v2i_ hi = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(a_src + ks * 32 * rbd + 4 * rbd)));
+              const v4i af = (v4i){lo[0], lo[1], hi[0], hi[1]};
+              const v2i_ blo = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(b_src + ks * 32 * rbx)));
+              const v2i_ bhi = __builtin_bit_cast(v2i_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(b_src + ks * 32 * rbx + 4 * rbx)));
+              const v4i bf = (v4i){blo[0], blo[1], bhi[0], bhi[1]};
+              wacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, af), __builtin_bit_cast(v8bf, bf), wacc[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (XB && p.dx) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // xb shares the dx tile's LDS (same size): every wave is done reading it before the data gradient writes there
       if (p.dx) {                                                                 // ---- data gradient: D[ci][pix], wave w = pixel sub-tile w
         const float swq = p.qw[FROST_Q_SCALE];
         const int CTd = (cin + 15) >> 4;
@@ -647,7 +688,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
           }
         }
       }
-      {                                                                           // ---- weight gradient: 16x16 (co x ci) tiles, K = the 128 pixels
+      if (!XB) {                                                                         // ---- weight gradient (many tiles per wave): B fragments straight from the int8 x tile
         const int nbw = (cin + 15) >> 4, ntw = CT * nbw;
         const float zpf = (float)(zpx + 128);
 #pragma unroll
@@ -918,7 +959,7 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
 }
 
 // ---- fused backward (dc + dgrad + wgrad in one kernel), host side
-struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off, wtl_off, wtl_bytes; };
+struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off, wtl_off, wtl_bytes, xb_off; };
 static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   FusePlan f = {};
   // the fused kernel is built from the resident-weight, DMA-staged, LDS-I/O instance: any of those switched off (A/B runs) switches it off too
@@ -937,9 +978,10 @@ static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   const size_t res_bytes = (size_t)CT * KS * 1024 + (size_t)cpad * (FROST_COEF_ROWS + 1) * 4;
   size_t lds = (size_t)2 * tile_bytes + 64 + io_bytes + res_bytes;
   f.dxo_off = (int)((lds + 15) & ~(size_t)15);
-  f.wtl_off = f.dxo_off + (want_dx ? 256 * cin : 0);
+  f.wtl_off = f.dxo_off + 256 * cin;
   f.wtl_bytes = want_dx ? ((cin + 15) / 16) * ((cout + 31) / 32) * 1024 : 0;
-  f.lds = (size_t)f.wtl_off + f.wtl_bytes;
+  f.xb_off = f.dxo_off;                                        // the bf16 x tile of the weight gradient lives where the dx tile is assembled afterwards (256 * cin bytes either way)
+  f.lds = (size_t)f.wtl_off + f.wtl_bytes + 64;               // (+ slack: the last K group's second read of a partial channel tile runs past the tile)
   if (f.lds > 160 * 1024) return f;
   f.ok = 1;
   return f;
@@ -967,7 +1009,7 @@ extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, con
   PwP pf = p;
   pf.g_bytes = 256 * cout; pf.o_bytes = 256 * cout; pf.io = 3; pf.io_bytes = 2 * pf.g_bytes + 64;
   pf.wtp = (const uint8_t*)wt_pack; pf.KSd = (cout + 31) / 32; pf.dwq = dwq; pf.dx = dx; pf.accumulate = accumulate;
-  pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin; pf.wtl_off = f.wtl_off; pf.wtl_bytes = f.wtl_bytes;
+  pf.dxo_off = f.dxo_off; pf.dx_bytes = 256 * cin; pf.wtl_off = f.wtl_off; pf.wtl_bytes = f.wtl_bytes; pf.xb_off = f.xb_off;
   hipStream_t s = as_stream(stream);
   int rc;
   const int sp = (f.ftw == 2 && nfull >= 2048) ? (f.wp == 8 ? pw_spec<8>(pf, true) : (f.wp == 4 ? pw_spec<4>(pf, true) : 0)) : 0;
