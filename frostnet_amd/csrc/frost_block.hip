@@ -587,6 +587,19 @@ __device__ __forceinline__ void blk_tr16(const uint8_t* row, int col0, int lane,
   out4[0] = bf2f((uint16_t)raw[0]); out4[1] = bf2f((uint16_t)raw[1]); out4[2] = bf2f((uint16_t)raw[2]); out4[3] = bf2f((uint16_t)raw[3]);
 }
 
+
+// v_dot2c_f32_bf16: acc += a.lo * b.lo + a.hi * b.hi (bf16 pairs, fp32 accumulate): the depthwise backward's stencils at two multiply-adds per VALU instruction
+typedef __bf16 v2bf_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float blk_dot2(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf_, a), __builtin_bit_cast(v2bf_, b), acc, false);
+}
+__device__ __forceinline__ void blk_tr16_raw(const uint8_t* row, int col0, int lane, uint32_t* out2) {     // 4 consecutive pixels of channel `lane` of a bf16 [col][64 ch] row, packed
+  typedef short v4s_ __attribute__((ext_vector_type(4)));
+  typedef int v2i__ __attribute__((ext_vector_type(2)));
+  const int jp = lane & 15, G = lane >> 4;
+  const v2i__ raw = __builtin_bit_cast(v2i__, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(row + ((col0 + (jp >> 2)) * 64 + 16 * G + 4 * (jp & 3)) * 2)));
+  out2[0] = (uint32_t)raw[0]; out2[1] = (uint32_t)raw[1];
+}
 template <int K, int HW, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   using G = BlkGeoC<K, HW, NW>;
@@ -623,6 +636,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
     }
     wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
   }
+  // data gradient: taps as bf16 pairs (integers <= 127: exact) in the order the dot product meets them -- pair a covers (kx = 2a + 1, kx = 2a) against the ascending
+  // pixel pair (ix + K - 2 - 2a, ix + K - 1 - 2a); the odd tap K - 1 stands alone against (ix, ix + 1) with a zero partner
+  constexpr int NPW = (K + 1) / 2;
+  uint32_t wp2[K][NPW];
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int a = 0; a < NPW; ++a) {
+      const uint32_t hi = __float_as_uint(wf[ky * K + 2 * a]) >> 16;
+      const uint32_t lo = (2 * a + 1 < K) ? (__float_as_uint(wf[ky * K + 2 * a + 1]) >> 16) : 0u;
+      wp2[ky][a] = (2 * a + 1 < K) ? (lo | (hi << 16)) : hi;               // lone tap: (w, 0) against (p_ix, p_ix+1)
+    }
   const int acc0 = chok ? (128 - zpx) * p.wsum[ch] : 0;
   const float sw = (p.wscale && chok) ? p.wscale[ch] : p.qw[FROST_Q_SCALE];
   float cA = 0, cB = 0, cK1 = 0, cE = 0, cF = 0;
@@ -704,15 +729,24 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
             sdc += dcv[o][r];
           }
         }
-        // wacc[ky][kx] += dc[o][r] * q[o + ky][r + kx]  (q = unsigned index; the zero point comes off through sdc at the end)
+        // wacc[ky][kx] += dc[o][r] * q[o + ky][r + kx]  (q = unsigned index; the zero point comes off through sdc at the end), two pixels per v_dot2c_f32_bf16:
+        // dc pairs (r, r + 1) for even r against the index pairs XP[i] = (q_i, q_i+1) as bf16 (0 .. 255: exact)
+        uint32_t D2[2][4];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int r2 = 0; r2 < 4; ++r2) D2[o][r2] = __builtin_amdgcn_perm(__float_as_uint(dcv[o][2 * r2 + 1]), __float_as_uint(dcv[o][2 * r2]), 0x07060302u);   // {hi[31:16], lo[31:16]}
 #pragma unroll
         for (int jr = 0; jr < K + 1; ++jr) {
           const uint8_t* rowp = xpl + (2 * w + jr) * PITCH * 64;
           const v2i ra = blk_tr8(rowp, seg * 8, lane), rb = blk_tr8(rowp, seg * 8 + 8, lane);
           const uint32_t u[4] = {(uint32_t)ra[0] ^ 0x80808080u, (uint32_t)ra[1] ^ 0x80808080u, (uint32_t)rb[0] ^ 0x80808080u, (uint32_t)rb[1] ^ 0x80808080u};
-          float xr[12];
+          uint32_t xf[12];
 #pragma unroll
-          for (int i = 0; i < 12; ++i) xr[i] = (float)((u[i >> 2] >> (8 * (i & 3))) & 255u);
+          for (int i = 0; i < 12; ++i) xf[i] = __float_as_uint((float)((u[i >> 2] >> (8 * (i & 3))) & 255u));
+          uint32_t XP[11];
+#pragma unroll
+          for (int i = 0; i < 11; ++i) XP[i] = __builtin_amdgcn_perm(xf[i + 1], xf[i], 0x07060302u);
 #pragma unroll
           for (int ky = 0; ky < K; ++ky) {
             if ((jr - ky) >= 0 && (jr - ky) < 2) {
@@ -720,7 +754,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
 #pragma unroll
               for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) wacc[ky * K + kx] = fmaf(dcv[o][r], xr[r + kx], wacc[ky * K + kx]);
+                for (int r2 = 0; r2 < 4; ++r2) wacc[ky * K + kx] = blk_dot2(D2[o][r2], XP[2 * r2 + kx], wacc[ky * K + kx]);
             }
           }
         }
@@ -738,9 +772,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
           for (int r = 0; r < 8; ++r) acc[o][r] = 0.0f;
 #pragma unroll
         for (int jr = 0; jr < K + 1; ++jr) {
-          float dcr[12];
+          // 12 pixels of the dc row as bf16 pairs: P[i] = (p_i, p_i+1) -- even i straight from the transposed read, odd i one v_alignbit
+          uint32_t d[6];
           const uint8_t* rowp = dpl + ((2 * w + jr) * PITCH) * 64 * 2;
-          blk_tr16(rowp, seg * 8, lane, dcr); blk_tr16(rowp, seg * 8 + 4, lane, dcr + 4); blk_tr16(rowp, seg * 8 + 8, lane, dcr + 8);
+          blk_tr16_raw(rowp, seg * 8, lane, d); blk_tr16_raw(rowp, seg * 8 + 4, lane, d + 2); blk_tr16_raw(rowp, seg * 8 + 8, lane, d + 4);
+          uint32_t P[11];
+#pragma unroll
+          for (int i = 0; i < 11; ++i) P[i] = (i & 1) ? __builtin_amdgcn_alignbit(d[(i >> 1) + 1], d[i >> 1], 16) : d[i >> 1];
 #pragma unroll
           for (int o = 0; o < 2; ++o) {
             const int ky = o + K - 1 - jr;
@@ -748,7 +786,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
 #pragma unroll
               for (int r = 0; r < 8; ++r)
 #pragma unroll
-                for (int kx = 0; kx < K; ++kx) acc[o][r] = fmaf(dcr[r + K - 1 - kx], wf[ky * K + kx], acc[o][r]);
+                for (int a = 0; a < NPW; ++a) acc[o][r] = blk_dot2(P[(2 * a + 1 < K) ? r + K - 2 - 2 * a : r], wp2[ky][a], acc[o][r]);
             }
           }
         }
