@@ -175,6 +175,8 @@ _PROTOS = {
     "frost_float_add_f32": [P, P, L, P, P],
     "frost_float_stem_im2col_f32": [P, I, I, I, L, L, L, L, P, P],
     "frost_infer_block_ok": [I, I, I, I, I, I, I, I, I, I],
+    "frost_infer_block_w_ok": [I, I, I, I, I, I, I, I, I],
+    "frost_infer_block_w": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P],
     "frost_infer_block": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
     "frost_g32_wq": [P, P, P, P, P, I, I, P, P],
     "frost_g32_conv_acc": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],

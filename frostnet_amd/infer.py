@@ -26,6 +26,8 @@ def round_up(a, b):
 _FUSED = {"0": False, "1": True}.get(os.environ.get("FROST_INFER_FUSED", "auto"), "auto")
 # the stem straight from the fp32 image (frost_infer_stem) instead of im2col + GEMM: bit-identical, no 128-byte-per-pixel patch buffer
 _STEM_DIRECT = os.environ.get("FROST_INFER_STEM", "direct") != "im2col"
+# the wave-per-tile block kernel (csrc/frost_iblockw.hip) as a further candidate of the measured choice for the bottlenecks without a squeeze conv ("0": not offered)
+_WAVE = os.environ.get("FROST_INFER_WAVE", "1") != "0"
 TILE_CANDIDATES = ((0, 0), (-1, 0), (7, 14), (8, 16), (16, 16), (7, 7), (8, 8), (4, 16), (4, 8))          # (0, 0) = the whole map, (-1, 0) = half of it
 
 
@@ -190,6 +192,23 @@ class Bf16Inference:
              tile[2] if len(tile) > 2 else 0, tile[3] if len(tile) > 3 else 0, ptr(out), stream())
         return out, l3.cout, h2, w2
 
+    def _block_wave(self, ent, a, c, n, h, w, tile):
+        """A bottleneck without a squeeze conv as ONE launch of frost_infer_block_w: one wave per (th, tw) output tile, no workgroup barriers."""
+        l2, l3, l1 = ent["conv2"], ent["reduce"], ent["conv1"]
+        pad = (l2.k - 1) // 2
+        h2, w2 = (h + 2 * pad - l2.k) // l2.stride + 1, (w + 2 * pad - l2.k) // l2.stride + 1
+        out = torch.empty(n * h2 * w2 * l3.cout + 64, dtype=torch.int16, device=self.device)
+        call("frost_infer_block_w", ptr(a), ptr(l1.pack) if l1 is not None else None, ptr(l1.biasf) if l1 is not None else None, ptr(l2.pack), ptr(l2.biasf),
+             ptr(l3.pack), ptr(l3.biasf), n, h, w, c, l2.cout, l3.cout, l2.k, l2.stride, 0 if ent["blk"].reduction else 1, tile[1], tile[2], ptr(out), stream())
+        return out, l3.cout, h2, w2
+
+    def _run_choice(self, ent, a, c, n, h, w, choice):
+        if choice == "plain":
+            return self._block_plain(ent, a, c, n, h, w)
+        if choice[0] == "w":
+            return self._block_wave(ent, a, c, n, h, w, choice)
+        return self._block_fused(ent, a, c, n, h, w, choice)
+
     def _block(self, ent, a, c, n, h, w):
         if _FUSED is False:
             return self._block_plain(ent, a, c, n, h, w)
@@ -208,8 +227,11 @@ class Bf16Inference:
                 tiles = candidate_tiles(lib, h, w, c, r, l2.cout, l3.cout, l2.k, l2.stride)
                 narrow = -(-(r + c) // 32) <= 2                       # conv1 K <= 64 (the high-resolution blocks): 32-channel chunks are an option
                 # every tile with 4 and with 8 waves per workgroup (and, for the narrow blocks, with 64- and 32-channel chunks of the expanded width)
-                for cand in ["plain"] + [(th, tw, nw, ch) for th, tw in tiles for nw in (4, 8) for ch in ((64, 32) if narrow else (64,))]:
-                    run = (lambda: self._block_plain(ent, a, c, n, h, w)) if cand == "plain" else (lambda t=cand: self._block_fused(ent, a, c, n, h, w, t))
+                # bottlenecks without a squeeze conv on small Cin (the high-resolution blocks): the wave-per-tile kernel with its two tiles
+                wave = [("w", 4, tw) for tw in (4, 8) if _WAVE and sq is None and
+                        lib.frost_infer_block_w_ok(c, 0, l2.cout, l3.cout, l2.k, l2.stride, 1 if ent["conv1"] is not None else 0, 4, tw)]
+                for cand in ["plain"] + [(th, tw, nw, ch) for th, tw in tiles for nw in (4, 8) for ch in ((64, 32) if narrow else (64,))] + wave:
+                    run = (lambda t=cand: self._run_choice(ent, a, c, n, h, w, t))
                     try:
                         run()
                     except RuntimeError:              # this wave count does not hold the tile's reduce_conv accumulators
@@ -224,7 +246,7 @@ class Bf16Inference:
                 choice = min(timed, key=lambda t: t[0])[1]
                 ent[("timing", n, h, w)] = timed
             ent[key] = choice
-        return self._block_plain(ent, a, c, n, h, w) if choice == "plain" else self._block_fused(ent, a, c, n, h, w, choice)
+        return self._run_choice(ent, a, c, n, h, w, choice)
 
     @torch.no_grad()
     def __call__(self, x):

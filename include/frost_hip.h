@@ -301,6 +301,12 @@ int frost_infer_block_ok(int h, int w, int cin, int r, int cexp, int cout, int k
 int frost_infer_block(const uint16_t* x, const uint16_t* wsq, const float* bsq, const uint16_t* w1, const float* b1, const float* wdw,
                       const float* bdw, const uint16_t* w3, const float* b3, int n, int h, int w, int cin, int r, int cexp, int cout, int k,
                       int stride, int residual, int th, int tw, int waves, int chunk, uint16_t* y, void* stream);
+/* The same bottleneck WITHOUT a squeeze conv (FrostNet's high-resolution blocks, /root/reference/frostnet.py:81-122: [conv1 ->] conv2 -> reduce_conv [-> + x]) with one
+ * WAVE per th x tw (4 x 4 / 4 x 8) output tile and no workgroup barriers: conv1's operand straight from HBM into the MFMA fragment layout, 32-channel chunks of the expanded
+ * width through 8 KB of wave-private LDS.  Bit-identical to frost_infer_block / the layer launches.  frost_infer_block_w_ok: 1 if the geometry is taken. */
+int frost_infer_block_w_ok(int cin, int r, int cexp, int cout, int k, int stride, int has_conv1, int th, int tw);
+int frost_infer_block_w(const uint16_t* x, const uint16_t* w1, const float* b1, const float* wdw, const float* bdw, const uint16_t* w3, const float* b3,
+                        int n, int h, int w, int cin, int cexp, int cout, int k, int stride, int residual, int th, int tw, uint16_t* y, void* stream);
 /* y[n][o] = sum_k x[n][k] * w[o][k] + bias[o], fp32 on the f32 MFMA (classifier of the float model) */
 int frost_linear_f32(const float* x, const float* w, const float* bias, int n, int k, int o, float* y, void* stream);
 

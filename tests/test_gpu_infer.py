@@ -87,6 +87,43 @@ def test_fused_block_inference_equals_layer_by_layer(name, res, batch):
     print(f"    measured choices: {picks}")
 
 
+@pytest.mark.parametrize("name,res,batch", [("frostnet_large_1_0", 224, 3), ("frostnet_large_1_0", 97, 2), ("frostnet_small_1_0", 131, 2), ("frostnet_base_1_25", 64, 5)])
+def test_wave_block_kernel_is_bit_identical_to_layer_by_layer(name, res, batch):
+    """frost_infer_block_w (csrc/frost_iblockw.hip: one WAVE per 4 x 4 / 4 x 8 output tile, no workgroup barriers, conv1's operand straight from HBM) on every
+    bottleneck without a squeeze conv it takes, block by block on the layer-by-layer path's own inputs: the outputs must be the same bits (same rounding points,
+    same summation order: one K step per 32-channel chunk, taps in (ky, kx) order) -- maps of 112 ... 8 pixels, stride 1 / 2, k 3 / 5, ragged edge tiles, residual."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, infer as I, _lib as L
+    torch.manual_seed(29)
+    model = F.MODEL_REGISTRY[name]()
+    _randomize_bn(model, 31)
+    model.eval().cuda()
+    x = torch.randn(batch, 3, res, res, device="cuda")
+    model.hip_infer_bf16(x)                               # builds the runner and its weight packs
+    run = model.__dict__["_bf16_infer"]
+    lib = L.load_library()
+    n, _, h, w = x.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    a = torch.empty(n * ho * wo * run.stem.cout, dtype=torch.int16, device="cuda")
+    L.call("frost_infer_stem", L.ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), L.ptr(run.stem.pack), L.ptr(run.stem.biasf), run.stem.cout, 1, L.ptr(a), L.stream())
+    c, h, w = run.stem.cout, ho, wo
+    taken = 0
+    for ent in run.blocks:
+        ref, c2, h2, w2 = run._block_plain(ent, a, c, n, h, w)
+        l2, l3 = ent["conv2"], ent["reduce"]
+        if ent["squeeze"] is None:
+            for tw in (4, 8):
+                if lib.frost_infer_block_w_ok(c, 0, l2.cout, l3.cout, l2.k, l2.stride, 1 if ent["conv1"] is not None else 0, 4, tw):
+                    out, c3, h3, w3 = run._block_wave(ent, a, c, n, h, w, ("w", 4, tw))
+                    torch.cuda.synchronize()
+                    m = n * h2 * w2 * c2
+                    assert (c3, h3, w3) == (c2, h2, w2) and torch.equal(out[:m], ref[:m]), (name, res, c, l2.cout, l3.cout, l2.k, l2.stride, tw, int((out[:m] != ref[:m]).sum()))
+                    taken += 1
+        a, c, h, w = ref, c2, h2, w2
+    assert taken >= (6 if name.endswith("large_1_0") else 2), taken
+
+
 @pytest.mark.parametrize("name,n,h,w", [("frostnet_large_1_0", 3, 224, 224), ("frostnet_small_1_0", 2, 97, 131), ("frostnet_base_0_75", 1, 600, 520), ("frostnet_large_1_0", 2, 31, 17)])
 def test_direct_stem_is_bit_identical_to_im2col_gemm(name, n, h, w):
     """frost_infer_stem (conv1 straight from the fp32 image, tile staged in LDS) against frost_infer_stem_im2col + frost_infer_pw on the same packs: the same
