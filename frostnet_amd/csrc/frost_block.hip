@@ -29,6 +29,12 @@ __device__ __forceinline__ int blk_xcd_item(int b, int total, int on) {
   const int xcd = b & 7, j = b >> 3;
   return (j >> 2) * 32 + xcd * 4 + (j & 3);
 }
+// the same with runs of `run` consecutive items per XCD (k_blk_expand_dw: the `csplit` workgroups of one image group read the same input rows)
+__device__ __forceinline__ int blk_xcd_run(int b, int total, int run) {
+  if (run < 2 || b >= total - total % (8 * run)) return b;
+  const int xcd = b & 7, j = b >> 3;
+  return (j / run) * (8 * run) + xcd * run + (j % run);
+}
 static int blk_xcd_on() { static const int on = getenv("FROST_BLK_XCD") ? atoi(getenv("FROST_BLK_XCD")) : 1; return on; }
 
 struct BlkAP {
@@ -37,7 +43,7 @@ struct BlkAP {
   const float* coef1; const float* qy1; int8_t* y1; // conv1: coefficient rows (finalized), output record, output tensor [n*map][c]
   const int8_t* wq2; const int32_t* wsum2;          // conv2 (depthwise): taps [k*k][cpad], weight sums
   uint8_t* stats2; FrostFinDesc fin;                // conv2: statistics table and the finalize descriptor
-  int n, cin, c, cpad, KS, kstr, nchunk, csplit, imgs, rounds;
+  int n, cin, c, cpad, KS, kstr, nchunk, csplit, imgs, rounds, xrun;
 };
 
 template <int K, int HW, int NW>
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 3 : 4) void k_blk_expand_dw(co
   int* const sflag = (int*)(pl + G::PLANE);
   // per-channel rows of the workgroup's chunk range (cw channels), resident for all its images:
   //   conv2 statistics s1, s2 (8 B each), min, max | conv1 A, B, weight sum | conv2 weight sum | conv2 taps [chunk][k*k][64]
-  const int cs = (int)blockIdx.x % p.csplit, ig = (int)blockIdx.x / p.csplit;
+  const int bi = blk_xcd_run((int)blockIdx.x, (int)gridDim.x, p.xrun);
+  const int cs = bi % p.csplit, ig = bi / p.csplit;
   const int chunk_lo = (cs * p.nchunk) / p.csplit, chunk_hi = ((cs + 1) * p.nchunk) / p.csplit;
   const int cw = (chunk_hi - chunk_lo) * 64;
   unsigned long long* const l_s1 = (unsigned long long*)(sflag + 16);
@@ -302,6 +309,7 @@ static int launch_blk_a(BlkAP& p, hipStream_t s) {
     int groups = (256 * occ * rounds) / p.csplit; if (groups < 1) groups = 1; if (groups > p.n) groups = p.n;
     p.imgs = (p.n + groups - 1) / groups;
   }
+  p.xrun = (blk_xcd_on() && p.csplit >= 2 && p.csplit <= 8) ? p.csplit : 0;
   hipLaunchKernelGGL((k_blk_expand_dw<K, HW, NW, KSM>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.csplit)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_expand_dw");
 }

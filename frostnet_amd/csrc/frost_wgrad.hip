@@ -16,9 +16,6 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 #ifndef WG_PFD
 #define WG_PFD 1      // prefetch depth (128-pixel blocks) of the 64 x 64-tile kernel (deeper: measured no faster -- the loop was LDS-bank bound, not latency bound)
 #endif
-#ifndef WGB_PFD
-#define WGB_PFD 1     // ... of the 128 x 128-tile kernel
-#endif
 #ifndef RSD
 #define RSD 160   // dc LDS row stride (bytes): 64 bf16 + 32 -- 40 dwords = 8 x odd: the 4 (8) rows a 16-lane group (half wave) reads land on disjoint 8-bank ranges
 #endif
@@ -149,78 +146,80 @@ __global__ __launch_bounds__(256, (WG_PFD > 1) ? 2 : 3) void k_pw_wgrad(const ui
 // reduction, and 32 accumulator + 24 prefetch registers per lane, so two 8-wave workgroups are resident per CU (the 4-wave
 // version needed 224 VGPRs: 8 waves per CU, latency-bound).
 #define BT 128
-#ifndef RSD2
-#define RSD2 288   // 128 bf16 + 32 bytes (72 dwords = 8 x 9, see RSD)
-#endif
-#ifndef RSX2
-#define RSX2 288   // the x tile lives in LDS as bf16 (q - zp, exact): converted ONCE per element while staging -- as int8 every wave converted its own B fragments
-                   // (the two co-halves twice over): 280 of the loop's ~330 VALU instructions per block, on 1 - 2 waves per SIMD with no MFMA overlap
-#endif
-__global__ __launch_bounds__(512, (WGB_PFD > 1) ? 1 : 2) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
-                                                         int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[KPIX * RSD2 + KPIX * RSX2];   // 72 KB
+#define RSD2 288   // dc rows: 128 bf16 + 32 bytes (72 dwords = 8 x 9, see RSD)
+// NB = 16-channel input tiles per wave: 2 -> a 128 x 128 (co x ci) workgroup tile, 4 -> 128 x 256.  The x tile lives in LDS as bf16 (q - zp, exact), converted ONCE per
+// element while staging -- as int8 every wave converted its own B fragments (the two co-halves twice over): 280 of the loop's ~330 VALU instructions per block, on 1 - 2
+// waves per SIMD with no MFMA overlap.  The 256-wide tile reads the dc tensor ONCE for layers with 128 < Cin <= 256 (the 7 x 7 expand convs: dc is 6 x the size of x)
+// and halves the re-reads of the narrow dc of the reduce convs (counters: 1.7x the algorithmic bytes with 128 x 128 tiles).
+template <int NB>
+__global__ __launch_bounds__(512, (NB == 2) ? 2 : 1) void k_pw_wgrad_big(const uint16_t* __restrict__ dc, const int8_t* __restrict__ x, const float* qx,
+                                                                           int64_t npix, int cin, int cout, float* __restrict__ dwq, int nsplit, int xmap) {
+  constexpr int BTI = NB * 64;                   // input channels of the workgroup tile
+  constexpr int RSXB = BTI * 2 + 32;              // x rows: bf16 + 32 bytes (8 x odd dwords, like the dc rows)
+  constexpr int XU = BTI / 32;                   // 8-byte x units per thread and block
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // [128][RSD2] + [128][RSXB]: 72 KB / 105 KB
   uint8_t* dcs = lds; uint8_t* xs = lds + KPIX * RSD2;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qa = w >> 2, qb = w & 3;                                   // co half, ci quarter of this wave
-  const int nci = (cin + BT - 1) / BT;
+  const int nci = (cin + BTI - 1) / BTI;
   const int ntile = ((cout + BT - 1) / BT) * nci;
   int tile, split;                   // XCD-aware map, see k_pw_wgrad
   if (xmap) { const int b = blockIdx.x, xcd = b & 7, jb = b >> 3; split = xcd + 8 * (jb / ntile); tile = jb % ntile; }
   else { tile = blockIdx.x % ntile; split = blockIdx.x / ntile; }
-  const int co0 = (tile / nci) * BT, ci0 = (tile % nci) * BT;
+  const int co0 = (tile / nci) * BT, ci0 = (tile % nci) * BTI;
   const int zpu = __float_as_int(qx[FROST_Q_ZP]);
   const float zpf = (float)zpu;
   const uint32_t zfill = (uint32_t)((zpu - 128) & 255) * 0x01010101u;
   int na = (cout - co0 - qa * 64 + 15) / 16; na = na < 0 ? 0 : (na > 4 ? 4 : na);
-  int nb = (cin - ci0 - qb * 32 + 15) / 16; nb = nb < 0 ? 0 : (nb > 2 ? 2 : nb);
-  v4f acc[4][2];
+  int nb = (cin - ci0 - qb * (NB * 16) + 15) / 16; nb = nb < 0 ? 0 : (nb > NB ? NB : nb);
+  v4f acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) acc[a][b] = (v4f){0.f, 0.f, 0.f, 0.f};
   const uint8_t* a_src = dcs + (g * 4 + (i16 >> 2)) * RSD2 + qa * 128 + (i16 & 3) * 8;         // K slot order: see k_pw_wgrad
-  const uint8_t* b_src = xs + (g * 4 + (i16 >> 2)) * RSX2 + qb * 64 + (i16 & 3) * 8;           // bf16 like the dc tile: + b*32 bytes, second read + 16 rows
+  const uint8_t* b_src = xs + (g * 4 + (i16 >> 2)) * RSXB + qb * (NB * 32) + (i16 & 3) * 8;     // bf16 like the dc tile: + b*32 bytes, second read + 16 rows
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
-  uint4 pd[WGB_PFD][4]; uint2 px[WGB_PFD][4];         // register prefetch, WGB_PFD blocks deep (see k_pw_wgrad)
-#define WGB_PREFETCH(S_, BLK_)                                                                                        \
-  {                                                                                                                   \
-    const int64_t q0_ = (BLK_) * KPIX;                                                                                \
-    _Pragma("unroll") for (int jn = 0; jn < 4; ++jn) {                                                                \
-      const int u_ = tid + jn * 512; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;         \
-      pd[S_][jn] = make_uint4(0, 0, 0, 0); px[S_][jn] = make_uint2(zfill, zfill);                                     \
-      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[S_][jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);        \
-      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[S_][jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);           \
-    }                                                                                                                 \
-  }
+  uint4 pd[4]; uint2 px[XU];         // register prefetch of the next block: HBM / L2 latency overlaps the MFMAs (deeper: measured no faster -- the loop is issue-bound)
+  auto prefetch = [&](int64_t blk_) __attribute__((always_inline)) {
+    const int64_t q0_ = blk_ * KPIX;
 #pragma unroll
-  for (int s = 0; s < WGB_PFD; ++s) { const int64_t b_ = (int64_t)split + (int64_t)s * nsplit; if (b_ < nblk) WGB_PREFETCH(s, b_) }
-  for (int64_t blk0 = split; blk0 < nblk; blk0 += (int64_t)nsplit * WGB_PFD) {
+    for (int jn = 0; jn < 4; ++jn) {
+      const int u_ = tid + jn * 512; const int pix_ = u_ >> 4, c8_ = u_ & 15; const int64_t gp_ = q0_ + pix_;
+      pd[jn] = make_uint4(0, 0, 0, 0);
+      if (gp_ < npix && (co0 + c8_ * 8) < cout) pd[jn] = *(const uint4*)(dc + gp_ * cout + co0 + c8_ * 8);
+    }
 #pragma unroll
-   for (int s = 0; s < WGB_PFD; ++s) {
-    const int64_t blk = blk0 + (int64_t)s * nsplit;
-    if (blk >= nblk) break;                               // workgroup-uniform
+    for (int jn = 0; jn < XU; ++jn) {
+      const int u_ = tid + jn * 512; const int pix_ = u_ / (BTI / 8), c8_ = u_ % (BTI / 8); const int64_t gp_ = q0_ + pix_;
+      px[jn] = make_uint2(zfill, zfill);
+      if (gp_ < npix && (ci0 + c8_ * 8) < cin) px[jn] = *(const uint2*)(x + gp_ * cin + ci0 + c8_ * 8);
+    }
+  };
+  if (split < nblk) prefetch((int64_t)split);
+  for (int64_t blk = split; blk < nblk; blk += nsplit) {
     __syncthreads();
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn) {
       const int u = tid + jn * 512; const int pix = u >> 4, c8 = u & 15;
-      *(uint4*)(dcs + pix * RSD2 + c8 * 16) = pd[s][jn];
-      const uint32_t u0 = px[s][jn].x ^ 0x80808080u, u1 = px[s][jn].y ^ 0x80808080u;          // offset-binary -> unsigned index
-      *(uint4*)(xs + pix * RSX2 + c8 * 16) = make_uint4(pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
-                                                         pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
-                                                         pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
-                                                         pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf));
+      *(uint4*)(dcs + pix * RSD2 + c8 * 16) = pd[jn];
+    }
+#pragma unroll
+    for (int jn = 0; jn < XU; ++jn) {
+      const int u = tid + jn * 512; const int pix = u / (BTI / 8), c8 = u % (BTI / 8);
+      const uint32_t u0 = px[jn].x ^ 0x80808080u, u1 = px[jn].y ^ 0x80808080u;          // offset-binary -> unsigned index
+      *(uint4*)(xs + pix * RSXB + c8 * 16) = make_uint4(pack_trunc_bf16((float)(u0 & 255u) - zpf, (float)((u0 >> 8) & 255u) - zpf),
+                                                        pack_trunc_bf16((float)((u0 >> 16) & 255u) - zpf, (float)(u0 >> 24) - zpf),
+                                                        pack_trunc_bf16((float)(u1 & 255u) - zpf, (float)((u1 >> 8) & 255u) - zpf),
+                                                        pack_trunc_bf16((float)((u1 >> 16) & 255u) - zpf, (float)(u1 >> 24) - zpf));
     }
     __syncthreads();
-    if (blk + (int64_t)nsplit * WGB_PFD < nblk) WGB_PREFETCH(s, blk + (int64_t)nsplit * WGB_PFD)
-#if defined(WGB_ABL) && WGB_ABL >= 2
-    if (na > 99) {
-#else
+    if (blk + nsplit < nblk) prefetch(blk + nsplit);
     if (na > 0 && nb > 0) {
-#endif
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        v4i afr[4], bfr[2];
+        v4i afr[4], bfr[NB];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           if (a < na) {
@@ -230,39 +229,47 @@ __global__ __launch_bounds__(512, (WGB_PFD > 1) ? 1 : 2) void k_pw_wgrad_big(con
           }
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NB; ++b) {
           if (b < nb) {
-            const v2i lo = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 32)));
-            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSX2 + b * 32 + 16 * RSX2)));
+            const v2i lo = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSXB + b * 32)));
+            const v2i hi = __builtin_bit_cast(v2i, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s __attribute__((address_space(3)))*)(b_src + ks * 32 * RSXB + b * 32 + 16 * RSXB)));
             bfr[b] = (v4i){lo[0], lo[1], hi[0], hi[1]};
           }
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b)
+          for (int b = 0; b < NB; ++b)
             if (a < na && b < nb)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, afr[a]), __builtin_bit_cast(v8bf, bfr[b]), acc[a][b], 0, 0, 0);
       }
     }
-   }
   }
   const float sx = qx[FROST_Q_SCALE];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
       if (a < na && b < nb) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * 32 + b * 16 + i16;
-#if defined(WGB_ABL) && WGB_ABL >= 1
-          if (co < cout && ci < cin && acc[a][b][r] == 12345.678f) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
-#else
+          const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * (NB * 16) + b * 16 + i16;
           if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
-#endif
         }
       }
+}
+static int xcd_round(int nsplit, int64_t nblk, int* xmap);
+template <int NB>
+static void launch_wgb(const uint16_t* dc, const int8_t* x, const float* qx, int64_t npix, int cin, int cout, float* dwq, int64_t nblk, hipStream_t s) {
+  constexpr int BTI = NB * 64;
+  const size_t lds = (size_t)KPIX * RSD2 + (size_t)KPIX * (BTI * 2 + 32);
+  static bool set = false;
+  if (!set) { (void)hipFuncSetAttribute((const void*)k_pw_wgrad_big<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+  const int ntile = ((cout + BT - 1) / BT) * ((cin + BTI - 1) / BTI);
+  static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 128;     // the kernel runs beside the main stream and competes with it for bandwidth: step 22.05 / 21.99 / 21.91 / 21.94 / 21.87 / 22.1 / 22.18 ms at 256 / 224 / 192 / 160 / 128 / 96 / 64 (end of round 3, interleaved runs; 512 = full residency: 22.3)
+  int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
+  int xmap; nsplit = xcd_round(nsplit, nblk, &xmap);
+  hipLaunchKernelGGL(k_pw_wgrad_big<NB>, dim3(ntile * nsplit), dim3(512), lds, s, dc, x, qx, npix, cin, cout, dwq, nsplit, xmap);
 }
 // split counts >= 8 become multiples of 8 so that the XCD-aware map above is a bijection (FROST_WG_XCD=0: the plain map, for A/B runs)
 static int xcd_round(int nsplit, int64_t nblk, int* xmap) {
@@ -278,12 +285,13 @@ extern "C" int frost_pw_wgrad(const uint16_t* dc, const int8_t* x, const float* 
                               float* dwq, void* stream) {
   FROST_REQUIRE(cin % 8 == 0 && cout % 8 == 0, "pw_wgrad: channels must be multiples of 8");
   const int64_t nblk = (npix + KPIX - 1) / KPIX;
-  if (cin > 64 && cout > 64) {      // wide layers: 128x128 tiles, quadrant-per-wave
-    const int ntile = ((cout + BT - 1) / BT) * ((cin + BT - 1) / BT);
-    static int target = getenv("FROST_WG_TARGET") ? atoi(getenv("FROST_WG_TARGET")) : 128;     // the kernel runs beside the main stream and competes with it for bandwidth: step 22.05 / 21.99 / 21.91 / 21.94 / 21.87 / 22.1 / 22.18 ms at 256 / 224 / 192 / 160 / 128 / 96 / 64 (end of round 3, interleaved runs; 512 = full residency: 22.3)
-    int nsplit = (target + ntile - 1) / ntile; if (nsplit > nblk) nsplit = (int)nblk; if (nsplit < 1) nsplit = 1;
-    int xmap; nsplit = xcd_round(nsplit, nblk, &xmap);
-    hipLaunchKernelGGL(k_pw_wgrad_big, dim3(ntile * nsplit), dim3(512), 0, as_stream(stream), dc, x, qrec_x, npix, cin, cout, dwq, nsplit, xmap);
+  if (cin > 64 && cout > 64) {      // wide layers: 128 x 128 tiles, or 128 x 256 where that saves a pass over dc / halves the passes over a narrow dc (Cin > 128)
+    // OFF by default: alone the wider tile is faster on those layers and reads dc once, but inside the step it is SLOWER (21.22 -> 21.34 ms/step, interleaved): one 512-thread
+    // workgroup with 105 KB of LDS and ~190 registers takes a whole CU away from the main stream for as long as it runs, the 128 x 128 workgroups share theirs
+    static const int wide = getenv("FROST_WG_CI256") ? atoi(getenv("FROST_WG_CI256")) : 0;
+    // only where the wider tile adds no padded channels (Cin = 240, 1440, 1728: measured 75 -> 62, 71 -> 55, 103 -> 106 us; Cin = 288 / 312 / 624 would pad 128 more: 103 -> 140, 41 -> 53, 56 -> 66)
+    if (wide && cin > 128 && round_up(cin, 256) == round_up(cin, 128)) launch_wgb<4>(dc, x, qrec_x, npix, cin, cout, dwq, nblk, as_stream(stream));
+    else launch_wgb<2>(dc, x, qrec_x, npix, cin, cout, dwq, nblk, as_stream(stream));
     return frost_check_launch("pw_wgrad_big");
   }
   const int ntile = ((cout + WT - 1) / WT) * ((cin + WT - 1) / WT);

@@ -203,7 +203,9 @@ def test_frost_block_fwd_bwd_entries_match_engine_sequence(case):
     for key in fa:
         assert torch.equal(fa[key].reshape(-1).view(torch.uint8), fb[key].reshape(-1).view(torch.uint8)), key
     dxa, dxb = ba["dx"].view(torch.bfloat16).double(), bb["dx"].view(torch.bfloat16).double()
-    assert float((dxa != dxb).double().mean()) <= 4e-2 and float((dxa - dxb).norm() / dxa.norm()) <= 3e-3
+    mism, rel = float((dxa != dxb).double().mean()), float((dxa - dxb).norm() / dxa.norm())
+    rels = [float((ba[f"dwq{i}"].double() - bb[f"dwq{i}"].double()).norm() / (ba[f"dwq{i}"].double().norm() + 1e-30)) for i in (1, 2, 3)]
+    print(f"[entries vs engine {case}] dx differs on {mism:.2e} of the elements, rel {rel:.2e}; dWq rel {rels[0]:.2e} {rels[1]:.2e} {rels[2]:.2e}")
+    assert mism <= 4e-2 and rel <= 3e-3, (mism, rel)
     for i in (1, 2, 3):
-        a, b = ba[f"dwq{i}"].double(), bb[f"dwq{i}"].double()
-        assert float((a - b).norm() / (a.norm() + 1e-30)) <= 2e-3, i
+        assert rels[i - 1] <= 2e-3, (i, rels)
