@@ -269,8 +269,8 @@ static size_t iblock_lds(int rpt, int tpt, int xs, int k, int ch) {
 
 static int iblock_waves(const IBlkP& p) {
   static const int forced = getenv("FROST_IB_NW") ? atoi(getenv("FROST_IB_NW")) : 0;
-  if (forced == 4 || forced == 8) return forced;
-  if (p.waves == 4 || p.waves == 8) return p.waves;                    // the caller measured (frostnet_amd/infer.py "auto")
+  if (forced == 4 || forced == 8 || forced == 16) return forced;
+  if (p.waves == 4 || p.waves == 8 || p.waves == 16) return p.waves;   // the caller measured (frostnet_amd/infer.py "auto"); 16: a 7 x 7 map is ONE workgroup per image -- with 256 images that is one workgroup per CU, and only more waves shorten its serial phases
   // 8 waves where a workgroup carries a whole (small) map and a wide expansion: its three phases per 64-channel chunk are serial, more waves shorten each
   return (p.tp >= 49 && p.cexp >= 256) ? 8 : 4;
 }
@@ -285,7 +285,11 @@ static int launch_iblock(const IBlkP& p, size_t lds, hipStream_t s) {
     if (!set) { (void)hipFuncSetAttribute((const void*)k_iblock<K, S, MT, KB, NW_, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((k_iblock<K, S, MT, KB, NW_, CH_>), grid, dim3(NW_ * 64), lds, s, p); } while (0)
 #define IB_GO2(MT, NW_) do { if (p.chunk == 32) IB_GO(MT, 2, NW_, 32); else if (p.kb1 <= 2) IB_GO(MT, 2, NW_, 64); else IB_GO(MT, 10, NW_, 64); } while (0)
-  if (nw == 8) {
+  if (nw == 16) {
+    if (p.chunk == 32) { frost_set_error("infer_block: 16 waves take 64-channel chunks only"); return 1; }
+    if (per_wave <= 4) { if (p.kb1 <= 2) IB_GO(4, 2, 16, 64); else IB_GO(4, 10, 16, 64); }
+    else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
+  } else if (nw == 8) {
     if (per_wave <= 4) IB_GO2(4, 8); else if (per_wave <= 12) IB_GO2(12, 8);
     else { frost_set_error("infer_block: too many output tiles per wave"); return 1; }
   } else {

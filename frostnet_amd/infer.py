@@ -230,7 +230,9 @@ class Bf16Inference:
                 # bottlenecks without a squeeze conv on small Cin (the high-resolution blocks): the wave-per-tile kernel with its two tiles
                 wave = [("w", 4, tw) for tw in (4, 8) if _WAVE and sq is None and
                         lib.frost_infer_block_w_ok(c, 0, l2.cout, l3.cout, l2.k, l2.stride, 1 if ent["conv1"] is not None else 0, 4, tw)]
-                for cand in ["plain"] + [(th, tw, nw, ch) for th, tw in tiles for nw in (4, 8) for ch in ((64, 32) if narrow else (64,))] + wave:
+                # (16 waves: only for whole small maps -- one workgroup per image, so with few images per CU only more waves shorten the serial phases)
+                wide16 = [(th, tw, 16, 64) for th, tw in tiles if th * tw <= 64]
+                for cand in ["plain"] + [(th, tw, nw, ch) for th, tw in tiles for nw in (4, 8) for ch in ((64, 32) if narrow else (64,))] + wide16 + wave:
                     run = (lambda t=cand: self._run_choice(ent, a, c, n, h, w, t))
                     try:
                         run()
