@@ -124,6 +124,42 @@ def test_wave_block_kernel_is_bit_identical_to_layer_by_layer(name, res, batch):
     assert taken >= (6 if name.endswith("large_1_0") else 2), taken
 
 
+def test_fused_block_kernel_with_16_waves_equals_8_waves_and_layer_by_layer():
+    """The 16-wave instances of frost_infer_block (whole 7 x 7 / 8 x 8 maps: one workgroup per image, so only more waves shorten its serial phases) against the
+    8-wave instances and the layer launches, block by block on FrostNet-Large @224: the wave count only deals the same tiles to more waves -- same bits."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, _lib as L
+    torch.manual_seed(41)
+    model = F.MODEL_REGISTRY["frostnet_large_1_0"]()
+    _randomize_bn(model, 43)
+    model.eval().cuda()
+    x = torch.randn(3, 3, 224, 224, device="cuda")
+    model.hip_infer_bf16(x)
+    run = model.__dict__["_bf16_infer"]
+    n, _, h, w = x.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    a = torch.empty(n * ho * wo * run.stem.cout, dtype=torch.int16, device="cuda")
+    L.call("frost_infer_stem", L.ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), L.ptr(run.stem.pack), L.ptr(run.stem.biasf), run.stem.cout, 1, L.ptr(a), L.stream())
+    c, h, w = run.stem.cout, ho, wo
+    taken = 0
+    for ent in run.blocks:
+        ref, c2, h2, w2 = run._block_plain(ent, a, c, n, h, w)
+        if h2 * w2 <= 64:
+            m = n * h2 * w2 * c2
+            try:
+                o16 = run._block_fused(ent, a, c, n, h, w, (h2, w2, 16, 64))[0]
+            except RuntimeError:          # a geometry the kernel (or this wave count) does not take
+                o16 = None
+            if o16 is not None:
+                o8 = run._block_fused(ent, a, c, n, h, w, (h2, w2, 8, 64))[0]
+                torch.cuda.synchronize()
+                assert torch.equal(o16[:m], o8[:m]) and torch.equal(o16[:m], ref[:m]), (c, c2, h2, w2)
+                taken += 1
+        a, c, h, w = ref, c2, h2, w2
+    assert taken >= 4, taken
+
+
 @pytest.mark.parametrize("name,n,h,w", [("frostnet_large_1_0", 3, 224, 224), ("frostnet_small_1_0", 2, 97, 131), ("frostnet_base_0_75", 1, 600, 520), ("frostnet_large_1_0", 2, 31, 17)])
 def test_direct_stem_is_bit_identical_to_im2col_gemm(name, n, h, w):
     """frost_infer_stem (conv1 straight from the fp32 image, tile staged in LDS) against frost_infer_stem_im2col + frost_infer_pw on the same packs: the same
