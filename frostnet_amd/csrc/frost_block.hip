@@ -69,7 +69,8 @@ __device__ __forceinline__ v2i blk_tr8(const uint8_t* row, int col0, int lane) {
 }
 
 // depthwise accumulators of one wave unit: output rows r0, r0 + 1, columns seg*8 .. +8 of channel `lane`, from the plane (signed bytes q - 128)
-template <int K, int PITCH>
+// RV: columns of the segment that exist (a 7 x 7 map has 7: the eighth column of every stencil, epilogue and store was computed and thrown away -- 1/8 of the work)
+template <int K, int PITCH, int RV = 8>
 __device__ __forceinline__ void blk_dw_unit(const uint8_t* pl, int r0, int seg, int lane, const int (&wpk)[K][2], int acc0, int (&acc)[2][8]) {
 #pragma unroll
   for (int o = 0; o < 2; ++o)
@@ -90,7 +91,7 @@ __device__ __forceinline__ void blk_dw_unit(const uint8_t* pl, int r0, int seg, 
       if ((jr - ky) >= 0 && (jr - ky) < 2) {
         const int o = jr - ky;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < RV; ++r) {
           acc[o][r] = __builtin_amdgcn_sdot4(win[r], wpk[ky][0], acc[o][r], false);
           if (K == 5) acc[o][r] = __builtin_amdgcn_sdot4(win[r + 4], wpk[ky][1], acc[o][r], false);
         }
@@ -255,11 +256,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 3 : 4) void k_blk_expand_dw(co
 #pragma unroll 1
         for (int seg = 0; seg < G::NSEG; ++seg) {
           int a[2][8];
-          blk_dw_unit<K, PITCH>(pl, 2 * w, seg, lane, wpk, acc0, a);
+          blk_dw_unit<K, PITCH, (HW == 7) ? 7 : 8>(pl, 2 * w, seg, lane, wpk, acc0, a);
 #pragma unroll
           for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r) {
               if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
                 const int vi = a[o][r]; const float v = (float)vi;
                 t1 += vi; t2 = fma((double)v, (double)v, t2); tmn = min(tmn, vi); tmx = max(tmx, vi);
@@ -441,11 +442,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
 #pragma unroll 1
       for (int seg = 0; seg < G::NSEG; ++seg) {
         int a[2][8];
-        blk_dw_unit<K, PITCH>(pl, 2 * w, seg, lane, wpk, acc0, a);
+        blk_dw_unit<K, PITCH, (HW == 7) ? 7 : 8>(pl, 2 * w, seg, lane, wpk, acc0, a);
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r) {
             if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
               const float yf = fmaf(row.A, (float)a[o][r], row.B);
               float qv = rintf(fmaxf(yf, relu_floor) * y_inv) + y_zpf;
@@ -716,15 +717,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
 #pragma unroll 1
       for (int seg = 0; seg < G::NSEG; ++seg) {
         int a[2][8];
-        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+        blk_dw_unit<K, PITCH, (HW == 7) ? 7 : 8>(xpl, 2 * w, seg, lane, wpk, acc0, a);
         float dcv[2][8];
+        if (HW == 7) { dcv[0][7] = 0.0f; dcv[1][7] = 0.0f; }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           float gq[8];
           const uint8_t* grow = gt + ((2 * w + o) * HW) * 64 * 2;
           blk_tr16(grow, seg * 8, lane, gq); blk_tr16(grow, seg * 8 + 4, lane, gq + 4);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r) {
             const bool valid = (2 * w + o) < HW && (seg * 8 + r) < HW && chok;
             const float v = (float)a[o][r];
             const float tq = fmaf(cA, v, cB) * y_inv;
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
             const int ky = o + K - 1 - jr;
             if (ky >= 0 && ky < K) {
 #pragma unroll
-              for (int r = 0; r < 8; ++r)
+              for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r)
 #pragma unroll
                 for (int a = 0; a < NPW; ++a) acc[o][r] = blk_dot2(P[(2 * a + 1 < K) ? r + K - 2 - 2 * a : r], wp2[ky][a], acc[o][r]);
             }
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
-          for (int r = 0; r < 8; ++r)
+          for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r)
             if ((2 * w + o) < HW && (seg * 8 + r) < HW && chok) dst[(int64_t)((2 * w + o) * HW + seg * 8 + r) * p.c] = (uint16_t)cvt_pk_bf16(acc[o][r] * sw, 0.0f);
       }
     }
@@ -953,14 +955,14 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
 #pragma unroll 1
       for (int seg = 0; seg < G::NSEG; ++seg) {
         int a[2][8];
-        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+        blk_dw_unit<K, PITCH, (HW == 7) ? 7 : 8>(xpl, 2 * w, seg, lane, wpk, acc0, a);
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
           float gq[8];
           const uint8_t* grow = gt + ((2 * w + o) * HW) * 64 * 2;
           blk_tr16(grow, seg * 8, lane, gq); blk_tr16(grow, seg * 8 + 4, lane, gq + 4);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r) {
             const bool valid = (2 * w + o) < HW && (seg * 8 + r) < HW && chok;
             const float v = (float)a[o][r];
             const float tq = fmaf(cA, v, cB) * y_inv;
@@ -1051,12 +1053,12 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_stats(const BlkCP p, uint
 #pragma unroll 1
       for (int seg = 0; seg < G::NSEG; ++seg) {
         int a[2][8];
-        blk_dw_unit<K, PITCH>(xpl, 2 * w, seg, lane, wpk, acc0, a);
+        blk_dw_unit<K, PITCH, (HW == 7) ? 7 : 8>(xpl, 2 * w, seg, lane, wpk, acc0, a);
         int t1 = 0; double t2 = 0.0;
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
+          for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r) {
             if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
               const int vi = a[o][r]; const float v = (float)vi;
               t1 += vi; t2 = fma((double)v, (double)v, t2); smn = min(smn, vi); smx = max(smx, vi);
