@@ -18,8 +18,14 @@ out = {"VAL": f"{d['value']:,.0f}".replace(",", " "), "VALK": f"{d['value'] / 1e
        "FL32": f"{side[4]['value'] / 1e3:.1f}", "OB": " / ".join(f"{o['value'] / 1e3:.1f}" for o in ob)}
 print(json.dumps(out, indent=1))
 if "--fill" in sys.argv:
+    # first run: the docs carry @@KEY@@ placeholders; later runs: the figures of the previous run (profiles/r04_doc_numbers.json) are replaced by the new ones
+    import os
+    prev = json.load(open("profiles/r04_doc_numbers.json")) if os.path.exists("profiles/r04_doc_numbers.json") else {}
     for p in ("DESIGN.md", "README.md"):
         s = open(p).read()
         for key, v in out.items():
             s = s.replace("@@" + key + "@@", v)
         open(p, "w").write(s)
+    changed = {k: (prev.get(k), v) for k, v in out.items() if prev.get(k) not in (None, v)}
+    print("changed since the previous run (edit the docs where these are quoted):", json.dumps(changed))
+    json.dump(out, open("profiles/r04_doc_numbers.json", "w"), indent=1)
