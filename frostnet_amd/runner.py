@@ -6,11 +6,15 @@ rows of the engine's qrecord arena, so `state_dict()` / `load_state_dict()` keep
 those scalars on-device.  Parameter gradients live in ONE flat fp32 arena (views assigned to `p.grad`), which is what
 the multi-tensor optimizer and the data-parallel all-reduce operate on.
 """
+import os
+
 import torch
 
 from . import _lib as L
 from .engine import ConvLayer, Engine, QArena
 
+
+_PREP_SIDE = os.environ.get("FROST_PREP_SIDE", "1") != "0"      # training: the per-step weight preparation on a second stream beside the QuantStub passes
 
 class _QATFunction(torch.autograd.Function):
     """autograd boundary: image -> logits.  backward() runs the hand-written backward pass, which writes the parameter
@@ -493,8 +497,20 @@ class FrostRunner:
             if gp not in ("bf16", "fp32"):
                 raise ValueError("model.grad_precision must be 'bf16' or 'fp32'")
             E.grad_fp32 = gp == "fp32"
-        E.begin_step(observe=obs)
-        a = E.quantize_input(x, self.q_in, observe=obs)
+        if _PREP_SIDE and training and not E.grad_fp32:
+            # the per-step weight preparation (BN fold + weight fake-quant + packing of all 70 layers: a handful of latency-bound launches, ~165 us) has nothing to do
+            # with the image: it runs on a second stream beside the QuantStub's passes over the input (range, observer, quantise: ~115 us of bandwidth), joined before conv1
+            if getattr(E, "_prep_stream", None) is None:
+                E._prep_stream = torch.cuda.Stream(device=E.device)
+            cur = torch.cuda.current_stream()
+            E._prep_stream.wait_stream(cur)
+            with torch.cuda.stream(E._prep_stream):
+                E.begin_step(observe=obs)
+            a = E.quantize_input(x, self.q_in, observe=obs)
+            cur.wait_stream(E._prep_stream)
+        else:
+            E.begin_step(observe=obs)
+            a = E.quantize_input(x, self.q_in, observe=obs)
         a = self._conv(self.stem, a, training, obs)
         feats = []
         for d in self.blocks:
