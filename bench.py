@@ -356,6 +356,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="dev/test: all ranks on cuda:0 with the gloo backend (checks launcher + segmented step + a real 2-rank all-reduce on a 1-GPU box)")
     ap.add_argument("--dry-run-launcher", action="store_true", help="no GPU: N gloo ranks, one all-reduce, one JSON line")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N>1: if the segmented hipGraph capture fails, degrade to one graph + a single post-backward all-reduce (or eager launches) and still print a "
+                         "line; WITHOUT this flag a failed capture ends the run with a non-zero exit code, so a degraded N-GPU number can never be the headline")
     ap.add_argument("--check-allreduce", action="store_true",
                     help="N>1: before timing, verify on the live process group that the bucketed all-reduce leaves the MEAN of the ranks' own shard gradients in every rank's arena")
     args = ap.parse_args()
@@ -376,11 +379,11 @@ def main():
     assert local_rank < torch.cuda.device_count(), f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPUs visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.workload != "qat":
-        assert world == 1, "the side workloads are single-GPU measurements"
+    dp = world > 1 or args.force_dp
+    if args.workload != "qat" and not (args.workload == "detect" and dp):
+        assert world == 1, "the side workloads infer / float / int8 are single-GPU measurements (detect runs data parallel: BASELINE.json config c5)"
         return side_workload(args, dev)
     import torch.distributed as dist
-    dp = world > 1 or args.force_dp
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -403,34 +406,74 @@ def main():
     from frostnet_amd.parallel import SegmentedStep, broadcast_model
 
     torch.manual_seed(1882)                       # Classification/train.py:38-39
-    model = F.MODEL_REGISTRY[f"frostnet_quant_{args.mode}_1_0"]()     # drop_rate 0.2 active, as in training
-    F.qat_prepare(model, version=0)
-    model.to(dev).train()
-    broadcast_model(model)
-    wd = 1e-5                                     # Classification/setting/train.json:5-21
-    groups = [{"params": [p], "weight_decay": (0.0 if p.shape[1] == 1 else wd) if p.dim() == 4 else wd * 0.01}
-              for p in model.parameters()]
-    opt = QSGD(groups, lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2, weight_decay=wd)
-    opt.is_warmup = False                         # StatAssist epoch done -> GradBoost noise on (train.py:162-164)
-    runner = model.hip_runner()
-
+    detect = args.workload == "detect"
     g = torch.Generator(device=dev).manual_seed(1882 + rank)
-    x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
-    tgt = torch.randint(0, 1000, (args.batch,), device=dev, generator=g)
-    from frostnet_amd.harness import CrossEntropyLoss
-    crit = CrossEntropyLoss()                     # nn.CrossEntropyLoss semantics, forward + backward in one HIP kernel (harness.py)
+    if detect:
+        # BASELINE.json config c5: SSDLite on the FrostNet backbone, 512 x 512 QAT, data parallel (Object_Detection/qtrainval.py:123-127 wraps the net in
+        # nn.DataParallel; here one process per GPU, the same bucketed gradient exchange as the classifier)
+        from frostnet_amd import ssdlite as S, harness as H
+        if args.batch == 512:
+            args.batch = 32
+        if args.res == 224:
+            args.res = 512
+        model = S.SSDLiteFrostNet(num_classes=21, mode=args.mode, cfg=S.ssd_cfg_for(args.res))
+        F.qat_prepare(model, version=0)
+        model.to(dev).train()
+        broadcast_model(model)
+        opt = QSGD(H.make_param_groups(model, 1e-5), lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2)
+        opt.is_warmup = False
+        runner = model.hip_runner()
+        x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        rng = torch.Generator().manual_seed(1882 + rank)
+        boxes = []
+        for i in range(args.batch):
+            k = 1 + i % 4
+            c, wh = torch.rand(k, 2, generator=rng) * 0.5 + 0.25, torch.rand(k, 2, generator=rng) * 0.3 + 0.1
+            boxes.append(torch.cat([c - wh / 2, c + wh / 2, torch.randint(0, 20, (k, 1), generator=rng).float()], 1).to(dev))
+        tgt = S.pad_targets(boxes, dev)           # the collate step of a detection loader: ragged boxes -> [N, K, 5] + validity mask
+        mbl = S.MultiBoxLoss(21)
+
+        def loss_of(xx, tt):                      # module surface: model(x) -> (loc, conf, priors) -> MultiBoxLoss (qtrainval.py:186-190)
+            ll, lc = mbl(model(xx), tt)
+            return ll + lc
+
+        def maps_loss(maps, tt):                  # the same loss from the twelve dequantised maps (SegmentedStep's body)
+            ll, lc = mbl(model._assemble(maps), tt)
+            return ll + lc
+        seg_kw = dict(maps_loss=maps_loss)
+    else:
+        model = F.MODEL_REGISTRY[f"frostnet_quant_{args.mode}_1_0"]()     # drop_rate 0.2 active, as in training
+        F.qat_prepare(model, version=0)
+        model.to(dev).train()
+        broadcast_model(model)
+        wd = 1e-5                                     # Classification/setting/train.json:5-21
+        groups = [{"params": [p], "weight_decay": (0.0 if p.shape[1] == 1 else wd) if p.dim() == 4 else wd * 0.01}
+                  for p in model.parameters()]
+        opt = QSGD(groups, lr=5e-3, momentum=0.9, nesterov=True, clip_by=1e-3, toss_coin=True, noise_decay=1e-2, weight_decay=wd)
+        opt.is_warmup = False                         # StatAssist epoch done -> GradBoost noise on (train.py:162-164)
+        runner = model.hip_runner()
+        x = torch.randn(args.batch, 3, args.res, args.res, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        tgt = torch.randint(0, 1000, (args.batch,), device=dev, generator=g)
+        from frostnet_amd.harness import CrossEntropyLoss
+        crit = CrossEntropyLoss()                     # nn.CrossEntropyLoss semantics, forward + backward in one HIP kernel (harness.py)
+
+        def loss_of(xx, tt):
+            return crit(model(xx), tt)
+        seg_kw = dict(criterion=crit)
 
     # N = 1: model(x) -> loss.backward() -> optimizer.step() (the reference loop, helper_functions.py:139-143) captured as ONE hipGraph.
     # N > 1 (default): the same kernels as a chain of hipGraph segments, one per gradient bucket; the bucket's RCCL all-reduce is issued
     # between segments and runs on RCCL's stream under the rest of the backward (frostnet_amd.parallel.SegmentedStep).
-    seg = SegmentedStep(runner, crit, nbuckets=args.buckets) if (dp and not args.single_allreduce) else None
+    seg = SegmentedStep(runner, nbuckets=args.buckets, **seg_kw) if (dp and not args.single_allreduce) else None
+
+    # d(step loss)/d(loss): 1 on one GPU, 1 / world under data parallel (the mean over the global batch; gradients are linear in it, so the SUM all-reduce of the
+    # shard gradients is the mean).  A persistent tensor handed to backward(): no root-gradient fill and no `loss / world` node in the captured step.
+    gscale = torch.full((), 1.0 / (dist.get_world_size() if dp else 1), dtype=torch.float32, device=dev)
 
     def fwd_bwd():
         opt.zero_grad(set_to_none=True)               # the reference loop (helper_functions.py:139); host-side only: p.grad = None, nothing is launched
-        loss = crit(model(x), tgt)
-        if dp:
-            loss = loss / dist.get_world_size()
-        loss.backward()
+        loss = loss_of(x, tgt)
+        loss.backward(gradient=gscale)
         return loss
 
     ctl = {"comm": True}                          # the exposed-communication measurement replays the step with the collectives switched off
@@ -451,38 +494,39 @@ def main():
 
     allreduce_check = None
     if dp and args.check_allreduce:
-        # same state, same shard, twice: once with the collectives switched off (the rank's own gradient, gathered from every rank), once with the
-        # bucketed exchange -> the arena must hold sum_r (g_r / world) = the mean.  Forward state (BN statistics, observers) is restored in between.
+        # ONE backward pass on the live process group: every bucket is snapshotted at the moment the backward hands it to the exchange (this rank's own
+        # gradient), then exchanged; afterwards the snapshots of all ranks are gathered and summed on the side.  The arena must hold that sum = the mean of
+        # the ranks' own shard gradients (each was produced from loss / world) up to the summation order of the collective.  (Two separate passes would
+        # differ by the order of the backward's fp32 atomics, 1e-3 ... 2e-2 at small batches: that noise is not what this check is about.)
         sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-        rng0 = runner.rng_state()                     # the dropout stream too: both passes must draw the same mask
+        rng0 = runner.rng_state()
+        mine = torch.zeros_like(runner.grad_arena)
         if seg is not None:
-            keep = seg._reduce
-            seg._reduce = lambda i: None
+            exchange = seg._reduce
+
+            def snapshot_then_reduce(i):
+                for lo, hi in seg.cuts[i][1]:
+                    mine[lo:hi].copy_(runner.grad_arena[lo:hi])
+                exchange(i)
+            seg._reduce = snapshot_then_reduce
             seg.run_eager(x, tgt)
-            seg._reduce = keep
+            seg.finish()
+            seg._reduce = exchange
         else:
             fwd_bwd()
+            mine.copy_(runner.grad_arena)
+            dist.all_reduce(runner.grad_arena)
         torch.cuda.synchronize()
-        mine = runner.grad_arena.clone()
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         want = torch.stack(parts).sum(0)
-        model.load_state_dict(sd0)
-        runner.set_rng_state(rng0)
-        if seg is not None:
-            seg.run_eager(x, tgt)
-            seg.finish()
-        else:
-            fwd_bwd()
-            dist.all_reduce(runner.grad_arena)
-        torch.cuda.synchronize()
         rel = float((runner.grad_arena - want).norm() / (want.norm() + 1e-30))
         own = float((mine * world - want).norm() / (want.norm() + 1e-30))            # how far a single rank's gradient is from the mean: the check is not vacuous
         model.load_state_dict(sd0)
         runner.set_rng_state(rng0)
-        allreduce_check = dict(rel_err_vs_mean_of_rank_gradients=rel, single_rank_vs_mean=own, ok=bool(rel <= 2e-2), devices=_rank_devices(dev, world))
+        allreduce_check = dict(rel_err_vs_mean_of_rank_gradients=rel, single_rank_vs_mean=own, ok=bool(rel <= 1e-5), devices=_rank_devices(dev, world))
         if rank == 0:
-            print(f"[bench] all-reduce check: arena vs mean of the ranks' own gradients {rel:.2e} (one rank alone: {own:.2e})", file=sys.stderr, flush=True)
+            print(f"[bench] all-reduce check: arena vs sum of the ranks' own (loss / world) gradients {rel:.2e} (one rank alone: {own:.2e})", file=sys.stderr, flush=True)
 
     graph = None
     capture_fallback = None
@@ -508,6 +552,11 @@ def main():
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
             graph = None
             torch.cuda.synchronize()
+            if dp and not args.allow_fallback:
+                # a degraded data-parallel run must never print a headline number: every rank leaves with the same code
+                print(f"[bench] rank {rank}: the data-parallel step could not be captured; refusing to time a fallback (pass --allow-fallback to measure the degraded form)",
+                      file=sys.stderr, flush=True)
+                sys.exit(4)
             if seg is not None:
                 # segment capture under a live RCCL watchdog failed: fall back to ONE graph + one post-backward all-reduce (the --single-allreduce form)
                 seg.graphs = None
@@ -573,9 +622,9 @@ def main():
     if dp:
         # (a) every bucket's all-reduce alone on an otherwise idle GPU (median of 5); (b) the EXPOSED part of the exchange = step time with the
         # collectives minus step time without them (the gradients of those extra steps stay un-reduced: they come after the timed region)
-        buckets = [(lo, hi) for _, lo, hi in seg.cuts] if seg is not None else [(0, runner.grad_arena.numel())]
+        buckets = seg.bucket_ranges() if seg is not None else [[(0, runner.grad_arena.numel())]]
         per_bucket = []
-        for lo, hi in buckets:
+        for ranges in buckets:                  # a bucket = one contiguous arena range (the classifier) or a few (the detector's loc / conf heads): one collective per range
             ts = []
             for _ in range(5):
                 if world > 1:
@@ -583,11 +632,12 @@ def main():
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                dist.all_reduce(runner.grad_arena[lo:hi])
+                for lo, hi in ranges:
+                    dist.all_reduce(runner.grad_arena[lo:hi])
                 e1.record()
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
-            per_bucket.append(dict(bytes=4 * (hi - lo), allreduce_us=round(sorted(ts)[2] * 1e3, 1)))
+            per_bucket.append(dict(bytes=4 * sum(hi - lo for lo, hi in ranges), ranges=len(ranges), allreduce_us=round(sorted(ts)[2] * 1e3, 1)))
         k = max(3, min(args.steps, 10))
         ctl["comm"] = False
         keep_reduce = seg._reduce if seg is not None else None
@@ -616,7 +666,7 @@ def main():
                     fallback=capture_fallback, allreduce_check=allreduce_check)
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not detect:
         # per-kernel HIP-event timing on the launch stream (eager pass: events cannot be read out of a replayed graph)
         def local_step():                  # no collective in here: only rank 0 runs this leg
             crit(model(x), tgt).backward()
@@ -666,17 +716,22 @@ def main():
 
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not detect:
             try:
                 cpu = cpu_baseline()
             except Exception as e:  # pragma: no cover
                 cpu = dict(value=None, error=str(e))
-        out = dict(metric="images/sec FrostNet-Large 224x224 QAT fwd+bwd", value=round(value, 2), unit="images/sec",
+        metric = (f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {args.res}x{args.res} QAT fwd+bwd" if detect
+                  else "images/sec FrostNet-Large 224x224 QAT fwd+bwd")
+        what = (f"SSDLite on the FrostNet-{args.mode.capitalize()} backbone (frostnet_amd.ssdlite), int8 fake-quant QAT fwd+bwd + MultiBoxLoss + GradBoost-SGD step, "
+                f"batch={args.batch}/GPU, {args.res}x{args.res} (BASELINE.json config c5, data parallel)" if detect else
+                f"FrostNet-{args.mode.capitalize()} int8 fake-quant QAT fwd+bwd + GradBoost-SGD step "
+                f"(noise on; StatAssist FP epoch is a one-off before it), batch={args.batch}/GPU, "
+                f"{args.res}x{args.res} NHWC, qnnpack qconfig v0 (per-tensor)")
+        out = dict(metric=metric, value=round(value, 2), unit="images/sec",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
-                   config=dict(workload=f"FrostNet-{args.mode.capitalize()} int8 fake-quant QAT fwd+bwd + GradBoost-SGD step "
-                                        f"(noise on; StatAssist FP epoch is a one-off before it), batch={args.batch}/GPU, "
-                                        f"{args.res}x{args.res} NHWC, qnnpack qconfig v0 (per-tensor)",
+                   config=dict(workload=what,
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
                                parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype=("fp32" if runner.E.grad_fp32 else "bf16"),
                                ms_per_step_median_hip_events=round(ms_median, 3),

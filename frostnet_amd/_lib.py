@@ -90,6 +90,7 @@ _PROTOS = {
     "frost_fake_quant_bwd_f32": [P, P, L, P, P],
     "frost_dequant_act": [P, L, P, P, P],
     "frost_weight_prep": [P, I, I, I, I, P],
+    "frost_export_wq": [P, I, L, P, P],
     "frost_stats_init_table": [P, P, P, I, P],
     "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
     "frost_pw_conv_fwd_fin": [P, P, P, P, L, I, I, P, P, P],
@@ -111,6 +112,7 @@ _PROTOS = {
     "frost_pw_conv_int": [P, P, P, P, L, I, I, P, P],
     "frost_pw_ew": [P, L, I, P, P, I, I, P, P, P],
     "frost_pw_ew_emit_add": [P, L, I, P, P, I, P, P, P, P, P, I, P],
+    "frost_pw_ew_add_bwd": [P, L, I, P, P, I, I, P, P, P, P, P, P, I, P, P],
     "frost_pw_conv_fwd_keep": [P, P, P, P, L, I, I, P, P, P, P],
     "frost_pwc_bwd_ok": [L, I, I],
     "frost_pwc_conv_bwd": [P, P, P, P, L, I, I, I, P, P, I, P, P, P],
@@ -259,6 +261,20 @@ class Profiler:
             a[1] += e0.elapsed_time(e1)
             a[2] += nbytes
         return {k: dict(launches=v[0], total_ms=v[1], avg_ms=v[1] / v[0], bytes_per_launch=v[2] / v[0]) for k, v in agg.items()}
+
+
+# Parameter / buffer writes that torch's tensor version counters do NOT see: the optimizer launch and the training forwards update weights and BatchNorm
+# running statistics through raw device pointers.  Every such writer calls note_raw_write(); caches keyed on tensor versions (Bf16Inference._prepare_weights)
+# compare RAW_WRITE_GEN as well.  A writer captured into a hipGraph is invisible at replay time, so from then on those caches are switched off.
+RAW_WRITE_GEN = 0
+RAW_WRITES_CAPTURED = False
+
+
+def note_raw_write():
+    global RAW_WRITE_GEN, RAW_WRITES_CAPTURED
+    RAW_WRITE_GEN += 1
+    if not RAW_WRITES_CAPTURED and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        RAW_WRITES_CAPTURED = True
 
 
 PROFILER = None

@@ -348,6 +348,25 @@ extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_e
   return frost_check_launch("weight_prep");
 }
 
+// replaces: the `weight` entry of a converted module's state_dict (nnq.Conv2d._weight_bias(), Classification/evaluate.py:140-143 saves it): the int8 values the
+// packs of frost_weight_prep hold, in the module's own [cout][cin/g][kh][kw] order -- the same wq_at() the pack kernels call, so the exported tensor IS the
+// weight the device convolves with
+__global__ __launch_bounds__(256) void k_export_wq(const FrostWDesc* descs, int layer, int8_t* __restrict__ out) {
+  const FrostWDesc d = descs[layer];
+  const float inv = 1.0f / d.qrec[FROST_Q_SCALE];
+  const int per = d.cin_g * d.kk;
+  const int64_t n = (int64_t)d.cout * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i / per);
+    out[i] = (int8_t)wq_at(d, inv, co, (int)(i - (int64_t)co * per));
+  }
+}
+extern "C" int frost_export_wq(const FrostWDesc* descs, int layer, int64_t nelem, int8_t* out, void* stream) {
+  FROST_REQUIRE(descs && out && layer >= 0 && nelem > 0, "export_wq: bad arguments");
+  hipLaunchKernelGGL(k_export_wq, dim3(grid_for(nelem, 256, 1024)), dim3(256), 0, as_stream(stream), descs, layer, out);
+  return frost_check_launch("export_wq");
+}
+
 // ------------------------------------------------------------------------------------------------ stats init
 __global__ __launch_bounds__(256) void k_stats_init(uint8_t* base, const int32_t* cpads, const int64_t* offs) {
   int l = blockIdx.y; int cp = cpads[l];

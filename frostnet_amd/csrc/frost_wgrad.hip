@@ -732,6 +732,122 @@ extern "C" int frost_pw_ew(const int32_t* conv_out, int64_t npix, int cout, floa
 }
 
 
+// ---- block-boundary fusion, backward: skip_add's backward (frostnet.py:142; k_add_bwd8) folded into the element-wise reduce / dc passes of the reduce_conv that
+// produced the add's second operand.  g = gsum if the add's FakeQuantize passed the element (STE window of q_sum on fake(a) + fake(yb)) else 0 -- the expression of
+// k_add_bwd8, term for term; the residual branch's gradient ga (+)= g leaves in the reduce pass (mode 0); the reduce_conv's own gout (= g) is never written: both
+// passes re-derive it from gsum / a / yb (4 bytes per element instead of writing and twice re-reading a 2-byte tensor, and one launch less per residual block).
+// Bit-identical to frost_add_bwd + frost_pw_ew (g is a bf16 value passed through or zeroed).  Thread = 4 channels x strided pixels, as k_pw_ew.
+__device__ __forceinline__ void ew_acc_store4(uint16_t* dst, const float* v, int accumulate) {      // = acc_store4 of frost_head.hip (k_add_bwd8's store)
+  float o[4] = {v[0], v[1], v[2], v[3]};
+  if (accumulate) { uint2 t = *(const uint2*)dst; o[0] += bf2f(t.x & 0xffff); o[1] += bf2f(t.x >> 16); o[2] += bf2f(t.y & 0xffff); o[3] += bf2f(t.y >> 16); }
+  uint2 w; w.x = cvt_pk_bf16(o[0], o[1]); w.y = cvt_pk_bf16(o[2], o[3]);
+  *(uint2*)dst = w;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pw_ew_add(const int32_t* __restrict__ cint, int64_t npix, int cout, int cpad, float* __restrict__ coef, const float* qy,
+                                                   int relu, float inv_count, const uint16_t* __restrict__ gsum, const int8_t* __restrict__ a, const float* qa,
+                                                   const int8_t* __restrict__ yb, const float* qsum, uint16_t* __restrict__ ga, int acc_a, uint16_t* __restrict__ dc, int sr) {
+  extern __shared__ float part[];                   // mode 0: [2][cout]
+  const int tid = threadIdx.x;
+  if (MODE == 0) { for (int i = tid; i < 2 * cout; i += 256) part[i] = 0.0f; __syncthreads(); }
+  const int c4n = cout >> 2;
+  const int64_t PP = ((int64_t)gridDim.x * 256) / c4n;
+  const int64_t tt = (int64_t)blockIdx.x * 256 + tid;
+  const int c4 = (int)(tt % c4n); const int64_t slot = tt / c4n;
+  const int ch = c4 * 4;
+  const QP QA = load_qp(qa), QB = load_qp(qy), QS = load_qp(qsum);
+  const float y_inv = 1.0f / qy[FROST_Q_SCALE];
+  const int zpy = __float_as_int(qy[FROST_Q_ZP]), qhi = q_hi(qy);
+  const float hi0 = (float)qhi + 0.5f - (float)zpy;
+  const float t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+  float t_lo = 0.0f;
+  if (!relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  float A[4], B[4], R[4], MR[4], K1[4], E[4], F[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    A[r] = coef[FROST_COEF_A * cpad + ch + r]; B[r] = coef[FROST_COEF_B * cpad + ch + r];
+    const float Mv = coef[FROST_COEF_M * cpad + ch + r]; R[r] = coef[FROST_COEF_R * cpad + ch + r]; MR[r] = -Mv * R[r];
+    K1[r] = 0.f; E[r] = 0.f; F[r] = 0.f;
+    if (MODE == 1) {
+      K1[r] = coef[FROST_COEF_K1 * cpad + ch + r];
+      const float s1 = coef[FROST_COEF_S1 * cpad + ch + r], s2 = coef[FROST_COEF_S2 * cpad + ch + r];
+      E[r] = -K1[r] * (s2 * inv_count) * R[r]; F[r] = -K1[r] * (s1 * inv_count) - E[r] * Mv;
+    }
+  }
+  float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  if (slot < PP) {
+    for (int64_t p0 = slot; p0 < npix; p0 += 2 * PP) {          // two pixels per trip: their loads are in flight together
+      v4i cv[2]; uint2 gv[2]; uint32_t av[2], bv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t p = p0 + u * PP;
+        cv[u] = (v4i){0, 0, 0, 0}; gv[u] = make_uint2(0, 0); av[u] = 0; bv[u] = 0;
+        if (p < npix) {
+          cv[u] = *(const v4i*)(cint + p * cout + ch); gv[u] = *(const uint2*)(gsum + p * cout + ch);
+          av[u] = *(const uint32_t*)(a + p * cout + ch); bv[u] = *(const uint32_t*)(yb + p * cout + ch);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t p = p0 + u * PP;
+        if (p >= npix) continue;
+        float gq[4] = {__uint_as_float(gv[u].x << 16), __uint_as_float(gv[u].x & 0xffff0000u), __uint_as_float(gv[u].y << 16), __uint_as_float(gv[u].y & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {          // skip_add's FakeQuantize: the sum of the two fake-quantised operands, window test of q_sum (k_add_bwd8)
+          const float v = (float)((int)(int8_t)(av[u] >> (8 * r)) + 128 - QA.zp) * QA.scale + (float)((int)(int8_t)(bv[u] >> (8 * r)) + 128 - QB.zp) * QB.scale;
+          bool inr; fq_index(v, QS.inv, QS.zp, 0, QS.hi, &inr);
+          if (!inr) gq[r] = 0.0f;
+        }
+        if (MODE == 0) ew_acc_store4(ga + p * cout + ch, gq, acc_a);
+        float dcv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float af = (float)cv[u][r];
+          const float tq = fmaf(A[r], af, B[r]) * y_inv;
+          const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;
+          if (MODE == 0) { r1[r] += gy; r2[r] = fmaf(gy, fmaf(af, R[r], MR[r]), r2[r]); }
+          else dcv[r] = fmaf(gy, K1[r], fmaf(af, E[r], F[r]));
+        }
+        if (MODE == 1) {
+          uint2 o;
+          if (sr) { o.x = sr_pk_bf16(dcv[0], dcv[1], rng); o.y = sr_pk_bf16(dcv[2], dcv[3], rng); }
+          else { o.x = cvt_pk_bf16(dcv[0], dcv[1]); o.y = cvt_pk_bf16(dcv[2], dcv[3]); }
+          *(uint2*)(dc + p * cout + ch) = o;
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    if (slot < PP) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { atomicAdd(&part[ch + r], r1[r]); atomicAdd(&part[cout + ch + r], r2[r]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < cout; i += 256) {
+      atomicAdd(coef + FROST_COEF_S1 * cpad + i, part[i]);
+      atomicAdd(coef + FROST_COEF_S2 * cpad + i, part[cout + i]);
+    }
+  }
+}
+extern "C" int frost_pw_ew_add_bwd(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gsum,
+                                   const int8_t* a, const float* qrec_a, const int8_t* yb, const float* qrec_sum, uint16_t* ga, int acc_a, uint16_t* dc, void* stream) {
+  FROST_REQUIRE((cout & 3) == 0, "pw_ew_add_bwd: cout must be a multiple of 4");
+  FROST_REQUIRE(conv_out && gsum && a && yb && qrec_a && qrec_sum && ((mode == 0 && ga) || (mode == 1 && dc)), "pw_ew_add_bwd: mode 0 (reduce, writes ga) or 1 (dc -> out)");
+  const int cpad = round_up(cout, 16); const int c4n = cout >> 2;
+  const int64_t tot = npix * c4n;
+  static int rcap = -1;
+  if (rcap < 0) { const char* e = getenv("FROST_PWEW_CAP"); rcap = e ? atoi(e) : 256; if (rcap < 64) rcap = 64; }
+  int64_t grid = (tot + 255) / 256; const int64_t cap = mode == 0 ? rcap : 2048; if (grid > cap) grid = cap;
+  const int64_t gmin = (c4n + 255) / 256; if (grid < gmin) grid = gmin;
+  const float inv_count = 1.0f / (float)npix;
+  if (mode == 0) hipLaunchKernelGGL(k_pw_ew_add<0>, dim3((unsigned)grid), dim3(256), (size_t)2 * cout * 4, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count,
+                                    gsum, a, qrec_a, yb, qrec_sum, ga, acc_a, (uint16_t*)nullptr, 0);
+  else hipLaunchKernelGGL(k_pw_ew_add<1>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), conv_out, npix, cout, cpad, coef, qrec_y, relu, inv_count,
+                          gsum, a, qrec_a, yb, qrec_sum, (uint16_t*)nullptr, 0, dc, frost_sr_enabled());
+  return frost_check_launch("pw_ew_add_bwd");
+}
+
 // ---- block-boundary fusion (first piece): the emit pass of a kept-conv-output reduce layer TOGETHER with the range pass of the residual add
 // that consumes it (frostnet.py:138-142: out = reduce_conv(out); out = skip_add.add(x, out)).  One sweep over the integer conv output writes the layer's
 // int8 output y AND accumulates min / max of (x + y) in the reference's fp32 arithmetic (k_add_minmax's expression, same operand order); the last

@@ -48,11 +48,23 @@ _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, b
 # depthwise weight gradients of maps no wider than this also go to the second stream.  Measured (two boxes, 2-3 runs each): 14 -> -0.2 ms, but
 # 7, 28, 56 and "only the 14x14 maps" -> +1.1 ms (the captured graph serialises differently): too close to a cliff for a default, stays off
 _DW_WG_MAXW = int(os.environ.get("FROST_DW_WG_MAXW", "0"))
+# join the weight-gradient stream back into the main stream after this many forked weight gradients (0 = only at the end of the backward).  Inside a captured
+# hipGraph ONE long side branch is not scheduled beside the layers it was forked from: the replay trace (profiles/r05_replay_nodes_*.txt) shows all 39 pointwise
+# weight gradients starting ~8 ms late, beside the bandwidth-bound 112 x 112 / 56 x 56 backward instead of the latency-bound 14 x 14 / 7 x 7 one
+_WG_JOIN = int(os.environ.get("FROST_WG_JOIN", "0"))
+# FROST_WG_DEFER = H > 0: the pointwise weight gradients of layers on maps of height <= H are not forked one by one but collected and launched on the side stream
+# behind ONE fork when the backward reaches a larger map (their dc / x buffers stay referenced until the join, as before).  Measured (profiles/r05_wgrad_schedule.txt):
+# H = 14 is 0.33 ms SLOWER than per-layer forks (21.63 vs 21.30 ms/step) -- in the captured step the per-layer forks already start ~8 ms late, and starting all of
+# them 1.8 ms earlier (beside layer3.0 / layer2.1's backward) costs more than the 39 fork gaps of ~4.6 us it removes.  0 = fork per layer (default).
+_WG_DEFER = int(os.environ.get("FROST_WG_DEFER", "0"))
+# skip_add's backward folded into the element-wise reduce / dc passes of the reduce_conv that produced its second operand (frost_pw_ew_add_bwd): one launch less per
+# residual block of the 14 x 14 / 7 x 7 stages and no materialised gout for that layer; bit-identical to the two launches it replaces (A/B switch)
+_ADD_BWD_FUSE = os.environ.get("FROST_ADD_BWD_FUSE", "1") != "0"
 
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done", "add_bwd")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
@@ -63,6 +75,7 @@ class Act:
         self.kept_next = None      # set by conv_pair: the integer conv output of the reduce_conv consuming this activation (its statistics pass already ran)
         self.sum_observed = False  # the residual add consuming this activation already had its range pass (fused into this layer's emit)
         self.cat_done = None       # the cat consuming this (squeeze) activation was already written by frost_sq_emit_cat: Engine.cat returns it
+        self.add_bwd = None        # backward: (gradient of the add's output, other operand, the add's record, ga, accumulate) -- the add's backward is folded into this activation's producer
 
     @property
     def npix(self):
@@ -542,7 +555,10 @@ class Engine:
     def _converted_coef(self, l, qx, fb):
         """Requantisation coefficients of a converted conv (integer bias at scale s_x * s_w, multiplier s_x * s_w / s_y): functions of records that are
         frozen after convert(), so they are computed ONCE per (layer, input record) -- not per forward (70 launches of a few microseconds each)."""
-        key = (qx.data_ptr(), bool(fb))
+        # (the key carries torch's version counters of everything the coefficients are computed from: load_state_dict / in-place edits of the records -- all rows
+        # of the qrecord arena share one counter -- or of the BatchNorm tensors of a converted model invalidate it.  A hipGraph captured AFTER an eager forward
+        # holds no finalize launch: re-capture after such an edit)
+        key = (qx.data_ptr(), bool(fb), qx._version, l.qy._version) + tuple(t._version for t in (l.gamma, l.beta, l.rmean, l.rvar, l.bias) if t is not None)
         if getattr(l, "_cfin_key", None) == key:
             return
         if fb:
@@ -595,7 +611,10 @@ class Engine:
             self._side = self._wg_stream
             self._side.wait_stream(torch.cuda.current_stream())          # after the dwq arena fill
             self._keep = []
-        for entry in reversed(self.tape):
+            self._forks = 0
+            self._deferred = []
+        rtape = list(reversed(self.tape))
+        for ti, entry in enumerate(rtape):
             kind = entry[0]
             if kind == "head":
                 _, l, x, pooled, raw, drop = entry
@@ -634,11 +653,21 @@ class Engine:
                 y.grad = None
             elif kind == "add":
                 _, a, b, y = entry
-                ga, fa = self._grad_slot(a)
-                gb, fb = self._grad_slot(b)
-                call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
-                     fa, ptr(gb), fb, stream(), prof=("add_bwd", 8 * a.numel))
+                nxt = rtape[ti + 1] if ti + 1 < len(rtape) else None
+                if (_ADD_BWD_FUSE and b.grad is None and getattr(b, "cint", None) is not None and nxt is not None and nxt[0] == "conv" and nxt[3] is b
+                        and self._ew_backward(nxt[1], nxt[2])):
+                    # the next tape entry is the reduce_conv that produced b, and its backward runs element-wise over its kept integer conv output: those two
+                    # passes apply the add's STE window themselves (frost_pw_ew_add_bwd) -- nothing is launched here, b's gradient is never materialised
+                    ga, fa = self._grad_slot(a)
+                    b.add_bwd = (y.grad, a, y.q, ga, fa)
+                    b.grad = y.grad                       # (placeholder: the fused passes read the add's gradient)
+                else:
+                    ga, fa = self._grad_slot(a)
+                    gb, fb = self._grad_slot(b)
+                    call("frost_add_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), ptr(b.buf), ptr(b.q), a.numel, ptr(y.q), ptr(ga),
+                         fa, ptr(gb), fb, stream(), prof=("add_bwd", 8 * a.numel))
                 y.grad = None
+        self._flush_deferred_wgrads()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)          # join: every weight gradient is accumulated
             self._side = None
@@ -735,8 +764,21 @@ class Engine:
             self._gtables = {}
         self._dwq_arena.zero_()
 
+    def _flush_deferred_wgrads(self, fork=True):
+        """Launch the collected pointwise weight gradients of the low-resolution stages on the side stream behind one fork (`fork=False`: the caller forks right after)."""
+        todo, self._deferred = getattr(self, "_deferred", None) or [], []
+        if not todo or self._side is None:
+            return
+        ev = torch.cuda.Event()                    # (fork=False: the caller forks again right after -- these launches still need their own dependency on the main stream)
+        ev.record()
+        self._side.wait_event(ev)
+        sw = C.c_void_p(self._side.cuda_stream)
+        for dc, x, l, ynum in todo:
+            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw, prof=("pw_wgrad", 2 * ynum + x.numel))
+
     def _close_bucket(self, index, on_bucket):
         """Every layer of gradient bucket `index` has run its backward: join the weight-gradient stream, finalize, notify."""
+        self._flush_deferred_wgrads()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._keep = []
@@ -773,10 +815,20 @@ class Engine:
             if p is not None and p.grad is None:
                 p.grad = torch.zeros_like(p)
 
+    def _ew_backward(self, l, x):
+        """True iff this layer's backward runs its reduce / dc passes element-wise over the kept integer conv output (the rule of _conv_backward)."""
+        fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
+        return bool(_PW_KEEP and not fused and l.kind == "pw" and x.c > 256 and l.cout < x.c and not getattr(l, "frozen", False))
+
     def _conv_backward(self, l, x, y):
         self._ensure_grad(l)
         gout = y.grad
         s = stream()
+        if getattr(self, "_deferred", None) and x.h > _WG_DEFER:
+            self._flush_deferred_wgrads()
+        if _WG_JOIN and self._side is not None and getattr(self, "_forks", 0) >= _WG_JOIN:
+            torch.cuda.current_stream().wait_stream(self._side)      # short side branches: the weight gradients forked so far must be done before this layer starts
+            self._forks = 0
         fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)
                   and bool(L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)))      # dc stays in LDS there: no buffer
@@ -798,8 +850,13 @@ class Engine:
                     call("frost_pw_conv_int", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(cint), s,
                          prof=("pw_bwd_reduce", x.numel + 4 * y.numel))
                 y.cint = None
-                call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 0, ptr(gout), None, s,
-                     prof=("pw_bwd_reduce", 6 * y.numel))
+                ab = getattr(y, "add_bwd", None)
+                if ab is not None:          # + skip_add's backward: g = the add's gradient inside the add's STE window; the residual branch's gradient leaves here
+                    call("frost_pw_ew_add_bwd", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 0, ptr(ab[0]), ptr(ab[1].buf), ptr(ab[1].q), ptr(y.buf),
+                         ptr(ab[2]), ptr(ab[3]), ab[4], None, s, prof=("pw_bwd_reduce", 10 * y.numel))
+                else:
+                    call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 0, ptr(gout), None, s,
+                         prof=("pw_bwd_reduce", 6 * y.numel))
             else:
                 # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
                 pwc = (not fused) and l.kind == "pw" and bool(L.load_library().frost_pwc_bwd_ok(x.npix, x.c, l.cout))      # wide layers: chunked kernel, full-line gout / dc I/O
@@ -821,7 +878,12 @@ class Engine:
                 self._after_conv_backward(l, s)
                 y.grad = None
                 return
-            if cint is not None:
+            if cint is not None and getattr(y, "add_bwd", None) is not None:
+                ab = y.add_bwd
+                call("frost_pw_ew_add_bwd", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 1, ptr(ab[0]), ptr(ab[1].buf), ptr(ab[1].q), ptr(y.buf),
+                     ptr(ab[2]), None, 0, ptr(dc), s, prof=("pw_bwd_dc", 10 * y.numel))
+                y.add_bwd = None
+            elif cint is not None:
                 call("frost_pw_ew", ptr(cint), x.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), 1, ptr(gout), ptr(dc), s,
                      prof=("pw_bwd_dc", 8 * y.numel))
             elif pwc:
@@ -830,10 +892,13 @@ class Engine:
             else:
                 call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                      prof=("pw_bwd_dc", x.numel + 4 * y.numel))
-            if self._side is not None and (_WG_STREAM & 1):      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
+            defer_wg = bool(_WG_DEFER and self._side is not None and (_WG_STREAM & 1) and l.kind == "pw" and x.h <= _WG_DEFER)
+            if self._side is not None and (_WG_STREAM & 1) and not defer_wg:      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
+                self._flush_deferred_wgrads(fork=False)
                 ev = torch.cuda.Event()
                 ev.record()
                 self._side.wait_event(ev)
+                self._forks = getattr(self, "_forks", 0) + 1
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
                 if l.kind == "pw" and L.load_library().frost_pw_dgrad_wide_ok(x.npix, x.c, l.cout):
@@ -847,8 +912,11 @@ class Engine:
             if self._side is not None and (_WG_STREAM & 1):      # dc (and x) stay referenced until the join
                 self._keep.append((dc, x.buf))
                 sw = C.c_void_p(self._side.cuda_stream)
-            call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw,
-                 prof=("pw_wgrad", 2 * y.numel + x.numel))
+            if defer_wg:
+                self._deferred.append((dc, x, l, y.numel))
+            else:
+                call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw,
+                     prof=("pw_wgrad", 2 * y.numel + x.numel))
             if l.kind == "stem":
                 l.dwq = dwq_final
                 call("frost_stem_wgrad_remap", ptr(l.dwq_col), l.cout, l.cin_g, ptr(l.dwq), sw)

@@ -316,6 +316,27 @@ class _FrostBase(_FlagNotify):
         return r
 
 
+    def hip_convert(self):
+        """Device counterpart of `torch.quantization.convert(model.eval(), inplace=True)` (Classification/evaluate.py:130): the QAT-prepared
+        model on the HIP device switches to converted int8 inference semantics (frostnet_amd.runner.FrostRunner.convert)."""
+        if not self._is_qat_prepared():
+            raise RuntimeError("hip_convert needs the QAT-prepared model (fuse_model + prepare_qat), like torch.quantization.convert")
+        self.eval()
+        self.hip_runner().convert()
+        # marks the module tree: if the runner holding the frozen int8 weights is ever lost (model.to(), a moved parameter, a deepcopy / pickle of the
+        # model -- __getstate__ keeps this flag and drops the runner), hip_runner() raises on every call instead of running the fake-quant eval graph
+        self.__dict__["_hip_converted"] = True
+        return self
+
+    def hip_export_converted(self):
+        """`model.state_dict()` of the converted model (Classification/evaluate.py:140-143 saves exactly that as `quantized_<name>.pth`): a mapping that the
+        stock-torch CPU model `torch.quantization.convert(<the same QAT-prepared architecture>.eval())` loads with load_state_dict(strict=True) and that
+        then computes, on the QNNPACK / FBGEMM CPU engine, the logits (maps) the device computes.  frostnet_amd.runner.FrostRunner.export_converted."""
+        if not self.__dict__.get("_hip_converted", False):
+            raise RuntimeError("hip_export_converted: call hip_convert() first")
+        return self.hip_runner().export_converted()
+
+
 class FrostNet(_FrostBase):
     def __init__(self, nclass=1000, mode='large', width_mult=1.0, quantized=False, bottleneck=CascadePreExBottleneck,
                  drop_rate=0.2, dilated=False, act='relu', **kwargs):
@@ -344,18 +365,6 @@ class FrostNet(_FrostBase):
         if self.quantized:
             self.quant = torch.quantization.QuantStub()
             self.dequant = torch.quantization.DeQuantStub()
-
-    def hip_convert(self):
-        """Device counterpart of `torch.quantization.convert(model.eval(), inplace=True)` (Classification/evaluate.py:130): the QAT-prepared
-        model on the HIP device switches to converted int8 inference semantics (frostnet_amd.runner.FrostRunner.convert)."""
-        if not self._is_qat_prepared():
-            raise RuntimeError("hip_convert needs the QAT-prepared model (fuse_model + prepare_qat), like torch.quantization.convert")
-        self.eval()
-        self.hip_runner().convert()
-        # marks the module tree: if the runner holding the frozen int8 weights is ever lost (model.to(), a moved parameter, a deepcopy / pickle of the
-        # model -- __getstate__ keeps this flag and drops the runner), hip_runner() raises on every call instead of running the fake-quant eval graph
-        self.__dict__["_hip_converted"] = True
-        return self
 
     def hip_infer_bf16(self, x):
         """bf16 inference of the float (un-fused, not QAT-prepared) model on the HIP kernels (BASELINE.json config c2):

@@ -128,13 +128,17 @@ class Bf16Inference:
         (Classification/evaluate.py:131-143): the descriptor table follows re-assigned tensors (data pointers), the packs follow in-place updates (tensor
         version counters).  `refresh()` forces it (for writes the counters do not see, e.g. through a raw pointer)."""
         ts = [t for l in self.layers for t in (l.conv.weight, l.bn.weight, l.bn.bias, l.bn.running_mean, l.bn.running_var)]
-        ptrs, versions = [t.data_ptr() for t in ts], [t._version for t in ts]
+        # + the generation of raw-pointer writers (the HIP optimizer step and the training forwards update parameters / running statistics behind torch's back);
+        # once such a writer sits in a captured hipGraph its replays are invisible here: prepare on every call then
+        ptrs, versions = [t.data_ptr() for t in ts], [t._version for t in ts] + [L.RAW_WRITE_GEN]
+        if L.RAW_WRITES_CAPTURED:
+            versions = None
         if ptrs != self._ptrs:
             arr = (L.FrostIDesc * len(self.layers))()
             for i, l in enumerate(self.layers):
                 arr[i] = l.desc()
             self._table, self._ptrs, self._versions = L.struct_to_tensor(arr, self.device), ptrs, None
-        if versions != self._versions:
+        if versions is None or versions != self._versions:
             call("frost_infer_weight_prep", ptr(self._table), len(self.layers), stream())
             self._versions = versions
 

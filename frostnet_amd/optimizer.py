@@ -53,6 +53,11 @@ def get_optimizer(optim, params_set, args):
     raise ValueError(f"unknown optimizer {optim}")
 
 
+def _upload(dst, host):
+    """Stream-ordered host -> device copy that does not block the host (pinned staging, see prepare_step)."""
+    dst.copy_(host.pin_memory(), non_blocking=True)
+
+
 class _GradBoost(Optimizer):
     KIND = None
     STATE = ()          # (state key, table slot) for buf0..buf2
@@ -169,14 +174,17 @@ class _GradBoost(Optimizer):
         h = self._hyper(group0, step, rstep, boost)
         # Philox stream position = the step count (part of state_dict): a resumed run continues the noise stream instead of replaying it
         h.seed, h.offset = self._seed, step
-        plan["hyper"].copy_(torch.frombuffer(bytearray(bytes(memoryview(h).cast("B"))), dtype=torch.uint8), non_blocking=False)
+        # uploads go through PINNED staging tensors with non_blocking copies: a copy from pageable memory blocks the host until the stream has drained, so the
+        # host could never run ahead of the device and every step exposed the launch latency of the captured step (a 135 us idle gap per replay in
+        # profiles/r05_replay_nodes_before.txt).  torch's pinned allocator keeps a staging block alive until the copy that reads it has executed.
+        _upload(plan["hyper"], torch.frombuffer(bytearray(bytes(memoryview(h).cast("B"))), dtype=torch.uint8))
         lrs = [g["lr"] for _, g in items]
         wds = [g["weight_decay"] for _, g in items]
         if plan["lr_host"] != lrs:
-            plan["words"][:, _T_LR] = torch.tensor(lrs, dtype=torch.float32).view(torch.int32).to(plan["words"].device)
+            _upload(plan["words"][:, _T_LR], torch.tensor(lrs, dtype=torch.float32).view(torch.int32))
             plan["lr_host"] = lrs
         if plan["wd_host"] != wds:
-            plan["words"][:, _T_WD] = torch.tensor(wds, dtype=torch.float32).view(torch.int32).to(plan["words"].device)
+            _upload(plan["words"][:, _T_WD], torch.tensor(wds, dtype=torch.float32).view(torch.int32))
             plan["wd_host"] = wds
         first = 1 if (self._needs_first_flag(group0) and step == 1) else 0
         if plan.get("first") != first:
@@ -193,6 +201,7 @@ class _GradBoost(Optimizer):
         if self._inject is not None:
             noise, coin = self._inject
             self._inject = None
+        L.note_raw_write()          # parameters change through raw pointers: version-keyed caches must not trust torch's counters
         call("frost_gradboost_step", ptr(plan["table"]), len(plan["items"]), plan["max_n"], ptr(plan["hyper"]),
              ptr(noise), ptr(coin), ptr(plan["prefix"]), stream())
 

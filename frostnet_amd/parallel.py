@@ -62,27 +62,44 @@ def broadcast_model(model, src=0, group=None):
 
 
 def plan_buckets(runner, nbuckets=4):
-    """Cut the gradient arena into `nbuckets` contiguous buckets along LAYER boundaries, in the order the backward pass
-    completes them (classifier first, stem last).  Returns [(layer, lo, hi)]: once `layer` has run its backward every gradient
-    in arena[lo:hi] is final.  FrostNet's parameters sit at the deep end (classifier 1.28 M + last_layer 0.41 M + layer5 1.1 M of
-    5.8 M), its backward *time* at the shallow end, so the first buckets carry most of the bytes and travel under almost the whole
-    backward pass; the last bucket is a few hundred KB."""
+    """Cut the gradient arena into `nbuckets` buckets along LAYER boundaries, in the order the backward pass completes them (for the
+    classifier: classifier first, stem last; for the SSDLite detector: prediction heads, extras, then the backbone from layer5 down).
+    Returns [(layer, ranges)]: once `layer` has run its backward every gradient in the arena ranges [(lo, hi), ...] is final.  A bucket
+    is ONE contiguous range wherever the parameter order follows the layer order (the whole classification network; the backbone and
+    the extras of the detector) and a few ranges where it does not (the detector registers `loc` and `conf` as two ModuleLists while
+    the backward visits loc_i / conf_i interleaved).  FrostNet's parameters sit at the deep end (classifier 1.28 M + last_layer 0.41 M +
+    layer5 1.1 M of 5.8 M), its backward *time* at the shallow end, so the first buckets carry most of the bytes and travel under almost
+    the whole backward pass; the last bucket is a few hundred KB."""
     offs, off = {}, 0
     for p in runner._params:
-        offs[p.data_ptr()] = off
+        offs[p.data_ptr()] = (off, off + p.numel())
         off += p.numel()
     total = off
-    layers = [l for l in runner.E.layers]                    # forward order
-    cuts, hi, k = [], total, 1
+    layers = [l for l in runner.E.layers]                    # forward order = reverse of the order the backward finishes them
+    cuts, pend, done, k = [], [], 0, 1
     for l in reversed(layers):
-        lo = offs[l.w.data_ptr()]
-        if l is layers[0] or (total - lo) >= total * k / nbuckets:
-            cuts.append((l, lo, hi))
-            hi = lo
-            while (total - lo) >= total * k / nbuckets:
+        for t in (l.w, l.gamma, l.beta, l.bias):
+            if t is not None:
+                pend.append(offs[t.data_ptr()])
+                done += t.numel()
+        if l is layers[0] or done >= total * k / nbuckets:
+            cuts.append((l, _coalesce(pend)))
+            pend = []
+            while done >= total * k / nbuckets:
                 k += 1
-    assert cuts[-1][1] == 0 and sum(h - l for _, l, h in cuts) == total
+    covered = _coalesce([r for _, rs in cuts for r in rs])
+    assert covered == [(0, total)], f"gradient buckets do not tile the arena: {covered} vs {total}"
     return cuts
+
+
+def _coalesce(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out
 
 
 class SegmentedStep:
@@ -91,30 +108,53 @@ class SegmentedStep:
     being reduced over xGMI on RCCL's stream.  The collective itself is never captured (plain torch.distributed launch), so
     the N-GPU path needs nothing from RCCL beyond what eager training uses.
 
-    replaces: nn.DataParallel's gather / ReduceAddCoalesced (Classification/train.py:88-92), timm DDP's bucketed overlap
-    (training_commands.txt).  The local loss is divided by the world size before the backward pass, so the SUM all-reduce
-    yields the mean gradient with no extra pass over the arena (exact: gradients are linear in dlogits)."""
+    replaces: nn.DataParallel's gather / ReduceAddCoalesced (Classification/train.py:88-92, Object_Detection/qtrainval.py:123-127), timm DDP's
+    bucketed overlap (training_commands.txt).  The gradient of the step loss w.r.t. the local loss is 1 / world, so the SUM all-reduce
+    yields the mean gradient with no extra pass over the arena (exact: gradients are linear in it).
 
-    def __init__(self, runner, criterion, nbuckets=4, group=None):
-        self.runner, self.crit, self.group = runner, criterion, group
+    Two step bodies: `criterion` (classification: logits -> criterion(logits, target)) or `maps_loss` (a model whose runner returns several
+    fake-quantised maps -- SSDRunner._maps_impl: maps_loss(list of dequantised fp32 maps, target) -> scalar loss; BASELINE.json config c5).
+    Either way torch autograd only differentiates the loss; the hand-written backward is called on THIS thread (segment captures must begin
+    and end on the thread that started them)."""
+
+    def __init__(self, runner, criterion=None, nbuckets=4, group=None, maps_loss=None):
+        assert (criterion is None) != (maps_loss is None), "SegmentedStep: give either a classification criterion or a maps_loss"
+        self.runner, self.crit, self.maps_loss, self.group = runner, criterion, maps_loss, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuts = plan_buckets(runner, nbuckets)
-        self.boundaries = {id(l): i for i, (l, _, _) in enumerate(self.cuts)}
+        self.boundaries = {id(l): i for i, (l, _) in enumerate(self.cuts)}
         self.graphs, self._handles, self.loss = None, [], None
+        self.gscale = torch.full((), 1.0 / self.world, dtype=torch.float32, device=runner.device)
 
-    # -- the step body: forward, loss, dlogits (torch autograd only for the cross-entropy), hand-written backward
+    def bucket_ranges(self):
+        """[(lo, hi), ...] per bucket, in the order the backward completes them."""
+        return [list(rs) for _, rs in self.cuts]
+
+    # -- the step body: forward, loss, gradient of the loss w.r.t. the network outputs (torch autograd only for the loss), hand-written backward
     def _body(self, x, target, on_bucket):
         r = self.runner
+        if self.maps_loss is not None:
+            from .engine import float_to_grad
+            acts = r._maps_impl(x, record=True)
+            leaves = [a.dequant().contiguous().requires_grad_(True) for a in acts]
+            loss = self.maps_loss(leaves, target)
+            loss.backward(gradient=self.gscale)
+            for a, t in zip(acts, leaves):
+                g = t.grad if t.grad is not None else torch.zeros_like(t)
+                a.grad = float_to_grad(g, fp32=r.E.grad_fp32)
+            r.bind_grads()
+            r.E.backward(None, boundaries=self.boundaries, on_bucket=on_bucket)
+            return loss.detach()
         logits = r._forward_impl(x, record=True).detach().requires_grad_(True)
         loss = self.crit(logits, target)
-        (loss / self.world).backward()
+        loss.backward(gradient=self.gscale)
         r.bind_grads()
         r.E.backward(logits.grad, boundaries=self.boundaries, on_bucket=on_bucket)
         return loss.detach()
 
     def _reduce(self, i):
-        _, lo, hi = self.cuts[i]
-        self._handles.append(dist.all_reduce(self.runner.grad_arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for lo, hi in self.cuts[i][1]:
+            self._handles.append(dist.all_reduce(self.runner.grad_arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for h in self._handles:

@@ -89,17 +89,23 @@ def rng_state(runner):
     return {"seed": int(runner._drop_seed), "draws": int(runner._drop_ctr[0].item())}
 
 
-def set_rng_state(runner, state):
+def set_rng_state(runner, state, discard_captured=False):
     """Restore the dropout stream.  The draw counter is written IN PLACE: a hipGraph captured earlier holds the counter's address and keeps drawing from
-    the restored position (a replaced tensor would leave the graph advancing the old one)."""
+    the restored position (a replaced tensor would leave the graph advancing the old one).  The seed is a launch argument baked into a captured graph:
+    restoring a DIFFERENT seed while such a graph exists raises before anything is changed (no partial restore); `discard_captured=True` says the
+    caller drops that graph and re-captures the step (the mark is cleared; the next capture bakes the new seed)."""
+    seed = int(state["seed"]) & 0xFFFFFFFFFFFFFFFF
+    if discard_captured:
+        runner._drop_captured = False
+    if getattr(runner, "_drop_seed", None) is not None and int(runner._drop_seed) != seed and getattr(runner, "_drop_captured", False):
+        raise RuntimeError("set_rng_state: the dropout seed is a launch argument baked into the captured hipGraph; drop that graph, call "
+                           "set_rng_state(state, discard_captured=True) and re-capture the step to restore a different seed")
     new = torch.tensor([int(state["draws"]), 0], dtype=torch.int64, device=runner.device)
     if getattr(runner, "_drop_ctr", None) is None:
         runner._drop_ctr = new
     else:
         runner._drop_ctr.copy_(new)
-    if getattr(runner, "_drop_seed", None) is not None and int(runner._drop_seed) != (int(state["seed"]) & 0xFFFFFFFFFFFFFFFF) and getattr(runner, "_drop_captured", False):
-        raise RuntimeError("set_rng_state: the dropout seed is a launch argument baked into the captured hipGraph; re-capture the step after restoring a different seed")
-    runner._drop_seed = int(state["seed"]) & 0xFFFFFFFFFFFFFFFF
+    runner._drop_seed = seed
 
 
 def _is_fused_fq(fq):
@@ -267,6 +273,7 @@ class FrostRunner:
         if pc:
             self._bind_weight_per_channel(m.weight_fake_quant, qw, l)
         l.bn_mod = m.bn
+        l.qmod = m                # the QAT module this layer executes (export_converted walks the module tree)
         l.hswish = None
         act = getattr(blk, "act", None)
         if act is not None and type(act).__name__ == "Hswish":
@@ -345,6 +352,7 @@ class FrostRunner:
                                                   1, 1, False, qw, qy))
             if pc:
                 self._bind_weight_per_channel(c.weight_fake_quant, qw, self.cls)
+            self.cls.qmod = c
             self.drop_rate = float(m.classifier[1].p)
         self._bind_extra()
         self.E.rule127 = 1 if self.rule127 else 0
@@ -415,8 +423,6 @@ class FrostRunner:
         pooled features are not re-quantised; the two differ by 8-25 % of the activations' indices, see tests/test_gpu_convert.py)."""
         if getattr(self, "converted", False):
             return self                          # idempotent: a second convert() must not move the weight observers again
-        if self.cls is None:
-            raise NotImplementedError("convert() is implemented for the classification model")
         if any(getattr(l, "hswish", None) is not None for l in self.E.layers):
             raise NotImplementedError("convert() of a hard-swish network: the converted-inference kernels restate the QNNPACK ReLU graph; the "
                                       "hard-swish variant runs the fake-quant graph (train / eval)")
@@ -434,7 +440,8 @@ class FrostRunner:
         self.converted = True
         return self
 
-    def _forward_converted(self, x, taps=None):
+    def _trunk_converted(self, x, taps=None):
+        """QuantStub + stem + every bottleneck of the converted model; returns (last activation, [block outputs])."""
         E, fb = self.E, getattr(self, "converted_fb", False)
         if x.dtype != torch.float32:
             x = x.float()
@@ -442,6 +449,7 @@ class FrostRunner:
         if a is None:
             a = E.quantize_input(x, self.q_in, observe=False)
             a = E.conv_converted(self.stem, a, fb)
+        feats = []
         for d in self.blocks:
             inp, out = a, a
             if d["conv1"] is not None:
@@ -456,12 +464,77 @@ class FrostRunner:
                 # QNNPACK: integer fixed-point q8add; FBGEMM: dequantise, add in fp32, quantise -- the fake-quant graph's own add arithmetic
                 out = E.add(inp, out, d["q_add"], observe=False) if fb else E.add_converted(inp, out, d["q_add"])
             a = out
+            feats.append(a)
             if taps is not None:
                 taps.append(a)
-        a = E.conv_converted(self.last, a, fb)
-        logits = E.head_converted(self.cls, a, fb)
-        E.tape = []
+        return a, feats
+
+    def _stage_ends(self, feats):
+        ends, i = [], 0
+        for lname in ("layer1", "layer2", "layer3", "layer4", "layer5"):
+            i += len(getattr(self.model, lname))
+            ends.append(feats[i - 1])
+        return ends
+
+    def _forward_converted(self, x, taps=None):
+        a, _ = self._trunk_converted(x, taps)
+        fb = getattr(self, "converted_fb", False)
+        a = self.E.conv_converted(self.last, a, fb)
+        logits = self.E.head_converted(self.cls, a, fb)
+        self.E.tape = []
         return logits
+
+    def _features_converted(self, x):
+        """The converted features backbone (frostnet_features.py:350: [x1, x2, x3, x5], DeQuantStub on each)."""
+        _, feats = self._trunk_converted(x)
+        ends = self._stage_ends(feats)
+        self.E.tape = []
+        return [ends[0], ends[1], ends[2], ends[4]]
+
+    def export_converted(self):
+        """The state_dict of `torch.quantization.convert(model.eval())` (what Classification/evaluate.py:140-143 and Object_Detection/qeval_convert.py save as the
+        deployment artefact), assembled from the device state of the converted model: per quantized conv `weight` (the int8 values the device convolves with --
+        frost_export_wq -- as a qint8 per-tensor / per-channel quantized tensor), `bias` (fuse_conv_bn_weights' fp32 expression, evaluated with torch on the
+        host), `scale` / `zero_point` (the layer's output record); `scale` / `zero_point` of the QuantStub and of every FloatFunctional.  Keys, shapes and
+        dtypes are those of stock torch, so the CPU model `torch.quantization.convert(prepare_qat(fuse_model(FrostNet(...))).eval())` loads it with
+        load_state_dict(strict=True) and computes the device's logits bit for bit (tests/test_gpu_convert.py)."""
+        from collections import OrderedDict
+        if not getattr(self, "converted", False):
+            raise RuntimeError("export_converted: call hip_convert() first (torch.quantization.convert precedes state_dict() in the reference)")
+        E = self.E
+        E._ensure_tables()
+        by_mod = {id(l.qmod): (i, l) for i, l in enumerate(E.layers) if getattr(l, "qmod", None) is not None}
+        sd = OrderedDict()
+
+        def qparams(fq, shape):
+            sc = fq.scale.detach().float().reshape(-1)[:1].cpu()
+            zp = fq.zero_point.detach().reshape(-1)[:1].to(torch.int64).cpu()
+            return sc.reshape(shape).clone(), zp.reshape(shape).clone()
+        with torch.cuda.device(self.device):
+            for name, mod in self.model.named_modules():
+                pre = name + "." if name else ""
+                if id(mod) in by_mod:
+                    i, l = by_mod[id(mod)]
+                    n = l.cout * l.cin_g * l.kk
+                    q8 = torch.empty(n, dtype=torch.int8, device=self.device)
+                    L.call("frost_export_wq", L.ptr(E._table), i, n, L.ptr(q8), L.stream())
+                    q8 = q8.cpu().view(l.cout, l.cin_g, l.k, l.k)
+                    if l.per_channel:
+                        w = torch._make_per_channel_quantized_tensor(q8, l.wscale[: l.cout].detach().double().cpu(), torch.zeros(l.cout, dtype=torch.int64), 0)
+                    else:
+                        w = torch._make_per_tensor_quantized_tensor(q8, float(l.qw[L.Q_SCALE]), 0)
+                    sd[pre + "weight"] = w
+                    if l.gamma is not None:             # torch.nn.utils.fusion.fuse_conv_bn_weights with conv bias None (nniqat.ConvBn2d.to_float)
+                        g, b, rm, rv = (t.detach().float().cpu() for t in (l.gamma, l.beta, l.rmean, l.rvar))
+                        sd[pre + "bias"] = (torch.zeros_like(rm) - rm) * torch.rsqrt(rv + l.bn_mod.eps) * g + b
+                    else:
+                        sd[pre + "bias"] = l.bias.detach().float().cpu().clone()
+                    sd[pre + "scale"], sd[pre + "zero_point"] = qparams(mod.activation_post_process, ())
+                elif isinstance(mod, torch.ao.quantization.QuantStub) and hasattr(mod, "activation_post_process"):
+                    sd[pre + "scale"], sd[pre + "zero_point"] = qparams(mod.activation_post_process, (1,))
+                elif type(mod).__name__ == "FloatFunctional" and hasattr(mod.activation_post_process, "scale"):
+                    sd[pre + "scale"], sd[pre + "zero_point"] = qparams(mod.activation_post_process, ())
+        return sd
 
     def _check_input(self, x):
         if x.device != self.device:
@@ -520,6 +593,11 @@ class FrostRunner:
 
     def forward_features(self, x):
         self._check_input(x)
+        if getattr(self, "converted", False):
+            if self.model.training:
+                raise RuntimeError("this model was converted to int8 inference (hip_convert): it cannot be trained; rebuild the QAT model")
+            with torch.cuda.device(self.device):
+                return [a.dequant().contiguous() for a in self._features_converted(x)]
         with torch.cuda.device(self.device):
             if self.model.training and torch.is_grad_enabled():
                 return list(_QATFeatFunction.apply(self._params[0], x, self))
@@ -600,8 +678,30 @@ class SSDRunner(FrostRunner):
             self.heads.append((self._conv_layer(f"loc.{i}.dw", l.dw, "dw"), self._conv_layer(f"loc.{i}.pw", l.pw, "pw"),
                                self._conv_layer(f"conf.{i}.dw", c.dw, "dw"), self._conv_layer(f"conf.{i}.pw", c.pw, "pw")))
 
+    def _maps_converted(self, x):
+        """The converted detector (Object_Detection/qeval_convert.py: torch.quantization.convert of the QAT SSD): backbone, extras and the separable
+        prediction heads as quantized convs with the requantisation epilogue; twelve maps."""
+        E, fb = self.E, getattr(self, "converted_fb", False)
+        a, feats = self._trunk_converted(x)
+        ends = self._stage_ends(feats)
+        sources = [ends[1], ends[2], ends[4]]
+        for pw1, dw, pw2 in self.extras:
+            a = E.conv_converted(pw2, E.conv_converted(dw, E.conv_converted(pw1, a, fb), fb), fb)
+            sources.append(a)
+        maps = []
+        for s, (ldw, lpw, cdw, cpw) in zip(sources, self.heads):
+            maps.append(E.conv_converted(lpw, E.conv_converted(ldw, s, fb), fb))
+            maps.append(E.conv_converted(cpw, E.conv_converted(cdw, s, fb), fb))
+        E.tape = []
+        return maps
+
     def forward_maps(self, x):
         self._check_input(x)
+        if getattr(self, "converted", False):
+            if self.model.training:
+                raise RuntimeError("this model was converted to int8 inference (hip_convert): it cannot be trained; rebuild the QAT model")
+            with torch.cuda.device(self.device):
+                return [a.dequant().contiguous() for a in self._maps_converted(x)]
         with torch.cuda.device(self.device):
             if self.model.training and torch.is_grad_enabled():
                 return list(_QATMapsFunction.apply(self._params[0], x, self))

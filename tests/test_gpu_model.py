@@ -162,6 +162,8 @@ def test_g4_block_true_shapes(fa, golden, name):
             assert ("frost_block_expand_dw_stats" in log) or ("frost_block_dw_stats" in log), log
             assert "frost_block_dw_reduce" in log and "frost_block_dw_bwd" in log and "frost_block_dw_bwd_reduce" in log, log
             assert "frost_dw_conv_fwd" not in log and "frost_dw_dgrad" not in log, log
+            if cin == cout and s == 1:        # residual block: skip_add's backward rides in the reduce_conv's element-wise passes (no stand-alone launch)
+                assert log.count("frost_pw_ew_add_bwd") == 2 and "frost_add_bwd" not in log, log
         d = (yidx.to(torch.int16) - T(g[f"s{step}_yidx"]).to(torch.int16)).abs()
         flips = float((d > 0).float().mean())
         assert int(d.max()) <= 2 and flips <= 2e-3, (name, step, int(d.max()), flips)
