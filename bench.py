@@ -110,6 +110,58 @@ def pmc_step_traffic(batch):
     return int(tot), round(n, 1), path
 
 
+def graph_census(graphs):
+    """Node count of the captured step, read from the hipGraph objects themselves (hipGraphGetNodes / hipGraphNodeGetType / hipGraphKernelNodeGetParams +
+    hipKernelNameRefByPtr): total nodes, kernel nodes split into this library's (k_* / frost_*) and everything else (aten element-wise kernels), memset and
+    memcpy nodes.  `graphs`: torch.cuda.CUDAGraph objects captured with keep_graph=True.  None if the runtime does not expose the graph."""
+    import ctypes as C
+    try:
+        hip = C.CDLL("libamdhip64.so")
+
+        class Dim3(C.Structure):
+            _fields_ = [("x", C.c_uint), ("y", C.c_uint), ("z", C.c_uint)]
+
+        class KParams(C.Structure):
+            _fields_ = [("blockDim", Dim3), ("extra", C.c_void_p), ("func", C.c_void_p), ("gridDim", Dim3), ("kernelParams", C.c_void_p), ("sharedMemBytes", C.c_uint)]
+        hip.hipKernelNameRefByPtr.restype = C.c_char_p
+        hip.hipKernelNameRefByPtr.argtypes = [C.c_void_p, C.c_void_p]
+        out = dict(nodes_total=0, kernels_own=0, kernels_other=0, memset=0, memcpy=0, other_nodes=0, other_kernel_names={})
+        for g in graphs:
+            raw = C.c_void_p(g.raw_cuda_graph())
+            n = C.c_size_t(0)
+            if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+                return None
+            nodes = (C.c_void_p * n.value)()
+            if hip.hipGraphGetNodes(raw, nodes, C.byref(n)) != 0:
+                return None
+            for nd in nodes:
+                t = C.c_int(-1)
+                hip.hipGraphNodeGetType(C.c_void_p(nd), C.byref(t))
+                out["nodes_total"] += 1
+                if t.value == 0:
+                    kp = KParams()
+                    name = b""
+                    if hip.hipGraphKernelNodeGetParams(C.c_void_p(nd), C.byref(kp)) == 0 and kp.func:
+                        name = hip.hipKernelNameRefByPtr(kp.func, None) or b""
+                    nm = name.decode(errors="replace")
+                    import re
+                    if re.match(r"^(_Z\d+)?(k_|frost_)", nm):      # this library's kernels are global-namespace k_* (mangled: _Z<len>k_...)
+                        out["kernels_own"] += 1
+                    else:
+                        out["kernels_other"] += 1
+                        key = nm[:60] or "?"
+                        out["other_kernel_names"][key] = out["other_kernel_names"].get(key, 0) + 1
+                elif t.value == 1:
+                    out["memcpy"] += 1
+                elif t.value == 2:
+                    out["memset"] += 1
+                else:
+                    out["other_nodes"] += 1
+        return out
+    except Exception as e:  # pragma: no cover
+        return dict(error=f"{type(e).__name__}: {e}")
+
+
 def side_workload(args, dev):
     """The two other device workloads, same timing protocol, single GPU: `infer` = BASELINE.json config c2 (float model, bf16 inference,
     B = 256 by default), `float` = the StatAssist warm-up training step (float model, forward + backward + QSGD step, is_warmup)."""
@@ -540,12 +592,13 @@ def main():
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     plan = opt.prepare_step()
-                    graph = torch.cuda.CUDAGraph()
+                    graph = torch.cuda.CUDAGraph(keep_graph=True)       # the hipGraph stays queryable (graph_census); instantiated below
                     # RCCL's watchdog thread polls events concurrently: restrict the capture check to this thread when a process group exists
                     with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local" if dp else "global"):
                         fwd_bwd()
                         if not dp:
                             opt.launch(plan)
+                    graph.instantiate()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
         except Exception as e:  # pragma: no cover
@@ -694,6 +747,8 @@ def main():
                         traffic_total_bytes_per_step=step_traffic, algorithmic_bytes_per_step=algo_step,
                         traffic_ratio=(round(step_traffic / algo_step, 3) if step_traffic else None),
                         kernel_launches_per_step=step_launches, algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG,
+                        # the captured step itself, node by node (read back from the hipGraph): own kernels / aten kernels / memset / memcpy
+                        graph_nodes=(graph_census([graph]) if (graph is not None and seg is None and not isinstance(graph, list)) else None),
                         dominant_kernel=dict(kernel=dom, achieved=round(achieved, 1), unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                                              traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(s2["avg_ms"], 4),
                                              launches_per_step=s2["launches"] // 3, algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),

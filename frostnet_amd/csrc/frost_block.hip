@@ -1371,3 +1371,170 @@ extern "C" int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int
   else hipLaunchKernelGGL(k_sq_emit_cat<3>, grid, dim3(256), lds, s, p);
   return frost_check_launch("sq_emit_cat");
 }
+
+// ================================================================================================ cat backward + squeeze_conv reduce pass in one launch
+// Backward sibling of k_sq_emit_cat: quant_cat's backward (frostnet.py:129; k_cat_bwd8: the gradient of the concatenated tensor passes where the cat's FakeQuantize
+// kept the requantised operand in range, into the squeeze_conv output's gradient ga and, accumulated, into the block input's gradient gb) TOGETHER with the
+// squeeze_conv's backward reduce pass (k_pw<M_BRED>: S1 += gy, S2 += gy * xhat over the STE window of its own output FakeQuantize) from ONE staged x tile:
+// the squeeze conv is recomputed on the int8 MFMA (as every backward pass of this design does), its output index -- the cat's first operand -- is re-derived from
+// the accumulator with the emit expression instead of being re-read.  ga is still written (the dc pass reads it as gout).  One launch less per CAS bottleneck;
+// same expressions as frost_cat_bwd + frost_pw_conv_bwd(mode 0), sums in a different order.
+struct SqBwdP {
+  const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum; float* coef; const float* qsq; const float* qcat;
+  const uint16_t* gcat; uint16_t* ga; uint16_t* gb; int acc_a, acc_b;
+  int64_t npix, ntiles; int cin, r, cpad, kstr, relu;
+};
+__device__ __forceinline__ void sqb_store4(uint16_t* dst, const float* v, int accumulate) {
+  float o[4] = {v[0], v[1], v[2], v[3]};
+  if (accumulate) { const uint2 t = *(const uint2*)dst; o[0] += bf2f(t.x & 0xffff); o[1] += bf2f(t.x >> 16); o[2] += bf2f(t.y & 0xffff); o[3] += bf2f(t.y >> 16); }
+  uint2 wv; wv.x = cvt_pk_bf16(o[0], o[1]); wv.y = cvt_pk_bf16(o[2], o[3]);
+  *(uint2*)dst = wv;
+}
+template <int KSM, int CTM>
+__global__ __launch_bounds__(256) void k_sq_bwd_cat(const SqBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                          // [128][kstr]
+  uint8_t* const ok = smem + 128 * p.kstr;           // [2][256]: does the cat's FakeQuantize pass index i of the squeeze output / of the block input
+  float* const red = (float*)(ok + 512);             // [2][cpad]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  {
+    const QP A = load_qp(p.qsq), B = load_qp(p.qx), Y = load_qp(p.qcat);
+    const int q = (int)(int8_t)tid + 128; bool ia, ib;
+    fq_index((float)(q - A.zp) * A.scale, Y.inv, Y.zp, 0, Y.hi, &ia);
+    fq_index((float)(q - B.zp) * B.scale, Y.inv, Y.zp, 0, Y.hi, &ib);
+    ok[tid] = ia; ok[256 + tid] = ib;
+    for (int c = tid; c < 2 * p.cpad; c += 256) red[c] = 0.0f;
+  }
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  const int zps = __float_as_int(p.qsq[FROST_Q_ZP]), qhi = q_hi(p.qsq);
+  const float y_inv = 1.0f / p.qsq[FROST_Q_SCALE], y_zpf = (float)zps;
+  const float qcap = (float)qhi; const bool lowq = qcap < 255.0f;
+  float t_lo = 0.0f, t_hi;
+  {
+    const float hi0 = (float)qhi + 0.5f - (float)zps;                             // rint(hi0) ties to the even neighbour (k_pw's window)
+    t_hi = ((qhi - zps) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zps - 0.5f; t_lo = (zps & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+  const int cy = p.r + p.cin;
+  const int CT = p.cpad >> 4;
+  float s1[CTM][4], s2[CTM][4];
+#pragma unroll
+  for (int m = 0; m < CTM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[m][r] = 0.0f; s2[m][r] = 0.0f; }
+  for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int64_t p0 = tile * 128;
+    __syncthreads();
+    {
+      const int upr = p.cin >> 3; const int total = 128 * upr;
+      for (int u = tid; u < total; u += 256) {
+        const int row = u / upr, col = u - row * upr;
+        const int64_t px = p0 + row;
+        uint2 v = make_uint2(0, 0);
+        if (px < p.npix) v = *(const uint2*)(p.x + px * p.cin + col * 8);
+        *(uint2*)(xs + row * p.kstr + col * 8) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CTM; ++ct) {
+      if (ct >= CT) break;
+      const int ch = ct * 16 + 4 * g;
+      const bool chok = ch < p.r;
+      v4i afr[KSM];
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) afr[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+      const int4 ws = *(const int4*)(p.wsum + ch);
+      const float4 A4 = *(const float4*)(p.coef + FROST_COEF_A * p.cpad + ch), B4 = *(const float4*)(p.coef + FROST_COEF_B * p.cpad + ch);
+      const float4 M4 = *(const float4*)(p.coef + FROST_COEF_M * p.cpad + ch), R4 = *(const float4*)(p.coef + FROST_COEF_R * p.cpad + ch);
+      const float A[4] = {A4.x, A4.y, A4.z, A4.w}, B[4] = {B4.x, B4.y, B4.z, B4.w}, R[4] = {R4.x, R4.y, R4.z, R4.w};
+      const float MR[4] = {-M4.x * R4.x, -M4.y * R4.y, -M4.z * R4.z, -M4.w * R4.w};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = (wv * 2 + t) * 16 + j;
+        v4i acc = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w};
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+          const v4i bfr = *(const v4i*)(xs + row * p.kstr + ks * 64 + g * 16);
+          acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, acc, 0, 0, 0);
+        }
+        const int64_t px = p0 + row;
+        if (px < p.npix && chok) {
+          const uint2 gv = *(const uint2*)(p.gcat + px * cy + ch);
+          float gq[4] = {__uint_as_float(gv.x << 16), __uint_as_float(gv.x & 0xffff0000u), __uint_as_float(gv.y << 16), __uint_as_float(gv.y & 0xffff0000u)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float af = (float)acc[r];
+            const float yv = fmaf(A[r], af, B[r]);
+            const float tq = yv * y_inv;
+            float qv = rintf(tq) + y_zpf;                         // the emitted index (k_sq_emit_cat / k_pw's emit expression): the cat's first operand
+            if (lowq) qv = fminf(qv, qcap);
+            const int qi = (int)fminf(fmaxf(qv, 0.0f), 255.0f);
+            if (!ok[(qi - 128) & 255]) gq[r] = 0.0f;              // quant_cat's STE window on the squeeze half
+            const float gy = (tq > t_lo && tq <= t_hi) ? gq[r] : 0.0f;   // the squeeze output's own FakeQuantize (+ ReLU)
+            s1[ct][r] += gy; s2[ct][r] = fmaf(gy, fmaf(af, R[r], MR[r]), s2[ct][r]);
+          }
+          sqb_store4(p.ga + px * p.r + ch, gq, p.acc_a);
+        }
+      }
+    }
+    {   // the input half of the cat: gb (+)= gcat[:, r:] where the requantised input stayed in range
+      const int upr = p.cin >> 3; const int total = 128 * upr;
+      const uint8_t* okb = ok + 256;
+      for (int u = tid; u < total; u += 256) {
+        const int row = u / upr, c0 = (u - row * upr) * 8;
+        const int64_t px = p0 + row;
+        if (px >= p.npix) continue;
+        const uint2 src = *(const uint2*)(xs + row * p.kstr + c0);
+        const uint4 gv = *(const uint4*)(p.gcat + px * cy + p.r + c0);
+        float gq[8] = {bf2f(gv.x & 0xffff), bf2f(gv.x >> 16), bf2f(gv.y & 0xffff), bf2f(gv.y >> 16), bf2f(gv.z & 0xffff), bf2f(gv.z >> 16), bf2f(gv.w & 0xffff), bf2f(gv.w >> 16)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { if (!okb[(src.x >> (8 * r)) & 255]) gq[r] = 0.0f; if (!okb[(src.y >> (8 * r)) & 255]) gq[4 + r] = 0.0f; }
+        uint16_t* dst = p.gb + px * p.cin + c0;
+        sqb_store4(dst, gq, p.acc_b); sqb_store4(dst + 4, gq + 4, p.acc_b);
+      }
+    }
+  }
+  // per-channel sums: the 16 pixel lanes of a lane group -> one value, the waves through LDS, one pair of atomics per channel and workgroup
+#pragma unroll
+  for (int ct = 0; ct < CTM; ++ct) {
+    if (ct >= CT) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = s1[ct][r], b = s2[ct][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      const int c = ct * 16 + 4 * g + r;
+      if (j == 0 && c < p.r) { atomicAdd(&red[c], a); atomicAdd(&red[p.cpad + c], b); }
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < p.r; c += 256) {
+    atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, red[c]);
+    atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, red[p.cpad + c]);
+  }
+}
+extern "C" int frost_sq_bwd_cat_ok(int cin, int r) { return (cin % 8 == 0) && (r % 8 == 0) && cin <= 192 && r <= 96; }
+extern "C" int frost_sq_bwd_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, float* coef,
+                                const float* qrec_sq, int relu, const float* qrec_cat, const uint16_t* g_cat, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream) {
+  FROST_REQUIRE(frost_sq_bwd_cat_ok(cin, r), "sq_bwd_cat: cin <= 192, r <= 96 (multiples of 8)");
+  FROST_REQUIRE(x && g_cat && ga && gb && coef, "sq_bwd_cat: incomplete arguments");
+  SqBwdP p = {};
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = coef; p.qsq = qrec_sq; p.qcat = qrec_cat; p.gcat = g_cat; p.ga = ga; p.gb = gb;
+  p.acc_a = acc_a; p.acc_b = acc_b; p.relu = relu;
+  p.npix = npix; p.ntiles = (npix + 127) / 128; p.cin = cin; p.r = r; p.cpad = round_up(r, 16);
+  const int ksm = round_up(cin, 64) / 64;
+  p.kstr = ksm * 64 + 16;
+  const size_t lds = (size_t)128 * p.kstr + 512 + (size_t)2 * p.cpad * 4;
+  static const int cap = getenv("FROST_SQB_WGS") ? atoi(getenv("FROST_SQB_WGS")) : 512;        // every workgroup ends with 2 * r float atomics into the coefficient rows
+  const dim3 grid((unsigned)(p.ntiles < cap ? p.ntiles : cap));
+  hipStream_t s = as_stream(stream);
+  const int ctm = p.cpad / 16;
+#define SQB(KS, CM) hipLaunchKernelGGL((k_sq_bwd_cat<KS, CM>), grid, dim3(256), lds, s, p)
+  if (ksm == 1) { if (ctm <= 2) SQB(1, 2); else SQB(1, 6); }
+  else if (ksm == 2) { if (ctm <= 2) SQB(2, 2); else SQB(2, 6); }
+  else { if (ctm <= 3) SQB(3, 3); else SQB(3, 6); }
+#undef SQB
+  return frost_check_launch("sq_bwd_cat");
+}

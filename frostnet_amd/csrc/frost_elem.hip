@@ -344,7 +344,8 @@ extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_e
   hipLaunchKernelGGL(k_wprep_observe, dim3((nlayers + 63) / 64), dim3(64), 0, s, descs, nlayers, rule127, observe);
   hipLaunchKernelGGL(k_wprep_scales, dim3(nlayers), dim3(256), 0, s, descs, rule127, observe);
   hipLaunchKernelGGL(k_wprep_pack, dim3(gx, nlayers), dim3(256), 0, s, descs);
-  hipLaunchKernelGGL(k_wprep_wsum, dim3(wcap >= 128 ? 128 : 32, nlayers), dim3(256), 0, s, descs);
+  static const int wsg = getenv("FROST_WSUM_WGS") ? atoi(getenv("FROST_WSUM_WGS")) : (wcap >= 128 ? 128 : 32);      // A/B: a wave per output channel, channels strided over the grid
+  hipLaunchKernelGGL(k_wprep_wsum, dim3(wsg, nlayers), dim3(256), 0, s, descs);
   return frost_check_launch("weight_prep");
 }
 

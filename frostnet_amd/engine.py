@@ -60,11 +60,16 @@ _WG_DEFER = int(os.environ.get("FROST_WG_DEFER", "0"))
 # skip_add's backward folded into the element-wise reduce / dc passes of the reduce_conv that produced its second operand (frost_pw_ew_add_bwd): one launch less per
 # residual block of the 14 x 14 / 7 x 7 stages and no materialised gout for that layer; bit-identical to the two launches it replaces (A/B switch)
 _ADD_BWD_FUSE = os.environ.get("FROST_ADD_BWD_FUSE", "1") != "0"
+# quant_cat's backward + the squeeze_conv's backward reduce pass in one launch (frost_sq_bwd_cat, the backward sibling of frost_sq_emit_cat).  Parity-green (the g4 / g4t
+# block goldens pass with it) but SLOWER inside the step: 21.31 vs 21.17 ms (interleaved, profiles/r05_fusion_ab.txt) -- the two launches it replaces are 10 - 17 us
+# (element-wise, 8 channels per thread) + 13 us (k_pw's reduce instance with DMA-staged tiles); one 256-thread workgroup per 128-pixel tile that recomputes the conv AND
+# walks the wide gradient rows at 8-byte granularity does not beat them.  Off by default, kept as the A/B switch.
+_SQ_BWD_CAT = os.environ.get("FROST_SQ_BWD_CAT", "0") != "0"
 
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done", "add_bwd")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done", "add_bwd", "bred_done")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
@@ -75,6 +80,7 @@ class Act:
         self.kept_next = None      # set by conv_pair: the integer conv output of the reduce_conv consuming this activation (its statistics pass already ran)
         self.sum_observed = False  # the residual add consuming this activation already had its range pass (fused into this layer's emit)
         self.cat_done = None       # the cat consuming this (squeeze) activation was already written by frost_sq_emit_cat: Engine.cat returns it
+        self.bred_done = False     # backward: this (squeeze) layer's reduce pass already ran inside the cat's backward launch (frost_sq_bwd_cat)
         self.add_bwd = None        # backward: (gradient of the add's output, other operand, the add's record, ga, accumulate) -- the add's backward is folded into this activation's producer
 
     @property
@@ -643,8 +649,17 @@ class Engine:
                 _, a, b, y = entry
                 ga, fa = self._grad_slot(a)
                 gb, fb = self._grad_slot(b)
-                call("frost_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q),
-                     ptr(ga), fa, ptr(gb), fb, stream(), prof=("cat_bwd", 5 * y.numel))
+                nxt = rtape[ti + 1] if ti + 1 < len(rtape) else None
+                sq = nxt[1] if (nxt is not None and nxt[0] == "conv" and nxt[3] is a and nxt[2] is b) else None
+                if (_SQ_BWD_CAT and sq is not None and sq.kind == "pw" and getattr(sq, "hswish", None) is None and not sq.per_channel
+                        and L.load_library().frost_sq_bwd_cat_ok(b.c, a.c)):
+                    # the next tape entry is the squeeze_conv that produced `a` from `b`: its reduce pass (S1 / S2) rides in the cat's backward launch
+                    call("frost_sq_bwd_cat", ptr(b.buf), ptr(b.q), ptr(sq.wq_pack), ptr(sq.wsum), b.npix, b.c, a.c, ptr(sq.coef), ptr(sq.qy), int(sq.relu), ptr(y.q),
+                         ptr(y.grad), ptr(ga), fa, ptr(gb), fb, stream(), prof=("cat_bwd", 5 * y.numel + b.numel))
+                    a.bred_done = True
+                else:
+                    call("frost_cat_bwd", ptr(y.grad), ptr(a.buf), ptr(a.q), a.c, ptr(b.buf), ptr(b.q), b.c, a.npix, ptr(y.q),
+                         ptr(ga), fa, ptr(gb), fb, stream(), prof=("cat_bwd", 5 * y.numel))
                 y.grad = None
             elif kind == "hswish":
                 _, x, y, lut = entry
@@ -860,7 +875,9 @@ class Engine:
             else:
                 # algorithmic bytes: x 1 B/el, gradients 2 B/el (bf16)
                 pwc = (not fused) and l.kind == "pw" and bool(L.load_library().frost_pwc_bwd_ok(x.npix, x.c, l.cout))      # wide layers: chunked kernel, full-line gout / dc I/O
-                if pwc and x.npix <= _PWC_RED_MAXPIX:       # (per 64-pixel tile a pair of float atomics per channel: above ~100 k pixels k_pw's fatter tiles win -- measured 98 vs 186 us at 28 x 28)
+                if getattr(y, "bred_done", False):          # squeeze_conv: S1 / S2 were accumulated by the cat's backward launch (frost_sq_bwd_cat)
+                    y.bred_done = False
+                elif pwc and x.npix <= _PWC_RED_MAXPIX:       # (per 64-pixel tile a pair of float atomics per channel: above ~100 k pixels k_pw's fatter tiles win -- measured 98 vs 186 us at 28 x 28)
                     call("frost_pwc_conv_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, 0, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), None, s,
                          prof=("pw_bwd_reduce", x.numel + 2 * y.numel))
                 else:

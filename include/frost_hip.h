@@ -292,7 +292,14 @@ int frost_g32_pool_bwd(const float* dpool, const float* drop, int n, int hw, int
  * frost_cat_requant, bit-identical; the cat's record qrec_cat must be final (FrostFinDesc.cat_qrec_y of the squeeze's statistics launch).  y_sq: [npix][r], y_cat: [npix][r + cin]. */
 int frost_sq_emit_cat_ok(int cin, int r);
 int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, const float* coef,
-                      const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, int mode, void* stream);   /* mode 1 / 2 / 3 as frost_pw_conv_fwd's emit modes */
+                      const float* qrec_sq, const float* qrec_cat, int8_t* y_sq, int8_t* y_cat, int mode, void* stream); /* quant_cat's backward (frostnet.py:129) + the squeeze_conv's backward reduce pass in one launch (the backward sibling of frost_sq_emit_cat): g_cat [npix][r + cin]
+ * bf16 = gradient of the concatenated tensor; ga [npix][r] (=, or += with acc_a) = its squeeze half inside the cat's STE window (the squeeze layer's gout, read by its
+ * dc pass); gb [npix][cin] (+)= the input half; S1 / S2 of the squeeze layer accumulate into its coefficient rows as frost_pw_conv_bwd(mode 0) does.
+ * frost_sq_bwd_cat_ok(cin, r) = 1 if the shape qualifies (cin <= 192, r <= 96, multiples of 8). */
+int frost_sq_bwd_cat_ok(int cin, int r);
+int frost_sq_bwd_cat(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, float* coef,
+                     const float* qrec_sq, int relu, const float* qrec_cat, const uint16_t* g_cat, uint16_t* ga, int acc_a, uint16_t* gb, int acc_b, void* stream);
+  /* mode 1 / 2 / 3 as frost_pw_conv_fwd's emit modes */
 
 /* ---- whole-bottleneck fused bf16 inference (csrc/frost_iblock.hip) -----------------------------------------------------------
  * replaces (eval mode, BatchNorm folded): CascadePreExBottleneck.forward, frostnet.py:124-145 -- [squeeze_conv -> cat] -> conv1 -> conv2 (depthwise) ->

@@ -16,6 +16,7 @@ import torch
 from oracle import frost_oracle as O
 
 pytestmark = pytest.mark.gpu
+TAIL_TOL = 2e-2          # classifier bias gradient of the data-parallel step vs the oracle (element-wise, relative L2)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODE, RES, B = "small", 64, 2
 
@@ -105,8 +106,22 @@ def test_two_rank_allreduce_equals_mean_of_shard_gradients():
         ratios[n_] = np.linalg.norm(got[off:off + p.numel()]) / (np.linalg.norm(expect[off:off + p.numel()]) + 1e-30)
         off += p.numel()
     med = float(np.median(list(ratios.values())))
-    print(f"[dp] gradient-norm ratio device/oracle of the all-reduced arena: median {med:.3f}, classifier {ratios['classifier.2.weight']:.3f}")
-    assert 0.33 < med < 3.0 and 0.5 < ratios["classifier.2.weight"] < 2.0
+    # the TAIL of the backward.  Element-wise the classifier / last_layer WEIGHT gradients are already 0.24 - 0.30 from the oracle's here (measured:
+    # isolated index flips of the train-mode forward move the logits, hence dlogits, at this batch size), so the element-wise bound is put on the quantity that
+    # averages them out -- the classifier BIAS gradient (sum of dlogits over the batch: 4.5e-3 measured) -- and the weight tensors of the tail get a NORM band that a
+    # 2x scaling bug or a wrong 1 / world factor cannot pass; the loose band is left to the deep layers
+    off, tail, tnorm = 0, {}, {}
+    for n_, p in P.items():
+        if n_.startswith("classifier.") or n_.startswith("last_layer."):
+            a_, b_ = got[off:off + p.numel()], expect[off:off + p.numel()]
+            tail[n_] = float(np.linalg.norm(a_ - b_) / (np.linalg.norm(b_) + 1e-30))
+            tnorm[n_] = float(np.linalg.norm(a_) / (np.linalg.norm(b_) + 1e-30))
+        off += p.numel()
+    print(f"[dp] gradient-norm ratio device/oracle of the all-reduced arena: median {med:.3f}, classifier {ratios['classifier.2.weight']:.3f}; "
+          f"tail gradients vs the oracle's shard mean, element-wise: { {k: round(v, 4) for k, v in tail.items()} }, norm ratios: { {k: round(v, 3) for k, v in tnorm.items()} }")
+    assert 0.33 < med < 3.0
+    assert tail["classifier.2.bias"] <= TAIL_TOL, tail
+    assert all(0.8 <= v <= 1.25 for v in tnorm.values()), tnorm
 
 
 def test_graph_segments_replay_equals_eager():

@@ -13,6 +13,7 @@ import torch
 from oracle import frost_oracle as O
 
 pytestmark = pytest.mark.gpu
+TAIL_NORM_TOL = 5e-2      # classifier gradient norms of the first step vs the reference golden (the logits feeding them already differ by isolated index flips)
 GRAD_TOL = 5e-2      # bf16 gradient storage + bf16 MFMA operands through 4-6 chained layers
 
 
@@ -162,6 +163,8 @@ def test_g4_block_true_shapes(fa, golden, name):
             assert ("frost_block_expand_dw_stats" in log) or ("frost_block_dw_stats" in log), log
             assert "frost_block_dw_reduce" in log and "frost_block_dw_bwd" in log and "frost_block_dw_bwd_reduce" in log, log
             assert "frost_dw_conv_fwd" not in log and "frost_dw_dgrad" not in log, log
+            if engine._SQ_BWD_CAT:            # (A/B switch FROST_SQ_BWD_CAT=1: quant_cat's backward + the squeeze_conv's reduce pass as one launch)
+                assert "frost_sq_bwd_cat" in log and "frost_cat_bwd" not in log, log
             if cin == cout and s == 1:        # residual block: skip_add's backward rides in the reduce_conv's element-wise passes (no stand-alone launch)
                 assert log.count("frost_pw_ew_add_bwd") == 2 and "frost_add_bwd" not in log, log
         d = (yidx.to(torch.int16) - T(g[f"s{step}_yidx"]).to(torch.int16)).abs()
@@ -274,6 +277,12 @@ def test_train_step_large(fa, golden):
         assert np.isfinite(float(loss))
         assert abs(float(loss) - float(g[f"s{step}_loss"])) <= 1.5      # chaotic at B=2@64 (BN over 8 samples), SURVEY H-2
         assert 0.33 <= np.median(ratio) <= 3.0
+        # the tail of the backward (classifier, last_layer: the first gradients produced, before the chaos of the layers below) against the REFERENCE's
+        # gradient norms: a 2x scaling bug anywhere in the head cannot hide in the loose band above
+        tail = {n: float(r_) for n, r_ in zip(names, ratio) if n.startswith("classifier.") or n.startswith("last_layer.")}
+        print(f"    tail gradient-norm ratios vs the reference: { {k: round(v, 3) for k, v in tail.items()} }")
+        if step == 0:
+            assert all(abs(v - 1.0) <= TAIL_NORM_TOL for k, v in tail.items() if k.startswith("classifier.")), tail
         if step == 0:
             sd = model.state_dict()
             qk = [str(k) for k in g["s0_qkeys"]]

@@ -46,6 +46,7 @@ def main():
     lo, hi = marks[-2] + 1, marks[-1] + 1
     step = rows[lo:hi]
     t0 = step[0][0]
+    boundary_us = (t0 - rows[marks[-2]][1]) / 1e3          # end of the previous step's optimizer launch -> this step's first node
     cnt = collections.Counter(kind_of(r[2]) for r in step)
     busy = sum(e - s for s, e, *_ in step)
     # timeline gaps: time in which NO kernel of the step is running
@@ -62,10 +63,11 @@ def main():
         by[k][0] += 1
         by[k][1] += e - s
     doc = dict(nodes_total=len(step), nodes_own=cnt["own"], nodes_aten=cnt["aten"], nodes_copy_fill=cnt["copy_fill"], span_us=span / 1e3, busy_sum_us=busy / 1e3,
-               idle_us=gap / 1e3, gaps_over_3us=ngap_big,
+               idle_us=gap / 1e3, gaps_over_3us=ngap_big, step_boundary_idle_us=boundary_us,
                non_own={k: v[0] for k, v in by.items() if kind_of(k) != "own"})
     lines = [f"# one replayed step: {len(step)} nodes = {cnt['own']} own + {cnt['aten']} aten + {cnt['copy_fill']} runtime copy/fill; span {span / 1e3:.1f} us, "
-             f"sum of kernel durations {busy / 1e3:.1f} us, idle (no kernel running) {gap / 1e3:.1f} us, gaps > 3 us: {ngap_big}"]
+             f"sum of kernel durations {busy / 1e3:.1f} us, idle (no kernel running) {gap / 1e3:.1f} us, gaps > 3 us: {ngap_big}; "
+             f"idle between the previous step's optimizer launch and this step's first node: {boundary_us:.1f} us"]
     lines.append("# by kernel (count, total us):")
     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"#   {v[0]:4d} {v[1] / 1e3:9.1f}  {k}")
