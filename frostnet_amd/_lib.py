@@ -91,6 +91,9 @@ _PROTOS = {
     "frost_dequant_act": [P, L, P, P, P],
     "frost_weight_prep": [P, I, I, I, I, P],
     "frost_export_wq": [P, I, L, P, P],
+    "frost_mbox_workspace_floats": [],
+    "frost_mbox_forward": [P, P, P, P, P, I, I, I, I, F, I, F, F, P, P, P, P, P, P, P, P, P],
+    "frost_mbox_backward": [P, P, P, P, P, P, P, P, I, I, I, P, P, P],
     "frost_stats_init_table": [P, P, P, I, P],
     "frost_pw_conv_fwd": [P, P, P, P, L, I, I, I, P, P, P, I, P, P],
     "frost_pw_conv_fwd_fin": [P, P, P, P, L, I, I, P, P, P],

@@ -57,6 +57,9 @@ _WG_JOIN = int(os.environ.get("FROST_WG_JOIN", "0"))
 # H = 14 is 0.33 ms SLOWER than per-layer forks (21.63 vs 21.30 ms/step) -- in the captured step the per-layer forks already start ~8 ms late, and starting all of
 # them 1.8 ms earlier (beside layer3.0 / layer2.1's backward) costs more than the 39 fork gaps of ~4.6 us it removes.  0 = fork per layer (default).
 _WG_DEFER = int(os.environ.get("FROST_WG_DEFER", "0"))
+# FROST_WG_BATCH = N > 1: one fork per N pointwise weight gradients (each fork costs the main stream a ~4.6 us gap in the captured step): the weight gradients of N
+# consecutive layers are launched on the side stream together, right after the dc pass of the N-th (A/B switch; 0 / 1 = fork per layer)
+_WG_BATCH = int(os.environ.get("FROST_WG_BATCH", "0"))
 # skip_add's backward folded into the element-wise reduce / dc passes of the reduce_conv that produced its second operand (frost_pw_ew_add_bwd): one launch less per
 # residual block of the 14 x 14 / 7 x 7 stages and no materialised gout for that layer; bit-identical to the two launches it replaces (A/B switch)
 _ADD_BWD_FUSE = os.environ.get("FROST_ADD_BWD_FUSE", "1") != "0"
@@ -605,8 +608,19 @@ class Engine:
         bucket's all-reduce) while the rest of the backward is still to run."""
         self._prepare_dwq()
         self._pending = []          # conv layers whose weight-gradient finalize is deferred to one table launch
-        if self.grad_fp32:
-            return self._backward_g32(dlogits, boundaries, on_bucket)
+        self._frozen_stashed = []   # frozen-BatchNorm layers whose S1 / S2 rows are set aside right now
+        try:
+            if self.grad_fp32:
+                return self._backward_g32(dlogits, boundaries, on_bucket)
+            return self._backward_bf16(dlogits, boundaries, on_bucket)
+        except BaseException:
+            for l in self._frozen_stashed:              # an aborted backward must not leave zeroed coefficient rows behind (ADVICE r4)
+                if getattr(l, "_s12", None) is not None:
+                    l.coef[L.COEF_S1: L.COEF_S2 + 1].copy_(l._s12)
+                    l._s12 = None
+            raise
+
+    def _backward_bf16(self, dlogits, boundaries, on_bucket):
         # Pointwise weight gradients run on a second stream: nothing downstream needs them until the finalize at the end of the
         # backward, and the short low-resolution kernels leave launch gaps and tails that an independent kernel can fill.
         # Off when per-layer gradients are awaited (data parallel) and while the per-kernel profiler times the main stream.
@@ -839,7 +853,7 @@ class Engine:
         self._ensure_grad(l)
         gout = y.grad
         s = stream()
-        if getattr(self, "_deferred", None) and x.h > _WG_DEFER:
+        if _WG_DEFER and getattr(self, "_deferred", None) and x.h > _WG_DEFER:
             self._flush_deferred_wgrads()
         if _WG_JOIN and self._side is not None and getattr(self, "_forks", 0) >= _WG_JOIN:
             torch.cuda.current_stream().wait_stream(self._side)      # short side branches: the weight gradients forked so far must be done before this layer starts
@@ -910,6 +924,10 @@ class Engine:
                 call("frost_pw_conv_bwd", *args, 1, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(dc), None, 0, s,
                      prof=("pw_bwd_dc", x.numel + 4 * y.numel))
             defer_wg = bool(_WG_DEFER and self._side is not None and (_WG_STREAM & 1) and l.kind == "pw" and x.h <= _WG_DEFER)
+            if _WG_BATCH > 1 and self._side is not None and (_WG_STREAM & 1) and l.kind == "pw":
+                defer_wg = True
+                if len(self._deferred) + 1 >= _WG_BATCH:          # this layer completes a batch: its dc is done, flush the earlier ones now and this one below
+                    self._wg_flush_after = True
             if self._side is not None and (_WG_STREAM & 1) and not defer_wg:      # fork right after the dc pass: the weight gradient runs beside dgrad and what follows
                 self._flush_deferred_wgrads(fork=False)
                 ev = torch.cuda.Event()
@@ -931,6 +949,9 @@ class Engine:
                 sw = C.c_void_p(self._side.cuda_stream)
             if defer_wg:
                 self._deferred.append((dc, x, l, y.numel))
+                if getattr(self, "_wg_flush_after", False):
+                    self._wg_flush_after = False
+                    self._flush_deferred_wgrads()
             else:
                 call("frost_pw_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), x.npix, x.c, l.cout, ptr(l.dwq), sw,
                      prof=("pw_wgrad", 2 * y.numel + x.numel))
@@ -990,8 +1011,12 @@ class Engine:
         if not getattr(l, "frozen", False):
             return
         rows = l.coef[L.COEF_S1: L.COEF_S2 + 1]
-        l._s12 = rows.clone()
+        if getattr(l, "_s12_buf", None) is None or l._s12_buf.shape != rows.shape:
+            l._s12_buf = torch.empty_like(rows)          # persistent stash: no allocation per step (a captured step keeps its address)
+        l._s12_buf.copy_(rows)
+        l._s12 = l._s12_buf
         rows.zero_()
+        self._frozen_stashed.append(l)
 
     def _frozen_restore(self, l):
         if getattr(l, "frozen", False) and getattr(l, "_s12", None) is not None:
@@ -1021,9 +1046,12 @@ def grad_to_float(g, n, h, w, c):
 
 
 def float_to_grad(t_nchw, fp32=False):
-    """fp32 NCHW -> NHWC gradient buffer with slack: bf16 bits, or fp32 (`fp32=True`: the fp32-gradient mode, Engine.grad_fp32)."""
-    v = t_nchw.permute(0, 2, 3, 1).contiguous()
-    v = v.float().reshape(-1) if fp32 else v.to(torch.bfloat16).view(torch.int16).reshape(-1)
-    out = torch.zeros(v.numel() + 64, dtype=v.dtype, device=t_nchw.device)
-    out[: v.numel()] = v
-    return out
+    """fp32 NCHW (any strides) -> NHWC gradient buffer with 64 elements of slack: bf16 bits, or fp32 (`fp32=True`: the fp32-gradient mode, Engine.grad_fp32).  One strided
+    copy with the conversion folded in (+ a 64-element fill of the slack), whatever the layout of the incoming gradient -- the detector's map gradients arrive as
+    strided slices of the loss's [N, P, 4] / [N, P, C] gradient tensors."""
+    n, c, h, w = t_nchw.shape
+    ne = n * h * w * c
+    out = torch.empty(ne + 64, dtype=torch.float32 if fp32 else torch.bfloat16, device=t_nchw.device)
+    out[ne:].zero_()
+    out[:ne].view(n, h, w, c).copy_(t_nchw.permute(0, 2, 3, 1))
+    return out if fp32 else out.view(torch.int16)

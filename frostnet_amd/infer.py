@@ -216,7 +216,10 @@ class Bf16Inference:
     def _block(self, ent, a, c, n, h, w):
         if _FUSED is False:
             return self._block_plain(ent, a, c, n, h, w)
-        key = ("choice", n, h, w, _FUSED)
+        # the measured choice is kept per (resolution, batch BUCKET): a last partial batch or a slightly different batch size reuses its bucket's choice instead of
+        # re-running dozens of timed launches inside the caller's forward, and the table stays bounded
+        bucket = 1 << max(0, int(n) - 1).bit_length()
+        key = ("choice", bucket, h, w, _FUSED)
         choice = ent.get(key)
         if choice is None:
             l2, l3, sq = ent["conv2"], ent["reduce"], ent["squeeze"]
@@ -240,7 +243,9 @@ class Bf16Inference:
                     run = (lambda t=cand: self._run_choice(ent, a, c, n, h, w, t))
                     try:
                         run()
-                    except RuntimeError:              # this wave count does not hold the tile's reduce_conv accumulators
+                    except RuntimeError as e:         # only the library's own "this tile / wave count does not fit" refusals mean "not a candidate"
+                        if not any(m in str(e) for m in ("too many output tiles per wave", "unsupported geometry / tile", "chunk = 64, or 32")):
+                            raise                     # a genuine launch failure must not be read as "candidate not applicable"
                         continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -250,7 +255,10 @@ class Bf16Inference:
                     e1.synchronize()
                     timed.append((e0.elapsed_time(e1) / 3.0, cand))
                 choice = min(timed, key=lambda t: t[0])[1]
-                ent[("timing", n, h, w)] = timed
+                ent[("timing", bucket, h, w)] = timed
+            stale = [k for k in ent if isinstance(k, tuple) and k[0] == "choice"]
+            for k in stale[:-7]:                      # at most 8 (bucket, resolution) entries per bottleneck
+                ent.pop(k, None); ent.pop(("timing",) + k[1:4], None)
             ent[key] = choice
         return self._run_choice(ent, a, c, n, h, w, choice)
 

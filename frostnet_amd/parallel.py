@@ -136,7 +136,7 @@ class SegmentedStep:
         if self.maps_loss is not None:
             from .engine import float_to_grad
             acts = r._maps_impl(x, record=True)
-            leaves = [a.dequant().contiguous().requires_grad_(True) for a in acts]
+            leaves = [a.dequant().requires_grad_(True) for a in acts]
             loss = self.maps_loss(leaves, target)
             loss.backward(gradient=self.gscale)
             for a, t in zip(acts, leaves):

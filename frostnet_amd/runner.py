@@ -650,7 +650,9 @@ class _QATMapsFunction(torch.autograd.Function):
         acts = runner._maps_impl(x, record=True)
         ctx.runner, ctx.acts = runner, acts
         ctx.gen = runner._new_generation()
-        return tuple(a.dequant().contiguous() for a in acts)
+        # NCHW-shaped views of NHWC memory (channels_last): the detector's `_assemble` permutes them straight back to NHWC, so a contiguous NCHW copy here would be
+        # a transposing pass per map each way
+        return tuple(a.dequant() for a in acts)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -11,6 +11,7 @@ composition SURVEY N3 asks for, following the reference's conventions:
     restated in vectorised, device-agnostic torch (they are the caller's loss, not conv math) and pinned to the reference by goldens.
 Class-score maps are padded to a multiple of 8 channels (the HIP backward's channel granularity); the padding is sliced off before the loss."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -98,6 +99,50 @@ def match_priors(threshold, truths, valid, priors, variances, labels):
     return torch.cat([g_cxcy, g_wh], 2), conf
 
 
+_MBOX_HIP = os.environ.get("FROST_MBOX_HIP", "1") != "0"          # dev switch: the loss as HIP kernels on the device (default) or as torch stages
+
+
+class _MBoxFunction(torch.autograd.Function):
+    """MultiBoxLoss forward + backward on the device (csrc/frost_mbox.hip): (loss_l, loss_c) = f(loc, conf); nothing synchronises with the host."""
+
+    @staticmethod
+    def forward(ctx, loc, conf, priors, boxes, valid, threshold, negpos, variance):
+        from ._lib import call, load_library, ptr, stream
+        lib = load_library()
+        n, p, c, k = loc.size(0), loc.size(1), conf.size(2), boxes.size(1)
+        dev = loc.device
+        loc_c, conf_c = loc.detach().contiguous().float(), conf.detach().contiguous().float()
+        pri = priors.detach().contiguous().float()
+        bx = boxes.detach().contiguous().float()
+        vd = valid.detach().contiguous().to(torch.uint8) if valid.dtype != torch.bool else valid.detach().contiguous()
+        bto = torch.empty(n, p, dtype=torch.float32, device=dev)
+        bti = torch.empty(n, p, dtype=torch.int32, device=dev)
+        loc_t = torch.empty(n, p, 4, dtype=torch.float32, device=dev)
+        conf_t = torch.empty(n, p, dtype=torch.int32, device=dev)
+        lc = torch.empty(n, p, dtype=torch.float32, device=dev)
+        sel = torch.empty(n, p, dtype=torch.uint8, device=dev)
+        num_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        out = torch.zeros(lib.frost_mbox_workspace_floats(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            call("frost_mbox_forward", ptr(loc_c), ptr(conf_c), ptr(pri), ptr(bx), ptr(vd), n, p, c, k, float(threshold), int(negpos), float(variance[0]), float(variance[1]),
+                 ptr(bto), ptr(bti), ptr(loc_t), ptr(conf_t), ptr(lc), ptr(sel), ptr(num_pos), ptr(out), stream())
+        ctx.save_for_backward(loc_c, conf_c, loc_t, conf_t, sel, out)
+        ctx.conf_t, ctx.num_pos = conf_t, num_pos          # (tests read the matching)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_l, g_c):
+        from ._lib import call, ptr, stream
+        loc, conf, loc_t, conf_t, sel, out = ctx.saved_tensors
+        n, p, c = conf.shape
+        dloc, dconf = torch.empty_like(loc), torch.empty_like(conf)
+        gl = g_l.contiguous().float() if g_l is not None else None
+        gc = g_c.contiguous().float() if g_c is not None else None
+        with torch.cuda.device(loc.device):
+            call("frost_mbox_backward", ptr(loc), ptr(conf), ptr(loc_t), ptr(conf_t), ptr(sel), ptr(out), ptr(gl), ptr(gc), n, p, c, ptr(dloc), ptr(dconf), stream())
+        return dloc, dconf, None, None, None, None, None, None
+
+
 class MultiBoxLoss(nn.Module):
     """SSD loss (layers/modules/multibox_loss.py:48-117): smooth-L1 on the matched priors + cross-entropy on positives and the hardest
     negatives (3:1), both divided by the number of positives.  forward((loc [N,P,4], conf [N,P,C], priors [P,4]), targets) with targets the
@@ -113,6 +158,14 @@ class MultiBoxLoss(nn.Module):
         num, num_priors = loc_data.size(0), loc_data.size(1)
         priors = priors[:num_priors].to(loc_data.device)
         boxes, valid = targets if isinstance(targets, tuple) else pad_targets(targets, loc_data.device)
+        if loc_data.is_cuda and _MBOX_HIP:
+            # the device path: matching, per-prior loss, hard negative mining and both gradients as four HIP kernels (csrc/frost_mbox.hip); the torch stages below
+            # are the CPU definition (and the yardstick of tests/test_gpu_detect.py)
+            return _MBoxFunction.apply(loc_data, conf_data, priors, boxes, valid, self.threshold, self.negpos_ratio, self.variance)
+        return self.forward_torch(loc_data, conf_data, priors, boxes, valid)
+
+    def forward_torch(self, loc_data, conf_data, priors, boxes, valid):
+        """The loss as batched torch stages (the restatement of multibox_loss.py:48-117 pinned to the reference's goldens, tests/test_oracle_golden.py G11)."""
         with torch.no_grad():
             loc_t, conf_t = match_priors(self.threshold, boxes[..., :4], valid, priors, self.variance, boxes[..., 4])
             pos = conf_t > 0

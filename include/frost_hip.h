@@ -582,6 +582,18 @@ int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n, uint32_t* 
                      int observe, uint8_t* lut, int8_t* y, void* stream);
 int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream);
 
+/* ---- SSD MultiBoxLoss (Object_Detection/layers/modules/multibox_loss.py:48-117 + layers/box_utils.py:71-139) ------------------------------------------------
+ * frost_mbox_forward: loc [n][p][4], conf [n][p][c], priors [p][4] (cx, cy, w, h), boxes [n][k][5] (x1, y1, x2, y2, label) with valid [n][k] (padding rows 0).
+ * Work buffers of the caller: bto [n][p] float, bti [n][p] int32, loc_t [n][p][4], conf_t [n][p] int32, lc [n][p], sel [n][p] bytes, num_pos [n] int32.
+ * out: frost_mbox_workspace_floats() floats, ZEROED before the first call: {loss_l, loss_c, 1 / N_pos, three running words that every call leaves zeroed, ...}.
+ * frost_mbox_backward: dloc [n][p][4], dconf [n][p][c] from the saved loc_t / conf_t / sel / out and the device scalars g_l, g_c (gradients of the two losses). */
+int frost_mbox_workspace_floats(void);
+int frost_mbox_forward(const float* loc, const float* conf, const float* priors, const float* boxes, const uint8_t* valid, int n, int p, int c, int k,
+                       float threshold, int negpos, float var0, float var1, float* bto, int32_t* bti, float* loc_t, int32_t* conf_t, float* lc, uint8_t* sel,
+                       int32_t* num_pos, float* out, void* stream);
+int frost_mbox_backward(const float* loc, const float* conf, const float* loc_t, const int32_t* conf_t, const uint8_t* sel, const float* out, const float* g_l,
+                        const float* g_c, int n, int p, int c, float* dloc, float* dconf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
