@@ -24,6 +24,7 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_DW_BWD_ONE = os.environ.get("FROST_DW_BWD_ONE", "1") != "0"   # depthwise k = 3 stride-1 backward of the tiled (high-resolution) layers: dc + weight gradient + data gradient in one sweep (csrc/frost_dwb.hip)
 _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
 _PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
@@ -861,7 +862,9 @@ class Engine:
         fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)
                   and bool(L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)))      # dc stays in LDS there: no buffer
-        dc = None if (fused or blk_dw) else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
+        dw_one = (l.kind == "dw" and not blk_dw and _DW_BWD_ONE and x.needs_grad and x.grad is None
+                  and bool(L.load_library().frost_dw_bwd_fused_ok(x.h, x.w, x.c, l.k, l.stride)))                 # dc stays in registers there: no buffer
+        dc = None if (fused or blk_dw or dw_one) else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
         if getattr(self, "_dbg", False):
             self._last_dc = dc
         if l.kind in ("pw", "stem"):
@@ -974,6 +977,14 @@ class Engine:
                 call("frost_block_dw_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
                      l.k, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]) if x.needs_grad else None, ptr(l.dwq), s,
                      prof=("blk_dw_bwd", x.numel + 2 * y.numel + (2 * x.numel if x.needs_grad else 0)))
+                self._after_conv_backward(l, s)
+                y.grad = None
+                return
+            if dw_one and not gslot[1]:
+                # dc never leaves registers: the strip-streaming kernel computes weight gradient and data gradient from it in the same sweep
+                call("frost_dw_bwd_fused", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
+                     l.k, l.stride, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]), ptr(l.dwq), s,
+                     prof=("dw_bwd_one", x.numel + 2 * y.numel + 2 * x.numel))
                 self._after_conv_backward(l, s)
                 y.grad = None
                 return

@@ -212,6 +212,15 @@ int frost_dw_dgrad(const uint16_t* dc, const int8_t* wq_pack, const float* qrec_
                    int stride, uint16_t* dx, int accumulate, const float* wscale, void* stream);
 int frost_dw_wgrad(const uint16_t* dc, const int8_t* x, const float* qrec_x, int n, int h, int w, int c, int k,
                    int stride, float* dwq, void* stream);
+/* dc pass + weight gradient + data gradient of a depthwise k = 3, stride-1 layer in ONE sweep (csrc/frost_dwb.hip): replaces frost_dw_conv_bwd_dc_wgrad +
+ * frost_dw_dgrad -- the backward of nniqat.ConvBnReLU2d with groups = channels (/root/reference/frostnet.py:96-101, conv2) after its reduce pass filled the S1 / S2
+ * coefficient rows.  dc never reaches HBM (5 instead of 9 bytes per element); dx is overwritten (no accumulate form); dwq receives the raw weight-gradient sums
+ * [c][k*k] like frost_dw_wgrad (atomics: zeroed by the caller).  Same expressions as the separate kernels; with FROST_SR=0 (round-to-nearest dc) dx is bit-identical
+ * to theirs.  wscale: per-channel weight scales or NULL (qrec_w's scalar). */
+int frost_dw_bwd_fused_ok(int h, int w, int c, int k, int stride);
+int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                       int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                       uint16_t* dx, float* dwq, void* stream);
 /* fold-path: dW = dWq*mask*sf ; dgamma = S2*vfrac + sum(dWq*mask*W)/sigma_r ; dbeta = S1  (SURVEY H-5) */
 /* sigma_r[c] = sqrt(running_var+eps) as used by THIS step's forward (frost_save_sigma runs before the update) */
 int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CSPLIT="0", FROST_DW_GEO="0", FROST_DW_FUSE="0", FROST_PW_FUSE="0", FROST_DW_XCD="0", FROST_WG_XCD="0",
-             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0", FROST_BLOCK_DWBRED="0", FROST_PWC="0", FROST_PWC_EMIT="0")
+             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0", FROST_BLOCK_DWBRED="0", FROST_PWC="0", FROST_PWC_EMIT="0", FROST_DW_BWD_ONE="0")
 FAST = dict()
 CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 32, 16, 1, 1, 112, 64), ("pw", 72, 24, 1, 1, 56, 128), ("pw", 144, 40, 1, 1, 28, 512), ("dw", 72, 72, 3, 1, 56, 64), ("pw", 56, 168, 1, 1, 28, 128), ("pw", 40, 16, 1, 1, 28, 64), ("pw", 56, 336, 1, 1, 28, 512), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
          ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
@@ -99,3 +99,30 @@ def test_fused_depthwise_backward_exact_without_stochastic_rounding(case, tmp_pa
     assert float(differ.mean()) <= 2e-3, float(differ.mean())
     assert relerr(a, b) <= 2e-4
     assert relerr(fused["dw"], sep["dw"]) <= 2e-5 and relerr(fused["dgamma"], sep["dgamma"]) <= 2e-5 and relerr(fused["dbeta"], sep["dbeta"]) <= 2e-5
+
+
+# The one-sweep depthwise backward of the tiled (high-resolution) k = 3 stride-1 layers (csrc/frost_dwb.hip: dc stays in registers, weight gradient and data gradient in the
+# same strip-streaming pass) against frost_dw_conv_bwd_dc_wgrad + frost_dw_dgrad, with round-to-nearest dc (FROST_SR=0): same dc, the data gradient summed in k_dw3_dgrad's
+# order -> dx BIT-IDENTICAL up to dc elements on a bf16 rounding boundary (S1 / S2 are float atomics); the weight gradient differs by the order of its fp32 sums only.
+# 32- and 64-channel blocks, partial channel blocks (72, 40, 168), maps that are not a multiple of the strip width (30, 28), several row chunks, fewer images than XCDs.
+@pytest.mark.parametrize("case", [("dw", 32, 32, 3, 1, 112, 16), ("dw", 72, 72, 3, 1, 56, 12), ("dw", 240, 240, 3, 1, 28, 9), ("dw", 40, 40, 3, 1, 30, 5), ("dw", 168, 168, 3, 1, 28, 3)],
+                         ids=lambda c: "_".join(str(v) for v in c))
+@pytest.mark.parametrize("chunks", ["0", "3"])
+def test_one_sweep_depthwise_backward_exact_without_stochastic_rounding(case, chunks, tmp_path):
+    one = run(str(tmp_path), "one", case, {"FROST_SR": "0", "FROST_DW_BWD_ONE": "1", "FROST_DWB_CHUNKS": chunks, "DIGEST_CALLS": os.path.join(str(tmp_path), "calls.txt")})
+    sep = run(str(tmp_path), "sep", case, {"FROST_SR": "0", "FROST_DW_BWD_ONE": "0"})
+    assert "frost_dw_bwd_fused" in open(os.path.join(str(tmp_path), "calls.txt")).read()
+    assert one["y"].tobytes() == sep["y"].tobytes()
+    a, b = bf16_to_f32(one["dx"]).astype(np.float64), bf16_to_f32(sep["dx"]).astype(np.float64)
+    differ = a != b
+    assert float(differ.mean()) <= 2e-3, float(differ.mean())
+    assert relerr(a, b) <= 2e-4
+    assert relerr(one["dw"], sep["dw"]) <= 2e-5 and relerr(one["dgamma"], sep["dgamma"]) <= 2e-5 and relerr(one["dbeta"], sep["dbeta"]) <= 2e-5
+
+
+def test_one_sweep_depthwise_backward_with_stochastic_rounding_matches_at_the_bf16_level(tmp_path):
+    case = ("dw", 72, 72, 3, 1, 56, 16)
+    one = run(str(tmp_path), "one", case, {"FROST_DW_BWD_ONE": "1"})
+    sep = run(str(tmp_path), "sep", case, {"FROST_DW_BWD_ONE": "0"})
+    assert relerr(bf16_to_f32(one["dx"]), bf16_to_f32(sep["dx"])) <= 8e-3
+    assert relerr(one["dw"], sep["dw"]) <= 1e-2 and relerr(one["dgamma"], sep["dgamma"]) <= 1e-2 and relerr(one["dbeta"], sep["dbeta"]) <= 1e-3

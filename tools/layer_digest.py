@@ -27,11 +27,15 @@ qx = qa.alloc(); qa.set_qparams(qx, 0.02, 3)
 x = E.new_act(B, H, H, cin, qx)
 x.buf[: x.numel] = torch.randint(-128, 128, (x.numel,), dtype=torch.int16, generator=g).to(torch.int8).to(dev)
 x.needs_grad = True
+if os.environ.get("DIGEST_CALLS"):
+    L.CALL_LOG = []          # which C-ABI entries this configuration launched (written next to the results)
 E.begin_step()
 y = E.conv(l, x)
 gy = (torch.randn(y.numel, generator=g) * 1e-3).to(dev)
 y.grad = torch.cat([gy.to(torch.bfloat16).view(torch.int16), torch.zeros(64, dtype=torch.int16, device=dev)])
 E.backward()
 torch.cuda.synchronize()
+if os.environ.get("DIGEST_CALLS"):
+    open(os.environ["DIGEST_CALLS"], "w").write("\n".join(L.CALL_LOG))
 np.savez(out, y=y.buf[: y.numel].cpu().numpy(), qy=l.qy.cpu().numpy(), rm=rm.cpu().numpy(), rv=rv.cpu().numpy(),
          dx=x.grad[: x.numel].cpu().numpy(), dw=w.grad.cpu().numpy(), dgamma=gamma.grad.cpu().numpy(), dbeta=beta.grad.cpu().numpy())
