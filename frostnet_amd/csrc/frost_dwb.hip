@@ -30,7 +30,8 @@ struct DwbP {
   const int8_t* x; const float* qx; const int8_t* wq; const int32_t* wsum; const float* qw; const float* wscale;
   const float* coef; const float* qy; const uint16_t* gout; uint16_t* dx; float* dwq;
   int n, h, w, c, cpad, relu, sr; float inv_count;
-  int ncb, nstrips, nchunks, rc;          // channel blocks, column strips per row, row chunks per image, rows per chunk
+  int ncb, nstrips, nchunks, rc;          // channel blocks, column strips per row, row chunks per image, rows per chunk (stride 2: output rows / columns)
+  int ho, wo;
 };
 
 __device__ __forceinline__ void dwb_glds16(const void* gsrc, uint32_t lds_addr) {
@@ -43,6 +44,7 @@ __device__ __forceinline__ void dwb_wait_vm(int n) {          // n: wave-uniform
   switch (n) {
     DWB_WAIT_CASE(1) DWB_WAIT_CASE(2) DWB_WAIT_CASE(3) DWB_WAIT_CASE(4) DWB_WAIT_CASE(5) DWB_WAIT_CASE(6) DWB_WAIT_CASE(7) DWB_WAIT_CASE(8)
     DWB_WAIT_CASE(9) DWB_WAIT_CASE(10) DWB_WAIT_CASE(11) DWB_WAIT_CASE(12) DWB_WAIT_CASE(13) DWB_WAIT_CASE(14) DWB_WAIT_CASE(15) DWB_WAIT_CASE(16)
+    DWB_WAIT_CASE(17) DWB_WAIT_CASE(18) DWB_WAIT_CASE(19) DWB_WAIT_CASE(20) DWB_WAIT_CASE(21) DWB_WAIT_CASE(22) DWB_WAIT_CASE(23) DWB_WAIT_CASE(24)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -294,50 +296,352 @@ __global__ __launch_bounds__(256, 3) void k_dwb_s1(const DwbP p) {
   }
 }
 
+// ================================================================================================ stride 2 (k = 3, 5)
+// The same strip-streaming scheme for the stride-2 layers (112 -> 56 k3, 56 -> 28 / 28 -> 14 / 14 -> 7 k5).  Today four launches (dc pass, weight gradient, data gradient:
+// x read twice, dc written once and read twice, dx written: 2 + 1 + 1 + 2 ... = 6 bytes per INPUT element); here 3.5 (x 1, gy 0.5, dx 2).  A lane owns 8 OUTPUT columns = 16
+// input columns; a step is one dc row m: two new x rows (the other k - 2 are carried in registers), one gy row, NDC = 9 (k3) / 10 (k5) dc columns (one halo column on the
+// right, for k5 one on the left too), and the two dx rows that became final -- rows 2m-1, 2m (k3: dc rows m-1, m) or 2m-2, 2m-1 (k5: dc rows m-2 .. m).  Only the taps whose
+// parity matches contribute to a dx element (2.25 of 9, 6.25 of 25 on average), in k_dw3_dgrad's order (dc rows ascending, kx ascending).
+template <int K, int CBW, int PD>
+struct DwbGeo2 {
+  static constexpr int PAD = (K - 1) / 2, LH = (K == 5) ? 1 : 0, NDC = 9 + LH, XL = (K == 3) ? 1 : 4, NDR = (K == 3) ? 2 : 3;
+  static constexpr int NXW = 2 * (NDC - 1) + K, NXD = 6;                                     // x window of a lane: 19 / 23 pixels; 3 transposed reads = 24 pixels = 6 dwords
+  static constexpr int HALF = 64 / CBW, SWO = 8 * HALF, SWI = 16 * HALF;
+  static constexpr int XPX = SWI - 16 + NXW, GPX = SWO + 1 + LH;
+  static constexpr int XR = XPX * CBW, GR = GPX * CBW * 2, OR = SWI * CBW * 2;               // bytes per x / gy row record, dx row (2 KB)
+  static constexpr int NXS = 2 * PD + ((K == 3) ? 2 : 3), NGS = PD + 1;
+  static constexpr int XU = XR / 16, GU = GR / 16;
+  static constexpr int XSL = 8 * CBW, GSL = 4 * CBW;                                          // slack: the last transposed read of a row runs past its record
+  static constexpr int X_OFF = 0, G_OFF = NXS * XR + XSL, O_OFF = G_OFF + NGS * GR + GSL, WAVE_LDS = O_OFF + OR;
+  static_assert(XU > 64 && XU <= 128 && GU > 64 && GU <= 128 && OR == 2048, "two copy instructions per x row, per gy row and per dx row");
+};
+
+template <int K, int CBW, int PD>
+__global__ __launch_bounds__(256, 2) void k_dwb_s2(const DwbP p) {
+  using G = DwbGeo2<K, CBW, PD>;
+  constexpr int PAD = G::PAD, LH = G::LH, NDC = G::NDC, XL = G::XL, NDR = G::NDR, NXD = G::NXD, SWO = G::SWO, SWI = G::SWI;
+  constexpr int XR = G::XR, GR = G::GR, NXS = G::NXS, NGS = G::NGS, KK = K * K, NPK = (K == 3) ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* const wl = smem + (size_t)wv * G::WAVE_LDS;
+  uint8_t* const xring = wl + G::X_OFF; uint8_t* const gring = wl + G::G_OFF; uint8_t* const orow = wl + G::O_OFF;
+  const uint32_t xring_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)xring);
+  const uint32_t gring_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)gring);
+  const int lc = lane & (CBW - 1), hf = lane / CBW;
+  const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3, nl = (int)gridDim.x >> 3;
+  const int cb = li % p.ncb, lwg = li / p.ncb, nlc = nl / p.ncb;
+  const int img_lo = (int)(((int64_t)p.n * xcd) >> 3), img_hi = (int)(((int64_t)p.n * (xcd + 1)) >> 3);
+  const int pit = p.nstrips * p.nchunks, ntask = (img_hi - img_lo) * pit;
+  const int ch = cb * CBW + lc; const bool chok = ch < p.c;
+
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
+  const uint32_t zp4 = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+  int wpk[K][NPK]; float wf[KK];
+  {
+    int8_t taps[KK];
+    load_taps_i8<KK>(p.wq, p.cpad, ch, chok, taps);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const uint32_t b = (uint32_t)(uint8_t)taps[ky * K + kx]; wf[ky * K + kx] = (float)taps[ky * K + kx];
+        if (kx < 4) lo |= b << (8 * kx); else hi |= b;
+      }
+      wpk[ky][0] = (int)lo; if (NPK > 1) wpk[ky][NPK - 1] = (int)hi;
+    }
+  }
+  const int chc = chok ? ch : 0;
+  const int acc0 = chok ? (128 - zpx) * p.wsum[chc] : 0;
+  const float sw = (p.wscale && chok) ? p.wscale[chc] : p.qw[FROST_Q_SCALE];
+  float cA = 0, cB = 0, cK1 = 0, cE = 0, cF = 0;
+  if (chok) {
+    cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
+    const float m = p.coef[FROST_COEF_M * p.cpad + ch], cR = p.coef[FROST_COEF_R * p.cpad + ch];
+    cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
+    cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
+    cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+  }
+  const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
+  float t_lo = 0.0f, t_hi;
+  {
+    const int zpy = __float_as_int(p.qy[FROST_Q_ZP]), qhi = q_hi(p.qy);
+    const float hi0 = (float)qhi + 0.5f - (float)zpy;
+    t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+  uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
+  const bool sr_on = p.sr != 0;
+  float wacc[KK]; float sdc = 0.0f;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) wacc[t] = 0.0f;
+
+  const int64_t xpitch = (int64_t)p.w * p.c, gpitch = (int64_t)p.wo * p.c;
+  for (int tt = lwg * 4 + wv; tt < ntask; tt += nlc * 4) {
+    const int img = img_lo + tt / pit; const int rem = tt - (tt / pit) * pit;
+    const int chunk = rem / p.nstrips, strip = rem - chunk * p.nstrips;
+    const int m0 = chunk * p.rc, m1 = min(m0 + p.rc, p.ho);           // own dc rows [m0, m1); own dx rows [2 m0, 2 m1)
+    const int oc0s = strip * SWO, ic0s = 2 * oc0s;
+    const int NS = (m1 - m0) + 1 + LH;                                 // dc rows m0 - LH .. m1
+    const int rbase = 2 * (m0 - LH) - PAD;                             // first x row of step 0
+    const int8_t* const ximg = p.x + (int64_t)img * p.h * xpitch;
+    const uint16_t* const gimg = p.gout + (int64_t)img * p.ho * gpitch;
+    uint16_t* const dimg = p.dx + (int64_t)img * p.h * xpitch;
+    int xoff0, xoff1, goff0, goff1, ooff0, ooff1; bool ook0, ook1;
+    {
+      constexpr int UPX = CBW / 16, UPG = CBW / 8;
+      auto xo = [&](int u) { const int px = u / UPX, cu = u % UPX, col = min(max(ic0s - XL + px, 0), p.w - 1); int cn = cb * CBW + cu * 16; if (cn >= p.c) cn = 0; return col * p.c + cn; };
+      auto go = [&](int u) { const int px = u / UPG, cu = u % UPG, col = min(max(oc0s - LH + px, 0), p.wo - 1); int cn = cb * CBW + cu * 8; if (cn >= p.c) cn = 0; return col * p.c + cn; };
+      xoff0 = xo(lane); xoff1 = xo(64 + lane); goff0 = go(lane); goff1 = go(64 + lane);
+      int px = lane / UPG, cu = lane % UPG, col = ic0s + px, cn = cb * CBW + cu * 8; ook0 = col < p.w && cn < p.c; ooff0 = col * p.c + cn;
+      px = (64 + lane) / UPG; cu = (64 + lane) % UPG; col = ic0s + px; cn = cb * CBW + cu * 8; ook1 = col < p.w && cn < p.c; ooff1 = col * p.c + cn;
+    }
+    const int nst_row = 1 + (__builtin_amdgcn_ballot_w64(ook1) != 0ull ? 1 : 0);        // store instructions a dx row certainly issues (the counted wait needs a lower bound)
+    const int ic0 = ic0s + 16 * hf, oc0 = oc0s + 8 * hf;
+    uint32_t xm[NXD]; uint32_t cmask = 0;
+#pragma unroll
+    for (int i = 0; i < NXD; ++i) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { const int col = ic0 - XL + 4 * i + b; if (col >= 0 && col < p.w) m |= 0xffu << (8 * b); }
+      xm[i] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < NDC; ++j) { const int col = oc0 - LH + j; if (col >= 0 && col < p.wo && chok) cmask |= 1u << j; }
+
+    auto issue_x = [&](int row, int slot) __attribute__((always_inline)) {
+      const int rr = min(max(row, 0), p.h - 1);
+      const int8_t* base = ximg + (int64_t)rr * xpitch;
+      dwb_glds16(base + xoff0, xring_a + (uint32_t)(slot * XR));
+      if (lane < G::XU - 64) dwb_glds16(base + xoff1, xring_a + (uint32_t)(slot * XR + 1024));
+    };
+    auto issue_g = [&](int row, int slot) __attribute__((always_inline)) {
+      const int rr = min(max(row, 0), p.ho - 1);
+      const uint16_t* base = gimg + (int64_t)rr * gpitch;
+      dwb_glds16(base + goff0, gring_a + (uint32_t)(slot * GR));
+      if (lane < G::GU - 64) dwb_glds16(base + goff1, gring_a + (uint32_t)(slot * GR + 1024));
+    };
+    auto load_x = [&](int row, uint32_t* d6) __attribute__((always_inline)) {
+      const int slot = (row - rbase) % NXS;
+      const uint8_t* rp = xring + slot * XR;
+      const v2i_b a = dwb_tr8<CBW>(rp, 16 * hf, lane), b = dwb_tr8<CBW>(rp, 16 * hf + 8, lane), c = dwb_tr8<CBW>(rp, 16 * hf + 16, lane);
+      const bool rok = row >= 0 && row < p.h;
+      const uint32_t raw[6] = {(uint32_t)a[0], (uint32_t)a[1], (uint32_t)b[0], (uint32_t)b[1], (uint32_t)c[0], (uint32_t)c[1]};
+#pragma unroll
+      for (int i = 0; i < NXD; ++i) d6[i] = rok ? ((raw[i] & xm[i]) | (zp4 & ~xm[i])) : zp4;
+    };
+    // ---- prologue: the k - 2 carried rows of step 0 and the bundles of steps 0 .. PD-1 (bundle s = x rows rbase + (K-2) + 2s, +1 and gy row m0 - LH + s)
+#pragma unroll
+    for (int i = 0; i < K - 2; ++i) issue_x(rbase + i, i % NXS);
+#pragma unroll
+    for (int b = 0; b < PD; ++b) {
+      issue_x(rbase + (K - 2) + 2 * b, (K - 2 + 2 * b) % NXS); issue_x(rbase + (K - 2) + 2 * b + 1, (K - 2 + 2 * b + 1) % NXS);
+      issue_g(m0 - LH + b, b % NGS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t xd[K][NXD]; float dcw[NDR][NDC];
+#pragma unroll
+    for (int i = 0; i < K - 2; ++i) load_x(rbase + i, xd[i + 2]);          // the step shifts them down by two before it loads its own two rows
+#pragma unroll
+    for (int i = 0; i < NDR; ++i)
+#pragma unroll
+      for (int j = 0; j < NDC; ++j) dcw[i][j] = 0.0f;
+    int sth[PD];                 // stores issued by the last PD steps (for the counted wait)
+#pragma unroll
+    for (int i = 0; i < PD; ++i) sth[i] = 0;
+
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      const int m = m0 - LH + s;
+      if (s > 0) { int ny = 6 * (PD - 1); for (int i = 0; i < PD; ++i) ny += sth[i]; dwb_wait_vm(ny); }
+      { const int r = rbase + (K - 2) + 2 * (s + PD); issue_x(r, (r - rbase) % NXS); issue_x(r + 1, (r + 1 - rbase) % NXS); issue_g(m + PD, (s + PD) % NGS); }
+#pragma unroll
+      for (int ky = 0; ky < K - 2; ++ky)
+#pragma unroll
+        for (int i = 0; i < NXD; ++i) xd[ky][i] = xd[ky + 2][i];
+      load_x(2 * m - PAD + K - 2, xd[K - 2]); load_x(2 * m - PAD + K - 1, xd[K - 1]);
+#pragma unroll
+      for (int i = 0; i + 1 < NDR; ++i)
+#pragma unroll
+        for (int j = 0; j < NDC; ++j) dcw[i][j] = dcw[i + 1][j];
+      const bool drow = m >= 0 && m < p.ho;
+      if (drow) {
+        float gq[12];
+        const uint8_t* gp = gring + (s % NGS) * GR;
+        dwb_tr16<CBW>(gp, 8 * hf, lane, gq); dwb_tr16<CBW>(gp, 8 * hf + 4, lane, gq + 4); dwb_tr16<CBW>(gp, 8 * hf + 8, lane, gq + 8);
+        int acc[NDC];
+#pragma unroll
+        for (int j = 0; j < NDC; ++j) acc[j] = acc0;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+          for (int j = 0; j < NDC; ++j) {
+#pragma unroll
+            for (int q = 0; q < NPK; ++q) {
+              const int o = 2 * j + 4 * q;                       // byte offset of the 4-byte window in the lane's row
+              const uint32_t lo = xd[ky][o / 4], hi = (o / 4 + 1 < NXD) ? xd[ky][(o / 4 + 1) % NXD] : 0u;
+              const int win = (o % 4 == 0) ? (int)lo : (int)__builtin_amdgcn_alignbyte(hi, lo, 2);
+              acc[j] = __builtin_amdgcn_sdot4(win, wpk[ky][q], acc[j], false);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NDC; ++j) {
+          const bool valid = (cmask >> j) & 1u;
+          const float v = (float)acc[j];
+          const float tq = fmaf(cA, v, cB) * y_inv;
+          const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq[j] : 0.0f;
+          const float dcf = fmaf(gy, cK1, fmaf(v, cE, cF));
+          const uint32_t db = __float_as_uint(dcf), dr = sr_next16(rng);
+          const uint32_t hb = (db + (sr_on ? dr : 0x7fffu + ((db >> 16) & 1u))) >> 16;
+          dcw[NDR - 1][j] = valid ? __uint_as_float(hb << 16) : 0.0f;
+        }
+        if (m >= m0 && m < m1) {          // weight gradient: own rows, own columns j = LH .. LH + 7; x pixel of (j, kx) = 2 j + kx
+#pragma unroll
+          for (int j = LH; j < LH + 8; ++j) sdc += dcw[NDR - 1][j];
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            float xf[NXD * 4];
+#pragma unroll
+            for (int t = 2 * LH; t < 2 * LH + 14 + K; ++t) xf[t] = (float)(((xd[ky][t >> 2] ^ 0x80808080u) >> (8 * (t & 3))) & 255u);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+              for (int j = LH; j < LH + 8; ++j) wacc[ky * K + kx] = fmaf(dcw[NDR - 1][j], xf[2 * j + kx], wacc[ky * K + kx]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NDC; ++j) dcw[NDR - 1][j] = 0.0f;
+      }
+      // ---- the two dx rows that are final now: iy = 2 m + IO, IO = -1, 0 (k3) / -2, -1 (k5)
+      int nst = 0;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        constexpr int IO0 = (K == 3) ? -1 : -2;
+        const int io = IO0 + rr;                                   // compile time after unrolling
+        const int iy = 2 * m + io;
+        if (iy >= 2 * m0 && iy < 2 * m1 && iy < p.h) {
+          float a[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) a[i] = 0.0f;
+#pragma unroll
+          for (int ky = K - 1; ky >= 0; --ky) {
+            const int ty = io + PAD - ky;                          // dc row = m + ty / 2 when ty is even
+            if (((ty % 2) + 2) % 2 == 0) {
+              const int dr = NDR - 1 + ty / 2;                     // ty <= 0 and even: exact
+              if (dr >= 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+#pragma unroll
+                  for (int kx = 0; kx < K; ++kx) {
+                    const int tx = i + PAD - kx;
+                    if (((tx % 2) + 2) % 2 == 0) a[i] = fmaf(dcw[dr < 0 ? 0 : dr][tx / 2 + LH], wf[ky * K + kx], a[i]);
+                  }
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) *(uint16_t*)(orow + ((16 * hf + i) * CBW + lc) * 2) = (uint16_t)cvt_pk_bf16(a[i] * sw, 0.0f);
+          const uint4 v0 = *(const uint4*)(orow + lane * 16), v1 = *(const uint4*)(orow + 1024 + lane * 16);
+          uint16_t* drow_p = dimg + (int64_t)iy * xpitch;
+          if (ook0) *(uint4*)(drow_p + ooff0) = v0;
+          if (ook1) *(uint4*)(drow_p + ooff1) = v1;
+          nst += nst_row;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i + 1 < PD; ++i) sth[i] = sth[i + 1];
+      sth[PD - 1] = nst;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  __syncthreads();
+  float* red = (float*)smem;                       // [4][k*k][64]
+  const float zpf = (float)zpx;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) red[(wv * KK + t) * 64 + lane] = wacc[t] - zpf * sdc;
+  __syncthreads();
+  const float sx = p.qx[FROST_Q_SCALE];
+  for (int i = tid; i < KK * CBW; i += 256) {
+    const int t = i / CBW, l2 = i % CBW; const int c2 = cb * CBW + l2;
+    float sum = 0.0f;
+    for (int w2 = 0; w2 < 4; ++w2)
+      for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * KK + t) * 64 + l3];
+    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * KK + t, sum * sx);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
+static int dwb_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+// grid and row chunks: one round of resident workgroups (a multiple of 8 XCDs x channel blocks); enough wave tasks per (XCD, channel block) for >= 4 per resident wave,
+// chunks no shorter than `min_rows` rows.  rows / strips are counted in the domain the waves stream over (stride 1: input = output rows; stride 2: output rows)
+static unsigned dwb_plan(DwbP& p, int occ, int rows, int strips, int cbw, int min_rows) {
+  static const int occ_env = dwb_env("FROST_DWB_OCC"), chunks_env = dwb_env("FROST_DWB_CHUNKS");
+  const int o = occ_env > 0 ? occ_env : occ;
+  p.ncb = (p.c + cbw - 1) / cbw; p.nstrips = strips;
+  int per = (256 * o) / (8 * p.ncb); if (per < 1) per = 1;
+  int nch = 1;
+  if (chunks_env > 0) nch = chunks_env;
+  else while (nch < 8 && (int64_t)(p.n / 8 > 0 ? p.n / 8 : 1) * strips * nch < (int64_t)16 * per && (rows + 2 * nch - 1) / (2 * nch) >= min_rows) nch *= 2;
+  p.rc = (rows + nch - 1) / nch; p.nchunks = (rows + p.rc - 1) / p.rc;
+  const int64_t tasks_x = (int64_t)((p.n + 7) / 8) * strips * p.nchunks;       // wave tasks per (XCD, channel block)
+  if ((int64_t)per * 4 > tasks_x) per = (int)((tasks_x + 3) / 4);
+  return (unsigned)(8 * p.ncb * per);
+}
 template <int CBW, int PD>
 static int launch_dwb(DwbP& p, hipStream_t s) {
   using G = DwbGeo<CBW, PD>;
   const size_t lds = (size_t)4 * G::WAVE_LDS;
   static int occ = 0;
   if (!occ) {
-    hipFuncSetAttribute((const void*)k_dwb_s1<CBW, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_dwb_s1<CBW, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dwb_s1<CBW, PD>, 256, lds) != hipSuccess || occ < 1) occ = 1;
     if (occ > 8) occ = 8;
   }
-  p.ncb = (p.c + CBW - 1) / CBW; p.nstrips = (p.w + G::SW - 1) / G::SW;
-  static const int occ_env = getenv("FROST_DWB_OCC") ? atoi(getenv("FROST_DWB_OCC")) : 0;
-  static const int chunks_env = getenv("FROST_DWB_CHUNKS") ? atoi(getenv("FROST_DWB_CHUNKS")) : 0;
-  const int o = occ_env > 0 ? occ_env : occ;
-  // workgroups: one round of resident ones, a multiple of 8 XCDs x channel blocks
-  int per = (256 * o) / (8 * p.ncb); if (per < 1) per = 1;
-  // row chunks: enough wave tasks per (XCD, channel block) for >= 4 per resident wave, chunks no shorter than 14 rows
-  int nch = 1;
-  if (chunks_env > 0) nch = chunks_env;
-  else while (nch < 8 && (int64_t)(p.n / 8 > 0 ? p.n / 8 : 1) * p.nstrips * nch < (int64_t)16 * per && (p.h + 2 * nch - 1) / (2 * nch) >= 14) nch *= 2;
-  p.rc = (p.h + nch - 1) / nch; p.nchunks = (p.h + p.rc - 1) / p.rc;
-  const int64_t tasks_x = (int64_t)((p.n + 7) / 8) * p.nstrips * p.nchunks;       // wave tasks per (XCD, channel block)
-  if ((int64_t)per * 4 > tasks_x) per = (int)((tasks_x + 3) / 4);
-  hipLaunchKernelGGL((k_dwb_s1<CBW, PD>), dim3((unsigned)(8 * p.ncb * per)), dim3(256), lds, s, p);
+  const unsigned grid = dwb_plan(p, occ, p.h, (p.w + G::SW - 1) / G::SW, CBW, 14);
+  hipLaunchKernelGGL((k_dwb_s1<CBW, PD>), dim3(grid), dim3(256), lds, s, p);
+  return frost_check_launch("dw_bwd_fused");
+}
+template <int K, int CBW, int PD>
+static int launch_dwb2(DwbP& p, hipStream_t s) {
+  using G = DwbGeo2<K, CBW, PD>;
+  const size_t lds = (size_t)4 * G::WAVE_LDS;
+  static int occ = 0;
+  if (!occ) {
+    (void)hipFuncSetAttribute((const void*)k_dwb_s2<K, CBW, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dwb_s2<K, CBW, PD>, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+  }
+  const unsigned grid = dwb_plan(p, occ, p.ho, (p.wo + G::SWO - 1) / G::SWO, CBW, 7);
+  hipLaunchKernelGGL((k_dwb_s2<K, CBW, PD>), dim3(grid), dim3(256), lds, s, p);
   return frost_check_launch("dw_bwd_fused");
 }
 
 extern "C" int frost_dw_bwd_fused_ok(int h, int w, int c, int k, int stride) {
-  return (k == 3 && stride == 1 && (c % 8) == 0 && w >= 16 && h >= 8) ? 1 : 0;
+  static const int s2_on = getenv("FROST_DWB_S2") ? atoi(getenv("FROST_DWB_S2")) : 1, minw = getenv("FROST_DWB_MINW") ? atoi(getenv("FROST_DWB_MINW")) : 28;     // measured: the 14 -> 7 layer is no faster here (9 steps per task: the prologue dominates)
+  if ((c % 8) != 0 || w < minw || h < 8) return 0;
+  if (k == 3 && stride == 1) return 1;
+  if (stride == 2 && (k == 3 || k == 5) && (h % 2) == 0 && (w % 2) == 0) return s2_on ? 1 : 0;
+  return 0;
 }
 
 extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
                                   int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
                                   uint16_t* dx, float* dwq, void* stream) {
-  FROST_REQUIRE(frost_dw_bwd_fused_ok(h, w, c, k, stride), "dw_bwd_fused: unsupported shape (k = 3, stride 1, maps >= 8 x 16, channels a multiple of 8)");
+  FROST_REQUIRE(frost_dw_bwd_fused_ok(h, w, c, k, stride), "dw_bwd_fused: unsupported shape (k = 3 stride 1, or k in {3, 5} stride 2 on even maps; channels a multiple of 8)");
   FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout && dx && dwq, "dw_bwd_fused: incomplete arguments");
   DwbP p = {};
   p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.qw = qrec_w; p.wscale = wscale; p.coef = coef; p.qy = qrec_y; p.gout = gout; p.dx = dx; p.dwq = dwq;
   p.n = n; p.h = h; p.w = w; p.c = c; p.cpad = round_up(c, 16); p.relu = relu; p.sr = frost_sr_enabled();
-  p.inv_count = 1.0f / (float)((int64_t)n * h * w);
+  const int pad = (k - 1) / 2; p.ho = (h + 2 * pad - k) / stride + 1; p.wo = (w + 2 * pad - k) / stride + 1;
+  p.inv_count = 1.0f / (float)((int64_t)n * p.ho * p.wo);
   hipStream_t s = as_stream(stream);
-  // 32-channel blocks when they waste fewer lanes than 64-channel blocks (32, 72, 96 channels: the high-resolution layers), as pick_geo of frost_dw3.hip
-  static const int cbw_env = getenv("FROST_DWB_CBW") ? atoi(getenv("FROST_DWB_CBW")) : 0;
+  // 32-channel blocks when they waste fewer lanes than 64-channel blocks (32, 72, 96, 144 channels: the high-resolution layers), as pick_geo of frost_dw3.hip
+  static const int cbw_env = dwb_env("FROST_DWB_CBW");
   const bool c32 = cbw_env ? (cbw_env == 32) : (round_up(c, 32) < round_up(c, 64));
-  return c32 ? launch_dwb<32, 2>(p, s) : launch_dwb<64, 2>(p, s);
+  if (stride == 1) return c32 ? launch_dwb<32, 2>(p, s) : launch_dwb<64, 2>(p, s);
+  if (k == 3) return c32 ? launch_dwb2<3, 32, 2>(p, s) : launch_dwb2<3, 64, 2>(p, s);
+  return c32 ? launch_dwb2<5, 32, 2>(p, s) : launch_dwb2<5, 64, 2>(p, s);
 }

@@ -105,11 +105,14 @@ def test_fused_depthwise_backward_exact_without_stochastic_rounding(case, tmp_pa
 # same strip-streaming pass) against frost_dw_conv_bwd_dc_wgrad + frost_dw_dgrad, with round-to-nearest dc (FROST_SR=0): same dc, the data gradient summed in k_dw3_dgrad's
 # order -> dx BIT-IDENTICAL up to dc elements on a bf16 rounding boundary (S1 / S2 are float atomics); the weight gradient differs by the order of its fp32 sums only.
 # 32- and 64-channel blocks, partial channel blocks (72, 40, 168), maps that are not a multiple of the strip width (30, 28), several row chunks, fewer images than XCDs.
-@pytest.mark.parametrize("case", [("dw", 32, 32, 3, 1, 112, 16), ("dw", 72, 72, 3, 1, 56, 12), ("dw", 240, 240, 3, 1, 28, 9), ("dw", 40, 40, 3, 1, 30, 5), ("dw", 168, 168, 3, 1, 28, 3)],
+# Stride 2 (k = 3, 5): 112 -> 56, 56 -> 28, 28 -> 14, 14 -> 7 and ragged relatives (a last strip that is half outside the map, channel blocks of 8 .. 64 live lanes).
+@pytest.mark.parametrize("case", [("dw", 32, 32, 3, 1, 112, 16), ("dw", 72, 72, 3, 1, 56, 12), ("dw", 240, 240, 3, 1, 28, 9), ("dw", 40, 40, 3, 1, 30, 5), ("dw", 168, 168, 3, 1, 28, 3),
+                                  ("dw", 96, 96, 3, 2, 112, 10), ("dw", 144, 144, 5, 2, 56, 12), ("dw", 336, 336, 5, 2, 28, 9), ("dw", 672, 672, 5, 2, 14, 11),
+                                  ("dw", 40, 40, 3, 2, 30, 5), ("dw", 72, 72, 5, 2, 20, 3), ("dw", 168, 168, 3, 2, 28, 8)],
                          ids=lambda c: "_".join(str(v) for v in c))
 @pytest.mark.parametrize("chunks", ["0", "3"])
 def test_one_sweep_depthwise_backward_exact_without_stochastic_rounding(case, chunks, tmp_path):
-    one = run(str(tmp_path), "one", case, {"FROST_SR": "0", "FROST_DW_BWD_ONE": "1", "FROST_DWB_CHUNKS": chunks, "DIGEST_CALLS": os.path.join(str(tmp_path), "calls.txt")})
+    one = run(str(tmp_path), "one", case, {"FROST_SR": "0", "FROST_DW_BWD_ONE": "1", "FROST_DWB_CHUNKS": chunks, "FROST_DWB_MINW": "8", "DIGEST_CALLS": os.path.join(str(tmp_path), "calls.txt")})
     sep = run(str(tmp_path), "sep", case, {"FROST_SR": "0", "FROST_DW_BWD_ONE": "0"})
     assert "frost_dw_bwd_fused" in open(os.path.join(str(tmp_path), "calls.txt")).read()
     assert one["y"].tobytes() == sep["y"].tobytes()
@@ -117,7 +120,8 @@ def test_one_sweep_depthwise_backward_exact_without_stochastic_rounding(case, ch
     differ = a != b
     assert float(differ.mean()) <= 2e-3, float(differ.mean())
     assert relerr(a, b) <= 2e-4
-    assert relerr(one["dw"], sep["dw"]) <= 2e-5 and relerr(one["dgamma"], sep["dgamma"]) <= 2e-5 and relerr(one["dbeta"], sep["dbeta"]) <= 2e-5
+    # (the weight-gradient sums are fp32 in both paths but grouped differently -- per lane across a whole strip here, per tile there: 4e-5 on the smallest case)
+    assert relerr(one["dw"], sep["dw"]) <= 1e-4 and relerr(one["dgamma"], sep["dgamma"]) <= 1e-4 and relerr(one["dbeta"], sep["dbeta"]) <= 2e-5
 
 
 def test_one_sweep_depthwise_backward_with_stochastic_rounding_matches_at_the_bf16_level(tmp_path):
