@@ -810,10 +810,17 @@ int frost_dwm_ok(int k, int stride, int c);
 int frost_dwm_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k, int mode,
                   void* stats, const float* coef, const float* qrec_y, int relu, int8_t* y, const FrostFinDesc* fin, hipStream_t s);
 
+// the strip-streaming forms of the statistics / emit / reduce passes (csrc/frost_dwb.hip) take the tiled layers they have an instance for
+int frost_dws_ok(int h, int w, int c, int k, int stride, int mode);
+int frost_dws_launch(int mode, const int8_t* x, const float* qx, const int8_t* wq, const int32_t* wsum, int n, int h, int w, int c, int k, int stride,
+                     void* stats, float* coef, const float* qy, int relu, int8_t* y, const uint16_t* gout, const FrostFinDesc* fin, hipStream_t s);
+
 extern "C" int frost_dw_conv_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n,
                                  int h, int w, int c, int k, int stride, int mode, void* stats, const float* coef,
                                  const float* qrec_y, int relu, int8_t* y, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
+  if (mode <= 1 && frost_dws_ok(h, w, c, k, stride, mode))
+    return frost_dws_launch(mode, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride, stats, (float*)coef, qrec_y, relu, y, nullptr, nullptr, as_stream(stream));
   if (mode != 3 && frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, mode, stats, coef, qrec_y, relu, y, nullptr, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = (float*)coef; p.qy = qrec_y; p.relu = relu; p.y = y; p.cvt = (mode == 2) ? 1 : ((mode == 3) ? 2 : 0);
@@ -823,6 +830,8 @@ extern "C" int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const
                                      int stride, void* stats, const FrostFinDesc* fin, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
   FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y, "dw_fwd_fin: incomplete finalize descriptor");
+  if (frost_dws_ok(h, w, c, k, stride, 0))
+    return frost_dws_launch(0, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride, stats, nullptr, nullptr, 0, nullptr, nullptr, fin, as_stream(stream));
   if (frost_dwm_ok(k, stride, c)) return frost_dwm_fwd(x, qrec_x, wq_pack, wsum, n, h, w, c, k, 0, stats, nullptr, nullptr, 0, nullptr, fin, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.stats = (uint8_t*)stats; p.coef = fin->coef; p.qy = fin->qrec_y; p.relu = fin->relu; p.fin = *fin; p.fin_on = 1;
@@ -832,6 +841,8 @@ extern "C" int frost_dw_conv_bwd(const int8_t* x, const float* qrec_x, const int
                                  const float* qrec_w, int n, int h, int w, int c, int k, int stride, int pass, float* coef,
                                  const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dc, void* stream) {
   FROST_REQUIRE(c % 8 == 0, "dw: channels must be a multiple of 8");
+  if (pass == 0 && frost_dws_ok(h, w, c, k, stride, 2))
+    return frost_dws_launch(2, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride, nullptr, coef, qrec_y, relu, nullptr, gout, nullptr, as_stream(stream));
   Dw3P p = {}; fill3(p, x, qrec_x, wq_pack, wsum, n, h, w, c, k, stride);
   p.coef = coef; p.qy = qrec_y; p.relu = relu; p.gout = gout; p.dc = dc; p.qw = qrec_w; p.sr = frost_sr_enabled();
   return dispatch3(p, k, stride, geo_env(pick_geo(c, p.wo, k, stride, false)), pass == 0 ? 2 : 3, as_stream(stream));

@@ -573,11 +573,253 @@ __global__ __launch_bounds__(256, 2) void k_dwb_s2(const DwbP p) {
   }
 }
 
+// ================================================================================================ the single-sweep passes on the same skeleton
+// Statistics pass, emit pass and backward reduce pass of the tiled depthwise layers (k_dw3 modes 0 / 1 / 2, frost_dw3.hip: same integer conv, same epilogue expressions)
+// as strip-streaming waves: a lane owns one channel and 8 OUTPUT columns, a step is one output row (S new x rows by direct-to-LDS copy, the other k - S carried in
+// registers; the backward reduce pass also takes the gy row).  No halo columns are recomputed here (nothing consumes a neighbour's result), no workgroup barrier, no tile
+// halo re-read in y.  Statistics are exact integers (sum, sum of squares in fp64 < 2^53, min, max): bit-identical to k_dw3 whatever the summation order; the emit pass
+// is a pure function of the accumulator; S1 / S2 of the reduce pass are fp32 sums grouped per lane here and per tile there (1e-7).
+enum { W_STATS = 0, W_EMIT = 1, W_BRED = 2 };
+struct DwsP {
+  const int8_t* x; const float* qx; const int8_t* wq; const int32_t* wsum;
+  uint8_t* stats; float* coef; const float* qy; int8_t* y; const uint16_t* gout;
+  int n, h, w, c, cpad, relu, ho, wo; float inv_count;
+  int ncb, nstrips, nchunks, rc;
+  FrostFinDesc fin; int fin_on;
+};
+template <int K, int S, int CBW, int PD, int MODE>
+struct DwsGeo {
+  static constexpr int PAD = (K - 1) / 2, HALF = 64 / CBW, SW = 8 * HALF;
+  static constexpr int NXW = 7 * S + K, NTR = (NXW + 7) / 8, NXD = 2 * NTR;                   // x window of a lane (pixels), transposed reads, dwords
+  static constexpr int XPX = S * 8 * (HALF - 1) + NXW;
+  static constexpr int XR = ((XPX * CBW + 15) / 16) * 16, GR = SW * CBW * 2, OR = SW * CBW;   // x row record, gy row record (1 KB), int8 out row (512 B)
+  static constexpr int XU = XR / 16, NXI = (XU + 63) / 64;                                    // 16-byte units / copy instructions per x row
+  static constexpr int NXS = S * PD + ((K - S > S) ? K - S : S), NGS = PD + 1;
+  static constexpr int XSL = 8 * CBW;
+  static constexpr int X_OFF = 0, G_OFF = NXS * XR + XSL, O_OFF = G_OFF + ((MODE == W_BRED) ? NGS * GR : 0), WAVE_RAW = O_OFF + ((MODE == W_EMIT) ? OR : 0);
+  static constexpr int WAVE_LDS = (WAVE_RAW < 2048) ? 2048 : WAVE_RAW;                        // (the final fold of the statistics needs 6 KB + 16 B per workgroup)
+  static constexpr int NDMA = S * NXI + ((MODE == W_BRED) ? 1 : 0), NST = (MODE == W_EMIT) ? 1 : 0;
+  static_assert(NXI <= 2 && GR == 1024, "one or two copy instructions per x row, one per gy row");
+};
+
+template <int K, int S, int CBW, int PD, int MODE>
+__global__ __launch_bounds__(256, 3) void k_dws(const DwsP p) {
+  using G = DwsGeo<K, S, CBW, PD, MODE>;
+  constexpr int PAD = G::PAD, NXD = G::NXD, NTR = G::NTR, SW = G::SW, XR = G::XR, GR = G::GR, NXS = G::NXS, NGS = G::NGS, KK = K * K, NPK = (K == 3) ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint8_t* const wl = smem + (size_t)wv * G::WAVE_LDS;
+  uint8_t* const xring = wl + G::X_OFF; uint8_t* const gring = wl + G::G_OFF; uint8_t* const orow = wl + G::O_OFF;
+  const uint32_t xring_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)xring);
+  const uint32_t gring_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)gring);
+  const int lc = lane & (CBW - 1), hf = lane / CBW;
+  const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3, nl = (int)gridDim.x >> 3;
+  const int cb = li % p.ncb, lwg = li / p.ncb, nlc = nl / p.ncb;
+  const int img_lo = (int)(((int64_t)p.n * xcd) >> 3), img_hi = (int)(((int64_t)p.n * (xcd + 1)) >> 3);
+  const int pit = p.nstrips * p.nchunks, ntask = (img_hi - img_lo) * pit;
+  const int ch = cb * CBW + lc; const bool chok = ch < p.c;
+
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]);
+  const uint32_t zp4 = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+  int wpk[K][NPK];
+  {
+    int8_t taps[KK];
+    load_taps_i8<KK>(p.wq, p.cpad, ch, chok, taps);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) { const uint32_t b = (uint32_t)(uint8_t)taps[ky * K + kx]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+      wpk[ky][0] = (int)lo; if (NPK > 1) wpk[ky][NPK - 1] = (int)hi;
+    }
+  }
+  const int chc = chok ? ch : 0;
+  const int acc0 = chok ? (128 - zpx) * p.wsum[chc] : 0;
+  float cA = 0, cB = 0, cR = 0, cMR = 0, y_inv = 1.0f, y_zpf = 0.0f, t_lo = 0.0f, t_hi = 0.0f, qcap = 255.0f; bool lowq = false;
+  if (MODE != W_STATS) {
+    y_inv = 1.0f / p.qy[FROST_Q_SCALE]; const int zpy = __float_as_int(p.qy[FROST_Q_ZP]); y_zpf = (float)zpy;
+    if (chok) {
+      cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
+      if (MODE == W_BRED) { const float m = p.coef[FROST_COEF_M * p.cpad + ch]; cR = p.coef[FROST_COEF_R * p.cpad + ch]; cMR = -m * cR; }
+    }
+    if (MODE == W_EMIT) { qcap = (float)q_hi(p.qy); lowq = qcap < 255.0f; }
+    if (MODE == W_BRED) {
+      const int qhi = q_hi(p.qy);
+      const float hi0 = (float)qhi + 0.5f - (float)zpy;
+      t_hi = ((qhi - zpy) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+      if (!p.relu) { const float lo0 = -(float)zpy - 0.5f; t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+    }
+  }
+  const float relu_floor = p.relu ? 0.0f : -INFINITY;
+  double st1 = 0.0, st2 = 0.0; float smn = INFINITY, smx = -INFINITY, r1 = 0.0f, r2 = 0.0f;
+
+  const int64_t xpitch = (int64_t)p.w * p.c, opitch = (int64_t)p.wo * p.c;
+  for (int tt = lwg * 4 + wv; tt < ntask; tt += nlc * 4) {
+    const int img = img_lo + tt / pit; const int rem = tt - (tt / pit) * pit;
+    const int chunk = rem / p.nstrips, strip = rem - chunk * p.nstrips;
+    const int m0 = chunk * p.rc, m1 = min(m0 + p.rc, p.ho);
+    const int oc0s = strip * SW, NS = m1 - m0, rbase = S * m0 - PAD;
+    const int8_t* const ximg = p.x + (int64_t)img * p.h * xpitch;
+    const uint16_t* const gimg = (MODE == W_BRED) ? p.gout + (int64_t)img * p.ho * opitch : nullptr;
+    int8_t* const yimg = (MODE == W_EMIT) ? p.y + (int64_t)img * p.ho * opitch : nullptr;
+    int xoff0, xoff1 = 0, goff = 0, ooff = 0; bool ook = false;
+    {
+      constexpr int UPX = CBW / 16, UPG = CBW / 8;
+      auto xo = [&](int u) { const int px = u / UPX, cu = u % UPX, col = min(max(S * oc0s - PAD + px, 0), p.w - 1); int cn = cb * CBW + cu * 16; if (cn >= p.c) cn = 0; return col * p.c + cn; };
+      xoff0 = xo(lane); if (G::NXI > 1) xoff1 = xo(64 + lane);
+      const int px = lane / UPG, cu = lane % UPG, col = oc0s + px, cn = cb * CBW + cu * 8;
+      ook = col < p.wo && cn < p.c; ooff = col * p.c + cn;                      // 8-channel unit of the out row (emit) ...
+      goff = min(col, p.wo - 1) * p.c + (cn < p.c ? cn : 0);                   // ... and of the gy row (reduce pass), clamped
+    }
+    const int oc0 = oc0s + 8 * hf;
+    uint32_t xm[NXD]; uint32_t cmask = 0;
+#pragma unroll
+    for (int i = 0; i < NXD; ++i) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { const int col = S * oc0 - PAD + 4 * i + b; if (col >= 0 && col < p.w) m |= 0xffu << (8 * b); }
+      xm[i] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (oc0 + j < p.wo && chok) cmask |= 1u << j;
+
+    auto issue_x = [&](int row) __attribute__((always_inline)) {
+      const int slot = (row - rbase) % NXS;
+      const int8_t* base = ximg + (int64_t)min(max(row, 0), p.h - 1) * xpitch;
+      if (G::XU >= 64 || lane < G::XU) dwb_glds16(base + xoff0, xring_a + (uint32_t)(slot * XR));
+      if (G::NXI > 1) { if (lane < G::XU - 64) dwb_glds16(base + xoff1, xring_a + (uint32_t)(slot * XR + 1024)); }
+    };
+    auto issue_g = [&](int row, int slot) __attribute__((always_inline)) {
+      if (MODE == W_BRED) dwb_glds16(gimg + (int64_t)min(max(row, 0), p.ho - 1) * opitch + goff, gring_a + (uint32_t)(slot * GR));
+    };
+    auto load_x = [&](int row, uint32_t* d) __attribute__((always_inline)) {
+      const uint8_t* rp = xring + ((row - rbase) % NXS) * XR;
+      const bool rok = row >= 0 && row < p.h;
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) {
+        const v2i_b a = dwb_tr8<CBW>(rp, 8 * S * hf + 8 * t, lane);
+        d[2 * t] = rok ? (((uint32_t)a[0] & xm[2 * t]) | (zp4 & ~xm[2 * t])) : zp4;
+        d[2 * t + 1] = rok ? (((uint32_t)a[1] & xm[2 * t + 1]) | (zp4 & ~xm[2 * t + 1])) : zp4;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < K - S; ++i) issue_x(rbase + i);
+#pragma unroll
+    for (int b = 0; b < PD; ++b) {
+#pragma unroll
+      for (int i = 0; i < S; ++i) issue_x(rbase + (K - S) + S * b + i);
+      issue_g(m0 + b, b % NGS);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t xd[K][NXD];
+#pragma unroll
+    for (int i = 0; i < K - S; ++i) load_x(rbase + i, xd[i + S]);
+
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      const int m = m0 + s;
+      if (s > 0) dwb_wait_vm((PD - 1) * G::NDMA + min(s, PD) * G::NST);
+#pragma unroll
+      for (int i = 0; i < S; ++i) issue_x(rbase + (K - S) + S * (s + PD) + i);
+      issue_g(m + PD, (s + PD) % NGS);
+#pragma unroll
+      for (int ky = 0; ky < K - S; ++ky)
+#pragma unroll
+        for (int i = 0; i < NXD; ++i) xd[ky][i] = xd[ky + S][i];
+#pragma unroll
+      for (int i = 0; i < S; ++i) load_x(S * m - PAD + (K - S) + i, xd[K - S + i]);
+      int acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = acc0;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int q = 0; q < NPK; ++q) {
+            const int o = S * j + 4 * q;
+            const uint32_t lo = xd[ky][o / 4], hi = (o / 4 + 1 < NXD) ? xd[ky][(o / 4 + 1) % NXD] : 0u;
+            const int win = (o % 4 == 0) ? (int)lo : (int)__builtin_amdgcn_alignbyte(hi, lo, o % 4);
+            acc[j] = __builtin_amdgcn_sdot4(win, wpk[ky][q], acc[j], false);
+          }
+      if (MODE == W_STATS) {
+        int t1 = 0, tmn = INT32_MAX, tmx = INT32_MIN; double t2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool valid = (cmask >> j) & 1u;
+          const int vi = acc[j]; const double v = (double)vi;
+          t1 += valid ? vi : 0; t2 = valid ? fma(v, v, t2) : t2; tmn = valid ? min(tmn, vi) : tmn; tmx = valid ? max(tmx, vi) : tmx;
+        }
+        st1 += (double)t1; st2 += t2; smn = fminf(smn, (float)tmn); smx = fmaxf(smx, (float)tmx);
+      } else if (MODE == W_EMIT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yv = fmaf(cA, (float)acc[j], cB);
+          float qv = rintf(fmaxf(yv, relu_floor) * y_inv) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          orow[(8 * hf + j) * CBW + lc] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
+        }
+        const uint2 v = *(const uint2*)(orow + lane * 8);
+        if (ook) *(uint2*)(yimg + (int64_t)m * opitch + ooff) = v;
+      } else {
+        float gq[8];
+        const uint8_t* gp = gring + (s % NGS) * GR;
+        dwb_tr16<CBW>(gp, 8 * hf, lane, gq); dwb_tr16<CBW>(gp, 8 * hf + 4, lane, gq + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool valid = (cmask >> j) & 1u;
+          const float v = (float)acc[j];
+          const float tq = fmaf(cA, v, cB) * y_inv;
+          const float gy = (valid && tq > t_lo && tq <= t_hi) ? gq[j] : 0.0f;
+          r1 += gy; r2 = fmaf(gy, fmaf(v, cR, cMR), r2);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  if (MODE == W_STATS || MODE == W_BRED) {      // the waves' lane-local partials, one global atomic set per channel and workgroup (k_dw3's tail)
+    __syncthreads();
+    double* red_d = (double*)smem; float* red_f = (float*)(red_d + 4 * 64 * 2);
+    if (MODE == W_STATS) { red_d[(wv * 64 + lane) * 2] = st1; red_d[(wv * 64 + lane) * 2 + 1] = st2; red_f[(wv * 64 + lane) * 2] = smn; red_f[(wv * 64 + lane) * 2 + 1] = smx; }
+    else { red_f[(wv * 64 + lane) * 2] = r1; red_f[(wv * 64 + lane) * 2 + 1] = r2; }
+    __syncthreads();
+    if (tid < CBW && (cb * CBW + tid) < p.c) {
+      const int ch2 = cb * CBW + tid;
+      if (MODE == W_STATS) {
+        double a = 0, b = 0; float c = INFINITY, d = -INFINITY;
+        for (int w2 = 0; w2 < 4; ++w2)
+          for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_d[(w2 * 64 + l2) * 2]; b += red_d[(w2 * 64 + l2) * 2 + 1]; c = fminf(c, red_f[(w2 * 64 + l2) * 2]); d = fmaxf(d, red_f[(w2 * 64 + l2) * 2 + 1]); }
+        long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+        int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+        if (c <= d) {
+          atomicAdd((unsigned long long*)&g_s1[ch2], (unsigned long long)(long long)a); atomicAdd(&g_s2[ch2], (unsigned long long)b);
+          atomicMin(&g_mn[ch2], (int)c); atomicMax(&g_mx[ch2], (int)d);
+        }
+      } else {
+        float a = 0, b = 0;
+        for (int w2 = 0; w2 < 4; ++w2)
+          for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_f[(w2 * 64 + l2) * 2]; b += red_f[(w2 * 64 + l2) * 2 + 1]; }
+        atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch2, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch2, b);
+      }
+    }
+    if (MODE == W_STATS && p.fin_on) {       // last workgroup done -> conv finalize in this launch (see frost_common.h)
+      int* sflag = (int*)smem;
+      if (last_block_done2(p.fin.counter, gridDim.x, sflag)) {
+        float* sh = (float*)(smem + 16);
+        conv_finalize_dev(p.stats, (int64_t)p.n * p.ho * p.wo, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar,
+                          p.fin.nbt, p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int dwb_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
 // grid and row chunks: one round of resident workgroups (a multiple of 8 XCDs x channel blocks); enough wave tasks per (XCD, channel block) for >= 4 per resident wave,
 // chunks no shorter than `min_rows` rows.  rows / strips are counted in the domain the waves stream over (stride 1: input = output rows; stride 2: output rows)
-static unsigned dwb_plan(DwbP& p, int occ, int rows, int strips, int cbw, int min_rows) {
+template <typename PT>
+static unsigned dwb_plan(PT& p, int occ, int rows, int strips, int cbw, int min_rows) {
   static const int occ_env = dwb_env("FROST_DWB_OCC"), chunks_env = dwb_env("FROST_DWB_CHUNKS");
   const int o = occ_env > 0 ? occ_env : occ;
   p.ncb = (p.c + cbw - 1) / cbw; p.nstrips = strips;
@@ -644,4 +886,49 @@ extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const in
   if (stride == 1) return c32 ? launch_dwb<32, 2>(p, s) : launch_dwb<64, 2>(p, s);
   if (k == 3) return c32 ? launch_dwb2<3, 32, 2>(p, s) : launch_dwb2<3, 64, 2>(p, s);
   return c32 ? launch_dwb2<5, 32, 2>(p, s) : launch_dwb2<5, 64, 2>(p, s);
+}
+
+// ---- the single-sweep passes: called by the frost_dw_conv_fwd / _fwd_fin / _bwd entries of frost_dw3.hip when the shape qualifies (FROST_DW_STREAM: bit 0 statistics, bit 1 emit,
+// bit 2 backward reduce pass; default 0 = off: bit-identical results, but measured no faster than k_dw3's tile kernels inside the step, profiles/r05_dw_onesweep_ab.txt).  mode: 0 statistics (fin != NULL: with the folded finalize), 1 emit, 2 reduce pass
+int frost_dws_ok(int h, int w, int c, int k, int stride, int mode) {
+  static const int mask = getenv("FROST_DW_STREAM") ? atoi(getenv("FROST_DW_STREAM")) : 0, minw = getenv("FROST_DWS_MINW") ? atoi(getenv("FROST_DWS_MINW")) : 28;
+  if (!((mask >> mode) & 1) || (c % 8) != 0 || w < minw || h < 8) return 0;
+  if (k == 3 && stride == 1) return 1;
+  if (stride == 2 && (k == 3 || k == 5) && (h % 2) == 0 && (w % 2) == 0) return 1;
+  return 0;
+}
+template <int K, int S, int CBW, int MODE>
+static int launch_dws(DwsP& p, hipStream_t s) {
+  constexpr int PD = 2;
+  using G = DwsGeo<K, S, CBW, PD, MODE>;
+  const size_t lds = (size_t)4 * G::WAVE_LDS;
+  static int occ = 0;
+  if (!occ) {
+    (void)hipFuncSetAttribute((const void*)k_dws<K, S, CBW, PD, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dws<K, S, CBW, PD, MODE>, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    if (occ > 8) occ = 8;
+  }
+  const unsigned grid = dwb_plan(p, occ, p.ho, (p.wo + G::SW - 1) / G::SW, CBW, 7);
+  hipLaunchKernelGGL((k_dws<K, S, CBW, PD, MODE>), dim3(grid), dim3(256), lds, s, p);
+  return frost_check_launch("dw_stream");
+}
+template <int MODE>
+static int dispatch_dws(DwsP& p, int k, int stride, hipStream_t s) {
+  static const int cbw_env = dwb_env("FROST_DWB_CBW");
+  const bool c32 = cbw_env ? (cbw_env == 32) : (round_up(p.c, 32) < round_up(p.c, 64));
+  if (stride == 1) return c32 ? launch_dws<3, 1, 32, MODE>(p, s) : launch_dws<3, 1, 64, MODE>(p, s);
+  if (k == 3) return c32 ? launch_dws<3, 2, 32, MODE>(p, s) : launch_dws<3, 2, 64, MODE>(p, s);
+  return c32 ? launch_dws<5, 2, 32, MODE>(p, s) : launch_dws<5, 2, 64, MODE>(p, s);
+}
+int frost_dws_launch(int mode, const int8_t* x, const float* qx, const int8_t* wq, const int32_t* wsum, int n, int h, int w, int c, int k, int stride,
+                     void* stats, float* coef, const float* qy, int relu, int8_t* y, const uint16_t* gout, const FrostFinDesc* fin, hipStream_t s) {
+  DwsP p = {};
+  p.x = x; p.qx = qx; p.wq = wq; p.wsum = wsum; p.stats = (uint8_t*)stats; p.coef = coef; p.qy = qy; p.relu = relu; p.y = y; p.gout = gout;
+  p.n = n; p.h = h; p.w = w; p.c = c; p.cpad = round_up(c, 16);
+  const int pad = (k - 1) / 2; p.ho = (h + 2 * pad - k) / stride + 1; p.wo = (w + 2 * pad - k) / stride + 1;
+  p.inv_count = 1.0f / (float)((int64_t)n * p.ho * p.wo);
+  if (fin) { p.fin = *fin; p.fin_on = 1; p.coef = fin->coef; p.qy = fin->qrec_y; p.relu = fin->relu; }
+  if (mode == 0) return dispatch_dws<W_STATS>(p, k, stride, s);
+  if (mode == 1) return dispatch_dws<W_EMIT>(p, k, stride, s);
+  return dispatch_dws<W_BRED>(p, k, stride, s);
 }

@@ -14,7 +14,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PLAIN = dict(FROST_PW_RESMASK="0", FROST_PW_IO="0", FROST_PW_GL="0", FROST_PW_CSPLIT="0", FROST_DW_GEO="0", FROST_DW_FUSE="0", FROST_PW_FUSE="0", FROST_DW_XCD="0", FROST_WG_XCD="0",
-             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0", FROST_BLOCK_DWBRED="0", FROST_PWC="0", FROST_PWC_EMIT="0", FROST_DW_BWD_ONE="0")
+             FROST_PW_SPEC="0", FROST_DW_SPEC="0", FROST_DGRAD_WIDE="0", FROST_INFER_WIDE="0", FROST_PW_KEEP="0", FROST_BLOCK_DWBWD="0", FROST_BLOCK_DWBRED="0", FROST_PWC="0", FROST_PWC_EMIT="0", FROST_DW_BWD_ONE="0", FROST_DW_STREAM="0")
 FAST = dict()
 CASES = [("pw", 16, 96, 1, 1, 112, 64), ("pw", 32, 16, 1, 1, 112, 64), ("pw", 72, 24, 1, 1, 56, 128), ("pw", 144, 40, 1, 1, 28, 512), ("dw", 72, 72, 3, 1, 56, 64), ("pw", 56, 168, 1, 1, 28, 128), ("pw", 40, 16, 1, 1, 28, 64), ("pw", 56, 336, 1, 1, 28, 512), ("pw", 96, 24, 1, 1, 56, 128), ("pw", 24, 144, 1, 1, 56, 128), ("pw", 240, 1440, 1, 1, 7, 512),
          ("pw", 1728, 320, 1, 1, 7, 256), ("dw", 96, 96, 3, 2, 112, 32), ("dw", 32, 32, 3, 1, 112, 32), ("dw", 1440, 1440, 5, 1, 7, 256),
@@ -130,3 +130,18 @@ def test_one_sweep_depthwise_backward_with_stochastic_rounding_matches_at_the_bf
     sep = run(str(tmp_path), "sep", case, {"FROST_DW_BWD_ONE": "0"})
     assert relerr(bf16_to_f32(one["dx"]), bf16_to_f32(sep["dx"])) <= 8e-3
     assert relerr(one["dw"], sep["dw"]) <= 1e-2 and relerr(one["dgamma"], sep["dgamma"]) <= 1e-2 and relerr(one["dbeta"], sep["dbeta"]) <= 1e-3
+
+
+# The strip-streaming statistics / emit / reduce passes (k_dws, csrc/frost_dwb.hip) against k_dw3's tile kernels: the statistics are exact integers, the finalize and the
+# emit pass pure functions of them -> outputs, observer / BatchNorm state BIT-IDENTICAL; S1 / S2 of the reduce pass are fp32 sums in another grouping (1e-6 on dbeta / dgamma).
+@pytest.mark.parametrize("case", [("dw", 32, 32, 3, 1, 112, 16), ("dw", 72, 72, 3, 1, 56, 12), ("dw", 240, 240, 3, 1, 28, 9), ("dw", 40, 40, 3, 1, 30, 5),
+                                  ("dw", 96, 96, 3, 2, 112, 10), ("dw", 144, 144, 5, 2, 56, 12), ("dw", 336, 336, 5, 2, 28, 9), ("dw", 40, 40, 3, 2, 30, 5), ("dw", 72, 72, 5, 2, 36, 3)],
+                         ids=lambda c: "_".join(str(v) for v in c))
+def test_streaming_depthwise_passes_are_exact(case, tmp_path):
+    new = run(str(tmp_path), "new", case, {"FROST_SR": "0", "FROST_DW_STREAM": "7", "FROST_DWS_MINW": "8", "DIGEST_CALLS": os.path.join(str(tmp_path), "calls.txt")})
+    old = run(str(tmp_path), "old", case, {"FROST_SR": "0", "FROST_DW_STREAM": "0"})
+    for k in ("y", "qy", "rm", "rv"):
+        assert new[k].tobytes() == old[k].tobytes(), k
+    assert relerr(new["dbeta"], old["dbeta"]) <= 1e-5 and relerr(new["dgamma"], old["dgamma"]) <= 1e-4
+    a, b = bf16_to_f32(new["dx"]).astype(np.float64), bf16_to_f32(old["dx"]).astype(np.float64)
+    assert float((a != b).mean()) <= 2e-3 and relerr(a, b) <= 2e-4
