@@ -23,6 +23,15 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DWB_PD
+#define DWB_PD 1          // rows of prefetch distance of the direct-to-LDS rings (measured: profiles/r05_dw_onesweep_ab.txt)
+#endif
+#ifndef DWB_LB1
+#define DWB_LB1 3         // waves per SIMD the register allocator leaves room for: stride-1 kernel / stride-2 kernels
+#endif
+#ifndef DWB_LB2
+#define DWB_LB2 2
+#endif
 typedef int v2i_b __attribute__((ext_vector_type(2)));
 typedef short v4s_b __attribute__((ext_vector_type(4)));
 
@@ -73,7 +82,7 @@ struct DwbGeo {
 };
 
 template <int CBW, int PD>
-__global__ __launch_bounds__(256, 3) void k_dwb_s1(const DwbP p) {
+__global__ __launch_bounds__(256, DWB_LB1) void k_dwb_s1(const DwbP p) {
   using G = DwbGeo<CBW, PD>;
   constexpr int SW = G::SW, XR = G::XR, GR = G::GR, NXS = G::NXS, NGS = G::NGS;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -317,7 +326,7 @@ struct DwbGeo2 {
 };
 
 template <int K, int CBW, int PD>
-__global__ __launch_bounds__(256, 2) void k_dwb_s2(const DwbP p) {
+__global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
   using G = DwbGeo2<K, CBW, PD>;
   constexpr int PAD = G::PAD, LH = G::LH, NDC = G::NDC, XL = G::XL, NDR = G::NDR, NXD = G::NXD, SWO = G::SWO, SWI = G::SWI;
   constexpr int XR = G::XR, GR = G::GR, NXS = G::NXS, NGS = G::NGS, KK = K * K, NPK = (K == 3) ? 1 : 2;
@@ -883,9 +892,9 @@ extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const in
   // 32-channel blocks when they waste fewer lanes than 64-channel blocks (32, 72, 96, 144 channels: the high-resolution layers), as pick_geo of frost_dw3.hip
   static const int cbw_env = dwb_env("FROST_DWB_CBW");
   const bool c32 = cbw_env ? (cbw_env == 32) : (round_up(c, 32) < round_up(c, 64));
-  if (stride == 1) return c32 ? launch_dwb<32, 2>(p, s) : launch_dwb<64, 2>(p, s);
-  if (k == 3) return c32 ? launch_dwb2<3, 32, 2>(p, s) : launch_dwb2<3, 64, 2>(p, s);
-  return c32 ? launch_dwb2<5, 32, 2>(p, s) : launch_dwb2<5, 64, 2>(p, s);
+  if (stride == 1) return c32 ? launch_dwb<32, DWB_PD>(p, s) : launch_dwb<64, DWB_PD>(p, s);
+  if (k == 3) return c32 ? launch_dwb2<3, 32, DWB_PD>(p, s) : launch_dwb2<3, 64, DWB_PD>(p, s);
+  return c32 ? launch_dwb2<5, 32, DWB_PD>(p, s) : launch_dwb2<5, 64, DWB_PD>(p, s);
 }
 
 // ---- the single-sweep passes: called by the frost_dw_conv_fwd / _fwd_fin / _bwd entries of frost_dw3.hip when the shape qualifies (FROST_DW_STREAM: bit 0 statistics, bit 1 emit,

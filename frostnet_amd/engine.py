@@ -45,6 +45,8 @@ _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "1") != "0"
 _STEM_FUSED_CVT = os.environ.get("FROST_STEM_CONVERTED", "1") != "0"   # converted inference: QuantStub + stem conv in one launch from the fp32 image (frost_stem_converted), bit-identical
 _BLOCK_SQCAT = os.environ.get("FROST_BLOCK_SQCAT", "1") != "0"      # squeeze_conv emit + cat requantisation in one launch (frost_sq_emit_cat), bit-identical to the two it replaces
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
+_WG_PRIO = int(os.environ.get("FROST_WG_PRIO", "0"))        # priority of the weight-gradient stream(s) (torch: lower = higher priority); A/B switch
+_WG_NSTREAMS = int(os.environ.get("FROST_WG_NSTREAMS", "1"))  # weight-gradient streams taken round-robin per fork (single-GPU step only); A/B switch
 _WG_STREAM = int(os.environ.get("FROST_WG_STREAM", "1"))   # bit 0: pointwise, bit 1: depthwise weight gradients on a second stream (A/B switch)
 # depthwise weight gradients of maps no wider than this also go to the second stream.  Measured (two boxes, 2-3 runs each): 14 -> -0.2 ms, but
 # 7, 28, 56 and "only the 14x14 maps" -> +1.1 ms (the captured graph serialises differently): too close to a cliff for a default, stays off
@@ -628,9 +630,12 @@ class Engine:
         self._side = None
         if _WG_STREAM and self.on_layer_grads is None and L.PROFILER is None and self.device.type == "cuda":
             if getattr(self, "_wg_stream", None) is None:
-                self._wg_stream = torch.cuda.Stream(device=self.device)
+                self._wg_stream = torch.cuda.Stream(device=self.device, priority=_WG_PRIO)
+                self._wg_more = [torch.cuda.Stream(device=self.device, priority=_WG_PRIO) for _ in range(max(0, _WG_NSTREAMS - 1))] if boundaries is None else []
             self._side = self._wg_stream
             self._side.wait_stream(torch.cuda.current_stream())          # after the dwq arena fill
+            for st in self._wg_more:
+                st.wait_stream(torch.cuda.current_stream())
             self._keep = []
             self._forks = 0
             self._deferred = []
@@ -699,7 +704,9 @@ class Engine:
                 y.grad = None
         self._flush_deferred_wgrads()
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)          # join: every weight gradient is accumulated
+            torch.cuda.current_stream().wait_stream(self._wg_stream)          # join: every weight gradient is accumulated
+            for st in getattr(self, "_wg_more", []):
+                torch.cuda.current_stream().wait_stream(st)
             self._side = None
         self._finalize_pending()
         self._keep = []
@@ -935,8 +942,11 @@ class Engine:
                 self._flush_deferred_wgrads(fork=False)
                 ev = torch.cuda.Event()
                 ev.record()
-                self._side.wait_event(ev)
                 self._forks = getattr(self, "_forks", 0) + 1
+                if getattr(self, "_wg_more", None):          # several weight-gradient streams: the next one takes this fork
+                    allst = [self._wg_stream] + self._wg_more
+                    self._side = allst[self._forks % len(allst)]
+                self._side.wait_event(ev)
             if x.needs_grad:
                 gx, acc = self._grad_slot(x)
                 if l.kind == "pw" and L.load_library().frost_pw_dgrad_wide_ok(x.npix, x.c, l.cout):

@@ -1,0 +1,14 @@
+#!/bin/bash
+exec < /dev/null
+O=gpurun_out/r5wgs; mkdir -p $O
+b() { ( export "$@"; timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'], d['value'])" ); }
+for rep in 1 2; do
+b FROST_X=0
+b FROST_WG_PRIO=-1
+b FROST_WG_PRIO=1
+b FROST_WG_NSTREAMS=2
+b FROST_WG_NSTREAMS=3
+b FROST_WG_NSTREAMS=2 FROST_WG_PRIO=-1
+b FROST_WG_CI256=1
+b FROST_WG_STREAM=0
+done 2>&1 | tee $O/ab.txt
