@@ -139,6 +139,8 @@ _PROTOS = {
     "frost_dw_wgrad": [P, P, P, I, I, I, I, I, I, P, P],
     "frost_dw_bwd_fused_ok": [I, I, I, I, I],
     "frost_dw_bwd_fused": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P],
+    "frost_dw_bwd_fused_c1_ok": [I, I, I, I, I, I],
+    "frost_dw_bwd_fused_c1": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "frost_weight_grad_finalize": [P, P, P, P, P, P, I, I, I, I, P, P, P, I, P, P],
     "frost_weight_grad_finalize_table": [P, I, P],
     "frost_infer_weight_prep": [P, I, P],

@@ -41,6 +41,8 @@ struct DwbP {
   int n, h, w, c, cpad, relu, sr; float inv_count;
   int ncb, nstrips, nchunks, rc;          // channel blocks, column strips per row, row chunks per image, rows per chunk (stride 2: output rows / columns)
   int ho, wo;
+  // conv1 fold (stride-2 kernels, C1D > 0): the reduce pass of the pointwise layer that PRODUCED x (its S1 / S2) rides on the dx rows as they are formed
+  const int8_t* c1_x; const float* c1_qx; const int8_t* c1_wq; const int32_t* c1_wsum; float* c1_coef; int c1_relu;
 };
 
 __device__ __forceinline__ void dwb_glds16(const void* gsrc, uint32_t lds_addr) {
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256, DWB_LB1) void k_dwb_s1(const DwbP p) {
 // input columns; a step is one dc row m: two new x rows (the other k - 2 are carried in registers), one gy row, NDC = 9 (k3) / 10 (k5) dc columns (one halo column on the
 // right, for k5 one on the left too), and the two dx rows that became final -- rows 2m-1, 2m (k3: dc rows m-1, m) or 2m-2, 2m-1 (k5: dc rows m-2 .. m).  Only the taps whose
 // parity matches contribute to a dx element (2.25 of 9, 6.25 of 25 on average), in k_dw3_dgrad's order (dc rows ascending, kx ascending).
-template <int K, int CBW, int PD>
+template <int K, int CBW, int PD, int C1D = 0>
 struct DwbGeo2 {
   static constexpr int PAD = (K - 1) / 2, LH = (K == 5) ? 1 : 0, NDC = 9 + LH, XL = (K == 3) ? 1 : 4, NDR = (K == 3) ? 2 : 3;
   static constexpr int NXW = 2 * (NDC - 1) + K, NXD = 6;                                     // x window of a lane: 19 / 23 pixels; 3 transposed reads = 24 pixels = 6 dwords
@@ -321,13 +323,16 @@ struct DwbGeo2 {
   static constexpr int NXS = 2 * PD + ((K == 3) ? 2 : 3), NGS = PD + 1;
   static constexpr int XU = XR / 16, GU = GR / 16;
   static constexpr int XSL = 8 * CBW, GSL = 4 * CBW;                                          // slack: the last transposed read of a row runs past its record
-  static constexpr int X_OFF = 0, G_OFF = NXS * XR + XSL, O_OFF = G_OFF + NGS * GR + GSL, WAVE_LDS = O_OFF + OR;
-  static_assert(XU > 64 && XU <= 128 && GU > 64 && GU <= 128 && OR == 2048, "two copy instructions per x row, per gy row and per dx row");
+  static constexpr int C1R = SWI * C1D * 4, C1U = C1R / 16, N1S = 2 * (PD + 1);                // conv1 fold: bytes of an x0 row segment [SWI pixels][Cin], its 16-byte units, ring slots
+  static constexpr int X_OFF = 0, G_OFF = NXS * XR + XSL, O_OFF = G_OFF + NGS * GR + GSL, C1_OFF = O_OFF + OR, WAVE_LDS = C1_OFF + N1S * C1R;
+  static constexpr int NDMA = 6 + ((C1D > 0) ? 2 : 0);
+  static_assert(XU > 64 && XU <= 128 && GU > 64 && GU <= 128 && OR == 2048 && C1U <= 64, "two copy instructions per x row, per gy row and per dx row, one per x0 row");
 };
 
-template <int K, int CBW, int PD>
+template <int K, int CBW, int PD, int C1D>
 __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
-  using G = DwbGeo2<K, CBW, PD>;
+  using G = DwbGeo2<K, CBW, PD, C1D>;
+  constexpr bool C1 = C1D > 0; constexpr int CIN1 = C1D * 4;
   constexpr int PAD = G::PAD, LH = G::LH, NDC = G::NDC, XL = G::XL, NDR = G::NDR, NXD = G::NXD, SWO = G::SWO, SWI = G::SWI;
   constexpr int XR = G::XR, GR = G::GR, NXS = G::NXS, NGS = G::NGS, KK = K * K, NPK = (K == 3) ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -385,6 +390,29 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
 #pragma unroll
   for (int t = 0; t < KK; ++t) wacc[t] = 0.0f;
 
+  // conv1 fold: this lane's row of conv1's fake-quantised weights (A-fragment pack [ct][ks = 0][kb * 16 + m][16 B]: channel ct * 16 + m, k = kb * 16 ..), its coefficient rows and
+  // STE window -- k_pw's reduce pass (frost_pw.hip, M_BRED) evaluated per dx element: S1 += g, S2 += g * xhat with g = the dx value BEFORE its bf16 rounding
+  uint8_t* const c1ring = wl + G::C1_OFF;
+  const uint32_t c1ring_a = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)c1ring);
+  int w1[C1 ? C1D : 1]; int acc01 = 0; float a1A = 0, a1B = 0, a1R = 0, a1MR = 0, y_inv1 = 1.0f, t_lo1 = 0.0f, t_hi1 = 0.0f, c1s1 = 0.0f, c1s2 = 0.0f;
+  if (C1) {
+    const uint4* wp = (const uint4*)p.c1_wq + (size_t)(chc >> 4) * 64 + (chc & 15);
+    const uint4 q0 = wp[0]; w1[0] = (int)q0.x; w1[1] = (int)q0.y; w1[2] = (int)q0.z; w1[C1D > 3 ? 3 : 0] = (int)q0.w;
+    if (C1D > 4) { const uint4 q1 = wp[16]; w1[C1D > 4 ? 4 : 0] = (int)q1.x; w1[C1D > 5 ? 5 : 0] = (int)q1.y; }
+    if (!chok) { for (int i = 0; i < C1D; ++i) w1[i] = 0; }
+    const int zp0 = __float_as_int(p.c1_qx[FROST_Q_ZP]);
+    acc01 = chok ? (128 - zp0) * p.c1_wsum[chc] : 0;
+    if (chok) {
+      a1A = p.c1_coef[FROST_COEF_A * p.cpad + ch]; a1B = p.c1_coef[FROST_COEF_B * p.cpad + ch];
+      const float m = p.c1_coef[FROST_COEF_M * p.cpad + ch]; a1R = p.c1_coef[FROST_COEF_R * p.cpad + ch]; a1MR = -m * a1R;
+    }
+    y_inv1 = 1.0f / p.qx[FROST_Q_SCALE];                      // conv1's output record IS this layer's input record
+    const int qhi = q_hi(p.qx);
+    const float hi0 = (float)qhi + 0.5f - (float)zpx;
+    t_hi1 = ((qhi - zpx) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.c1_relu) { const float lo0 = -(float)zpx - 0.5f; t_lo1 = (zpx & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
+  }
+
   const int64_t xpitch = (int64_t)p.w * p.c, gpitch = (int64_t)p.wo * p.c;
   for (int tt = lwg * 4 + wv; tt < ntask; tt += nlc * 4) {
     const int img = img_lo + tt / pit; const int rem = tt - (tt / pit) * pit;
@@ -407,6 +435,14 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
     }
     const int nst_row = 1 + (__builtin_amdgcn_ballot_w64(ook1) != 0ull ? 1 : 0);        // store instructions a dx row certainly issues (the counted wait needs a lower bound)
     const int ic0 = ic0s + 16 * hf, oc0 = oc0s + 8 * hf;
+    int c1off = 0; uint32_t pmask = 0;                 // conv1 fold: byte offset of this lane's 16-byte unit inside the strip's x0 row segment (clamped into the image row), own dx pixels inside the map
+    const int8_t* c1img = nullptr;
+    if (C1) {
+      c1off = min(lane * 16, (p.w - ic0s) * CIN1 - 16);
+      c1img = p.c1_x + ((int64_t)img * p.h * p.w + ic0s) * CIN1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) if (ic0 + i < p.w && chok) pmask |= 1u << i;
+    }
     uint32_t xm[NXD]; uint32_t cmask = 0;
 #pragma unroll
     for (int i = 0; i < NXD; ++i) {
@@ -430,6 +466,16 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
       dwb_glds16(base + goff0, gring_a + (uint32_t)(slot * GR));
       if (lane < G::GU - 64) dwb_glds16(base + goff1, gring_a + (uint32_t)(slot * GR + 1024));
     };
+    auto issue_c1 = [&](int step) __attribute__((always_inline)) {      // the x0 rows of the two dx rows that step `step` finalises
+      if (C1) {
+        constexpr int IO0 = (K == 3) ? -1 : -2;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int iy = min(max(2 * (m0 - LH + step) + IO0 + rr, 0), p.h - 1);
+          if (lane < G::C1U) dwb_glds16(c1img + (int64_t)iy * p.w * CIN1 + c1off, c1ring_a + (uint32_t)(((step % (PD + 1)) * 2 + rr) * G::C1R));
+        }
+      }
+    };
     auto load_x = [&](int row, uint32_t* d6) __attribute__((always_inline)) {
       const int slot = (row - rbase) % NXS;
       const uint8_t* rp = xring + slot * XR;
@@ -445,7 +491,7 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
 #pragma unroll
     for (int b = 0; b < PD; ++b) {
       issue_x(rbase + (K - 2) + 2 * b, (K - 2 + 2 * b) % NXS); issue_x(rbase + (K - 2) + 2 * b + 1, (K - 2 + 2 * b + 1) % NXS);
-      issue_g(m0 - LH + b, b % NGS);
+      issue_g(m0 - LH + b, b % NGS); issue_c1(b);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t xd[K][NXD]; float dcw[NDR][NDC];
@@ -462,8 +508,8 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
 #pragma unroll 1
     for (int s = 0; s < NS; ++s) {
       const int m = m0 - LH + s;
-      if (s > 0) { int ny = 6 * (PD - 1); for (int i = 0; i < PD; ++i) ny += sth[i]; dwb_wait_vm(ny); }
-      { const int r = rbase + (K - 2) + 2 * (s + PD); issue_x(r, (r - rbase) % NXS); issue_x(r + 1, (r + 1 - rbase) % NXS); issue_g(m + PD, (s + PD) % NGS); }
+      if (s > 0) { int ny = G::NDMA * (PD - 1); for (int i = 0; i < PD; ++i) ny += sth[i]; dwb_wait_vm(ny); }
+      { const int r = rbase + (K - 2) + 2 * (s + PD); issue_x(r, (r - rbase) % NXS); issue_x(r + 1, (r + 1 - rbase) % NXS); issue_g(m + PD, (s + PD) % NGS); issue_c1(s + PD); }
 #pragma unroll
       for (int ky = 0; ky < K - 2; ++ky)
 #pragma unroll
@@ -550,6 +596,39 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
               }
             }
           }
+          if (C1) {
+            // two pixels at a time, the next group's LDS reads in flight under this group's arithmetic; the volatile asm ties the running sums to program order (left alone, the
+            // compiler reads all sixteen pixels first and keeps 64 - 96 registers of x0 bytes alive: 229 - 256 VGPRs, spills)
+            const uint8_t* x0r = c1ring + ((s % (PD + 1)) * 2 + rr) * G::C1R + 16 * hf * CIN1;
+            constexpr int GS = 2, NG = 16 / GS;
+            uint2 xb[2][GS][C1D / 2];
+#pragma unroll
+            for (int i = 0; i < GS; ++i)
+#pragma unroll
+              for (int q = 0; q < C1D / 2; ++q) xb[0][i][q] = *(const uint2*)(x0r + i * CIN1 + 8 * q);
+#pragma unroll
+            for (int g4 = 0; g4 < NG; ++g4) {
+              if (g4 + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < GS; ++i)
+#pragma unroll
+                  for (int q = 0; q < C1D / 2; ++q) xb[(g4 + 1) & 1][i][q] = *(const uint2*)(x0r + (GS * (g4 + 1) + i) * CIN1 + 8 * q);
+              }
+#pragma unroll
+              for (int i = 0; i < GS; ++i) {
+                int acc1 = acc01;
+#pragma unroll
+                for (int q = 0; q < C1D / 2; ++q) {
+                  acc1 = __builtin_amdgcn_sdot4((int)xb[g4 & 1][i][q].x, w1[2 * q], acc1, false); acc1 = __builtin_amdgcn_sdot4((int)xb[g4 & 1][i][q].y, w1[2 * q + 1], acc1, false);
+                }
+                const float v = (float)acc1;
+                const float tq = fmaf(a1A, v, a1B) * y_inv1;
+                const float gg = (((pmask >> (GS * g4 + i)) & 1u) && tq > t_lo1 && tq <= t_hi1) ? a[GS * g4 + i] * sw : 0.0f;
+                c1s1 += gg; c1s2 = fmaf(gg, v, c1s2);          // sum g and sum g * acc: xhat = acc * R - M * R is applied once, at the end
+              }
+              asm volatile("" : "+v"(c1s1), "+v"(c1s2) :: "memory");
+            }
+          }
 #pragma unroll
           for (int i = 0; i < 16; ++i) *(uint16_t*)(orow + ((16 * hf + i) * CBW + lc) * 2) = (uint16_t)cvt_pk_bf16(a[i] * sw, 0.0f);
           const uint4 v0 = *(const uint4*)(orow + lane * 16), v1 = *(const uint4*)(orow + 1024 + lane * 16);
@@ -579,6 +658,17 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
     for (int w2 = 0; w2 < 4; ++w2)
       for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * KK + t) * 64 + l3];
     if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * KK + t, sum * sx);
+  }
+  if (C1) {           // conv1's S1 / S2: the waves' lane-local sums, one pair of float atomics per channel and workgroup (k_pw's reduce-pass tail)
+    __syncthreads();
+    red[(wv * 64 + lane) * 2] = c1s1; red[(wv * 64 + lane) * 2 + 1] = fmaf(c1s2, a1R, a1MR * c1s1);
+    __syncthreads();
+    if (tid < CBW && (cb * CBW + tid) < p.c) {
+      float a = 0, b = 0;
+      for (int w2 = 0; w2 < 4; ++w2)
+        for (int l2 = tid; l2 < 64; l2 += CBW) { a += red[(w2 * 64 + l2) * 2]; b += red[(w2 * 64 + l2) * 2 + 1]; }
+      atomicAdd(p.c1_coef + FROST_COEF_S1 * p.cpad + cb * CBW + tid, a); atomicAdd(p.c1_coef + FROST_COEF_S2 * p.cpad + cb * CBW + tid, b);
+    }
   }
 }
 
@@ -855,18 +945,18 @@ static int launch_dwb(DwbP& p, hipStream_t s) {
   hipLaunchKernelGGL((k_dwb_s1<CBW, PD>), dim3(grid), dim3(256), lds, s, p);
   return frost_check_launch("dw_bwd_fused");
 }
-template <int K, int CBW, int PD>
+template <int K, int CBW, int PD, int C1D = 0>
 static int launch_dwb2(DwbP& p, hipStream_t s) {
-  using G = DwbGeo2<K, CBW, PD>;
+  using G = DwbGeo2<K, CBW, PD, C1D>;
   const size_t lds = (size_t)4 * G::WAVE_LDS;
   static int occ = 0;
   if (!occ) {
-    (void)hipFuncSetAttribute((const void*)k_dwb_s2<K, CBW, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dwb_s2<K, CBW, PD>, 256, lds) != hipSuccess || occ < 1) occ = 1;
+    (void)hipFuncSetAttribute((const void*)k_dwb_s2<K, CBW, PD, C1D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_dwb_s2<K, CBW, PD, C1D>, 256, lds) != hipSuccess || occ < 1) occ = 1;
     if (occ > 8) occ = 8;
   }
   const unsigned grid = dwb_plan(p, occ, p.ho, (p.wo + G::SWO - 1) / G::SWO, CBW, 7);
-  hipLaunchKernelGGL((k_dwb_s2<K, CBW, PD>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_dwb_s2<K, CBW, PD, C1D>), dim3(grid), dim3(256), lds, s, p);
   return frost_check_launch("dw_bwd_fused");
 }
 
@@ -878,9 +968,11 @@ extern "C" int frost_dw_bwd_fused_ok(int h, int w, int c, int k, int stride) {
   return 0;
 }
 
-extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
-                                  int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
-                                  uint16_t* dx, float* dwq, void* stream) {
+extern "C" int frost_dw_bwd_fused_c1_ok(int h, int w, int c, int k, int stride, int c1_cin);
+static int dwb_fused_impl(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                          int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                          uint16_t* dx, float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef,
+                          int c1_cin, int c1_relu, void* stream) {
   FROST_REQUIRE(frost_dw_bwd_fused_ok(h, w, c, k, stride), "dw_bwd_fused: unsupported shape (k = 3 stride 1, or k in {3, 5} stride 2 on even maps; channels a multiple of 8)");
   FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout && dx && dwq, "dw_bwd_fused: incomplete arguments");
   DwbP p = {};
@@ -892,9 +984,35 @@ extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const in
   // 32-channel blocks when they waste fewer lanes than 64-channel blocks (32, 72, 96, 144 channels: the high-resolution layers), as pick_geo of frost_dw3.hip
   static const int cbw_env = dwb_env("FROST_DWB_CBW");
   const bool c32 = cbw_env ? (cbw_env == 32) : (round_up(c, 32) < round_up(c, 64));
+  if (c1_x) {
+    FROST_REQUIRE(frost_dw_bwd_fused_c1_ok(h, w, c, k, stride, c1_cin) && c32, "dw_bwd_fused_c1: the conv1 fold has no instance for this shape");
+    FROST_REQUIRE(c1_qrec_x && c1_wq_pack && c1_wsum && c1_coef, "dw_bwd_fused_c1: incomplete conv1 arguments");
+    p.c1_x = c1_x; p.c1_qx = c1_qrec_x; p.c1_wq = c1_wq_pack; p.c1_wsum = c1_wsum; p.c1_coef = c1_coef; p.c1_relu = c1_relu;
+    if (k == 3) return (c1_cin == 16) ? launch_dwb2<3, 32, DWB_PD, 4>(p, s) : launch_dwb2<3, 32, DWB_PD, 6>(p, s);
+    return (c1_cin == 16) ? launch_dwb2<5, 32, DWB_PD, 4>(p, s) : launch_dwb2<5, 32, DWB_PD, 6>(p, s);
+  }
   if (stride == 1) return c32 ? launch_dwb<32, DWB_PD>(p, s) : launch_dwb<64, DWB_PD>(p, s);
   if (k == 3) return c32 ? launch_dwb2<3, 32, DWB_PD>(p, s) : launch_dwb2<3, 64, DWB_PD>(p, s);
   return c32 ? launch_dwb2<5, 32, DWB_PD>(p, s) : launch_dwb2<5, 64, DWB_PD>(p, s);
+}
+extern "C" int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                                  int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                                  uint16_t* dx, float* dwq, void* stream) {
+  return dwb_fused_impl(x, qrec_x, wq_pack, wsum, qrec_w, wscale, n, h, w, c, k, stride, coef, qrec_y, relu, gout, dx, dwq, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+// the same sweep carrying the REDUCE PASS of the pointwise layer that produced x (conv1 of the bottleneck: frost_pw_conv_bwd pass 0 on (c1_x -> x)): its S1 / S2 accumulate into
+// c1_coef from the dx values as they are formed (before their bf16 rounding), so that layer's backward starts at its dc pass and never re-reads dx for the sums
+extern "C" int frost_dw_bwd_fused_c1_ok(int h, int w, int c, int k, int stride, int c1_cin) {
+  static const int on = getenv("FROST_DWB_C1") ? atoi(getenv("FROST_DWB_C1")) : 3;          // bit 0: k = 3 layers, bit 1: k = 5 layers
+  return (((on >> (k == 3 ? 0 : 1)) & 1) && stride == 2 && (c1_cin == 16 || c1_cin == 24) && round_up(c, 32) < round_up(c, 64) && frost_dw_bwd_fused_ok(h, w, c, k, stride)) ? 1 : 0;
+}
+extern "C" int frost_dw_bwd_fused_c1(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                                     int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                                     uint16_t* dx, float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef,
+                                     int c1_cin, int c1_relu, void* stream) {
+  FROST_REQUIRE(c1_x, "dw_bwd_fused_c1: conv1's input is required");
+  return dwb_fused_impl(x, qrec_x, wq_pack, wsum, qrec_w, wscale, n, h, w, c, k, stride, coef, qrec_y, relu, gout, dx, dwq, c1_x, c1_qrec_x, c1_wq_pack, c1_wsum, c1_coef, c1_cin,
+                        c1_relu, stream);
 }
 
 // ---- the single-sweep passes: called by the frost_dw_conv_fwd / _fwd_fin / _bwd entries of frost_dw3.hip when the shape qualifies (FROST_DW_STREAM: bit 0 statistics, bit 1 emit,

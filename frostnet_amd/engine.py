@@ -25,6 +25,7 @@ def round_up(a, b):
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
 _DW_BWD_ONE = os.environ.get("FROST_DW_BWD_ONE", "1") != "0"   # depthwise k = 3 stride-1 backward of the tiled (high-resolution) layers: dc + weight gradient + data gradient in one sweep (csrc/frost_dwb.hip)
+_DW_C1 = os.environ.get("FROST_DWB_C1", "3") != "0"          # ... carrying the reduce pass of the pointwise layer in front of it (stride-2 layers with Cin = 16 / 24)
 _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
 _PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
 _FIN_FOLD = os.environ.get("FROST_FIN_FOLD", "1") != "0"    # dev switch: conv finalize folded into the statistics kernels' last workgroup
@@ -660,7 +661,7 @@ class Engine:
                     self._close_bucket(boundaries[id(l)], on_bucket)
             elif kind == "conv":
                 _, l, x, y = entry
-                self._conv_backward(l, x, y)
+                self._conv_backward(l, x, y, rtape[ti + 1] if ti + 1 < len(rtape) else None)
                 if self.on_layer_grads is not None:
                     self.on_layer_grads(l)
                 if boundaries is not None and id(l) in boundaries:
@@ -857,7 +858,7 @@ class Engine:
         fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         return bool(_PW_KEEP and not fused and l.kind == "pw" and x.c > 256 and l.cout < x.c and not getattr(l, "frozen", False))
 
-    def _conv_backward(self, l, x, y):
+    def _conv_backward(self, l, x, y, nxt=None):
         self._ensure_grad(l)
         gout = y.grad
         s = stream()
@@ -987,6 +988,20 @@ class Engine:
                 call("frost_block_dw_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
                      l.k, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]) if x.needs_grad else None, ptr(l.dwq), s,
                      prof=("blk_dw_bwd", x.numel + 2 * y.numel + (2 * x.numel if x.needs_grad else 0)))
+                self._after_conv_backward(l, s)
+                y.grad = None
+                return
+            c1 = nxt[1] if (dw_one and _DW_C1 and nxt is not None and nxt[0] == "conv" and nxt[3] is x) else None
+            if (c1 is not None and c1.kind == "pw" and not getattr(c1, "frozen", False) and not c1.per_channel and getattr(c1, "hswish", None) is None and not gslot[1]
+                    and L.load_library().frost_dw_bwd_fused_c1_ok(x.h, x.w, x.c, l.k, l.stride, nxt[2].c)):
+                # ... and the sweep carries the reduce pass of the pointwise layer that produced x (conv1 of the bottleneck): its S1 / S2 accumulate from the dx values as they
+                # are formed, so conv1's backward starts at its dc pass (x.bred_done) and the gradient tensor is read once instead of twice
+                x0 = nxt[2]
+                call("frost_dw_bwd_fused_c1", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
+                     l.k, l.stride, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]), ptr(l.dwq),
+                     ptr(x0.buf), ptr(x0.q), ptr(c1.wq_pack), ptr(c1.wsum), ptr(c1.coef), x0.c, int(c1.relu), s,
+                     prof=("dw_bwd_one", x.numel + 2 * y.numel + 2 * x.numel + x0.numel))
+                x.bred_done = True
                 self._after_conv_backward(l, s)
                 y.grad = None
                 return

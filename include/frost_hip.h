@@ -221,6 +221,15 @@ int frost_dw_bwd_fused_ok(int h, int w, int c, int k, int stride);
 int frost_dw_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
                        int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
                        uint16_t* dx, float* dwq, void* stream);
+/* the same sweep carrying the REDUCE PASS of the pointwise layer that produced x (conv1 of the bottleneck, frostnet.py:88-95: replaces frost_pw_conv_bwd pass 0 on
+ * (c1_x -> x)): S1 = sum g, S2 = sum g * xhat of that layer accumulate into c1_coef (its coefficient rows; S1 / S2 zero on entry as for the separate pass) with g = the dx
+ * value before its bf16 rounding, inside conv1's STE window (k_pw's reduce-pass expressions on conv1's integer accumulator, recomputed from c1_x and c1_wq_pack).
+ * c1_x: conv1's input [n][h][w][c1_cin] (c1_cin = 16 or 24), c1_qrec_x its record; conv1's output record is qrec_x.  Stride-2 layers only (_c1_ok). */
+int frost_dw_bwd_fused_c1_ok(int h, int w, int c, int k, int stride, int c1_cin);
+int frost_dw_bwd_fused_c1(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                          int n, int h, int w, int c, int k, int stride, const float* coef, const float* qrec_y, int relu, const uint16_t* gout,
+                          uint16_t* dx, float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef,
+                          int c1_cin, int c1_relu, void* stream);
 /* fold-path: dW = dWq*mask*sf ; dgamma = S2*vfrac + sum(dWq*mask*W)/sigma_r ; dbeta = S1  (SURVEY H-5) */
 /* sigma_r[c] = sqrt(running_var+eps) as used by THIS step's forward (frost_save_sigma runs before the update) */
 int frost_weight_grad_finalize(const float* dwq, const float* w, const float* gamma, const float* sigma_r,

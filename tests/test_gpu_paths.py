@@ -145,3 +145,34 @@ def test_streaming_depthwise_passes_are_exact(case, tmp_path):
     assert relerr(new["dbeta"], old["dbeta"]) <= 1e-5 and relerr(new["dgamma"], old["dgamma"]) <= 1e-4
     a, b = bf16_to_f32(new["dx"]).astype(np.float64), bf16_to_f32(old["dx"]).astype(np.float64)
     assert float((a != b).mean()) <= 2e-3 and relerr(a, b) <= 2e-4
+
+
+# The conv1 fold of the stride-2 one-sweep kernel (frost_dw_bwd_fused_c1): conv1's reduce pass (S1 / S2) rides on the dx rows of the depthwise backward instead of a pass
+# of its own over the stored gradient.  The sums now see the dx values BEFORE their bf16 rounding, so conv1's dc (and what follows from it) moves at the bf16-noise level and
+# nothing else moves at all: conv2 / reduce_conv gradients identical, conv1's launch list loses its reduce pass.  16 -> 96 @112 (k3), 24 -> 144 @56 (k5), ragged relatives.
+def _block(tmp, tag, case, env):
+    out = os.path.join(tmp, f"{tag}.npz")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "block_digest.py"), out] + [str(v) for v in case], check=True, env=dict(os.environ, **env), cwd=ROOT,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("case", [(16, 96, 112, 3, 24, 6, 2), (24, 144, 56, 5, 40, 5, 2), (24, 72, 30, 3, 24, 9, 2), (16, 72, 44, 5, 16, 3, 2)], ids=lambda c: "_".join(str(v) for v in c))
+def test_conv1_reduce_pass_folded_into_the_depthwise_backward(case, tmp_path):
+    calls = os.path.join(str(tmp_path), "calls.txt")
+    on = _block(str(tmp_path), "on", case, {"FROST_SR": "0", "FROST_DWB_C1": "3", "FROST_DWB_MINW": "8", "DIGEST_CALLS": calls})
+    log = open(calls).read().split("\n")
+    assert "frost_dw_bwd_fused_c1" in log and log.count("frost_pw_conv_bwd") + log.count("frost_pw_conv_bwd_fused") <= 3, log      # conv1: no reduce pass left (reduce_conv keeps its own)
+    off = _block(str(tmp_path), "off", case, {"FROST_SR": "0", "FROST_DWB_C1": "0", "FROST_DWB_MINW": "8"})
+    ref = _block(str(tmp_path), "ref", case, {"FROST_GRAD": "fp32"})          # fp32 gradient storage, fp64 sums (csrc/frost_g32.hip): the yardstick
+    assert on["y3"].tobytes() == off["y3"].tobytes() == ref["y3"].tobytes()
+    for k in ("dw2", "dgamma2", "dbeta2", "dw3", "dgamma3", "dbeta3"):
+        assert relerr(on[k], off[k]) <= 1e-4, k
+    assert relerr(bf16_to_f32(on["dx"]), bf16_to_f32(off["dx"])) <= 5e-3
+    # conv1's gradients against the fp32-gradient mode: the fold must not be further from it than the separate pass is (its sums skip one bf16 rounding), within a 1.25 x
+    # allowance for noise on the components that do not depend on S1 / S2 alone
+    e_on = {k: relerr(on[k], ref[k]) for k in ("dw1", "dgamma1", "dbeta1")}
+    e_off = {k: relerr(off[k], ref[k]) for k in ("dw1", "dgamma1", "dbeta1")}
+    print("conv1 vs fp32-gradient mode: fold", e_on, "separate", e_off)
+    assert e_on["dbeta1"] <= 1.25 * e_off["dbeta1"] + 1e-4 and e_on["dgamma1"] <= 1.25 * e_off["dgamma1"] + 1e-4 and e_on["dw1"] <= 1.25 * e_off["dw1"] + 1e-4, (e_on, e_off)
+    assert relerr(bf16_to_f32(on["dx"]), ref["dx"]) <= 1.25 * relerr(bf16_to_f32(off["dx"]), ref["dx"]) + 1e-4
