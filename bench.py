@@ -66,7 +66,7 @@ def cpu_baseline(res=224, batch=64, timed=3):
                        f"FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU kernels via oracle/frost_oracle.py")
 
 
-PMC_TAGS = ("r04", "r03", "r02")
+PMC_TAGS = ("r05", "r04", "r03", "r02")
 
 
 def pmc_table(batch):

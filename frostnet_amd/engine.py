@@ -25,6 +25,7 @@ def round_up(a, b):
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
 _DW_BWD_ONE = os.environ.get("FROST_DW_BWD_ONE", "1") != "0"   # depthwise k = 3 stride-1 backward of the tiled (high-resolution) layers: dc + weight gradient + data gradient in one sweep (csrc/frost_dwb.hip)
+_DW_ONE_OVER_BLK = os.environ.get("FROST_DWB_OVER_BLK", "0") != "0"
 _DW_C1 = os.environ.get("FROST_DWB_C1", "3") != "0"          # ... carrying the reduce pass of the pointwise layer in front of it (stride-2 layers with Cin = 16 / 24)
 _DW_FUSE_K5 = os.environ.get("FROST_DW_FUSE_K5", "0") != "0"   # the 5x5 two-images-per-tile fused dc + wgrad variant spills 132 B of scratch: separate kernels are 0.8 % faster end to end (A/B, r2)
 _PW_KEEP = os.environ.get("FROST_PW_KEEP", "1") != "0"      # backward of the wide-K pointwise layers: one conv recomputation + element-wise reduce / dc (A/B switch)
@@ -870,6 +871,8 @@ class Engine:
         fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)
                   and bool(L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)))      # dc stays in LDS there: no buffer
+        if blk_dw and _DW_ONE_OVER_BLK and x.needs_grad and x.grad is None and L.load_library().frost_dw_bwd_fused_ok(x.h, x.w, x.c, l.k, l.stride):
+            blk_dw = False          # A/B: the strip-streaming kernel instead of the image-resident one where both have an instance (FROST_DWB_MINW lets it take small maps)
         dw_one = (l.kind == "dw" and not blk_dw and _DW_BWD_ONE and x.needs_grad and x.grad is None
                   and bool(L.load_library().frost_dw_bwd_fused_ok(x.h, x.w, x.c, l.k, l.stride)))                 # dc stays in registers there: no buffer
         dc = None if (fused or blk_dw or dw_one) else torch.empty(y.numel + 64, dtype=torch.int16, device=self.device)
@@ -975,7 +978,9 @@ class Engine:
         elif l.kind == "dw":
             args = (ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), x.n, x.h, x.w, x.c, l.k, l.stride)
             blk = _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and L.load_library().frost_block_dw_bwd_supported(x.h, x.w, l.k, l.stride, x.c)
-            if blk and _BLOCK_DWBRED:
+            blk_reduce = blk          # (the image-resident reduce pass stays even when the strip-streaming kernel takes the rest: FROST_DWB_OVER_BLK)
+            blk = blk and (blk_dw or not dw_one)
+            if blk_reduce and _BLOCK_DWBRED:
                 call("frost_block_dw_bwd_reduce", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.n, x.h, x.w, x.c, l.k, ptr(l.coef), ptr(l.qy), int(l.relu),
                      ptr(gout), s, prof=("blk_dw_bred", x.numel + 2 * y.numel))
             else:

@@ -1,0 +1,28 @@
+#!/bin/bash
+# End-of-round job: profiles (rocprofv3 kernel stats + PMC passes), default bench line, per-layer table, side workloads, other batch sizes, full GPU suite, smoke.
+# Every step runs under `timeout` and reads nothing from stdin.
+exec < /dev/null
+mkdir -p gpurun_out
+timeout 1500 bash tools/collect_profiles.sh r05 512 > gpurun_out/collect_r05.log 2>&1
+[ -f gpurun_out/prof_r05/summary.json ] && cp gpurun_out/prof_r05/summary.json profiles/r05_kernels_b512.json
+timeout 900 python bench.py > gpurun_out/bench_r05.json 2> gpurun_out/bench_r05.err
+timeout 900 python tests/devtools/layer_times.py 512 > gpurun_out/layer_times_r05_b512.txt 2>&1
+f=$(find gpurun_out/prof_r05/stats -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_kernel_stats.csv
+find gpurun_out/prof_r05 -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+find gpurun_out/prof_r05 -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
+: > gpurun_out/r05_side_workloads.jsonl
+for wl in infer int8 detect float; do timeout 600 python bench.py --workload $wl 2>/dev/null | tail -1 >> gpurun_out/r05_side_workloads.jsonl; done
+FROST_FLOAT_PRECISION=fp32 timeout 600 python bench.py --workload float 2>/dev/null | tail -1 >> gpurun_out/r05_side_workloads.jsonl
+( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r05_float -o s -- python bench.py --workload float --steps 10 --warmup 3 > gpurun_out/prof_r05_float.log 2>&1 )
+f=$(find gpurun_out/prof_r05_float -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_float_b256_kernel_stats.csv
+find gpurun_out/prof_r05_float -name "*kernel_trace.csv" -delete 2>/dev/null
+: > gpurun_out/r05_other_batches.jsonl
+for b in 64 200 256; do timeout 600 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_other_batches.jsonl; done
+# the fp32-gradient parity mode next to the production bf16 backward at the same (small) batch: what the plain fp32 kernels cost
+: > gpurun_out/r05_grad_modes.jsonl
+timeout 900 python bench.py --batch 64 --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+FROST_GRAD=fp32 timeout 1500 python bench.py --batch 64 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+timeout 600 python tools/bench_iblock.py > gpurun_out/r05_infer_blocks.txt 2>&1
+( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r05.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_r05.log 2>&1
+tail -c 300 gpurun_out/bench_r05.json; echo; tail -3 gpurun_out/gpu_suite_r05.log; tail -1 gpurun_out/smoke_r05.log; cut -c1-200 gpurun_out/r05_other_batches.jsonl

@@ -20,8 +20,9 @@ FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- 
     ("pw_bwd_reduce", r"k_pw<2,|k_pw_ew<0>|k_dgrad_wide<1,|k_pwc<0,"),
     ("pw_bwd_fused", r"k_pw<3, \d+, \w+, \w+, [1-9]\d*[,>]"), ("pw_bwd_dc", r"k_pw<3,|k_pw_ew<1>|k_pwc<1,"), ("pw_dgrad", r"k_pw<4,|k_dgrad_wide<0,"), ("pw_wgrad", r"k_pw_wgrad"),
     ("blk_expand_dw", r"k_blk_expand_dw"), ("blk_dw_reduce", r"k_blk_dw_reduce"), ("blk_dw_stats", r"k_blk_dw_stats"), ("blk_dw_bwd", r"k_blk_dw_bwd"), ("blk_dw_bred", r"k_blk_dw_bred"),          # block-level fused forward kernels (csrc/frost_block.hip)
-    ("dw_fwd_stats", r"k_dw3<DwGeo<[^>]*>, 0[,>]|k_dwm<\d, \d+, 0>"), ("dw_fwd_emit", r"k_dw3<DwGeo<[^>]*>, 1[,>]|k_dwm<\d, \d+, [14]>"),
-    ("dw_bwd_reduce", r"k_dw3<DwGeo<[^>]*>, 2[,>]"), ("dw_bwd_dc", r"k_dw3<DwGeo<[^>]*>, [34][,>]"),
+    ("dw_bwd_one", r"k_dwb_s[12]<"),          # one-sweep depthwise backward (csrc/frost_dwb.hip): dc pass + weight gradient + data gradient (+ conv1's reduce pass)
+    ("dw_fwd_stats", r"k_dw3<DwGeo<[^>]*>, 0[,>]|k_dwm<\d, \d+, 0>|k_dws<\d, \d, \d+, \d, 0>"), ("dw_fwd_emit", r"k_dw3<DwGeo<[^>]*>, 1[,>]|k_dwm<\d, \d+, [14]>|k_dws<\d, \d, \d+, \d, 1>"),
+    ("dw_bwd_reduce", r"k_dw3<DwGeo<[^>]*>, 2[,>]|k_dws<\d, \d, \d+, \d, 2>"), ("dw_bwd_dc", r"k_dw3<DwGeo<[^>]*>, [34][,>]"),
     ("dw_wgrad", r"k_dw3_wgrad"), ("dw_dgrad", r"k_dw3_dgrad"),
     ("conv_finalize", r"k_conv_finalize"), ("wgrad_finalize", r"k_wgrad_finalize|k_weight_grad_finalize"),
     ("cat_fwd", r"k_cat_requant|k_cat_observe"), ("cat_bwd", r"k_cat_bwd"), ("add_fwd_minmax", r"k_add_minmax"),
