@@ -36,7 +36,7 @@ class FrostFDesc(C.Structure):
                 ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("fp32", C.c_int32)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TICKET_WORDS = 40      # FROST_TICKET_WORDS: zeroed uint32 words behind every last-workgroup-done ticket (main counter + 32 sub-counters)
 
 
@@ -189,10 +189,12 @@ _PROTOS = {
     "frost_infer_block": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
     "frost_g32_wq": [P, P, P, P, P, I, I, P, P],
     "frost_g32_conv_acc": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
-    "frost_g32_reduce": [P, L, I, P, P, I, P, P],
+    "frost_g32_scratch_bytes": [],
+    "frost_g32_set_plain": [I],
+    "frost_g32_reduce": [P, L, I, P, P, I, P, P, P],
     "frost_g32_dc": [P, L, I, P, P, I, P, P, P],
     "frost_g32_dgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
-    "frost_g32_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, P],
+    "frost_g32_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P],
     "frost_g32_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],
     "frost_g32_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
     "frost_g32_pool_bwd": [P, P, I, I, I, P, P],
@@ -236,6 +238,7 @@ def load_library():
         fn.argtypes = args
         fn.restype = C.c_int       # (frost_pw_bwd_fused_ok / frost_abi_version return a value, not a status)
     lib.frost_last_error.restype = C.c_char_p
+    lib.frost_g32_scratch_bytes.restype = C.c_int64
     # the sizes a binding must agree on with the library (the ticket buffers grew from 1 to 40 words, FrostFinDesc gained two fields)
     if lib.frost_abi_version() != ABI_VERSION or lib.frost_ticket_words() != TICKET_WORDS or lib.frost_fin_desc_bytes() != C.sizeof(FrostFinDesc):
         raise RuntimeError(f"{LIB_PATH}: ABI mismatch (library abi {lib.frost_abi_version()} / ticket words {lib.frost_ticket_words()} / FrostFinDesc "

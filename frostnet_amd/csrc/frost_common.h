@@ -181,44 +181,82 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
     if (cat_qy) { pre_cat = observer_prefetch(cat_qy); cat_b_lo = cat_qb[FROST_Q_FQMIN]; cat_b_hi = cat_qb[FROST_Q_FQMAX]; }
   }
   float lo = INFINITY, hi = -INFINITY;
-  for (int c = tid; c < cpad; c += nthr) {
-    float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
-    if (c < cout) {
-      const float sw = wscale ? wscale[c] : sw0;            // per-output-channel weight scale (per-tensor mode: all equal)
-      const float sigr = sqrtf(rvar[c] + FROST_BN_EPS);
-      const float sf = gamma[c] / sigr;
-      const double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha
-      double mean_acc, mu, v;
-      if (training) {
-        const int64_t v1 = __hip_atomic_load(&s1[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint64_t v2 = __hip_atomic_load(&s2[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mean_acc = (double)v1 / (double)count;
-        double var_acc = (double)v2 / (double)count - mean_acc * mean_acc;
-        if (var_acc < 0) var_acc = 0;
-        mu = mean_acc * alpha; v = var_acc * alpha * alpha;
-        const double unb = (count > 1) ? v * (double)count / (double)(count - 1) : v;
-        rmean[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rmean[c] + (double)FROST_BN_MOM * mu);
-        rvar[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)rvar[c] + (double)FROST_BN_MOM * unb);
-      } else {
-        mu = (double)rmean[c]; v = (double)rvar[c]; mean_acc = mu / alpha;
-      }
-      const double invstd = 1.0 / sqrt(v + (double)FROST_BN_EPS);
-      const double a = (double)gamma[c] * invstd * alpha;
-      A = (float)a; B = (float)((double)beta[c] - a * mean_acc);
-      M = (float)mean_acc; R = (float)(alpha * invstd);
-      K1 = (float)(invstd * (double)sigr);                         // gamma*invstd/sf
-      VF = (float)(v / (v + (double)FROST_BN_EPS));
-      if (have_stats) {
-        const int32_t imn = __hip_atomic_load(&mnp[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int32_t imx = __hip_atomic_load(&mxp[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        float ya = fmaf(A, (float)imn, B), yb = fmaf(A, (float)imx, B);
-        if (relu) { ya = fmaxf(ya, 0.0f); yb = fmaxf(yb, 0.0f); }
-        lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
-      }
+  // FIN_U channels per thread and round: every load of a round (the other workgroups' statistics through agent-scope loads, the BatchNorm parameters and running
+  // statistics) is issued before the first fp64 chain starts, at clamped addresses and without per-channel branches -- one memory round trip per round instead of
+  // one per channel (1728 channels on 256 threads were seven dependent round trips of ~2 us on the critical path of the layer; now two)
+  constexpr int FIN_U = 4;
+  for (int c0 = tid; c0 < cpad; c0 += FIN_U * nthr) {
+    float f_sw[FIN_U], f_rv[FIN_U], f_rm[FIN_U], f_g[FIN_U], f_b[FIN_U]; int64_t f_v1[FIN_U]; uint64_t f_v2[FIN_U]; int32_t f_mn[FIN_U], f_mx[FIN_U];
+#pragma unroll
+    for (int u = 0; u < FIN_U; ++u) {
+      const int cc = min(c0 + u * nthr, cout - 1);
+      f_rv[u] = rvar[cc]; f_rm[u] = rmean[cc]; f_g[u] = gamma[cc]; f_b[u] = beta[cc];
     }
-    coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
-    coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
-    coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
+    if (wscale) {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) f_sw[u] = wscale[min(c0 + u * nthr, cout - 1)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) f_sw[u] = sw0;
+    }
+    if (training) {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) {
+        const int cc = min(c0 + u * nthr, cout - 1);
+        f_v1[u] = __hip_atomic_load(&s1[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f_v2[u] = __hip_atomic_load(&s2[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) { f_v1[u] = 0; f_v2[u] = 0; }
+    }
+    if (have_stats) {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) {
+        const int cc = min(c0 + u * nthr, cout - 1);
+        f_mn[u] = __hip_atomic_load(&mnp[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f_mx[u] = __hip_atomic_load(&mxp[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < FIN_U; ++u) { f_mn[u] = 0; f_mx[u] = 0; }
+    }
+#pragma unroll
+    for (int u = 0; u < FIN_U; ++u) {
+      const int c = c0 + u * nthr;
+      if (c >= cpad) break;
+      float A = 0, B = 0, M = 0, R = 0, K1 = 0, VF = 0;
+      if (c < cout) {
+        const float sw = f_sw[u];                              // per-output-channel weight scale (per-tensor mode: all equal)
+        const float sigr = sqrtf(f_rv[u] + FROST_BN_EPS);
+        const float sf = f_g[u] / sigr;
+        const double alpha = (double)sx * (double)sw / (double)sf;       // c0 = acc * alpha
+        double mean_acc, mu, v;
+        if (training) {
+          mean_acc = (double)f_v1[u] / (double)count;
+          double var_acc = (double)f_v2[u] / (double)count - mean_acc * mean_acc;
+          if (var_acc < 0) var_acc = 0;
+          mu = mean_acc * alpha; v = var_acc * alpha * alpha;
+          const double unb = (count > 1) ? v * (double)count / (double)(count - 1) : v;
+          rmean[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)f_rm[u] + (double)FROST_BN_MOM * mu);
+          rvar[c] = (float)((1.0 - (double)FROST_BN_MOM) * (double)f_rv[u] + (double)FROST_BN_MOM * unb);
+        } else {
+          mu = (double)f_rm[u]; v = (double)f_rv[u]; mean_acc = mu / alpha;
+        }
+        const double invstd = 1.0 / sqrt(v + (double)FROST_BN_EPS);
+        const double a = (double)f_g[u] * invstd * alpha;
+        A = (float)a; B = (float)((double)f_b[u] - a * mean_acc);
+        M = (float)mean_acc; R = (float)(alpha * invstd);
+        K1 = (float)(invstd * (double)sigr);                         // gamma*invstd/sf
+        VF = (float)(v / (v + (double)FROST_BN_EPS));
+        if (have_stats) {
+          float ya = fmaf(A, (float)f_mn[u], B), yb = fmaf(A, (float)f_mx[u], B);
+          if (relu) { ya = fmaxf(ya, 0.0f); yb = fmaxf(yb, 0.0f); }
+          lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
+        }
+      }
+      coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
+      coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
+      coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
+    }
   }
   const int nw = nthr >> 6;
   lo = wave_min(lo); hi = wave_max(hi);

@@ -4,8 +4,11 @@
 // GEMMs: measured 2-9e-3 from an fp64 evaluation per layer, 2-3e-2 on ill-conditioned sums.  This file is the SAME backward -- the same masks (STE window of the
 // activation fake-quantise incl. ReLU, evaluated on the exact integer conv output with the forward's coefficient rows), the same BatchNorm expression
 // dc = K1 (gy - S1/n - xhat S2/n), the same fake-quantised weights / inputs in the data / weight gradient -- with every gradient held in fp32 and every
-// long sum accumulated in fp64, as plain one-thread-per-output kernels.  Not for speed (it is 10-30 x slower than the production kernels): it exists to show
-// that the formulas meet the reference's fp32 autograd at <= 1e-3, and what the bf16 storage costs (tests/test_gpu_round4.py, DESIGN "fp32-gradient mode").
+// long sum accumulated in fp64.  Round 4 wrote it as plain one-thread-per-output kernels (a parity instrument, 30 x slower than the production step); since round 5
+// the same entries run tiled / coalesced kernels (section "fast forms" below: the pointwise conv output on the int8 MFMA, pointwise data / weight gradients on
+// v_mfma_f32_16x16x4_f32 with fp32 operands, per-channel sums as deterministic two-stage reductions with fp64 partials, every element-wise pass with a fixed
+// channel quad per thread) so that a user can TRAIN at the reference's gradient precision; the plain kernels stay as the fallback for channel counts that are not
+// a multiple of 4.  It shows that the formulas meet the reference's fp32 autograd at <= 1e-3, and what the bf16 storage costs (tests/test_gpu_round4.py).
 // Entry points mirror the production passes: frost_g32_conv_acc (integer conv output) -> frost_g32_reduce -> frost_g32_dc -> frost_g32_dgrad / frost_g32_wgrad,
 // then the ordinary frost_weight_grad_finalize(_table).
 #include "frost_common.h"
@@ -57,20 +60,6 @@ __global__ __launch_bounds__(256) void k_g32_conv_acc(const int8_t* __restrict__
     acc[i] = s;
   }
 }
-static G32Geo g32_geo(int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride) {
-  G32Geo g; g.kind = kind; g.n = n; g.h = h; g.w = w; g.xc = xc; g.cin_g = cin_g; g.cout = cout; g.k = k; g.stride = stride; g.pad = (k - 1) / 2;
-  if (kind == 1) { g.ho = (h + 2 * g.pad - k) / stride + 1; g.wo = (w + 2 * g.pad - k) / stride + 1; } else { g.ho = h; g.wo = w; }
-  return g;
-}
-/* kind 0 / 2: (n, h, w) = the OUTPUT map (x is already per output pixel); kind 1: (n, h, w) = the input map */
-extern "C" int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k,
-                                  int stride, int32_t* acc, void* stream) {
-  const G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, k, stride);
-  int64_t grid = ((int64_t)g.n * g.ho * g.wo * cout + 255) / 256; if (grid > 65535) grid = 65535;
-  hipLaunchKernelGGL(k_g32_conv_acc, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, qrec_x, qw, g, acc);
-  return frost_check_launch("g32_conv_acc");
-}
-
 // STE window of the activation fake-quantise on t = fma(A, acc, B) / s_y (k_pw_ew's expression, ReLU included)
 struct G32Win { float y_inv, t_lo, t_hi; };
 __device__ __forceinline__ G32Win g32_win(const float* qy, int relu) {
@@ -81,6 +70,424 @@ __device__ __forceinline__ G32Win g32_win(const float* qy, int relu) {
   w.t_lo = 0.0f;
   if (!relu) { const float lo0 = -(float)zpy - 0.5f; w.t_lo = (zpy & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
   return w;
+}
+
+
+// ================================================================================================ fast forms (round 5)
+// Shared thread map of the channel-parallel passes: a thread owns ONE channel quad (4 consecutive channels: 16-byte loads of fp32 / int32 rows, 4-byte loads of
+// int8 rows) for the whole launch and walks pixels; blockIdx.y selects the block of 256 quads for layers wider than 1024 channels.  cq: quad index, pl / PL: the
+// thread's pixel lane and the number of pixel lanes per workgroup.
+struct G32Map { int cq, pl, PL; bool ok; };
+__device__ __forceinline__ G32Map g32_map(int c) {
+  const int CQ = c >> 2, CQB = min(CQ, 256);
+  G32Map m; m.PL = 256 / CQB; m.pl = (int)threadIdx.x / CQB; m.cq = (int)blockIdx.y * 256 + (int)threadIdx.x % CQB;
+  m.ok = m.pl < m.PL && m.cq < CQ;
+  return m;
+}
+static inline dim3 g32_map_grid(int c, int64_t blocks_x) { return dim3((unsigned)blocks_x, (unsigned)(((c >> 2) + 255) / 256)); }
+static inline int g32_map_pl(int c) { const int CQB = (c >> 2) < 256 ? (c >> 2) : 256; return 256 / CQB; }
+
+// ---- pointwise (kind 0) / stem-on-im2col (kind 2) integer conv output on v_mfma_i32_16x16x64_i8: D[co][pixel], one wave = MI x 4 tiles of 16 x 16, operands straight
+// from global memory (rows of q_w and of x are contiguous in k); the zero-point term (128 - zp) * sum_k q_w comes from one more MFMA against an all-ones operand
+__device__ __forceinline__ v4i g32_row16(const int8_t* row, int k0, int klim) {      // 16 bytes of a row at k0 (k0 % 4 == 0, klim % 4 == 0), zero past klim
+  v4i v = {0, 0, 0, 0};
+  if (k0 + 16 <= klim) { v[0] = *(const int*)(row + k0); v[1] = *(const int*)(row + k0 + 4); v[2] = *(const int*)(row + k0 + 8); v[3] = *(const int*)(row + k0 + 12); }
+  else {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) if (k0 + 4 * d < klim) v[d] = *(const int*)(row + k0 + 4 * d);
+  }
+  return v;
+}
+template <int MI>
+__global__ __launch_bounds__(256) void k_g32_pw_acc(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc) {
+  constexpr int NJ = 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const int64_t npix = (int64_t)g.n * g.ho * g.wo;
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * (NJ * 16);
+  const int co0 = (int)blockIdx.y * (MI * 16);
+  if (p0 >= npix) return;
+  const int K = (g.kind == 2) ? g.xc : g.cin_g;                  // stem: the im2col columns tap * 4 + c
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  v4i d[MI][NJ], dw[MI];
+#pragma unroll
+  for (int m = 0; m < MI; ++m) { dw[m] = (v4i){0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) d[m][t] = (v4i){0, 0, 0, 0}; }
+  const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
+  const int8_t* xr[NJ];
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) xr[t] = x + min(p0 + 16 * t + j, npix - 1) * g.xc;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    v4i a[MI];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+      const int co = co0 + 16 * m + j;
+      a[m] = (v4i){0, 0, 0, 0};
+      if (co < g.cout) {
+        if (g.kind == 0) a[m] = g32_row16(qw + (int64_t)co * g.cin_g, k0 + 16 * gq, K);
+        else {                                                   // stem weights OIHW [co][c * 9 + tap] -> column tap * 4 + c
+          const int8_t* wr = qw + (int64_t)co * g.cin_g * 9;
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const int col = k0 + 16 * gq + 4 * dd + b, tap = col >> 2, c = col & 3;
+              if (tap < 9 && c < g.cin_g) pk |= (uint32_t)(uint8_t)wr[c * 9 + tap] << (8 * b);
+            }
+            a[m][dd] = (int)pk;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m) dw[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], ones, dw[m], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const v4i b = g32_row16(xr[t], k0 + 16 * gq, (g.kind == 2) ? g.xc : K);
+#pragma unroll
+      for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b, d[m][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    const int co = co0 + 16 * m + 4 * gq;
+    if (co >= g.cout) continue;
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const int64_t p = p0 + 16 * t + j;
+      if (p >= npix) continue;
+      v4i o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = d[m][t][i] + (128 - zp) * dw[m][i];
+      *(v4i*)(acc + p * g.cout + co) = o;
+    }
+  }
+}
+
+// ---- depthwise integer conv output: a thread's four channels, its taps packed once (one dword per tap), pixels walked
+template <int K>
+__global__ __launch_bounds__(256) void k_g32_dw_acc(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc) {
+  constexpr int KK = K * K;
+  const G32Map mp = g32_map(g.cout);
+  if (!mp.ok) return;
+  const int c0 = mp.cq * 4, zp = __float_as_int(qx[FROST_Q_ZP]);
+  int w4[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    uint32_t pk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pk |= (uint32_t)(uint8_t)qw[(int64_t)(c0 + b) * KK + t] << (8 * b);
+    w4[t] = (int)pk;
+  }
+  const int npo = g.n * g.ho * g.wo;
+  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npo; p += (int)gridDim.x * mp.PL) {
+    const int ox = p % g.wo, oy = (p / g.wo) % g.ho, in = p / (g.wo * g.ho);
+    v4i s = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * g.stride - g.pad + ky;
+      if (iy < 0 || iy >= g.h) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * g.stride - g.pad + kx;
+        if (ix < 0 || ix >= g.w) continue;
+        const int xv = *(const int*)(x + (((int64_t)in * g.h + iy) * g.w + ix) * g.xc + c0), wv = w4[ky * K + kx];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[b] += (__builtin_amdgcn_sbfe(xv, 8 * b, 8) + 128 - zp) * __builtin_amdgcn_sbfe(wv, 8 * b, 8);
+      }
+    }
+    *(v4i*)(acc + (int64_t)p * g.cout + c0) = s;
+  }
+}
+
+// ---- reduce pass, stage 1: fp64 partial sums of a thread's channel quad over its pixels -> part[row][2][cpad4] (row = blockIdx.x * PL + pl); stage 2 adds the rows in
+// a fixed order (deterministic, no atomics -- as the plain kernel)
+__global__ __launch_bounds__(256) void k_g32_reduce_part(const int32_t* __restrict__ acc, int npix, int cout, int cpad, const float* __restrict__ coef, const float* qy, int relu,
+                                                         const float* __restrict__ gout, double* __restrict__ part) {
+  const G32Map mp = g32_map(cout);
+  if (!mp.ok) return;
+  const int c0 = mp.cq * 4;
+  const G32Win w = g32_win(qy, relu);
+  const v4f A = *(const v4f*)(coef + FROST_COEF_A * cpad + c0), B = *(const v4f*)(coef + FROST_COEF_B * cpad + c0);
+  const v4f M = *(const v4f*)(coef + FROST_COEF_M * cpad + c0), R = *(const v4f*)(coef + FROST_COEF_R * cpad + c0);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npix; p += (int)gridDim.x * mp.PL) {
+    const v4i a = *(const v4i*)(acc + (int64_t)p * cout + c0); const v4f gy4 = *(const v4f*)(gout + (int64_t)p * cout + c0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float af = (float)a[b];
+      const float tq = fmaf(A[b], af, B[b]) * w.y_inv;
+      if (tq > w.t_lo && tq <= w.t_hi) { const double gy = (double)gy4[b]; s1[b] += gy; s2[b] += gy * (((double)af - (double)M[b]) * (double)R[b]); }
+    }
+  }
+  double* row = part + (int64_t)((int)blockIdx.x * mp.PL + mp.pl) * 2 * cout;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { row[c0 + b] = s1[b]; row[cout + c0 + b] = s2[b]; }
+}
+__global__ __launch_bounds__(256) void k_g32_reduce_fin(const double* __restrict__ part, int rows, int cout, int cpad, float* coef) {
+  __shared__ double sh[2][256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int r = tid; r < rows; r += 256) { a += part[(int64_t)r * 2 * cout + c]; b += part[(int64_t)r * 2 * cout + cout + c]; }
+  sh[0][tid] = a; sh[1][tid] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; } __syncthreads(); }
+  if (tid == 0) { coef[FROST_COEF_S1 * cpad + c] = (float)sh[0][0]; coef[FROST_COEF_S2 * cpad + c] = (float)sh[1][0]; }
+}
+
+// ---- dc pass with the same thread map (coefficient rows loaded once per thread)
+__global__ __launch_bounds__(256) void k_g32_dc4(const int32_t* __restrict__ acc, int npix, int cout, int cpad, const float* __restrict__ coef, const float* qy, int relu,
+                                                 const float* __restrict__ gout, float* __restrict__ dc) {
+  const G32Map mp = g32_map(cout);
+  if (!mp.ok) return;
+  const int c0 = mp.cq * 4;
+  const G32Win w = g32_win(qy, relu);
+  const double inv_n = 1.0 / (double)npix;
+  const v4f A = *(const v4f*)(coef + FROST_COEF_A * cpad + c0), B = *(const v4f*)(coef + FROST_COEF_B * cpad + c0);
+  const v4f M = *(const v4f*)(coef + FROST_COEF_M * cpad + c0), R = *(const v4f*)(coef + FROST_COEF_R * cpad + c0);
+  const v4f K1 = *(const v4f*)(coef + FROST_COEF_K1 * cpad + c0), S1 = *(const v4f*)(coef + FROST_COEF_S1 * cpad + c0), S2 = *(const v4f*)(coef + FROST_COEF_S2 * cpad + c0);
+  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npix; p += (int)gridDim.x * mp.PL) {
+    const v4i a = *(const v4i*)(acc + (int64_t)p * cout + c0); const v4f gy4 = *(const v4f*)(gout + (int64_t)p * cout + c0);
+    v4f o;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float af = (float)a[b];
+      const float tq = fmaf(A[b], af, B[b]) * w.y_inv;
+      const double gy = (tq > w.t_lo && tq <= w.t_hi) ? (double)gy4[b] : 0.0;
+      const double xhat = ((double)af - (double)M[b]) * (double)R[b];
+      o[b] = (float)((double)K1[b] * (gy - (double)S1[b] * inv_n - xhat * (double)S2[b] * inv_n));
+    }
+    *(v4f*)(dc + (int64_t)p * cout + c0) = o;
+  }
+}
+
+// ---- pointwise data gradient on v_mfma_f32_16x16x4_f32: D[ci][pixel] = sum_co wf[co][ci] * dc[pixel][co], wf = q_w * s_w (exact in fp32).  The four k slots of
+// MFMA q of a 16-channel step hold co = kb + 4 g + q, so that a lane's dc operands of the four MFMAs are ONE 16-byte load of its pixel's row.
+template <int MI>
+__global__ __launch_bounds__(256) void k_g32_pw_dgrad(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
+                                                      float* __restrict__ gx, int accumulate) {
+  constexpr int NJ = 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const int64_t npix = (int64_t)g.n * g.h * g.w;
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * (NJ * 16);
+  const int ci0 = (int)blockIdx.y * (MI * 16);
+  if (p0 >= npix) return;
+  const float sw0 = qrec_w[FROST_Q_SCALE];
+  v4f d[MI][NJ];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) d[m][t] = (v4f){0, 0, 0, 0};
+  const float* dr[NJ]; bool pok[NJ];
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) { const int64_t p = p0 + 16 * t + j; pok[t] = p < npix; dr[t] = dc + min(p, npix - 1) * g.cout; }
+  for (int kb = 0; kb < g.cout; kb += 16) {
+    const int cok = kb + 4 * gq;                         // this lane's four output channels of the step (cout % 4 == 0: all four inside, or none)
+    const bool kok = cok < g.cout;
+    float a[MI][4];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+      const int ci = ci0 + 16 * m + j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cok + q;
+        a[m][q] = (kok && ci < g.cin_g) ? (float)qw[(int64_t)co * g.cin_g + ci] * (wscale ? wscale[co] : sw0) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const v4f b = (kok && pok[t]) ? *(const v4f*)(dr[t] + cok) : (v4f){0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[q], d[m][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    const int ci = ci0 + 16 * m + 4 * gq;
+    if (ci >= g.xc) continue;
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const int64_t p = p0 + 16 * t + j;
+      if (p >= npix) continue;
+      float* dst = gx + p * g.xc + ci;
+      v4f o = d[m][t];
+      if (accumulate) { const v4f old = *(const v4f*)dst; o = old + o; }
+      *(v4f*)dst = o;
+    }
+  }
+}
+
+// ---- depthwise data gradient with the channel-quad map (taps packed once)
+template <int K>
+__global__ __launch_bounds__(256) void k_g32_dw_dgrad(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
+                                                      float* __restrict__ gx, int accumulate) {
+  constexpr int KK = K * K;
+  const G32Map mp = g32_map(g.xc);
+  if (!mp.ok) return;
+  const int c0 = mp.cq * 4;
+  const float sw0 = qrec_w[FROST_Q_SCALE];
+  float sw[4]; int w4[KK];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) sw[b] = wscale ? wscale[c0 + b] : sw0;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) {
+    uint32_t pk = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) pk |= (uint32_t)(uint8_t)qw[(int64_t)(c0 + b) * KK + t] << (8 * b);
+    w4[t] = (int)pk;
+  }
+  const int npi = g.n * g.h * g.w;
+  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npi; p += (int)gridDim.x * mp.PL) {
+    const int ix = p % g.w, iy = (p / g.w) % g.h, in = p / (g.w * g.h);
+    double s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int ty = iy + g.pad - ky;
+      if (ty < 0 || ty % g.stride) continue;
+      const int oy = ty / g.stride;
+      if (oy >= g.ho) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int tx = ix + g.pad - kx;
+        if (tx < 0 || tx % g.stride) continue;
+        const int ox = tx / g.stride;
+        if (ox >= g.wo) continue;
+        const v4f dv = *(const v4f*)(dc + (((int64_t)in * g.ho + oy) * g.wo + ox) * g.cout + c0);
+        const int wv = w4[ky * K + kx];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s[b] += (double)dv[b] * (double)((float)__builtin_amdgcn_sbfe(wv, 8 * b, 8) * sw[b]);
+      }
+    }
+    float* dst = gx + (int64_t)p * g.xc + c0;
+    v4f o = {(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+    if (accumulate) { const v4f old = *(const v4f*)dst; o = old + o; }
+    *(v4f*)dst = o;
+  }
+}
+
+// ---- pointwise / stem weight gradient, stage 1, on v_mfma_f32_16x16x4_f32: D[co][col] = sum_pixels dc[p][co] * (q_x[p][col] - zp), K = the pixels of the wave's chunk.
+// One 16-byte load of a dc row gives a lane the A operands of FOUR co tiles (tile r holds co = co0 + 4 m + r in row m), one dword of the x row the B operands of four
+// column tiles (col = ci0 + 4 n + r): 16 MFMAs per two loads.  Partial tiles -> part[chunk][co][ncp] (fp32), stage 2 adds the chunks in fp64 in a fixed order.
+__global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, int ncol, int ncp,
+                                                           int chunk_px, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const int64_t npix = (int64_t)g.n * g.ho * g.wo;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t lo = chunk * chunk_px, hi = min(lo + chunk_px, npix);
+  if (lo >= npix) return;
+  const int co0 = (int)blockIdx.y * 64, ci0 = (int)blockIdx.z * 64;
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  const bool aok = (co0 + 4 * j) < g.cout, bok = (ci0 + 4 * j) < ncol;
+  v4f d[4][4];
+#pragma unroll
+  for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) d[ra][rb] = (v4f){0, 0, 0, 0};
+  const float* ap = dc + co0 + 4 * j; const int8_t* bp = x + ci0 + 4 * j;
+  for (int64_t pb = lo; pb < hi; pb += 4) {
+    const int64_t p = pb + gq; const bool ok = p < hi;
+    const v4f a = (ok && aok) ? *(const v4f*)(ap + p * g.cout) : (v4f){0, 0, 0, 0};
+    const int xv = (ok && bok) ? *(const int*)(bp + p * g.xc) : 0;
+    float b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = (ok && bok) ? (float)(__builtin_amdgcn_sbfe(xv, 8 * r, 8) + 128 - zp) : 0.0f;
+#pragma unroll
+    for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ra], b[rb], d[ra][rb], 0, 0, 0);
+  }
+  float* prt = part + chunk * (int64_t)g.cout * ncp;
+#pragma unroll
+  for (int ra = 0; ra < 4; ++ra)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 4 * (4 * gq + i) + ra, col = ci0 + 4 * j + rb;
+        if (co < g.cout && col < ncp) prt[(int64_t)co * ncp + col] = d[ra][rb][i];
+      }
+}
+// stage 2 of the weight gradients: out[e] = scale * sum_rows part[row][e'] in fp64, fixed order.  kind 2 maps the OIHW index c * 9 + tap to the im2col column tap * 4 + c.
+template <typename T>
+__global__ __launch_bounds__(256) void k_g32_sum_part(const T* __restrict__ part, int rows, int cout, int per, int ncp, int kind, const float* qx, float* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cout * per) return;
+  const int co = e / per, jj = e - co * per;
+  const int col = (kind == 2) ? ((jj % 9) * 4 + jj / 9) : jj;
+  const int64_t stride = (int64_t)cout * ncp;
+  const T* src = part + (int64_t)co * ncp + col;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)src[r * stride];
+  out[e] = (float)(s * (double)qx[FROST_Q_SCALE]);
+}
+// ---- depthwise weight gradient, stage 1: a thread = one channel, fp64 sums of its taps over its pixels -> part[row][c][kk] (fp64)
+template <int K>
+__global__ __launch_bounds__(256) void k_g32_dw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, double* __restrict__ part) {
+  constexpr int KK = K * K;
+  const int CB = min(g.cout, 256), PL = 256 / CB;
+  const int pl = (int)threadIdx.x / CB, c = (int)blockIdx.y * 256 + (int)threadIdx.x % CB;
+  if (pl >= PL || c >= g.cout) return;
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  double s[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t) s[t] = 0.0;
+  const int npo = g.n * g.ho * g.wo;
+  for (int p = (int)blockIdx.x * PL + pl; p < npo; p += (int)gridDim.x * PL) {
+    const int ox = p % g.wo, oy = (p / g.wo) % g.ho, in = p / (g.wo * g.ho);
+    const double dv = (double)dc[(int64_t)p * g.cout + c];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * g.stride - g.pad + ky;
+      if (iy < 0 || iy >= g.h) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * g.stride - g.pad + kx;
+        if (ix < 0 || ix >= g.w) continue;
+        s[ky * K + kx] += dv * (double)(g32_x(x, (((int64_t)in * g.h + iy) * g.w + ix) * g.xc + c) - zp);
+      }
+    }
+  }
+  double* row = part + ((int64_t)((int)blockIdx.x * PL + pl) * g.cout + c) * KK;
+#pragma unroll
+  for (int t = 0; t < KK; ++t) row[t] = s[t];
+}
+
+static G32Geo g32_geo(int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride) {
+  G32Geo g; g.kind = kind; g.n = n; g.h = h; g.w = w; g.xc = xc; g.cin_g = cin_g; g.cout = cout; g.k = k; g.stride = stride; g.pad = (k - 1) / 2;
+  if (kind == 1) { g.ho = (h + 2 * g.pad - k) / stride + 1; g.wo = (w + 2 * g.pad - k) / stride + 1; } else { g.ho = h; g.wo = w; }
+  return g;
+}
+/* kind 0 / 2: (n, h, w) = the OUTPUT map (x is already per output pixel); kind 1: (n, h, w) = the input map */
+// FROST_G32_PLAIN=1 / frost_g32_set_plain(1): the round-4 one-thread-per-output kernels (A/B, debugging, the yardstick of tests/test_gpu_round5.py)
+static int g_g32_plain = -1;
+static int g32_fast() { if (g_g32_plain < 0) g_g32_plain = (getenv("FROST_G32_PLAIN") && atoi(getenv("FROST_G32_PLAIN"))) ? 1 : 0; return !g_g32_plain; }
+extern "C" int frost_g32_set_plain(int on) { g_g32_plain = on ? 1 : 0; return 0; }
+extern "C" int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k,
+                                  int stride, int32_t* acc, void* stream) {
+  const G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, k, stride);
+  hipStream_t s = as_stream(stream);
+  const int64_t npo = (int64_t)g.n * g.ho * g.wo;
+  if (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npo < (1ll << 31)) {
+    if ((kind == 0 && (cin_g % 4) == 0) || (kind == 2 && xc <= 64 && cin_g <= 4)) {
+      const unsigned gx = (unsigned)((npo + 255) / 256);
+      if (cout <= 16) hipLaunchKernelGGL((k_g32_pw_acc<1>), dim3(gx, (unsigned)((cout + 15) / 16)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      else if (cout <= 32) hipLaunchKernelGGL((k_g32_pw_acc<2>), dim3(gx, (unsigned)((cout + 31) / 32)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      else hipLaunchKernelGGL((k_g32_pw_acc<4>), dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      return frost_check_launch("g32_conv_acc");
+    }
+    if (kind == 1 && (k == 3 || k == 5)) {
+      int64_t bx = (npo + g32_map_pl(cout) - 1) / g32_map_pl(cout); if (bx > 8192) bx = 8192;
+      if (k == 3) hipLaunchKernelGGL((k_g32_dw_acc<3>), g32_map_grid(cout, bx), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      else hipLaunchKernelGGL((k_g32_dw_acc<5>), g32_map_grid(cout, bx), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      return frost_check_launch("g32_conv_acc");
+    }
+  }
+  int64_t grid = (npo * cout + 255) / 256; if (grid > 65535) grid = 65535;
+  hipLaunchKernelGGL(k_g32_conv_acc, dim3((unsigned)grid), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+  return frost_check_launch("g32_conv_acc");
 }
 
 // reduce pass: S1[c] = sum gy, S2[c] = sum gy * xhat -- one workgroup per channel, fp64 partial sums, no atomics (deterministic)
@@ -101,8 +508,21 @@ __global__ __launch_bounds__(256) void k_g32_reduce(const int32_t* __restrict__ 
   for (int o = 128; o > 0; o >>= 1) { if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; } __syncthreads(); }
   if (tid == 0) { coef[FROST_COEF_S1 * cpad + c] = (float)sh[0][0]; coef[FROST_COEF_S2 * cpad + c] = (float)sh[1][0]; }
 }
-extern "C" int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* stream) {
-  hipLaunchKernelGGL(k_g32_reduce, dim3((unsigned)cout), dim3(256), 0, as_stream(stream), acc, npix, cout, round_up(cout, 16), coef, qrec_y, relu, gout);
+/* scratch: fp64 partial sums of the two-stage form, >= frost_g32_scratch_bytes(); NULL selects the plain one-workgroup-per-channel kernel */
+extern "C" int64_t frost_g32_scratch_bytes(void) { return (int64_t)160 << 20; }
+extern "C" int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* scratch, void* stream) {
+  hipStream_t s = as_stream(stream);
+  const int cpad = round_up(cout, 16);
+  if (g32_fast() && scratch && (cout % 4) == 0 && npix < (1ll << 31)) {
+    const int PL = g32_map_pl(cout);
+    int64_t bx = (npix + (int64_t)PL * 64 - 1) / ((int64_t)PL * 64);                   // ~64 pixels per thread
+    const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)PL * 2 * cout * 8);
+    if (bx > cap) bx = cap; if (bx > 2048) bx = 2048; if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_g32_reduce_part, g32_map_grid(cout, bx), dim3(256), 0, s, acc, (int)npix, cout, cpad, coef, qrec_y, relu, gout, (double*)scratch);
+    hipLaunchKernelGGL(k_g32_reduce_fin, dim3((unsigned)cout), dim3(256), 0, s, (const double*)scratch, (int)(bx * PL), cout, cpad, coef);
+    return frost_check_launch("g32_reduce");
+  }
+  hipLaunchKernelGGL(k_g32_reduce, dim3((unsigned)cout), dim3(256), 0, s, acc, npix, cout, cpad, coef, qrec_y, relu, gout);
   return frost_check_launch("g32_reduce");
 }
 
@@ -125,8 +545,15 @@ __global__ __launch_bounds__(256) void k_g32_dc(const int32_t* __restrict__ acc,
 }
 extern "C" int frost_g32_dc(const int32_t* acc, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const float* gout, float* dc,
                             void* stream) {
+  hipStream_t s = as_stream(stream);
+  if (g32_fast() && (cout % 4) == 0 && npix < (1ll << 31)) {
+    const int PL = g32_map_pl(cout);
+    int64_t bx = (npix + (int64_t)PL * 16 - 1) / ((int64_t)PL * 16); if (bx > 16384) bx = 16384;
+    hipLaunchKernelGGL(k_g32_dc4, g32_map_grid(cout, bx), dim3(256), 0, s, acc, (int)npix, cout, round_up(cout, 16), coef, qrec_y, relu, gout, dc);
+    return frost_check_launch("g32_dc");
+  }
   int64_t grid = (npix * cout + 255) / 256; if (grid > 65535) grid = 65535;
-  hipLaunchKernelGGL(k_g32_dc, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), acc, npix, cout, round_up(cout, 16), coef, qrec_y, relu, gout, dc);
+  hipLaunchKernelGGL(k_g32_dc, dim3((unsigned)grid), dim3(256), 0, s, acc, npix, cout, round_up(cout, 16), coef, qrec_y, relu, gout, dc);
   return frost_check_launch("g32_dc");
 }
 
@@ -154,8 +581,25 @@ extern "C" int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* q
                                int cout, int k, int stride, float* gx, int accumulate, void* stream) {
   FROST_REQUIRE(kind == 0 || kind == 1, "g32_dgrad: pointwise or depthwise");
   G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, k, stride);
-  int64_t grid = ((int64_t)n * h * w * xc + 255) / 256; if (grid > 65535) grid = 65535;
-  hipLaunchKernelGGL(k_g32_dgrad, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), dc, qw, qrec_w, wscale, g, gx, accumulate);
+  hipStream_t s = as_stream(stream);
+  const int64_t npi = (int64_t)n * h * w;
+  if (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npi < (1ll << 31)) {
+    if (kind == 0) {
+      const unsigned bx = (unsigned)((npi + 255) / 256);
+      if (xc <= 16) hipLaunchKernelGGL((k_g32_pw_dgrad<1>), dim3(bx, (unsigned)((xc + 15) / 16)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      else if (xc <= 32) hipLaunchKernelGGL((k_g32_pw_dgrad<2>), dim3(bx, (unsigned)((xc + 31) / 32)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      else hipLaunchKernelGGL((k_g32_pw_dgrad<4>), dim3(bx, (unsigned)((xc + 63) / 64)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      return frost_check_launch("g32_dgrad");
+    }
+    if (xc == cout && (k == 3 || k == 5)) {
+      int64_t bx = (npi + g32_map_pl(xc) - 1) / g32_map_pl(xc); if (bx > 8192) bx = 8192;
+      if (k == 3) hipLaunchKernelGGL((k_g32_dw_dgrad<3>), g32_map_grid(xc, bx), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      else hipLaunchKernelGGL((k_g32_dw_dgrad<5>), g32_map_grid(xc, bx), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      return frost_check_launch("g32_dgrad");
+    }
+  }
+  int64_t grid = (npi * xc + 255) / 256; if (grid > 65535) grid = 65535;
+  hipLaunchKernelGGL(k_g32_dgrad, dim3((unsigned)grid), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
   return frost_check_launch("g32_dgrad");
 }
 
@@ -184,11 +628,40 @@ __global__ __launch_bounds__(256) void k_g32_wgrad(const float* __restrict__ dc,
   for (int o = 128; o > 0; o >>= 1) { if (tid < o) sh[tid] += sh[tid + o]; __syncthreads(); }
   if (tid == 0) dwq[(int64_t)co * per + jj] = (float)(sh[0] * (double)qx[FROST_Q_SCALE]);
 }
+/* scratch: partial tiles of the two-stage form, >= frost_g32_scratch_bytes(); NULL selects the plain one-workgroup-per-weight kernel */
 extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qrec_x, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride,
-                               float* dwq, void* stream) {
+                               float* dwq, void* scratch, void* stream) {
   G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, k, stride);
+  hipStream_t s = as_stream(stream);
   const int per = (kind == 1) ? k * k : (kind == 2 ? cin_g * 9 : cin_g);
-  hipLaunchKernelGGL(k_g32_wgrad, dim3((unsigned)(cout * per)), dim3(256), 0, as_stream(stream), dc, x, qrec_x, g, dwq);
+  const int64_t npo = (int64_t)g.n * g.ho * g.wo;
+  if (g32_fast() && scratch && (cout % 4) == 0 && (xc % 4) == 0 && npo < (1ll << 31)) {
+    if ((kind == 0 && (cin_g % 4) == 0) || (kind == 2 && cin_g <= 4)) {
+      const int ncol = (kind == 2) ? xc : cin_g, ncp = ncol;
+      int64_t chunk_px = 1024;
+      const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)cout * ncp * 4);            // chunks the scratch holds
+      while ((npo + chunk_px - 1) / chunk_px > cap) chunk_px *= 2;
+      const int64_t nchunk = (npo + chunk_px - 1) / chunk_px;
+      hipLaunchKernelGGL(k_g32_pw_wgrad_part, dim3((unsigned)((nchunk + 3) / 4), (unsigned)((cout + 63) / 64), (unsigned)((ncol + 63) / 64)), dim3(256), 0, s, dc, x,
+                         qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch);
+      hipLaunchKernelGGL((k_g32_sum_part<float>), dim3((unsigned)((cout * per + 255) / 256)), dim3(256), 0, s, (const float*)scratch, (int)nchunk, cout, per, ncp, kind,
+                         qrec_x, dwq);
+      return frost_check_launch("g32_wgrad");
+    }
+    if (kind == 1 && (k == 3 || k == 5)) {
+      const int CB = cout < 256 ? cout : 256, PL = 256 / CB;
+      int64_t bx = (npo + (int64_t)PL * 256 - 1) / ((int64_t)PL * 256);                     // ~256 pixels per thread
+      const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)PL * cout * per * 8);
+      if (bx > cap) bx = cap; if (bx > 4096) bx = 4096; if (bx < 1) bx = 1;
+      const dim3 grid((unsigned)bx, (unsigned)((cout + 255) / 256));
+      if (k == 3) hipLaunchKernelGGL((k_g32_dw_wgrad_part<3>), grid, dim3(256), 0, s, dc, x, qrec_x, g, (double*)scratch);
+      else hipLaunchKernelGGL((k_g32_dw_wgrad_part<5>), grid, dim3(256), 0, s, dc, x, qrec_x, g, (double*)scratch);
+      hipLaunchKernelGGL((k_g32_sum_part<double>), dim3((unsigned)((cout * per + 255) / 256)), dim3(256), 0, s, (const double*)scratch, (int)(bx * PL), cout, per, per, 1,
+                         qrec_x, dwq);
+      return frost_check_launch("g32_wgrad");
+    }
+  }
+  hipLaunchKernelGGL(k_g32_wgrad, dim3((unsigned)(cout * per)), dim3(256), 0, s, dc, x, qrec_x, g, dwq);
   return frost_check_launch("g32_wgrad");
 }
 

@@ -774,7 +774,10 @@ class Engine:
         geo = (kind, x.n, x.h, x.w, x.c, cin_g, l.cout, l.k, l.stride)
         acc = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
         call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s)
-        call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), s)
+        if getattr(self, "_g32_scratch", None) is None:          # partial sums / partial tiles of the two-stage reductions (deterministic, fp64 second stage)
+            self._g32_scratch = torch.empty(int(L.load_library().frost_g32_scratch_bytes()), dtype=torch.uint8, device=self.device)
+        scr = self._g32_scratch
+        call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
         self._frozen_after_reduce(l)
         dc = torch.empty(y.numel + 64, dtype=torch.float32, device=self.device)
         call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
@@ -783,7 +786,7 @@ class Engine:
         if x.needs_grad:
             gx, accf = self._grad_slot(x)
             call("frost_g32_dgrad", ptr(dc), ptr(qw), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, *geo, ptr(gx), accf, s)
-        call("frost_g32_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), *geo, ptr(l.dwq), s)
+        call("frost_g32_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), *geo, ptr(l.dwq), ptr(scr), s)
         self._after_conv_backward(l, s)
         y.grad = None
 

@@ -32,8 +32,9 @@ extern "C" {
  *          the state of frost_add_minmax_observe / frost_pw_ew_emit_add is frost_add_state_floats() floats: {2 unused, ticket[FROST_TICKET_WORDS], per-workgroup
  *          range slots} (was {lo, hi, ticket}); FrostFinDesc gained
  *          cat_qrec_b / cat_qrec_y.  A 1-word ticket under the new kernels is an out-of-bounds device atomic: frost_ticket_words() and
- *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does). */
-#define FROST_ABI_VERSION 3
+ *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does).
+ *   3 -> 4 (round 5): frost_g32_reduce / frost_g32_wgrad take a `scratch` pointer (>= frost_g32_scratch_bytes() bytes; NULL = the plain kernels) before `stream`. */
+#define FROST_ABI_VERSION 4
 
 /* qrecord field indices (floats) */
 #define FROST_Q_MIN 0
@@ -284,7 +285,9 @@ int frost_infer_add(const uint16_t* a, const uint16_t* b, int64_t n, uint16_t* y
 int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void* stream);
 /* ---- fp32-GRADIENT parity mode of the fake-quant backward (csrc/frost_g32.hip) --------------------------------------------------------------
  * replaces: the reference's fp32 autograd (loss.backward(), Classification/utils/helper_functions.py:139-143) for one ConvBn(ReLU)2d + activation FakeQuantize, with
- * the production backward's formulas but fp32 gradient storage and fp64 sums (plain one-thread-per-output kernels; 10-30 x slower -- a parity instrument).
+ * the production backward's formulas but fp32 gradient storage and fp64 sums.  Since round 5 the entries run tiled kernels (int8 MFMA conv output, fp32 MFMA data / weight
+ * gradients, two-stage deterministic sums through `scratch`, >= frost_g32_scratch_bytes() bytes of device memory; scratch == NULL or a channel count that is not a
+ * multiple of 4 selects the round-4 one-thread-per-output kernels).
  *   frost_g32_wq        fake-quantised weight INDICES [cout][per] (OIHW), q = clamp(rint(W * gamma/sigma_r / s_w), -128, 127)
  *   frost_g32_conv_acc  exact int32 conv output acc[p][co] = sum (q_x - zp_x) q_w;  kind 0 pointwise / 2 stem-on-im2col: (n, h, w) = the OUTPUT map, x = [npix][xc];
  *                       kind 1 depthwise: (n, h, w) = the input map
@@ -294,12 +297,14 @@ int frost_infer_avgpool(const uint16_t* x, int n, int hw, int c, float* y, void*
 int frost_g32_wq(const float* w, const float* gamma, const float* sigma, const float* qrec_w, const float* wscale, int cout, int per, int8_t* out, void* stream);
 int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride,
                        int32_t* acc, void* stream);
-int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* stream);
+int64_t frost_g32_scratch_bytes(void);
+int frost_g32_set_plain(int on);   /* 1: every frost_g32_* entry runs its plain (round-4) kernel -- the yardstick of the fast forms; default 0 (env FROST_G32_PLAIN) */
+int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* scratch, void* stream);
 int frost_g32_dc(const int32_t* acc, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const float* gout, float* dc, void* stream);
 int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* qrec_w, const float* wscale, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k,
                     int stride, float* gx, int accumulate, void* stream);
 int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qrec_x, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride, float* dwq,
-                    void* stream);
+                    void* scratch, void* stream);
 int frost_g32_cat_bwd(const float* gy, const int8_t* a, const float* qrec_a, int ca, const int8_t* b, const float* qrec_b, int cb, int64_t npix, const float* qrec_y,
                       float* ga, int acc_a, float* gb, int acc_b, void* stream);
 int frost_g32_add_bwd(const float* gy, const int8_t* a, const float* qrec_a, const int8_t* b, const float* qrec_b, int64_t n, const float* qrec_y, float* ga, int acc_a,

@@ -1,0 +1,146 @@
+"""Round-5 additions on the GPU: the FAST forms of the fp32-gradient mode (csrc/frost_g32.hip, section "fast forms": int8-MFMA conv output, fp32-MFMA data / weight
+gradients, two-stage deterministic sums) against the plain one-thread-per-output kernels of round 4, entry by entry through the C ABI, on production layer shapes
+(reference: loss.backward() is fp32 autograd, Classification/utils/helper_functions.py:139-143; the mode-level parity against the oracle / the reference golden is
+tests/test_gpu_round4.py::test_fp32_gradient_mode_*)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import _lib
+    assert torch.cuda.is_available()
+    yield _lib
+    _lib.load_library().frost_g32_set_plain(0)
+
+
+def relerr(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# (name, kind, cin, cout, k, stride, H, N): kind 0 pointwise, 1 depthwise, 2 stem on the im2col'd input.  Widths / maps of FrostNet-Large (frostnet.py:176-198) at small
+# batches, plus ragged cases: a K that is no multiple of 64 / 16, a pixel count that is no multiple of the 64-pixel wave tile, cout > 1024 (two quad blocks).
+CASES = [("pw16_96_28", 0, 16, 96, 1, 1, 28, 3), ("pw104_624_14", 0, 104, 624, 1, 1, 14, 3), ("pw624_104_14", 0, 624, 104, 1, 1, 14, 2), ("pw288_1728_7", 0, 288, 1728, 1, 1, 7, 5),
+         ("pw1728_320_7", 0, 1728, 320, 1, 1, 7, 3), ("pw40_24_9", 0, 40, 24, 1, 1, 9, 1), ("pw24_8_5", 0, 24, 8, 1, 1, 5, 1),
+         ("dw96_k3s2_28", 1, 96, 96, 3, 2, 28, 2), ("dw144_k5s2_14", 1, 144, 144, 5, 2, 14, 3), ("dw624_k3s1_14", 1, 624, 624, 3, 1, 14, 2), ("dw1440_k5s1_7", 1, 1440, 1440, 5, 1, 7, 3),
+         ("dw32_k3s1_9", 1, 32, 32, 3, 1, 9, 1), ("stem_3_32_20", 2, 3, 32, 3, 1, 20, 2)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_fp32_gradient_fast_forms_equal_the_plain_kernels(L, case):
+    """Every frost_g32_* entry, fast form vs plain form on the same inputs: the integer conv output and dc bit-equal, S1 / S2 to fp32 rounding of the same fp64 sums,
+    the data / weight gradients (fp32 MFMA accumulation vs fp64 sums) norm-wise <= 2e-6 -- three orders inside the mode's 1e-3 bound."""
+    from frostnet_amd.engine import ptr, stream
+    name, kind, cin, cout, k, stride, H, N = case
+    lib = L.load_library()
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(500 + CASES.index(case))
+    pad = (k - 1) // 2
+    if kind == 1:
+        h = w = H
+        ho = (H + 2 * pad - k) // stride + 1
+        xc, cin_g, per = cin, 1, k * k
+        nin, npo = N * H * H, N * ho * ho
+        geo = (kind, N, H, H, xc, cin_g, cout, k, stride)
+    else:
+        ho = H
+        xc = 40 if kind == 2 else cin
+        cin_g = cin
+        per = cin * 9 if kind == 2 else cin
+        nin = npo = N * H * H
+        geo = (kind, N, H, H, xc, cin_g, cout, 1 if kind == 0 else 3, 1)
+    x = torch.randint(-128, 128, (nin * xc + 64,), generator=g, dtype=torch.int8).to(dev)
+    qw = torch.randint(-128, 128, (cout * per + 64,), generator=g, dtype=torch.int8).to(dev)
+    zp = 117
+    qx = torch.zeros(16, dtype=torch.float32)
+    qx[2] = 0.0231
+    qx[3] = torch.tensor([zp], dtype=torch.int32).view(torch.float32)[0]
+    qx[6] = 1.0 / 0.0231
+    qy = torch.zeros(16, dtype=torch.float32)
+    qy[2] = 0.05
+    qy[3] = torch.tensor([3], dtype=torch.int32).view(torch.float32)[0]
+    qy[6] = 20.0
+    qwr = torch.zeros(16, dtype=torch.float32)
+    qwr[2] = 0.0123
+    qx, qy, qwr = qx.to(dev), qy.to(dev), qwr.to(dev)
+    cpad = (cout + 15) // 16 * 16
+    coef0 = torch.zeros(8 * cpad, dtype=torch.float32)           # rows A, B, M, R, K1, ... (include/frost_hip.h FROST_COEF_*)
+    kk = cin_g * (k * k if kind == 1 else (9 if kind == 2 else 1))
+    coef0.view(8, cpad)[0, :cout] = (torch.rand(cout, generator=g) + 0.5) * 0.05 / (40.0 * kk ** 0.5)      # A: acc -> a few output levels
+    coef0.view(8, cpad)[1, :cout] = torch.randn(cout, generator=g) * 0.05
+    coef0.view(8, cpad)[2, :cout] = torch.randn(cout, generator=g) * 10.0
+    coef0.view(8, cpad)[3, :cout] = (torch.rand(cout, generator=g) + 0.5) / (40.0 * kk ** 0.5)
+    coef0.view(8, cpad)[4, :cout] = torch.rand(cout, generator=g) + 0.5
+    gout = (torch.randn(npo * cout + 64, generator=g) * 1e-3).to(dev)
+    scr = torch.empty(int(lib.frost_g32_scratch_bytes()), dtype=torch.uint8, device=dev)
+    s = stream()
+    res = {}
+    for plain in (1, 0):
+        lib.frost_g32_set_plain(plain)
+        coef = coef0.clone().to(dev)
+        acc = torch.zeros(npo * cout + 64, dtype=torch.int32, device=dev)
+        dc = torch.zeros(npo * cout + 64, dtype=torch.float32, device=dev)
+        L.call("frost_g32_conv_acc", ptr(x), ptr(qx), ptr(qw), *geo, ptr(acc), s)
+        L.call("frost_g32_reduce", ptr(acc), npo, cout, ptr(coef), ptr(qy), 1, ptr(gout), ptr(scr), s)
+        s12 = coef.view(8, cpad).clone()
+        L.call("frost_g32_dc", ptr(acc), npo, cout, ptr(coef), ptr(qy), 1, ptr(gout), ptr(dc), s)
+        out = {"acc": acc[: npo * cout].clone(), "coef": s12, "dc": dc[: npo * cout].clone()}
+        if kind != 2:
+            for accum in (0, 1):
+                gx = torch.full((nin * xc + 64,), 0.25, dtype=torch.float32, device=dev)
+                L.call("frost_g32_dgrad", ptr(dc), ptr(qw), ptr(qwr), None, *geo, ptr(gx), accum, s)
+                out[f"gx{accum}"] = gx[: nin * xc].clone()
+        dwq = torch.zeros(cout * per, dtype=torch.float32, device=dev)
+        L.call("frost_g32_wgrad", ptr(dc), ptr(x), ptr(qx), *geo, ptr(dwq), ptr(scr), s)
+        out["dwq"] = dwq
+        torch.cuda.synchronize()
+        res[plain] = out
+    lib.frost_g32_set_plain(0)
+    a, b = res[0], res[1]
+    assert torch.equal(a["acc"], b["acc"]), (name, "integer conv output")
+    assert float(b["acc"].float().abs().max()) > 0
+    srow = [r for r in range(8) if not torch.equal(b["coef"][r], coef0.view(8, cpad).to(dev)[r])]          # the rows the reduce pass wrote: S1, S2
+    assert len(srow) == 2, srow
+    for r in srow:
+        assert relerr(a["coef"][r], b["coef"][r]) <= 1e-6, (name, "S row", r, relerr(a["coef"][r], b["coef"][r]))
+    for r in range(8):
+        if r not in srow:
+            assert torch.equal(a["coef"][r], b["coef"][r])
+    assert relerr(a["dc"], b["dc"]) <= 1e-6, (name, "dc", relerr(a["dc"], b["dc"]))          # (the S rows differ in their last bit)
+    errs = {key: relerr(a[key], b[key]) for key in a if key.startswith("gx") or key == "dwq"}
+    print(f"[g32 fast vs plain {name}] " + " ".join(f"{k_} {v:.1e}" for k_, v in errs.items()))
+    assert all(v <= 2e-6 for v in errs.values()), (name, errs)
+    assert float(b["dwq"].abs().max()) > 0 and float(b["dc"].abs().max()) > 0
+
+
+def test_fp32_gradient_mode_trains_a_step_at_the_bf16_modes_loss(L):
+    """The mode end to end through the module surface: one QAT step of FrostNet-Small with `grad_precision = "fp32"` next to the production bf16 step from the same state --
+    same forward (bit-equal logits), parameter gradients of the classifier / last_layer (the tail of the backward, before chaos amplifies) within the bf16 mode's own bound."""
+    from frostnet_amd import frostnet as F
+    grads = {}
+    for mode in ("bf16", "fp32"):
+        torch.manual_seed(11)
+        model = F.MODEL_REGISTRY["frostnet_quant_small_1_0"](drop_rate=0.0)
+        F.qat_prepare(model, version=0)
+        model.cuda().train()
+        model.grad_precision = mode
+        x = torch.randn(8, 3, 96, 96, generator=torch.Generator().manual_seed(5)).cuda()
+        y = torch.arange(8, device="cuda") % 1000
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[mode] = ({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, out.detach().clone())
+    assert torch.equal(grads["bf16"][1], grads["fp32"][1])
+    ga, gb = grads["bf16"][0], grads["fp32"][0]
+    assert set(ga) == set(gb) and len(ga) > 100
+    for n in ga:
+        if n.startswith("classifier.") or n.startswith("last_layer."):
+            assert relerr(ga[n], gb[n]) <= 3e-2, (n, relerr(ga[n], gb[n]))
+    assert all(torch.isfinite(v).all() for v in gb.values())
