@@ -199,6 +199,8 @@ _PROTOS = {
     "frost_g32_add_bwd": [P, P, P, P, P, L, P, P, I, P, I, P],
     "frost_g32_pool_bwd": [P, P, I, I, I, P, P],
     "frost_sq_emit_cat_ok": [I, I],
+    "frost_sq_fwd_ok": [L, I, I],
+    "frost_sq_fwd": [P, P, P, P, L, I, I, P, P, P, P, P],
     "frost_sq_emit_cat": [P, P, P, P, L, I, I, P, P, P, P, P, I, P],
     "frost_sq_bwd_cat_ok": [I, I],
     "frost_sq_bwd_cat": [P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, I, P],

@@ -1372,6 +1372,222 @@ extern "C" int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int
   return frost_check_launch("sq_emit_cat");
 }
 
+// ================================================================================================ squeeze_conv forward as ONE persistent launch
+// statistics -> [device-wide barrier, the finalize inside it] -> emit + cat (frostnet.py:127-129), the first multi-phase kernel of the training path (SURVEY 8(f) N1;
+// VERDICT r4 #1).  One workgroup per 128-pixel tile, every workgroup resident at once (frost_sq_fwd_ok checks the grid against the occupancy): the tile's integer conv
+// output stays in the MFMA accumulators across the barrier, so x is staged once, the GEMM runs once and the emit pass has no launch, no prologue and no recomputation.
+// The barrier is the hierarchical ticket of last_block_done2 (32 sub-counters + one main counter, relaxed agent-scope atomics: 1.7 - 2.4 us for 256 - 1024 workgroups,
+// profiles/r05_gridbar_probe.txt) with the LAST arrival running conv_finalize_dev<true> -- coefficient rows and FakeQuantize records written by agent-scope stores --
+// before it flips the generation word (ticket word 36, monotonic) the other workgroups poll; they read rows and records back through agent-scope loads, so no L2
+// write-back / invalidate sits on the path.  Results are bit-identical to frost_pw_conv_fwd_fin + frost_sq_emit_cat (integer statistics: order-independent).
+// A workgroup that polls for ~2^22 rounds gives up, raises ticket word 37 and emits with whatever it reads: wrong results and a test failure instead of a hung device.
+#define SQF_GEN 36
+#define SQF_ERR 37
+struct SqFwdP { SqCatP c; uint8_t* stats; FrostFinDesc fin; };
+template <int KSM, int CTM>
+__global__ __launch_bounds__(256, 4) void k_sq_fwd(const SqFwdP q) {
+  const SqCatP& p = q.c;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                          // [128][kstr]
+  uint8_t* const lut = smem + 128 * p.kstr;          // [2][256]
+  int* const sflag = (int*)(lut + 512);              // 16 B: flag; then 8 floats for the finalize's reduction
+  float* const shf = (float*)(lut + 512 + 16);
+  unsigned long long* const l_s1 = (unsigned long long*)(lut + 512 + 64);
+  unsigned long long* const l_s2 = l_s1 + p.cpad;
+  int* const l_mn = (int*)(l_s2 + p.cpad); int* const l_mx = l_mn + p.cpad;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t p0 = (int64_t)blockIdx.x * 128;
+  uint32_t gen0 = 0;
+  if (tid == 0) gen0 = __hip_atomic_load(q.fin.counter + SQF_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // before this workgroup can arrive: nobody can have flipped it
+  for (int i = tid; i < p.cpad; i += 256) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }
+  {
+    const int upr = p.cin >> 3; const int total = 128 * upr;
+    for (int u = tid; u < total; u += 256) {
+      const int row = u / upr, col = u - row * upr;
+      const int64_t px = p0 + row;
+      uint2 v = make_uint2(0, 0);
+      if (px < p.npix) v = *(const uint2*)(p.x + px * p.cin + col * 8);
+      *(uint2*)(xs + row * p.kstr + col * 8) = v;
+    }
+  }
+  __syncthreads();
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  const int CT = p.cpad >> 4;
+  v4i acc[CTM][2];
+  // ---- phase 1: the tile's integer conv output (kept) and its exact statistics
+#pragma unroll
+  for (int ct = 0; ct < CTM; ++ct) {
+    if (ct < CT) {
+      const int ch = ct * 16 + 4 * g;
+      v4i afr[KSM];
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) afr[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+      const int4 ws = *(const int4*)(p.wsum + ch);
+      int a1[4] = {0, 0, 0, 0}, mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+      long long a2[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = (wv * 2 + t) * 16 + j;
+        v4i a = (v4i){-zpx * ws.x, -zpx * ws.y, -zpx * ws.z, -zpx * ws.w};
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+          const v4i bfr = *(const v4i*)(xs + row * p.kstr + ks * 64 + g * 16);
+          a = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[ks], bfr, a, 0, 0, 0);
+        }
+        acc[ct][t] = a;
+        if ((p0 + row) < p.npix) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int v = a[r]; a1[r] += v; a2[r] += (long long)v * v; mn[r] = min(mn[r], v); mx[r] = max(mx[r], v); }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {          // the 16 pixel lanes j of this g (a tile's 128 values of one channel sum to < 2^31: 127 * 255 * 192 * 128)
+          a1[r] += __shfl_xor(a1[r], o); a2[r] += __shfl_xor(a2[r], o); mn[r] = min(mn[r], __shfl_xor(mn[r], o)); mx[r] = max(mx[r], __shfl_xor(mx[r], o));
+        }
+        if (j == 0 && (ch + r) < p.r && mn[r] <= mx[r]) {
+          atomicAdd(&l_s1[ch + r], (unsigned long long)(long long)a1[r]); atomicAdd(&l_s2[ch + r], (unsigned long long)a2[r]);
+          atomicMin(&l_mn[ch + r], mn[r]); atomicMax(&l_mx[ch + r], mx[r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    long long* g_s1 = (long long*)q.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+    for (int c = tid; c < p.r; c += 256) {
+      if (l_mn[c] <= l_mx[c]) {
+        atomicAdd((unsigned long long*)&g_s1[c], l_s1[c]); atomicAdd(&g_s2[c], l_s2[c]);
+        atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
+      }
+    }
+  }
+  // ---- the barrier: the last workgroup to arrive finalizes (BatchNorm coefficients, running statistics, the conv's and the cat's FakeQuantize records), then releases
+  if (last_block_done2(q.fin.counter, gridDim.x, sflag)) {
+    conv_finalize_dev<true>(q.stats, p.npix, p.r, p.cpad, p.qx, q.fin.qrec_w, q.fin.wscale, q.fin.gamma, q.fin.beta, q.fin.rmean, q.fin.rvar, q.fin.nbt, q.fin.training,
+                            q.fin.relu, q.fin.observe, 1, q.fin.coef, q.fin.qrec_y, tid, 256, shf, q.fin.cat_qrec_b, q.fin.cat_qrec_y);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's agent-scope stores have been performed
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(q.fin.counter + SQF_GEN, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (tid == 0) {
+      int it = 0;
+      while (__hip_atomic_load(q.fin.counter + SQF_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++it > (1 << 22)) { __hip_atomic_store(q.fin.counter + SQF_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- phase 2: emit from the kept accumulators + both halves of the cat (k_sq_emit_cat's expressions); rows / records through agent-scope loads
+  auto ld = [](const float* a) __attribute__((always_inline)) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto ld_qp = [&](const float* a) __attribute__((always_inline)) {
+    QP r; r.scale = ld(a + FROST_Q_SCALE); r.zp = __float_as_int(ld(a + FROST_Q_ZP)); r.inv = 1.0f / r.scale;
+    const float m = ld(a + FROST_Q_QMAX); r.hi = (m > 0.0f) ? (int)m : 255; return r;
+  };
+  const QP A = ld_qp(p.qsq);
+  {
+    const QP B = load_qp(p.qx), Y = ld_qp(p.qcat);
+    const int qi = (int)(int8_t)tid + 128;
+    lut[tid] = (uint8_t)((fq_index((float)(qi - A.zp) * A.scale, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
+    lut[256 + tid] = (uint8_t)((fq_index((float)(qi - B.zp) * B.scale, Y.inv, Y.zp, 0, Y.hi) - 128) & 255);
+  }
+  __syncthreads();
+  const float y_inv = 1.0f / A.scale, y_zpf = (float)A.zp;
+  const float qcap = (float)A.hi; const bool lowq = qcap < 255.0f;
+  const int cy = p.r + p.cin;
+#pragma unroll
+  for (int ct = 0; ct < CTM; ++ct) {
+    if (ct < CT) {
+      const int ch = ct * 16 + 4 * g;
+      float cA[4], cB[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { cA[r] = ld(p.coef + FROST_COEF_A * p.cpad + ch + r); cB[r] = ld(p.coef + FROST_COEF_B * p.cpad + ch + r); }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = (wv * 2 + t) * 16 + j;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yv = fmaf(cA[r], (float)acc[ct][t][r], cB[r]);
+          float qv = rintf(yv * y_inv) + y_zpf;
+          if (lowq) qv = fminf(qv, qcap);
+          packed = __builtin_amdgcn_cvt_pk_u8_f32(qv, r, packed);
+        }
+        packed ^= 0x80808080u;
+        const int64_t px = p0 + row;
+        if (px < p.npix && ch < p.r) {
+          *(uint32_t*)(p.ysq + px * p.r + ch) = packed;
+          const uint32_t o = (uint32_t)lut[packed & 255] | ((uint32_t)lut[(packed >> 8) & 255] << 8) | ((uint32_t)lut[(packed >> 16) & 255] << 16) | ((uint32_t)lut[packed >> 24] << 24);
+          *(uint32_t*)(p.ycat + px * cy + ch) = o;
+        }
+      }
+    }
+  }
+  {   // the input half of the cat, from the staged tile
+    const int dpp = p.cin >> 2; const int total = 128 * dpp;
+    const uint8_t* l1 = lut + 256;
+    for (int u = tid; u < total; u += 256) {
+      const int row = u / dpp, c0 = (u - row * dpp) * 4;
+      const int64_t px = p0 + row;
+      if (px >= p.npix) continue;
+      const uint32_t src = *(const uint32_t*)(xs + row * p.kstr + c0);
+      const uint32_t o = (uint32_t)l1[src & 255] | ((uint32_t)l1[(src >> 8) & 255] << 8) | ((uint32_t)l1[(src >> 16) & 255] << 16) | ((uint32_t)l1[src >> 24] << 24);
+      *(uint32_t*)(p.ycat + px * cy + p.r + c0) = o;
+    }
+  }
+}
+template <int KSM, int CTM>
+static int sq_fwd_capacity(size_t lds) {          // workgroups of this instance the device holds at once
+  static int cap = -1;
+  if (cap < 0) {
+    int occ = 0, dev = 0; hipDeviceProp_t pr;
+    (void)hipFuncSetAttribute((const void*)k_sq_fwd<KSM, CTM>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_sq_fwd<KSM, CTM>, 256, 40 * 1024) != hipSuccess) occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) occ = 0; else occ *= pr.multiProcessorCount;
+    cap = occ;
+  }
+  (void)lds;
+  return cap;
+}
+static size_t sq_fwd_lds(int cin, int r) { const int ksm = round_up(cin, 64) / 64; return (size_t)128 * (ksm * 64 + 16) + 512 + 64 + (size_t)round_up(r, 16) * 24; }
+extern "C" int frost_sq_fwd_ok(int64_t npix, int cin, int r) {
+  static const int on = getenv("FROST_SQ_PERSIST") ? atoi(getenv("FROST_SQ_PERSIST")) : 1;
+  if (!on || !frost_sq_emit_cat_ok(cin, r) || npix <= 0) return 0;
+  const int ksm = round_up(cin, 64) / 64, ct = round_up(r, 16) / 16, ctm = ct <= 2 ? 2 : (ct <= 4 ? 4 : 6);
+  const size_t lds = sq_fwd_lds(cin, r);
+  if (lds > 40 * 1024 || ct > 6) return 0;
+  int cap = 0;
+#define SQF_CAP(K_, C_) if (ksm == K_ && ctm == C_) cap = sq_fwd_capacity<K_, C_>(lds);
+  SQF_CAP(1, 2) SQF_CAP(2, 2) SQF_CAP(3, 2) SQF_CAP(1, 4) SQF_CAP(2, 4) SQF_CAP(3, 4) SQF_CAP(1, 6) SQF_CAP(2, 6) SQF_CAP(3, 6)
+#undef SQF_CAP
+  const int64_t tiles = (npix + 127) / 128;
+  return (tiles <= (int64_t)cap * 9 / 10) ? 1 : 0;          // a margin: the grid must be resident as a whole
+}
+extern "C" int frost_sq_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, void* stats,
+                            const FrostFinDesc* fin, int8_t* y_sq, int8_t* y_cat, void* stream) {
+  FROST_REQUIRE(frost_sq_fwd_ok(npix, cin, r), "sq_fwd: the shape has no instance, or its grid does not fit the device at once (frost_sq_fwd_ok)");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y && fin->cat_qrec_b && fin->cat_qrec_y && stats && fin->relu, "sq_fwd: a squeeze_conv (ReLU) with its cat records is required");
+  SqFwdP q = {};
+  SqCatP& p = q.c;
+  p.cvt = 0;
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.coef = fin->coef; p.qsq = fin->qrec_y; p.qcat = fin->cat_qrec_y; p.ysq = y_sq; p.ycat = y_cat;
+  p.npix = npix; p.cin = cin; p.r = r; p.cpad = round_up(r, 16);
+  const int ksm = round_up(cin, 64) / 64, ct = p.cpad / 16, ctm = ct <= 2 ? 2 : (ct <= 4 ? 4 : 6);
+  p.kstr = ksm * 64 + 16;
+  q.stats = (uint8_t*)stats; q.fin = *fin;
+  const size_t lds = sq_fwd_lds(cin, r);
+  const dim3 grid((unsigned)((npix + 127) / 128));
+  hipStream_t s = as_stream(stream);
+#define SQF_GO(K_, C_) if (ksm == K_ && ctm == C_) hipLaunchKernelGGL((k_sq_fwd<K_, C_>), grid, dim3(256), lds, s, q);
+  SQF_GO(1, 2) SQF_GO(2, 2) SQF_GO(3, 2) SQF_GO(1, 4) SQF_GO(2, 4) SQF_GO(3, 4) SQF_GO(1, 6) SQF_GO(2, 6) SQF_GO(3, 6)
+#undef SQF_GO
+  return frost_check_launch("sq_fwd");
+}
+
 // ================================================================================================ cat backward + squeeze_conv reduce pass in one launch
 // Backward sibling of k_sq_emit_cat: quant_cat's backward (frostnet.py:129; k_cat_bwd8: the gradient of the concatenated tensor passes where the cat's FakeQuantize
 // kept the requantised operand in range, into the squeeze_conv output's gradient ga and, accumulated, into the block input's gradient gb) TOGETHER with the

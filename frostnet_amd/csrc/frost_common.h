@@ -127,16 +127,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ticket -> statistics -> this record; loaded early the record travels with the statistics)
 struct ObsPre { float mn, mx, en, qmax; };
 __device__ __forceinline__ ObsPre observer_prefetch(const float* q) { ObsPre p; p.mn = q[FROST_Q_MIN]; p.mx = q[FROST_Q_MAX]; p.en = q[FROST_Q_OBS_EN]; p.qmax = q[FROST_Q_QMAX]; return p; }
+// AG = true: every record / coefficient word is written with an agent-scope store and read back with an agent-scope load, so that OTHER workgroups of the SAME launch
+// may consume them after a device-wide barrier (k_sq_fwd, csrc/frost_block.hip) -- per-location coherence at agent scope, no L2 write-back / invalidate on the path
+template <bool AG> __device__ __forceinline__ void fin_st(float* p, float v) {
+  if (AG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool AG> __device__ __forceinline__ float fin_ld(const float* p) { return AG ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+template <bool AG = false>
 __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi, int symmetric, int rule127,
                                            int observe, const ObsPre* pre = nullptr) {
-  float mn = pre ? pre->mn : q[FROST_Q_MIN], mx = pre ? pre->mx : q[FROST_Q_MAX];
-  observe = observe && (__float_as_int(pre ? pre->en : q[FROST_Q_OBS_EN]) != 0);       // the site's own observer_enabled buffer (device resident)
+  float mn = pre ? pre->mn : fin_ld<AG>(q + FROST_Q_MIN), mx = pre ? pre->mx : fin_ld<AG>(q + FROST_Q_MAX);
+  observe = observe && (__float_as_int(pre ? pre->en : fin_ld<AG>(q + FROST_Q_OBS_EN)) != 0);       // the site's own observer_enabled buffer (device resident)
   float fscale = 1.0f; int fzp = 0; bool have = false;
   const int qhi = pre ? ((pre->qmax > 0.0f) ? (int)pre->qmax : 255) : q_hi(q);
   if (observe) {
     if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = cur_lo; mx = cur_hi; }
     else { mn = mn + FROST_OBS_C * (cur_lo - mn); mx = mx + FROST_OBS_C * (cur_hi - mx); }
-    q[FROST_Q_MIN] = mn; q[FROST_Q_MAX] = mx;
+    fin_st<AG>(q + FROST_Q_MIN, mn); fin_st<AG>(q + FROST_Q_MAX, mx);
     float scale; int zp = 0;
     if (mx < mn) { scale = 1.0f; zp = 0; }
     else {
@@ -152,22 +159,23 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
         zp = min(max(zp, 0), qhi);
       }
     }
-    q[FROST_Q_SCALE] = scale; q[FROST_Q_ZP] = __int_as_float(zp);
+    fin_st<AG>(q + FROST_Q_SCALE, scale); fin_st<AG>(q + FROST_Q_ZP, __int_as_float(zp));
     fscale = scale; fzp = zp; have = true;
   }
-  const float scale = have ? fscale : q[FROST_Q_SCALE]; const int zp = have ? fzp : __float_as_int(q[FROST_Q_ZP]);
+  const float scale = have ? fscale : fin_ld<AG>(q + FROST_Q_SCALE); const int zp = have ? fzp : __float_as_int(fin_ld<AG>(q + FROST_Q_ZP));
   float inv = 1.0f / scale;
-  q[FROST_Q_INV] = inv;
+  fin_st<AG>(q + FROST_Q_INV, inv);
   int lo = symmetric ? -128 : 0, hi = symmetric ? 127 : qhi;
   int ilo = fq_index(cur_lo, inv, zp, lo, hi), ihi = fq_index(cur_hi, inv, zp, lo, hi);
-  q[FROST_Q_FQMIN] = (float)(ilo - zp) * scale;
-  q[FROST_Q_FQMAX] = (float)(ihi - zp) * scale;
+  fin_st<AG>(q + FROST_Q_FQMIN, (float)(ilo - zp) * scale);
+  fin_st<AG>(q + FROST_Q_FQMAX, (float)(ihi - zp) * scale);
 }
 
 // ---- conv finalize (shared by k_conv_finalize and the statistics kernels' last-workgroup tail) ------------------------------
 // Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
 // workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read
 // with agent-scope loads.  sh: >= 2 * (nthr / 64) floats of shared memory.
+template <bool AG = false>
 __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, int cout, int cpad, const float* qx, const float* qw, const float* wscale,
                                          const float* gamma, const float* beta, float* rmean, float* rvar, int64_t* nbt, int training,
                                          int relu, int observe, int have_stats, float* coef, float* qy, int tid, int nthr, float* sh,
@@ -253,9 +261,9 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
           lo = fminf(lo, fminf(ya, yb)); hi = fmaxf(hi, fmaxf(ya, yb));
         }
       }
-      coef[FROST_COEF_A * cpad + c] = A; coef[FROST_COEF_B * cpad + c] = B; coef[FROST_COEF_M * cpad + c] = M;
-      coef[FROST_COEF_R * cpad + c] = R; coef[FROST_COEF_K1 * cpad + c] = K1; coef[FROST_COEF_VFRAC * cpad + c] = VF;
-      coef[FROST_COEF_S1 * cpad + c] = 0.0f; coef[FROST_COEF_S2 * cpad + c] = 0.0f;
+      fin_st<AG>(coef + FROST_COEF_A * cpad + c, A); fin_st<AG>(coef + FROST_COEF_B * cpad + c, B); fin_st<AG>(coef + FROST_COEF_M * cpad + c, M);
+      fin_st<AG>(coef + FROST_COEF_R * cpad + c, R); fin_st<AG>(coef + FROST_COEF_K1 * cpad + c, K1); fin_st<AG>(coef + FROST_COEF_VFRAC * cpad + c, VF);
+      fin_st<AG>(coef + FROST_COEF_S1 * cpad + c, 0.0f); fin_st<AG>(coef + FROST_COEF_S2 * cpad + c, 0.0f);
     }
   }
   const int nw = nthr >> 6;
@@ -266,12 +274,12 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
   if (tid == 0) {
     for (int i = 1; i < nw; ++i) { lo = fminf(lo, sh[i]); hi = fmaxf(hi, sh[nw + i]); }
     if (training && nbt) *nbt += 1;
-    if (have_stats) observer_update_dev(qy, lo, hi, 0, 0, observe, &pre_y);
-    else qy[FROST_Q_INV] = 1.0f / qy[FROST_Q_SCALE];
+    if (have_stats) observer_update_dev<AG>(qy, lo, hi, 0, 0, observe, &pre_y);
+    else fin_st<AG>(qy + FROST_Q_INV, 1.0f / fin_ld<AG>(qy + FROST_Q_SCALE));
     // squeeze_conv of a Frost bottleneck: the cat's FakeQuantize sees min / max of the fake-quantised halves (k_cat_observe's expression)
     if (cat_qy) {
-      if (have_stats) observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_b_lo), fmaxf(qy[FROST_Q_FQMAX], cat_b_hi), 0, 0, observe, &pre_cat);
-      else observer_update_dev(cat_qy, fminf(qy[FROST_Q_FQMIN], cat_qb[FROST_Q_FQMIN]), fmaxf(qy[FROST_Q_FQMAX], cat_qb[FROST_Q_FQMAX]), 0, 0, observe);
+      if (have_stats) observer_update_dev<AG>(cat_qy, fminf(fin_ld<AG>(qy + FROST_Q_FQMIN), cat_b_lo), fmaxf(fin_ld<AG>(qy + FROST_Q_FQMAX), cat_b_hi), 0, 0, observe, &pre_cat);
+      else observer_update_dev<AG>(cat_qy, fminf(fin_ld<AG>(qy + FROST_Q_FQMIN), cat_qb[FROST_Q_FQMIN]), fmaxf(fin_ld<AG>(qy + FROST_Q_FQMAX), cat_qb[FROST_Q_FQMAX]), 0, 0, observe);
     }
   }
 }

@@ -77,6 +77,7 @@ __device__ __forceinline__ G32Win g32_win(const float* qy, int relu) {
 // Shared thread map of the channel-parallel passes: a thread owns ONE channel quad (4 consecutive channels: 16-byte loads of fp32 / int32 rows, 4-byte loads of
 // int8 rows) for the whole launch and walks pixels; blockIdx.y selects the block of 256 quads for layers wider than 1024 channels.  cq: quad index, pl / PL: the
 // thread's pixel lane and the number of pixel lanes per workgroup.
+__device__ __forceinline__ int g32_sb(int v, int b) { return (int)(int8_t)(v >> (8 * b)); }      // signed byte b of a dword (v_bfe_i32)
 struct G32Map { int cq, pl, PL; bool ok; };
 __device__ __forceinline__ G32Map g32_map(int c) {
   const int CQ = c >> 2, CQB = min(CQ, 256);
@@ -85,6 +86,12 @@ __device__ __forceinline__ G32Map g32_map(int c) {
   return m;
 }
 static inline dim3 g32_map_grid(int c, int64_t blocks_x) { return dim3((unsigned)blocks_x, (unsigned)(((c >> 2) + 255) / 256)); }
+static inline int64_t g32_run_blocks(int c, int64_t np, int target) {      // blockIdx.x extent: runs of ~`target` pixels per thread, at most 4096 blocks
+  const int CQB = (c >> 2) < 256 ? (c >> 2) : 256; const int PL = 256 / CQB;
+  int64_t bx = (np + (int64_t)PL * target - 1) / ((int64_t)PL * target);
+  if (bx > 4096) bx = 4096; if (bx < 1) bx = 1;
+  return bx;
+}
 static inline int g32_map_pl(int c) { const int CQB = (c >> 2) < 256 ? (c >> 2) : 256; return 256 / CQB; }
 
 // ---- pointwise (kind 0) / stem-on-im2col (kind 2) integer conv output on v_mfma_i32_16x16x64_i8: D[co][pixel], one wave = MI x 4 tiles of 16 x 16, operands straight
@@ -165,39 +172,48 @@ __global__ __launch_bounds__(256) void k_g32_pw_acc(const int8_t* __restrict__ x
   }
 }
 
-// ---- depthwise integer conv output: a thread's four channels, its taps packed once (one dword per tap), pixels walked
-template <int K>
+// ---- depthwise kernels: a thread owns a channel quad and a CONTIGUOUS run of pixels (row = blockIdx.x * PL + pl of gridDim.x * PL rows): the pixel coordinates are
+// divided out once and then stepped, the taps of the quad are unpacked once into registers, K and the stride are compile-time
+struct G32Run { int p, pe, x, y, n; };
+__device__ __forceinline__ G32Run g32_run(const G32Map& mp, int np, int W, int H) {
+  const int rows = (int)gridDim.x * mp.PL, row = (int)blockIdx.x * mp.PL + mp.pl;
+  const int R = (np + rows - 1) / rows;
+  G32Run r; r.p = min(row * R, np); r.pe = min(r.p + R, np);
+  r.x = r.p % W; r.y = (r.p / W) % H; r.n = r.p / (W * H);
+  return r;
+}
+#define G32_RUN_STEP(r, W, H) do { ++(r).p; if (++(r).x == (W)) { (r).x = 0; if (++(r).y == (H)) { (r).y = 0; ++(r).n; } } } while (0)
+
+template <int K, int S>
 __global__ __launch_bounds__(256) void k_g32_dw_acc(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc) {
-  constexpr int KK = K * K;
+  constexpr int KK = K * K, PAD = (K - 1) / 2;
   const G32Map mp = g32_map(g.cout);
   if (!mp.ok) return;
   const int c0 = mp.cq * 4, zp = __float_as_int(qx[FROST_Q_ZP]);
-  int w4[KK];
+  int wq[KK][4];
 #pragma unroll
-  for (int t = 0; t < KK; ++t) {
-    uint32_t pk = 0;
+  for (int t = 0; t < KK; ++t)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) pk |= (uint32_t)(uint8_t)qw[(int64_t)(c0 + b) * KK + t] << (8 * b);
-    w4[t] = (int)pk;
-  }
-  const int npo = g.n * g.ho * g.wo;
-  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npo; p += (int)gridDim.x * mp.PL) {
-    const int ox = p % g.wo, oy = (p / g.wo) % g.ho, in = p / (g.wo * g.ho);
+    for (int b = 0; b < 4; ++b) wq[t][b] = (int)qw[(int64_t)(c0 + b) * KK + t];
+  G32Run r = g32_run(mp, g.n * g.ho * g.wo, g.wo, g.ho);
+  for (; r.p < r.pe;) {
     v4i s = {0, 0, 0, 0};
+    const int8_t* base = x + ((int64_t)r.n * g.h * g.w) * g.xc + c0;
+    // every tap's load is issued (clamped coordinates, no branch around it: K * K loads travel together); an out-of-map tap contributes q - zp = 0
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      const int iy = oy * g.stride - g.pad + ky;
-      if (iy < 0 || iy >= g.h) continue;
+      const int iy = r.y * S - PAD + ky, iyc = min(max(iy, 0), g.h - 1);
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int ix = ox * g.stride - g.pad + kx;
-        if (ix < 0 || ix >= g.w) continue;
-        const int xv = *(const int*)(x + (((int64_t)in * g.h + iy) * g.w + ix) * g.xc + c0), wv = w4[ky * K + kx];
+        const int ix = r.x * S - PAD + kx, ixc = min(max(ix, 0), g.w - 1);
+        const uint32_t xl = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;          // the four indices q as unsigned bytes
+        const uint32_t xq = (iy == iyc && ix == ixc) ? xl : (uint32_t)zp * 0x01010101u;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s[b] += (__builtin_amdgcn_sbfe(xv, 8 * b, 8) + 128 - zp) * __builtin_amdgcn_sbfe(wv, 8 * b, 8);
+        for (int b = 0; b < 4; ++b) s[b] += ((int)((xq >> (8 * b)) & 255u) - zp) * wq[ky * K + kx][b];
       }
     }
-    *(v4i*)(acc + (int64_t)p * g.cout + c0) = s;
+    *(v4i*)(acc + (int64_t)r.p * g.cout + c0) = s;
+    G32_RUN_STEP(r, g.wo, g.ho);
   }
 }
 
@@ -320,57 +336,54 @@ __global__ __launch_bounds__(256) void k_g32_pw_dgrad(const float* __restrict__ 
   }
 }
 
-// ---- depthwise data gradient with the channel-quad map (taps packed once)
-template <int K>
+// ---- depthwise data gradient (fp32 sums of <= 25 terms; the weight scale is applied once, after the sum)
+template <int K, int S>
 __global__ __launch_bounds__(256) void k_g32_dw_dgrad(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
                                                       float* __restrict__ gx, int accumulate) {
-  constexpr int KK = K * K;
+  constexpr int KK = K * K, PAD = (K - 1) / 2;
   const G32Map mp = g32_map(g.xc);
   if (!mp.ok) return;
   const int c0 = mp.cq * 4;
   const float sw0 = qrec_w[FROST_Q_SCALE];
-  float sw[4]; int w4[KK];
+  float sw[4], wf[KK][4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) sw[b] = wscale ? wscale[c0 + b] : sw0;
 #pragma unroll
-  for (int t = 0; t < KK; ++t) {
-    uint32_t pk = 0;
+  for (int t = 0; t < KK; ++t)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) pk |= (uint32_t)(uint8_t)qw[(int64_t)(c0 + b) * KK + t] << (8 * b);
-    w4[t] = (int)pk;
-  }
-  const int npi = g.n * g.h * g.w;
-  for (int p = (int)blockIdx.x * mp.PL + mp.pl; p < npi; p += (int)gridDim.x * mp.PL) {
-    const int ix = p % g.w, iy = (p / g.w) % g.h, in = p / (g.w * g.h);
-    double s[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 4; ++b) wf[t][b] = (float)qw[(int64_t)(c0 + b) * KK + t];
+  G32Run r = g32_run(mp, g.n * g.h * g.w, g.w, g.h);
+  for (; r.p < r.pe;) {
+    v4f sacc = {0, 0, 0, 0};
+    const float* base = dc + ((int64_t)r.n * g.ho * g.wo) * g.cout + c0;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      const int ty = iy + g.pad - ky;
-      if (ty < 0 || ty % g.stride) continue;
-      const int oy = ty / g.stride;
-      if (oy >= g.ho) continue;
+      const int ty = r.y + PAD - ky, oy = ty / S, oyc = min(max(oy, 0), g.ho - 1);
+      const bool yok = ty >= 0 && (ty % S) == 0 && oy < g.ho;
+      if (S == 2 && !yok) continue;                    // stride 2: the row parity is the same for every tap column (half of the rows drop out as a whole)
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int tx = ix + g.pad - kx;
-        if (tx < 0 || tx % g.stride) continue;
-        const int ox = tx / g.stride;
-        if (ox >= g.wo) continue;
-        const v4f dv = *(const v4f*)(dc + (((int64_t)in * g.ho + oy) * g.wo + ox) * g.cout + c0);
-        const int wv = w4[ky * K + kx];
+        const int tx = r.x + PAD - kx, ox = tx / S, oxc = min(max(ox, 0), g.wo - 1);
+        const bool ok = yok && tx >= 0 && (tx % S) == 0 && ox < g.wo;
+        const v4f dl = *(const v4f*)(base + (int64_t)(oyc * g.wo + oxc) * g.cout);          // issued for every tap (clamped): no branch between the loads
+        const float m = ok ? 1.0f : 0.0f;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s[b] += (double)dv[b] * (double)((float)__builtin_amdgcn_sbfe(wv, 8 * b, 8) * sw[b]);
+        for (int b = 0; b < 4; ++b) sacc[b] = fmaf(dl[b] * m, wf[ky * K + kx][b], sacc[b]);
       }
     }
-    float* dst = gx + (int64_t)p * g.xc + c0;
-    v4f o = {(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
+    float* dst = gx + (int64_t)r.p * g.xc + c0;
+    v4f o = {sacc[0] * sw[0], sacc[1] * sw[1], sacc[2] * sw[2], sacc[3] * sw[3]};
     if (accumulate) { const v4f old = *(const v4f*)dst; o = old + o; }
     *(v4f*)dst = o;
+    G32_RUN_STEP(r, g.w, g.h);
   }
 }
 
-// ---- pointwise / stem weight gradient, stage 1, on v_mfma_f32_16x16x4_f32: D[co][col] = sum_pixels dc[p][co] * (q_x[p][col] - zp), K = the pixels of the wave's chunk.
-// One 16-byte load of a dc row gives a lane the A operands of FOUR co tiles (tile r holds co = co0 + 4 m + r in row m), one dword of the x row the B operands of four
-// column tiles (col = ci0 + 4 n + r): 16 MFMAs per two loads.  Partial tiles -> part[chunk][co][ncp] (fp32), stage 2 adds the chunks in fp64 in a fixed order.
+// ---- pointwise / stem weight gradient, stage 1, on v_mfma_f32_16x16x4_f32: D[co][col] = sum_pixels dc[p][co] * (q_x[p][col] - zp), K = the pixels of the wave's chunk
+// (fp32 accumulation over <= chunk_px pixels; stage 2 adds the chunks in fp64).  One load of NA consecutive floats of a dc row gives a lane the A operands of NA co tiles
+// (tile r holds co = co0 + NA m + r in row m), one load of NB consecutive bytes of the x row the B operands of NB column tiles (col = ci0 + NB n + r): NA x NB MFMAs per
+// two loads; NA / NB = 1, 2, 4 by the layer's widths (a 16 -> 96 layer at 112 x 112 runs 4 x 1 tiles, not 4 x 4).  Partial tiles -> part[chunk][co][ncp] (fp32).
+template <int NA, int NB>
 __global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, int ncol, int ncp,
                                                            int chunk_px, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
@@ -378,81 +391,112 @@ __global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restri
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wv;
   const int64_t lo = chunk * chunk_px, hi = min(lo + chunk_px, npix);
   if (lo >= npix) return;
-  const int co0 = (int)blockIdx.y * 64, ci0 = (int)blockIdx.z * 64;
-  const int zp = __float_as_int(qx[FROST_Q_ZP]);
-  const bool aok = (co0 + 4 * j) < g.cout, bok = (ci0 + 4 * j) < ncol;
-  v4f d[4][4];
+  const int co0 = (int)blockIdx.y * (16 * NA), ci0 = (int)blockIdx.z * (16 * NB);
+  const float zpf = (float)__float_as_int(qx[FROST_Q_ZP]);
+  const bool aok = (co0 + NA * j) < g.cout, bok = (ci0 + NB * j) < ncol;          // cout % 4 == 0, ncol % 4 == 0 and NA, NB in {1, 2, 4}: a lane's run is inside or outside as a whole
+  v4f d[NA][NB];
 #pragma unroll
-  for (int ra = 0; ra < 4; ++ra)
+  for (int ra = 0; ra < NA; ++ra)
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) d[ra][rb] = (v4f){0, 0, 0, 0};
-  const float* ap = dc + co0 + 4 * j; const int8_t* bp = x + ci0 + 4 * j;
+    for (int rb = 0; rb < NB; ++rb) d[ra][rb] = (v4f){0, 0, 0, 0};
+  const float* ap = dc + co0 + NA * j; const int8_t* bp = x + ci0 + NB * j;
   for (int64_t pb = lo; pb < hi; pb += 4) {
     const int64_t p = pb + gq; const bool ok = p < hi;
-    const v4f a = (ok && aok) ? *(const v4f*)(ap + p * g.cout) : (v4f){0, 0, 0, 0};
-    const int xv = (ok && bok) ? *(const int*)(bp + p * g.xc) : 0;
-    float b[4];
+    float a[NA], b[NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b[r] = (ok && bok) ? (float)(__builtin_amdgcn_sbfe(xv, 8 * r, 8) + 128 - zp) : 0.0f;
+    for (int r = 0; r < NA; ++r) a[r] = 0.0f;
 #pragma unroll
-    for (int ra = 0; ra < 4; ++ra)
+    for (int r = 0; r < NB; ++r) b[r] = 0.0f;
+    if (ok && aok) {
+      const float* src = ap + p * g.cout;
+      if (NA == 4) { const v4f v = *(const v4f*)src; a[0] = v[0]; a[1 % NA] = v[1]; a[2 % NA] = v[2]; a[3 % NA] = v[3]; }
+      else if (NA == 2) { const float2 v = *(const float2*)src; a[0] = v.x; a[1 % NA] = v.y; }
+      else a[0] = *src;
+    }
+    if (ok && bok) {
+      const int8_t* src = bp + p * g.xc;
+      uint32_t xq;
+      if (NB == 4) xq = *(const uint32_t*)src; else if (NB == 2) xq = *(const uint16_t*)src; else xq = *(const uint8_t*)src;
+      xq ^= 0x80808080u;
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ra], b[rb], d[ra][rb], 0, 0, 0);
+      for (int r = 0; r < NB; ++r) b[r] = (float)((xq >> (8 * r)) & 255u) - zpf;
+    }
+#pragma unroll
+    for (int ra = 0; ra < NA; ++ra)
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb) d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ra], b[rb], d[ra][rb], 0, 0, 0);
   }
   float* prt = part + chunk * (int64_t)g.cout * ncp;
 #pragma unroll
-  for (int ra = 0; ra < 4; ++ra)
+  for (int ra = 0; ra < NA; ++ra)
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < NB; ++rb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int co = co0 + 4 * (4 * gq + i) + ra, col = ci0 + 4 * j + rb;
+        const int co = co0 + NA * (4 * gq + i) + ra, col = ci0 + NB * j + rb;
         if (co < g.cout && col < ncp) prt[(int64_t)co * ncp + col] = d[ra][rb][i];
       }
 }
-// stage 2 of the weight gradients: out[e] = scale * sum_rows part[row][e'] in fp64, fixed order.  kind 2 maps the OIHW index c * 9 + tap to the im2col column tap * 4 + c.
-template <typename T>
-__global__ __launch_bounds__(256) void k_g32_sum_part(const T* __restrict__ part, int rows, int cout, int per, int ncp, int kind, const float* qx, float* __restrict__ out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= cout * per) return;
-  const int co = e / per, jj = e - co * per;
-  const int col = (kind == 2) ? ((jj % 9) * 4 + jj / 9) : jj;
-  const int64_t stride = (int64_t)cout * ncp;
-  const T* src = part + (int64_t)co * ncp + col;
+// stage 2 of the weight gradients: out[e] = scale * sum_rows part[row][e'] in fp64, in a fixed order (16 row lanes per element, a fixed tree over them: deterministic).
+// kind 2 maps the OIHW index c * 9 + tap to the im2col column tap * 4 + c.
+__global__ __launch_bounds__(256) void k_g32_sum_part(const float* __restrict__ part, int rows, int cout, int per, int ncp, int kind, const float* qx, float* __restrict__ out) {
+  __shared__ double sh[16][17];
+  const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int e = (int)blockIdx.x * 16 + el;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)src[r * stride];
-  out[e] = (float)(s * (double)qx[FROST_Q_SCALE]);
-}
-// ---- depthwise weight gradient, stage 1: a thread = one channel, fp64 sums of its taps over its pixels -> part[row][c][kk] (fp64)
-template <int K>
-__global__ __launch_bounds__(256) void k_g32_dw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, double* __restrict__ part) {
-  constexpr int KK = K * K;
-  const int CB = min(g.cout, 256), PL = 256 / CB;
-  const int pl = (int)threadIdx.x / CB, c = (int)blockIdx.y * 256 + (int)threadIdx.x % CB;
-  if (pl >= PL || c >= g.cout) return;
-  const int zp = __float_as_int(qx[FROST_Q_ZP]);
-  double s[KK];
+  if (e < cout * per) {
+    const int co = e / per, jj = e - co * per;
+    const int col = (kind == 2) ? ((jj % 9) * 4 + jj / 9) : jj;
+    const int64_t stride = (int64_t)cout * ncp;
+    const float* src = part + (int64_t)co * ncp + col;
+    for (int r = rl; r < rows; r += 16) s += (double)src[r * stride];
+  }
+  sh[rl][el] = s;
+  __syncthreads();
+  if (rl == 0 && e < cout * per) {
+    double t = 0.0;
 #pragma unroll
-  for (int t = 0; t < KK; ++t) s[t] = 0.0;
-  const int npo = g.n * g.ho * g.wo;
-  for (int p = (int)blockIdx.x * PL + pl; p < npo; p += (int)gridDim.x * PL) {
-    const int ox = p % g.wo, oy = (p / g.wo) % g.ho, in = p / (g.wo * g.ho);
-    const double dv = (double)dc[(int64_t)p * g.cout + c];
+    for (int r = 0; r < 16; ++r) t += sh[r][el];
+    out[e] = (float)(t * (double)qx[FROST_Q_SCALE]);
+  }
+}
+// ---- depthwise weight gradient, stage 1: a thread = one channel quad over its run of pixels, fp32 sums per tap -> part[row][c][kk] (fp32; a run is <= ~512 pixels)
+template <int K, int S>
+__global__ __launch_bounds__(256) void k_g32_dw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, float* __restrict__ part) {
+  constexpr int KK = K * K, PAD = (K - 1) / 2;
+  const G32Map mp = g32_map(g.cout);
+  if (!mp.ok) return;
+  const int c0 = mp.cq * 4;
+  const float zpf = (float)__float_as_int(qx[FROST_Q_ZP]);
+  float sf[KK][4];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sf[t][b] = 0.0f;
+  G32Run r = g32_run(mp, g.n * g.ho * g.wo, g.wo, g.ho);
+  const int row = (int)blockIdx.x * mp.PL + mp.pl;
+  for (; r.p < r.pe;) {
+    const v4f dv = *(const v4f*)(dc + (int64_t)r.p * g.cout + c0);
+    const int8_t* base = x + ((int64_t)r.n * g.h * g.w) * g.xc + c0;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      const int iy = oy * g.stride - g.pad + ky;
-      if (iy < 0 || iy >= g.h) continue;
+      const int iy = r.y * S - PAD + ky, iyc = min(max(iy, 0), g.h - 1);
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int ix = ox * g.stride - g.pad + kx;
-        if (ix < 0 || ix >= g.w) continue;
-        s[ky * K + kx] += dv * (double)(g32_x(x, (((int64_t)in * g.h + iy) * g.w + ix) * g.xc + c) - zp);
+        const int ix = r.x * S - PAD + kx, ixc = min(max(ix, 0), g.w - 1);
+        const uint32_t xq = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;          // every tap's load is issued (clamped): K * K loads in flight together
+        const float m = (iy == iyc && ix == ixc) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sf[ky * K + kx][b] = fmaf(dv[b] * m, (float)((xq >> (8 * b)) & 255u) - zpf, sf[ky * K + kx][b]);
       }
     }
+    G32_RUN_STEP(r, g.wo, g.ho);
   }
-  double* row = part + ((int64_t)((int)blockIdx.x * PL + pl) * g.cout + c) * KK;
+  float* dst = part + ((int64_t)row * g.cout + c0) * KK;
 #pragma unroll
-  for (int t = 0; t < KK; ++t) row[t] = s[t];
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int t = 0; t < KK; ++t) dst[b * KK + t] = sf[t][b];
 }
 
 static G32Geo g32_geo(int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride) {
@@ -478,10 +522,11 @@ extern "C" int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const in
       else hipLaunchKernelGGL((k_g32_pw_acc<4>), dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
       return frost_check_launch("g32_conv_acc");
     }
-    if (kind == 1 && (k == 3 || k == 5)) {
-      int64_t bx = (npo + g32_map_pl(cout) - 1) / g32_map_pl(cout); if (bx > 8192) bx = 8192;
-      if (k == 3) hipLaunchKernelGGL((k_g32_dw_acc<3>), g32_map_grid(cout, bx), dim3(256), 0, s, x, qrec_x, qw, g, acc);
-      else hipLaunchKernelGGL((k_g32_dw_acc<5>), g32_map_grid(cout, bx), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+    if (kind == 1 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+      const int64_t bx = g32_run_blocks(cout, npo, 16);
+#define G32_ACC(KK_, SS_) hipLaunchKernelGGL((k_g32_dw_acc<KK_, SS_>), g32_map_grid(cout, bx), dim3(256), 0, s, x, qrec_x, qw, g, acc)
+      if (k == 3) { if (stride == 1) G32_ACC(3, 1); else G32_ACC(3, 2); } else { if (stride == 1) G32_ACC(5, 1); else G32_ACC(5, 2); }
+#undef G32_ACC
       return frost_check_launch("g32_conv_acc");
     }
   }
@@ -591,10 +636,11 @@ extern "C" int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* q
       else hipLaunchKernelGGL((k_g32_pw_dgrad<4>), dim3(bx, (unsigned)((xc + 63) / 64)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
       return frost_check_launch("g32_dgrad");
     }
-    if (xc == cout && (k == 3 || k == 5)) {
-      int64_t bx = (npi + g32_map_pl(xc) - 1) / g32_map_pl(xc); if (bx > 8192) bx = 8192;
-      if (k == 3) hipLaunchKernelGGL((k_g32_dw_dgrad<3>), g32_map_grid(xc, bx), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
-      else hipLaunchKernelGGL((k_g32_dw_dgrad<5>), g32_map_grid(xc, bx), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+    if (xc == cout && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+      const int64_t bx = g32_run_blocks(xc, npi, 16);
+#define G32_DG(KK_, SS_) hipLaunchKernelGGL((k_g32_dw_dgrad<KK_, SS_>), g32_map_grid(xc, bx), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate)
+      if (k == 3) { if (stride == 1) G32_DG(3, 1); else G32_DG(3, 2); } else { if (stride == 1) G32_DG(5, 1); else G32_DG(5, 2); }
+#undef G32_DG
       return frost_check_launch("g32_dgrad");
     }
   }
@@ -640,24 +686,28 @@ extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qr
       const int ncol = (kind == 2) ? xc : cin_g, ncp = ncol;
       int64_t chunk_px = 1024;
       const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)cout * ncp * 4);            // chunks the scratch holds
-      while ((npo + chunk_px - 1) / chunk_px > cap) chunk_px *= 2;
+      while ((npo + chunk_px - 1) / chunk_px > cap || (npo + chunk_px - 1) / chunk_px > 4096) chunk_px *= 2;
       const int64_t nchunk = (npo + chunk_px - 1) / chunk_px;
-      hipLaunchKernelGGL(k_g32_pw_wgrad_part, dim3((unsigned)((nchunk + 3) / 4), (unsigned)((cout + 63) / 64), (unsigned)((ncol + 63) / 64)), dim3(256), 0, s, dc, x,
-                         qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch);
-      hipLaunchKernelGGL((k_g32_sum_part<float>), dim3((unsigned)((cout * per + 255) / 256)), dim3(256), 0, s, (const float*)scratch, (int)nchunk, cout, per, ncp, kind,
-                         qrec_x, dwq);
+      const int na = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4), nb = ncol <= 16 ? 1 : (ncol <= 32 ? 2 : 4);
+      const dim3 grid((unsigned)((nchunk + 3) / 4), (unsigned)((cout + 16 * na - 1) / (16 * na)), (unsigned)((ncol + 16 * nb - 1) / (16 * nb)));
+#define G32_WG(A_, B_) hipLaunchKernelGGL((k_g32_pw_wgrad_part<A_, B_>), grid, dim3(256), 0, s, dc, x, qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch)
+      if (na == 1) { if (nb == 1) G32_WG(1, 1); else if (nb == 2) G32_WG(1, 2); else G32_WG(1, 4); }
+      else if (na == 2) { if (nb == 1) G32_WG(2, 1); else if (nb == 2) G32_WG(2, 2); else G32_WG(2, 4); }
+      else { if (nb == 1) G32_WG(4, 1); else if (nb == 2) G32_WG(4, 2); else G32_WG(4, 4); }
+#undef G32_WG
+      hipLaunchKernelGGL(k_g32_sum_part, dim3((unsigned)((cout * per + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (int)nchunk, cout, per, ncp, kind, qrec_x, dwq);
       return frost_check_launch("g32_wgrad");
     }
-    if (kind == 1 && (k == 3 || k == 5)) {
-      const int CB = cout < 256 ? cout : 256, PL = 256 / CB;
-      int64_t bx = (npo + (int64_t)PL * 256 - 1) / ((int64_t)PL * 256);                     // ~256 pixels per thread
-      const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)PL * cout * per * 8);
-      if (bx > cap) bx = cap; if (bx > 4096) bx = 4096; if (bx < 1) bx = 1;
-      const dim3 grid((unsigned)bx, (unsigned)((cout + 255) / 256));
-      if (k == 3) hipLaunchKernelGGL((k_g32_dw_wgrad_part<3>), grid, dim3(256), 0, s, dc, x, qrec_x, g, (double*)scratch);
-      else hipLaunchKernelGGL((k_g32_dw_wgrad_part<5>), grid, dim3(256), 0, s, dc, x, qrec_x, g, (double*)scratch);
-      hipLaunchKernelGGL((k_g32_sum_part<double>), dim3((unsigned)((cout * per + 255) / 256)), dim3(256), 0, s, (const double*)scratch, (int)(bx * PL), cout, per, per, 1,
-                         qrec_x, dwq);
+    if (kind == 1 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
+      const int PL = g32_map_pl(cout);
+      int64_t bx = g32_run_blocks(cout, npo, 256);                                          // runs of ~256 pixels per thread: fp32 sums per run, fp64 across the runs
+      const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)PL * cout * per * 4);
+      if (bx > cap) bx = cap;
+      if (bx < 1) bx = 1;
+#define G32_DWG(KK_, SS_) hipLaunchKernelGGL((k_g32_dw_wgrad_part<KK_, SS_>), g32_map_grid(cout, bx), dim3(256), 0, s, dc, x, qrec_x, g, (float*)scratch)
+      if (k == 3) { if (stride == 1) G32_DWG(3, 1); else G32_DWG(3, 2); } else { if (stride == 1) G32_DWG(5, 1); else G32_DWG(5, 2); }
+#undef G32_DWG
+      hipLaunchKernelGGL(k_g32_sum_part, dim3((unsigned)((cout * per + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (int)(bx * PL), cout, per, per, 1, qrec_x, dwq);
       return frost_check_launch("g32_wgrad");
     }
   }

@@ -35,7 +35,7 @@ CASES = [("pw16_96_28", 0, 16, 96, 1, 1, 28, 3), ("pw104_624_14", 0, 104, 624, 1
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_fp32_gradient_fast_forms_equal_the_plain_kernels(L, case):
     """Every frost_g32_* entry, fast form vs plain form on the same inputs: the integer conv output and dc bit-equal, S1 / S2 to fp32 rounding of the same fp64 sums,
-    the data / weight gradients (fp32 MFMA accumulation vs fp64 sums) norm-wise <= 2e-6 -- three orders inside the mode's 1e-3 bound."""
+    the data gradients (fp32 MFMA accumulation vs fp64 sums) norm-wise <= 2e-6, the weight gradients <= 1e-5 -- two to three orders inside the mode's 1e-3 bound."""
     from frostnet_amd.engine import ptr, stream
     name, kind, cin, cout, k, stride, H, N = case
     lib = L.load_library()
@@ -115,7 +115,7 @@ def test_fp32_gradient_fast_forms_equal_the_plain_kernels(L, case):
     assert relerr(a["dc"], b["dc"]) <= 1e-6, (name, "dc", relerr(a["dc"], b["dc"]))          # (the S rows differ in their last bit)
     errs = {key: relerr(a[key], b[key]) for key in a if key.startswith("gx") or key == "dwq"}
     print(f"[g32 fast vs plain {name}] " + " ".join(f"{k_} {v:.1e}" for k_, v in errs.items()))
-    assert all(v <= 2e-6 for v in errs.values()), (name, errs)
+    assert all(v <= (1e-5 if k_ == "dwq" else 2e-6) for k_, v in errs.items()), (name, errs)          # (the weight gradient: fp32 sums over runs of <= 1024 pixels, fp64 across runs)
     assert float(b["dwq"].abs().max()) > 0 and float(b["dc"].abs().max()) > 0
 
 
@@ -144,3 +144,65 @@ def test_fp32_gradient_mode_trains_a_step_at_the_bf16_modes_loss(L):
         if n.startswith("classifier.") or n.startswith("last_layer."):
             assert relerr(ga[n], gb[n]) <= 3e-2, (n, relerr(ga[n], gb[n]))
     assert all(torch.isfinite(v).all() for v in gb.values())
+
+
+# ------------------------------------------------------------------------------------------ squeeze_conv forward as one persistent launch
+@pytest.mark.parametrize("cin,r,H,n", [(80, 24, 14, 7), (96, 24, 14, 33), (96, 24, 14, 512), (192, 48, 7, 9), (192, 48, 7, 512), (192, 96, 7, 130), (120, 32, 9, 2), (40, 16, 28, 5)])
+def test_squeeze_forward_persistent_launch_is_bit_identical(L, cin, r, H, n):
+    """frost_sq_fwd (statistics -> device-wide barrier with the finalize inside -> emit + cat from the kept accumulators; frostnet.py:127-129) against the launches it
+    replaces (frost_pw_conv_fwd_fin + frost_sq_emit_cat): squeezed activation, cat output, both FakeQuantize records, coefficient rows, running statistics and
+    num_batches_tracked bit-identical over three steps (moving observers), ragged last tiles, the production grids of the 14 x 14 / 7 x 7 stages at B = 512 (784 / 196
+    workgroups) included; the barrier's give-up flag must stay clear and its generation word must advance once per launch."""
+    from frostnet_amd import engine
+    dev = "cuda"
+
+    def run(persist):
+        old = engine._SQ_PERSIST
+        engine._SQ_PERSIST = persist
+        try:
+            g = torch.Generator(device="cpu").manual_seed(77)
+            E, qa = engine.Engine(dev), engine.QArena(8, dev)
+            w = (torch.randn(r, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(dev).requires_grad_(True)
+            gamma = (torch.rand(r, generator=g) * 0.5 + 0.75).to(dev).requires_grad_(True)
+            beta = (torch.rand(r, generator=g) * 0.2 - 0.05).to(dev).requires_grad_(True)
+            l = E.add_layer(engine.ConvLayer("sq", "pw", w, gamma, beta, torch.zeros(r, device=dev), torch.ones(r, device=dev), torch.zeros((), dtype=torch.int64, device=dev),
+                                             None, 1, 1, True, qa.alloc(), qa.alloc()))
+            qx, qcat = qa.alloc(), qa.alloc()
+            qa.set_qparams(qx, 0.021, 117)
+            qx[4], qx[5] = -2.4, 2.9
+            outs = []
+            for step in range(3):
+                x = E.new_act(n, H, H, cin, qx)
+                x.buf[: x.numel] = torch.randint(-128, 128, (x.numel,), dtype=torch.int16, generator=g).to(torch.int8).to(dev)
+                E.begin_step()
+                L.CALL_LOG = []
+                sq = E.conv(l, x, True, True, cat=(x.q, qcat))
+                y = E.cat(sq, x, qcat, True)
+                torch.cuda.synchronize()
+                log, L.CALL_LOG = list(L.CALL_LOG), None
+                assert ("frost_sq_fwd" in log) == persist and ("frost_sq_emit_cat" in log) == (not persist), log
+                outs.append((sq.buf[: sq.numel].clone(), y.buf[: y.numel].clone(), qcat.clone(), l.qy.clone(), l.coef.clone(), l.rmean.clone(), l.rvar.clone(), l.nbt.clone()))
+            ctl = l.fin_counter.cpu()
+            if persist:
+                assert int(ctl[37]) == 0, "a workgroup gave up waiting at the device-wide barrier"
+                assert int(ctl[36]) == 3 and int(ctl[:36].abs().sum()) == 0, ctl          # one generation per launch; every ticket counter re-armed
+            return outs
+        finally:
+            engine._SQ_PERSIST = old
+            L.CALL_LOG = None
+    if not L.load_library().frost_sq_fwd_ok(n * H * H, cin, r):
+        pytest.skip("grid does not fit the device at once: the layer launches are the path")
+    a, b = run(True), run(False)
+    for step, (sa, sb) in enumerate(zip(a, b)):
+        for i, (ta, tb) in enumerate(zip(sa, sb)):
+            assert torch.equal(ta, tb), (step, i)
+
+
+def test_squeeze_forward_persistent_refuses_a_grid_that_cannot_be_resident(L):
+    """frost_sq_fwd_ok is the co-residency guard of the device-wide barrier: a 28 x 28 map at B = 512 (3136 tiles) is beyond any occupancy of 256 CUs and must be refused
+    (the engine then takes frost_pw_conv_fwd_fin + frost_sq_emit_cat), the 14 x 14 / 7 x 7 grids of FrostNet-Large at B = 512 accepted."""
+    lib = L.load_library()
+    assert lib.frost_sq_fwd_ok(512 * 28 * 28, 40, 16) == 0
+    assert lib.frost_sq_fwd_ok(512 * 14 * 14, 96, 24) == 1 and lib.frost_sq_fwd_ok(512 * 14 * 14, 80, 24) == 1
+    assert lib.frost_sq_fwd_ok(512 * 7 * 7, 192, 48) == 1 and lib.frost_sq_fwd_ok(512 * 7 * 7, 192, 96) == 1
+    assert lib.frost_sq_fwd_ok(1000, 196, 48) == 0          # cin beyond the staged tile

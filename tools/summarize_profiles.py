@@ -16,7 +16,7 @@ import sys
 
 FAMILIES = [                      # label (frostnet_amd/engine.py prof tags) <- kernel-name regex; first match wins
     ("stem_fwd_stats", r"k_pw<0, 8, true, true, 0, 2>"), ("stem_fwd_emit", r"k_pw<1, 8, true, true, 0, 2>"),        # SP = 2 (32 channels, 40-byte rows) is the stem's instance only
-    ("pw_fwd_stats", r"k_pw<0,|k_dgrad_wide<2,"), ("pw_fwd_emit_add", r"k_pw_ew_emit_add"), ("pw_fwd_emit", r"k_pw<1,|k_pw_ew<2>|k_pwc<2,|k_sq_emit_cat"),
+    ("sq_fwd", r"k_sq_fwd"), ("pw_fwd_stats", r"k_pw<0,|k_dgrad_wide<2,"), ("pw_fwd_emit_add", r"k_pw_ew_emit_add"), ("pw_fwd_emit", r"k_pw<1,|k_pw_ew<2>|k_pwc<2,|k_sq_emit_cat"),
     ("pw_bwd_reduce", r"k_pw<2,|k_pw_ew<0>|k_dgrad_wide<1,|k_pwc<0,"),
     ("pw_bwd_fused", r"k_pw<3, \d+, \w+, \w+, [1-9]\d*[,>]"), ("pw_bwd_dc", r"k_pw<3,|k_pw_ew<1>|k_pwc<1,"), ("pw_dgrad", r"k_pw<4,|k_dgrad_wide<0,"), ("pw_wgrad", r"k_pw_wgrad"),
     ("blk_expand_dw", r"k_blk_expand_dw"), ("blk_dw_reduce", r"k_blk_dw_reduce"), ("blk_dw_stats", r"k_blk_dw_stats"), ("blk_dw_bwd", r"k_blk_dw_bwd"), ("blk_dw_bred", r"k_blk_dw_bred"),          # block-level fused forward kernels (csrc/frost_block.hip)
