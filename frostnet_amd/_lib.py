@@ -200,7 +200,8 @@ _PROTOS = {
     "frost_g32_pool_bwd": [P, P, I, I, I, P, P],
     "frost_sq_emit_cat_ok": [I, I],
     "frost_sq_fwd_ok": [L, I, I],
-    "frost_sq_fwd": [P, P, P, P, L, I, I, P, P, P, P, P],
+    "frost_sq_fwd_slot_bytes": [L, I],
+    "frost_sq_fwd": [P, P, P, P, L, I, I, P, P, P, P, P, P],
     "frost_sq_emit_cat": [P, P, P, P, L, I, I, P, P, P, P, P, I, P],
     "frost_sq_bwd_cat_ok": [I, I],
     "frost_sq_bwd_cat": [P, P, P, P, L, I, I, P, P, I, P, P, P, I, P, I, P],
@@ -241,6 +242,7 @@ def load_library():
         fn.restype = C.c_int       # (frost_pw_bwd_fused_ok / frost_abi_version return a value, not a status)
     lib.frost_last_error.restype = C.c_char_p
     lib.frost_g32_scratch_bytes.restype = C.c_int64
+    lib.frost_sq_fwd_slot_bytes.restype = C.c_int64
     # the sizes a binding must agree on with the library (the ticket buffers grew from 1 to 40 words, FrostFinDesc gained two fields)
     if lib.frost_abi_version() != ABI_VERSION or lib.frost_ticket_words() != TICKET_WORDS or lib.frost_fin_desc_bytes() != C.sizeof(FrostFinDesc):
         raise RuntimeError(f"{LIB_PATH}: ABI mismatch (library abi {lib.frost_abi_version()} / ticket words {lib.frost_ticket_words()} / FrostFinDesc "

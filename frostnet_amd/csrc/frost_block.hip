@@ -1376,14 +1376,15 @@ extern "C" int frost_sq_emit_cat(const int8_t* x, const float* qrec_x, const int
 // statistics -> [device-wide barrier, the finalize inside it] -> emit + cat (frostnet.py:127-129), the first multi-phase kernel of the training path (SURVEY 8(f) N1;
 // VERDICT r4 #1).  One workgroup per 128-pixel tile, every workgroup resident at once (frost_sq_fwd_ok checks the grid against the occupancy): the tile's integer conv
 // output stays in the MFMA accumulators across the barrier, so x is staged once, the GEMM runs once and the emit pass has no launch, no prologue and no recomputation.
-// The barrier is the hierarchical ticket of last_block_done2 (32 sub-counters + one main counter, relaxed agent-scope atomics: 1.7 - 2.4 us for 256 - 1024 workgroups,
+// The barrier is the two-level ticket of last_block_done2 (32 sub-counters + one main counter, relaxed agent-scope atomics: 1.7 - 2.4 us for 256 - 1024 workgroups,
 // profiles/r05_gridbar_probe.txt) with the LAST arrival running conv_finalize_dev<true> -- coefficient rows and FakeQuantize records written by agent-scope stores --
 // before it flips the generation word (ticket word 36, monotonic) the other workgroups poll; they read rows and records back through agent-scope loads, so no L2
-// write-back / invalidate sits on the path.  Results are bit-identical to frost_pw_conv_fwd_fin + frost_sq_emit_cat (integer statistics: order-independent).
+// write-back / invalidate sits on the path.  The statistics are EXACT integers here (sum of squares in int64; k_pw's statistics pass forms it in fp32 within a tile),
+// so coefficient rows agree with frost_pw_conv_fwd_fin to ~1e-7 and the emitted indices wherever that does not move a rounding tie.
 // A workgroup that polls for ~2^22 rounds gives up, raises ticket word 37 and emits with whatever it reads: wrong results and a test failure instead of a hung device.
 #define SQF_GEN 36
 #define SQF_ERR 37
-struct SqFwdP { SqCatP c; uint8_t* stats; FrostFinDesc fin; };
+struct SqFwdP { SqCatP c; uint8_t* stats; uint8_t* slots; FrostFinDesc fin; int dbg; };      // dbg (FROST_SQF_DBG, timing only, wrong results): 1 = nobody waits, 2 = no fold / finalize either
 template <int KSM, int CTM>
 __global__ __launch_bounds__(256, 4) void k_sq_fwd(const SqFwdP q) {
   const SqCatP& p = q.c;
@@ -1455,24 +1456,67 @@ __global__ __launch_bounds__(256, 4) void k_sq_fwd(const SqFwdP q) {
     }
   }
   __syncthreads();
+  // ---- the tile's statistics -> the layer's table WITHOUT one same-address atomic per workgroup and channel (784 workgroups x 45 ns serialised at the memory side were
+  // 35 us of the first version of this kernel): every workgroup stores its rows into its own slot (agent-scope stores), the last arrival of each of the 32 ticket
+  // sub-groups adds its group's ~total / 32 slots and issues ONE set of atomics for the group, the last of those finalizes: a reduction tree riding on the barrier's tickets
+  const unsigned total = gridDim.x, bidx = blockIdx.x, sub = bidx & 31u, nsub = total < 32u ? total : 32u;
   {
-    long long* g_s1 = (long long*)q.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
-    int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+    unsigned long long* sl1 = (unsigned long long*)q.slots + (size_t)bidx * 3 * p.cpad; unsigned long long* sl2 = sl1 + p.cpad; int* slm = (int*)(sl2 + p.cpad);
     for (int c = tid; c < p.r; c += 256) {
-      if (l_mn[c] <= l_mx[c]) {
-        atomicAdd((unsigned long long*)&g_s1[c], l_s1[c]); atomicAdd(&g_s2[c], l_s2[c]);
-        atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]);
-      }
+      __hip_atomic_store(sl1 + c, l_s1[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(sl2 + c, l_s2[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(slm + 2 * c, l_mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(slm + 2 * c + 1, l_mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's slot stores have been performed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned mine = (total - sub + 31u) >> 5;                // workgroups with index = sub (mod 32)
+    const unsigned t = atomicAdd(q.fin.counter + 1 + sub, 1u);
+    if (t == mine - 1u) __hip_atomic_store(q.fin.counter + 1 + sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *sflag = (t == mine - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  bool last = false;
+  if (*sflag && !(q.dbg & 2)) {                                                    // last of its sub-group: fold the group's slots, one set of atomics, then the main ticket
+    long long* g_s1 = (long long*)q.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+    // thread = (channel, member slice): the group's ~total / 32 slots are read by 256 / r... threads side by side (one memory round trip, not one per member), LDS atomics fold the slices
+    for (int i = tid; i < p.cpad; i += 256) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }
+    __syncthreads();
+    {
+      const int nsl = 256 / p.cpad > 0 ? 256 / p.cpad : 1;        // member slices (cpad <= 96: 2 .. 16)
+      const int c = tid % p.cpad, sl = tid / p.cpad;
+      if (sl < nsl && c < p.r) {
+        unsigned long long a1 = 0, a2 = 0; int mn = INT32_MAX, mx = INT32_MIN;
+        for (unsigned m = sub + 32u * (unsigned)sl; m < total; m += 32u * (unsigned)nsl) {
+          const unsigned long long* sl1 = (const unsigned long long*)q.slots + (size_t)m * 3 * p.cpad; const unsigned long long* sl2 = sl1 + p.cpad; const int* slm = (const int*)(sl2 + p.cpad);
+          a1 += __hip_atomic_load(sl1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); a2 += __hip_atomic_load(sl2 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          mn = min(mn, __hip_atomic_load(slm + 2 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); mx = max(mx, __hip_atomic_load(slm + 2 * c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        if (mn <= mx) { atomicAdd(&l_s1[c], a1); atomicAdd(&l_s2[c], a2); atomicMin(&l_mn[c], mn); atomicMax(&l_mx[c], mx); }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < p.r; c += 256)
+      if (l_mn[c] <= l_mx[c]) { atomicAdd((unsigned long long*)&g_s1[c], l_s1[c]); atomicAdd(&g_s2[c], l_s2[c]); atomicMin(&g_mn[c], l_mn[c]); atomicMax(&g_mx[c], l_mx[c]); }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t2 = atomicAdd(q.fin.counter, 1u);
+      if (t2 == nsub - 1u) __hip_atomic_store(q.fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sflag[1] = (t2 == nsub - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    last = sflag[1] != 0;
+  }
   // ---- the barrier: the last workgroup to arrive finalizes (BatchNorm coefficients, running statistics, the conv's and the cat's FakeQuantize records), then releases
-  if (last_block_done2(q.fin.counter, gridDim.x, sflag)) {
+  if (last) {
     conv_finalize_dev<true>(q.stats, p.npix, p.r, p.cpad, p.qx, q.fin.qrec_w, q.fin.wscale, q.fin.gamma, q.fin.beta, q.fin.rmean, q.fin.rvar, q.fin.nbt, q.fin.training,
                             q.fin.relu, q.fin.observe, 1, q.fin.coef, q.fin.qrec_y, tid, 256, shf, q.fin.cat_qrec_b, q.fin.cat_qrec_y);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's agent-scope stores have been performed
     __syncthreads();
     if (tid == 0) __hip_atomic_store(q.fin.counter + SQF_GEN, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else {
+  } else if (!(q.dbg & 1)) {
     if (tid == 0) {
       int it = 0;
       while (__hip_atomic_load(q.fin.counter + SQF_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
@@ -1567,10 +1611,11 @@ extern "C" int frost_sq_fwd_ok(int64_t npix, int cin, int r) {
   const int64_t tiles = (npix + 127) / 128;
   return (tiles <= (int64_t)cap * 9 / 10) ? 1 : 0;          // a margin: the grid must be resident as a whole
 }
+extern "C" int64_t frost_sq_fwd_slot_bytes(int64_t npix, int r) { return ((npix + 127) / 128) * 3 * (int64_t)round_up(r, 16) * 8; }
 extern "C" int frost_sq_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, void* stats,
-                            const FrostFinDesc* fin, int8_t* y_sq, int8_t* y_cat, void* stream) {
+                            const FrostFinDesc* fin, void* slots, int8_t* y_sq, int8_t* y_cat, void* stream) {
   FROST_REQUIRE(frost_sq_fwd_ok(npix, cin, r), "sq_fwd: the shape has no instance, or its grid does not fit the device at once (frost_sq_fwd_ok)");
-  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y && fin->cat_qrec_b && fin->cat_qrec_y && stats && fin->relu, "sq_fwd: a squeeze_conv (ReLU) with its cat records is required");
+  FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y && fin->cat_qrec_b && fin->cat_qrec_y && stats && slots && fin->relu, "sq_fwd: a squeeze_conv (ReLU) with its cat records, statistics table and slot buffer is required");
   SqFwdP q = {};
   SqCatP& p = q.c;
   p.cvt = 0;
@@ -1578,7 +1623,8 @@ extern "C" int frost_sq_fwd(const int8_t* x, const float* qrec_x, const int8_t* 
   p.npix = npix; p.cin = cin; p.r = r; p.cpad = round_up(r, 16);
   const int ksm = round_up(cin, 64) / 64, ct = p.cpad / 16, ctm = ct <= 2 ? 2 : (ct <= 4 ? 4 : 6);
   p.kstr = ksm * 64 + 16;
-  q.stats = (uint8_t*)stats; q.fin = *fin;
+  q.stats = (uint8_t*)stats; q.slots = (uint8_t*)slots; q.fin = *fin;
+  { static const int dbg = getenv("FROST_SQF_DBG") ? atoi(getenv("FROST_SQF_DBG")) : 0; q.dbg = dbg; }
   const size_t lds = sq_fwd_lds(cin, r);
   const dim3 grid((unsigned)((npix + 127) / 128));
   hipStream_t s = as_stream(stream);

@@ -45,7 +45,9 @@ _PW_FUSE_MINMAP = int(os.environ.get("FROST_PW_FUSE_MINMAP", "400"))
 _PWC_EMIT = os.environ.get("FROST_PWC_EMIT", "1") != "0"          # forward emit of wide pointwise layers on the chunked kernel
 _BLOCK_EMIT_ADD = os.environ.get("FROST_BLOCK_EMIT_ADD", "1") != "0"
 _STEM_FUSED_CVT = os.environ.get("FROST_STEM_CONVERTED", "1") != "0"   # converted inference: QuantStub + stem conv in one launch from the fp32 image (frost_stem_converted), bit-identical
-_SQ_PERSIST = os.environ.get("FROST_SQ_PERSIST", "1") != "0"        # squeeze_conv statistics + finalize + emit + cat as one persistent launch with a device-wide barrier (frost_sq_fwd), bit-identical
+# squeeze_conv statistics + finalize + emit + cat as ONE persistent launch with a device-wide barrier (frost_sq_fwd, csrc/frost_block.hip).  Parity-green and measured: 38 us
+# against 27 + 19 us per layer in isolation at 14 x 14, +-0 inside the captured step (20.00 vs 20.01 ms, profiles/r05_persistent_squeeze.txt) -- off by default
+_SQ_PERSIST = os.environ.get("FROST_SQ_PERSIST", "0") != "0"
 _BLOCK_SQCAT = os.environ.get("FROST_BLOCK_SQCAT", "1") != "0"      # squeeze_conv emit + cat requantisation in one launch (frost_sq_emit_cat), bit-identical to the two it replaces
 _PW_FUSE = os.environ.get("FROST_PW_FUSE", "1") != "0"     # dev switch: fused pointwise backward (dc + dgrad + wgrad in one kernel)
 _WG_PRIO = int(os.environ.get("FROST_WG_PRIO", "0"))        # priority of the weight-gradient stream(s) (torch: lower = higher priority); A/B switch
@@ -372,7 +374,10 @@ class Engine:
                 # squeeze_conv of a CAS bottleneck as ONE persistent launch: statistics -> device-wide barrier with the finalize inside -> emit + both halves of the cat from
                 # the accumulators the workgroup kept (csrc/frost_block.hip k_sq_fwd; bit-identical to frost_pw_conv_fwd_fin + frost_sq_emit_cat)
                 ycat = self.new_act(x.n, ho, wo, l.cout + x.c, cat[1])
-                call("frost_sq_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(y.buf), ptr(ycat.buf),
+                need = int(L.load_library().frost_sq_fwd_slot_bytes(x.npix, l.cout))
+                if getattr(self, "_sq_slots", None) is None or self._sq_slots.numel() < need:          # per-workgroup statistics rows (one buffer: the squeeze convs run one after another)
+                    self._sq_slots = torch.empty(max(need, 4 << 20), dtype=torch.uint8, device=self.device)
+                call("frost_sq_fwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.stats), C.byref(fin), ptr(self._sq_slots), ptr(y.buf), ptr(ycat.buf),
                      stream(), prof=("sq_fwd", x.numel + l.wq_pack.numel() + y.numel + ycat.numel))
                 y.cat_done = ycat
                 y.cat_observed = True

@@ -456,12 +456,14 @@ int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq
                           void* stats, const FrostFinDesc* fin, void* stream);
 /* The whole squeeze_conv forward (frostnet.py:127-129) as ONE persistent launch: integer statistics of the 1x1 conv -> device-wide barrier whose last arrival runs the
  * finalize (BatchNorm coefficients, running statistics, the conv's and the cat's FakeQuantize records: FrostFinDesc incl. cat_qrec_b / cat_qrec_y) -> emit + both halves of
- * the cat from the accumulators each workgroup kept.  Replaces frost_pw_conv_fwd_fin + frost_sq_emit_cat, bit-identical.  Every workgroup must be resident at once:
+ * the cat from the accumulators each workgroup kept.  Replaces frost_pw_conv_fwd_fin + frost_sq_emit_cat (same expressions; the integer statistics are exact here, so
+ * coefficient rows agree to ~1e-7).  slots: >= frost_sq_fwd_slot_bytes(npix, r) bytes of scratch (per-workgroup statistics rows).  Every workgroup must be resident at once:
  * frost_sq_fwd_ok(npix, cin, r) checks ceil(npix / 128) against the device's capacity for the instance (and the shape); ticket words 36 / 37 of fin->counter are the
  * barrier's generation word (monotonic) and its give-up flag (non-zero = a workgroup stopped waiting: results invalid). */
 int frost_sq_fwd_ok(int64_t npix, int cin, int r);
+int64_t frost_sq_fwd_slot_bytes(int64_t npix, int r);
 int frost_sq_fwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int r, void* stats, const FrostFinDesc* fin,
-                 int8_t* y_sq, int8_t* y_cat, void* stream);
+                 void* slots, int8_t* y_sq, int8_t* y_cat, void* stream);
 int frost_dw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int n, int h, int w, int c, int k,
                           int stride, void* stats, const FrostFinDesc* fin, void* stream);
 /* forward of a wide-K pointwise layer (see frost_pw_conv_int / frost_pw_ew) keeping the integer conv output: statistics pass + folded finalize (the job of frost_pw_conv_fwd_fin) on the stand-alone GEMM
