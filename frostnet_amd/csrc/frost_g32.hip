@@ -700,7 +700,7 @@ extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qr
     }
     if (kind == 1 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
       const int PL = g32_map_pl(cout);
-      int64_t bx = g32_run_blocks(cout, npo, 256);                                          // runs of ~256 pixels per thread: fp32 sums per run, fp64 across the runs
+      int64_t bx = g32_run_blocks(cout, npo, 64);                                           // runs of ~64 pixels per thread (fp32 sums per run, fp64 across the runs): runs of 256 left 392 workgroups for a 14 x 14 layer
       const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)PL * cout * per * 4);
       if (bx > cap) bx = cap;
       if (bx < 1) bx = 1;
