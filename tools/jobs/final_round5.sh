@@ -18,10 +18,15 @@ f=$(find gpurun_out/prof_r05_float -name "*kernel_stats.csv" 2>/dev/null | head 
 find gpurun_out/prof_r05_float -name "*kernel_trace.csv" -delete 2>/dev/null
 : > gpurun_out/r05_other_batches.jsonl
 for b in 64 200 256; do timeout 600 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_other_batches.jsonl; done
-# the fp32-gradient parity mode next to the production bf16 backward at the same (small) batch: what the plain fp32 kernels cost
+# the fp32-gradient mode next to the production bf16 backward: B = 64 eager (bf16, fp32 fast forms, fp32 plain round-4 kernels), B = 512 captured (fp32), and its kernel table
 : > gpurun_out/r05_grad_modes.jsonl
 timeout 900 python bench.py --batch 64 --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
-FROST_GRAD=fp32 timeout 1500 python bench.py --batch 64 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+FROST_GRAD=fp32 timeout 900 python bench.py --batch 64 --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+FROST_GRAD=fp32 FROST_G32_PLAIN=1 timeout 1500 python bench.py --batch 64 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+FROST_GRAD=fp32 timeout 900 python bench.py --batch 512 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r05_grad_modes.jsonl
+( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && FROST_GRAD=fp32 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r05_g32 -o s -- python bench.py --batch 512 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > gpurun_out/prof_r05_g32.log 2>&1 )
+f=$(find gpurun_out/prof_r05_g32 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_g32_b512_kernel_stats.csv
+find gpurun_out/prof_r05_g32 -name "*kernel_trace.csv" -delete 2>/dev/null
 timeout 600 python tools/bench_iblock.py > gpurun_out/r05_infer_blocks.txt 2>&1
 ( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r05.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_r05.log 2>&1
