@@ -28,6 +28,6 @@ FROST_GRAD=fp32 timeout 900 python bench.py --batch 512 --steps 10 --warmup 2 --
 f=$(find gpurun_out/prof_r05_g32 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r05_g32_b512_kernel_stats.csv
 find gpurun_out/prof_r05_g32 -name "*kernel_trace.csv" -delete 2>/dev/null
 timeout 600 python tools/bench_iblock.py > gpurun_out/r05_infer_blocks.txt 2>&1
-( timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > gpurun_out/gpu_suite_r05.log
+timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/gpu_suite_r05_full.log 2>&1; tail -8 gpurun_out/gpu_suite_r05_full.log > gpurun_out/gpu_suite_r05.log; grep -n -B2 -A40 "^____\|^E  " gpurun_out/gpu_suite_r05_full.log | head -150 > gpurun_out/gpu_suite_r05_failures.log
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke_r05.log 2>&1
 tail -c 300 gpurun_out/bench_r05.json; echo; tail -3 gpurun_out/gpu_suite_r05.log; tail -1 gpurun_out/smoke_r05.log; cut -c1-200 gpurun_out/r05_other_batches.jsonl
