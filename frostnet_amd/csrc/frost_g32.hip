@@ -439,26 +439,33 @@ __global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restri
 }
 // stage 2 of the weight gradients: out[e] = scale * sum_rows part[row][e'] in fp64, in a fixed order (16 row lanes per element, a fixed tree over them: deterministic).
 // kind 2 maps the OIHW index c * 9 + tap to the im2col column tap * 4 + c.
+template <int EL>            // EL element lanes x 256 / EL row lanes per workgroup: 16 x 16, or 4 x 64 for a layer with few weights and many partial rows (a narrow depthwise layer at 112 x 112)
 __global__ __launch_bounds__(256) void k_g32_sum_part(const float* __restrict__ part, int rows, int cout, int per, int ncp, int kind, const float* qx, float* __restrict__ out) {
-  __shared__ double sh[16][17];
-  const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int e = (int)blockIdx.x * 16 + el;
+  constexpr int RL = 256 / EL;
+  __shared__ double sh[RL][EL + 1];
+  const int el = threadIdx.x % EL, rl = threadIdx.x / EL;
+  const int e = (int)blockIdx.x * EL + el;
   double s = 0.0;
   if (e < cout * per) {
     const int co = e / per, jj = e - co * per;
     const int col = (kind == 2) ? ((jj % 9) * 4 + jj / 9) : jj;
     const int64_t stride = (int64_t)cout * ncp;
     const float* src = part + (int64_t)co * ncp + col;
-    for (int r = rl; r < rows; r += 16) s += (double)src[r * stride];
+    for (int r = rl; r < rows; r += RL) s += (double)src[r * stride];
   }
   sh[rl][el] = s;
   __syncthreads();
   if (rl == 0 && e < cout * per) {
     double t = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t += sh[r][el];
+    for (int r = 0; r < RL; ++r) t += sh[r][el];
     out[e] = (float)(t * (double)qx[FROST_Q_SCALE]);
   }
+}
+static void g32_sum_part(const float* part, int rows, int cout, int per, int ncp, int kind, const float* qx, float* out, hipStream_t s) {
+  const int ne = cout * per;
+  if (ne <= 8192 && rows >= 1024) hipLaunchKernelGGL((k_g32_sum_part<4>), dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, s, part, rows, cout, per, ncp, kind, qx, out);
+  else hipLaunchKernelGGL((k_g32_sum_part<16>), dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, part, rows, cout, per, ncp, kind, qx, out);
 }
 // ---- depthwise weight gradient, stage 1: a thread = one channel quad over its run of pixels, fp32 sums per tap -> part[row][c][kk] (fp32; a run is <= ~512 pixels)
 template <int K, int S>
@@ -695,7 +702,7 @@ extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qr
       else if (na == 2) { if (nb == 1) G32_WG(2, 1); else if (nb == 2) G32_WG(2, 2); else G32_WG(2, 4); }
       else { if (nb == 1) G32_WG(4, 1); else if (nb == 2) G32_WG(4, 2); else G32_WG(4, 4); }
 #undef G32_WG
-      hipLaunchKernelGGL(k_g32_sum_part, dim3((unsigned)((cout * per + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (int)nchunk, cout, per, ncp, kind, qrec_x, dwq);
+      g32_sum_part((const float*)scratch, (int)nchunk, cout, per, ncp, kind, qrec_x, dwq, s);
       return frost_check_launch("g32_wgrad");
     }
     if (kind == 1 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
@@ -707,7 +714,7 @@ extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qr
 #define G32_DWG(KK_, SS_) hipLaunchKernelGGL((k_g32_dw_wgrad_part<KK_, SS_>), g32_map_grid(cout, bx), dim3(256), 0, s, dc, x, qrec_x, g, (float*)scratch)
       if (k == 3) { if (stride == 1) G32_DWG(3, 1); else G32_DWG(3, 2); } else { if (stride == 1) G32_DWG(5, 1); else G32_DWG(5, 2); }
 #undef G32_DWG
-      hipLaunchKernelGGL(k_g32_sum_part, dim3((unsigned)((cout * per + 15) / 16)), dim3(256), 0, s, (const float*)scratch, (int)(bx * PL), cout, per, per, 1, qrec_x, dwq);
+      g32_sum_part((const float*)scratch, (int)(bx * PL), cout, per, per, 1, qrec_x, dwq, s);
       return frost_check_launch("g32_wgrad");
     }
   }
