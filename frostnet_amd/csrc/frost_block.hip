@@ -522,6 +522,228 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
   }
 }
 
+// ---- the same kernel for 7 x 7 maps with TWO 64-channel chunks per iteration on eight waves (waves 0-3: the depthwise stencil of the even chunk, waves 4-7: of the odd
+// chunk; the reduce GEMM's pixel tiles split over the two wave groups, each wave taking both chunks' K steps).  One image per workgroup is one serial chain of chunk
+// iterations with ONE wave per SIMD and workgroup; this form halves the chain and puts two waves of the workgroup on every SIMD.  Integer results: bit-identical to
+// k_blk_dw_reduce<K, 7, 4, NCTW>.  MEASURED SLOWER at B = 512 (see frost_block_dw_reduce below): its accumulators + both chunks' fragments need > 128 registers, so only one
+// workgroup fits a CU (or it spills), and 256 workgroups at a time of half the chain each is no shorter than 512 at a time of the whole chain.  Kept as an A/B switch.
+template <int K, int NCTW>
+__global__ __launch_bounds__(512, 2) void k_blk_dw_reduce2(const BlkBP p) {
+  using G = BlkGeoB<K, 7, 4>;                                     // plane / stencil-unit geometry of ONE chunk
+  constexpr int HW = 7, MAP = 49, PAD = G::PAD, PITCH = G::PITCH, NT = 512, NPTW = 2, KK = K * K;
+  constexpr int UCH = MAP * 8;                                    // 8-byte units of one y chunk
+  constexpr int YU = (2 * UCH + NT - 1) / NT;                     // ... of both chunks, per thread
+  constexpr int TCH = KK * 16;                                    // dword units of one chunk's taps
+  constexpr int NTAPW = (2 * TCH + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const pl = smem;                                       // [2][PHA][PITCH][64]
+  uint8_t* const y2t = smem + 2 * G::PLANE;                       // [2][64 px][64]
+  uint8_t* const taps = y2t + 2 * G::Y2;                         // [2 (iteration parity)][2][k*k][64]
+  int* const sflag = (int*)(taps + 4 * KK * 64);
+  unsigned long long* const l_s1 = (unsigned long long*)(sflag + 16);
+  unsigned long long* const l_s2 = l_s1 + p.cpad3;
+  int* const l_mn = (int*)(l_s2 + p.cpad3); int* const l_mx = l_mn + p.cpad3;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int slot_w = w >> 2, unit = w & 3;                        // depthwise phase: this wave's chunk slot and its pair of output rows
+  const int ph = w >> 2, wct = w & 3;                             // GEMM phase: pixel-tile half, first channel tile
+  const int CT3 = p.cpad3 >> 4;
+  const int img_lo = (int)blockIdx.x * p.imgs, img_hi = min(img_lo + p.imgs, p.n);
+  const int nit_img = (p.nchunk + 1) >> 1;
+  const int nit = (img_hi - img_lo) * nit_img;
+
+  const int zp1 = __float_as_int(p.qy1[FROST_Q_ZP]), zp2 = __float_as_int(p.qy2[FROST_Q_ZP]);
+  {
+    const uint32_t zf = (uint32_t)((zp1 - 128) & 255) * 0x01010101u;
+    for (int i = tid; i < (2 * G::PLANE >> 4); i += NT) ((uint4*)pl)[i] = make_uint4(zf, zf, zf, zf);
+    for (int i = tid; i < (2 * G::Y2 >> 4); i += NT) ((uint4*)y2t)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < p.cpad3; i += NT) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }
+  }
+  const float y_inv = 1.0f / p.qy2[FROST_Q_SCALE], y_zpf = (float)zp2;
+  const float qcap = (float)q_hi(p.qy2); const bool lowq = qcap < 255.0f;
+  const float relu_floor = p.relu2 ? 0.0f : -INFINITY;
+  const int zpx3 = zp2 - 128;
+  // the chunk slot / plane position / tensor pixel of the y units this thread moves (the same for every iteration)
+  int uoff[YU], upx[YU], uslot[YU];
+#pragma unroll
+  for (int i = 0; i < YU; ++i) {
+    const int u = tid + i * NT, sl = (u >= UCH) ? 1 : 0, v = u - sl * UCH, px = v >> 3, part = v & 7;
+    const int r = px / HW, cc = px - r * HW;
+    upx[i] = (u < 2 * UCH) ? px : -1; uslot[i] = sl;
+    uoff[i] = sl * G::PLANE + ((r + PAD) * PITCH + cc + PAD) * 64 + part * 8;
+  }
+  const int upart = (tid & 7) * 8;                                // NT and UCH are multiples of 8: every unit of a thread has the same channel part
+  const int tap_c = (tid & 15) * 4;
+  auto load_y1 = [&](int img, int itc, uint2 (&dst)[YU]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int chunk = 2 * itc + uslot[i];
+      const bool ok = upx[i] >= 0 && chunk < p.nchunk && (chunk * 64 + upart) < p.c;
+      const int8_t* src = p.y1 + ((int64_t)img * MAP + (ok ? upx[i] : 0)) * p.c + (ok ? chunk * 64 + upart : 0);
+      const uint2 v = *(const uint2*)src;
+      dst[i] = ok ? v : make_uint2(0, 0);
+    }
+  };
+  auto load_taps = [&](int itc, uint32_t (&dst)[NTAPW]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NTAPW; ++i) {
+      const int v = tid + i * NT, sl = (v >= TCH) ? 1 : 0, t = (v - sl * TCH) >> 4, chunk = 2 * itc + sl;
+      const bool ok = v < 2 * TCH && chunk < p.nchunk && (chunk * 64 + tap_c) < p.c;
+      const uint32_t q = *(const uint32_t*)(p.wq2 + (ok ? t * p.cpad + chunk * 64 + tap_c : 0));
+      dst[i] = ok ? q : 0u;
+    }
+  };
+  struct ChRow { float A, B; int ws; };
+  auto load_row = [&](int itc) __attribute__((always_inline)) {          // this wave's chunk slot, lane = channel
+    ChRow r; const int chunk = 2 * itc + slot_w; const int c2 = chunk * 64 + lane; const bool ok = chunk < p.nchunk && c2 < p.c;
+    const int cc = ok ? c2 : 0;
+    const float rA = p.coef2[FROST_COEF_A * p.cpad + cc], rB = p.coef2[FROST_COEF_B * p.cpad + cc]; const int rW = p.wsum2[cc];
+    r.A = ok ? rA : 0.0f; r.B = ok ? rB : 0.0f; r.ws = ok ? rW : 0;
+    return r;
+  };
+  uint2 yv[YU]; uint32_t tv[NTAPW]; ChRow row_n;
+  if (nit > 0) { load_y1(img_lo, 0, yv); load_taps(0, tv); row_n = load_row(0); }
+  v4i acc[NCTW][NPTW];
+  __syncthreads();
+
+  for (int it = 0; it < nit; ++it) {
+    const int img = img_lo + it / nit_img, itc = it - (it / nit_img) * nit_img;
+    const bool have1 = (2 * itc + 1) < p.nchunk;                    // the odd chunk of this iteration exists
+    uint8_t* const tapb = taps + (it & 1) * 2 * KK * 64;
+    if (itc == 0) {
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) acc[m][t] = (v4i){0, 0, 0, 0};
+    }
+    // ---- 1. both chunks' y1 rows into their planes, their taps into LDS; 2. the next iteration's come into registers under the arithmetic
+#pragma unroll
+    for (int i = 0; i < YU; ++i) if (upx[i] >= 0) *(uint2*)(pl + uoff[i]) = yv[i];
+#pragma unroll
+    for (int i = 0; i < NTAPW; ++i) {
+      const int v = tid + i * NT, sl = (v >= TCH) ? 1 : 0, t = (v - sl * TCH) >> 4;
+      if (v < 2 * TCH) *(uint32_t*)(tapb + (sl * KK + t) * 64 + tap_c) = tv[i];
+    }
+    const ChRow row = row_n;
+    if (it + 1 < nit) {
+      const int it2 = it + 1; const int img2 = img_lo + it2 / nit_img, itc2 = it2 - (it2 / nit_img) * nit_img;
+      load_y1(img2, itc2, yv); load_taps(itc2, tv); row_n = load_row(itc2);
+    }
+    blk_barrier();
+    // ---- conv2: depthwise conv + emit of output rows 2 unit, 2 unit + 1 of this wave group's chunk, lane = channel -> its y2 chunk [pixel][64]
+    if (slot_w == 0 || have1) {
+      const uint8_t* const plw = pl + slot_w * G::PLANE; uint8_t* const y2w = y2t + slot_w * G::Y2; const uint8_t* const tapw = tapb + slot_w * KK * 64;
+      int wpk[K][2];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) { const uint32_t b = tapw[(ky * K + kx) * 64 + lane]; if (kx < 4) lo |= b << (8 * kx); else hi |= b; }
+        wpk[ky][0] = (int)lo; wpk[ky][1] = (int)hi;
+      }
+      const int acc0 = (128 - zp1) * row.ws;
+      int a[2][8];
+      blk_dw_unit<K, PITCH, 7>(plw, 2 * unit, 0, lane, wpk, acc0, a);
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+          if ((2 * unit + o) < HW) {
+            const float yf = fmaf(row.A, (float)a[o][r], row.B);
+            float qv = rintf(fmaxf(yf, relu_floor) * y_inv) + y_zpf;
+            if (lowq) qv = fminf(qv, qcap);
+            y2w[((2 * unit + o) * HW + r) * 64 + lane] = (uint8_t)((__builtin_amdgcn_cvt_pk_u8_f32(qv, 0, 0u) ^ 0x80u) & 255u);
+          }
+        }
+    }
+    // reduce_conv weight fragments of the two K steps: requested only now (the stencil's registers are free again -- held across the depthwise phase they cost 40 of
+    // the 128 registers a wave may have with two workgroups per CU), they travel under the barrier and the y2 stores
+    v4i afr[2][NCTW];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m) {
+        const int ct = min(wct + 4 * m, CT3 - 1), chunk = min(2 * itc + sl, p.nchunk - 1);
+        const v4i f = *(const v4i*)(p.w3 + ((((int64_t)ct * p.nchunk + chunk) * 64 + lane) << 4));
+        afr[sl][m] = (sl == 0 || have1) ? f : (v4i){0, 0, 0, 0};
+      }
+    blk_barrier();
+    // ---- both y2 chunks out to HBM; reduce_conv: acc[cout tile][pixel tile] += W3[:, chunk] * y2 chunk, two K steps
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int chunk = 2 * itc + uslot[i];
+      if (upx[i] >= 0 && chunk < p.nchunk && (chunk * 64 + upart) < p.c)
+        *(uint2*)(p.y2 + ((int64_t)img * MAP + upx[i]) * p.c + chunk * 64 + upart) = *(const uint2*)(y2t + uslot[i] * G::Y2 + upx[i] * 64 + upart);
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int t = 0; t < NPTW; ++t) {
+        const v4i bfr = *(const v4i*)(y2t + sl * G::Y2 + ((ph * NPTW + t) * 16 + j) * 64 + g * 16);
+#pragma unroll
+        for (int m = 0; m < NCTW; ++m) acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr[sl][m], bfr, acc[m][t], 0, 0, 0);        // D[chan][pix]
+      }
+    if (itc == nit_img - 1) {
+      // ---- the image's integer conv output c = acc - (zp - 128) * wsum and its exact statistics (table format of k_pw / conv_finalize_dev)
+#pragma unroll
+      for (int m = 0; m < NCTW; ++m) {
+        const int ct = wct + 4 * m;
+        if (ct >= CT3) continue;
+        const int ch0 = ct * 16 + 4 * g;
+        const v4i ws = *(const v4i*)(p.wsum3 + ch0);
+        long long a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}; int mn[4] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MAX}, mx[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+#pragma unroll
+        for (int t = 0; t < NPTW; ++t) {
+          const int px = (ph * NPTW + t) * 16 + j;
+          if (px < MAP && ch0 < p.cout) {
+            const v4i cv = (v4i){acc[m][t][0] - zpx3 * ws[0], acc[m][t][1] - zpx3 * ws[1], acc[m][t][2] - zpx3 * ws[2], acc[m][t][3] - zpx3 * ws[3]};
+            *(v4i*)(p.cint + ((int64_t)img * MAP + px) * p.cout + ch0) = cv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int v = cv[r]; a1[r] += v; a2[r] += (long long)v * v; mn[r] = min(mn[r], v); mx[r] = max(mx[r], v); }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {                               // the 16 pixel lanes j of this g
+            a1[r] += __shfl_xor(a1[r], o); a2[r] += __shfl_xor(a2[r], o); mn[r] = min(mn[r], __shfl_xor(mn[r], o)); mx[r] = max(mx[r], __shfl_xor(mx[r], o));
+          }
+          if (j == 0 && (ch0 + r) < p.cout && mn[r] <= mx[r]) {
+            atomicAdd(&l_s1[ch0 + r], (unsigned long long)a1[r]); atomicAdd(&l_s2[ch0 + r], (unsigned long long)a2[r]);
+            atomicMin(&l_mn[ch0 + r], mn[r]); atomicMax(&l_mx[ch0 + r], mx[r]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    long long* g_s1 = (long long*)p.stats3; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
+    int* g_mn = (int*)(g_s2 + p.cpad3); int* g_mx = g_mn + p.cpad3;
+    for (int i = tid; i < p.cout; i += NT) {
+      if (l_mn[i] <= l_mx[i]) {
+        atomicAdd((unsigned long long*)&g_s1[i], l_s1[i]); atomicAdd(&g_s2[i], l_s2[i]);
+        atomicMin(&g_mn[i], l_mn[i]); atomicMax(&g_mx[i], l_mx[i]);
+      }
+    }
+  }
+  if (last_block_done2(p.fin.counter, gridDim.x, sflag)) {
+    float* sh = (float*)smem;
+    conv_finalize_dev(p.stats3, (int64_t)p.n * MAP, p.cout, p.cpad3, p.qy2, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+                      p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, NT, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
+  }
+}
+template <int K, int NCTW>
+static int launch_blk_b2(BlkBP& p, hipStream_t s) {
+  using G = BlkGeoB<K, 7, 4>;
+  const size_t lds = (size_t)2 * G::PLANE + 2 * G::Y2 + 4 * K * K * 64 + 64 + (size_t)p.cpad3 * 24;
+  FROST_REQUIRE(lds <= 160 * 1024, "block_dw_reduce: LDS budget exceeded");
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)k_blk_dw_reduce2<K, NCTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  hipLaunchKernelGGL((k_blk_dw_reduce2<K, NCTW>), dim3((unsigned)((p.n + p.imgs - 1) / p.imgs)), dim3(512), lds, s, p);
+  return frost_check_launch("block_dw_reduce");
+}
+
 template <int K, int HW, int NW, int NCTW>
 static int launch_blk_b(BlkBP& p, hipStream_t s) {
   using G = BlkGeoB<K, HW, NW>;
@@ -555,6 +777,14 @@ extern "C" int frost_block_dw_reduce(const int8_t* y1, const float* qrec_y1, con
   const int ct3 = p.cpad3 >> 4;
   if (h == 7) {
     const int nctw = (ct3 + 3) / 4;
+    // two chunks per iteration on eight waves (k_blk_dw_reduce2): bit-identical, measured SLOWER (profiles/r05_fusion_ab.txt: 118 / 77 / 157 us against 93 / 63 / 117 with
+    // 256 registers and one workgroup per CU, worse with 128 registers and spills) -- off; the four-wave kernel stays
+    static const int two = getenv("FROST_BLK_B2") ? atoi(getenv("FROST_BLK_B2")) : 0;
+    if (two) {
+#define BLK_B2(KK, NN) if (k == KK && nctw <= NN) return launch_blk_b2<KK, NN>(p, s);
+      BLK_B2(3, 3) BLK_B2(3, 5) BLK_B2(5, 3) BLK_B2(5, 5)
+#undef BLK_B2
+    }
 #define BLK_B(KK, NN) if (k == KK && nctw <= NN) return launch_blk_b<KK, 7, 4, NN>(p, s);
     BLK_B(3, 3) BLK_B(3, 5) BLK_B(5, 3) BLK_B(5, 5)
 #undef BLK_B

@@ -152,11 +152,18 @@ def _dp_worker(rank, world, port, q):
         sync.ready(offs[i])
     sync.finish()
     lin = torch.nn.Linear(3, 2)
+    # buffers of every dtype a QAT model carries (int64 num_batches_tracked, uint8 observer switches, a bool, a non-contiguous float view, a 0-d tensor): the
+    # broadcast is coalesced per dtype and must put each value back where it belongs
+    lin.register_buffer("nbt", torch.tensor(3 + rank, dtype=torch.int64))
+    lin.register_buffer("flags", torch.tensor([rank, 1 - rank, 1], dtype=torch.uint8))
+    lin.register_buffer("on", torch.tensor([bool(rank), True]))
+    lin.register_buffer("view", torch.arange(12, dtype=torch.float32).reshape(3, 4).t()[:, 1:] * (1 + rank))
     torch.manual_seed(rank)
     with torch.no_grad():
         lin.weight.normal_()
     broadcast_model(lin)
-    q.put((rank, arena.numpy().copy(), lin.weight.detach().numpy().copy(), len(sync.buckets)))
+    extra = [lin.nbt.item(), lin.flags.tolist(), lin.on.tolist(), lin.view.tolist(), lin.bias.detach().tolist()]
+    q.put((rank, arena.numpy().copy(), lin.weight.detach().numpy().copy(), len(sync.buckets), extra))
     dist.destroy_process_group()
 
 
@@ -184,6 +191,8 @@ def test_data_parallel_grad_sync_gloo_world2():
     for r in range(2):
         torch.testing.assert_close(T(res[r][1]), expect)          # every rank holds the mean of the per-shard gradients
     torch.testing.assert_close(T(res[0][2]), T(res[1][2]))           # broadcast made the replicas identical
+    assert res[0][4] == res[1][4] and res[1][4][0] == 3 and res[1][4][1] == [0, 1, 1] and res[1][4][2] == [False, True]          # ... rank 0's values, every dtype
+    assert res[1][4][3] == (torch.arange(12, dtype=torch.float32).reshape(3, 4).t()[:, 1:]).tolist()
 
 
 def test_features_backbone_cpu_matches_reference(built, golden):
