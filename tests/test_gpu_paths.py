@@ -176,3 +176,21 @@ def test_conv1_reduce_pass_folded_into_the_depthwise_backward(case, tmp_path):
     print("conv1 vs fp32-gradient mode: fold", e_on, "separate", e_off)
     assert e_on["dbeta1"] <= 1.25 * e_off["dbeta1"] + 1e-4 and e_on["dgamma1"] <= 1.25 * e_off["dgamma1"] + 1e-4 and e_on["dw1"] <= 1.25 * e_off["dw1"] + 1e-4, (e_on, e_off)
     assert relerr(bf16_to_f32(on["dx"]), ref["dx"]) <= 1.25 * relerr(bf16_to_f32(off["dx"]), ref["dx"]) + 1e-4
+
+
+# The 7 x 7 conv2-emit + reduce_conv kernel with two chunks per iteration on eight waves (k_blk_dw_reduce2, FROST_BLK_B2=1; measured slower, off by default, kept as an A/B
+# form): integer GEMM + exact statistics -> every output, record and gradient must be BIT-IDENTICAL to the four-wave kernel -- odd and even chunk counts, partial last chunks,
+# k = 3 / 5, 12 and 20 output-channel tiles, several images per launch (the backward then runs on identical saved tensors).
+@pytest.mark.parametrize("case", [(192, 1008, 7, 5, 192, 5, 1), (192, 1152, 7, 3, 192, 3, 1), (288, 1728, 7, 5, 320, 2, 1), (96, 328, 7, 5, 56, 9, 1), (64, 264, 7, 3, 320, 4, 1)],
+                         ids=lambda c: "_".join(str(v) for v in c))
+def test_two_chunk_eight_wave_block_kernel_is_bit_identical(case, tmp_path):
+    calls = os.path.join(str(tmp_path), "calls.txt")
+    two = _block(str(tmp_path), "two", case, {"FROST_BLK_B2": "1", "DIGEST_CALLS": calls})
+    assert "frost_block_dw_reduce" in open(calls).read().split("\n")
+    one = _block(str(tmp_path), "one", case, {"FROST_BLK_B2": "0"})
+    for k in ("y3", "qy1", "qy2", "qy3"):          # the forward: integer GEMM + exact statistics
+        assert two[k].tobytes() == one[k].tobytes(), k
+    for k in one.files:                            # the backward runs on identical saved tensors; its float atomics group differently from run to run
+        if k.startswith("d") and k != "dx":
+            assert relerr(two[k], one[k]) <= 1e-4, k
+    assert relerr(bf16_to_f32(two["dx"]), bf16_to_f32(one["dx"])) <= 5e-3
