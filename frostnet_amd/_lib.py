@@ -193,6 +193,9 @@ _PROTOS = {
     "frost_g32_set_plain": [I],
     "frost_g32_reduce": [P, L, I, P, P, I, P, P, P],
     "frost_g32_dc": [P, L, I, P, P, I, P, P, P],
+    "frost_g32_x_ok": [I, L, I, I, I],
+    "frost_g32_reduce_x": [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
+    "frost_g32_dc_x": [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, P],
     "frost_g32_dgrad": [P, P, P, P, I, I, I, I, I, I, I, I, I, P, I, P],
     "frost_g32_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, P, P, P],
     "frost_g32_cat_bwd": [P, P, P, I, P, P, I, L, P, P, I, P, I, P],

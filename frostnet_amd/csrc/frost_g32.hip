@@ -105,70 +105,168 @@ __device__ __forceinline__ v4i g32_row16(const int8_t* row, int k0, int klim) { 
   }
   return v;
 }
-template <int MI>
-__global__ __launch_bounds__(256) void k_g32_pw_acc(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc) {
+// EPI 0: store the integer conv output (acc);  EPI 1 / 2: the REDUCE / DC pass of the backward straight from the accumulators -- the int32 tensor is never written or read
+// (24 -> 12 bytes per output element over the three passes; the int8 GEMM is recomputed, it costs a fraction of the bytes it saves).  EPI 1: a wave walks pixel blocks
+// pb = its index, += the launch's wave count, keeps fp64 sums of its 4 * MI channels per lane and writes ONE partial row part[wave][2][cout] at the end (k_g32_reduce_fin adds
+// the rows in a fixed order); EPI 2: dc = K1 (gy - S1 / n - xhat S2 / n) as 16-byte stores.  Coefficient rows of the block's channels sit in LDS.
+struct G32Epi { const float* coef; int cpad; const float* qy; int relu; const float* gout; double* part; float* dc; };
+template <int MI, int EPI>
+__global__ __launch_bounds__(256, 2) void k_g32_pw(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc, G32Epi e) {
   constexpr int NJ = 4;
+  __shared__ float rows[7][MI * 16];                             // A, B, M, R, K1, S1, S2 of this block's channels
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
   const int64_t npix = (int64_t)g.n * g.ho * g.wo;
-  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * (NJ * 16);
   const int co0 = (int)blockIdx.y * (MI * 16);
-  if (p0 >= npix) return;
   const int K = (g.kind == 2) ? g.xc : g.cin_g;                  // stem: the im2col columns tap * 4 + c
   const int zp = __float_as_int(qx[FROST_Q_ZP]);
-  v4i d[MI][NJ], dw[MI];
+  G32Win win = {1.0f, 0.0f, 0.0f};
+  if (EPI != 0) {
+    for (int i = threadIdx.x; i < 7 * MI * 16; i += 256) {
+      const int r = i / (MI * 16), c = i - r * (MI * 16);
+      const int row = (r < 4) ? r : (r == 4 ? FROST_COEF_K1 : (r == 5 ? FROST_COEF_S1 : FROST_COEF_S2));          // rows 0 .. 3 are A, B, M, R
+      rows[r][c] = (co0 + c < g.cout) ? e.coef[row * e.cpad + co0 + c] : 0.0f;
+    }
+    win = g32_win(e.qy, e.relu);
+    __syncthreads();
+  }
+  const double inv_n = 1.0 / (double)npix;
+  float s1[EPI == 1 ? MI : 1][4], s2[EPI == 1 ? MI : 1][4];          // fp32 over a lane's ~200 values of a channel, fp64 across lanes / waves / rows
+  if (EPI == 1) {
 #pragma unroll
-  for (int m = 0; m < MI; ++m) { dw[m] = (v4i){0, 0, 0, 0};
+    for (int m = 0; m < MI; ++m)
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) d[m][t] = (v4i){0, 0, 0, 0}; }
+      for (int i = 0; i < 4; ++i) { s1[m][i] = 0.0f; s2[m][i] = 0.0f; }
+  }
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
   const v4i ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
-  const int8_t* xr[NJ];
+  for (int64_t pb = wave; pb * (NJ * 16) < npix; pb += nwaves) {
+    const int64_t p0 = pb * (NJ * 16);
+    v4i d[MI][NJ], dw[MI];
 #pragma unroll
-  for (int t = 0; t < NJ; ++t) xr[t] = x + min(p0 + 16 * t + j, npix - 1) * g.xc;
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    v4i a[MI];
+    for (int m = 0; m < MI; ++m) { dw[m] = (v4i){0, 0, 0, 0};
 #pragma unroll
-    for (int m = 0; m < MI; ++m) {
-      const int co = co0 + 16 * m + j;
-      a[m] = (v4i){0, 0, 0, 0};
-      if (co < g.cout) {
-        if (g.kind == 0) a[m] = g32_row16(qw + (int64_t)co * g.cin_g, k0 + 16 * gq, K);
-        else {                                                   // stem weights OIHW [co][c * 9 + tap] -> column tap * 4 + c
-          const int8_t* wr = qw + (int64_t)co * g.cin_g * 9;
+      for (int t = 0; t < NJ; ++t) d[m][t] = (v4i){0, 0, 0, 0}; }
+    const int8_t* xr[NJ];
 #pragma unroll
-          for (int dd = 0; dd < 4; ++dd) {
-            uint32_t pk = 0;
+    for (int t = 0; t < NJ; ++t) xr[t] = x + min(p0 + 16 * t + j, npix - 1) * g.xc;
+    if (g.kind == 0 && K >= 16) {
+      // pointwise: operands by unconditional 16-byte loads at k clamped into the row (no branch around a load), two operand sets in turn so that the next K step's
+      // loads are in flight under this step's MFMAs; a clamped load repeats bytes another lane group / step already contributed: those dwords of the A operand are zeroed
+      struct Op { v4i a[MI]; v4i b[NJ]; };
+      const int8_t* wr[MI]; bool cok[MI];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const int col = k0 + 16 * gq + 4 * dd + b, tap = col >> 2, c = col & 3;
-              if (tap < 9 && c < g.cin_g) pk |= (uint32_t)(uint8_t)wr[c * 9 + tap] << (8 * b);
+      for (int m = 0; m < MI; ++m) { const int co = co0 + 16 * m + j; cok[m] = co < g.cout; wr[m] = qw + (int64_t)min(co, g.cout - 1) * g.cin_g; }
+      auto ld = [&](int k0) __attribute__((always_inline)) {
+        Op o; const int kc = min(k0 + 16 * gq, K - 16);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) { const int8_t* r = wr[m] + kc; o.a[m] = (v4i){*(const int*)r, *(const int*)(r + 4), *(const int*)(r + 8), *(const int*)(r + 12)}; }
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) { const int8_t* r = xr[t] + kc; o.b[t] = (v4i){*(const int*)r, *(const int*)(r + 4), *(const int*)(r + 8), *(const int*)(r + 12)}; }
+        return o;
+      };
+      auto step = [&](const Op& o, int k0) __attribute__((always_inline)) {
+        const int kreq = k0 + 16 * gq, kc = min(kreq, K - 16);
+        v4i a[MI];
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) a[m][dd] = (cok[m] && (kc + 4 * dd) >= kreq) ? o.a[m][dd] : 0;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) dw[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], ones, dw[m], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+          for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], o.b[t], d[m][t], 0, 0, 0);
+      };
+      Op o0 = ld(0);
+      for (int k0 = 0; k0 < K; k0 += 128) {
+        const Op o1 = ld(k0 + 64);
+        step(o0, k0);
+        o0 = ld(k0 + 128);
+        if (k0 + 64 < K) step(o1, k0 + 64);
+      }
+    } else
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      v4i a[MI];
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        const int co = co0 + 16 * m + j;
+        a[m] = (v4i){0, 0, 0, 0};
+        if (co < g.cout) {
+          if (g.kind == 0) a[m] = g32_row16(qw + (int64_t)co * g.cin_g, k0 + 16 * gq, K);
+          else {                                                   // stem weights OIHW [co][c * 9 + tap] -> column tap * 4 + c
+            const int8_t* wr = qw + (int64_t)co * g.cin_g * 9;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+              uint32_t pk = 0;
+#pragma unroll
+              for (int b = 0; b < 4; ++b) {
+                const int col = k0 + 16 * gq + 4 * dd + b, tap = col >> 2, c = col & 3;
+                if (tap < 9 && c < g.cin_g) pk |= (uint32_t)(uint8_t)wr[c * 9 + tap] << (8 * b);
+              }
+              a[m][dd] = (int)pk;
             }
-            a[m][dd] = (int)pk;
           }
         }
       }
+#pragma unroll
+      for (int m = 0; m < MI; ++m) dw[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], ones, dw[m], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) {
+        const v4i b = g32_row16(xr[t], k0 + 16 * gq, K);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b, d[m][t], 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int m = 0; m < MI; ++m) dw[m] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], ones, dw[m], 0, 0, 0);
+    for (int m = 0; m < MI; ++m) {
+      const int cl = 16 * m + 4 * gq, co = co0 + cl;
+      if (co >= g.cout) continue;
+      float rA[4], rB[4], rM[4], rR[4]; double rK[4], rS1[4], rS2[4];          // this lane's four channels: read from LDS once per channel tile, not once per pixel
+      if (EPI != 0) {
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) {
-      const v4i b = g32_row16(xr[t], k0 + 16 * gq, (g.kind == 2) ? g.xc : K);
+        for (int i = 0; i < 4; ++i) {
+          rA[i] = rows[0][cl + i]; rB[i] = rows[1][cl + i]; rM[i] = rows[2][cl + i]; rR[i] = rows[3][cl + i];
+          if (EPI == 2) { rK[i] = (double)rows[4][cl + i]; rS1[i] = (double)rows[5][cl + i] * inv_n; rS2[i] = (double)rows[6][cl + i] * inv_n; }
+        }
+      }
 #pragma unroll
-      for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m], b, d[m][t], 0, 0, 0);
+      for (int t = 0; t < NJ; ++t) {
+        const int64_t p = p0 + 16 * t + j;
+        if (p >= npix) continue;
+        v4i o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = d[m][t][i] + (128 - zp) * dw[m][i];
+        if (EPI == 0) { *(v4i*)(acc + p * g.cout + co) = o; continue; }
+        const v4f gy4 = *(const v4f*)(e.gout + p * g.cout + co);
+        v4f dcv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float af = (float)o[i];
+          const float tq = fmaf(rA[i], af, rB[i]) * win.y_inv;
+          const bool in = tq > win.t_lo && tq <= win.t_hi;
+          if (EPI == 1) { if (in) { const float gy = gy4[i]; s1[m][i] += gy; s2[m][i] = fmaf(gy, (af - rM[i]) * rR[i], s2[m][i]); } }
+          else {
+            const double xhat = ((double)af - (double)rM[i]) * (double)rR[i];
+            dcv[i] = (float)(rK[i] * ((in ? (double)gy4[i] : 0.0) - rS1[i] - xhat * rS2[i]));
+          }
+        }
+        if (EPI == 2) *(v4f*)(e.dc + p * g.cout + co) = dcv;
+      }
     }
   }
+  if (EPI == 1) {                                                  // the 16 pixel lanes of a lane group -> one value; one partial row per wave
+    double* row = e.part + wave * 2 * (int64_t)g.cout;
 #pragma unroll
-  for (int m = 0; m < MI; ++m) {
-    const int co = co0 + 16 * m + 4 * gq;
-    if (co >= g.cout) continue;
+    for (int m = 0; m < MI; ++m)
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) {
-      const int64_t p = p0 + 16 * t + j;
-      if (p >= npix) continue;
-      v4i o;
+      for (int i = 0; i < 4; ++i) {
+        double a = (double)s1[m][i], b = (double)s2[m][i];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = d[m][t][i] + (128 - zp) * dw[m][i];
-      *(v4i*)(acc + p * g.cout + co) = o;
-    }
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        const int co = co0 + 16 * m + 4 * gq + i;
+        if (j == 0 && co < g.cout) { row[co] = a; row[g.cout + co] = b; }
+      }
   }
 }
 
@@ -295,30 +393,48 @@ __global__ __launch_bounds__(256) void k_g32_pw_dgrad(const float* __restrict__ 
   for (int m = 0; m < MI; ++m)
 #pragma unroll
     for (int t = 0; t < NJ; ++t) d[m][t] = (v4f){0, 0, 0, 0};
-  const float* dr[NJ]; bool pok[NJ];
+  const float* dr[NJ]; float pm[NJ];
 #pragma unroll
-  for (int t = 0; t < NJ; ++t) { const int64_t p = p0 + 16 * t + j; pok[t] = p < npix; dr[t] = dc + min(p, npix - 1) * g.cout; }
-  for (int kb = 0; kb < g.cout; kb += 16) {
-    const int cok = kb + 4 * gq;                         // this lane's four output channels of the step (cout % 4 == 0: all four inside, or none)
-    const bool kok = cok < g.cout;
-    float a[MI][4];
+  for (int t = 0; t < NJ; ++t) { const int64_t p = p0 + 16 * t + j; pm[t] = (p < npix) ? 1.0f : 0.0f; dr[t] = dc + min(p, npix - 1) * g.cout; }
+  // operands: unconditional loads at clamped indices, masked by a factor afterwards (no branch around a load), the next 16-channel step's issued before this step's MFMAs
+  int cia[MI]; float cim[MI];
 #pragma unroll
-    for (int m = 0; m < MI; ++m) {
-      const int ci = ci0 + 16 * m + j;
+  for (int m = 0; m < MI; ++m) { const int ci = ci0 + 16 * m + j; cim[m] = (ci < g.cin_g) ? 1.0f : 0.0f; cia[m] = min(ci, g.cin_g - 1); }
+  struct Op { int8_t w[MI][4]; float sc[4]; v4f b[NJ]; };
+  auto ld = [&](int kb) __attribute__((always_inline)) {
+    Op o; const int cok = min(kb + 4 * gq, g.cout - 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = cok + q;
-        a[m][q] = (kok && ci < g.cin_g) ? (float)qw[(int64_t)co * g.cin_g + ci] * (wscale ? wscale[co] : sw0) : 0.0f;
-      }
+    for (int q = 0; q < 4; ++q) {
+      o.sc[q] = wscale ? wscale[cok + q] : sw0;
+#pragma unroll
+      for (int m = 0; m < MI; ++m) o.w[m][q] = qw[(int64_t)(cok + q) * g.cin_g + cia[m]];
     }
 #pragma unroll
+    for (int t = 0; t < NJ; ++t) o.b[t] = *(const v4f*)(dr[t] + cok);
+    return o;
+  };
+  auto step = [&](const Op& o, int kb) __attribute__((always_inline)) {
+    const float km = ((kb + 4 * gq) < g.cout) ? 1.0f : 0.0f;          // cout % 4 == 0: this lane's four output channels of the step are inside, or none
+    float a[MI][4];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[m][q] = (float)o.w[m][q] * o.sc[q] * (km * cim[m]);
+#pragma unroll
     for (int t = 0; t < NJ; ++t) {
-      const v4f b = (kok && pok[t]) ? *(const v4f*)(dr[t] + cok) : (v4f){0, 0, 0, 0};
+      const v4f b = o.b[t] * pm[t];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int m = 0; m < MI; ++m) d[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][q], b[q], d[m][t], 0, 0, 0);
     }
+  };
+  Op o0 = ld(0);          // two operand sets in turn, no register copy between them
+  for (int kb = 0; kb < g.cout; kb += 32) {
+    const Op o1 = ld(min(kb + 16, g.cout - 4));
+    step(o0, kb);
+    o0 = ld(min(kb + 32, g.cout - 4));
+    step(o1, kb + 16);          // past cout every lane is masked off (km = 0)
   }
 #pragma unroll
   for (int m = 0; m < MI; ++m) {
@@ -399,32 +515,44 @@ __global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restri
   for (int ra = 0; ra < NA; ++ra)
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) d[ra][rb] = (v4f){0, 0, 0, 0};
-  const float* ap = dc + co0 + NA * j; const int8_t* bp = x + ci0 + NB * j;
-  for (int64_t pb = lo; pb < hi; pb += 4) {
-    const int64_t p = pb + gq; const bool ok = p < hi;
+  // operands: every load unconditional at clamped addresses (a branch around a load puts its wait right behind it), the next step's issued before this step's MFMAs
+  const float* ap = dc + min(co0 + NA * j, g.cout - NA); const int8_t* bp = x + min(ci0 + NB * j, ncol - NB);
+  struct Op { float a[NA]; uint32_t xq; };
+  auto ld = [&](int64_t pb) __attribute__((always_inline)) {
+    Op o; const int64_t p = min(pb + gq, hi - 1);
+    const float* sa = ap + p * g.cout; const int8_t* sb = bp + p * g.xc;
+    if (NA == 4) { const v4f v = *(const v4f*)sa; o.a[0] = v[0]; o.a[1 % NA] = v[1]; o.a[2 % NA] = v[2]; o.a[3 % NA] = v[3]; }
+    else if (NA == 2) { const float2 v = *(const float2*)sa; o.a[0] = v.x; o.a[1 % NA] = v.y; }
+    else o.a[0] = *sa;
+    if (NB == 4) o.xq = *(const uint32_t*)sb; else if (NB == 2) o.xq = *(const uint16_t*)sb; else o.xq = *(const uint8_t*)sb;
+    return o;
+  };
+  auto step = [&](const Op& o, int64_t pb) __attribute__((always_inline)) {
+    const bool ok = (pb + gq) < hi;
+    const float ma = (ok && aok) ? 1.0f : 0.0f, mb = (ok && bok) ? 1.0f : 0.0f;
     float a[NA], b[NB];
+    const uint32_t xq = o.xq ^ 0x80808080u;
 #pragma unroll
-    for (int r = 0; r < NA; ++r) a[r] = 0.0f;
+    for (int r = 0; r < NA; ++r) a[r] = o.a[r] * ma;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) b[r] = 0.0f;
-    if (ok && aok) {
-      const float* src = ap + p * g.cout;
-      if (NA == 4) { const v4f v = *(const v4f*)src; a[0] = v[0]; a[1 % NA] = v[1]; a[2 % NA] = v[2]; a[3 % NA] = v[3]; }
-      else if (NA == 2) { const float2 v = *(const float2*)src; a[0] = v.x; a[1 % NA] = v.y; }
-      else a[0] = *src;
-    }
-    if (ok && bok) {
-      const int8_t* src = bp + p * g.xc;
-      uint32_t xq;
-      if (NB == 4) xq = *(const uint32_t*)src; else if (NB == 2) xq = *(const uint16_t*)src; else xq = *(const uint8_t*)src;
-      xq ^= 0x80808080u;
-#pragma unroll
-      for (int r = 0; r < NB; ++r) b[r] = (float)((xq >> (8 * r)) & 255u) - zpf;
-    }
+    for (int r = 0; r < NB; ++r) b[r] = ((float)((xq >> (8 * r)) & 255u) - zpf) * mb;
 #pragma unroll
     for (int ra = 0; ra < NA; ++ra)
 #pragma unroll
       for (int rb = 0; rb < NB; ++rb) d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ra], b[rb], d[ra][rb], 0, 0, 0);
+  };
+  // two operand sets in turn (no register copy between them: a copy would wait for the load it copies)
+  // a ring of four operand sets, loads three steps ahead (a step is 16 MFMAs = 512 cycles of the matrix pipe; a global load takes ~2000)
+  Op o0 = ld(lo), o1 = ld(min(lo + 4, hi - 1)), o2 = ld(min(lo + 8, hi - 1));
+  for (int64_t pb = lo; pb < hi; pb += 16) {
+    const Op o3 = ld(min(pb + 12, hi - 1));
+    step(o0, pb);
+    o0 = ld(min(pb + 16, hi - 1));
+    step(o1, pb + 4);          // past `hi` every lane is masked off
+    o1 = ld(min(pb + 20, hi - 1));
+    step(o2, pb + 8);
+    o2 = ld(min(pb + 24, hi - 1));
+    step(o3, pb + 12);
   }
   float* prt = part + chunk * (int64_t)g.cout * ncp;
 #pragma unroll
@@ -524,9 +652,9 @@ extern "C" int frost_g32_conv_acc(const int8_t* x, const float* qrec_x, const in
   if (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npo < (1ll << 31)) {
     if ((kind == 0 && (cin_g % 4) == 0) || (kind == 2 && xc <= 64 && cin_g <= 4)) {
       const unsigned gx = (unsigned)((npo + 255) / 256);
-      if (cout <= 16) hipLaunchKernelGGL((k_g32_pw_acc<1>), dim3(gx, (unsigned)((cout + 15) / 16)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
-      else if (cout <= 32) hipLaunchKernelGGL((k_g32_pw_acc<2>), dim3(gx, (unsigned)((cout + 31) / 32)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
-      else hipLaunchKernelGGL((k_g32_pw_acc<4>), dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, x, qrec_x, qw, g, acc);
+      if (cout <= 16) hipLaunchKernelGGL((k_g32_pw<1, 0>), dim3(gx, (unsigned)((cout + 15) / 16)), dim3(256), 0, s, x, qrec_x, qw, g, acc, G32Epi{});
+      else if (cout <= 32) hipLaunchKernelGGL((k_g32_pw<2, 0>), dim3(gx, (unsigned)((cout + 31) / 32)), dim3(256), 0, s, x, qrec_x, qw, g, acc, G32Epi{});
+      else hipLaunchKernelGGL((k_g32_pw<4, 0>), dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, x, qrec_x, qw, g, acc, G32Epi{});
       return frost_check_launch("g32_conv_acc");
     }
     if (kind == 1 && (k == 3 || k == 5) && (stride == 1 || stride == 2)) {
@@ -607,6 +735,43 @@ extern "C" int frost_g32_dc(const int32_t* acc, int64_t npix, int cout, const fl
   int64_t grid = (npix * cout + 255) / 256; if (grid > 65535) grid = 65535;
   hipLaunchKernelGGL(k_g32_dc, dim3((unsigned)grid), dim3(256), 0, s, acc, npix, cout, round_up(cout, 16), coef, qrec_y, relu, gout, dc);
   return frost_check_launch("g32_dc");
+}
+
+// ---- reduce / dc passes of a pointwise (kind 0) or stem (kind 2) layer that RECOMPUTE the integer conv output on the int8 MFMA instead of reading a stored one
+// (frost_g32_conv_acc + frost_g32_reduce + frost_g32_dc without the int32 tensor): frost_g32_x_ok says whether the shape has the form
+extern "C" int frost_g32_x_ok(int kind, int64_t npix, int xc, int cin_g, int cout) {
+  return (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npix < (1ll << 31) && ((kind == 0 && (cin_g % 4) == 0) || (kind == 2 && xc <= 64 && cin_g <= 4))) ? 1 : 0;
+}
+template <int EPI>
+static int g32_launch_x(const int8_t* x, const float* qrec_x, const int8_t* qw, const G32Geo& g, G32Epi e, unsigned gx, hipStream_t s) {
+  const int cout = g.cout;
+  if (cout <= 16) hipLaunchKernelGGL((k_g32_pw<1, EPI>), dim3(gx, (unsigned)((cout + 15) / 16)), dim3(256), 0, s, x, qrec_x, qw, g, (int32_t*)nullptr, e);
+  else if (cout <= 32) hipLaunchKernelGGL((k_g32_pw<2, EPI>), dim3(gx, (unsigned)((cout + 31) / 32)), dim3(256), 0, s, x, qrec_x, qw, g, (int32_t*)nullptr, e);
+  else hipLaunchKernelGGL((k_g32_pw<4, EPI>), dim3(gx, (unsigned)((cout + 63) / 64)), dim3(256), 0, s, x, qrec_x, qw, g, (int32_t*)nullptr, e);
+  return 0;
+}
+extern "C" int frost_g32_reduce_x(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, float* coef,
+                                  const float* qrec_y, int relu, const float* gout, void* scratch, void* stream) {
+  const G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, 1, 1);
+  const int64_t npix = (int64_t)n * h * w;
+  FROST_REQUIRE(frost_g32_x_ok(kind, npix, xc, cin_g, cout) && scratch, "g32_reduce_x: no recomputing form for this shape (frost_g32_x_ok), or no scratch");
+  hipStream_t s = as_stream(stream);
+  int64_t gx = (npix + 255) / 256;                                  // one wave per 64-pixel block at most; <= 512 workgroups (2048 partial rows) walk the rest
+  const int64_t cap = frost_g32_scratch_bytes() / ((int64_t)4 * 2 * cout * 8);
+  if (gx > 512) gx = 512; if (gx > cap) gx = cap; if (gx < 1) gx = 1;
+  G32Epi e = {coef, round_up(cout, 16), qrec_y, relu, gout, (double*)scratch, nullptr};
+  g32_launch_x<1>(x, qrec_x, qw, g, e, (unsigned)gx, s);
+  hipLaunchKernelGGL(k_g32_reduce_fin, dim3((unsigned)cout), dim3(256), 0, s, (const double*)scratch, (int)(gx * 4), cout, round_up(cout, 16), coef);
+  return frost_check_launch("g32_reduce_x");
+}
+extern "C" int frost_g32_dc_x(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, const float* coef,
+                              const float* qrec_y, int relu, const float* gout, float* dc, void* stream) {
+  const G32Geo g = g32_geo(kind, n, h, w, xc, cin_g, cout, 1, 1);
+  const int64_t npix = (int64_t)n * h * w;
+  FROST_REQUIRE(frost_g32_x_ok(kind, npix, xc, cin_g, cout), "g32_dc_x: no recomputing form for this shape (frost_g32_x_ok)");
+  G32Epi e = {coef, round_up(cout, 16), qrec_y, relu, gout, nullptr, dc};
+  g32_launch_x<2>(x, qrec_x, qw, g, e, (unsigned)((npix + 255) / 256), as_stream(stream));
+  return frost_check_launch("g32_dc_x");
 }
 
 // data gradient: gx[pixel][ci] (+)= sum_co dc[.][co] * q_w * s_w[co]     (kind 0: pointwise, 1: depthwise; the stem needs none)

@@ -791,15 +791,22 @@ class Engine:
         call("frost_g32_wq", ptr(l.w), ptr(l.gamma), ptr(l.sigma), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, l.cout, per, ptr(qw), s)
         cin_g = 1 if kind == 1 else l.cin_g
         geo = (kind, x.n, x.h, x.w, x.c, cin_g, l.cout, l.k, l.stride)
-        acc = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
-        call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s)
         if getattr(self, "_g32_scratch", None) is None:          # partial sums / partial tiles of the two-stage reductions (deterministic, fp64 second stage)
             self._g32_scratch = torch.empty(int(L.load_library().frost_g32_scratch_bytes()), dtype=torch.uint8, device=self.device)
         scr = self._g32_scratch
-        call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
-        self._frozen_after_reduce(l)
         dc = torch.empty(y.numel + 64, dtype=torch.float32, device=self.device)
-        call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
+        if kind != 1 and L.load_library().frost_g32_x_ok(kind, y.npix, x.c, cin_g, l.cout):
+            # pointwise / stem: the reduce and dc passes recompute the integer conv output on the int8 MFMA -- no int32 tensor is written or re-read
+            gx_ = (kind, x.n, x.h, x.w, x.c, cin_g, l.cout)
+            call("frost_g32_reduce_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
+            self._frozen_after_reduce(l)
+            call("frost_g32_dc_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
+        else:
+            acc = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
+            call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s)
+            call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
+            self._frozen_after_reduce(l)
+            call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
         if getattr(self, "_dbg", False):
             self._last_dc = dc
         if x.needs_grad:

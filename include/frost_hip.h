@@ -301,6 +301,13 @@ int64_t frost_g32_scratch_bytes(void);
 int frost_g32_set_plain(int on);   /* 1: every frost_g32_* entry runs its plain (round-4) kernel -- the yardstick of the fast forms; default 0 (env FROST_G32_PLAIN) */
 int frost_g32_reduce(const int32_t* acc, int64_t npix, int cout, float* coef, const float* qrec_y, int relu, const float* gout, void* scratch, void* stream);
 int frost_g32_dc(const int32_t* acc, int64_t npix, int cout, const float* coef, const float* qrec_y, int relu, const float* gout, float* dc, void* stream);
+/* reduce / dc passes of a pointwise (kind 0) or stem (kind 2) layer that recompute the integer conv output on the int8 MFMA instead of reading the stored one: with them
+ * frost_g32_conv_acc is not needed for such a layer (24 -> 12 bytes per output element).  frost_g32_x_ok: the shape has the form (else: conv_acc + reduce + dc). */
+int frost_g32_x_ok(int kind, int64_t npix, int xc, int cin_g, int cout);
+int frost_g32_reduce_x(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, float* coef,
+                       const float* qrec_y, int relu, const float* gout, void* scratch, void* stream);
+int frost_g32_dc_x(const int8_t* x, const float* qrec_x, const int8_t* qw, int kind, int n, int h, int w, int xc, int cin_g, int cout, const float* coef,
+                   const float* qrec_y, int relu, const float* gout, float* dc, void* stream);
 int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* qrec_w, const float* wscale, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k,
                     int stride, float* gx, int accumulate, void* stream);
 int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qrec_x, int kind, int n, int h, int w, int xc, int cin_g, int cout, int k, int stride, float* dwq,

@@ -91,6 +91,15 @@ def test_fp32_gradient_fast_forms_equal_the_plain_kernels(L, case):
         s12 = coef.view(8, cpad).clone()
         L.call("frost_g32_dc", ptr(acc), npo, cout, ptr(coef), ptr(qy), 1, ptr(gout), ptr(dc), s)
         out = {"acc": acc[: npo * cout].clone(), "coef": s12, "dc": dc[: npo * cout].clone()}
+        if not plain and kind != 1:          # the reduce / dc passes that recompute the integer conv output instead of reading `acc` (frost_g32_reduce_x / _dc_x)
+            assert lib.frost_g32_x_ok(kind, npo, xc, cin_g, cout)
+            coefx = coef0.clone().to(dev)
+            dcx = torch.zeros(npo * cout + 64, dtype=torch.float32, device=dev)
+            gx_ = (kind, N, H, H, xc, cin_g, cout)
+            L.call("frost_g32_reduce_x", ptr(x), ptr(qx), ptr(qw), *gx_, ptr(coefx), ptr(qy), 1, ptr(gout), ptr(scr), s)
+            out["coefx"] = coefx.view(8, cpad).clone()
+            L.call("frost_g32_dc_x", ptr(x), ptr(qx), ptr(qw), *gx_, ptr(coefx), ptr(qy), 1, ptr(gout), ptr(dcx), s)
+            out["dcx"] = dcx[: npo * cout].clone()
         if kind != 2:
             for accum in (0, 1):
                 gx = torch.full((nin * xc + 64,), 0.25, dtype=torch.float32, device=dev)
@@ -113,7 +122,11 @@ def test_fp32_gradient_fast_forms_equal_the_plain_kernels(L, case):
         if r not in srow:
             assert torch.equal(a["coef"][r], b["coef"][r])
     assert relerr(a["dc"], b["dc"]) <= 1e-6, (name, "dc", relerr(a["dc"], b["dc"]))          # (the S rows differ in their last bit)
-    errs = {key: relerr(a[key], b[key]) for key in a if key.startswith("gx") or key == "dwq"}
+    if "coefx" in a:          # recomputing forms: S rows from fp32 lane sums of ~200 values (fp64 across lanes / waves), dc from them
+        for r in srow:
+            assert relerr(a["coefx"][r], b["coef"][r]) <= 5e-6, (name, "S row (recomputing form)", r, relerr(a["coefx"][r], b["coef"][r]))
+        assert relerr(a["dcx"], b["dc"]) <= 5e-6, (name, "dc (recomputing form)", relerr(a["dcx"], b["dc"]))
+    errs = {key: relerr(a[key], b[key]) for key in a if (key.startswith("gx") or key == "dwq") and key in b}
     print(f"[g32 fast vs plain {name}] " + " ".join(f"{k_} {v:.1e}" for k_, v in errs.items()))
     assert all(v <= (1e-5 if k_ == "dwq" else 2e-6) for k_, v in errs.items()), (name, errs)          # (the weight gradient: fp32 sums over runs of <= 1024 pixels, fp64 across runs)
     assert float(b["dwq"].abs().max()) > 0 and float(b["dc"].abs().max()) > 0
