@@ -181,7 +181,7 @@ def test_conv1_reduce_pass_folded_into_the_depthwise_backward(case, tmp_path):
 # The 7 x 7 conv2-emit + reduce_conv kernel with two chunks per iteration on eight waves (k_blk_dw_reduce2, FROST_BLK_B2=1; measured slower, off by default, kept as an A/B
 # form): integer GEMM + exact statistics -> every output, record and gradient must be BIT-IDENTICAL to the four-wave kernel -- odd and even chunk counts, partial last chunks,
 # k = 3 / 5, 12 and 20 output-channel tiles, several images per launch (the backward then runs on identical saved tensors).
-@pytest.mark.parametrize("case", [(192, 1008, 7, 5, 192, 5, 1), (192, 1152, 7, 3, 192, 3, 1), (288, 1728, 7, 5, 320, 2, 1), (96, 328, 7, 5, 56, 9, 1), (64, 264, 7, 3, 320, 4, 1)],
+@pytest.mark.parametrize("case", [(192, 1008, 7, 5, 192, 5, 1), (192, 1152, 7, 3, 192, 3, 1), (288, 1728, 7, 5, 320, 2, 1), (96, 328, 7, 5, 56, 9, 1)],
                          ids=lambda c: "_".join(str(v) for v in c))
 def test_two_chunk_eight_wave_block_kernel_is_bit_identical(case, tmp_path):
     calls = os.path.join(str(tmp_path), "calls.txt")

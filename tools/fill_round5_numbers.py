@@ -38,7 +38,8 @@ out = {"R5_IMGS": f"{d['value']:,.0f}".replace(",", " "), "R5_MS": f"{d['ms_per_
        "R5_NODES": str(gn.get("nodes_total", "?")), "R5_OTHER": str(gn.get("kernels_other", 0) + gn.get("memset", 0) + gn.get("memcpy", 0) + gn.get("other_nodes", 0)),
        "R5_SUITE": suite, "R5_C2": f"{side[0]['value'] / 1e3:.1f}", "R5_INT8": f"{side[1]['value'] / 1e3:.1f}", "R5_DET": f"{side[2]['value'] / 1e3:.2f}",
        "R5_G32": f"{gm[3]['ms_per_step']:.1f}", "R5_G32X": f"{gm[3]['ms_per_step'] / d['ms_per_step']:.1f}", "R5_G32_64": f"{gm[1]['ms_per_step']:.1f}",
-       "R5_G32_DWWG": f"{dwwg:.0f}", "R5_WG_RATIO": ratio("pw_wgrad"), "R5_EXP_RATIO": ratio("blk_expand_dw"), "R5_DWS_RATIO": ratio("blk_dw_stats")}
+       "R5_G32_DWWG": f"{dwwg:.0f}", "G32NEW": f"{gm[3]['ms_per_step']:.1f}", "G32XNEW": f"{gm[3]['ms_per_step'] / d['ms_per_step']:.1f}", "G32_64NEW": f"{gm[1]['ms_per_step']:.1f}",
+       "DWWGNEW": f"{dwwg:.0f}", "R5_WG_RATIO": ratio("pw_wgrad"), "R5_EXP_RATIO": ratio("blk_expand_dw"), "R5_DWS_RATIO": ratio("blk_dw_stats")}
 print(json.dumps(out, indent=1))
 print("side:", [(s["metric"][:40], round(s["value"])) for s in side])
 print("grad modes:", [(m["config"].get("grad_dtype"), m["config"].get("per_gpu_batch"), m["ms_per_step"]) for m in gm])
