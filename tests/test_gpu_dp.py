@@ -214,8 +214,8 @@ def test_bench_two_physical_gpus_rccl():
     print(f"[2 GPUs] {rec['value']:.0f} img/s, exposed communication {ga['exposed_comm_ms_per_step']} ms / step, all-reduce check {chk}")
 
 
-def _bench_ranks(extra, timeout=1800):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _bench_ranks(extra, timeout=1800, **more_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **more_env)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra + ["--no-roofline", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     if out.returncode == 3 and "process-group bring-up failed" in out.stderr:
@@ -250,6 +250,15 @@ def test_eight_rank_rehearsal_detector_on_one_gpu():
     assert ga["fallback"] is None and "buckets overlapped" in ga["mode"] and len(ga["buckets"]) >= 2
     chk = ga["allreduce_check"]
     assert chk["ok"] and chk["single_rank_vs_mean"] > 10 * chk["rel_err_vs_mean_of_rank_gradients"], chk
+
+
+def test_two_rank_data_parallel_in_the_fp32_gradient_mode():
+    """The fp32-gradient mode (the reference's gradient precision, Classification/utils/helper_functions.py:139-143; csrc/frost_g32.hip) under the same data-parallel
+    machinery: two ranks on one device, captured segments, bucketed exchange -- the arena (fp32 either way) must hold the mean of the ranks' own gradients."""
+    rec = _bench_ranks(["--gpus", "2", "--share-gpu", "--batch", "8", "--steps", "2", "--warmup", "2", "--check-allreduce"], FROST_GRAD="fp32")
+    ga = rec["config"]["grad_allreduce"]
+    assert rec["n_gpus"] == 2 and rec["config"]["grad_dtype"] == "fp32" and rec["config"]["hip_graph"] is True
+    assert ga["fallback"] is None and ga["allreduce_check"]["ok"] and ga["allreduce_check"]["single_rank_vs_mean"] > 0.1, ga
 
 
 def test_detector_segmented_step_equals_module_surface():
