@@ -595,14 +595,18 @@ static void g32_sum_part(const float* part, int rows, int cout, int per, int ncp
   if (ne <= 8192 && rows >= 1024) hipLaunchKernelGGL((k_g32_sum_part<4>), dim3((unsigned)((ne + 3) / 4)), dim3(256), 0, s, part, rows, cout, per, ncp, kind, qx, out);
   else hipLaunchKernelGGL((k_g32_sum_part<16>), dim3((unsigned)((ne + 15) / 16)), dim3(256), 0, s, part, rows, cout, per, ncp, kind, qx, out);
 }
-// ---- depthwise weight gradient, stage 1: a thread = one channel quad over its run of pixels, fp32 sums per tap -> part[row][c][kk] (fp32; a run is <= ~512 pixels)
+// ---- depthwise weight gradient, stage 1: a thread = one channel quad over its run of pixels, fp32 sums per tap -> part[row][c][kk] (fp32; a run is <= ~512 pixels).
+// The K x K input window of the quad lives in registers as packed bytes and SLIDES along the row: a step loads its K * S new columns (5 instead of 25 loads for k = 5,
+// stride 1), an out-of-map entry is stored as the zero point (q - zp = 0: no mask in the arithmetic); a new row or the start of the run reloads the window.
 template <int K, int S>
 __global__ __launch_bounds__(256) void k_g32_dw_wgrad_part(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, float* __restrict__ part) {
   constexpr int KK = K * K, PAD = (K - 1) / 2;
   const G32Map mp = g32_map(g.cout);
   if (!mp.ok) return;
   const int c0 = mp.cq * 4;
-  const float zpf = (float)__float_as_int(qx[FROST_Q_ZP]);
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  const float zpf = (float)zp;
+  const uint32_t zpb = (uint32_t)(zp & 255) * 0x01010101u;
   float sf[KK][4];
 #pragma unroll
   for (int t = 0; t < KK; ++t)
@@ -610,21 +614,41 @@ __global__ __launch_bounds__(256) void k_g32_dw_wgrad_part(const float* __restri
     for (int b = 0; b < 4; ++b) sf[t][b] = 0.0f;
   G32Run r = g32_run(mp, g.n * g.ho * g.wo, g.wo, g.ho);
   const int row = (int)blockIdx.x * mp.PL + mp.pl;
+  uint32_t win[K][K];
+  bool fresh = true;
   for (; r.p < r.pe;) {
-    const v4f dv = *(const v4f*)(dc + (int64_t)r.p * g.cout + c0);
     const int8_t* base = x + ((int64_t)r.n * g.h * g.w) * g.xc + c0;
+    const int ix0 = r.x * S - PAD;
+    auto entry = [&](int ky, int jc) __attribute__((always_inline)) {          // window entry (ky, column jc) of the current pixel: the four indices q as unsigned bytes
+      const int iy = r.y * S - PAD + ky, ix = ix0 + jc;
+      const int iyc = min(max(iy, 0), g.h - 1), ixc = min(max(ix, 0), g.w - 1);
+      const uint32_t v = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;
+      return (iy == iyc && ix == ixc) ? v : zpb;
+    };
+    if (fresh || r.x == 0) {
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int iy = r.y * S - PAD + ky, iyc = min(max(iy, 0), g.h - 1);
+      for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const int ix = r.x * S - PAD + kx, ixc = min(max(ix, 0), g.w - 1);
-        const uint32_t xq = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;          // every tap's load is issued (clamped): K * K loads in flight together
-        const float m = (iy == iyc && ix == ixc) ? 1.0f : 0.0f;
+        for (int jc = 0; jc < K; ++jc) win[ky][jc] = entry(ky, jc);
+      fresh = false;
+    } else {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) sf[ky * K + kx][b] = fmaf(dv[b] * m, (float)((xq >> (8 * b)) & 255u) - zpf, sf[ky * K + kx][b]);
+      for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+        for (int jc = 0; jc < K - S; ++jc) win[ky][jc] = win[ky][jc + S];
+#pragma unroll
+        for (int jc = (K - S > 0 ? K - S : 0); jc < K; ++jc) win[ky][jc] = entry(ky, jc);
       }
     }
+    const v4f dv = *(const v4f*)(dc + (int64_t)r.p * g.cout + c0);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const uint32_t xq = win[ky][kx];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sf[ky * K + kx][b] = fmaf(dv[b], (float)((xq >> (8 * b)) & 255u) - zpf, sf[ky * K + kx][b]);
+      }
     G32_RUN_STEP(r, g.wo, g.ho);
   }
   float* dst = part + ((int64_t)row * g.cout + c0) * KK;
