@@ -282,34 +282,61 @@ __device__ __forceinline__ G32Run g32_run(const G32Map& mp, int np, int W, int H
 }
 #define G32_RUN_STEP(r, W, H) do { ++(r).p; if (++(r).x == (W)) { (r).x = 0; if (++(r).y == (H)) { (r).y = 0; ++(r).n; } } } while (0)
 
+// the K x K input window of a channel quad as packed bytes in registers, sliding along the output row: a step loads its K * S new columns; an out-of-map entry is stored as
+// the zero point (q - zp = 0), so no mask is left in the arithmetic; the start of a run and of a row reload the window
+template <int K, int S>
+struct G32Window {
+  uint32_t win[K][K]; bool fresh = true;
+  template <typename F> __device__ __forceinline__ void advance(int x, F&& entry) {
+    if (fresh || x == 0) {
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int jc = 0; jc < K; ++jc) win[ky][jc] = entry(ky, jc);
+      fresh = false;
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+        for (int jc = 0; jc < K - S; ++jc) win[ky][jc] = win[ky][jc + S];
+#pragma unroll
+        for (int jc = (K - S > 0 ? K - S : 0); jc < K; ++jc) win[ky][jc] = entry(ky, jc);
+      }
+    }
+  }
+};
 template <int K, int S>
 __global__ __launch_bounds__(256) void k_g32_dw_acc(const int8_t* __restrict__ x, const float* qx, const int8_t* __restrict__ qw, G32Geo g, int32_t* __restrict__ acc) {
   constexpr int KK = K * K, PAD = (K - 1) / 2;
   const G32Map mp = g32_map(g.cout);
   if (!mp.ok) return;
   const int c0 = mp.cq * 4, zp = __float_as_int(qx[FROST_Q_ZP]);
+  const uint32_t zpb = (uint32_t)(zp & 255) * 0x01010101u;
   int wq[KK][4];
 #pragma unroll
   for (int t = 0; t < KK; ++t)
 #pragma unroll
     for (int b = 0; b < 4; ++b) wq[t][b] = (int)qw[(int64_t)(c0 + b) * KK + t];
   G32Run r = g32_run(mp, g.n * g.ho * g.wo, g.wo, g.ho);
+  G32Window<K, S> W;
   for (; r.p < r.pe;) {
-    v4i s = {0, 0, 0, 0};
     const int8_t* base = x + ((int64_t)r.n * g.h * g.w) * g.xc + c0;
-    // every tap's load is issued (clamped coordinates, no branch around it: K * K loads travel together); an out-of-map tap contributes q - zp = 0
+    const int ix0 = r.x * S - PAD;
+    W.advance(r.x, [&](int ky, int jc) __attribute__((always_inline)) {
+      const int iy = r.y * S - PAD + ky, ix = ix0 + jc;
+      const int iyc = min(max(iy, 0), g.h - 1), ixc = min(max(ix, 0), g.w - 1);
+      const uint32_t v = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;          // the four indices q as unsigned bytes
+      return (iy == iyc && ix == ixc) ? v : zpb;
+    });
+    v4i s = {0, 0, 0, 0};
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int iy = r.y * S - PAD + ky, iyc = min(max(iy, 0), g.h - 1);
+    for (int ky = 0; ky < K; ++ky)
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int ix = r.x * S - PAD + kx, ixc = min(max(ix, 0), g.w - 1);
-        const uint32_t xl = (uint32_t)*(const int*)(base + (int64_t)(iyc * g.w + ixc) * g.xc) ^ 0x80808080u;          // the four indices q as unsigned bytes
-        const uint32_t xq = (iy == iyc && ix == ixc) ? xl : (uint32_t)zp * 0x01010101u;
+        const uint32_t xq = W.win[ky][kx];
 #pragma unroll
         for (int b = 0; b < 4; ++b) s[b] += ((int)((xq >> (8 * b)) & 255u) - zp) * wq[ky * K + kx][b];
       }
-    }
     *(v4i*)(acc + (int64_t)r.p * g.cout + c0) = s;
     G32_RUN_STEP(r, g.wo, g.ho);
   }
