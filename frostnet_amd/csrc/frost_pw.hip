@@ -817,10 +817,12 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       }
     }
     __syncthreads();
+#ifndef PW_ABL_NOGATOM
     for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {
       atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
       atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, l_f2[c]);
     }
+#endif
   }
 }
 
