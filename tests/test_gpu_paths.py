@@ -190,7 +190,9 @@ def test_two_chunk_eight_wave_block_kernel_is_bit_identical(case, tmp_path):
     one = _block(str(tmp_path), "one", case, {"FROST_BLK_B2": "0"})
     for k in ("y3", "qy1", "qy2", "qy3"):          # the forward: integer GEMM + exact statistics
         assert two[k].tobytes() == one[k].tobytes(), k
-    for k in one.files:                            # the backward runs on identical saved tensors; its float atomics group differently from run to run
+    # the backward does not touch this kernel: it runs on identical saved tensors in both processes and differs only by its own run-to-run noise (float atomics group
+    # differently, which moves stochastic-rounding decisions of dc: <= 1.2e-2 of a layer's gradient norm over 36 runs, tests/test_gpu_model.py) -- a sanity bound only
+    for k in one.files:
         if k.startswith("d") and k != "dx":
-            assert relerr(two[k], one[k]) <= 1e-4, k
-    assert relerr(bf16_to_f32(two["dx"]), bf16_to_f32(one["dx"])) <= 5e-3
+            assert relerr(two[k], one[k]) <= 2e-2, k
+    assert relerr(bf16_to_f32(two["dx"]), bf16_to_f32(one["dx"])) <= 2e-2
