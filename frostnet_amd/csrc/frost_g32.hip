@@ -496,6 +496,47 @@ __global__ __launch_bounds__(256) void k_g32_dw_dgrad(const float* __restrict__ 
 #pragma unroll
     for (int b = 0; b < 4; ++b) wf[t][b] = (float)qw[(int64_t)(c0 + b) * KK + t];
   G32Run r = g32_run(mp, g.n * g.h * g.w, g.w, g.h);
+  if (S == 1) {
+    // stride 1: the K x K window of dc values around the pixel lives in registers and slides along the row (K new 16-byte loads per pixel instead of K * K); an entry
+    // outside the map is 0, so no mask is left in the arithmetic; dx = sum win[r][c] * w[K - 1 - r][K - 1 - c]
+    v4f win[K][K]; bool fresh = true;
+    for (; r.p < r.pe;) {
+      const float* base = dc + ((int64_t)r.n * g.ho * g.wo) * g.cout + c0;
+      auto entry = [&](int rr, int cc) __attribute__((always_inline)) {
+        const int oy = r.y - PAD + rr, ox = r.x - PAD + cc;
+        const int oyc = min(max(oy, 0), g.ho - 1), oxc = min(max(ox, 0), g.wo - 1);
+        const v4f v = *(const v4f*)(base + (int64_t)(oyc * g.wo + oxc) * g.cout);
+        return (oy == oyc && ox == oxc) ? v : (v4f){0, 0, 0, 0};
+      };
+      if (fresh || r.x == 0) {
+#pragma unroll
+        for (int rr = 0; rr < K; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < K; ++cc) win[rr][cc] = entry(rr, cc);
+        fresh = false;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < K; ++rr) {
+#pragma unroll
+          for (int cc = 0; cc < K - 1; ++cc) win[rr][cc] = win[rr][cc + 1];
+          win[rr][K - 1] = entry(rr, K - 1);
+        }
+      }
+      v4f sacc = {0, 0, 0, 0};
+#pragma unroll
+      for (int rr = 0; rr < K; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < K; ++cc)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) sacc[b] = fmaf(win[rr][cc][b], wf[(K - 1 - rr) * K + (K - 1 - cc)][b], sacc[b]);
+      float* dst = gx + (int64_t)r.p * g.xc + c0;
+      v4f o = {sacc[0] * sw[0], sacc[1] * sw[1], sacc[2] * sw[2], sacc[3] * sw[3]};
+      if (accumulate) { const v4f old = *(const v4f*)dst; o = old + o; }
+      *(v4f*)dst = o;
+      G32_RUN_STEP(r, g.w, g.h);
+    }
+    return;
+  }
   for (; r.p < r.pe;) {
     v4f sacc = {0, 0, 0, 0};
     const float* base = dc + ((int64_t)r.n * g.ho * g.wo) * g.cout + c0;
