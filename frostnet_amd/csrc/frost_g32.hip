@@ -479,6 +479,106 @@ __global__ __launch_bounds__(256) void k_g32_pw_dgrad(const float* __restrict__ 
   }
 }
 
+// ---- the same data gradient on the bf16 MFMA with fp32 operands SPLIT into three bf16 pieces (hi + mid + lo = the fp32 value exactly: 3 x 8 mantissa bits, by truncation):
+// dc * s_w as B operand (three pieces -> three MFMAs), the weight indices as A operand (an int8 is exact in bf16), products exact in fp32, accumulation in fp32 as before --
+// the arithmetic of k_g32_pw_dgrad at 3 v_mfma_f32_16x16x32_bf16 per 32 output channels instead of 8 v_mfma_f32_16x16x4_f32 (2.7 x fewer cycles of the matrix pipe).
+// A lane's B operand of a step is 8 consecutive channels of its pixel's dc row (two 16-byte loads).  cout % 8 == 0.
+typedef __bf16 g32_v8bf __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void g32_split3(const float (&v)[8], v4i& hi, v4i& mid, v4i& lo) {
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t xb = __float_as_uint(v[i]); h[i] = xb & 0xffff0000u;
+    const float r1 = v[i] - __uint_as_float(h[i]); m[i] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m[i]); l[i] = __float_as_uint(r2) & 0xffff0000u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {          // two bf16 per dword: element 2i in the low half
+    hi[i] = (int)((h[2 * i] >> 16) | h[2 * i + 1]); mid[i] = (int)((m[2 * i] >> 16) | m[2 * i + 1]); lo[i] = (int)((l[2 * i] >> 16) | l[2 * i + 1]);
+  }
+}
+template <int MI>
+__global__ __launch_bounds__(256, 2) void k_g32_pw_dgrad_b3(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
+                                                            float* __restrict__ gx, int accumulate) {
+  constexpr int NJ = 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const int64_t npix = (int64_t)g.n * g.h * g.w;
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wv) * (NJ * 16);
+  const int ci0 = (int)blockIdx.y * (MI * 16);
+  if (p0 >= npix) return;
+  const float sw0 = qrec_w[FROST_Q_SCALE];
+  v4f d[MI][NJ];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) d[m][t] = (v4f){0, 0, 0, 0};
+  const float* dr[NJ]; float pm[NJ];
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) { const int64_t p = p0 + 16 * t + j; pm[t] = (p < npix) ? 1.0f : 0.0f; dr[t] = dc + min(p, npix - 1) * g.cout; }
+  int cia[MI]; bool cio[MI];
+#pragma unroll
+  for (int m = 0; m < MI; ++m) { const int ci = ci0 + 16 * m + j; cio[m] = ci < g.cin_g; cia[m] = min(ci, g.cin_g - 1); }
+  struct Op { int8_t w[MI][8]; float sc[8]; v4f b[NJ][2]; };
+  auto ld = [&](int kb) __attribute__((always_inline)) {
+    Op o; const int cok = min(kb + 8 * gq, g.cout - 8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      o.sc[q] = wscale ? wscale[cok + q] : sw0;
+#pragma unroll
+      for (int m = 0; m < MI; ++m) o.w[m][q] = qw[(int64_t)(cok + q) * g.cin_g + cia[m]];
+    }
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) { o.b[t][0] = *(const v4f*)(dr[t] + cok); o.b[t][1] = *(const v4f*)(dr[t] + cok + 4); }
+    return o;
+  };
+  auto step = [&](const Op& o, int kb) __attribute__((always_inline)) {
+    const bool kok = (kb + 8 * gq) < g.cout;                     // cout % 8 == 0: this lane's eight output channels of the step are inside, or none
+    v4i a[MI];
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t e0 = __float_as_uint((float)o.w[m][2 * i]) >> 16, e1 = __float_as_uint((float)o.w[m][2 * i + 1]) & 0xffff0000u;          // an int8 is exact in bf16
+        a[m][i] = (kok && cio[m]) ? (int)(e0 | e1) : 0;
+      }
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = o.b[t][q >> 2][q & 3] * o.sc[q] * pm[t];
+      v4i hi, mid, lo;
+      g32_split3(v, hi, mid, lo);
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        d[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, a[m]), __builtin_bit_cast(g32_v8bf, hi), d[m][t], 0, 0, 0);
+        d[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, a[m]), __builtin_bit_cast(g32_v8bf, mid), d[m][t], 0, 0, 0);
+        d[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, a[m]), __builtin_bit_cast(g32_v8bf, lo), d[m][t], 0, 0, 0);
+      }
+    }
+  };
+  Op o0 = ld(0);          // two operand sets in turn, no register copy between them
+  for (int kb = 0; kb < g.cout; kb += 64) {
+    const Op o1 = ld(min(kb + 32, g.cout - 8));
+    step(o0, kb);
+    o0 = ld(min(kb + 64, g.cout - 8));
+    step(o1, kb + 32);          // past cout every lane is masked off
+  }
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    const int ci = ci0 + 16 * m + 4 * gq;
+    if (ci >= g.xc) continue;
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) {
+      const int64_t p = p0 + 16 * t + j;
+      if (p >= npix) continue;
+      float* dst = gx + p * g.xc + ci;
+      v4f o = d[m][t];
+      if (accumulate) { const v4f old = *(const v4f*)dst; o = old + o; }
+      *(v4f*)dst = o;
+    }
+  }
+}
+
 // ---- depthwise data gradient (fp32 sums of <= 25 terms; the weight scale is applied once, after the sum)
 template <int K, int S>
 __global__ __launch_bounds__(256) void k_g32_dw_dgrad(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
@@ -893,6 +993,14 @@ extern "C" int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* q
   hipStream_t s = as_stream(stream);
   const int64_t npi = (int64_t)n * h * w;
   if (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npi < (1ll << 31)) {
+    static const int b3 = getenv("FROST_G32_B3") ? atoi(getenv("FROST_G32_B3")) : 1;          // data gradient on the bf16 MFMA with three-way split fp32 operands (0: v_mfma_f32_16x16x4_f32)
+    if (kind == 0 && b3 && (cout % 8) == 0 && cout >= 8) {
+      const unsigned bx = (unsigned)((npi + 255) / 256);
+      if (xc <= 16) hipLaunchKernelGGL((k_g32_pw_dgrad_b3<1>), dim3(bx, (unsigned)((xc + 15) / 16)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      else if (xc <= 32) hipLaunchKernelGGL((k_g32_pw_dgrad_b3<2>), dim3(bx, (unsigned)((xc + 31) / 32)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      else hipLaunchKernelGGL((k_g32_pw_dgrad_b3<4>), dim3(bx, (unsigned)((xc + 63) / 64)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
+      return frost_check_launch("g32_dgrad");
+    }
     if (kind == 0) {
       const unsigned bx = (unsigned)((npi + 255) / 256);
       if (xc <= 16) hipLaunchKernelGGL((k_g32_pw_dgrad<1>), dim3(bx, (unsigned)((xc + 15) / 16)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
