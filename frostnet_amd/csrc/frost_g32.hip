@@ -403,6 +403,20 @@ __global__ __launch_bounds__(256) void k_g32_dc4(const int32_t* __restrict__ acc
   }
 }
 
+typedef __bf16 g32_v8bf __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void g32_split3(const float (&v)[8], v4i& hi, v4i& mid, v4i& lo) {
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t xb = __float_as_uint(v[i]); h[i] = xb & 0xffff0000u;
+    const float r1 = v[i] - __uint_as_float(h[i]); m[i] = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m[i]); l[i] = __float_as_uint(r2) & 0xffff0000u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {          // two bf16 per dword: element 2i in the low half
+    hi[i] = (int)((h[2 * i] >> 16) | h[2 * i + 1]); mid[i] = (int)((m[2 * i] >> 16) | m[2 * i + 1]); lo[i] = (int)((l[2 * i] >> 16) | l[2 * i + 1]);
+  }
+}
 // ---- pointwise data gradient on v_mfma_f32_16x16x4_f32: D[ci][pixel] = sum_co wf[co][ci] * dc[pixel][co], wf = q_w * s_w (exact in fp32).  The four k slots of
 // MFMA q of a 16-channel step hold co = kb + 4 g + q, so that a lane's dc operands of the four MFMAs are ONE 16-byte load of its pixel's row.
 template <int MI>
@@ -483,20 +497,6 @@ __global__ __launch_bounds__(256) void k_g32_pw_dgrad(const float* __restrict__ 
 // dc * s_w as B operand (three pieces -> three MFMAs), the weight indices as A operand (an int8 is exact in bf16), products exact in fp32, accumulation in fp32 as before --
 // the arithmetic of k_g32_pw_dgrad at 3 v_mfma_f32_16x16x32_bf16 per 32 output channels instead of 8 v_mfma_f32_16x16x4_f32 (2.7 x fewer cycles of the matrix pipe).
 // A lane's B operand of a step is 8 consecutive channels of its pixel's dc row (two 16-byte loads).  cout % 8 == 0.
-typedef __bf16 g32_v8bf __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void g32_split3(const float (&v)[8], v4i& hi, v4i& mid, v4i& lo) {
-  uint32_t h[8], m[8], l[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t xb = __float_as_uint(v[i]); h[i] = xb & 0xffff0000u;
-    const float r1 = v[i] - __uint_as_float(h[i]); m[i] = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m[i]); l[i] = __float_as_uint(r2) & 0xffff0000u;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {          // two bf16 per dword: element 2i in the low half
-    hi[i] = (int)((h[2 * i] >> 16) | h[2 * i + 1]); mid[i] = (int)((m[2 * i] >> 16) | m[2 * i + 1]); lo[i] = (int)((l[2 * i] >> 16) | l[2 * i + 1]);
-  }
-}
 template <int MI>
 __global__ __launch_bounds__(256, 2) void k_g32_pw_dgrad_b3(const float* __restrict__ dc, const int8_t* __restrict__ qw, const float* qrec_w, const float* wscale, G32Geo g,
                                                             float* __restrict__ gx, int accumulate) {
@@ -730,6 +730,74 @@ __global__ __launch_bounds__(256) void k_g32_pw_wgrad_part(const float* __restri
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int co = co0 + NA * (4 * gq + i) + ra, col = ci0 + NB * j + rb;
+        if (co < g.cout && col < ncp) prt[(int64_t)co * ncp + col] = d[ra][rb][i];
+      }
+}
+// ---- the same weight gradient on the bf16 MFMA: dc split three ways (hi + mid + lo exact) as A operand, the input indices q - zp (integers of magnitude <= 255: exact in
+// bf16) as B operand, K = 32 pixels per MFMA triple; a lane gathers its eight pixels of a channel column row by row (the 16 lanes of a group read 64 consecutive bytes of a dc
+// row, 16 consecutive bytes of an x row).  Tile = 16 NA output channels x 16 NB columns, D[co][col]; partial tiles as in k_g32_pw_wgrad_part.
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 2) void k_g32_pw_wgrad_part_b3(const float* __restrict__ dc, const int8_t* __restrict__ x, const float* qx, G32Geo g, int ncol, int ncp,
+                                                                 int chunk_px, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, gq = lane >> 4;
+  const int64_t npix = (int64_t)g.n * g.ho * g.wo;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wv;
+  const int64_t lo = chunk * chunk_px, hi = min(lo + chunk_px, npix);
+  if (lo >= npix) return;
+  const int co0 = (int)blockIdx.y * (16 * NA), ci0 = (int)blockIdx.z * (16 * NB);
+  const int zp = __float_as_int(qx[FROST_Q_ZP]);
+  v4f d[NA][NB];
+#pragma unroll
+  for (int ra = 0; ra < NA; ++ra)
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) d[ra][rb] = (v4f){0, 0, 0, 0};
+  const float* ap[NA]; bool aok[NA]; const int8_t* bp[NB]; bool bok[NB];
+#pragma unroll
+  for (int ra = 0; ra < NA; ++ra) { const int co = co0 + 16 * ra + j; aok[ra] = co < g.cout; ap[ra] = dc + min(co, g.cout - 1); }
+#pragma unroll
+  for (int rb = 0; rb < NB; ++rb) { const int ci = ci0 + 16 * rb + j; bok[rb] = ci < ncol; bp[rb] = x + min(ci, ncol - 1); }
+  for (int64_t pb = lo; pb < hi; pb += 32) {
+    int64_t pq[8]; float pmk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int64_t p = pb + 8 * gq + q; pmk[q] = (p < hi) ? 1.0f : 0.0f; pq[q] = min(p, hi - 1); }
+    v4i ah[NA], am[NA], al[NA], bb[NB];
+#pragma unroll
+    for (int ra = 0; ra < NA; ++ra) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = ap[ra][pq[q] * g.cout];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = aok[ra] ? v[q] * pmk[q] : 0.0f;
+      g32_split3(v, ah[ra], am[ra], al[ra]);
+    }
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+      int xb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xb[q] = (int)bp[rb][pq[q] * g.xc];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float f0 = bok[rb] ? (float)(xb[2 * i] + 128 - zp) : 0.0f, f1 = bok[rb] ? (float)(xb[2 * i + 1] + 128 - zp) : 0.0f;          // |q - zp| <= 255: exact in bf16
+        bb[rb][i] = (int)((__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u));
+      }
+    }
+#pragma unroll
+    for (int ra = 0; ra < NA; ++ra)
+#pragma unroll
+      for (int rb = 0; rb < NB; ++rb) {
+        d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, ah[ra]), __builtin_bit_cast(g32_v8bf, bb[rb]), d[ra][rb], 0, 0, 0);
+        d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, am[ra]), __builtin_bit_cast(g32_v8bf, bb[rb]), d[ra][rb], 0, 0, 0);
+        d[ra][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g32_v8bf, al[ra]), __builtin_bit_cast(g32_v8bf, bb[rb]), d[ra][rb], 0, 0, 0);
+      }
+  }
+  float* prt = part + chunk * (int64_t)g.cout * ncp;
+#pragma unroll
+  for (int ra = 0; ra < NA; ++ra)
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 16 * ra + 4 * gq + i, col = ci0 + 16 * rb + j;
         if (co < g.cout && col < ncp) prt[(int64_t)co * ncp + col] = d[ra][rb][i];
       }
 }
@@ -993,8 +1061,8 @@ extern "C" int frost_g32_dgrad(const float* dc, const int8_t* qw, const float* q
   hipStream_t s = as_stream(stream);
   const int64_t npi = (int64_t)n * h * w;
   if (g32_fast() && (cout % 4) == 0 && (xc % 4) == 0 && npi < (1ll << 31)) {
-    static const int b3 = getenv("FROST_G32_B3") ? atoi(getenv("FROST_G32_B3")) : 1;          // data gradient on the bf16 MFMA with three-way split fp32 operands (0: v_mfma_f32_16x16x4_f32)
-    if (kind == 0 && b3 && (cout % 8) == 0 && cout >= 8) {
+    static const int b3 = getenv("FROST_G32_B3") ? atoi(getenv("FROST_G32_B3")) : 3;          // bit 0: data gradient on the bf16 MFMA with three-way split fp32 operands (0: v_mfma_f32_16x16x4_f32)
+    if (kind == 0 && (b3 & 1) && (cout % 8) == 0 && cout >= 8) {
       const unsigned bx = (unsigned)((npi + 255) / 256);
       if (xc <= 16) hipLaunchKernelGGL((k_g32_pw_dgrad_b3<1>), dim3(bx, (unsigned)((xc + 15) / 16)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
       else if (xc <= 32) hipLaunchKernelGGL((k_g32_pw_dgrad_b3<2>), dim3(bx, (unsigned)((xc + 31) / 32)), dim3(256), 0, s, dc, qw, qrec_w, wscale, g, gx, accumulate);
@@ -1062,7 +1130,9 @@ extern "C" int frost_g32_wgrad(const float* dc, const int8_t* x, const float* qr
       const int64_t nchunk = (npo + chunk_px - 1) / chunk_px;
       const int na = cout <= 16 ? 1 : (cout <= 32 ? 2 : 4), nb = ncol <= 16 ? 1 : (ncol <= 32 ? 2 : 4);
       const dim3 grid((unsigned)((nchunk + 3) / 4), (unsigned)((cout + 16 * na - 1) / (16 * na)), (unsigned)((ncol + 16 * nb - 1) / (16 * nb)));
-#define G32_WG(A_, B_) hipLaunchKernelGGL((k_g32_pw_wgrad_part<A_, B_>), grid, dim3(256), 0, s, dc, x, qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch)
+      static const int b3 = getenv("FROST_G32_B3") ? atoi(getenv("FROST_G32_B3")) : 3;          // bit 1: weight gradient on the bf16 MFMA with three-way split dc (0: v_mfma_f32_16x16x4_f32)
+#define G32_WG(A_, B_) do { if (b3 & 2) hipLaunchKernelGGL((k_g32_pw_wgrad_part_b3<A_, B_>), grid, dim3(256), 0, s, dc, x, qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch); \
+                           else hipLaunchKernelGGL((k_g32_pw_wgrad_part<A_, B_>), grid, dim3(256), 0, s, dc, x, qrec_x, g, ncol, ncp, (int)chunk_px, (float*)scratch); } while (0)
       if (na == 1) { if (nb == 1) G32_WG(1, 1); else if (nb == 2) G32_WG(1, 2); else G32_WG(1, 4); }
       else if (na == 2) { if (nb == 1) G32_WG(2, 1); else if (nb == 2) G32_WG(2, 2); else G32_WG(2, 4); }
       else { if (nb == 1) G32_WG(4, 1); else if (nb == 2) G32_WG(4, 2); else G32_WG(4, 4); }
