@@ -6,7 +6,7 @@
 // dc = K1 (gy - S1/n - xhat S2/n), the same fake-quantised weights / inputs in the data / weight gradient -- with every gradient held in fp32 and every
 // long sum accumulated in fp64.  Round 4 wrote it as plain one-thread-per-output kernels (a parity instrument, 30 x slower than the production step); since round 5
 // the same entries run tiled / coalesced kernels (section "fast forms" below: the pointwise conv output on the int8 MFMA, pointwise data / weight gradients on
-// v_mfma_f32_16x16x4_f32 with fp32 operands, per-channel sums as deterministic two-stage reductions with fp64 partials, every element-wise pass with a fixed
+// v_mfma_f32_16x16x4_f32 with fp32 operands, or on the bf16 MFMA with the fp32 operand split three ways (default), per-channel sums as deterministic two-stage reductions with fp64 partials, every element-wise pass with a fixed
 // channel quad per thread) so that a user can TRAIN at the reference's gradient precision; the plain kernels stay as the fallback for channel counts that are not
 // a multiple of 4.  It shows that the formulas meet the reference's fp32 autograd at <= 1e-3, and what the bf16 storage costs (tests/test_gpu_round4.py).
 // Entry points mirror the production passes: frost_g32_conv_acc (integer conv output) -> frost_g32_reduce -> frost_g32_dc -> frost_g32_dgrad / frost_g32_wgrad,
