@@ -390,11 +390,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
     }
   };
   struct ChRow { float A, B; int ws; };
+  // the row of the NEXT chunk is requested with the other prefetches and must stay un-touched until it is consumed: zeroing the lanes past the last channel right here
+  // (`ok ? rA : 0`) is a use of the loaded value, i.e. an s_waitcnt vmcnt(0) in front of the depthwise phase that drains the whole prefetch (y1 rows, taps, weight
+  // fragments) every iteration -- seen in the ISA; the select now happens where the row is taken over, one iteration later (row_take)
   auto load_row = [&](int chunk) __attribute__((always_inline)) {
-    ChRow r; const int c2 = chunk * 64 + lane; const bool ok = c2 < p.c;
-    const int cc = ok ? c2 : 0;
-    const float rA = p.coef2[FROST_COEF_A * p.cpad + cc], rB = p.coef2[FROST_COEF_B * p.cpad + cc]; const int rW = p.wsum2[cc];
-    r.A = ok ? rA : 0.0f; r.B = ok ? rB : 0.0f; r.ws = ok ? rW : 0;
+    ChRow r; const int c2 = chunk * 64 + lane; const int cc = (c2 < p.c) ? c2 : 0;
+    r.A = p.coef2[FROST_COEF_A * p.cpad + cc]; r.B = p.coef2[FROST_COEF_B * p.cpad + cc]; r.ws = p.wsum2[cc];
+    return r;
+  };
+  auto row_take = [&](const ChRow& raw, int chunk) __attribute__((always_inline)) {
+    ChRow r; const bool ok = (chunk * 64 + lane) < p.c;
+    r.A = ok ? raw.A : 0.0f; r.B = ok ? raw.B : 0.0f; r.ws = ok ? raw.ws : 0;
     return r;
   };
   uint2 yv[YU]; uint32_t tv[NTAPW]; ChRow row_n;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
     for (int i = 0; i < YU; ++i) if (upx[i] >= 0) *(uint2*)(pl + uoff[i]) = yv[i];
 #pragma unroll
     for (int i = 0; i < NTAPW; ++i) { const int t = (tid + i * NT) >> 4; if (t < K * K) *(uint32_t*)(tapb + t * 64 + tap_c) = tv[i]; }
-    const ChRow row = row_n;
+    const ChRow row = row_take(row_n, chunk);
     v4i afr[NCTW];
 #pragma unroll
     for (int m = 0; m < NCTW; ++m) {       // reduce_conv weight fragments of this K step (one chunk = 64 input channels), consumed after the depthwise phase
@@ -594,11 +600,15 @@ __global__ __launch_bounds__(512, 2) void k_blk_dw_reduce2(const BlkBP p) {
     }
   };
   struct ChRow { float A, B; int ws; };
-  auto load_row = [&](int itc) __attribute__((always_inline)) {          // this wave's chunk slot, lane = channel
+  auto load_row = [&](int itc) __attribute__((always_inline)) {          // this wave's chunk slot, lane = channel; raw values: the zeroing waits until the row is taken over
     ChRow r; const int chunk = 2 * itc + slot_w; const int c2 = chunk * 64 + lane; const bool ok = chunk < p.nchunk && c2 < p.c;
     const int cc = ok ? c2 : 0;
-    const float rA = p.coef2[FROST_COEF_A * p.cpad + cc], rB = p.coef2[FROST_COEF_B * p.cpad + cc]; const int rW = p.wsum2[cc];
-    r.A = ok ? rA : 0.0f; r.B = ok ? rB : 0.0f; r.ws = ok ? rW : 0;
+    r.A = p.coef2[FROST_COEF_A * p.cpad + cc]; r.B = p.coef2[FROST_COEF_B * p.cpad + cc]; r.ws = p.wsum2[cc];
+    return r;
+  };
+  auto row_take = [&](const ChRow& raw, int itc) __attribute__((always_inline)) {
+    ChRow r; const int chunk = 2 * itc + slot_w; const bool ok = chunk < p.nchunk && (chunk * 64 + lane) < p.c;
+    r.A = ok ? raw.A : 0.0f; r.B = ok ? raw.B : 0.0f; r.ws = ok ? raw.ws : 0;
     return r;
   };
   uint2 yv[YU]; uint32_t tv[NTAPW]; ChRow row_n;
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void k_blk_dw_reduce2(const BlkBP p) {
       const int v = tid + i * NT, sl = (v >= TCH) ? 1 : 0, t = (v - sl * TCH) >> 4;
       if (v < 2 * TCH) *(uint32_t*)(tapb + (sl * KK + t) * 64 + tap_c) = tv[i];
     }
-    const ChRow row = row_n;
+    const ChRow row = row_take(row_n, itc);
     if (it + 1 < nit) {
       const int it2 = it + 1; const int img2 = img_lo + it2 / nit_img, itc2 = it2 - (it2 / nit_img) * nit_img;
       load_y1(img2, itc2, yv); load_taps(itc2, tv); row_n = load_row(itc2);
