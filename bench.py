@@ -66,7 +66,44 @@ def cpu_baseline(res=224, batch=64, timed=3):
                        f"FrostNet-Large QAT fwd+bwd+GradBoost-SGD, torch {torch.__version__} CPU kernels via oracle/frost_oracle.py")
 
 
-PMC_TAGS = ("r05", "r04", "r03", "r02")
+PMC_TAGS = ("r06", "r05", "r04", "r03", "r02")
+
+
+def extra_leg(extra_args, extra_env=None, timeout=420):
+    """One more single-GPU measurement of THIS script in a child process (its own device context: a failure or a stalled RCCL bring-up there costs this
+    run a field, not its headline).  Returns the child's JSON line as a dict, or {"error": ...}."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-roofline", "--no-extras"] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, stdin=subprocess.DEVNULL)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return dict(error=f"exit code {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}")
+        return json.loads(lines[-1])
+    except Exception as e:  # pragma: no cover
+        return dict(error=f"{type(e).__name__}: {e}")
+
+
+def tape_algorithmic_bytes(tape, image_elems):
+    """Algorithmic HBM bytes of one fwd + bwd pass from the engine's tape of a training forward, by SURVEY 8(d)'s layer-granular rule: every conv reads its input
+    and writes its output once at 1 B / element (forward), its backward reads dY (2 B, bf16) and the saved input (1 B) and writes dX (2 B) unless the input
+    is the image.  `image_elems`: elements of the network input (the stem's input in the tape is its im2col view).  FrostNet-Large @224: 45 593 016 B / image."""
+    total = 0
+    for e in tape:
+        if e[0] == "conv":
+            _, l, x, y = e
+            xin = image_elems if l.kind == "stem" else x.numel
+            total += xin + y.numel + 2 * y.numel + xin + (0 if l.kind == "stem" else 2 * xin)
+        elif e[0] == "head":
+            _, l, x = e[:3]
+            xin, yout = x.n * l.cin_g, x.n * l.cout          # the classifier conv on the pooled vector
+            total += xin + yout + 2 * yout + xin + 2 * xin
+    return total
 
 
 def pmc_table(batch):
@@ -201,7 +238,16 @@ def side_workload(args, dev):
             ll, lc = crit((loc, conf, pri), tgts)
             (ll + lc).backward()
         step = None
-        bytes_per_img, metric, dtype = None, f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {res}x{res} QAT fwd+bwd", "int8"
+        # algorithmic bytes of the detector step by the headline's rule, counted from the engine's tape of one training forward: backbone
+        # (Large @512: 2 139 234 304 MAC) + extras + the twelve prediction heads, every conv 1 B / element forward, bf16 gradients backward
+        opt.zero_grad(set_to_none=True)
+        loc0, conf0, pri0 = model(x)
+        bytes_per_img = tape_algorithmic_bytes(model.hip_runner().E.tape, x.numel()) // batch
+        ll0, lc0 = crit((loc0, conf0, pri0), tgts)
+        (ll0 + lc0).backward()
+        opt.step()
+        del loc0, conf0, pri0, ll0, lc0
+        metric, dtype = f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {res}x{res} QAT fwd+bwd", "int8"
         what = (f"SSDLite on the FrostNet-{args.mode.capitalize()} backbone (frostnet_amd.ssdlite), int8 fake-quant QAT fwd+bwd + MultiBoxLoss + GradBoost-SGD step, "
                 f"batch={batch}, {res}x{res} (BASELINE.json config c5, per GPU)")
         args.res = res
@@ -299,8 +345,9 @@ def side_workload(args, dev):
                ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype=dtype,
                data="synthetic", config=dict(workload=what, per_gpu_batch=batch, resolution=args.res, hip_graph=graphed))
     if bytes_per_img:
-        out["roofline"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, whole_step=dict(
-            achieved=round(value * bytes_per_img / 1e9, 1), frac=round(value * bytes_per_img / 1e9 / HBM_PEAK_GBS, 4), algorithmic_bytes_per_image=bytes_per_img))
+        gbs = value * bytes_per_img / 1e9
+        out["roofline"] = dict(bound="hbm", kernel="whole step", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                               traffic=None, algorithmic_bytes_per_image=bytes_per_img, algorithmic_bytes_per_step=bytes_per_img * batch)
     print(json.dumps(out), flush=True)
 
 
@@ -401,6 +448,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N=1 headline run: skip the two extra legs (the fp32-gradient mode's step time; the data-parallel code path on a 1-rank RCCL group)")
     ap.add_argument("--buckets", type=int, default=4, help="N>1: gradient buckets = hipGraph segments of the backward pass")
     ap.add_argument("--single-allreduce", action="store_true",
                     help="N>1: one graph + ONE all-reduce after the backward instead of the bucketed, backward-overlapped default (A/B)")
@@ -543,6 +592,17 @@ def main():
     for _ in range(max(1, min(args.warmup, 3))):      # first steps build tables / state before any capture
         eager_step()
     torch.cuda.synchronize()
+    det_bytes = None
+    if detect:                                        # algorithmic bytes / image of the detector step, counted from the tape of one training forward (see side_workload)
+        opt.zero_grad(set_to_none=True)
+        l0 = loss_of(x, tgt)
+        det_bytes = tape_algorithmic_bytes(runner.E.tape, x.numel()) // args.batch
+        l0.backward(gradient=gscale)
+        if dp:
+            dist.all_reduce(runner.grad_arena)
+        opt.step()
+        del l0
+        torch.cuda.synchronize()
 
     allreduce_check = None
     if dp and args.check_allreduce:
@@ -742,13 +802,19 @@ def main():
         # The headline roofline figure is the WHOLE STEP: algorithmic bytes of one image (layer-granular) x images / s over the
         # 8 TB/s HBM peak; `traffic` = HBM bytes of one step summed over every kernel family of the committed counter passes.  The dominant kernel family
         # (the contract's per-kernel figure: algorithmic bytes per launch / average launch duration by HIP events on the launch stream) is `dominant_kernel`.
+        census = graph_census([graph]) if (graph is not None and seg is None and not isinstance(graph, list)) else None
+        # ONE launch count in the line: this library's kernel nodes of the captured step, read back from the hipGraph of THIS run; the count of the
+        # committed counter pass (an eager step under rocprofv3) only when no graph was captured
+        own = census.get("kernels_own") if isinstance(census, dict) else None
         roofline = dict(bound="hbm", kernel="whole step", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(step_gbs / HBM_PEAK_GBS, 4), traffic=step_traffic, traffic_source=step_src,
                         traffic_total_bytes_per_step=step_traffic, algorithmic_bytes_per_step=algo_step,
                         traffic_ratio=(round(step_traffic / algo_step, 3) if step_traffic else None),
-                        kernel_launches_per_step=step_launches, algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG,
+                        kernel_launches_per_step=(own if own else step_launches),
+                        kernel_launches_source=("hipGraph nodes of this run (graph_nodes.kernels_own)" if own else step_src),
+                        algorithmic_bytes_per_image=ALGO_BYTES_PER_IMG,
                         # the captured step itself, node by node (read back from the hipGraph): own kernels / aten kernels / memset / memcpy
-                        graph_nodes=(graph_census([graph]) if (graph is not None and seg is None and not isinstance(graph, list)) else None),
+                        graph_nodes=census,
                         dominant_kernel=dict(kernel=dom, achieved=round(achieved, 1), unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                                              traffic=traffic, traffic_source=traffic_src, avg_launch_ms=round(s2["avg_ms"], 4),
                                              launches_per_step=s2["launches"] // 3, algorithmic_bytes_per_launch=int(s2["bytes_per_launch"]),
@@ -766,6 +832,10 @@ def main():
                                           traffic_ratio=(round(pmc_traffic(k, args.batch)[0] / v["bytes_per_launch"], 2)
                                                          if pmc_traffic(k, args.batch)[0] and args.res == 224 and args.mode == "large" else None))
                                   for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])})
+    if rank == 0 and detect and det_bytes:
+        gbs = value / world * det_bytes / 1e9
+        roofline = dict(bound="hbm", kernel="whole step", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                        algorithmic_bytes_per_image=det_bytes, algorithmic_bytes_per_step=det_bytes * args.batch)
     if world > 1:
         dist.barrier()
 
@@ -776,6 +846,28 @@ def main():
                 cpu = cpu_baseline()
             except Exception as e:  # pragma: no cover
                 cpu = dict(value=None, error=str(e))
+        extras = {}
+        if world == 1 and not dp and not detect and not args.no_extras and graph is not None:
+            # (1) the mode that meets north_star's 1e-3 gradient statement (FROST_GRAD=fp32: fp32 activation gradients, fp64 long sums) gets a driver-timed number
+            # beside the bf16-gradient headline; (2) the N > 1 code path -- chain of hipGraph segments with the bucket's RCCL all-reduce between them -- on a 1-rank
+            # RCCL group: its cost over the single graph is the segmentation + collective-launch overhead every rank pays at N = 8
+            shape = ["--batch", str(args.batch), "--res", str(args.res), "--mode", args.mode]
+            g32 = extra_leg(shape + ["--steps", "5", "--warmup", "2"], {"FROST_GRAD": "fp32"})
+            extras["fp32_grad_ms_per_step"] = g32.get("ms_per_step")
+            if "error" in g32:
+                extras["fp32_grad_error"] = g32["error"]
+            dpl = extra_leg(shape + ["--steps", "10", "--warmup", "3", "--force-dp"])
+            if "error" in dpl:
+                extras["dp_overhead_ms"] = None
+                extras["dp_overhead_error"] = dpl["error"]
+            else:
+                gar = (dpl.get("config") or {}).get("grad_allreduce") or {}
+                extras["dp_overhead_ms"] = round(dpl["ms_per_step"] - ms, 3)
+                extras["dp_overhead"] = dict(what="bench.py --force-dp: 1-rank RCCL group, chain of hipGraph segments + one all-reduce per bucket, minus this run's single-graph step",
+                                             segmented_ms_per_step=dpl["ms_per_step"], single_graph_ms_per_step=round(ms, 3), mode=gar.get("mode"),
+                                             bucket_bytes=[b.get("bytes") for b in gar.get("buckets", [])],
+                                             bucket_allreduce_us_1rank=[b.get("allreduce_us") for b in gar.get("buckets", [])],
+                                             step_ms_without_collectives=gar.get("step_ms_without_collectives"))
         metric = (f"images/sec SSDLite-FrostNet-{args.mode.capitalize()} {args.res}x{args.res} QAT fwd+bwd" if detect
                   else "images/sec FrostNet-Large 224x224 QAT fwd+bwd")
         what = (f"SSDLite on the FrostNet-{args.mode.capitalize()} backbone (frostnet_amd.ssdlite), int8 fake-quant QAT fwd+bwd + MultiBoxLoss + GradBoost-SGD step, "
@@ -790,7 +882,7 @@ def main():
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
                                parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype=("fp32" if runner.E.grad_fp32 else "bf16"),
                                ms_per_step_median_hip_events=round(ms_median, 3),
-                               grad_allreduce=comm),
+                               grad_allreduce=comm, **extras),
                    roofline=roofline, cpu_baseline=cpu)
     if dp:
         dist.destroy_process_group()

@@ -87,8 +87,9 @@ __global__ __launch_bounds__(MB_T) void k_mbox_match(const float* __restrict__ p
 
 // ---- per-prior losses: lc = logsumexp(conf) - conf[target]; smooth-L1 of the positives
 __global__ __launch_bounds__(256) void k_mbox_loss(const float* __restrict__ loc, const float* __restrict__ conf, const float* __restrict__ loc_t, const int* __restrict__ conf_t,
-                                                   int P, int C, float* __restrict__ lc, float* __restrict__ sums) {
-  __shared__ float shf[32];
+                                                   int P, int C, float* __restrict__ lc, float* __restrict__ llp) {
+  // llp [n][P]: the smooth-L1 term of every prior (0 off the positives).  The sums over it are formed by k_mbox_mine in a FIXED order (per image: one workgroup's
+  // tree; across images: slot by slot in the last arrival) -- float atomics here made the two losses differ in the last bits from run to run
   const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
   float ll = 0.0f;
   if (p < P) {
@@ -106,15 +107,14 @@ __global__ __launch_bounds__(256) void k_mbox_loss(const float* __restrict__ loc
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float ad = fabsf(d[e]); ll += ad < 1.0f ? 0.5f * d[e] * d[e] : ad - 0.5f; }
     }
+    llp[i] = ll;
   }
-  ll = mb_block_sum(ll, shf);
-  if (threadIdx.x == 0 && ll != 0.0f) atomicAdd(sums, ll);
 }
 
 // ---- hard negative mining: one workgroup per image; the image's lc (positives as 0) sits in LDS, the num_neg-th largest value is found by a radix select on the
 // float bits (all values >= 0: bit order = value order); out[] is finished by the last image to arrive
 __global__ __launch_bounds__(MB_T) void k_mbox_mine(const float* __restrict__ lc, const int* __restrict__ conf_t, const int* __restrict__ num_pos, int N, int P, int negpos,
-                                                    uint8_t* __restrict__ sel, float* __restrict__ out) {
+                                                    uint8_t* __restrict__ sel, float* __restrict__ llp, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   unsigned* v = (unsigned*)smem;                                      // [P] bits of lc, positives 0
   unsigned* hist = v + P;                                            // [256]
@@ -145,9 +145,10 @@ __global__ __launch_bounds__(MB_T) void k_mbox_mine(const float* __restrict__ lc
     }
     thr = ctl[0]; need_eq = ctl[1];
   }
-  float lcs = 0.0f;
+  float lcs = 0.0f, lls = 0.0f;
   for (int p = tid; p < P; p += MB_T) {
     const bool pos = conf_t[base + p] > 0;
+    if (pos) lls += llp[base + p];
     bool s = pos;
     if (!pos && k > 0) {
       const unsigned x = v[p];
@@ -158,14 +159,22 @@ __global__ __launch_bounds__(MB_T) void k_mbox_mine(const float* __restrict__ lc
     if (s) lcs += lc[base + p];
   }
   lcs = mb_block_sum(lcs, shf);
+  lls = mb_block_sum(lls, shf);                                        // (its barriers also end every thread's reads of this image's llp row)
   if (tid == 0) {
-    atomicAdd(out + 4, lcs);
+    // the image's two sums into the first two words of its own llp row (agent-scope stores), then the arrival ticket; the LAST image adds the slots up in image
+    // order: the same bits every run
+    __hip_atomic_store(llp + base, lls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(llp + base + 1, lcs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();
     const unsigned t = atomicAdd((unsigned*)(out + 5), 1u);
     if (t == (unsigned)N - 1u) {                                     // last image: totals -> the two losses and 1 / N_pos for the backward; re-arm
-      float np = 0.0f;
-      for (int i = 0; i < N; ++i) np += (float)num_pos[i];
-      const float sl = __hip_atomic_load(out + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), sc = __hip_atomic_load(out + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      float np = 0.0f, sl = 0.0f, sc = 0.0f;
+      for (int i = 0; i < N; ++i) {
+        np += (float)num_pos[i];
+        sl += __hip_atomic_load(llp + (int64_t)i * P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sc += __hip_atomic_load(llp + (int64_t)i * P + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       out[0] = sl / np; out[1] = sc / np; out[2] = 1.0f / np;
       out[3] = 0.0f; out[4] = 0.0f; ((unsigned*)out)[5] = 0u;
     }
@@ -219,8 +228,10 @@ extern "C" int frost_mbox_forward(const float* loc, const float* conf, const flo
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute((const void*)k_mbox_mine, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
   hipLaunchKernelGGL(k_mbox_match, dim3(n), dim3(MB_T), lds_m, s, priors, boxes, valid, p, k, threshold, var0, var1, bto, bti, loc_t, conf_t, num_pos);
-  hipLaunchKernelGGL(k_mbox_loss, dim3((p + 255) / 256, n), dim3(256), 0, s, loc, conf, loc_t, conf_t, p, c, lc, out + 3);
-  hipLaunchKernelGGL(k_mbox_mine, dim3(n), dim3(MB_T), lds_s, s, lc, conf_t, num_pos, n, p, negpos, sel, out);
+  FROST_REQUIRE(p >= 2, "mbox_forward: at least two priors per image (the per-image sums take the first two words of the scratch row)");
+  // bto (best overlap per prior) is dead once the matching kernel has run: its rows carry the per-prior smooth-L1 terms, then the per-image sums
+  hipLaunchKernelGGL(k_mbox_loss, dim3((p + 255) / 256, n), dim3(256), 0, s, loc, conf, loc_t, conf_t, p, c, lc, bto);
+  hipLaunchKernelGGL(k_mbox_mine, dim3(n), dim3(MB_T), lds_s, s, lc, conf_t, num_pos, n, p, negpos, sel, bto, out);
   return frost_check_launch("mbox_forward");
 }
 extern "C" int frost_mbox_backward(const float* loc, const float* conf, const float* loc_t, const int32_t* conf_t, const uint8_t* sel, const float* out, const float* g_l,

@@ -594,6 +594,13 @@ class Engine:
         key = (qx.data_ptr(), bool(fb), qx._version, l.qy._version) + tuple(t._version for t in (l.gamma, l.beta, l.rmean, l.rvar, l.bias) if t is not None)
         if getattr(l, "_cfin_key", None) == key:
             return
+        if getattr(l, "_cfin_key", None) is not None and getattr(self, "_cfin_captured", False) and not getattr(self, "_cfin_warned", False):
+            # a hipGraph captured earlier replays the kernels with the OLD coefficient rows only until this launch rewrites them in place (same buffer), but a graph
+            # captured after an eager forward holds no finalize launch at all: say so once instead of leaving it to a comment
+            import warnings
+            warnings.warn("frostnet_amd: a FakeQuantize record / BatchNorm tensor of a converted model changed after a forward was captured into a hipGraph; "
+                          "the coefficient rows are recomputed now -- re-capture the graph if it was captured after an eager forward", RuntimeWarning)
+            self._cfin_warned = True
         if fb:
             call("frost_conv_finalize_converted_fb", ptr(qx), ptr(l.wscale), ptr(l.gamma), ptr(l.beta), ptr(l.rmean), ptr(l.rvar), l.cout, ptr(l.coef),
                  ptr(l.qy), stream())
@@ -602,6 +609,8 @@ class Engine:
                  ptr(l.qy), stream())
         if not torch.cuda.is_current_stream_capturing():
             l._cfin_key = key
+        else:
+            self._cfin_captured = True
 
     def add_converted(self, a, b, q):
         y = self.new_act(a.n, a.h, a.w, a.c, q)
@@ -652,7 +661,10 @@ class Engine:
         if _WG_STREAM and self.on_layer_grads is None and L.PROFILER is None and self.device.type == "cuda":
             if getattr(self, "_wg_stream", None) is None:
                 self._wg_stream = torch.cuda.Stream(device=self.device, priority=_WG_PRIO)
-                self._wg_more = [torch.cuda.Stream(device=self.device, priority=_WG_PRIO) for _ in range(max(0, _WG_NSTREAMS - 1))] if boundaries is None else []
+                self._wg_extra = [torch.cuda.Stream(device=self.device, priority=_WG_PRIO) for _ in range(max(0, _WG_NSTREAMS - 1))]
+            # several weight-gradient streams only in the single-GPU step: a bucketed backward joins ONE side stream per bucket (decided per backward, not
+            # once at the first one -- an eager single-GPU backward followed by a bucketed one must not keep round-robining)
+            self._wg_more = self._wg_extra if boundaries is None else []
             self._side = self._wg_stream
             self._side.wait_stream(torch.cuda.current_stream())          # after the dwq arena fill
             for st in self._wg_more:
@@ -798,21 +810,21 @@ class Engine:
         if kind != 1 and L.load_library().frost_g32_x_ok(kind, y.npix, x.c, cin_g, l.cout):
             # pointwise / stem: the reduce and dc passes recompute the integer conv output on the int8 MFMA -- no int32 tensor is written or re-read
             gx_ = (kind, x.n, x.h, x.w, x.c, cin_g, l.cout)
-            call("frost_g32_reduce_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
+            call("frost_g32_reduce_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s, prof=("g32_reduce", x.numel + 4 * y.numel))
             self._frozen_after_reduce(l)
-            call("frost_g32_dc_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
+            call("frost_g32_dc_x", ptr(x.buf), ptr(x.q), ptr(qw), *gx_, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s, prof=("g32_dc", x.numel + 8 * y.numel))
         else:
             acc = torch.empty(y.numel + 64, dtype=torch.int32, device=self.device)
-            call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s)
-            call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s)
+            call("frost_g32_conv_acc", ptr(x.buf), ptr(x.q), ptr(qw), *geo, ptr(acc), s, prof=("g32_conv_acc", x.numel + 4 * y.numel))
+            call("frost_g32_reduce", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(scr), s, prof=("g32_reduce", 8 * y.numel))
             self._frozen_after_reduce(l)
-            call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s)
+            call("frost_g32_dc", ptr(acc), y.npix, l.cout, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(y.grad), ptr(dc), s, prof=("g32_dc", 12 * y.numel))
         if getattr(self, "_dbg", False):
             self._last_dc = dc
         if x.needs_grad:
             gx, accf = self._grad_slot(x)
-            call("frost_g32_dgrad", ptr(dc), ptr(qw), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, *geo, ptr(gx), accf, s)
-        call("frost_g32_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), *geo, ptr(l.dwq), ptr(scr), s)
+            call("frost_g32_dgrad", ptr(dc), ptr(qw), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, *geo, ptr(gx), accf, s, prof=("g32_dgrad", 4 * y.numel + 4 * x.numel))
+        call("frost_g32_wgrad", ptr(dc), ptr(x.buf), ptr(x.q), *geo, ptr(l.dwq), ptr(scr), s, prof=("g32_wgrad", 4 * y.numel + x.numel))
         self._after_conv_backward(l, s)
         y.grad = None
 
@@ -848,7 +860,8 @@ class Engine:
         """Every layer of gradient bucket `index` has run its backward: join the weight-gradient stream, finalize, notify."""
         self._flush_deferred_wgrads()
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            for st in [self._wg_stream] + list(getattr(self, "_wg_more", [])):
+                torch.cuda.current_stream().wait_stream(st)
             self._keep = []
         self._finalize_pending(slot=index)
         if on_bucket is not None:
@@ -895,7 +908,8 @@ class Engine:
         if _WG_DEFER and getattr(self, "_deferred", None) and x.h > _WG_DEFER:
             self._flush_deferred_wgrads()
         if _WG_JOIN and self._side is not None and getattr(self, "_forks", 0) >= _WG_JOIN:
-            torch.cuda.current_stream().wait_stream(self._side)      # short side branches: the weight gradients forked so far must be done before this layer starts
+            for st in [self._wg_stream] + list(getattr(self, "_wg_more", [])):      # short side branches: the weight gradients forked so far (on every side stream) must be done before this layer starts
+                torch.cuda.current_stream().wait_stream(st)
             self._forks = 0
         fused = l.kind in ("pw", "stem") and _PW_FUSE and bool(L.load_library().frost_pw_bwd_fused_ok(x.npix, x.c, l.cout)) and (l.kind == "stem" or x.h * x.w >= _PW_FUSE_MINMAP)
         blk_dw = (l.kind == "dw" and _BLOCK_DWBWD and (x.h <= 7 or _BLOCK_DWBWD >= 2) and (x.grad is None or not x.needs_grad)

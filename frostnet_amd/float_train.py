@@ -294,6 +294,7 @@ class FloatRunner:
             else:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, ptr(cbuf), l.cout, stream())
             call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
+            L.note_raw_write()          # running_mean / running_var change through raw pointers: the bf16-inference weight cache must not trust torch's version counters
             if lazy:
                 y = FAct(cbuf, a.n, ho, wo, l.cout, src=(l.desc_ptr, int(l.relu)))
             else:
@@ -304,11 +305,13 @@ class FloatRunner:
             if training:
                 call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), STATS, None, None, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
+                L.note_raw_write()
             call(self._fn["frost_float_dw"], l.desc_ptr, ptr(a.buf), a.n, a.h, a.w, a.c, l.k, l.stride, int(l.relu), EMIT, None, dst, stream())
         else:
             if training:
                 call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), STATS, None, 0, None, 0, stream())
                 call("frost_float_bn_finalize", l.desc_ptr, l.cout, npix_o, stream())
+                L.note_raw_write()
             call(self._fn["frost_float_pw"], l.desc_ptr, ptr(a.buf), ptr(l.pack), npix_o, a.c, l.cout, int(l.relu), EMIT, None, 0, dst, ld, stream())
         if record:
             l.x = a

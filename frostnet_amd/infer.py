@@ -221,6 +221,8 @@ class Bf16Inference:
         bucket = 1 << max(0, int(n) - 1).bit_length()
         key = ("choice", bucket, h, w, _FUSED)
         choice = ent.get(key)
+        if choice is not None:
+            ent[key] = ent.pop(key)                   # re-inserted on a hit: the eviction below drops the LEAST RECENTLY USED entry, not the oldest insertion
         if choice is None:
             l2, l3, sq = ent["conv2"], ent["reduce"], ent["squeeze"]
             r = sq.cout if sq is not None else 0
@@ -244,7 +246,7 @@ class Bf16Inference:
                     try:
                         run()
                     except RuntimeError as e:         # only the library's own "this tile / wave count does not fit" refusals mean "not a candidate"
-                        if not any(m in str(e) for m in ("too many output tiles per wave", "unsupported geometry / tile", "chunk = 64, or 32")):
+                        if not any(m in str(e) for m in ("too many output tiles per wave", "unsupported geometry / tile", "chunk = 64, or 32", "16 waves take 64-channel chunks only")):
                             raise                     # a genuine launch failure must not be read as "candidate not applicable"
                         continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

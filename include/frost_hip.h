@@ -624,7 +624,8 @@ int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uin
 
 /* ---- SSD MultiBoxLoss (Object_Detection/layers/modules/multibox_loss.py:48-117 + layers/box_utils.py:71-139) ------------------------------------------------
  * frost_mbox_forward: loc [n][p][4], conf [n][p][c], priors [p][4] (cx, cy, w, h), boxes [n][k][5] (x1, y1, x2, y2, label) with valid [n][k] (padding rows 0).
- * Work buffers of the caller: bto [n][p] float, bti [n][p] int32, loc_t [n][p][4], conf_t [n][p] int32, lc [n][p], sel [n][p] bytes, num_pos [n] int32.
+ * Work buffers of the caller: bto [n][p] float (best overlaps during the matching, afterwards scratch: per-prior smooth-L1 terms, then the image's two sums in its
+ * first two words -- the losses are summed in a fixed order, bit-reproducible run to run), bti [n][p] int32, loc_t [n][p][4], conf_t [n][p] int32, lc [n][p], sel [n][p] bytes, num_pos [n] int32.
  * out: frost_mbox_workspace_floats() floats, ZEROED before the first call: {loss_l, loss_c, 1 / N_pos, three running words that every call leaves zeroed, ...}.
  * frost_mbox_backward: dloc [n][p][4], dconf [n][p][c] from the saved loc_t / conf_t / sel / out and the device scalars g_l, g_c (gradients of the two losses). */
 int frost_mbox_workspace_floats(void);

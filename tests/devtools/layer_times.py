@@ -19,7 +19,7 @@ x = torch.randn(B, 3, 224, 224, device="cuda")
 t = torch.randint(0, 1000, (B,), device="cuda")
 
 ctx = [""]
-for fn in ("conv", "conv_pair", "_conv_backward"):
+for fn in ("conv", "conv_pair", "_conv_backward", "_conv_backward_g32"):
     orig = getattr(E.Engine, fn)
     def wrap(self, l, *a, _o=orig, **k):
         ctx[0] = l.name
