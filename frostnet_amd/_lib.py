@@ -90,6 +90,7 @@ _PROTOS = {
     "frost_fake_quant_bwd_f32": [P, P, L, P, P],
     "frost_dequant_act": [P, L, P, P, P],
     "frost_weight_prep": [P, I, I, I, I, P],
+    "frost_step_prologue": [P, I, P, I, P, P, P, P, I, I, P],
     "frost_export_wq": [P, I, L, P, P],
     "frost_mbox_workspace_floats": [],
     "frost_mbox_forward": [P, P, P, P, P, I, I, I, I, F, I, F, F, P, P, P, P, P, P, P, P, P],
@@ -129,6 +130,8 @@ _PROTOS = {
     "frost_block_dw_bwd_supported": [I, I, I, I, I],
     "frost_block_dw_bwd_reduce": [P, P, P, P, I, I, I, I, I, P, P, I, P, P],
     "frost_block_dw_bwd": [P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P, P],
+    "frost_block_dw_bwd_c1": [P, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
+    "frost_block_dw_bwd_c1_ok": [I, I, I, I, I, I],
     "frost_block_dw_reduce": [P, P, P, P, P, P, I, P, I, I, I, I, I, P, P, I, P, P, P, P],
     "frost_pw_dgrad_wide_ok": [L, I, I],
     "frost_pw_dgrad_wide": [P, P, P, L, I, I, P, I, P],

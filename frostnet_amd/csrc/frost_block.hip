@@ -818,6 +818,10 @@ struct BlkCP {
   float* coef; const float* qy;                     // coefficient rows (the reduce pass accumulates S1 / S2 into them; the dc pass reads them), output record
   const uint16_t* gout; uint16_t* dx; float* dwq;   // gradient w.r.t. conv2's output (bf16), w.r.t. its input (bf16, or NULL), raw weight-gradient sums [c][k*k]
   int n, c, cpad, nchunk, imgs, rounds, relu, sr; float inv_count; int xmap;
+  // conv1 fold (k_blk_dw_bwd<.., KS1 > 0>): the backward REDUCE pass of the pointwise layer that produced x (conv1 of the bottleneck) rides on the dx values of this
+  // kernel -- c1_x = conv1's input (the block-internal cat, [n*map][c1_cin] offset-binary bytes) and its record, conv1's MFMA weight pack / weight sums, and its coefficient
+  // rows (A, B, M, R read; S1 / S2 accumulated with float atomics).  conv1's output record is this layer's input record (qx).
+  const int8_t* c1_x; const float* c1_qx; const int8_t* c1_w; const int32_t* c1_wsum; float* c1_coef; int c1_cin, c1_kstr, c1_relu;
 };
 
 template <int K, int HW, int NW>
@@ -827,6 +831,11 @@ struct BlkGeoC : BlkGeo<K, HW, NW> {
   static constexpr int GT = (G::MAP + 8) * 64 * 2;                        // gout tile bf16 [pixel][64] (+ slack: the last row's 4-pixel reads run past it)
   static constexpr int RED = NW * K * K * 64 * 4;                         // weight-gradient partials of the waves (reuses the planes after the loop)
   __host__ __device__ static constexpr int lds() { return (G::PLANE + DPL + GT > RED ? G::PLANE + DPL + GT : RED) + 64; }
+  // conv1 fold: the fp32 dx values of the image's chunk [pixel][64] live over the x plane + the gout tile (both dead once the dc phase is done; layout x plane | gout tile |
+  // dc plane), behind the dc plane: conv1's input rows of the image [NPT*16][kstr] and the chunk's 64 x K weight fragments + per-channel rows (A, B, weight sum)
+  static constexpr int GB = G::MAP * 64 * 4;
+  static_assert(GB <= G::PLANE + GT, "conv1 fold: the fp32 dx tile must fit over the x plane and the gout tile");
+  __host__ __device__ static constexpr int lds_c1(int kstr, int ks1) { return lds() + G::NPT * 16 * kstr + ks1 * 4 * 1024 + 64 * 12; }
 };
 
 __device__ __forceinline__ void blk_tr16(const uint8_t* row, int col0, int lane, float* out4) {     // 4 consecutive pixels of channel `lane` of a bf16 [col][64 ch] row
@@ -849,15 +858,23 @@ __device__ __forceinline__ void blk_tr16_raw(const uint8_t* row, int col0, int l
   const v2i__ raw = __builtin_bit_cast(v2i__, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_ __attribute__((address_space(3)))*)(row + ((col0 + (jp >> 2)) * 64 + 16 * G + 4 * (jp & 3)) * 2)));
   out2[0] = (uint32_t)raw[0]; out2[1] = (uint32_t)raw[1];
 }
-template <int K, int HW, int NW>
+template <int K, int HW, int NW, int KS1 = 0>
 __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   using G = BlkGeoC<K, HW, NW>;
   constexpr int MAP = G::MAP, PAD = G::PAD, PITCH = G::PITCH, NT = G::NT;
+  constexpr bool C1 = KS1 > 0;
+  constexpr bool X1_EARLY = (HW == 7);       // conv1 fold: the image's conv1 input rows are prefetched one image ahead with the x / gout rows (7 x 7) or requested under the data gradient (14 x 14)
+  constexpr int NPTW = G::NPTW, NPT = G::NPT;
   constexpr int XU = (MAP * 8 + NT - 1) / NT, GU = (MAP * 8 + NT - 1) / NT;       // 8-byte units of x, 16-byte units of gout per thread (8 per pixel each)
+  constexpr int X1U = C1 ? (MAP * KS1 * 8 + NT - 1) / NT : 1;                      // conv1 fold: 8-byte units of the image's conv1 input rows per thread
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* const xpl = smem;                                    // [PHA][PITCH][64] int8
-  uint8_t* const dpl = smem + G::PLANE;                         // [PHA][PITCH][64] bf16
-  uint8_t* const gt = dpl + G::DPL;                             // [MAP][64] bf16
+  uint8_t* const gt = smem + G::PLANE;                          // [MAP][64] bf16            (x plane | gout tile: the fold's fp32 dx tile lies over both)
+  uint8_t* const dpl = gt + G::GT;                              // [PHA][PITCH][64] bf16
+  float* const gb = (float*)smem;                               // conv1 fold: [MAP][64] fp32 dx of the chunk BEFORE its bf16 rounding
+  uint8_t* const x1s = smem + G::lds();                         // conv1 fold: [NPT*16][kstr] conv1's input rows of the image
+  uint8_t* const w1s = x1s + (C1 ? NPT * 16 * p.c1_kstr : 0);   //             [4 channel tiles][KS1][64 lanes][16 B] conv1 weight fragments of the chunk
+  float* const tab1 = (float*)(w1s + KS1 * 4 * 1024);           //             A[64], B[64], weight sum[64] of the chunk's conv1 channels
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bi = blk_xcd_item((int)blockIdx.x, (int)gridDim.x, p.xmap);
   const int chunk = bi % p.nchunk, ig = bi / p.nchunk;
@@ -868,7 +885,30 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   {
     const uint32_t zf = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
     for (int i = tid; i < (G::PLANE >> 4); i += NT) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
-    for (int i = tid; i < ((G::DPL + G::GT) >> 4); i += NT) ((uint4*)dpl)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < ((G::DPL + G::GT) >> 4); i += NT) ((uint4*)gt)[i] = make_uint4(0, 0, 0, 0);
+  }
+  // conv1 fold: the chunk's weight fragments and per-channel rows (the same for every image of this workgroup), the rows of the input tile past the map zeroed
+  int zpx1 = 0; float y_inv1 = 1.0f, t_lo1 = 0.0f, t_hi1 = 0.0f;
+  float c1s1[4] = {0.f, 0.f, 0.f, 0.f}, c1s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (C1) {
+    const int CT1 = p.cpad >> 4;
+    for (int i = tid; i < KS1 * 4 * 64; i += NT) {
+      const int ln = i & 63, ks = (i >> 6) % KS1, wt = i / (64 * KS1);
+      const int ct = min(chunk * 4 + wt, CT1 - 1);            // (a partial last chunk repeats the last tile: its channels are masked out below)
+      ((uint4*)w1s)[(wt * KS1 + ks) * 64 + ln] = *(const uint4*)(p.c1_w + ((((int64_t)ct * KS1 + ks) * 64 + ln) << 4));
+    }
+    for (int i = tid; i < 64; i += NT) {
+      const int c2 = chunk * 64 + i; const bool ok = c2 < p.c; const int cc = ok ? c2 : 0;
+      const float rA = p.c1_coef[FROST_COEF_A * p.cpad + cc], rB = p.c1_coef[FROST_COEF_B * p.cpad + cc]; const int rW = p.c1_wsum[cc];
+      tab1[i] = ok ? rA : 0.0f; tab1[64 + i] = ok ? rB : 0.0f; ((int*)tab1)[128 + i] = ok ? rW : 0;
+    }
+    for (int i = tid; i < ((NPT * 16 * p.c1_kstr) >> 4); i += NT) ((uint4*)x1s)[i] = make_uint4(0, 0, 0, 0);
+    zpx1 = __float_as_int(p.c1_qx[FROST_Q_ZP]) - 128;
+    y_inv1 = 1.0f / p.qx[FROST_Q_SCALE];                       // conv1's output record IS this layer's input record
+    const int zpy1 = __float_as_int(p.qx[FROST_Q_ZP]), qhi1 = q_hi(p.qx);
+    const float hi0 = (float)qhi1 + 0.5f - (float)zpy1;
+    t_hi1 = ((qhi1 - zpy1) & 1) ? __int_as_float(__float_as_int(hi0) - 1) : hi0;
+    if (!p.c1_relu) { const float lo0 = -(float)zpy1 - 0.5f; t_lo1 = (zpy1 & 1) ? lo0 : __int_as_float(__float_as_int(lo0) + 1); }
   }
   // per-lane (= per-channel) constants
   int wpk[K][2]; float wf[K * K];         // (the taps as floats in LDS instead, to fit 3 waves per SIMD: 28 spilled registers, 20 % slower -- measured)
@@ -917,6 +957,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   }
   uint32_t rng = sr_seed(blockIdx.x, threadIdx.x);
   const bool sr_on = p.sr != 0;
+  const uint32_t zpfill = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
   float wacc[K * K]; float sdc = 0.0f;
 #pragma unroll
   for (int t = 0; t < K * K; ++t) wacc[t] = 0.0f;
@@ -931,7 +972,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   }
   const int part = tid & 7;
   const bool pok = (chunk * 64 + part * 8) < p.c;
-  uint2 xv[XU]; uint4 gv[GU];
+  uint2 xv[XU]; uint4 gv[GU]; uint2 x1v[X1U];
+  const int upr1 = C1 ? (p.c1_cin >> 3) : 1, tot1 = MAP * upr1;
   auto prefetch = [&](int img) __attribute__((always_inline)) {
     const int8_t* xs = p.x + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
     const uint16_t* gs = p.gout + (int64_t)img * MAP * p.c + chunk * 64 + part * 8;
@@ -941,14 +983,33 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
       xv[i] = ok ? *(const uint2*)(xs + (int64_t)upx[i] * p.c) : make_uint2(0, 0);
       gv[i] = ok ? *(const uint4*)(gs + (int64_t)upx[i] * p.c) : make_uint4(0, 0, 0, 0);
     }
+    if (C1 && X1_EARLY) {      // conv1's input rows of the image (MAP * c1_cin contiguous bytes) travel with the other prefetches
+      const int8_t* s1 = p.c1_x + (int64_t)img * MAP * p.c1_cin;
+#pragma unroll
+      for (int i = 0; i < X1U; ++i) { const int u = min(tid + i * NT, tot1 - 1); x1v[i] = *(const uint2*)(s1 + (int64_t)u * 8); }
+    }
   };
   if (img_lo < img_hi) prefetch(img_lo);
   __syncthreads();
 
   for (int img = img_lo; img < img_hi; ++img) {
+    if (C1 && X1_EARLY) {      // (conv1's input tile is read only by the GEMM phase at the end of an iteration: free here)
+#pragma unroll
+      for (int i = 0; i < X1U; ++i) { const int u = tid + i * NT; const int row = u / upr1, col = u - row * upr1; if (u < tot1) *(uint2*)(x1s + row * p.c1_kstr + col * 8) = x1v[i]; }
+    }
+    if (C1 && img > img_lo) {
+      // the fp32 dx tile of the previous image lay over the x plane: its zero-point halo comes back (cells outside the map; the interior is stored right below, the
+      // two sets of addresses are disjoint, so no barrier between them)
+      const uint32_t zf = (uint32_t)((zpx - 128) & 255) * 0x01010101u;
+      for (int i = tid; i < G::PHA * PITCH * 4; i += NT) {
+        const int cell = i >> 2, r = cell / PITCH, cc = cell - r * PITCH;
+        if (!(r >= PAD && r < PAD + HW && cc >= PAD && cc < PAD + HW)) ((uint4*)xpl)[i] = make_uint4(zf, zf, zf, zf);
+      }
+      for (int i = tid; i < ((G::GT - MAP * 128) >> 4); i += NT) ((uint4*)(gt + MAP * 128))[i] = make_uint4(0, 0, 0, 0);      // the slack rows behind the gout tile
+    }
 #pragma unroll
     for (int i = 0; i < XU; ++i) {
-      if (upx[i] >= 0) { if (pok) *(uint2*)(xpl + uoff[i] + part * 8) = xv[i]; *(uint4*)(gt + (upx[i] * 64 + part * 8) * 2) = gv[i]; }
+      if (upx[i] >= 0) { if (pok) *(uint2*)(xpl + uoff[i] + part * 8) = xv[i]; else if (C1) *(uint2*)(xpl + uoff[i] + part * 8) = make_uint2(zpfill, zpfill); *(uint4*)(gt + (upx[i] * 64 + part * 8) * 2) = gv[i]; }
     }
     if (img + 1 < img_hi) prefetch(img + 1);
     blk_barrier();
@@ -1011,6 +1072,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
       }
     }
     blk_barrier();
+    if (C1 && !X1_EARLY) {      // conv1's input rows of THIS image: requested here, they travel under the data gradient (unconditional loads from clamped
+                   // addresses: a branch around a load puts its wait right behind it) and go to LDS before the barrier in front of the GEMM phase.  (14 x 14 form: held
+                   // across the whole iteration like the other prefetches they spill; the price is that the wait below also drains this image's dx stores)
+      const int8_t* s1 = p.c1_x + (int64_t)img * MAP * p.c1_cin;
+#pragma unroll
+      for (int i = 0; i < X1U; ++i) { const int u = min(tid + i * NT, tot1 - 1); x1v[i] = *(const uint2*)(s1 + (int64_t)u * 8); }
+    }
     // ---- data gradient of input rows 2w, 2w + 1 from the dc plane: dx[iy][ix] = s_w * sum dc[iy + pad - ky][ix + pad - kx] * wq[ky][kx]  (k_dw3_dgrad's order)
     if (p.dx && w < G::NRG) {
 #pragma unroll 1
@@ -1045,10 +1113,83 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
         for (int o = 0; o < 2; ++o)
 #pragma unroll
           for (int r = 0; r < ((HW == 7) ? 7 : 8); ++r)
-            if ((2 * w + o) < HW && (seg * 8 + r) < HW && chok) dst[(int64_t)((2 * w + o) * HW + seg * 8 + r) * p.c] = (uint16_t)cvt_pk_bf16(acc[o][r] * sw, 0.0f);
+            if ((2 * w + o) < HW && (seg * 8 + r) < HW) {
+              const float dxv = acc[o][r] * sw;
+              if (chok) dst[(int64_t)((2 * w + o) * HW + seg * 8 + r) * p.c] = (uint16_t)cvt_pk_bf16(dxv, 0.0f);
+              // (the x plane / gout tile are dead: every wave passed the barrier above.  Column XOR-swizzled by the pixel's position in its 16-pixel tile: the GEMM phase
+              // reads float4s of one channel quad for 16 consecutive pixels -- 16 rows of 64 floats would all sit on the same four banks)
+              if (C1) { const int px = (2 * w + o) * HW + seg * 8 + r; gb[px * 64 + (lane ^ ((px & 15) << 2))] = chok ? dxv : 0.0f; }
+            }
       }
     }
+    if (C1 && !X1_EARLY) {
+#pragma unroll
+      for (int i = 0; i < X1U; ++i) { const int u = tid + i * NT; const int row = u / upr1, col = u - row * upr1; if (u < tot1) *(uint2*)(x1s + row * p.c1_kstr + col * 8) = x1v[i]; }
+    }
     blk_barrier();
+    if (C1) {
+      // ---- conv1's reduce pass on this (image, chunk): recompute conv1's integer output of the chunk's 64 channels on the matrix cores (k_blk_expand_dw's GEMM: channel
+      // tile = wave & 3, the pixel tiles split over the wave halves), STE window of conv1's output FakeQuantize, S1 += g, S2 += g * acc with g = the fp32 dx value
+      // (frost_pw.hip M_BRED's expressions; xhat = acc * R - M * R is applied once, at the end)
+      const int ph = (NW == 8) ? (w >> 2) : 0, wct = w & 3;
+      const int j = lane & 15, g4 = lane >> 4;
+      const int ti = wct * 16 + 4 * g4;
+      const float4 A4 = *(const float4*)(tab1 + ti), B4 = *(const float4*)(tab1 + 64 + ti);
+      const int4 ws = *(const int4*)((const int*)tab1 + 128 + ti);
+      const float Ar[4] = {A4.x, A4.y, A4.z, A4.w}, Br[4] = {B4.x, B4.y, B4.z, B4.w};
+      constexpr int TG = (NPTW > 4) ? 4 : NPTW;               // pixel tiles in flight (the 14 x 14 form has 7 per wave: two rounds keep the accumulators at 16 registers)
+#pragma unroll
+      for (int t0 = 0; t0 < NPTW; t0 += TG) {
+        v4i acc1[TG];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc1[t] = (v4i){-zpx1 * ws.x, -zpx1 * ws.y, -zpx1 * ws.z, -zpx1 * ws.w};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const v4i afr = *(const v4i*)(w1s + (((wct * KS1 + ks) * 64 + lane) << 4));
+#pragma unroll
+          for (int t = 0; t < TG; ++t) {
+            if (t0 + t < NPTW) {
+              const int prow = min((ph * NPTW + t0 + t) * 16 + j, NPT * 16 - 1);
+              const v4i bfr = *(const v4i*)(x1s + prow * p.c1_kstr + ks * 64 + g4 * 16);
+              acc1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afr, bfr, acc1[t], 0, 0, 0);          // D[chan][pix]
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const int pix = (ph * NPTW + t0 + t) * 16 + j;
+          if (t0 + t < NPTW && pix < MAP) {
+            const float4 gq = *(const float4*)(gb + pix * 64 + (ti ^ ((pix & 15) << 2)));
+            const float gr[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = (float)acc1[t][r];
+              const float tq = fmaf(Ar[r], v, Br[r]) * y_inv1;
+              const float gg = (tq > t_lo1 && tq <= t_hi1) ? gr[r] : 0.0f;
+              c1s1[r] += gg; c1s2[r] = fmaf(gg, v, c1s2[r]);
+            }
+          }
+        }
+      }
+      blk_barrier();          // the dx tile is free: the next image's x plane / gout tile may be stored over it
+    }
+  }
+  if (C1) {
+    // conv1's S1 / S2 of the chunk: the 16 pixel lanes of every channel quad fold with DPP-free shuffles, then one pair of float atomics per channel and wave
+    // (4 or 8 waves per workgroup: k_pw's reduce pass issues one pair per channel and workgroup, this kernel runs ~22 workgroups per chunk)
+    const int wct = w & 3, g4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = c1s1[r], b = c1s2[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      const int c2 = chunk * 64 + wct * 16 + 4 * g4 + r;
+      if ((lane & 15) == 0 && c2 < p.c) {
+        const float Rv = p.c1_coef[FROST_COEF_R * p.cpad + c2], Mv = p.c1_coef[FROST_COEF_M * p.cpad + c2];
+        atomicAdd(p.c1_coef + FROST_COEF_S1 * p.cpad + c2, a);
+        atomicAdd(p.c1_coef + FROST_COEF_S2 * p.cpad + c2, fmaf(b, Rv, -Mv * Rv * a));
+      }
+    }
   }
   // ---- dW[c][tap] += s_x * (sum dc*q - zp * sum dc): the waves' partials through LDS, one atomic per (channel, tap) and workgroup
   __syncthreads();
@@ -1067,15 +1208,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
   }
 }
 
-template <int K, int HW, int NW>
+template <int K, int HW, int NW, int KS1 = 0>
 static int launch_blk_c(BlkCP& p, hipStream_t s) {
   using G = BlkGeoC<K, HW, NW>;
-  const size_t lds = (size_t)G::lds();
+  if (KS1 > 0) p.c1_kstr = KS1 * 64 + 16;          // conv1's input rows in LDS: 16 bytes of padding (the K tail of a row reads on into the next: zero weights there)
+  const size_t lds = (KS1 > 0) ? (size_t)G::lds_c1(p.c1_kstr, KS1) : (size_t)G::lds();
   FROST_REQUIRE(lds <= 160 * 1024, "block_dw_bwd: LDS budget exceeded");
   static bool attr_set = false; static int occ = 0;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_blk_dw_bwd<K, HW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_dw_bwd<K, HW, NW>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
+    hipFuncSetAttribute((const void*)k_blk_dw_bwd<K, HW, NW, KS1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_blk_dw_bwd<K, HW, NW, KS1>, NW * 64, lds) != hipSuccess || occ < 1) occ = 1;
   }
   if (p.imgs <= 0) {
     // one round of RESIDENT workgroups (queried, not guessed): a launch of 1.5 rounds costs two -- image groups = floor(slots / chunks), images per group to match
@@ -1084,7 +1226,7 @@ static int launch_blk_c(BlkCP& p, hipStream_t s) {
     p.imgs = (p.n + groups - 1) / groups;
   }
   p.xmap = blk_xcd_on();
-  hipLaunchKernelGGL((k_blk_dw_bwd<K, HW, NW>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL((k_blk_dw_bwd<K, HW, NW, KS1>), dim3((unsigned)(((p.n + p.imgs - 1) / p.imgs) * p.nchunk)), dim3(NW * 64), lds, s, p);
   return frost_check_launch("block_dw_bwd");
 }
 
@@ -1092,12 +1234,43 @@ extern "C" int frost_block_dw_bwd_supported(int h, int w, int k, int stride, int
   return (h == w && (h == 7 || h == 14) && (k == 3 || k == 5) && stride == 1 && (c % 8) == 0) ? 1 : 0;
 }
 
+// conv1 fold: 1 if frost_block_dw_bwd_c1 has an instance for a depthwise layer (h x w, c channels, kernel k, stride 1) behind a pointwise conv1 of c1_cin input channels
+extern "C" int frost_block_dw_bwd_c1_ok(int h, int w, int k, int stride, int c, int c1_cin) {
+  // bit 0: 7 x 7 maps, bit 1: 14 x 14 maps.  Default 2: inside the captured step (B = 512, interleaved, profiles/r06_conv1_fold_ab.txt) the fold is -0.04 ms at 14 x 14 and +0.14 ms
+  // at 7 x 7 -- the image-resident kernel is the loaded resource there (23 chunk iterations per image), the reduce pass it replaces a cheaper kernel for the same sums
+  static const int on = getenv("FROST_BLK_C1") ? atoi(getenv("FROST_BLK_C1")) : 2;
+  const int ks1 = (c1_cin + 63) / 64;
+  return (frost_block_dw_bwd_supported(h, w, k, stride, c) && ((on >> (h == 7 ? 0 : 1)) & 1) && (c1_cin % 8) == 0 && ks1 >= 1 && ks1 <= (h == 7 ? 5 : (k == 5 ? 2 : 3))) ? 1 : 0;      // (the 14 x 14 k = 5 form with three K steps spills)
+}
+static int blk_dw_bwd_impl(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                           int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                           float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef, int c1_cin, int c1_relu,
+                           void* stream);
 extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
                                   int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
                                   float* dwq, void* stream) {
+  return blk_dw_bwd_impl(x, qrec_x, wq_pack, wsum, qrec_w, wscale, n, h, w, c, k, coef, qrec_y, relu, gout, dx, dwq, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+// The same launch carrying the backward REDUCE pass of the pointwise layer that produced x (conv1 of the bottleneck, frost_pw_conv_bwd pass 0 on (c1_x -> x)): conv1's integer
+// output of every (image, 64-channel chunk) is recomputed on the matrix cores from conv1's input rows and its S1 / S2 accumulate into c1_coef from the dx values of this kernel
+// BEFORE their bf16 rounding -- conv1's backward then starts at its dc pass (one launch and one read of the expanded gradient tensor less per bottleneck; conv1's dgamma / dbeta
+// no longer carry the rounding of dx).  The training half of SURVEY 8(f) N1 for the conv2 -> conv1 boundary of the 14 x 14 / 7 x 7 stages.
+extern "C" int frost_block_dw_bwd_c1(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                                     int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                                     float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef, int c1_cin,
+                                     int c1_relu, void* stream) {
+  FROST_REQUIRE(c1_x && c1_qrec_x && c1_wq_pack && c1_wsum && c1_coef && dx, "block_dw_bwd_c1: incomplete conv1 arguments (the data gradient is required)");
+  FROST_REQUIRE(frost_block_dw_bwd_c1_ok(h, w, k, 1, c, c1_cin), "block_dw_bwd_c1: the conv1 fold has no instance for this shape");
+  return blk_dw_bwd_impl(x, qrec_x, wq_pack, wsum, qrec_w, wscale, n, h, w, c, k, coef, qrec_y, relu, gout, dx, dwq, c1_x, c1_qrec_x, c1_wq_pack, c1_wsum, c1_coef, c1_cin, c1_relu, stream);
+}
+static int blk_dw_bwd_impl(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                           int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                           float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef, int c1_cin, int c1_relu,
+                           void* stream) {
   FROST_REQUIRE(frost_block_dw_bwd_supported(h, w, k, 1, c), "block_dw_bwd: unsupported shape (7x7 / 14x14 maps, k in {3,5}, stride 1)");
   FROST_REQUIRE(x && wq_pack && wsum && coef && qrec_y && gout && dwq, "block_dw_bwd: incomplete arguments");
   BlkCP p = {};
+  p.c1_x = c1_x; p.c1_qx = c1_qrec_x; p.c1_w = c1_wq_pack; p.c1_wsum = c1_wsum; p.c1_coef = c1_coef; p.c1_cin = c1_cin; p.c1_relu = c1_relu;
   p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.qw = qrec_w; p.wscale = wscale; p.coef = (float*)coef /* read-only in this pass */; p.qy = qrec_y; p.gout = gout; p.dx = dx; p.dwq = dwq;
   p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu; p.sr = frost_sr_enabled();
   p.inv_count = 1.0f / (float)((int64_t)n * h * w);
@@ -1110,6 +1283,16 @@ extern "C" int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const in
   if (imgs > n) imgs = n;
   p.imgs = imgs; p.rounds = rounds_env;
   hipStream_t s = as_stream(stream);
+  if (c1_x) {
+    const int ks1 = (c1_cin + 63) / 64;
+#define BLK_C1(KK, HH, NWW, KS) if (k == KK && h == HH && ks1 == KS) return launch_blk_c<KK, HH, NWW, KS>(p, s);
+    BLK_C1(5, 7, 4, 1) BLK_C1(5, 7, 4, 2) BLK_C1(5, 7, 4, 3) BLK_C1(5, 7, 4, 4) BLK_C1(5, 7, 4, 5)
+    BLK_C1(3, 7, 4, 1) BLK_C1(3, 7, 4, 2) BLK_C1(3, 7, 4, 3) BLK_C1(3, 7, 4, 4) BLK_C1(3, 7, 4, 5)
+    BLK_C1(5, 14, 8, 1) BLK_C1(5, 14, 8, 2)
+    BLK_C1(3, 14, 8, 1) BLK_C1(3, 14, 8, 2) BLK_C1(3, 14, 8, 3)
+#undef BLK_C1
+    FROST_REQUIRE(false, "block_dw_bwd_c1: no instance");
+  }
   if (h == 7) return (k == 3) ? launch_blk_c<3, 7, 4>(p, s) : launch_blk_c<5, 7, 4>(p, s);
   return (k == 3) ? launch_blk_c<3, 14, 8>(p, s) : launch_blk_c<5, 14, 8>(p, s);
 }
@@ -1390,7 +1573,7 @@ extern "C" int frost_block_dw_bwd_reduce(const int8_t* x, const float* qrec_x, c
   p.x = x; p.qx = qrec_x; p.wq = wq_pack; p.wsum = wsum; p.coef = coef; p.qy = qrec_y; p.gout = gout;
   p.n = n; p.c = c; p.cpad = round_up(c, 16); p.nchunk = (c + 63) / 64; p.relu = relu;
   static const int wgs_env = getenv("FROST_BLK_WGS_R") ? atoi(getenv("FROST_BLK_WGS_R")) : 0;
-  static const int rounds_env = getenv("FROST_BLK_ROUNDS_R") ? atoi(getenv("FROST_BLK_ROUNDS_R")) : 0;
+  static const int rounds_env = getenv("FROST_BLK_ROUNDS_R") ? atoi(getenv("FROST_BLK_ROUNDS_R")) : 2;      // two rounds of resident workgroups: -0.04 ms in the step (round 6 re-sweep, profiles/r06_sweep.txt; 3: the same)
   int imgs = wgs_env > 0 ? (int)(((int64_t)n * p.nchunk + wgs_env - 1) / wgs_env) : 0;       // 0: sized from the kernel's residency at launch
   if (imgs > n) imgs = n;
   p.imgs = imgs; p.rounds = rounds_env;

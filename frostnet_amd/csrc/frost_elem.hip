@@ -349,6 +349,160 @@ extern "C" int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_e
   return frost_check_launch("weight_prep");
 }
 
+// ------------------------------------------------------------------------------------------------ step prologue in three launches (round 6)
+// frost_save_sigma + frost_weight_prep (5 launches) + frost_stats_init_table = 7 launches of `nlayers` x 8 ... 256 workgroups each, most of which exit at once, every one as
+// long as its largest layer: 0.28 ms at the head of every captured step (FROST_ABL_SKIP pricing, profiles/r06_pricing.txt) whether or not it ran on a second stream.  Here the
+// same arithmetic -- w_scaled(), observer_update_dev(), wq_at(): bit-identical packs -- over a FLAT workgroup map built by the host (a layer gets workgroups in proportion to
+// its weights: wgmap[b] = {layer, slot, slots of the layer, -}):
+//   A  range of the BN-scaled weights (look-before-atomic commit) + sigma_r snapshot + reset of the layer's integer statistics rows
+//   B  one workgroup per layer: weight observer / qparams, per-channel scales (k_wprep_observe + k_wprep_scales)
+//   C  packs (int8 MFMA fragments, transposed bf16, depthwise taps, classifier rows) + per-channel weight sums
+__global__ __launch_bounds__(256) void k_wprep_a(const FrostWDesc* descs, const int4* __restrict__ wgmap, float* const* sigma_outs, uint8_t* stats_base,
+                                                 const int32_t* cpads, const int64_t* offs, int observe) {
+  const int4 wm = wgmap[blockIdx.x];
+  const int l = wm.x, slot = wm.y, nsl = wm.z;
+  const FrostWDesc d = descs[l];
+  {   // integer statistics rows of the layer: identity values
+    const int cp = cpads[l];
+    int64_t* s1 = (int64_t*)(stats_base + offs[l]); uint64_t* s2 = (uint64_t*)(s1 + cp);
+    int32_t* mn = (int32_t*)(s2 + cp); int32_t* mx = mn + cp;
+    for (int c = slot * 256 + threadIdx.x; c < cp; c += nsl * 256) { s1[c] = 0; s2[c] = 0; mn[c] = INT32_MAX; mx[c] = INT32_MIN; }
+  }
+  if (d.rvar) {   // sigma_r = sqrt(running_var + eps) BEFORE this step's forward updates running_var
+    float* o = sigma_outs[l];
+    for (int c = slot * 256 + threadIdx.x; c < d.cout; c += nsl * 256) o[c] = sqrtf(d.rvar[c] + FROST_BN_EPS);
+  }
+  if (!observe) return;
+  const int per = d.cin_g * d.kk; const int64_t tot = (int64_t)d.cout * per;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = (int64_t)slot * 256 + threadIdx.x; i < tot; i += (int64_t)nsl * 256) {
+    const int co = (int)(i / per);
+    const float v = w_scaled(d, co, (int)(i - (int64_t)co * per));
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  block_minmax_commit(lo, hi, d.minmax2);
+}
+__global__ __launch_bounds__(256) void k_wprep_b(const FrostWDesc* descs, int rule127, int observe) {
+  const FrostWDesc d = descs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    observer_update_dev(d.qrec, d.minmax2[0], d.minmax2[1], 1, rule127, observe);
+    d.minmax2[0] = INFINITY; d.minmax2[1] = -INFINITY;
+  }
+  __syncthreads();          // (one workgroup: the record written by thread 0 is visible to it after the barrier)
+  if (!d.reserved1) {
+    const float s = d.qrec[FROST_Q_SCALE];
+    for (int c = tid; c < d.cpad; c += 256) d.wscale[c] = s;
+    return;
+  }
+  const bool obs = observe && (__float_as_int(d.qrec[FROST_Q_OBS_EN]) != 0);
+  const int per = d.cin_g * d.kk;
+  __shared__ float smax[4];
+  float best = 0.0f;
+  for (int co = wv; co < d.cpad; co += 4) {
+    float sc = 1.0f;
+    if (co < d.cout) {
+      if (obs) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int r = lane; r < per; r += 64) { const float v = w_scaled(d, co, r); lo = fminf(lo, v); hi = fmaxf(hi, v); }
+        lo = wave_min(lo); hi = wave_max(hi);
+        float mn = d.wmin[co], mx = d.wmax[co];
+        if (isinf(mn) && isinf(mx) && mn > 0.0f && mx < 0.0f) { mn = lo; mx = hi; }
+        else { mn = mn + FROST_OBS_C * (lo - mn); mx = mx + FROST_OBS_C * (hi - mx); }
+        if (lane == 0) { d.wmin[co] = mn; d.wmax[co] = mx; }
+        const float mn_neg = fminf(mn, 0.0f), mx_pos = fmaxf(mx, 0.0f);
+        sc = rule127 ? fmaxf(-mn_neg / 128.0f, mx_pos / 127.0f) : fmaxf(-mn_neg, mx_pos) / 127.5f;
+        sc = fmaxf(sc, FROST_F32_EPS);
+      } else sc = d.wscale[co];
+      best = fmaxf(best, sc);
+    }
+    if (lane == 0) d.wscale[co] = sc;
+  }
+  if (lane == 0) smax[wv] = best;
+  __syncthreads();
+  if (tid == 0) { const float m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3])); d.qrec[FROST_Q_SCALE] = m; d.qrec[FROST_Q_INV] = 1.0f / m; }
+}
+__global__ __launch_bounds__(256) void k_wprep_c(const FrostWDesc* descs, const int4* __restrict__ wgmap) {
+  const int4 wm = wgmap[blockIdx.x];
+  const int slot = wm.y, nsl = wm.z;
+  const FrostWDesc d = descs[wm.x];
+  const float inv = 1.0f / d.qrec[FROST_Q_SCALE];
+  const int64_t i0 = (int64_t)slot * 256 + threadIdx.x, istep = (int64_t)nsl * 256;
+  if (d.kind == 0) {            // pointwise: [ct][ks][lane][16B]; also bf16 transposed pack [cit][kb][lane][8]   (k_wprep_pack's index arithmetic)
+    const int CT = d.cpad / 16, KS = d.kpad / 64;
+    const int64_t ndw = (int64_t)CT * KS * 64 * 4;
+    for (int64_t i = i0; i < ndw; i += istep) {
+      const int dwi = (int)(i & 3), lane = (int)((i >> 2) & 63); const int64_t t = i >> 8; const int ks = (int)(t % KS), ct = (int)(t / KS);
+      const int co = ct * 16 + (lane & 15), k0 = ks * 64 + (lane >> 4) * 16 + dwi * 4;
+      uint32_t packed = 0;
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e; int v = 0;
+        if (co < d.cout && k < d.cin_g) v = wq_at(d, inv, co, k);
+        packed |= ((uint32_t)(v & 255)) << (8 * e);
+      }
+      ((uint32_t*)d.wq_pack)[i] = packed;
+    }
+    if (d.wt_pack) {
+      const int cinp = round_up(d.cin_g, 16); const int CIT = cinp / 16, KB = d.cpad / 32 + ((d.cpad % 32) ? 1 : 0);
+      const int64_t nel = (int64_t)CIT * KB * 64 * 8;
+      for (int64_t i = i0; i < nel; i += istep) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63); const int64_t t = i >> 9; const int kb = (int)(t % KB), cit = (int)(t / KB);
+        const int ci = cit * 16 + (lane & 15), g = lane >> 4;
+        const int co = kb * 32 + 8 * g + e;
+        float v = 0.0f;
+        if (co < d.cout && ci < d.cin_g) v = (float)wq_at(d, inv, co, ci) * (d.reserved1 ? d.wscale[co] * inv : 1.0f);
+        d.wt_pack[i] = f2bf(v);
+      }
+    }
+  } else if (d.kind == 1) {     // depthwise: [tap][cpad]
+    const int64_t nb = (int64_t)d.kk * d.cpad;
+    for (int64_t i = i0; i < nb; i += istep) {
+      const int c = (int)(i % d.cpad), tap = (int)(i / d.cpad);
+      d.wq_pack[i] = (int8_t)((c < d.cout) ? wq_at(d, inv, c, tap) : 0);
+    }
+  } else if (d.kind == 2) {     // stem as im2col + pointwise: K index k = tap*4 + c
+    const int CT = d.cpad / 16, KS = d.kpad / 64;
+    const int64_t ndw = (int64_t)CT * KS * 64 * 4;
+    for (int64_t i = i0; i < ndw; i += istep) {
+      const int dwi = (int)(i & 3), lane = (int)((i >> 2) & 63); const int64_t t = i >> 8; const int ks = (int)(t % KS), ct = (int)(t / KS);
+      const int co = ct * 16 + (lane & 15), k0 = ks * 64 + (lane >> 4) * 16 + dwi * 4;
+      uint32_t packed = 0;
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e; const int tap = k >> 2, c = k & 3; int v = 0;
+        if (co < d.cout && tap < d.kk && c < d.cin_g) v = wq_at(d, inv, co, c * d.kk + tap);
+        packed |= ((uint32_t)(v & 255)) << (8 * e);
+      }
+      ((uint32_t*)d.wq_pack)[i] = packed;
+    }
+  } else {                      // classifier: plain [cout][cin]
+    const int64_t nb = (int64_t)d.cout * d.cin_g;
+    for (int64_t i = i0; i < nb; i += istep) {
+      const int co = (int)(i / d.cin_g);
+      d.wq_pack[i] = (int8_t)wq_at(d, inv, co, (int)(i - (int64_t)co * d.cin_g));
+    }
+  }
+  if (d.wsum) {                 // per-channel sums of the quantised weights: one wave per output channel (k_wprep_wsum)
+    const int per = d.cin_g * d.kk;
+    for (int co = slot * 4 + (threadIdx.x >> 6); co < d.cpad; co += nsl * 4) {
+      int sm = 0;
+      if (co < d.cout) for (int r = threadIdx.x & 63; r < per; r += 64) sm += wq_at(d, inv, co, r);
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+      if ((threadIdx.x & 63) == 0) d.wsum[co] = sm;
+    }
+  }
+}
+// descs / sigma_outs / cpads / offs: the tables of frost_save_sigma / frost_weight_prep / frost_stats_init_table for `nlayers` layers; wgmap: `nwg` entries
+// {layer index into those tables, slot, slots of that layer, unused}, every layer with >= 1 slot, slots of a layer 0 .. n-1 each exactly once.
+extern "C" int frost_step_prologue(const FrostWDesc* descs, int nlayers, const int32_t* wgmap, int nwg, float* const* sigma_outs, void* stats,
+                                   const int32_t* cpads, const int64_t* offs, int rule127, int observe, void* stream) {
+  FROST_REQUIRE(descs && wgmap && sigma_outs && stats && cpads && offs && nlayers >= 1 && nwg >= nlayers, "step_prologue: incomplete arguments");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(k_wprep_a, dim3(nwg), dim3(256), 0, s, descs, (const int4*)wgmap, sigma_outs, (uint8_t*)stats, cpads, offs, observe);
+  hipLaunchKernelGGL(k_wprep_b, dim3(nlayers), dim3(256), 0, s, descs, rule127, observe);
+  hipLaunchKernelGGL(k_wprep_c, dim3(nwg), dim3(256), 0, s, descs, (const int4*)wgmap);
+  return frost_check_launch("step_prologue");
+}
+
 // replaces: the `weight` entry of a converted module's state_dict (nnq.Conv2d._weight_bias(), Classification/evaluate.py:140-143 saves it): the int8 values the
 // packs of frost_weight_prep hold, in the module's own [cout][cin/g][kh][kw] order -- the same wq_at() the pack kernels call, so the exported tensor IS the
 // weight the device convolves with

@@ -24,6 +24,8 @@ def round_up(a, b):
 
 
 _DW_FUSE = os.environ.get("FROST_DW_FUSE", "1") != "0"     # dev switch for A/B runs
+_PROLOGUE3 = os.environ.get("FROST_PROLOGUE3", "1") != "0"  # per-step prologue (sigma snapshot, weight preparation, statistics reset) as three launches over a flat workgroup map (0 = the seven table launches; bit-identical)
+_PROLOGUE3_CAP = int(os.environ.get("FROST_PROLOGUE3_CAP", "128"))  # most workgroups one layer gets (32 / 64 / 128: 19.94 / 19.87 / 19.83 ms per step, interleaved)
 _DW_BWD_ONE = os.environ.get("FROST_DW_BWD_ONE", "1") != "0"   # depthwise k = 3 stride-1 backward of the tiled (high-resolution) layers: dc + weight gradient + data gradient in one sweep (csrc/frost_dwb.hip)
 _DW_ONE_OVER_BLK = os.environ.get("FROST_DWB_OVER_BLK", "0") != "0"
 _DW_C1 = os.environ.get("FROST_DWB_C1", "3") != "0"          # ... carrying the reduce pass of the pointwise layer in front of it (stride-2 layers with Cin = 16 / 24)
@@ -38,6 +40,7 @@ _BLOCK_PAIR = int(os.environ.get("FROST_BLOCK_PAIR", "3"))         # conv1 emit 
 _BLOCK_DWRED = os.environ.get("FROST_BLOCK_DWRED", "1") != "0"    # conv2 emit + reduce_conv GEMM / statistics in one launch (same stages)
 _BLOCK_DWBWD = int(os.environ.get("FROST_BLOCK_DWBWD", "2"))     # depthwise backward: dc + weight gradient + data gradient in one launch; 1 = 7x7 maps only, 2 = 14x14 too
 _BLOCK_DWBRED = os.environ.get("FROST_BLOCK_DWBRED", "1") != "0"  # and its reduce pass in the same image-resident scheme
+_BLOCK_C1 = os.environ.get("FROST_BLOCK_C1", "1") != "0"          # ... carrying the reduce pass of the bottleneck's conv1 (frost_block_dw_bwd_c1: conv1's output recomputed on the matrix cores per (image, chunk), S1 / S2 from the fp32 dx values)
 _PWC_RED_MAXPIX = int(os.environ.get("FROST_PWC_RED_MAXPIX", "131072"))   # largest pixel count whose reduce pass runs on the chunked kernel (the dc pass always does)
 # fused pointwise backward only on maps of at least this many pixels PER IMAGE (28 x 28 and up); below -- the squeeze convs of the 14 x 14 / 7 x 7 stages -- dc + data gradient,
 # weight gradient on the second stream (-0.08 ms at B = 512).  A per-image rule: the decision is about which STAGE a layer belongs to and must not flip with the batch size
@@ -228,6 +231,7 @@ class Engine:
         if self._table is not None:
             return
         n = len(self.layers)
+        self._wgmaps = {}
         arr = (L.FrostWDesc * n)()
         for i, l in enumerate(self.layers):
             arr[i] = l.desc()
@@ -245,16 +249,38 @@ class Engine:
         ptrs = (C.c_void_p * n)(*[l.sigma.data_ptr() for l in self.layers])
         self._sigma_ptrs = L.struct_to_tensor(ptrs, self.device)
 
-    def begin_step(self, observe=True):
+    def begin_step(self, observe=True, part=None):
         """Per-step prologue: BN-fold + weight fake-quant + packing for every layer (3 launches), sigma_r snapshot,
-        integer-stat reset.  Must run before the first conv of a forward pass (uses running_var BEFORE its update)."""
+        integer-stat reset.  Must run before the first conv of a forward pass (uses running_var BEFORE its update).
+        part = (lo, hi): only the layers [lo, hi) of the table (registration order = forward order) -- the runner prepares the few small layers of the
+        high-resolution stages first and the rest (where the parameters are) on a second stream under them; every layer must be covered before it runs."""
         self._ensure_tables()
         n = len(self.layers)
-        call("frost_save_sigma", ptr(self._table), ptr(self._sigma_ptrs), n, stream())
-        call("frost_weight_prep", ptr(self._table), n, self._max_elems, self.rule127, 1 if observe else 0, stream(),
-             prof=("weight_prep", sum(4 * l.w.numel() + l.wq_pack.numel() for l in self.layers)))
-        call("frost_stats_init_table", ptr(self._stats), ptr(self._cpads), ptr(self._offs), n, stream())
-        self.tape = []
+        lo, hi = (0, n) if part is None else (max(0, int(part[0])), min(n, int(part[1])))
+        if hi > lo and _PROLOGUE3:
+            # three launches over a flat workgroup map (a layer gets workgroups in proportion to its weights) instead of seven launches of nlayers x 8 ... 256 mostly idle ones
+            m = hi - lo
+            maps = self.__dict__.setdefault("_wgmaps", {})
+            if (lo, hi) not in maps:
+                rows = []
+                for i, l in enumerate(self.layers[lo:hi]):
+                    nsl = max(1, min(_PROLOGUE3_CAP, -(-l.w.numel() // 2048)))
+                    rows += [[i, sl, nsl, 0] for sl in range(nsl)]
+                maps[(lo, hi)] = torch.tensor(rows, dtype=torch.int32, device=self.device)
+            wg = maps[(lo, hi)]
+            call("frost_step_prologue", C.c_void_p(self._table.data_ptr() + lo * C.sizeof(L.FrostWDesc)), m, ptr(wg), wg.shape[0],
+                 C.c_void_p(self._sigma_ptrs.data_ptr() + 8 * lo), ptr(self._stats), C.c_void_p(self._cpads.data_ptr() + 4 * lo),
+                 C.c_void_p(self._offs.data_ptr() + 8 * lo), self.rule127, 1 if observe else 0, stream(),
+                 prof=("weight_prep", sum(4 * l.w.numel() + l.wq_pack.numel() for l in self.layers[lo:hi])))
+        elif hi > lo:
+            m = hi - lo
+            tab = C.c_void_p(self._table.data_ptr() + lo * C.sizeof(L.FrostWDesc))
+            call("frost_save_sigma", tab, C.c_void_p(self._sigma_ptrs.data_ptr() + 8 * lo), m, stream())
+            call("frost_weight_prep", tab, m, max(l.w.numel() for l in self.layers[lo:hi]), self.rule127, 1 if observe else 0, stream(),
+                 prof=("weight_prep", sum(4 * l.w.numel() + l.wq_pack.numel() for l in self.layers[lo:hi])))
+            call("frost_stats_init_table", ptr(self._stats), C.c_void_p(self._cpads.data_ptr() + 4 * lo), C.c_void_p(self._offs.data_ptr() + 8 * lo), m, stream())
+        if lo == 0:
+            self.tape = []
 
     # ------------------------------------------------------------------------------------------ helpers
     def new_act(self, n, h, w, c, q):
@@ -1031,6 +1057,20 @@ class Engine:
                      prof=("dw_bwd_reduce", x.numel + 2 * y.numel))
             self._frozen_after_reduce(l)
             gslot = self._grad_slot(x) if x.needs_grad else (None, 0)
+            c1b = nxt[1] if (blk and not gslot[1] and _BLOCK_C1 and x.needs_grad and nxt is not None and nxt[0] == "conv" and nxt[3] is x) else None
+            if (c1b is not None and c1b.kind == "pw" and c1b.k == 1 and not getattr(c1b, "frozen", False) and not c1b.per_channel and getattr(c1b, "hswish", None) is None
+                    and L.load_library().frost_block_dw_bwd_c1_ok(x.h, x.w, l.k, l.stride, x.c, nxt[2].c)):
+                # ... and the launch carries the reduce pass of the pointwise layer that produced x (conv1 of the bottleneck): conv1's integer output is recomputed per
+                # (image, chunk) on the matrix cores and its S1 / S2 accumulate from the fp32 dx values, so conv1's backward starts at its dc pass (x.bred_done)
+                x0 = nxt[2]
+                call("frost_block_dw_bwd_c1", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,
+                     l.k, ptr(l.coef), ptr(l.qy), int(l.relu), ptr(gout), ptr(gslot[0]), ptr(l.dwq),
+                     ptr(x0.buf), ptr(x0.q), ptr(c1b.wq_pack), ptr(c1b.wsum), ptr(c1b.coef), x0.c, int(c1b.relu), s,
+                     prof=("blk_dw_bwd", x.numel + 2 * y.numel + 2 * x.numel + x0.numel))
+                x.bred_done = True
+                self._after_conv_backward(l, s)
+                y.grad = None
+                return
             if blk and not gslot[1]:
                 # 14x14 / 7x7 maps: the image's dc lives in an LDS plane; weight gradient and data gradient come from it (csrc/frost_block.hip)
                 call("frost_block_dw_bwd", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), ptr(l.qw), ptr(l.wscale) if l.per_channel else None, x.n, x.h, x.w, x.c,

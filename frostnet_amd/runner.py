@@ -14,6 +14,7 @@ from . import _lib as L
 from .engine import ConvLayer, Engine, QArena
 
 
+_PREP_SPLIT = os.environ.get("FROST_PREP_SPLIT", "0") != "0"    # ... in two parts: the high-resolution stages' layers first, the rest joined in front of layer3 (A/B switch; measured +-0 inside the captured step, profiles/r06_prologue_ab.txt: off)
 _PREP_SIDE = os.environ.get("FROST_PREP_SIDE", "1") != "0"      # training: the per-step weight preparation on a second stream beside the QuantStub passes
 
 class _QATFunction(torch.autograd.Function):
@@ -570,26 +571,59 @@ class FrostRunner:
             if gp not in ("bf16", "fp32"):
                 raise ValueError("model.grad_precision must be 'bf16' or 'fp32'")
             E.grad_fp32 = gp == "fp32"
+        late_at = None
         if _PREP_SIDE and training and not E.grad_fp32:
             # the per-step weight preparation (BN fold + weight fake-quant + packing of all 70 layers: a handful of latency-bound launches, ~165 us) has nothing to do
             # with the image: it runs on a second stream beside the QuantStub's passes over the input (range, observer, quantise: ~115 us of bandwidth), joined before conv1
             if getattr(E, "_prep_stream", None) is None:
                 E._prep_stream = torch.cuda.Stream(device=E.device)
+            # ... and in TWO parts (round 6): the stem + layer1 + layer2 (a few thousand weights) first; the rest -- layer3 on, where the parameters are: the launch is as
+            # long as its largest layers -- stays on the second stream under the high-resolution forward and is joined in front of the first block that needs it.  In the
+            # captured step the whole preparation cost 0.28 ms (FROST_ABL_SKIP, profiles/r06_pricing.txt) although it ran beside the QuantStub.
             cur = torch.cuda.current_stream()
             E._prep_stream.wait_stream(cur)
+            split = self._prep_split() if _PREP_SPLIT else None
             with torch.cuda.stream(E._prep_stream):
-                E.begin_step(observe=obs)
+                E.begin_step(observe=obs, part=None if split is None else (0, split[0]))
+                if split is not None:
+                    early = torch.cuda.Event()
+                    early.record()
+                    E.begin_step(observe=obs, part=(split[0], len(E.layers)))
             a = E.quantize_input(x, self.q_in, observe=obs)
-            cur.wait_stream(E._prep_stream)
+            if split is None:
+                cur.wait_stream(E._prep_stream)
+            else:
+                cur.wait_event(early)
+                late_at = split[1]
         else:
             E.begin_step(observe=obs)
             a = E.quantize_input(x, self.q_in, observe=obs)
         a = self._conv(self.stem, a, training, obs)
         feats = []
-        for d in self.blocks:
+        for bi, d in enumerate(self.blocks):
+            if late_at is not None and bi == late_at:
+                torch.cuda.current_stream().wait_stream(E._prep_stream)
+                late_at = None
             a = self.block_forward(d, a, training, obs)
             feats.append(a)
+        if late_at is not None:
+            torch.cuda.current_stream().wait_stream(E._prep_stream)
         return a, feats
+
+    def _prep_split(self):
+        """(layer index, block index) at which the late part of the weight preparation starts: the first block of layer3 (None: no such block / too few layers)."""
+        got = getattr(self, "_prep_split_cache", None)
+        if got is None:
+            got = (None,)
+            for bi, d in enumerate(self.blocks):
+                first = d["squeeze"] or d["conv1"] or d["conv2"]
+                if first.name.startswith("layer3."):
+                    idx = self.E.layers.index(first)
+                    if 0 < idx < len(self.E.layers):
+                        got = ((idx, bi),)
+                    break
+            self._prep_split_cache = got
+        return got[0]
 
     def forward_features(self, x):
         self._check_input(x)

@@ -115,6 +115,11 @@ typedef struct FrostWDesc {
                           scale per output channel, qrec.scale = the largest of them (the scalar the data-gradient kernels apply)  */
 } FrostWDesc;
 int frost_weight_prep(const FrostWDesc* descs, int nlayers, int max_elems, int rule127, int observe, void* stream);
+/* The whole per-step prologue -- frost_save_sigma + frost_weight_prep + frost_stats_init_table, same results bit for bit -- in THREE launches over a flat workgroup
+ * map the caller builds once: wgmap = nwg x {layer index, slot, slots of that layer, 0} (int32 x 4), every layer with >= 1 slot (round 6: the seven launches of
+ * mostly idle workgroups cost 0.28 ms at the head of every captured step). */
+int frost_step_prologue(const FrostWDesc* descs, int nlayers, const int32_t* wgmap, int nwg, float* const* sigma_outs, void* stats,
+                        const int32_t* cpads, const int64_t* offs, int rule127, int observe, void* stream);
 /* Export of the converted model (torch.quantization.convert + state_dict(), Classification/evaluate.py:130-143): the int8 weight values of layer
  * `layer` of the table as frost_weight_prep quantised them, in the module's own [cout][cin/g][kh][kw] order (nelem = cout * cin_g * kk bytes). */
 int frost_export_wq(const FrostWDesc* descs, int layer, int64_t nelem, int8_t* out, void* stream);
@@ -543,6 +548,15 @@ int frost_block_dw_bwd_reduce(const int8_t* x, const float* qrec_x, const int8_t
 int frost_block_dw_bwd(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
                        int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
                        float* dwq, void* stream);
+/* frost_block_dw_bwd carrying the backward REDUCE pass of the pointwise layer that produced x (conv1 of the bottleneck: frost_pw_conv_bwd pass 0 on c1_x -> x): conv1's
+ * integer output of every (image, 64-channel chunk) is recomputed on the matrix cores from c1_x [n*h*w][c1_cin] (record c1_qrec_x) with conv1's weight pack / weight sums, and
+ * its S1 / S2 rows of c1_coef accumulate from the dx values BEFORE their bf16 rounding; conv1's backward then starts at its dc pass.  dx is required.
+ * frost_block_dw_bwd_c1_ok() = 1 if an instance exists (7 x 7: c1_cin <= 320; 14 x 14: <= 128 for k = 5, <= 192 for k = 3; FROST_BLK_C1 masks map sizes). */
+int frost_block_dw_bwd_c1_ok(int h, int w, int k, int stride, int c, int c1_cin);
+int frost_block_dw_bwd_c1(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, const float* qrec_w, const float* wscale,
+                          int n, int h, int w, int c, int k, const float* coef, const float* qrec_y, int relu, const uint16_t* gout, uint16_t* dx,
+                          float* dwq, const int8_t* c1_x, const float* c1_qrec_x, const int8_t* c1_wq_pack, const int32_t* c1_wsum, float* c1_coef, int c1_cin,
+                          int c1_relu, void* stream);
 
 /* ---- frost_block_fwd / frost_block_bwd: the conv1 -> conv2 -> reduce_conv chain of one bottleneck as ONE call each (SURVEY 8(b) "frost_block_fwd/bwd") ------
  * replaces: `out = self.reduce_conv(self.conv2(self.conv1(out)))` of CascadePreExBottleneck.forward (frostnet.py:134-138) in training mode with observers on, and

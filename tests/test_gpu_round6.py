@@ -1,0 +1,172 @@
+"""Round-6 additions on the GPU (every case calls through the C ABI of libfrost_hip.so)."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as ge
+    ge.build()
+    from frostnet_amd import _lib
+    assert torch.cuda.is_available()
+    return _lib
+
+
+def _qat_model(name="frostnet_quant_large_1_0", per_channel=False):
+    from frostnet_amd import frostnet as F
+    torch.manual_seed(11)
+    m = F.MODEL_REGISTRY[name]()
+    if per_channel:
+        F.qat_prepare(m, backend="fbgemm")
+    else:
+        F.qat_prepare(m, version=0)
+    return m.cuda().train()
+
+
+@pytest.mark.parametrize("name,per_channel", [("frostnet_quant_large_1_0", False), ("frostnet_quant_small_0_5", False), ("frostnet_quant_base_1_0", True)])
+def test_step_prologue_three_launches_equal_the_seven(L, name, per_channel):
+    """frost_step_prologue (flat workgroup map: sigma snapshot + weight range | observer / scales | packs + weight sums; csrc/frost_elem.hip) against
+    frost_save_sigma + frost_weight_prep + frost_stats_init_table on the same state: every pack, weight sum, scale row, weight FakeQuantize record, sigma row and the
+    statistics arena bit for bit -- over THREE consecutive steps (the observers are moving averages: torch MovingAverageMinMaxObserver, Q2 of SURVEY 8(a)), for the whole
+    table and for a part of it (the runner's two-part preparation)."""
+    from frostnet_amd.engine import ptr, stream
+    try:
+        model = _qat_model(name, per_channel)
+    except TypeError:
+        pytest.skip("qat_prepare has no backend switch")
+    run = model.hip_runner()
+    E = run.E
+    E._ensure_tables()
+    n = len(E.layers)
+    # a weight perturbation between steps, so that the ranges move
+    state = lambda: dict(q=run.qa.t.clone(), mm=[l.minmax2.clone() for l in E.layers], ws=[l.wscale.clone() for l in E.layers],
+                         wmin=[l.wmin.clone() if l.per_channel else None for l in E.layers], wmax=[l.wmax.clone() if l.per_channel else None for l in E.layers])
+
+    def restore(st):
+        run.qa.t.copy_(st["q"])
+        for l, a, b, c, d in zip(E.layers, st["mm"], st["ws"], st["wmin"], st["wmax"]):
+            l.minmax2.copy_(a); l.wscale.copy_(b)
+            if c is not None:
+                l.wmin.copy_(c); l.wmax.copy_(d)
+
+    def outputs():
+        return dict(q=run.qa.t.clone(), packs=[l.wq_pack.clone() for l in E.layers], wt=[l.wt_pack.clone() if l.wt_pack is not None else None for l in E.layers],
+                    wsum=[l.wsum.clone() for l in E.layers], ws=[l.wscale.clone() for l in E.layers], sig=[l.sigma.clone() for l in E.layers], stats=E._stats.clone(),
+                    mm=[l.minmax2.clone() for l in E.layers])
+
+    def scrub():
+        for l in E.layers:
+            l.wq_pack.fill_(77); l.wsum.fill_(-5); l.sigma.fill_(-1.0)
+            if l.wt_pack is not None:
+                l.wt_pack.fill_(0x3f80)
+        E._stats.fill_(0x5a)
+
+    def seven(lo, hi):
+        m = hi - lo
+        tab = C.c_void_p(E._table.data_ptr() + lo * C.sizeof(L.FrostWDesc))
+        L.call("frost_save_sigma", tab, C.c_void_p(E._sigma_ptrs.data_ptr() + 8 * lo), m, stream())
+        L.call("frost_weight_prep", tab, m, max(l.w.numel() for l in E.layers[lo:hi]), E.rule127, 1, stream())
+        L.call("frost_stats_init_table", ptr(E._stats), C.c_void_p(E._cpads.data_ptr() + 4 * lo), C.c_void_p(E._offs.data_ptr() + 8 * lo), m, stream())
+
+    def three(lo, hi):
+        rows = []
+        for i, l in enumerate(E.layers[lo:hi]):
+            nsl = max(1, min(64, -(-l.w.numel() // 2048)))
+            rows += [[i, sl, nsl, 0] for sl in range(nsl)]
+        wg = torch.tensor(rows, dtype=torch.int32, device="cuda")
+        L.call("frost_step_prologue", C.c_void_p(E._table.data_ptr() + lo * C.sizeof(L.FrostWDesc)), hi - lo, ptr(wg), wg.shape[0],
+               C.c_void_p(E._sigma_ptrs.data_ptr() + 8 * lo), ptr(E._stats), C.c_void_p(E._cpads.data_ptr() + 4 * lo), C.c_void_p(E._offs.data_ptr() + 8 * lo),
+               E.rule127, 1, stream())
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for lo, hi in ((0, n), (n // 3, n - 2)):
+        for step in range(3):
+            with torch.no_grad():
+                for l in E.layers:
+                    l.w.mul_(1.0 + 0.05 * step).add_(torch.randn(l.w.shape, device="cuda", generator=g) * 0.01)
+            st = state()
+            scrub(); seven(lo, hi); a = outputs()
+            restore(st)
+            scrub(); three(lo, hi); b = outputs()
+            torch.cuda.synchronize()
+            assert torch.equal(a["q"].view(torch.int32), b["q"].view(torch.int32)), (lo, hi, step, "records")
+            assert torch.equal(a["stats"], b["stats"])
+            for i in range(n):
+                for key in ("packs", "wsum", "ws", "sig", "mm"):
+                    assert torch.equal(a[key][i].view(torch.int32) if a[key][i].dtype == torch.float32 else a[key][i],
+                                       b[key][i].view(torch.int32) if b[key][i].dtype == torch.float32 else b[key][i]), (E.layers[i].name, key, lo, hi, step)
+                if a["wt"][i] is not None:
+                    assert torch.equal(a["wt"][i], b["wt"][i]), (E.layers[i].name, "wt_pack")
+    # and the engine's own prologue takes the three-launch entry
+    log = []
+    L.CALL_LOG = log
+    try:
+        E.begin_step()
+    finally:
+        L.CALL_LOG = None
+    assert "frost_step_prologue" in log and "frost_weight_prep" not in log
+
+
+# ------------------------------------------------------------------------------------------------ conv1's reduce pass inside the image-resident depthwise backward
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _bf16(a):
+    return (np.asarray(a).astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def _block(tmp, tag, case, env):
+    out = os.path.join(tmp, f"{tag}.npz")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "block_digest.py"), out] + [str(v) for v in case], check=True, env=dict(os.environ, **env), cwd=ROOT,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return np.load(out)
+
+
+# (cin of conv1, expanded width, map, k, cout of reduce_conv, images): the stride-1 CAS bottlenecks of FrostNet-Large's 14 x 14 / 7 x 7 stages (frostnet.py:176-198: 104 -> 312
+# k5, 104 -> 624 k5, 120 -> 360 k5 / k3 @14; 240 -> 1440, 240 -> 720, 288 -> 1728 k5 @7) and ragged relatives: a partial last 64-channel chunk, a K that is no multiple of 64 or
+# 16, one image, k = 3 at 7 x 7
+C1_CASES = [(104, 312, 14, 5, 80, 5), (104, 624, 14, 5, 96, 3), (120, 360, 14, 3, 96, 4), (240, 1440, 7, 5, 192, 6), (240, 720, 7, 5, 192, 9), (288, 1728, 7, 5, 320, 4),
+            (56, 168, 14, 3, 40, 1), (72, 200, 7, 3, 48, 7), (320, 328, 7, 5, 64, 3), (40, 72, 14, 5, 24, 2)]
+
+
+@pytest.mark.parametrize("case", C1_CASES, ids=lambda c: "_".join(str(v) for v in c))
+def test_conv1_reduce_pass_inside_the_image_resident_depthwise_backward(case, tmp_path):
+    """frost_block_dw_bwd_c1 (csrc/frost_block.hip, k_blk_dw_bwd<.., KS1 > 0>): the depthwise backward of a 14 x 14 / 7 x 7 bottleneck carries the reduce pass of the
+    conv1 in front of it (CascadePreExBottleneck, /root/reference/frostnet.py:134-137; the reference's backward is autograd through nniqat.ConvBnReLU2d).  conv2 / reduce_conv
+    gradients and dx of the depthwise layer do not move at all (same kernel, same draws); conv1's S1 / S2 now see the dx values BEFORE their bf16 rounding, so conv1's
+    gradients move at the bf16-noise level and must not be further from the fp32-gradient mode (FROST_GRAD=fp32) than the separate reduce pass is."""
+    calls = os.path.join(str(tmp_path), "calls.txt")
+    on = _block(str(tmp_path), "on", case, {"FROST_SR": "0", "FROST_BLOCK_C1": "1", "FROST_BLK_C1": "3", "DIGEST_CALLS": calls})          # (7 x 7 maps too: off by default, +0.14 ms in the step)
+    log = open(calls).read().split("\n")
+    assert "frost_block_dw_bwd_c1" in log and "frost_block_dw_bwd" not in log, log
+    red_on = log.count("frost_pw_conv_bwd") + log.count("frost_pwc_conv_bwd")
+    calls2 = os.path.join(str(tmp_path), "calls2.txt")
+    off = _block(str(tmp_path), "off", case, {"FROST_SR": "0", "FROST_BLOCK_C1": "0", "DIGEST_CALLS": calls2})
+    log2 = open(calls2).read().split("\n")
+    assert "frost_block_dw_bwd" in log2 and "frost_block_dw_bwd_c1" not in log2
+    assert red_on == log2.count("frost_pw_conv_bwd") + log2.count("frost_pwc_conv_bwd") - 1, (log, log2)          # exactly conv1's reduce pass is gone
+    ref = _block(str(tmp_path), "ref", case, {"FROST_GRAD": "fp32"})
+    assert on["y3"].tobytes() == off["y3"].tobytes() == ref["y3"].tobytes()
+    for k in ("dw2", "dgamma2", "dbeta2", "dw3", "dgamma3", "dbeta3"):
+        assert _relerr(on[k], off[k]) <= 1e-4, k
+    assert _relerr(_bf16(on["dx"]), _bf16(off["dx"])) <= 5e-3
+    e_on = {k: _relerr(on[k], ref[k]) for k in ("dw1", "dgamma1", "dbeta1")}
+    e_off = {k: _relerr(off[k], ref[k]) for k in ("dw1", "dgamma1", "dbeta1")}
+    print("conv1 vs fp32-gradient mode: fold", e_on, "separate", e_off)
+    assert e_on["dbeta1"] <= 1.25 * e_off["dbeta1"] + 1e-4 and e_on["dgamma1"] <= 1.25 * e_off["dgamma1"] + 1e-4 and e_on["dw1"] <= 1.25 * e_off["dw1"] + 1e-4, (e_on, e_off)
+    assert _relerr(_bf16(on["dx"]), ref["dx"]) <= 1.25 * _relerr(_bf16(off["dx"]), ref["dx"]) + 1e-4
