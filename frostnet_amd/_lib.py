@@ -15,7 +15,7 @@ Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_QMAX, Q_OBS_EN, Q_FQ_EN,
 COEF_ROWS = 8
 COEF_A, COEF_B = 0, 1
 COEF_M, COEF_R, COEF_K1, COEF_S1, COEF_S2, COEF_VFRAC = 2, 3, 4, 5, 6, 7      # FROST_COEF_* of include/frost_hip.h
-STATS_BYTES_PER_CH = 24
+STATS_BYTES_PER_CH = 96      # FROST_STATS_BYTES_PER_CH: four replicated 24-byte-per-channel tables (ABI 5)
 
 
 class FrostWDesc(C.Structure):
@@ -36,7 +36,7 @@ class FrostFDesc(C.Structure):
                 ("kind", C.c_int32), ("cpad", C.c_int32), ("kpad", C.c_int32), ("kpad_t", C.c_int32), ("fp32", C.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 TICKET_WORDS = 40      # FROST_TICKET_WORDS: zeroed uint32 words behind every last-workgroup-done ticket (main counter + 32 sub-counters)
 
 

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 3 : 4) void k_blk_expand_dw(co
   }
   // ---- one set of global atomics per channel of the range, then: last workgroup done -> conv2's finalize in this launch
   {
-    long long* g_s1 = (long long*)p.stats2; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    long long* g_s1 = (long long*)stats_copy(p.stats2, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
     for (int i = tid; i < cw; i += NT) {
       const int c2 = chunk_lo * 64 + i;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_reduce(const BlkBP p) {
   }
   __syncthreads();
   {
-    long long* g_s1 = (long long*)p.stats3; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
+    long long* g_s1 = (long long*)stats_copy(p.stats3, p.cpad3); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
     int* g_mn = (int*)(g_s2 + p.cpad3); int* g_mx = g_mn + p.cpad3;
     for (int i = tid; i < p.cout; i += NT) {
       if (l_mn[i] <= l_mx[i]) {
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void k_blk_dw_reduce2(const BlkBP p) {
   }
   __syncthreads();
   {
-    long long* g_s1 = (long long*)p.stats3; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
+    long long* g_s1 = (long long*)stats_copy(p.stats3, p.cpad3); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad3);
     int* g_mn = (int*)(g_s2 + p.cpad3); int* g_mx = g_mn + p.cpad3;
     for (int i = tid; i < p.cout; i += NT) {
       if (l_mn[i] <= l_mx[i]) {
@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_stats(const BlkCP p, uint
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) { a1 += red_d[(w2 * 2) * 64 + tid]; a2 += red_d[(w2 * 2 + 1) * 64 + tid]; mn = min(mn, red_i[(w2 * 2) * 64 + tid]); mx = max(mx, red_i[(w2 * 2 + 1) * 64 + tid]); }
     if (c2 < p.c && mn <= mx) {
-      long long* g_s1 = (long long*)stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+      long long* g_s1 = (long long*)stats_copy(stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
       int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
       atomicAdd((unsigned long long*)&g_s1[c2], (unsigned long long)(long long)a1); atomicAdd(&g_s2[c2], (unsigned long long)a2);
       atomicMin(&g_mn[c2], mn); atomicMax(&g_mx[c2], mx);
@@ -1901,7 +1901,7 @@ __global__ __launch_bounds__(256, 4) void k_sq_fwd(const SqFwdP q) {
   __syncthreads();
   bool last = false;
   if (*sflag && !(q.dbg & 2)) {                                                    // last of its sub-group: fold the group's slots, one set of atomics, then the main ticket
-    long long* g_s1 = (long long*)q.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    long long* g_s1 = (long long*)stats_copy(q.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
     // thread = (channel, member slice): the group's ~total / 32 slots are read by 256 / r... threads side by side (one memory round trip, not one per member), LDS atomics fold the slices
     for (int i = tid; i < p.cpad; i += 256) { l_s1[i] = 0; l_s2[i] = 0; l_mn[i] = INT32_MAX; l_mx[i] = INT32_MIN; }

@@ -171,6 +171,17 @@ __device__ inline void observer_update_dev(float* q, float cur_lo, float cur_hi,
   fin_st<AG>(q + FROST_Q_FQMAX, (float)(ihi - zp) * scale);
 }
 
+// ---- replicated statistics tables (round 6) -------------------------------------------------------------------------------
+// A layer's integer statistics live in FROST_STATS_NC identical tables ([s1 | s2 | min | max] x cpad, 24 bytes per channel each): a workgroup flushes into table
+// stats_copy() picks from its index, the finalize adds the tables up (sums are exact integers, min / max exact: the result does not depend on who wrote where).
+// Hundreds of workgroups finishing together hit ONE address per channel and value before: same-address device atomics are serialised at the memory side
+// (~45 ns each; the step with k_pw's flush atomics compiled out was 0.40 ms shorter, profiles/r05_fusion_ab.txt).
+#define FROST_STATS_NC FROST_STATS_TABLES
+__device__ __forceinline__ uint8_t* stats_copy(uint8_t* base, int cpad) {
+  const unsigned b = blockIdx.x;
+  return base + (size_t)(((b >> 3) ^ b) & (FROST_STATS_NC - 1)) * (size_t)cpad * 24;          // (index bits mixed: launches that deal channel ranges out by index % 2 / 4 still spread)
+}
+
 // ---- conv finalize (shared by k_conv_finalize and the statistics kernels' last-workgroup tail) ------------------------------
 // Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
 // workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read
@@ -182,6 +193,7 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
                                          const float* cat_qb = nullptr, float* cat_qy = nullptr) {
   const int64_t* s1 = (const int64_t*)stats; const uint64_t* s2 = (const uint64_t*)(s1 + cpad);
   const int32_t* mnp = (const int32_t*)(s2 + cpad); const int32_t* mxp = mnp + cpad;
+  const size_t cst8 = (size_t)cpad * 3, cst4 = (size_t)cpad * 6;          // stride between the FROST_STATS_NC replicated tables, in 8- / 4-byte words
   const float sx = qx[FROST_Q_SCALE], sw0 = qw[FROST_Q_SCALE];
   ObsPre pre_y = {}, pre_cat = {}; float cat_b_lo = 0.0f, cat_b_hi = 0.0f;
   if (tid == 0 && have_stats) {      // the records thread 0 updates at the end: requested now, they arrive with the statistics
@@ -192,7 +204,7 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
   // FIN_U channels per thread and round: every load of a round (the other workgroups' statistics through agent-scope loads, the BatchNorm parameters and running
   // statistics) is issued before the first fp64 chain starts, at clamped addresses and without per-channel branches -- one memory round trip per round instead of
   // one per channel (1728 channels on 256 threads were seven dependent round trips of ~2 us on the critical path of the layer; now two)
-  constexpr int FIN_U = 4;
+  constexpr int FIN_U = 2;          // (round 6: 4 -> 2 with the four replicated tables -- 2 channels x 4 tables x 4 values in flight per thread; four channels went to scratch memory)
   for (int c0 = tid; c0 < cpad; c0 += FIN_U * nthr) {
     float f_sw[FIN_U], f_rv[FIN_U], f_rm[FIN_U], f_g[FIN_U], f_b[FIN_U]; int64_t f_v1[FIN_U]; uint64_t f_v2[FIN_U]; int32_t f_mn[FIN_U], f_mx[FIN_U];
 #pragma unroll
@@ -211,7 +223,12 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
 #pragma unroll
       for (int u = 0; u < FIN_U; ++u) {
         const int cc = min(c0 + u * nthr, cout - 1);
-        f_v1[u] = __hip_atomic_load(&s1[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f_v2[u] = __hip_atomic_load(&s2[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t a = 0; uint64_t b = 0;
+#pragma unroll
+        for (int k = 0; k < FROST_STATS_NC; ++k) {          // the producers spread their flushes over FROST_STATS_NC tables (stats_copy): every load of the round in flight together
+          a += __hip_atomic_load(&s1[cc + k * cst8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); b += __hip_atomic_load(&s2[cc + k * cst8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        f_v1[u] = a; f_v2[u] = b;
       }
     } else {
 #pragma unroll
@@ -221,7 +238,12 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
 #pragma unroll
       for (int u = 0; u < FIN_U; ++u) {
         const int cc = min(c0 + u * nthr, cout - 1);
-        f_mn[u] = __hip_atomic_load(&mnp[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); f_mx[u] = __hip_atomic_load(&mxp[cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int32_t a = INT32_MAX, b = INT32_MIN;
+#pragma unroll
+        for (int k = 0; k < FROST_STATS_NC; ++k) {
+          a = min(a, __hip_atomic_load(&mnp[cc + k * cst4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); b = max(b, __hip_atomic_load(&mxp[cc + k * cst4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        f_mn[u] = a; f_mx[u] = b;
       }
     } else {
 #pragma unroll

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256, 3) void k_dws(const DwsP p) {
         double a = 0, b = 0; float c = INFINITY, d = -INFINITY;
         for (int w2 = 0; w2 < 4; ++w2)
           for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_d[(w2 * 64 + l2) * 2]; b += red_d[(w2 * 64 + l2) * 2 + 1]; c = fminf(c, red_f[(w2 * 64 + l2) * 2]); d = fmaxf(d, red_f[(w2 * 64 + l2) * 2 + 1]); }
-        long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+        long long* g_s1 = (long long*)stats_copy(p.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
         int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
         if (c <= d) {
           atomicAdd((unsigned long long*)&g_s1[ch2], (unsigned long long)(long long)a); atomicAdd(&g_s2[ch2], (unsigned long long)b);

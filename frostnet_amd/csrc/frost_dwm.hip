@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512, 4) void k_dwm(const DwmP p) {
       const int lc = (lane >> 2) * 32 + 4 * w + (lane & 3);
       if (lc < cvalid && mmn <= mmx) {
         const int ch = cb * CB + lc;
-        long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+        long long* g_s1 = (long long*)stats_copy(p.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
         int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
         atomicAdd((unsigned long long*)&g_s1[ch], (unsigned long long)m1); atomicAdd(&g_s2[ch], (unsigned long long)__double2ll_rn(m2));
         atomicMin(&g_mn[ch], mmn); atomicMax(&g_mx[ch], mmx);

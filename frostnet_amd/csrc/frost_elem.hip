@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256) void k_wprep_a(const FrostWDesc* descs, const 
     const int cp = cpads[l];
     int64_t* s1 = (int64_t*)(stats_base + offs[l]); uint64_t* s2 = (uint64_t*)(s1 + cp);
     int32_t* mn = (int32_t*)(s2 + cp); int32_t* mx = mn + cp;
-    for (int c = slot * 256 + threadIdx.x; c < cp; c += nsl * 256) { s1[c] = 0; s2[c] = 0; mn[c] = INT32_MAX; mx[c] = INT32_MIN; }
+    for (int i = slot * 256 + threadIdx.x; i < cp * FROST_STATS_NC; i += nsl * 256) {          // every replicated table (frost_common.h, stats_copy)
+      const int k = i / cp, c = i - k * cp; const size_t o8 = (size_t)k * cp * 3, o4 = (size_t)k * cp * 6;
+      s1[o8 + c] = 0; s2[o8 + c] = 0; mn[o4 + c] = INT32_MAX; mx[o4 + c] = INT32_MIN;
+    }
   }
   if (d.rvar) {   // sigma_r = sqrt(running_var + eps) BEFORE this step's forward updates running_var
     float* o = sigma_outs[l];
@@ -527,7 +530,10 @@ __global__ __launch_bounds__(256) void k_stats_init(uint8_t* base, const int32_t
   int l = blockIdx.y; int cp = cpads[l];
   int64_t* s1 = (int64_t*)(base + offs[l]); uint64_t* s2 = (uint64_t*)(s1 + cp);
   int32_t* mn = (int32_t*)(s2 + cp); int32_t* mx = mn + cp;
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < cp; c += gridDim.x * 256) { s1[c] = 0; s2[c] = 0; mn[c] = INT32_MAX; mx[c] = INT32_MIN; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cp * FROST_STATS_NC; i += gridDim.x * 256) {          // every replicated table (frost_common.h, stats_copy)
+    const int k = i / cp, c = i - k * cp; const size_t o8 = (size_t)k * cp * 3, o4 = (size_t)k * cp * 6;
+    s1[o8 + c] = 0; s2[o8 + c] = 0; mn[o4 + c] = INT32_MAX; mx[o4 + c] = INT32_MIN;
+  }
 }
 extern "C" int frost_stats_init_table(void* stats, const int32_t* cpads, const int64_t* offs, int nlayers, void* stream) {
   hipLaunchKernelGGL(k_stats_init, dim3(8, nlayers), dim3(256), 0, as_stream(stream), (uint8_t*)stats, cpads, offs);

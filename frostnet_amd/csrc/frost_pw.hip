@@ -782,7 +782,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       }
     }
     __syncthreads();
-    long long* g_s1 = (long long*)p.stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+    long long* g_s1 = (long long*)stats_copy(p.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
     int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
 #ifndef PW_ABL_NOGATOM
     for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {

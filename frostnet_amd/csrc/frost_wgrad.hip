@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
       }
       __syncthreads();
       const int cpadn = CIT * 16;
-      long long* g_s1 = (long long*)stats; unsigned long long* g_s2 = (unsigned long long*)(g_s1 + cpadn);
+      long long* g_s1 = (long long*)stats_copy(stats, cpadn); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + cpadn);
       int* g_mn = (int*)(g_s2 + cpadn); int* g_mx = g_mn + cpadn;
       for (int i = tid; i < nct * 16; i += 256) {
         const int c = ct0 * 16 + i;

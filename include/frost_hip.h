@@ -33,8 +33,10 @@ extern "C" {
  *          range slots} (was {lo, hi, ticket}); FrostFinDesc gained
  *          cat_qrec_b / cat_qrec_y.  A 1-word ticket under the new kernels is an out-of-bounds device atomic: frost_ticket_words() and
  *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does).
- *   3 -> 4 (round 5): frost_g32_reduce / frost_g32_wgrad take a `scratch` pointer (>= frost_g32_scratch_bytes() bytes; NULL = the plain kernels) before `stream`. */
-#define FROST_ABI_VERSION 4
+ *   3 -> 4 (round 5): frost_g32_reduce / frost_g32_wgrad take a `scratch` pointer (>= frost_g32_scratch_bytes() bytes; NULL = the plain kernels) before `stream`.
+ *   4 -> 5 (round 6): a layer's statistics scratch is FROST_STATS_TABLES replicated tables (FROST_STATS_BYTES_PER_CH 24 -> 96): a buffer sized for one table is
+ *          overrun by the statistics kernels.  New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
+#define FROST_ABI_VERSION 5
 
 /* qrecord field indices (floats) */
 #define FROST_Q_MIN 0
@@ -62,9 +64,12 @@ extern "C" {
 #define FROST_COEF_VFRAC 7  /* v/(v+eps): d(gamma) = S2*VFRAC + fold term           */
 #define FROST_COEF_ROWS 8
 
-/* stats scratch per conv layer: 24 bytes per (padded) channel: int64 sum, uint64 sumsq, int32 min, int32 max,
- * laid out SoA: [cpad] i64 | [cpad] u64 | [cpad] i32 | [cpad] i32 */
-#define FROST_STATS_BYTES_PER_CH 24
+/* stats scratch per conv layer: FROST_STATS_TABLES identical tables of 24 bytes per (padded) channel -- int64 sum, uint64 sumsq, int32 min, int32 max,
+ * laid out SoA: [cpad] i64 | [cpad] u64 | [cpad] i32 | [cpad] i32 -- one after the other.  The statistics kernels spread their flush atomics over the tables by
+ * workgroup index, the finalize adds them up (exact integers: the result does not depend on the spread); frost_stats_init_table / frost_step_prologue reset all of
+ * them.  A caller sizes the buffer as cpad * FROST_STATS_BYTES_PER_CH (ABI 5: was ONE table, 24 bytes per channel). */
+#define FROST_STATS_TABLES 4
+#define FROST_STATS_BYTES_PER_CH (24 * FROST_STATS_TABLES)
 
 int frost_abi_version(void);
 int frost_ticket_words(void);      /* == FROST_TICKET_WORDS of the library that was loaded */

@@ -161,7 +161,10 @@ def test_g4_block_true_shapes(fa, golden, name):
         # the kernels the bench times at these stages are the ones under test
         if not os.environ.get("FROST_G4T_ANY_PATH"):          # (dev knob: the same comparison with the block kernels switched off by FROST_BLOCK_*=0)
             assert ("frost_block_expand_dw_stats" in log) or ("frost_block_dw_stats" in log), log
-            assert "frost_block_dw_reduce" in log and "frost_block_dw_bwd" in log and "frost_block_dw_bwd_reduce" in log, log
+            # (round 6: at 14 x 14 the image-resident depthwise backward carries conv1's reduce pass -- frost_block_dw_bwd_c1 -- by default)
+            assert "frost_block_dw_reduce" in log and ("frost_block_dw_bwd" in log or "frost_block_dw_bwd_c1" in log) and "frost_block_dw_bwd_reduce" in log, log
+            if str(name).startswith("l3"):          # the 14 x 14 bottlenecks
+                assert "frost_block_dw_bwd_c1" in log, log
             assert "frost_dw_conv_fwd" not in log and "frost_dw_dgrad" not in log, log
             if engine._SQ_BWD_CAT:            # (A/B switch FROST_SQ_BWD_CAT=1: quant_cat's backward + the squeeze_conv's reduce pass as one launch)
                 assert "frost_sq_bwd_cat" in log and "frost_cat_bwd" not in log, log
