@@ -62,11 +62,12 @@ def test_c2_bf16_inference_at_batch_256(engine):
     # per-image independence: image i's logits do not depend on the batch it travels in.  The kernel INSTANCE does (pixel-count thresholds pick
     # the tile shapes), so the comparison is at bf16 rounding level, not bitwise
     rel_ind = float((out[:8] - small).norm() / small.norm())
-    assert rel_ind <= 1e-2, rel_ind
-    assert int((out[:8].argmax(1) == small.argmax(1)).sum()) >= 7
+    assert rel_ind <= 5e-3, rel_ind                      # (measured 0.0 -- the same instances are chosen at B = 8 and B = 256 today -- the bound leaves room for a bf16 rounding apart)
+    assert int((out[:8].argmax(1) == small.argmax(1)).sum()) == 8
     rel = float((out[:8].cpu() - ref8).norm() / ref8.norm())
-    assert rel <= 3e-2, rel
-    assert int((out[:8].cpu().argmax(1) == ref8.argmax(1)).sum()) >= 7
+    # bf16 activations through 70 layers against the fp32 definition: measured 2.5e-3 (round 6, gpurun_out/r6_side.log); bound = 3 x that (was a flat 3e-2: VERDICT r5 #7)
+    assert rel <= 8e-3, rel
+    assert int((out[:8].cpu().argmax(1) == ref8.argmax(1)).sum()) == 8
     # a permutation of the batch permutes the logits (no cross-image coupling anywhere in the eval graph)
     perm = torch.randperm(256, generator=g)
     outp = model.hip_infer_bf16(xd[perm.cuda()].contiguous())
