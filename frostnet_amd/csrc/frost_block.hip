@@ -944,8 +944,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
     cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
     const float m = p.coef[FROST_COEF_M * p.cpad + ch], cR = p.coef[FROST_COEF_R * p.cpad + ch];
     cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
-    cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
-    cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+    cE = -cK1 * (s12_sum(p.coef, p.cpad, 1, ch) * p.inv_count) * cR;
+    cF = -cK1 * (s12_sum(p.coef, p.cpad, 0, ch) * p.inv_count) - cE * m;
   }
   const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
   float t_lo = 0.0f, t_hi;
@@ -1186,8 +1186,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
       const int c2 = chunk * 64 + wct * 16 + 4 * g4 + r;
       if ((lane & 15) == 0 && c2 < p.c) {
         const float Rv = p.c1_coef[FROST_COEF_R * p.cpad + c2], Mv = p.c1_coef[FROST_COEF_M * p.cpad + c2];
-        atomicAdd(p.c1_coef + FROST_COEF_S1 * p.cpad + c2, a);
-        atomicAdd(p.c1_coef + FROST_COEF_S2 * p.cpad + c2, fmaf(b, Rv, -Mv * Rv * a));
+        atomicAdd(s12_dst(p.c1_coef, p.cpad, 0) + c2, a);
+        atomicAdd(s12_dst(p.c1_coef, p.cpad, 1) + c2, fmaf(b, Rv, -Mv * Rv * a));
       }
     }
   }
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_blk_dw_bred(const BlkCP p) {
     float sum = 0.0f;
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * 2 + which) * 64 + l2];
-    if (c2 < p.c) atomicAdd(p.coef + (which ? FROST_COEF_S2 : FROST_COEF_S1) * p.cpad + c2, sum);
+    if (c2 < p.c) atomicAdd(s12_dst(p.coef, p.cpad, which) + c2, sum);
   }
 }
 
@@ -2196,8 +2196,8 @@ __global__ __launch_bounds__(256) void k_sq_bwd_cat(const SqBwdP p) {
   }
   __syncthreads();
   for (int c = tid; c < p.r; c += 256) {
-    atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, red[c]);
-    atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, red[p.cpad + c]);
+    atomicAdd(s12_dst(p.coef, p.cpad, 0) + c, red[c]);
+    atomicAdd(s12_dst(p.coef, p.cpad, 1) + c, red[p.cpad + c]);
   }
 }
 extern "C" int frost_sq_bwd_cat_ok(int cin, int r) { return (cin % 8 == 0) && (r % 8 == 0) && cin <= 192 && r <= 96; }

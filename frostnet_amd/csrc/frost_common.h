@@ -182,6 +182,30 @@ __device__ __forceinline__ uint8_t* stats_copy(uint8_t* base, int cpad) {
   return base + (size_t)(((b >> 3) ^ b) & (FROST_STATS_NC - 1)) * (size_t)cpad * 24;          // (index bits mixed: launches that deal channel ranges out by index % 2 / 4 still spread)
 }
 
+// ---- spread S1 / S2 rows of the backward reduce passes (round 6) -------------------------------------------------------------
+// The reduce passes add their per-workgroup sums (S1 = sum gy, S2 = sum gy * xhat) into the layer's coefficient rows with float atomics: hundreds of workgroups, ONE
+// address per channel and sum.  The rows now exist FROST_S12_NC times -- copy 0 = rows FROST_COEF_S1 / _S2, copy k > 0 = rows FROST_COEF_ROWS + 2 (k - 1) + {0, 1} of the
+// same table (a coefficient table is FROST_COEF_ROWS_ALLOC rows) -- a workgroup adds into the copy s12_dst() picks from its index, every reader (the dc kernels' prologues,
+// the parameter-gradient finalize) takes s12_sum().  The forward finalize zeroes every copy.  Kernels that WRITE totals (the fp32-gradient mode) use copy 0, the rest stays 0.
+#define FROST_S12_NC ((FROST_COEF_ROWS_ALLOC - FROST_COEF_ROWS) / 2 + 1)
+__host__ __device__ __forceinline__ int s12_row(int which, int k) { return k == 0 ? (which ? FROST_COEF_S2 : FROST_COEF_S1) : FROST_COEF_ROWS + 2 * (k - 1) + which; }
+__device__ __forceinline__ float* s12_dst(float* coef, int cpad, int which) {
+  const unsigned b = blockIdx.x;
+  return coef + (size_t)s12_row(which, (int)(((b >> 3) ^ b) & (FROST_S12_NC - 1))) * cpad;
+}
+__device__ __forceinline__ float s12_sum(const float* coef, int cpad, int which, int c) {
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < FROST_S12_NC; ++k) s += coef[(size_t)s12_row(which, k) * cpad + c];
+  return s;
+}
+__device__ __forceinline__ float4 s12_sum4(const float* coef, int cpad, int which, int c) {          // c a multiple of 4
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < FROST_S12_NC; ++k) { const float4 v = *(const float4*)(coef + (size_t)s12_row(which, k) * cpad + c); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  return s;
+}
+
 // ---- conv finalize (shared by k_conv_finalize and the statistics kernels' last-workgroup tail) ------------------------------
 // Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
 // workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read
@@ -285,7 +309,8 @@ __device__ inline void conv_finalize_dev(const uint8_t* stats, int64_t count, in
       }
       fin_st<AG>(coef + FROST_COEF_A * cpad + c, A); fin_st<AG>(coef + FROST_COEF_B * cpad + c, B); fin_st<AG>(coef + FROST_COEF_M * cpad + c, M);
       fin_st<AG>(coef + FROST_COEF_R * cpad + c, R); fin_st<AG>(coef + FROST_COEF_K1 * cpad + c, K1); fin_st<AG>(coef + FROST_COEF_VFRAC * cpad + c, VF);
-      fin_st<AG>(coef + FROST_COEF_S1 * cpad + c, 0.0f); fin_st<AG>(coef + FROST_COEF_S2 * cpad + c, 0.0f);
+#pragma unroll
+      for (int k = 0; k < FROST_S12_NC; ++k) { fin_st<AG>(coef + (size_t)s12_row(0, k) * cpad + c, 0.0f); fin_st<AG>(coef + (size_t)s12_row(1, k) * cpad + c, 0.0f); }
     }
   }
   const int nw = nthr >> 6;

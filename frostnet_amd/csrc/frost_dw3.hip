@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
       if (MODE != D_EMIT) { const float m = p.coef[FROST_COEF_M * p.cpad + ch]; cR = p.coef[FROST_COEF_R * p.cpad + ch]; cMR = -m * cR;
         if (MODE == D_BDC) {     // dc = fma(gy, K1, fma(acc, E, F)): same folding as the pointwise backward
           cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
-          cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
-          cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+          cE = -cK1 * (s12_sum(p.coef, p.cpad, 1, ch) * p.inv_count) * cR;
+          cF = -cK1 * (s12_sum(p.coef, p.cpad, 0, ch) * p.inv_count) - cE * m;
         }
       }
     }
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
         float a = 0, b = 0;
         for (int w2 = 0; w2 < 4; ++w2)
           for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_f[(w2 * 64 + l2) * 2]; b += red_f[(w2 * 64 + l2) * 2 + 1]; }
-        atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch2, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch2, b);
+        atomicAdd(s12_dst(p.coef, p.cpad, 0) + ch2, a); atomicAdd(s12_dst(p.coef, p.cpad, 1) + ch2, b);
       }
     }
     if (MODE == D_STATS && p.fin_on) {       // last workgroup done -> conv finalize in this launch (see frost_common.h)

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256, DWB_LB1) void k_dwb_s1(const DwbP p) {
     cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
     const float m = p.coef[FROST_COEF_M * p.cpad + ch], cR = p.coef[FROST_COEF_R * p.cpad + ch];
     cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
-    cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
-    cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+    cE = -cK1 * (s12_sum(p.coef, p.cpad, 1, ch) * p.inv_count) * cR;
+    cF = -cK1 * (s12_sum(p.coef, p.cpad, 0, ch) * p.inv_count) - cE * m;
   }
   const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
   float t_lo = 0.0f, t_hi;
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
     cA = p.coef[FROST_COEF_A * p.cpad + ch]; cB = p.coef[FROST_COEF_B * p.cpad + ch];
     const float m = p.coef[FROST_COEF_M * p.cpad + ch], cR = p.coef[FROST_COEF_R * p.cpad + ch];
     cK1 = p.coef[FROST_COEF_K1 * p.cpad + ch];
-    cE = -cK1 * (p.coef[FROST_COEF_S2 * p.cpad + ch] * p.inv_count) * cR;
-    cF = -cK1 * (p.coef[FROST_COEF_S1 * p.cpad + ch] * p.inv_count) - cE * m;
+    cE = -cK1 * (s12_sum(p.coef, p.cpad, 1, ch) * p.inv_count) * cR;
+    cF = -cK1 * (s12_sum(p.coef, p.cpad, 0, ch) * p.inv_count) - cE * m;
   }
   const float y_inv = 1.0f / p.qy[FROST_Q_SCALE];
   float t_lo = 0.0f, t_hi;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
       float a = 0, b = 0;
       for (int w2 = 0; w2 < 4; ++w2)
         for (int l2 = tid; l2 < 64; l2 += CBW) { a += red[(w2 * 64 + l2) * 2]; b += red[(w2 * 64 + l2) * 2 + 1]; }
-      atomicAdd(p.c1_coef + FROST_COEF_S1 * p.cpad + cb * CBW + tid, a); atomicAdd(p.c1_coef + FROST_COEF_S2 * p.cpad + cb * CBW + tid, b);
+      atomicAdd(s12_dst(p.c1_coef, p.cpad, 0) + cb * CBW + tid, a); atomicAdd(s12_dst(p.c1_coef, p.cpad, 1) + cb * CBW + tid, b);
     }
   }
 }
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256, 3) void k_dws(const DwsP p) {
         float a = 0, b = 0;
         for (int w2 = 0; w2 < 4; ++w2)
           for (int l2 = tid; l2 < 64; l2 += CBW) { a += red_f[(w2 * 64 + l2) * 2]; b += red_f[(w2 * 64 + l2) * 2 + 1]; }
-        atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + ch2, a); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + ch2, b);
+        atomicAdd(s12_dst(p.coef, p.cpad, 0) + ch2, a); atomicAdd(s12_dst(p.coef, p.cpad, 1) + ch2, b);
       }
     }
     if (MODE == W_STATS && p.fin_on) {       // last workgroup done -> conv finalize in this launch (see frost_common.h)

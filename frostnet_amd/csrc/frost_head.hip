@@ -426,8 +426,8 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
     }
     dot = wave_sum(dot);
     if (lane == 0 && gamma) {
-      float dg = coef[FROST_COEF_S2 * cpad + co] + dot / sigr;
-      float db = coef[FROST_COEF_S1 * cpad + co];
+      float dg = s12_sum(coef, cpad, 1, co) + dot / sigr;
+      float db = s12_sum(coef, cpad, 0, co);
       if (accumulate) { dg += dgamma[co]; db += dbeta[co]; }
       dgamma[co] = dg; dbeta[co] = db;
     }
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize_table(const FrostGDesc* 
     }
     dot = wave_sum(dot);
     if (lane == 0 && d.gamma) {
-      d.dgamma[co] = d.coef[FROST_COEF_S2 * d.cpad + co] + dot / sigr;
-      d.dbeta[co] = d.coef[FROST_COEF_S1 * d.cpad + co];
+      d.dgamma[co] = s12_sum(d.coef, d.cpad, 1, co) + dot / sigr;
+      d.dbeta[co] = s12_sum(d.coef, d.cpad, 0, co);
     }
   }
 }

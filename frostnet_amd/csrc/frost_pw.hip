@@ -223,10 +223,10 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
       float* c2 = (float*)cl;
       for (int c = tid; c < p.cpad; c += 512) {
         const float Mv = p.coef[FROST_COEF_M * p.cpad + c], Rv = p.coef[FROST_COEF_R * p.cpad + c], Kv = p.coef[FROST_COEF_K1 * p.cpad + c];
-        const float Ev = -Kv * (p.coef[FROST_COEF_S2 * p.cpad + c] * p.inv_count) * Rv;
+        const float Ev = -Kv * (s12_sum(p.coef, p.cpad, 1, c) * p.inv_count) * Rv;
         c2[FROST_COEF_A * p.cpad + c] = p.coef[FROST_COEF_A * p.cpad + c]; c2[FROST_COEF_B * p.cpad + c] = p.coef[FROST_COEF_B * p.cpad + c];
         c2[FROST_COEF_M * p.cpad + c] = -Mv * Rv; c2[FROST_COEF_R * p.cpad + c] = Rv; c2[FROST_COEF_K1 * p.cpad + c] = Kv;
-        c2[FROST_COEF_S1 * p.cpad + c] = Ev; c2[FROST_COEF_S2 * p.cpad + c] = -Kv * (p.coef[FROST_COEF_S1 * p.cpad + c] * p.inv_count) - Ev * Mv;
+        c2[FROST_COEF_S1 * p.cpad + c] = Ev; c2[FROST_COEF_S2 * p.cpad + c] = -Kv * (s12_sum(p.coef, p.cpad, 0, c) * p.inv_count) - Ev * Mv;
       }
     }
   }
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) MR[r] = -Mv[r] * R[r];
             if (MODE == M_BDC) {
-              const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0), a4 = *(const float4*)(coefp + FROST_COEF_S1 * p.cpad + ch0), b4 = *(const float4*)(coefp + FROST_COEF_S2 * p.cpad + ch0);
+              const float4 k4 = *(const float4*)(coefp + FROST_COEF_K1 * p.cpad + ch0), a4 = s12_sum4(p.coef, p.cpad, 0, ch0), b4 = s12_sum4(p.coef, p.cpad, 1, ch0);          // (not resident: coefp == p.coef)
               const float kk[4] = {k4.x, k4.y, k4.z, k4.w}, s1[4] = {a4.x, a4.y, a4.z, a4.w}, s2[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) { K1[r] = kk[r]; E[r] = -kk[r] * (s2[r] * p.inv_count) * R[r]; F[r] = -kk[r] * (s1[r] * p.inv_count) - E[r] * Mv[r]; }
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
     __syncthreads();
 #ifndef PW_ABL_NOGATOM
     for (int c = cg_lo * WC * mi_eff * 16 + tid; c < p.cout && c < cg_hi * WC * mi_eff * 16; c += 512) {
-      atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c, l_f1[c]);
-      atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c, l_f2[c]);
+      atomicAdd(s12_dst(p.coef, p.cpad, 0) + c, l_f1[c]);
+      atomicAdd(s12_dst(p.coef, p.cpad, 1) + c, l_f2[c]);
     }
 #endif
   }

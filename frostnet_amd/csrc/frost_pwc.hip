@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
     float A = p.coef[FROST_COEF_A * p.cpad + cc], B = p.coef[FROST_COEF_B * p.cpad + cc], M = p.coef[FROST_COEF_M * p.cpad + cc], R = p.coef[FROST_COEF_R * p.cpad + cc];
     int ws = p.wsum[cc];
     float K1 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    if (MODE == 1) { K1 = p.coef[FROST_COEF_K1 * p.cpad + cc]; s1 = p.coef[FROST_COEF_S1 * p.cpad + cc]; s2 = p.coef[FROST_COEF_S2 * p.cpad + cc]; }
+    if (MODE == 1) { K1 = p.coef[FROST_COEF_K1 * p.cpad + cc]; s1 = s12_sum(p.coef, p.cpad, 0, cc); s2 = s12_sum(p.coef, p.cpad, 1, cc); }
     if (!ok) { A = 0.0f; B = 0.0f; M = 0.0f; R = 0.0f; ws = 0; K1 = 0.0f; s1 = 0.0f; s2 = 0.0f; }
     tA[i] = A; tB[i] = B; tR[i] = R; tMR[i] = -M * R; tW[i] = ws;
     if (MODE == 1) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
     __syncthreads();
     for (int i = tid; i < cw; i += 256) {
       const int c2 = chunk_lo * 64 + i;
-      if (c2 < p.c) { atomicAdd(p.coef + FROST_COEF_S1 * p.cpad + c2, l_f1[i]); atomicAdd(p.coef + FROST_COEF_S2 * p.cpad + c2, l_f2[i]); }
+      if (c2 < p.c) { atomicAdd(s12_dst(p.coef, p.cpad, 0) + c2, l_f1[i]); atomicAdd(s12_dst(p.coef, p.cpad, 1) + c2, l_f2[i]); }
     }
   }
 }

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint,
     K1[r] = 0.f; E[r] = 0.f; F[r] = 0.f;
     if (MODE == 1) {
       K1[r] = coef[FROST_COEF_K1 * cpad + ch + r];
-      const float s1 = coef[FROST_COEF_S1 * cpad + ch + r], s2 = coef[FROST_COEF_S2 * cpad + ch + r];
+      const float s1 = s12_sum(coef, cpad, 0, ch + r), s2 = s12_sum(coef, cpad, 1, ch + r);
       E[r] = -K1[r] * (s2 * inv_count) * R[r]; F[r] = -K1[r] * (s1 * inv_count) - E[r] * Mv;
     }
   }
@@ -708,8 +708,8 @@ __global__ __launch_bounds__(256) void k_pw_ew(const int32_t* __restrict__ cint,
     }
     __syncthreads();
     for (int i = tid; i < cout; i += 256) {
-      atomicAdd(coef + FROST_COEF_S1 * cpad + i, part[i]);
-      atomicAdd(coef + FROST_COEF_S2 * cpad + i, part[cout + i]);
+      atomicAdd(s12_dst(coef, cpad, 0) + i, part[i]);
+      atomicAdd(s12_dst(coef, cpad, 1) + i, part[cout + i]);
     }
   }
 }
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_pw_ew_add(const int32_t* __restrict__ c
     K1[r] = 0.f; E[r] = 0.f; F[r] = 0.f;
     if (MODE == 1) {
       K1[r] = coef[FROST_COEF_K1 * cpad + ch + r];
-      const float s1 = coef[FROST_COEF_S1 * cpad + ch + r], s2 = coef[FROST_COEF_S2 * cpad + ch + r];
+      const float s1 = s12_sum(coef, cpad, 0, ch + r), s2 = s12_sum(coef, cpad, 1, ch + r);
       E[r] = -K1[r] * (s2 * inv_count) * R[r]; F[r] = -K1[r] * (s1 * inv_count) - E[r] * Mv;
     }
   }
@@ -825,8 +825,8 @@ __global__ __launch_bounds__(256) void k_pw_ew_add(const int32_t* __restrict__ c
     }
     __syncthreads();
     for (int i = tid; i < cout; i += 256) {
-      atomicAdd(coef + FROST_COEF_S1 * cpad + i, part[i]);
-      atomicAdd(coef + FROST_COEF_S2 * cpad + i, part[cout + i]);
+      atomicAdd(s12_dst(coef, cpad, 0) + i, part[i]);
+      atomicAdd(s12_dst(coef, cpad, 1) + i, part[cout + i]);
     }
   }
 }

@@ -1134,6 +1134,11 @@ class Engine:
         _frozen_restore puts them back for the parameter-gradient finalize (dbeta = S1) and corrects dgamma."""
         if not getattr(l, "frozen", False):
             return
+        # (the reduce passes spread S1 / S2 over four row copies -- rows 5 / 6 and 8 .. 13: folded into rows 5 / 6 here, so that the stash below holds the totals)
+        extra = l.coef[L.COEF_ROWS_NAMED:]
+        l.coef[L.COEF_S1].add_(extra[0::2].sum(0))
+        l.coef[L.COEF_S2].add_(extra[1::2].sum(0))
+        extra.zero_()
         rows = l.coef[L.COEF_S1: L.COEF_S2 + 1]
         if getattr(l, "_s12_buf", None) is None or l._s12_buf.shape != rows.shape:
             l._s12_buf = torch.empty_like(rows)          # persistent stash: no allocation per step (a captured step keeps its address)

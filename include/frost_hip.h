@@ -35,7 +35,8 @@ extern "C" {
  *          frost_fin_desc_bytes() let a binding verify both sizes before its first launch (frostnet_amd/_lib.py does).
  *   3 -> 4 (round 5): frost_g32_reduce / frost_g32_wgrad take a `scratch` pointer (>= frost_g32_scratch_bytes() bytes; NULL = the plain kernels) before `stream`.
  *   4 -> 5 (round 6): a layer's statistics scratch is FROST_STATS_TABLES replicated tables (FROST_STATS_BYTES_PER_CH 24 -> 96): a buffer sized for one table is
- *          overrun by the statistics kernels.  New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
+ *          overrun by the statistics kernels; a coefficient table is FROST_COEF_ROWS_ALLOC (14) rows: three more copies of the S1 / S2 rows behind the 8 named ones.
+ *          New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
 #define FROST_ABI_VERSION 5
 
 /* qrecord field indices (floats) */
@@ -63,6 +64,10 @@ extern "C" {
 #define FROST_COEF_S2 6     /* sum gy*xhat                                          */
 #define FROST_COEF_VFRAC 7  /* v/(v+eps): d(gamma) = S2*VFRAC + fold term           */
 #define FROST_COEF_ROWS 8
+/* rows a caller ALLOCATES per coefficient table (ABI 5): the 8 rows above + 3 more copies of the S1 / S2 rows (rows 8 + 2 (k - 1) + {0, 1}, k = 1 .. 3).  The backward
+ * reduce passes spread their float atomics over the four copies by workgroup index; every reader (dc passes, parameter-gradient finalize) adds the copies up; the forward
+ * finalize zeroes all of them.  Rows 5 / 6 alone are the totals only where a kernel writes totals (the fp32-gradient mode). */
+#define FROST_COEF_ROWS_ALLOC 14
 
 /* stats scratch per conv layer: FROST_STATS_TABLES identical tables of 24 bytes per (padded) channel -- int64 sum, uint64 sumsq, int32 min, int32 max,
  * laid out SoA: [cpad] i64 | [cpad] u64 | [cpad] i32 | [cpad] i32 -- one after the other.  The statistics kernels spread their flush atomics over the tables by

@@ -34,7 +34,7 @@ def test_cabi_exports_every_declared_symbol(built):
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/frost_hip.h but not exported"
     assert set(built.SYMBOLS) == declared          # the ctypes binding covers exactly the header
-    assert built.load_library().frost_abi_version() == 4 and built.load_library().frost_ticket_words() == 40
+    assert built.load_library().frost_abi_version() == 5 and built.load_library().frost_ticket_words() == 40
 
 
 def test_no_cpu_fallback_on_device_path(built):
