@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_blk_dw_bwd(const BlkCP p) {
     float sum = 0.0f;
 #pragma unroll
     for (int w2 = 0; w2 < NW; ++w2) sum += red[(w2 * K * K + t) * 64 + l2];
-    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
+    if (c2 < p.c) atomicAdd(dwq_dst(p.dwq, (int64_t)p.c * K * K) + (int64_t)c2 * K * K + t, sum * sx);
   }
 }
 

@@ -206,6 +206,27 @@ __device__ __forceinline__ float4 s12_sum4(const float* coef, int cpad, int whic
   return s;
 }
 
+// ---- spread raw weight-gradient sums (round 6) ------------------------------------------------------------------------------
+// dL/d(fake-quantised weight) is accumulated with float atomics into the layer's `dwq` buffer [cout][cin/g * k * k]; the fused pointwise backward and the depthwise backward
+// kernels are persistent launches whose 500 - 1000 workgroups all flush the SAME few thousand addresses at the end.  Layers of at most FROST_DWQ_SPREAD_MAX weights -- every
+// layer those kernels serve -- keep FROST_DWQ_NC copies of the buffer (copy k at dwq + k * dwq_stride(numel); the caller sizes and zeroes all of them), a workgroup adds into
+// the copy picked from its index, the parameter-gradient finalize (its only reader) adds the copies up.  Producers that do not spread (split-K GEMMs of the wide layers, the
+// fp32-gradient mode) write copy 0; larger layers have ONE copy.  The rule is a function of the layer's weight count alone, so both sides evaluate it from their own arguments.
+__host__ __device__ __forceinline__ int64_t dwq_stride(int64_t numel) { return (numel + 63) & ~(int64_t)63; }
+__device__ __forceinline__ float* dwq_dst(float* dwq, int64_t numel) {
+  const unsigned b = blockIdx.x;
+  return (numel <= FROST_DWQ_SPREAD_MAX) ? dwq + (int64_t)(((b >> 3) ^ b) & (FROST_DWQ_NC - 1)) * dwq_stride(numel) : dwq;
+}
+__device__ __forceinline__ float dwq_sum(const float* dwq, int64_t numel, int64_t idx) {
+  float s = dwq[idx];
+  if (numel <= FROST_DWQ_SPREAD_MAX) {
+    const int64_t st = dwq_stride(numel);
+#pragma unroll
+    for (int k = 1; k < FROST_DWQ_NC; ++k) s += dwq[idx + k * st];
+  }
+  return s;
+}
+
 // ---- conv finalize (shared by k_conv_finalize and the statistics kernels' last-workgroup tail) ------------------------------
 // Turns the integer statistics of one layer into BN coefficients, running-stat updates and the activation qrecord.  Runs in ONE
 // workgroup of `nthr` threads.  The statistics were produced by device-scope atomics of (possibly) other workgroups: they are read

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3(const Dw3P pin) {
       float sum = 0.0f;
       for (int w2 = 0; w2 < 4; ++w2)
         for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * K * K + t) * 64 + l3];
-      if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
+      if (c2 < p.c) atomicAdd(dwq_dst(p.dwq, (int64_t)p.c * K * K) + (int64_t)c2 * K * K + t, sum * sx);
     }
   }
   if (MODE == D_STATS || MODE == D_BRED) {      // sum the waves' lane-local partials, one global atomic set per channel
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void k_dw3_wgrad(const Dw3P pin) {
     float sum = 0.0f;
     for (int w2 = 0; w2 < 4; ++w2)
       for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * K * K + t) * 64 + l3];
-    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * K * K + t, sum * sx);
+    if (c2 < p.c) atomicAdd(dwq_dst(p.dwq, (int64_t)p.c * K * K) + (int64_t)c2 * K * K + t, sum * sx);
   }
 }
 

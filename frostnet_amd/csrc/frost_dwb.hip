@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, DWB_LB1) void k_dwb_s1(const DwbP p) {
     float sum = 0.0f;
     for (int w2 = 0; w2 < 4; ++w2)
       for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * 9 + t) * 64 + l3];
-    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * 9 + t, sum * sx);
+    if (c2 < p.c) atomicAdd(dwq_dst(p.dwq, (int64_t)p.c * 9) + (int64_t)c2 * 9 + t, sum * sx);
   }
 }
 
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, DWB_LB2) void k_dwb_s2(const DwbP p) {
     float sum = 0.0f;
     for (int w2 = 0; w2 < 4; ++w2)
       for (int l3 = l2; l3 < 64; l3 += CBW) sum += red[(w2 * KK + t) * 64 + l3];
-    if (c2 < p.c) atomicAdd(p.dwq + (int64_t)c2 * KK + t, sum * sx);
+    if (c2 < p.c) atomicAdd(dwq_dst(p.dwq, (int64_t)p.c * KK) + (int64_t)c2 * KK + t, sum * sx);
   }
   if (C1) {           // conv1's S1 / S2: the waves' lane-local sums, one pair of float atomics per channel and workgroup (k_pw's reduce-pass tail)
     __syncthreads();

@@ -731,7 +731,7 @@ __global__ void k_stem_wgrad_remap(const float* __restrict__ src, int cout, int 
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cout * cin_g * 9) return;
   int co = i / (cin_g * 9), r = i % (cin_g * 9); int c = r / 9, tap = r % 9;
-  dst[i] = src[co * 40 + tap * 4 + c];
+  dst[i] = dwq_sum(src, (int64_t)cout * 40, co * 40 + tap * 4 + c);          // the fused stem backward spreads its sums over the copies of dwq_col (frost_common.h)
 }
 extern "C" int frost_stem_wgrad_remap(const float* dwq_col, int cout, int cin_g, float* dwq, void* stream) {
   int tot = cout * cin_g * 9;

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize(const float* __restrict_
     for (int r = lane; r < per; r += 64) {
       const int64_t idx = (int64_t)co * per + r;
       const float wv = w[idx]; bool inr; const int qi = fq_index(wv * sf, inv, 0, -128, 127, &inr);
-      const float gr = dwq[idx], g = inr ? gr : 0.0f;
+      const float gr = dwq_sum(dwq, (int64_t)cout * per, idx), g = inr ? gr : 0.0f;
       float o = g * sf; if (accumulate) o += dw[idx];
       dw[idx] = o; dot += gr * (inr ? (wv - (float)qi * qstep) : -(float)qi * qstep);
     }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_wgrad_finalize_table(const FrostGDesc* 
     for (int r = lane; r < d.per; r += 64) {
       const int64_t idx = (int64_t)co * d.per + r;
       const float wv = d.w[idx]; bool inr; const int qi = fq_index(wv * sf, inv, 0, -128, 127, &inr);
-      const float gr = d.dwq[idx], g = inr ? gr : 0.0f;
+      const float gr = dwq_sum(d.dwq, (int64_t)d.cout * d.per, idx), g = inr ? gr : 0.0f;
       d.dw[idx] = g * sf; dot += gr * (inr ? (wv - (float)qi * qstep) : -(float)qi * qstep);
     }
     dot = wave_sum(dot);

@@ -753,6 +753,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
   if (FUSE) {                          // one flush of this workgroup's weight-gradient partials
     const int cin = p.rowbytes, nbw = (cin + 15) >> 4, ntw = CT * nbw;
     const float sx = p.qx[FROST_Q_SCALE];
+    float* const dwq_w = dwq_dst(p.dwq, (int64_t)p.cout * cin);          // this workgroup's copy of the raw weight-gradient sums (frost_common.h)
 #pragma unroll
     for (int i = 0; i < FTW; ++i) {
       const int tt = w + 8 * i;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = a * 16 + 4 * g + r, ci = b * 16 + j;
-          if (co < p.cout && ci < cin) atomicAdd(p.dwq + (int64_t)co * cin + ci, wacc[i][r] * sx);
+          if (co < p.cout && ci < cin) atomicAdd(dwq_w + (int64_t)co * cin + ci, wacc[i][r] * sx);
         }
       }
     }

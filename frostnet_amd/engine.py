@@ -705,7 +705,7 @@ class Engine:
                 _, l, x, pooled, raw, drop = entry
                 g = torch.empty_like(raw)
                 call("frost_mask_logits", ptr(dlogits.contiguous()), ptr(raw), ptr(l.qy), raw.numel(), ptr(g), stream())
-                dwq = torch.empty(l.cout, l.cin_g, dtype=torch.float32, device=self.device)
+                dwq = self._dwq_buf(l.cout * l.cin_g)
                 gx, _ = self._grad_slot(x)
                 dpool = torch.empty_like(pooled)
                 self._ensure_grad(l)
@@ -782,7 +782,7 @@ class Engine:
                 _, l, x, pooled, raw, drop = entry
                 g = torch.empty_like(raw)
                 call("frost_mask_logits", ptr(dlogits.contiguous()), ptr(raw), ptr(l.qy), raw.numel(), ptr(g), s)
-                dwq = torch.empty(l.cout, l.cin_g, dtype=torch.float32, device=self.device)
+                dwq = self._dwq_buf(l.cout * l.cin_g)
                 gx, _ = self._grad_slot(x)
                 dpool = torch.empty_like(pooled)
                 scratch = torch.empty(x.numel + 64, dtype=torch.int16, device=self.device)          # (the fp32 GEMMs of the head are shared; its bf16 gx is discarded)
@@ -854,17 +854,30 @@ class Engine:
         self._after_conv_backward(l, s)
         y.grad = None
 
+    @staticmethod
+    def _dwq_elems(numel):
+        """Floats of a raw weight-gradient buffer for a layer of `numel` weights: layers of at most FROST_DWQ_SPREAD_MAX weights keep FROST_DWQ_NC copies at a stride of
+        round_up(numel, 64) -- the persistent backward kernels spread their flush atomics over them, the parameter-gradient finalize adds them up (csrc/frost_common.h)."""
+        return numel if numel > L.DWQ_SPREAD_MAX else L.DWQ_NC * round_up(numel, 64)
+
+    def _dwq_buf(self, numel):
+        """A raw weight-gradient buffer outside the arena (the classifier head): zeroed, sized by the same rule (its kernels write copy 0)."""
+        t = torch.zeros(self._dwq_elems(numel), dtype=torch.float32, device=self.device) if numel <= L.DWQ_SPREAD_MAX \
+            else torch.empty(numel, dtype=torch.float32, device=self.device)
+        return t
+
     def _prepare_dwq(self):
         """One fp32 scratch arena for every layer's dL/d(fake-quantised weight) (the wgrad kernels accumulate with atomics):
         one fill per step instead of one per layer."""
         if getattr(self, "_dwq_arena", None) is None or self._dwq_layers != len(self.layers):
-            sizes = [l.w.numel() + (l.cout * 40 if l.kind == "stem" else 0) for l in self.layers]
+            sizes = [self._dwq_elems(l.w.numel()) + (self._dwq_elems(l.cout * 40) if l.kind == "stem" else 0) for l in self.layers]
             self._dwq_arena = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
             o = 0
             for l, sz in zip(self.layers, sizes):
-                l.dwq = self._dwq_arena[o: o + l.w.numel()]
+                l.dwq = self._dwq_arena[o: o + l.w.numel()]                 # copy 0 (the views the kernels get are base pointers: the copies follow at dwq_stride)
                 if l.kind == "stem":
-                    l.dwq_col = self._dwq_arena[o + l.w.numel(): o + sz]
+                    o2 = o + self._dwq_elems(l.w.numel())
+                    l.dwq_col = self._dwq_arena[o2: o2 + l.cout * 40]
                 o += sz
             self._dwq_layers = len(self.layers)
             self._gtables = {}

@@ -36,7 +36,12 @@ extern "C" {
  *   3 -> 4 (round 5): frost_g32_reduce / frost_g32_wgrad take a `scratch` pointer (>= frost_g32_scratch_bytes() bytes; NULL = the plain kernels) before `stream`.
  *   4 -> 5 (round 6): a layer's statistics scratch is FROST_STATS_TABLES replicated tables (FROST_STATS_BYTES_PER_CH 24 -> 96): a buffer sized for one table is
  *          overrun by the statistics kernels; a coefficient table is FROST_COEF_ROWS_ALLOC (14) rows: three more copies of the S1 / S2 rows behind the 8 named ones.
+ *          A raw weight-gradient buffer (`dwq`) of a layer with at most FROST_DWQ_SPREAD_MAX (32768) weights is FROST_DWQ_NC (4) copies at a stride of round_up(weights, 64)
+ *          floats, all zeroed by the caller: the fused pointwise / depthwise backward kernels spread their flush atomics over the copies, frost_weight_grad_finalize[_table]
+ *          and frost_stem_wgrad_remap add them up; every other producer writes copy 0.  Larger layers keep one copy.
  *          New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
+#define FROST_DWQ_NC 4
+#define FROST_DWQ_SPREAD_MAX 32768
 #define FROST_ABI_VERSION 5
 
 /* qrecord field indices (floats) */
