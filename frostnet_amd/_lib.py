@@ -12,12 +12,12 @@ _lib = None
 P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 Q_MIN, Q_MAX, Q_SCALE, Q_ZP, Q_FQMIN, Q_FQMAX, Q_INV, Q_QMAX, Q_OBS_EN, Q_FQ_EN, Q_STRIDE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12
-COEF_ROWS = 14          # FROST_COEF_ROWS_ALLOC: the 8 named rows + three more copies of the S1 / S2 rows (ABI 5: the reduce passes spread their atomics, readers add the copies up)
+COEF_ROWS = int(os.environ.get("FROST_COEF_ROWS_ALLOC", "14"))          # FROST_COEF_ROWS_ALLOC: the 8 named rows + three more copies of the S1 / S2 rows (ABI 5: the reduce passes spread their atomics, readers add the copies up)
 COEF_ROWS_NAMED = 8
-DWQ_NC, DWQ_SPREAD_MAX = 4, 32768      # FROST_DWQ_NC / FROST_DWQ_SPREAD_MAX: copies of the raw weight-gradient sums of small layers (csrc/frost_common.h)
+DWQ_NC, DWQ_SPREAD_MAX = int(os.environ.get("FROST_DWQ_NC", "4")), 32768      # FROST_DWQ_NC / FROST_DWQ_SPREAD_MAX: copies of the raw weight-gradient sums of small layers (csrc/frost_common.h)
 COEF_A, COEF_B = 0, 1
 COEF_M, COEF_R, COEF_K1, COEF_S1, COEF_S2, COEF_VFRAC = 2, 3, 4, 5, 6, 7      # FROST_COEF_* of include/frost_hip.h
-STATS_BYTES_PER_CH = 96      # FROST_STATS_BYTES_PER_CH: four replicated 24-byte-per-channel tables (ABI 5)
+STATS_BYTES_PER_CH = 24 * int(os.environ.get("FROST_STATS_TABLES", "4"))      # FROST_STATS_BYTES_PER_CH: four replicated 24-byte-per-channel tables (ABI 5)
 
 
 class FrostWDesc(C.Structure):

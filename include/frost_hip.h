@@ -40,7 +40,9 @@ extern "C" {
  *          floats, all zeroed by the caller: the fused pointwise / depthwise backward kernels spread their flush atomics over the copies, frost_weight_grad_finalize[_table]
  *          and frost_stem_wgrad_remap add them up; every other producer writes copy 0.  Larger layers keep one copy.
  *          New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
+#ifndef FROST_DWQ_NC          /* (a -D override is a dev A/B build: the binding must be told the same value, FROST_DWQ_NC / FROST_COEF_ROWS_ALLOC / FROST_STATS_TABLES in the environment) */
 #define FROST_DWQ_NC 4
+#endif
 #define FROST_DWQ_SPREAD_MAX 32768
 #define FROST_ABI_VERSION 5
 
@@ -72,13 +74,17 @@ extern "C" {
 /* rows a caller ALLOCATES per coefficient table (ABI 5): the 8 rows above + 3 more copies of the S1 / S2 rows (rows 8 + 2 (k - 1) + {0, 1}, k = 1 .. 3).  The backward
  * reduce passes spread their float atomics over the four copies by workgroup index; every reader (dc passes, parameter-gradient finalize) adds the copies up; the forward
  * finalize zeroes all of them.  Rows 5 / 6 alone are the totals only where a kernel writes totals (the fp32-gradient mode). */
+#ifndef FROST_COEF_ROWS_ALLOC
 #define FROST_COEF_ROWS_ALLOC 14
+#endif
 
 /* stats scratch per conv layer: FROST_STATS_TABLES identical tables of 24 bytes per (padded) channel -- int64 sum, uint64 sumsq, int32 min, int32 max,
  * laid out SoA: [cpad] i64 | [cpad] u64 | [cpad] i32 | [cpad] i32 -- one after the other.  The statistics kernels spread their flush atomics over the tables by
  * workgroup index, the finalize adds them up (exact integers: the result does not depend on the spread); frost_stats_init_table / frost_step_prologue reset all of
  * them.  A caller sizes the buffer as cpad * FROST_STATS_BYTES_PER_CH (ABI 5: was ONE table, 24 bytes per channel). */
+#ifndef FROST_STATS_TABLES
 #define FROST_STATS_TABLES 4
+#endif
 #define FROST_STATS_BYTES_PER_CH (24 * FROST_STATS_TABLES)
 
 int frost_abi_version(void);
