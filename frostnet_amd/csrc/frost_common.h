@@ -217,6 +217,9 @@ __device__ __forceinline__ float* dwq_dst(float* dwq, int64_t numel) {
   const unsigned b = blockIdx.x;
   return (numel <= FROST_DWQ_SPREAD_MAX) ? dwq + (int64_t)(((b >> 3) ^ b) & (FROST_DWQ_NC - 1)) * dwq_stride(numel) : dwq;
 }
+__device__ __forceinline__ float* dwq_dst_k(float* dwq, int64_t numel, int k) {          // ... with the copy chosen by the caller (split-K kernels: the pixel split)
+  return (numel <= FROST_DWQ_SPREAD_MAX) ? dwq + (int64_t)(k & (FROST_DWQ_NC - 1)) * dwq_stride(numel) : dwq;
+}
 __device__ __forceinline__ float dwq_sum(const float* dwq, int64_t numel, int64_t idx) {
   float s = dwq[idx];
   if (numel <= FROST_DWQ_SPREAD_MAX) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (WG_PFD > 1) ? 2 : 3) void k_pw_wgrad(const ui
   const float sx = qx[FROST_Q_SCALE];
   for (int i = tid; i < WT * WT; i += 256) {
     const int co = co0 + i / WT, ci = ci0 + i % WT;
-    if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, red[i] * sx);
+    if (co < cout && ci < cin) atomicAdd(dwq_dst_k(dwq, (int64_t)cout * cin, split) + (int64_t)co * cin + ci, red[i] * sx);          // small layers: the splits of a tile spread over the dwq copies (frost_common.h)
   }
 }
 // Large-channel variant: 128x128 (co x ci) output tile over ALL 128 staged pixels (4 K-steps), 8 waves: wave w owns the
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, (NB == 2) ? 2 : 1) void k_pw_wgrad_big(const u
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + qa * 64 + a * 16 + 4 * g + r, ci = ci0 + qb * (NB * 16) + b * 16 + i16;
-          if (co < cout && ci < cin) atomicAdd(dwq + (int64_t)co * cin + ci, acc[a][b][r] * sx);
+          if (co < cout && ci < cin) atomicAdd(dwq_dst_k(dwq, (int64_t)cout * cin, split) + (int64_t)co * cin + ci, acc[a][b][r] * sx);
         }
       }
 }
