@@ -69,7 +69,7 @@ def cpu_baseline(res=224, batch=64, timed=3):
 PMC_TAGS = ("r06", "r05", "r04", "r03", "r02")
 
 
-def extra_leg(extra_args, extra_env=None, timeout=420):
+def extra_leg(extra_args, extra_env=None, timeout=200):
     """One more single-GPU measurement of THIS script in a child process (its own device context: a failure or a stalled RCCL bring-up there costs this
     run a field, not its headline).  Returns the child's JSON line as a dict, or {"error": ...}."""
     import subprocess
@@ -856,7 +856,7 @@ def main():
             extras["fp32_grad_ms_per_step"] = g32.get("ms_per_step")
             if "error" in g32:
                 extras["fp32_grad_error"] = g32["error"]
-            dpl = extra_leg(shape + ["--steps", "10", "--warmup", "3", "--force-dp"])
+            dpl = extra_leg(shape + ["--steps", "10", "--warmup", "3", "--force-dp"], {"FROST_RDZV_TIMEOUT": "60"})          # (a communicator bring-up that stalls costs a minute, not the line)
             if "error" in dpl:
                 extras["dp_overhead_ms"] = None
                 extras["dp_overhead_error"] = dpl["error"]
