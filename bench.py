@@ -880,7 +880,7 @@ def main():
                    scaling="weak", vs_baseline=None, dtype="int8", data="synthetic",
                    config=dict(workload=what,
                                per_gpu_batch=args.batch, global_batch=args.batch * world, resolution=args.res,
-                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype=("fp32" if runner.E.grad_fp32 else "bf16"),
+                               parallelism=f"dp{world}", hip_graph=graph is not None, grad_dtype=("fp32" if runner.E.grad_fp32 else ("mixed (fp32 on maps <= 14 x 14, bf16 above)" if getattr(runner.E, "grad_mixed", False) else "bf16")),
                                ms_per_step_median_hip_events=round(ms_median, 3),
                                grad_allreduce=comm, **extras),
                    roofline=roofline, cpu_baseline=cpu)

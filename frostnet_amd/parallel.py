@@ -153,7 +153,7 @@ class SegmentedStep:
             loss.backward(gradient=self.gscale)
             for a, t in zip(acts, leaves):
                 g = t.grad if t.grad is not None else torch.zeros_like(t)
-                a.grad = float_to_grad(g, fp32=r.E.grad_fp32)
+                a.grad = float_to_grad(g, fp32=r.E.grad_is_fp32(a))
             r.bind_grads()
             r.E.backward(None, boundaries=self.boundaries, on_bucket=on_bucket)
             return loss.detach()

@@ -52,7 +52,7 @@ class _QATFeatFunction(torch.autograd.Function):
         for a, g in zip(ctx.acts, grads):     # tap gradients first; later layers' dgrads accumulate on top
             if g is None:
                 g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
-            a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_fp32)
+            a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_is_fp32(a))
         ctx.runner._backward_impl(None)
         return None, None, None
 
@@ -568,9 +568,9 @@ class FrostRunner:
         self._obs = obs
         gp = getattr(self.model, "grad_precision", None)          # "fp32": the fp32-gradient parity mode of the backward (csrc/frost_g32.hip); default bf16 storage
         if gp is not None:
-            if gp not in ("bf16", "fp32"):
-                raise ValueError("model.grad_precision must be 'bf16' or 'fp32'")
-            E.grad_fp32 = gp == "fp32"
+            if gp not in ("bf16", "fp32", "mixed"):
+                raise ValueError("model.grad_precision must be 'bf16', 'fp32' or 'mixed'")
+            E.grad_fp32, E.grad_mixed = gp == "fp32", gp == "mixed"
         late_at = None
         if _PREP_SIDE and training and not E.grad_fp32:
             # the per-step weight preparation (BN fold + weight fake-quant + packing of all 70 layers: a handful of latency-bound launches, ~165 us) has nothing to do
@@ -696,7 +696,7 @@ class _QATMapsFunction(torch.autograd.Function):
             for a, g in zip(ctx.acts, grads):
                 if g is None:
                     g = torch.zeros(a.n, a.c, a.h, a.w, device=a.buf.device)
-                a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_fp32)
+                a.grad = float_to_grad(g, fp32=ctx.runner.E.grad_is_fp32(a))
             ctx.runner._backward_impl(None)
         return None, None, None
 
