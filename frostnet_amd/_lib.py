@@ -229,6 +229,7 @@ _PROTOS = {
     "frost_stem_converted": [P, I, I, I, L, L, L, L, P, P, P, P, P, I, I, P, P],
     "frost_hswish_fwd": [P, P, L, P, P, P, P, I, P, P, P],
     "frost_hswish_bwd": [P, P, L, P, P, I, P],
+    "frost_hswish_converted": [P, P, L, P, P, P, P, P],
     "frost_classifier_q": [P, P, P, P, I, I, I, P, P, P, P],
     "frost_classifier_q_fb": [P, P, P, P, I, I, I, P, P, P, P],
 }

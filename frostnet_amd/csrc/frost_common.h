@@ -39,6 +39,9 @@ __device__ __forceinline__ int fq_index(float x, float inv, int zp, int lo, int 
 
 // ---- bf16 ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// hard-swish z * relu6(z + 3) / 6 in the order torch evaluates the reference's _Hswish (mobilenetv3.py:43-56): add_scalar, relu6, mul, mul_scalar(1/6).
+// The float and bf16-inference entries take it as activation code 2 of their `relu` argument (0 = none, 1 = ReLU).
+__device__ __forceinline__ float hswish_f(float z) { return (z * fminf(fmaxf(z + 3.0f, 0.0f), 6.0f)) * (1.0f / 6.0f); }
 __device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even
   uint32_t u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);

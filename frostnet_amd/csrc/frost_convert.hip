@@ -422,6 +422,48 @@ extern "C" int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n,
   hipLaunchKernelGGL(k_hsw_apply, dim3((unsigned)g), dim3(256), 0, s, x, n, lut, y);
   return frost_check_launch("hswish_fwd");
 }
+// The CONVERTED model's hard-swish (torch.quantization.convert of `_Hswish`: QFunctional.add_scalar -> nnq.ReLU6 -> QFunctional.mul -> QFunctional.mul_scalar on
+// quint8 tensors), again a 256-entry table of the input index -- but integer arithmetic, not the fake-quant graph's:
+//   add_scalar (ATen quantized BinaryOps _add_scalar_out): c_q = nearbyint(3 / s_x);  z_x - c_q in [0, 255]: same indices, zero point z_x - c_q;  below 0:
+//     scale s' = (255 - (z_x - c_q)) / 255 * s_x, zero point 0, indices requantised: 0 + lrintf((q - z_x + c_q) * (float(s_x) * (1.0f / float(s'))))
+//   relu6 (qrelu6): clamp(index, z', z' + nearbyint(6.0f * (1.0f / float(s'))))      -- no record of its own: nn.ReLU6's observer is NOT used after convert
+//   mul (qmul): z_m + lrintf(((q - z_x) * (t - z')) * (float(s_x) * float(s') * (1.0f / float(s_m)))), saturated to [0, 255]; (s_m, z_m) = quant_mul1's record
+//   mul_scalar(1/6): same indices, scale double(s_m) * (1/6)
+// tests: oracle.frost_oracle.converted_hswish_table (pinned against stock torch on the CPU, tests/golden g14) and the whole converted network against stock torch.
+__global__ __launch_bounds__(256) void k_hsw_cvt_lut(const float* qx, const float* qsite, float* qout, uint8_t* lut) {
+  const int q = threadIdx.x;
+  const float sxf = qx[FROST_Q_SCALE]; const int zx = __float_as_int(qx[FROST_Q_ZP]);
+  const double sx = (double)sxf;
+  const int c_q = (int)nearbyint(3.0 / sx);
+  int z1 = zx - c_q, a = q; float s1f = sxf;
+  if (z1 < 0) {
+    const double s1 = (255.0 - (double)z1) / 255.0 * sx;
+    s1f = (float)s1;
+    const float mult = sxf * (1.0f / s1f);
+    const int r = (int)lrintf((float)(q - zx + c_q) * mult);
+    a = min(max(r, 0), 255); z1 = 0;
+  }
+  const int six = min(max(z1 + (int)nearbyintf(6.0f * (1.0f / s1f)), 0), 255);
+  const int t = min(max(a, z1), six);
+  const float smf = qsite[FROST_Q_SCALE]; const int zm = __float_as_int(qsite[FROST_Q_ZP]);
+  const float mult2 = sxf * s1f * (1.0f / smf);
+  const int c = zm + (int)lrintf((float)((q - zx) * (t - z1)) * mult2);
+  lut[q] = (uint8_t)((min(max(c, 0), 255) - 128) & 255);
+  if (q == 0) {
+    for (int k = 0; k < FROST_Q_STRIDE; ++k) qout[k] = qsite[k];
+    const float s6 = (float)((double)smf * (1.0 / 6.0));
+    qout[FROST_Q_SCALE] = s6; qout[FROST_Q_INV] = 1.0f / s6;
+    qout[FROST_Q_FQMIN] = qsite[FROST_Q_FQMIN] * (1.0f / 6.0f); qout[FROST_Q_FQMAX] = qsite[FROST_Q_FQMAX] * (1.0f / 6.0f);
+  }
+}
+extern "C" int frost_hswish_converted(const int8_t* x, const float* qrec_x, int64_t n, const float* qrec_site, float* qrec_out, uint8_t* lut, int8_t* y, void* stream) {
+  FROST_REQUIRE(n % 4 == 0, "hswish_converted: n must be a multiple of 4");
+  hipStream_t s = as_stream(stream);
+  int64_t g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_hsw_cvt_lut, dim3(1), dim3(256), 0, s, qrec_x, qrec_site, qrec_out, lut);
+  hipLaunchKernelGGL(k_hsw_apply, dim3((unsigned)g), dim3(256), 0, s, x, n, lut, y);
+  return frost_check_launch("hswish_converted");
+}
 extern "C" int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream) {
   int64_t g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
   hipLaunchKernelGGL(k_hsw_bwd, dim3((unsigned)g), dim3(256), 0, as_stream(stream), gout, x, n, lut, dx, accumulate);

@@ -17,6 +17,18 @@ typedef short v4s16 __attribute__((ext_vector_type(4)));
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 
 enum { F_STATS = 0, F_EMIT = 1, F_BRED = 2, F_BDC = 3, F_PLAIN = 4 };      // F_PLAIN: out = conv (the data-gradient GEMM of the fp32 mode)
+// The `relu` argument of every entry is an activation code: 0 = none, 1 = ReLU, 2 = hard-swish z * relu6(z + 3) / 6 (the reference's _Hswish,
+// Classification/models/imagenet/mobilenetv3.py:43-56, in the order torch evaluates it: add_scalar, relu6, mul, mul_scalar(1/6)).  The backward passes
+// recompute z from the kept conv output and scale the incoming gradient by the derivative: ReLU's mask, or for hard-swish
+// (relu6(z + 3) + z * [0 < z + 3 < 6]) / 6 -- hardtanh's open-interval gradient, as autograd forms it.
+enum { F_ACT_NONE = 0, F_ACT_RELU = 1, F_ACT_HSWISH = 2 };
+__device__ __forceinline__ float f_act(float z, float lo, bool hs) {
+  return hs ? hswish_f(z) : fmaxf(z, lo);
+}
+__device__ __forceinline__ float f_dhswish(float z) {
+  const float t = z + 3.0f;
+  return (fminf(fmaxf(t, 0.0f), 6.0f) + ((t > 0.0f && t < 6.0f) ? z : 0.0f)) * (1.0f / 6.0f);
+}
 // element access for the two storage types
 template <typename T> struct FEl;
 template <> struct FEl<uint16_t> {
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
   };
   const int rowb = cin * (int)sizeof(ET); const int U = (KB * 64) >> 4;
   const int CT = cpad >> 4;
-  const float lo = relu ? 0.0f : -INFINITY;
+  const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t p0 = tile * IPX;
     __syncthreads();
@@ -314,14 +326,17 @@ __global__ __launch_bounds__(256) void k_f_pw(const FrostFDesc* dp, const ET* __
             if (y && ok) { const float o4[4] = {a[0], a[1], a[2], a[3]}; FEl<ET>::st4(y + prow * ldy + ch0, o4); }       // the conv output itself (training: kept for the element-wise passes)
           } else if constexpr (MODE == F_EMIT) {
             if (ok) {
-              const float o4[4] = {fmaxf(fmaf(a[0], sc[0], bi[0]), lo), fmaxf(fmaf(a[1], sc[1], bi[1]), lo),
-                                   fmaxf(fmaf(a[2], sc[2], bi[2]), lo), fmaxf(fmaf(a[3], sc[3], bi[3]), lo)};
+              const float o4[4] = {f_act(fmaf(a[0], sc[0], bi[0]), lo, hs), f_act(fmaf(a[1], sc[1], bi[1]), lo, hs),
+                                   f_act(fmaf(a[2], sc[2], bi[2]), lo, hs), f_act(fmaf(a[3], sc[3], bi[3]), lo, hs)};
               FEl<ET>::st4(y + prow * ldy + ch0, o4);
             }
           } else {
             float gm[4];
             FEl<ET>::cv4(gpre[t][m], gm);               // requested before the K loop (zeros outside the tensor)
-            if (relu) {
+            if (hs) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) gm[r] *= f_dhswish(fmaf(a[r], sc[r], bi[r]));
+            } else if (relu) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) if (!(fmaf(a[r], sc[r], bi[r]) > 0.0f)) gm[r] = 0.0f;
             }
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
   SA s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
-  const float lo = relu ? 0.0f : -INFINITY;
+  const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
   if (slot < PP) {
     for (int64_t u = u_lo + slot; u < nunits; u += PP) {
       int64_t pp = u; const int oxg = (int)(pp % wog); pp /= wog; const int oy = (int)(pp % ho); const int in = (int)(pp / ho);
@@ -565,12 +580,15 @@ __global__ __launch_bounds__(256) void k_f_dw(const FrostFDesc* dp, const ET* __
         } else if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(acc[o][e], sc[e], bi[e]), lo);
+          for (int e = 0; e < 8; ++e) o8[e] = f_act(fmaf(acc[o][e], sc[e], bi[e]), lo, hs);
           FEl<ET>::st8(y + p * c + ch, o8);
         } else {
           float gm[8];
           FEl<ET>::cv8(graw[o], gm);
-          if (relu) {
+          if (hs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[e] *= f_dhswish(fmaf(acc[o][e], sc[e], bi[e]));
+          } else if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (!(fmaf(acc[o][e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
           }
@@ -630,10 +648,10 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
       for (int kx = 0; kx < K; ++kx) wt[ky][kx] = *(const v2f*)(wf + (ky * K + kx) * cpad + ch);
     v2f sc = (v2f){1.0f, 1.0f}, bi = (v2f){0.0f, 0.0f};
     if (MODE == F_EMIT) { sc = *(const v2f*)(dp->coef + FC_SCALE * cpad + ch); bi = *(const v2f*)(dp->coef + FC_BIAS * cpad + ch); }
-    v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY;
-    if (SRC) { ssc = *(const v2f*)(dsrc->coef + FC_SCALE * cpad + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * cpad + ch); slo = relu_src ? 0.0f : -INFINITY; }
-    auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){fmaxf(fmaf(v[0], ssc[0], sbi[0]), slo), fmaxf(fmaf(v[1], ssc[1], sbi[1]), slo)} : v; };
-    const float lo = relu ? 0.0f : -INFINITY;
+    v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; bool shs = false;
+    if (SRC) { ssc = *(const v2f*)(dsrc->coef + FC_SCALE * cpad + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * cpad + ch); slo = relu_src ? 0.0f : -INFINITY; shs = relu_src == F_ACT_HSWISH; }
+    auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){f_act(fmaf(v[0], ssc[0], sbi[0]), slo, shs), f_act(fmaf(v[1], ssc[1], sbi[1]), slo, shs)} : v; };
+    const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
     const int rows = n * ho;
     for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {
       const int in = r / ho, oy = r - in * ho;
@@ -690,7 +708,7 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
               s0 += (SA)acc[0]; s1 += (SA)acc[1]; q0 += (SA)acc[0] * (SA)acc[0]; q1 += (SA)acc[1] * (SA)acc[1];
               if (orow) FdwOut<ET>::st(orow + (int64_t)ox * c, acc);
             } else {
-              const v2f o = (v2f){fmaxf(fmaf(acc[0], sc[0], bi[0]), lo), fmaxf(fmaf(acc[1], sc[1], bi[1]), lo)};
+              const v2f o = (v2f){f_act(fmaf(acc[0], sc[0], bi[0]), lo, hs), f_act(fmaf(acc[1], sc[1], bi[1]), lo, hs)};
               FdwOut<ET>::st(orow + (int64_t)ox * c, o);
             }
           }
@@ -813,7 +831,7 @@ __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __
   SA s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
-  const float lo = relu ? 0.0f : -INFINITY;
+  const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
   if (slot < PP) {
     for (int64_t p0 = slot; p0 < npix; p0 += 4 * PP) {          // four pixels per trip: their loads are in flight together
       typename FEl<ET>::R8 ra[4], rg[4];
@@ -832,12 +850,15 @@ __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __
         if constexpr (MODE == F_EMIT) {
           float o8[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] = fmaxf(fmaf(a[e], sc[e], bi[e]), lo);
+          for (int e = 0; e < 8; ++e) o8[e] = f_act(fmaf(a[e], sc[e], bi[e]), lo, hs);
           FEl<ET>::st8(y + p * ldy + ch, o8);
         } else {
           float gm[8];
           FEl<ET>::cv8(rg[u], gm);
-          if (relu) {
+          if (hs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[e] *= f_dhswish(fmaf(a[e], sc[e], bi[e]));
+          } else if (relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) if (!(fmaf(a[e], sc[e], bi[e]) > 0.0f)) gm[e] = 0.0f;
           }
@@ -1109,9 +1130,9 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
   for (int ky = 0; ky < K; ++ky)
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) acc[ky][kx] = (v2f){0.0f, 0.0f};
-  v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY;          // SRC: x is the kept conv output of the layer in front (see k_f_dw_row<SRC>)
-  if (SRC && live) { const int scp = dsrc->cpad; ssc = *(const v2f*)(dsrc->coef + FC_SCALE * scp + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * scp + ch); slo = relu_src ? 0.0f : -INFINITY; }
-  auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){fmaxf(fmaf(v[0], ssc[0], sbi[0]), slo), fmaxf(fmaf(v[1], ssc[1], sbi[1]), slo)} : v; };
+  v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; bool shs = false;          // SRC: x is the kept conv output of the layer in front (see k_f_dw_row<SRC>)
+  if (SRC && live) { const int scp = dsrc->cpad; ssc = *(const v2f*)(dsrc->coef + FC_SCALE * scp + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * scp + ch); slo = relu_src ? 0.0f : -INFINITY; shs = relu_src == F_ACT_HSWISH; }
+  auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){f_act(fmaf(v[0], ssc[0], sbi[0]), slo, shs), f_act(fmaf(v[1], ssc[1], sbi[1]), slo, shs)} : v; };
   const int rows = n * ho;
   if (live) {
     for (int r = (blockIdx.x * 4 + wv) * RPW + rsub; r < rows; r += gridDim.x * 4 * RPW) {

@@ -1,11 +1,14 @@
 // bf16 inference of the FLOAT (not fake-quantised) FrostNet graph -- BASELINE.json config c2 (Large, B = 256, bf16).
 // Eval-mode BatchNorm is folded into the conv (W' = W * gamma/sqrt(rv+eps), b' = beta - rm * gamma/sqrt(rv+eps)) once per call
 // by frost_infer_weight_prep; activations are NHWC bf16; every conv accumulates in fp32 (bf16 MFMA 16x16x32 for the 1x1s and the
-// im2col'd stem, fp32 FMA for the depthwise convs), adds the folded bias, applies ReLU and rounds to bf16 once.
+// im2col'd stem, fp32 FMA for the depthwise convs), adds the folded bias, applies the activation (ReLU, or hard-swish for act='hswish' networks) and rounds to bf16 once.
 // replaces (eval mode, float model): frostnet.py:14-60 ConvBNReLU / ConvBN, :108-121 block wiring, :295-299 head.
 #include "frost_common.h"
 
 typedef __bf16 v8bf16 __attribute__((ext_vector_type(8)));
+
+// activation of an inference epilogue: the `relu` argument is a code, 0 = none, 1 = ReLU, 2 = hard-swish (hswish_f, frost_common.h)
+__device__ __forceinline__ float i_act(float z, float lo, bool hs) { return hs ? hswish_f(z) : fmaxf(z, lo); }
 
 // ------------------------------------------------------------------------------------------------ weight preparation
 __device__ __forceinline__ float inf_sf(const FrostIDesc& d, int co) { return d.gamma ? d.gamma[co] / sqrtf(d.rvar[co] + FROST_BN_EPS) : 1.0f; }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void k_inf_stem(const float* __restrict__ x, i
   // K block 0: k = 8 g .. 8 g + 7 = taps 2 g and 2 g + 1; K block 1: tap 8 in group 0, zero elsewhere
   const int t0 = 2 * g, t1 = 2 * g + 1;
   const int off0 = (t0 / 3) * IS_LW + t0 % 3, off1 = (t1 / 3) * IS_LW + t1 % 3, off8 = 2 * IS_LW + 2;
-  const float flo = relu ? 0.0f : -INFINITY;
+  const float flo = relu ? 0.0f : -INFINITY; const bool hs = relu == 2;
   __syncthreads();
   const int nxt = min(IS_XT, (wo - ox0 + 15) >> 4);
   uint16_t* dst = y + (int64_t)in * ho * wo * cout;
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(256) void k_inf_stem(const float* __restrict__ x, i
       const int ch = ct * 16 + 4 * g;
       if (oy < ho && ox < wo && ch < cout) {
         uint2 o;
-        o.x = cvt_pk_bf16(fmaxf(acc[0] + bb[ct].x, flo), fmaxf(acc[1] + bb[ct].y, flo));
-        o.y = cvt_pk_bf16(fmaxf(acc[2] + bb[ct].z, flo), fmaxf(acc[3] + bb[ct].w, flo));
+        o.x = cvt_pk_bf16(i_act(acc[0] + bb[ct].x, flo, hs), i_act(acc[1] + bb[ct].y, flo, hs));
+        o.y = cvt_pk_bf16(i_act(acc[2] + bb[ct].z, flo, hs), i_act(acc[3] + bb[ct].w, flo, hs));
         *(uint2*)(dst + ((int64_t)oy * wo + ox) * cout + ch) = o;
       }
     }
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void k_inf_dw(const uint16_t* __restrict__ x, 
   constexpr int PAD = (K - 1) / 2, SPAN = (IDW_WO - 1) * S + K;
   const int c8n = c >> 3; const int wo4 = (wo + IDW_WO - 1) / IDW_WO;
   const int64_t tot = (int64_t)n * ho * wo4 * c8n;
-  const float lo = relu ? 0.0f : -INFINITY;
+  const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == 2;
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     const int c8 = (int)(i % c8n); int64_t p = i / c8n; const int oxg = (int)(p % wo4); p /= wo4; const int oy = (int)(p % ho); const int in = (int)(p / ho);
     const int ch = c8 * 8, ox0 = oxg * IDW_WO, ix0 = ox0 * S - PAD;
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256) void k_inf_dw(const uint16_t* __restrict__ x, 
     for (int o = 0; o < IDW_WO; ++o) {
       if (ox0 + o < wo) {
         uint4 ov;
-        ov.x = cvt_pk_bf16(fmaxf(acc[o][0], lo), fmaxf(acc[o][1], lo)); ov.y = cvt_pk_bf16(fmaxf(acc[o][2], lo), fmaxf(acc[o][3], lo));
-        ov.z = cvt_pk_bf16(fmaxf(acc[o][4], lo), fmaxf(acc[o][5], lo)); ov.w = cvt_pk_bf16(fmaxf(acc[o][6], lo), fmaxf(acc[o][7], lo));
+        ov.x = cvt_pk_bf16(i_act(acc[o][0], lo, hs), i_act(acc[o][1], lo, hs)); ov.y = cvt_pk_bf16(i_act(acc[o][2], lo, hs), i_act(acc[o][3], lo, hs));
+        ov.z = cvt_pk_bf16(i_act(acc[o][4], lo, hs), i_act(acc[o][5], lo, hs)); ov.w = cvt_pk_bf16(i_act(acc[o][6], lo, hs), i_act(acc[o][7], lo, hs));
         *(uint4*)(y + (((int64_t)in * ho + oy) * wo + ox0 + o) * c + ch) = ov;
       }
     }

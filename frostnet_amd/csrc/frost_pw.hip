@@ -40,7 +40,7 @@ struct PwP {
   int cres;                       // BN/quant coefficient rows (folded) live in LDS even when the weights do not (RES)
   int io, io_bytes, g_bytes, o_bytes;   // io bit0: gout tile arrives by DMA (reduce/dc passes); bit1: outputs leave through an LDS tile
   int gl, tile_bytes;             // gl: linear double-buffered LDS tile image filled by direct-to-LDS loads
-  const float* bias; int act_relu;   // bf16 GEMM mode used as an inference layer: + bias[ch], optional ReLU (qw == NULL: no weight scale)
+  const float* bias; int act_relu;   // bf16 GEMM mode used as an inference layer: + bias[ch], activation code 0 none / 1 ReLU / 2 hard-swish (qw == NULL: no weight scale)
   // fused backward (k_pw<M_BDC, .., FTW > 0>): the dc tile never leaves LDS -- data gradient and weight gradient are taken from it
   const uint8_t* wtp; int KSd;       // bf16 transposed weight pack [cin tile][co step][lane][16 B], K steps of 32 output channels
   float* dwq;                        // fp32 dL/dWq accumulator [cout][cin] (atomics, one flush per workgroup)
@@ -458,13 +458,17 @@ __global__ __launch_bounds__(512, (FTW > 0) ? PW_FUSE_MINW : PW_MINW(MODE, WP)) 
             uint16_t* base = p.dx + p0 * p.cout;
             float bv[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && chok) { const float4 b4 = *(const float4*)(p.bias + ch0); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-            const float flo = p.act_relu ? 0.0f : -INFINITY;
+            const float flo = p.act_relu == 1 ? 0.0f : -INFINITY;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
               const int prow = (wp * NT + t) * 16 + j;
               float v[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(accf[m][t][r], sw, bv[r]), flo);
+              if (p.act_relu == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = hswish_f(v[r]);
+              }
               if (o_lds) {
                 if (chok) { uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); *(uint2*)(gcur + (prow * p.cout + ch0) * 2) = o; }
               } else if ((FULL || (p0 + prow) < p.npix) && chok) {

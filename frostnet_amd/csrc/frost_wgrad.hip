@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256, 2) void k_dgrad_wide(const uint16_t* __restric
       uint16_t* dst = dx + p * cin + ci;
       float v[4] = {acc[m][t][0] * sw, acc[m][t][1] * sw, acc[m][t][2] * sw, acc[m][t][3] * sw};
       if (bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-      if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      else if (relu == 2) { v[0] = hswish_f(v[0]); v[1] = hswish_f(v[1]); v[2] = hswish_f(v[2]); v[3] = hswish_f(v[3]); }
       if (accumulate) { const uint2 o = prev[m][t]; v[0] += bf2f(o.x & 0xffff); v[1] += bf2f(o.x >> 16); v[2] += bf2f(o.y & 0xffff); v[3] += bf2f(o.y >> 16); }
       uint2 o; o.x = cvt_pk_bf16(v[0], v[1]); o.y = cvt_pk_bf16(v[2], v[3]);
       *(uint2*)dst = o;

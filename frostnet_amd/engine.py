@@ -550,6 +550,14 @@ class Engine:
         self.tape.append(("hswish", x, y, lut))
         return y
 
+    def hswish_converted(self, x, q_site, q_out):
+        """The converted model's hard-swish on a quint8 activation (QFunctional.add_scalar -> nnq.ReLU6 -> QFunctional.mul at quant_mul1's frozen record -> mul_scalar):
+        a 256-entry table of the input index built on the device from the two records (csrc/frost_convert.hip k_hsw_cvt_lut), then one pass."""
+        lut = torch.empty(256, dtype=torch.uint8, device=self.device)
+        y = self.new_act(x.n, x.h, x.w, x.c, q_out)
+        call("frost_hswish_converted", ptr(x.buf), ptr(x.q), x.numel, ptr(q_site), ptr(q_out), ptr(lut), ptr(y.buf), stream(), prof=("hswish_converted", 2 * x.numel))
+        return y
+
     def head(self, l, x, drop_mask=None, observe=True):
         """AdaptiveAvgPool2d(1) -> Dropout -> nnqat.Conv2d(1280,nclass,1) + activation FQ (frostnet.py:295-299)."""
         n, c = x.n, x.c
@@ -593,7 +601,8 @@ class Engine:
             x = xc
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
         self._converted_coef(l, x.q, fb)
-        if cat is not None and _BLOCK_SQCAT and l.kind == "pw" and L.load_library().frost_sq_emit_cat_ok(x.c, l.cout):
+        hsw = getattr(l, "hswish", None)
+        if hsw is None and cat is not None and _BLOCK_SQCAT and l.kind == "pw" and L.load_library().frost_sq_emit_cat_ok(x.c, l.cout):
             # squeeze_conv of a CAS bottleneck: the converted emit and both halves of the cat (records frozen) in one launch
             ycat = self.new_act(x.n, ho, wo, l.cout + x.c, cat)
             call("frost_sq_emit_cat", ptr(x.buf), ptr(x.q), ptr(l.wq_pack), ptr(l.wsum), x.npix, x.c, l.cout, ptr(l.coef), ptr(l.qy), ptr(cat), ptr(y.buf), ptr(ycat.buf),
@@ -604,6 +613,10 @@ class Engine:
         self._conv_launch(l, x, 3 if fb else 2, y)
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
+        if hsw is not None:                       # ConvBNHswish: the conv emitted linearly at its own record; the hard-swish is a table pass
+            y = self.hswish_converted(y, hsw[1], hsw[2])
+            if getattr(self, "trace", None) is not None:
+                self.trace.append((l.name + ".act", y))
         return y
 
     def stem_converted(self, l, x, q_in, fb=False):
@@ -618,6 +631,8 @@ class Engine:
         y = self.new_act(n, ho, wo, l.cout, l.qy)
         call("frost_stem_converted", ptr(x), n, h, w, *x.stride(), ptr(q_in), ptr(l.wq_pack), ptr(l.wsum), ptr(l.coef), ptr(l.qy), l.cout, 3 if fb else 2,
              ptr(y.buf), stream())
+        if getattr(l, "hswish", None) is not None:
+            y = self.hswish_converted(y, l.hswish[1], l.hswish[2])
         return y
 
     def _converted_coef(self, l, qx, fb):

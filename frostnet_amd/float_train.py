@@ -55,6 +55,12 @@ _WGRAD_SIDE = os.environ.get("FROST_FLOAT_WGRAD_SIDE", "1") != "0"      # weight
 _LAZY_EMIT = os.environ.get("FROST_FLOAT_LAZY_EMIT", "1") != "0"        # training: conv1's activation is never written -- the depthwise kernels apply BN + ReLU to its kept conv output on load (A/B knob)
 
 
+def _act_code(mod):
+    """Activation code of the float kernels' `relu` argument (csrc/frost_float.hip: 0 none, 1 ReLU, 2 hard-swish) for an activated layer module."""
+    from .frostnet import ConvBNHswish
+    return 2 if isinstance(mod, ConvBNHswish) else 1
+
+
 class _FLayer:
     def __init__(self, name, seq, relu, dev, stem=False, fp32=False):
         conv, bn = seq[0], seq[1]
@@ -125,9 +131,6 @@ class FloatRunner:
     """Binds a float FrostNet (classification model or features backbone) to the float HIP kernels."""
 
     def __init__(self, model, precision=None):
-        if getattr(model, "act", "relu") != "relu":
-            raise NotImplementedError("the float (StatAssist warm-up) kernels implement the reference's ReLU network; act='hswish' runs on the device in "
-                                      "fake-quant (QAT-prepared) mode only")
         L.load_library()
         self._set_precision(precision or getattr(model, "float_precision", None))
         params = list(model.parameters())
@@ -138,13 +141,13 @@ class FloatRunner:
         self.model, self.device = model, params[0].device
         self._bind_params(params)
         self.layers = []
-        self.stem = self._add("conv1", model.conv1.conv, True, stem=True)
+        self.stem = self._add("conv1", model.conv1.conv, _act_code(model.conv1), stem=True)
         self.blocks, self.stage_ends = [], []
         for lname in ("layer1", "layer2", "layer3", "layer4", "layer5"):
             for bi, blk in enumerate(getattr(model, lname)):
                 self.blocks.append(self._bind_block(f"{lname}.{bi}", blk))
             self.stage_ends.append(len(self.blocks) - 1)
-        self.last = self._add("last_layer", model.last_layer.conv, True) if hasattr(model, "last_layer") else None
+        self.last = self._add("last_layer", model.last_layer.conv, _act_code(model.last_layer)) if hasattr(model, "last_layer") else None
         self.fc = model.classifier[2] if hasattr(model, "classifier") else None
         self.drop_rate = float(model.classifier[1].p) if self.fc is not None else 0.0
         self._finish()
@@ -194,10 +197,10 @@ class FloatRunner:
         ent = dict(blk=blk, squeeze=None, conv1=None)
         if blk.expand_ratio != 1:
             if blk.block_type == "CAS":
-                ent["squeeze"] = self._add(pre + ".squeeze_conv", blk.squeeze_conv.conv, True)
-            ent["conv1"] = self._add(pre + ".conv1", blk.conv1.conv, True)
-        ent["conv2"] = self._add(pre + ".conv2", blk.conv2.conv, True)
-        ent["reduce"] = self._add(pre + ".reduce_conv", blk.reduce_conv.conv, False)
+                ent["squeeze"] = self._add(pre + ".squeeze_conv", blk.squeeze_conv.conv, _act_code(blk.squeeze_conv))
+            ent["conv1"] = self._add(pre + ".conv1", blk.conv1.conv, _act_code(blk.conv1))
+        ent["conv2"] = self._add(pre + ".conv2", blk.conv2.conv, _act_code(blk.conv2))
+        ent["reduce"] = self._add(pre + ".reduce_conv", blk.reduce_conv.conv, 0)
         return ent
 
     def _finish(self):

@@ -100,26 +100,28 @@ class Bf16Inference:
 
     def __init__(self, model):
         L.load_library()
-        if getattr(model, "act", "relu") != "relu":
-            raise NotImplementedError("bf16 inference implements the reference's ReLU network (act='hswish' runs in fake-quant mode only)")
+        # act='hswish' networks (frostnet.py ConvBNHswish): the layer kernels take the activation as a code (0 none, 1 ReLU, 2 hard-swish); the fused
+        # bottleneck kernels (frost_infer_block / _block_w) are written for ReLU, so such a network runs layer by layer
+        self.hswish = getattr(model, "act", "relu") == "hswish"
+        A = 2 if self.hswish else 1
         p = next(model.parameters())
         if not p.is_cuda:
             raise RuntimeError("Bf16Inference needs the model on the GPU (no CPU fallback on the product path)")
         self.model, self.device = model, p.device
         self.layers = []
-        self.stem = self._add(model.conv1.conv, True, stem=True)
+        self.stem = self._add(model.conv1.conv, A, stem=True)
         self.blocks = []
         for stage in (model.layer1, model.layer2, model.layer3, model.layer4, model.layer5):
             for blk in stage:
                 ent = dict(blk=blk, squeeze=None, conv1=None)
                 if blk.expand_ratio != 1:
                     if blk.block_type == "CAS":
-                        ent["squeeze"] = self._add(blk.squeeze_conv.conv, True)
-                    ent["conv1"] = self._add(blk.conv1.conv, True)
-                ent["conv2"] = self._add(blk.conv2.conv, True)
-                ent["reduce"] = self._add(blk.reduce_conv.conv, False)
+                        ent["squeeze"] = self._add(blk.squeeze_conv.conv, A)
+                    ent["conv1"] = self._add(blk.conv1.conv, A)
+                ent["conv2"] = self._add(blk.conv2.conv, A)
+                ent["reduce"] = self._add(blk.reduce_conv.conv, 0)
                 self.blocks.append(ent)
-        self.last = self._add(model.last_layer.conv, True)
+        self.last = self._add(model.last_layer.conv, A)
         self.fc = model.classifier[2]
         self._table, self._ptrs, self._versions = None, None, None
 
@@ -214,7 +216,7 @@ class Bf16Inference:
         return self._block_fused(ent, a, c, n, h, w, choice)
 
     def _block(self, ent, a, c, n, h, w):
-        if _FUSED is False:
+        if _FUSED is False or self.hswish:
             return self._block_plain(ent, a, c, n, h, w)
         # the measured choice is kept per (resolution, batch BUCKET): a last partial batch or a slightly different batch size reuses its bucket's choice instead of
         # re-running dozens of timed launches inside the caller's forward, and the table stays bounded
@@ -277,7 +279,7 @@ class Bf16Inference:
         if _STEM_DIRECT and L.load_library().frost_infer_stem_ok(self.stem.cout):
             a = torch.empty(npix * self.stem.cout, dtype=torch.int16, device=self.device)
             call("frost_infer_stem", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(self.stem.pack), ptr(self.stem.biasf),
-                 self.stem.cout, 1, ptr(a), stream())
+                 self.stem.cout, int(self.stem.relu), ptr(a), stream())
         else:
             col = torch.empty(npix * 64 + 64, dtype=torch.int16, device=self.device)
             call("frost_infer_stem_im2col", ptr(x), n, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3), ptr(col), stream())

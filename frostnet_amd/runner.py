@@ -424,9 +424,6 @@ class FrostRunner:
         pooled features are not re-quantised; the two differ by 8-25 % of the activations' indices, see tests/test_gpu_convert.py)."""
         if getattr(self, "converted", False):
             return self                          # idempotent: a second convert() must not move the weight observers again
-        if any(getattr(l, "hswish", None) is not None for l in self.E.layers):
-            raise NotImplementedError("convert() of a hard-swish network: the converted-inference kernels restate the QNNPACK ReLU graph; the "
-                                      "hard-swish variant runs the fake-quant graph (train / eval)")
         pcs = [l.per_channel for l in self.E.layers]
         if any(pcs) and not all(pcs):
             raise NotImplementedError("convert(): mixed per-tensor / per-channel weight quantisation")

@@ -39,7 +39,8 @@ extern "C" {
  *          A raw weight-gradient buffer (`dwq`) of a layer with at most FROST_DWQ_SPREAD_MAX (32768) weights is FROST_DWQ_NC (4) copies at a stride of round_up(weights, 64)
  *          floats, all zeroed by the caller: the fused pointwise / depthwise backward kernels spread their flush atomics over the copies, frost_weight_grad_finalize[_table]
  *          and frost_stem_wgrad_remap add them up; every other producer writes copy 0.  Larger layers keep one copy.
- *          New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok. */
+ *          New entries (additive): frost_step_prologue, frost_block_dw_bwd_c1 / _c1_ok, frost_hswish_converted.  The `relu` argument of the frost_float_* and
+ *          frost_infer_pw / _dw / _stem entries is an activation code: 0 none, 1 ReLU, 2 hard-swish (0 / 1 mean what they meant). */
 #ifndef FROST_DWQ_NC          /* (a -D override is a dev A/B build: the binding must be told the same value, FROST_DWQ_NC / FROST_COEF_ROWS_ALLOC / FROST_STATS_TABLES in the environment) */
 #define FROST_DWQ_NC 4
 #endif
@@ -656,6 +657,10 @@ int frost_classifier_q(const int32_t* pooled, const float* qrec_x, const int8_t*
 int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n, uint32_t* present8, float* qrec_relu6, float* qrec_site, float* qrec_out,
                      int observe, uint8_t* lut, int8_t* y, void* stream);
 int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream);
+/* replaces: the same `_Hswish` after torch.quantization.convert (Classification/evaluate.py:130-134 on a hard-swish network): QFunctional.add_scalar(x, 3) ->
+ * nnq.ReLU6 -> QFunctional.mul(x, .) at quant_mul1's frozen record (qrec_site) -> mul_scalar(1/6), integer arithmetic on quint8 indices restated as a 256-entry
+ * table of the input index (lut: >= 256 bytes).  qrec_out is written: qrec_site's indices at scale double(s) * (1/6).  n % 4 == 0. */
+int frost_hswish_converted(const int8_t* x, const float* qrec_x, int64_t n, const float* qrec_site, float* qrec_out, uint8_t* lut, int8_t* y, void* stream);
 
 /* ---- SSD MultiBoxLoss (Object_Detection/layers/modules/multibox_loss.py:48-117 + layers/box_utils.py:71-139) ------------------------------------------------
  * frost_mbox_forward: loc [n][p][4], conf [n][p][c], priors [p][4] (cx, cy, w, h), boxes [n][k][5] (x1, y1, x2, y2, label) with valid [n][k] (padding rows 0).

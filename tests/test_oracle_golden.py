@@ -454,6 +454,21 @@ def test_g10_hswish(golden):
 G12 = ["pw16_96", "dw5s1_144", "pw312_80_lin"]
 
 
+def test_g14_hswish_converted(golden):
+    """The converted model's hard-swish as a table of the quint8 input index (oracle.converted_hswish_table) against the REFERENCE's `_Hswish` converted by stock
+    torch and run on both CPU engines (tools/gen_golden.py g14): every table entry and the output qparams, both branches of add_scalar."""
+    g = golden("g14_hswish_converted")
+    branches = set()
+    for ci in range(len(g["cases"])):
+        for eng in ("qnnpack", "fbgemm"):
+            sx, zx, sm, zm, so, zo = g[f"c{ci}_{eng}_qp"]
+            tab, s_out, z_out = O.converted_hswish_table(sx, zx, sm, zm)
+            assert np.array_equal(tab, g[f"c{ci}_{eng}_table"]), (ci, eng, np.nonzero(tab != g[f"c{ci}_{eng}_table"])[0][:8])
+            assert s_out == so and z_out == zo, (ci, eng)
+            branches.add(bool(zx - int(np.rint(3.0 / sx)) < 0))
+    assert branches == {True, False}
+
+
 @pytest.mark.parametrize("name", G12)
 def test_g12_fbgemm_layer(golden, name):
     """The reference's 'fbgemm' qconfig (Classification/latency_check.py:221-226), QAT flavour: per-channel symmetric weights

@@ -547,6 +547,37 @@ def g10_hswish():
     save("g10_hswish", **out)
 
 
+# ------------------------------------------------------------------------------------------ G14 (SURVEY N4 after convert)
+def g14_hswish_converted():
+    """The reference's `_Hswish` prepared for QAT, calibrated by one train-mode step on the dequantised input indices that are present, converted
+    (torch.quantization.convert, as Classification/evaluate.py:130-134 converts a network) and applied to ALL 256 quint8 input indices on both CPU engines:
+    the output index table + qparams per case.  Cases cover both branches of add_scalar (zero point shifted in range / re-scaled)."""
+    from torch.ao.quantization import get_default_qat_qconfig, prepare_qat, convert
+    mv3 = refshim.load_mobilenetv3()
+    cases = [(0.0473, 131, 0, 256), (0.02297, 44, 0, 256), (0.129, 248, 100, 256), (0.0516, 22, 0, 200), (0.011, 162, 30, 256), (0.235, 10, 0, 64), (0.0871, 0, 0, 256),
+             (0.0302, 99, 0, 256), (0.0302, 100, 0, 256)]
+    out = dict(cases=np.array(cases, dtype=np.float64))
+    for ci, (sx, zx, lo, hi) in enumerate(cases):
+        sx = float(np.float32(sx))
+        for eng in ("qnnpack", "fbgemm"):
+            torch.backends.quantized.engine = eng
+            m = mv3._Hswish(inplace=False)
+            m.train()
+            m.qconfig = get_default_qat_qconfig("qnnpack", version=0)
+            prepare_qat(m, inplace=True)
+            idx = torch.arange(lo, hi, dtype=torch.float32)
+            m((idx.view(1, -1, 1, 1) - zx) * sx)                       # calibration: both observers see the values of indices lo .. hi-1
+            m.eval()
+            mc = convert(m, inplace=False)
+            xq = torch._make_per_tensor_quantized_tensor(torch.arange(256, dtype=torch.uint8).view(1, 256, 1, 1), sx, int(zx))
+            y = mc(xq)
+            out[f"c{ci}_{eng}_table"] = y.int_repr().flatten().clone()
+            out[f"c{ci}_{eng}_qp"] = np.array([sx, zx, float(m.quant_mul1.activation_post_process.scale[0]), float(m.quant_mul1.activation_post_process.zero_point[0]),
+                                               y.q_scale(), y.q_zero_point()], dtype=np.float64)
+    torch.backends.quantized.engine = "qnnpack"
+    save("g14_hswish_converted", **out)
+
+
 # ------------------------------------------------------------------------------------------ G11 (SURVEY N3)
 def g11_detection():
     """The reference's PriorBox (layers/functions/prior_box.py) and MultiBoxLoss (layers/modules/multibox_loss.py) on the 512x512 table of
@@ -653,8 +684,8 @@ def g8_features():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g4t"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g3c", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g4t"]
     fns = dict(g1=g1_fake_quant, g2=g2_observer, g3=g3_layers, g3c=g3_classifier, g4=g4_blocks, g5=g5_wholenet, g6=g6_optimizers,
-               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection, g12=g12_fbgemm, g13=g13_convert_fbgemm, g4t=g4_true_shapes)
+               g7=g7_scalars, g8=g8_features, g9=g9_convert, g10=g10_hswish, g11=g11_detection, g12=g12_fbgemm, g13=g13_convert_fbgemm, g14=g14_hswish_converted, g4t=g4_true_shapes)
     for w in which:
         fns[w]()
