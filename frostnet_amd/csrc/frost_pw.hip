@@ -994,6 +994,9 @@ static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   return f;
 }
 int frost_gemm_bf16_rows(const uint16_t* x, const uint16_t* pack, const float* bias, int64_t npix, int k, int n, int relu, uint16_t* y, hipStream_t s);      // frost_wgrad.hip
+int frost_pwc_stats_fin_ok(int64_t npix, int cin, int cout);                                                                                                    // frost_pwc.hip
+int frost_pwc_stats_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout, void* stats, const FrostFinDesc* fin,
+                        hipStream_t s);
 extern "C" int frost_pw_bwd_fused_ok(int64_t npix, int cin, int cout) { return fuse_plan(npix, cin, cout, true).ok; }
 
 extern "C" int frost_pw_conv_bwd_fused(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum,
@@ -1052,6 +1055,7 @@ extern "C" int frost_pw_conv_fwd_fin(const int8_t* x, const float* qrec_x, const
   FROST_REQUIRE(cin % 8 == 0 && cout % 4 == 0, "pw_fwd: cin must be a multiple of 8, cout of 4");
   FROST_REQUIRE(((uintptr_t)x & 15) == 0, "pw_fwd: x must be 16B aligned");
   FROST_REQUIRE(fin && fin->counter && fin->coef && fin->qrec_y, "pw_fwd_fin: incomplete finalize descriptor");
+  if (frost_pwc_stats_fin_ok(npix, cin, cout)) return frost_pwc_stats_fin(x, qrec_x, wq_pack, wsum, npix, cin, cout, stats, fin, as_stream(stream));      // wide layers: chunked form
   PwP p = {};
   p.T = (const uint8_t*)x; p.cout = cout; p.cpad = round_up(cout, 16); p.wpack = (const uint8_t*)wq_pack;
   p.wsum = wsum; p.qx = qrec_x; p.qy = fin->qrec_y; p.coef = fin->coef; p.stats = (uint8_t*)stats; p.relu = fin->relu;

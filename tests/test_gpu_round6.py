@@ -505,3 +505,29 @@ def test_hswish_network_convert_and_export_vs_stock_torch_cpu(L, backend):
     torch.backends.quantized.engine = "qnnpack"
     assert torch.isfinite(y_dev).all() and float(y_dev.std()) > 0
     assert torch.equal(y_cpu, y_dev), float((y_cpu - y_dev).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------------------
+# the forward statistics pass of the wide pointwise layers in the chunked layout (csrc/frost_pwc.hip MODE 3; frost_pw_conv_fwd_fin routes to it)
+@pytest.mark.parametrize("case", [(240, 1440, 7, 5, 192, 21), (288, 1728, 7, 5, 320, 9), (104, 624, 14, 5, 96, 10), (120, 360, 14, 3, 96, 7), (104, 312, 14, 5, 80, 17),
+                                  (144, 864, 14, 5, 192, 6, 2)], ids=lambda c: "_".join(str(v) for v in c))
+def test_chunked_forward_statistics_equal_the_tile_kernel(L, case, tmp_path):
+    """conv1's batch statistics (sum, sum of squares, min, max per channel: the replicated tables added up) from k_pwc<3> against k_pw's statistics pass
+    (FROST_PWC_STATS=0) on the same seeded bottleneck: bit for bit (same per-lane grouping of the fp32 square sums, integer sums across workgroups), and therefore
+    every forward coefficient row, output record, running statistic and the block's output; ragged pixel counts (17 x 196 = 52 tiles + 4 pixels) included."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digest(tag, env):
+        out = os.path.join(str(tmp_path), f"{tag}.npz")
+        log = os.path.join(str(tmp_path), f"{tag}.calls")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "block_digest.py"), out] + [str(v) for v in case], check=True, cwd=root,
+                       env=dict(os.environ, DIGEST_CALLS=log, **env), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        return np.load(out)
+    new, old = digest("pwc", {"FROST_PWC_STATS": "1"}), digest("pw", {"FROST_PWC_STATS": "0"})      # (1 = every layer the chunked kernels take; the default takes Cout >= 1024)
+    for key in ("stats1_s1", "stats1_s2", "stats1_mn", "stats1_mx", "coef1_fwd", "rmean1", "rvar1", "qy1", "qy2", "qy3", "y3"):
+        assert new[key].tobytes() == old[key].tobytes(), key
+    assert int(np.abs(new["stats1_s1"]).max()) > 0 and int(new["stats1_mn"].min()) < int(new["stats1_mx"].max())

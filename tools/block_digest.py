@@ -51,4 +51,12 @@ if os.environ.get("DIGEST_CALLS"):
 res = dict(y3=y3.buf[: y3.numel].cpu().numpy(), dx=x.grad[: x.numel].cpu().numpy())          # dx: bf16 bits, or fp32 values in the fp32-gradient mode
 for i, l in enumerate((l1, l2, l3), 1):
     res.update({f"dw{i}": l.w.grad.cpu().numpy(), f"dgamma{i}": l.gamma.grad.cpu().numpy(), f"dbeta{i}": l.beta.grad.cpu().numpy(), f"qy{i}": l.qy.cpu().numpy()})
+# conv1's forward statistics as the finalize saw them (the replicated tables summed) and what it derived: forward-side coefficient rows, running statistics
+from frostnet_amd._lib import STATS_BYTES_PER_CH
+nc, cp = STATS_BYTES_PER_CH // 24, l1.coef.numel() // L.COEF_ROWS
+tab = l1.stats.view(torch.uint8)[: cp * STATS_BYTES_PER_CH].cpu().numpy().reshape(nc, cp * 24)
+s1 = sum(t[: cp * 8].view(np.int64) for t in tab); s2 = sum(t[cp * 8: cp * 16].view(np.uint64) for t in tab)
+mn = np.min([t[cp * 16: cp * 20].view(np.int32) for t in tab], 0); mx = np.max([t[cp * 20: cp * 24].view(np.int32) for t in tab], 0)
+res.update(stats1_s1=s1, stats1_s2=s2, stats1_mn=mn, stats1_mx=mx, coef1_fwd=l1.coef.view(L.COEF_ROWS, cp)[[0, 1, 2, 3, 4, 7]].cpu().numpy(),
+           rmean1=l1.rmean.cpu().numpy(), rvar1=l1.rvar.cpu().numpy())
 np.savez(out, **res)

@@ -2,8 +2,8 @@
 
     python tools/replay_nodes.py <kernel_trace.csv> [--out profiles/r05_replay_nodes.txt] [--json profiles/r05_replay_nodes.json]
 
-The optimizer launch (k_gradboost) ends every step: the kernels between the last two of them are one replay of the captured step (plus the optimizer
-launch itself).  Reports the node count split into own kernels (k_* / frost_*), aten element-wise kernels, and runtime copy / fill kernels
+The optimizer launch (k_gradboost) ends every step: the kernels between two consecutive ones are one replay of the captured step (plus the optimizer
+launch itself); the step with the median span is reported.  Reports the node count split into own kernels (k_* / frost_*), aten element-wise kernels, and runtime copy / fill kernels
 (__amd_rocclr_*), the busy time, the gaps between consecutive kernels on the timeline, and one line per node.
 """
 import argparse
@@ -43,10 +43,14 @@ def main():
     marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
     if len(marks) < 2:
         sys.exit(f"fewer than two {a.marker} launches in the trace")
-    lo, hi = marks[-2] + 1, marks[-1] + 1
+    # the step with the MEDIAN span among the replays (the last one can overlap the profiler's own teardown, the first ones are eager / capture: round 6 found a
+    # 1.3 ms hole in the last step of one trace that no other step had -- tools/step_gaps.py lists every step)
+    spans = sorted((max(r[1] for r in rows[marks[i] + 1: marks[i + 1] + 1]) - rows[marks[i] + 1][0], i) for i in range(len(marks) - 1))
+    pick = spans[len(spans) // 2][1]
+    lo, hi = marks[pick] + 1, marks[pick + 1] + 1
     step = rows[lo:hi]
     t0 = step[0][0]
-    boundary_us = (t0 - rows[marks[-2]][1]) / 1e3          # end of the previous step's optimizer launch -> this step's first node
+    boundary_us = (t0 - rows[marks[pick]][1]) / 1e3        # end of the previous step's optimizer launch -> this step's first node
     cnt = collections.Counter(kind_of(r[2]) for r in step)
     busy = sum(e - s for s, e, *_ in step)
     # timeline gaps: time in which NO kernel of the step is running
