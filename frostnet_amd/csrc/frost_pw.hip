@@ -938,10 +938,11 @@ static int launch_pw(PwP& p, hipStream_t s) {
   return rc;
 }
 
+static int pw_wave_split(int CT);
 template <int MODE>
 static int dispatch_pw(PwP& p, hipStream_t s) {
   const int CT = p.cpad / 16;
-  int WPsel = CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
+  int WPsel = pw_wave_split(CT);
   int WC = 8 / WPsel;
   const int MI = PW_MI(MODE, WPsel);
   p.ngroups = (CT + WC * MI - 1) / (WC * MI);
@@ -965,6 +966,14 @@ static void set_tiling(PwP& p, int64_t npix, int rowbytes) {
   p.inv_count = 1.0f / (float)npix;
 }
 
+// pixel-wave split of the 8 waves for a layer of CT channel tiles: 8 pixel waves x 1 channel wave up to 4 tiles, 4 x 2 up to 8, 2 x 4 above.
+// FROST_PW_WP8_CT (dev): bit mask of CT values that take 8 x 1 instead (a tile count the channel waves cannot share evenly, e.g. 9 = 3 groups of 3 for one channel wave)
+static int pw_wave_split(int CT) {
+  static const long wp8 = getenv("FROST_PW_WP8_CT") ? strtol(getenv("FROST_PW_WP8_CT"), nullptr, 0) : 0;
+  if (CT < 63 && ((wp8 >> CT) & 1)) return 8;
+  return CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
+}
+
 // ---- fused backward (dc + dgrad + wgrad in one kernel), host side
 struct FusePlan { int ok, wp, ftw; size_t lds; int dxo_off, wtl_off, wtl_bytes, xb_off; };
 static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
@@ -978,7 +987,7 @@ static FusePlan fuse_plan(int64_t npix, int cin, int cout, bool want_dx) {
   if (cin > 512 || tile_bytes > 32 * 1024) return f;                         // the DMA'd linear x tile (set_tiling's gl rule)
   const int ntw = CT * ((cin + 15) / 16);
   if (ntw > 88) return f;
-  f.wp = CT <= 4 ? 8 : (CT <= 8 ? 4 : 2);
+  f.wp = pw_wave_split(CT);
   f.ftw = ntw <= 16 ? 2 : (ntw <= 48 ? 6 : 11);
   if ((f.wp == 4 && f.ftw != 2) || (f.wp == 2 && f.ftw == 2)) return f;     // instantiated pairs only
   const size_t io_bytes = (size_t)2 * 256 * cout + 64;

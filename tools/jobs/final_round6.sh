@@ -24,6 +24,7 @@ timeout 900 python bench.py --batch 64 --steps 5 --warmup 2 --no-graph --no-cpu-
 FROST_GRAD=fp32 timeout 900 python bench.py --batch 64 --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r06_grad_modes.jsonl
 FROST_GRAD=fp32 FROST_G32_PLAIN=1 timeout 1500 python bench.py --batch 64 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r06_grad_modes.jsonl
 FROST_GRAD=fp32 timeout 900 python bench.py --batch 512 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> gpurun_out/r06_grad_modes.jsonl
+FROST_GRAD=mixed timeout 900 python bench.py --batch 512 --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extras 2>/dev/null | tail -1 >> gpurun_out/r06_grad_modes.jsonl
 ( cd /tmp && export TMPDIR=/tmp && cd $OLDPWD && FROST_GRAD=fp32 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r06_g32 -o s -- python bench.py --batch 512 --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > gpurun_out/prof_r06_g32.log 2>&1 )
 f=$(find gpurun_out/prof_r06_g32 -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r06_g32_b512_kernel_stats.csv
 find gpurun_out/prof_r06_g32 -name "*kernel_trace.csv" -delete 2>/dev/null
