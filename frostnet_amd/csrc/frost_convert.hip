@@ -460,7 +460,7 @@ extern "C" int frost_hswish_converted(const int8_t* x, const float* qrec_x, int6
   FROST_REQUIRE(n % 4 == 0, "hswish_converted: n must be a multiple of 4");
   hipStream_t s = as_stream(stream);
   int64_t g = (n / 4 + 255) / 256; if (g > 2048) g = 2048; if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_hsw_cvt_lut, dim3(1), dim3(256), 0, s, qrec_x, qrec_site, qrec_out, lut);
+  if (qrec_site) hipLaunchKernelGGL(k_hsw_cvt_lut, dim3(1), dim3(256), 0, s, qrec_x, qrec_site, qrec_out, lut);      // NULL: `lut` (and qrec_out) were built by an earlier call
   hipLaunchKernelGGL(k_hsw_apply, dim3((unsigned)g), dim3(256), 0, s, x, n, lut, y);
   return frost_check_launch("hswish_converted");
 }

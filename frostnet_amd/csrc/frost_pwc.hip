@@ -14,7 +14,7 @@ struct PwcP {
   const int8_t* x; const float* qx; const int8_t* w; const int32_t* wsum;
   float* coef; const float* qy; const uint16_t* gout; uint16_t* dc; int8_t* y;
   int64_t npix; int cin, c, cpad, kstr, nchunk, csplit, relu, sr; float inv_count;
-  uint8_t* stats; FrostFinDesc fin; unsigned fin_total;        // MODE 3 (forward statistics): the layer's statistics tables and the finalize folded into the last workgroup
+  uint8_t* stats; FrostFinDesc fin; unsigned fin_total; int ptpw; int64_t ntiles;      // k_pwc_stats: the layer's statistics tables, the finalize folded into the last workgroup, pixel tiles per workgroup
 };
 
 __device__ __forceinline__ void pwc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -24,10 +24,7 @@ __device__ __forceinline__ float pwc_dpp_add(float v) { return v + __int_as_floa
 __device__ __forceinline__ float pwc_row_sum(float v) { v = pwc_dpp_add<0x111>(v); v = pwc_dpp_add<0x112>(v); v = pwc_dpp_add<0x114>(v); v = pwc_dpp_add<0x118>(v); return v; }
 
 #define PWC_PX 64
-// MODE 0: reduce pass (S1 += gy, S2 += gy * xhat into the coefficient rows); MODE 1: dc pass; MODE 2: forward emit; MODE 3: forward STATISTICS (sum, sum of squares,
-// min, max of the conv output per channel -> the layer's replicated tables, finalize in the last workgroup: k_pw's M_STATS contract and arithmetic -- the MFMA
-// operands are swapped so that a lane owns ONE channel and 16 pixels, its fp32 square sums run in k_pw's order: bit-identical tables).  KSM: K steps of 64 input
-// channels (exact).
+// MODE 0: reduce pass (S1 += gy, S2 += gy * xhat into the coefficient rows); MODE 1: dc pass; MODE 2: forward emit.  KSM: K steps of 64 input channels (exact).
 template <int MODE, int KSM>
 __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -45,16 +42,7 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
   float* const l_f1 = (float*)(tW + cw); float* const l_f2 = l_f1 + cw;
   const int64_t p0 = tile * PWC_PX;
   const int CT = p.cpad >> 4;
-  // MODE 3: no gout window and no coefficient rows (they do not exist yet) -- [cw] weight sums | [cw] sum (i64) | [cw] sum of squares (u64) | [cw] min | [cw] max behind the x tile
-  long long* const q_s1 = (long long*)(smem + PWC_PX * p.kstr); unsigned long long* const q_s2 = (unsigned long long*)(q_s1 + cw);
-  int* const q_mn = (int*)(q_s2 + cw); int* const q_mx = q_mn + cw; int* const q_w = q_mx + cw;
-  if (MODE == 3) {
-    for (int i = tid; i < cw; i += 256) {
-      const int c2 = chunk_lo * 64 + i;
-      q_w[i] = c2 < p.c ? p.wsum[c2] : 0; q_s1[i] = 0; q_s2[i] = 0; q_mn[i] = INT32_MAX; q_mx[i] = INT32_MIN;
-    }
-  }
-  for (int i = tid; MODE != 3 && i < cw; i += 256) {
+  for (int i = tid; i < cw; i += 256) {
     const int c2 = chunk_lo * 64 + i; const bool ok = c2 < p.c;
     const int cc = ok ? c2 : 0;                  // every row unconditional from a clamped channel (a load under `ok ?` waits at its own join), zeroed afterwards
     float A = p.coef[FROST_COEF_A * p.cpad + cc], B = p.coef[FROST_COEF_B * p.cpad + cc], M = p.coef[FROST_COEF_M * p.cpad + cc], R = p.coef[FROST_COEF_R * p.cpad + cc];
@@ -107,50 +95,10 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
     for (int ks = 0; ks < KSM; ++ks) dst[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
   };
   uint4 gv[2]; v4i afr[KSM];
-  if (chunk_lo < chunk_hi) { if (MODE < 2) load_g(chunk_lo, gv); load_w(chunk_lo, afr); }
+  if (chunk_lo < chunk_hi) { if (MODE != 2) load_g(chunk_lo, gv); load_w(chunk_lo, afr); }
   __syncthreads();
 
   for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-    if (MODE == 3) {
-      // D'[pix][chan]: lane (j, g) holds channel w * 16 + j of the chunk, pixels t * 16 + 4 g + r
-      const int ci = (chunk - chunk_lo) * 64 + w * 16 + j;
-      v4i acc[4];
-      { const int c0 = -zpx * q_w[ci]; const v4i init = (v4i){c0, c0, c0, c0};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = init; }
-#pragma unroll
-      for (int ks = 0; ks < KSM; ++ks)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const v4i bfr = *(const v4i*)(xs + (t * 16 + j) * p.kstr + ks * 64 + g * 16);
-          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr, afr[ks], acc[t], 0, 0, 0);
-        }
-      if (chunk + 1 < chunk_hi) load_w(chunk + 1, afr);
-      int a1 = 0; float a2 = 0.0f; int mn = INT32_MAX, mx = INT32_MIN;
-      if (p0 + PWC_PX <= p.npix) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int v0 = acc[t][0], v1 = acc[t][1], v2 = acc[t][2], v3 = acc[t][3];
-          a1 += (v0 + v1) + (v2 + v3);
-          const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2, f3 = (float)v3;
-          a2 = fmaf(f0, f0, a2); a2 = fmaf(f1, f1, a2); a2 = fmaf(f2, f2, a2); a2 = fmaf(f3, f3, a2);
-          mn = min(mn, min(v0, v1)); mn = min(mn, min(v2, v3)); mx = max(mx, max(v0, v1)); mx = max(mx, max(v2, v3));
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int v = acc[t][r];
-            if ((p0 + t * 16 + 4 * g + r) < p.npix) { a1 += v; const float fv = (float)v; a2 = fmaf(fv, fv, a2); mn = min(mn, v); mx = max(mx, v); }
-          }
-      }
-      long long b1 = a1; double b2 = (double)a2;
-      b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32); b2 += __shfl_xor(b2, 16); b2 += __shfl_xor(b2, 32);
-      mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
-      if (g == 0) { q_s1[ci] = b1; q_s2[ci] = (unsigned long long)__double2ll_rn(b2); q_mn[ci] = mn; q_mx[ci] = mx; }      // one owner per channel: this workgroup visits it once
-      continue;
-    }
     uint8_t* const gw = gwin + ((chunk - chunk_lo) & 1) * (PWC_PX * 64 * 2);
     if (MODE != 2) {
       *(uint4*)(gw + (upx0 * 64 + part * 8) * 2) = gv[0];
@@ -255,33 +203,14 @@ __global__ __launch_bounds__(256, 4) void k_pwc(const PwcP p) {
       if (c2 < p.c) { atomicAdd(s12_dst(p.coef, p.cpad, 0) + c2, l_f1[i]); atomicAdd(s12_dst(p.coef, p.cpad, 1) + c2, l_f2[i]); }
     }
   }
-  if (MODE == 3) {
-    __syncthreads();
-    long long* g_s1 = (long long*)stats_copy(p.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
-    int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
-    for (int i = tid; i < cw; i += 256) {
-      const int c2 = chunk_lo * 64 + i;
-      if (c2 < p.c && q_mn[i] <= q_mx[i]) {
-        atomicAdd((unsigned long long*)&g_s1[c2], (unsigned long long)q_s1[i]); atomicAdd(&g_s2[c2], q_s2[i]);
-        atomicMin(&g_mn[c2], q_mn[i]); atomicMax(&g_mx[c2], q_mx[i]);
-      }
-    }
-    int* sflag = (int*)smem;                                    // (the x tile is dead: last_block_done2 starts with a workgroup barrier)
-    if (last_block_done2(p.fin.counter, p.fin_total, sflag)) {
-      float* sh = (float*)(smem + 16);
-      conv_finalize_dev(p.stats, p.npix, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
-                        p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
-    }
-  }
 }
 
 template <int MODE, int KSM>
 static int launch_pwc(PwcP& p, hipStream_t s) {
   const int cwmax = ((p.nchunk + p.csplit - 1) / p.csplit) * 64;
-  const size_t lds = MODE == 3 ? (size_t)PWC_PX * p.kstr + (size_t)cwmax * 28 + 64 : (size_t)PWC_PX * p.kstr + 2 * PWC_PX * 64 * 2 + (size_t)cwmax * 4 * 10 + 64;
+  const size_t lds = (size_t)PWC_PX * p.kstr + 2 * PWC_PX * 64 * 2 + (size_t)cwmax * 4 * 10 + 64;
   FROST_REQUIRE(lds <= 64 * 1024, "pwc: LDS budget exceeded");
   const int64_t tiles = (p.npix + PWC_PX - 1) / PWC_PX;
-  p.fin_total = (unsigned)(tiles * p.csplit);
   hipLaunchKernelGGL((k_pwc<MODE, KSM>), dim3((unsigned)(tiles * p.csplit)), dim3(256), lds, s, p);
   return frost_check_launch("pwc");
 }
@@ -338,28 +267,142 @@ extern "C" int frost_pwc_conv_fwd_emit(const int8_t* x, const float* qrec_x, con
   return 1;
 }
 
-// the forward statistics pass of the same layers with the finalize folded in (the contract of frost_pw_conv_fwd_fin, which routes here): k_pw walks ALL output channels of a
-// 128-pixel tile with 8 waves per workgroup -- at 14 x 14 / 7 x 7 that is < 1 workgroup per CU, each wave waiting on one weight fetch after the other (33 - 83 us for 3 - 6 us of
-// MFMA + VALU work, profiles/r06_layer_times_b512.txt); here tiles x channel splits give ~2000 workgroups of 4 waves.  Tables bit-identical to k_pw's.
-// Measured per layer at B = 512 (profiles/r06_pwc_stats_ab.txt): faster from Cout = 1280 up (the 7 x 7 expand convs and last_layer: 82 -> 50, 46 -> 41 us), SLOWER on the 14 x 14
-// layers (Cout 312 .. 864: 33 -> 40 us -- 3136 small workgroups, each ending in its own flush + ticket round trip, against k_pw's 512 persistent ones), hence the threshold.
+// The forward STATISTICS pass of the same layers with the finalize folded in (the contract of frost_pw_conv_fwd_fin, which routes here): sum, sum of squares, min, max of
+// the integer conv output per channel -> the layer's replicated tables (stats_copy), conv_finalize_dev in the last workgroup.  k_pw walks ALL output channels of a 128-pixel
+// tile with 8 waves per workgroup -- on the widest layers that is < 1 workgroup per CU, each wave waiting on one weight fetch after the other (46 - 83 us for 4 - 6 us of MFMA +
+// VALU work).  Here a workgroup owns `ptpw` 64-pixel tiles x a range of 64-channel chunks.  MFMA operands as k_pw's M_STATS: D'[pix][chan], a lane owns ONE channel and 16
+// pixels, the fp32 square sums run in k_pw's order and leave as integers -- tables bit-identical to k_pw's.
+template <int KSM>
+__global__ __launch_bounds__(256, 4) void k_pwc_stats(const PwcP p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* const xs = smem;                                   // [64][kstr]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int cs = (int)blockIdx.x % p.csplit; const int64_t grp = (int64_t)blockIdx.x / p.csplit;
+  const int chunk_lo = (cs * p.nchunk) / p.csplit, chunk_hi = ((cs + 1) * p.nchunk) / p.csplit;
+  const int cw = (chunk_hi - chunk_lo) * 64;
+  const int CT = p.cpad >> 4;
+  // behind the x tile: [cw] sum (i64) | [cw] sum of squares (u64) | [cw] min | [cw] max | [cw] weight sums -- every entry has ONE owner lane (wave = channel tile of the chunk)
+  long long* const q_s1 = (long long*)(smem + PWC_PX * p.kstr); unsigned long long* const q_s2 = (unsigned long long*)(q_s1 + cw);
+  int* const q_mn = (int*)(q_s2 + cw); int* const q_mx = q_mn + cw; int* const q_w = q_mx + cw;
+  for (int i = tid; i < cw; i += 256) {
+    const int c2 = chunk_lo * 64 + i;
+    q_w[i] = c2 < p.c ? p.wsum[c2] : 0; q_s1[i] = 0; q_s2[i] = 0; q_mn[i] = INT32_MAX; q_mx[i] = INT32_MIN;
+  }
+  const int zpx = __float_as_int(p.qx[FROST_Q_ZP]) - 128;
+  auto load_w = [&](int chunk, v4i (&dst)[KSM]) __attribute__((always_inline)) {
+    const int ct = min(chunk * 4 + w, CT - 1);
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) dst[ks] = *(const v4i*)(p.w + ((((int64_t)ct * KSM + ks) * 64 + lane) << 4));
+  };
+  const int upr = p.cin >> 3;
+  constexpr int XB = (PWC_PX * KSM * 8 + 255) / 256;
+  const int64_t t0 = grp * p.ptpw, t1 = (t0 + p.ptpw < p.ntiles) ? t0 + p.ptpw : p.ntiles;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t p0 = tile * PWC_PX;
+    {   // the tile's input rows: contiguous in HBM; rows past the tensor stay zero
+      const int64_t rows = p.npix - p0 < PWC_PX ? p.npix - p0 : PWC_PX; const int total = (int)rows * upr;
+      const int8_t* src = p.x + p0 * p.cin;
+      uint2 xv[XB];
+#pragma unroll
+      for (int i = 0; i < XB; ++i) { const int u = tid + i * 256; xv[i] = (u < total) ? *(const uint2*)(src + (int64_t)u * 8) : make_uint2(0, 0); }
+      if (tile > t0) __syncthreads();                         // the previous tile's fragment reads are done
+#pragma unroll
+      for (int i = 0; i < XB; ++i) {
+        const int u = tid + i * 256; const int row = u / upr, col = u - row * upr;
+        if (u < PWC_PX * upr) *(uint2*)(xs + row * p.kstr + col * 8) = xv[i];
+      }
+    }
+    v4i afr[KSM];
+    if (chunk_lo < chunk_hi) load_w(chunk_lo, afr);
+    __syncthreads();
+    const bool full = p0 + PWC_PX <= p.npix;
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
+      // D'[pix][chan]: lane (j, g) holds channel w * 16 + j of the chunk, pixels t * 16 + 4 g + r
+      const int ci = (chunk - chunk_lo) * 64 + w * 16 + j;
+      v4i acc[4];
+      { const int c0 = -zpx * q_w[ci]; const v4i init = (v4i){c0, c0, c0, c0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = init; }
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const v4i bfr = *(const v4i*)(xs + (t * 16 + j) * p.kstr + ks * 64 + g * 16);
+          acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bfr, afr[ks], acc[t], 0, 0, 0);
+        }
+      if (chunk + 1 < chunk_hi) load_w(chunk + 1, afr);
+      int a1 = 0; float a2 = 0.0f; int mn = INT32_MAX, mx = INT32_MIN;
+      if (full) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int v0 = acc[t][0], v1 = acc[t][1], v2 = acc[t][2], v3 = acc[t][3];
+          a1 += (v0 + v1) + (v2 + v3);
+          const float f0 = (float)v0, f1 = (float)v1, f2 = (float)v2, f3 = (float)v3;
+          a2 = fmaf(f0, f0, a2); a2 = fmaf(f1, f1, a2); a2 = fmaf(f2, f2, a2); a2 = fmaf(f3, f3, a2);
+          mn = min(mn, min(v0, v1)); mn = min(mn, min(v2, v3)); mx = max(mx, max(v0, v1)); mx = max(mx, max(v2, v3));
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int v = acc[t][r];
+            if ((p0 + t * 16 + 4 * g + r) < p.npix) { a1 += v; const float fv = (float)v; a2 = fmaf(fv, fv, a2); mn = min(mn, v); mx = max(mx, v); }
+          }
+      }
+      long long b1 = a1; double b2 = (double)a2;
+      b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32); b2 += __shfl_xor(b2, 16); b2 += __shfl_xor(b2, 32);
+      mn = min(mn, __shfl_xor(mn, 16)); mn = min(mn, __shfl_xor(mn, 32)); mx = max(mx, __shfl_xor(mx, 16)); mx = max(mx, __shfl_xor(mx, 32));
+      if (g == 0 && mn <= mx) {                              // the owner lane: plain read-modify-write (integers: the order of the tiles does not matter)
+        q_s1[ci] += b1; q_s2[ci] += (unsigned long long)__double2ll_rn(b2); q_mn[ci] = min(q_mn[ci], mn); q_mx[ci] = max(q_mx[ci], mx);
+      }
+    }
+  }
+  __syncthreads();
+  long long* g_s1 = (long long*)stats_copy(p.stats, p.cpad); unsigned long long* g_s2 = (unsigned long long*)(g_s1 + p.cpad);
+  int* g_mn = (int*)(g_s2 + p.cpad); int* g_mx = g_mn + p.cpad;
+  for (int i = tid; i < cw; i += 256) {
+    const int c2 = chunk_lo * 64 + i;
+    if (c2 < p.c && q_mn[i] <= q_mx[i]) {
+      atomicAdd((unsigned long long*)&g_s1[c2], (unsigned long long)q_s1[i]); atomicAdd(&g_s2[c2], q_s2[i]);
+      atomicMin(&g_mn[c2], q_mn[i]); atomicMax(&g_mx[c2], q_mx[i]);
+    }
+  }
+  int* sflag = (int*)smem;                                    // (the x tile is dead: last_block_done2 starts with a workgroup barrier)
+  if (last_block_done2(p.fin.counter, p.fin_total, sflag)) {
+    float* sh = (float*)(smem + 16);
+    conv_finalize_dev(p.stats, p.npix, p.c, p.cpad, p.qx, p.fin.qrec_w, p.fin.wscale, p.fin.gamma, p.fin.beta, p.fin.rmean, p.fin.rvar, p.fin.nbt,
+                      p.fin.training, p.fin.relu, p.fin.observe, 1, p.fin.coef, p.fin.qrec_y, tid, 256, sh, p.fin.cat_qrec_b, p.fin.cat_qrec_y);
+  }
+}
+
+// Measured (profiles/r06_pwc_stats_ab.txt, B = 512): with ONE tile per workgroup faster only from Cout = 1280 up (82 -> 50 us at 288 -> 1728) and slower on the 14 x 14 layers
+// (33 -> 40 us: 3136 small workgroups, each ending in its own flush + ticket round trip); with 4 tiles per workgroup equal or faster everywhere it applies, -0.04 ms in the step.
 int frost_pwc_stats_fin_ok(int64_t npix, int cin, int cout) {
-  static const int minc = getenv("FROST_PWC_STATS") ? atoi(getenv("FROST_PWC_STATS")) : 1024;        // smallest Cout it takes; 0 = off, 1 = every layer the chunked kernels take
+  static const int minc = getenv("FROST_PWC_STATS") ? atoi(getenv("FROST_PWC_STATS")) : 1;        // smallest Cout it takes (on top of frost_pwc_bwd_ok's 256); 0 = off
   return minc > 0 && cout >= minc && frost_pwc_bwd_ok(npix, cin, cout);
 }
 int frost_pwc_stats_fin(const int8_t* x, const float* qrec_x, const int8_t* wq_pack, const int32_t* wsum, int64_t npix, int cin, int cout, void* stats, const FrostFinDesc* fin,
                         hipStream_t s) {
   PwcP p = {};
-  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.npix = npix; p.cin = cin; p.c = cout; p.stats = (uint8_t*)stats; p.fin = *fin; p.qy = fin->qrec_y;
+  p.x = x; p.qx = qrec_x; p.w = wq_pack; p.wsum = wsum; p.npix = npix; p.cin = cin; p.c = cout; p.stats = (uint8_t*)stats; p.fin = *fin;
   p.cpad = round_up(cout, 16); const int KS = (cin + 63) / 64; p.kstr = KS * 64 + 16; p.nchunk = (cout + 63) / 64;
   static const int cpw_env = getenv("FROST_PWC_STATS_CPW") ? atoi(getenv("FROST_PWC_STATS_CPW")) : 0;
-  const int64_t tiles = (npix + PWC_PX - 1) / PWC_PX;
-  int cpw = cpw_env > 0 ? cpw_env : (int)((tiles * p.nchunk + 2047) / 2048);
+  static const int pt_env = getenv("FROST_PWC_STATS_PT") ? atoi(getenv("FROST_PWC_STATS_PT")) : 4;           // 64-pixel tiles per workgroup (1 / 2 / 4 / 8 measured: r06_pwc_stats_ab.txt)
+  p.ntiles = (npix + PWC_PX - 1) / PWC_PX;
+  p.ptpw = pt_env < 1 ? 1 : pt_env;
+  const int64_t groups = (p.ntiles + p.ptpw - 1) / p.ptpw;
+  int cpw = cpw_env > 0 ? cpw_env : (int)((groups * p.nchunk + 2047) / 2048);
   if (cpw < 2) cpw = 2;
   if (cpw > p.nchunk) cpw = p.nchunk;
   if (cpw > 12) cpw = 12;
   p.csplit = (p.nchunk + cpw - 1) / cpw;
-#define PWC_GO(KK) if (KS == KK) return launch_pwc<3, KK>(p, s);
+  p.fin_total = (unsigned)(groups * p.csplit);
+  const int cwmax = ((p.nchunk + p.csplit - 1) / p.csplit) * 64;
+  const size_t lds = (size_t)PWC_PX * p.kstr + (size_t)cwmax * 28 + 64;
+  FROST_REQUIRE(lds <= 64 * 1024, "pwc_stats: LDS budget exceeded");
+#define PWC_GO(KK) if (KS == KK) { hipLaunchKernelGGL((k_pwc_stats<KK>), dim3((unsigned)(groups * p.csplit)), dim3(256), lds, s, p); return frost_check_launch("pwc_stats"); }
   PWC_GO(1) PWC_GO(2) PWC_GO(3) PWC_GO(4) PWC_GO(5)
 #undef PWC_GO
   FROST_REQUIRE(false, "pwc_stats_fin: no instance");

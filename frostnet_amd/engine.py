@@ -550,12 +550,18 @@ class Engine:
         self.tape.append(("hswish", x, y, lut))
         return y
 
-    def hswish_converted(self, x, q_site, q_out):
+    def hswish_converted(self, x, q_site, q_out, owner=None):
         """The converted model's hard-swish on a quint8 activation (QFunctional.add_scalar -> nnq.ReLU6 -> QFunctional.mul at quant_mul1's frozen record -> mul_scalar):
-        a 256-entry table of the input index built on the device from the two records (csrc/frost_convert.hip k_hsw_cvt_lut), then one pass."""
-        lut = torch.empty(256, dtype=torch.uint8, device=self.device)
+        a 256-entry table of the input index built on the device from the two records (csrc/frost_convert.hip k_hsw_cvt_lut), then one pass.  `owner` (the conv layer):
+        the records are frozen after convert(), so the table is built once per (layer, records' version) and later forwards run the table pass alone."""
+        key = (x.q.data_ptr(), x.q._version, q_site._version)
+        cached = owner is not None and getattr(owner, "_hsw_cvt", None) is not None and owner._hsw_cvt[0] == key
+        lut = owner._hsw_cvt[1] if cached else torch.empty(256, dtype=torch.uint8, device=self.device)
         y = self.new_act(x.n, x.h, x.w, x.c, q_out)
-        call("frost_hswish_converted", ptr(x.buf), ptr(x.q), x.numel, ptr(q_site), ptr(q_out), ptr(lut), ptr(y.buf), stream(), prof=("hswish_converted", 2 * x.numel))
+        call("frost_hswish_converted", ptr(x.buf), ptr(x.q), x.numel, None if cached else ptr(q_site), ptr(q_out), ptr(lut), ptr(y.buf), stream(),
+             prof=("hswish_converted", 2 * x.numel))
+        if owner is not None and not cached:
+            owner._hsw_cvt = (key, lut)
         return y
 
     def head(self, l, x, drop_mask=None, observe=True):
@@ -586,6 +592,7 @@ class Engine:
         for l in self.layers:
             l.fold_rsqrt = True
             l._cfin_key = None
+            l._hsw_cvt = None
         self._table = None
         self._ensure_tables()
         call("frost_weight_prep", ptr(self._table), len(self.layers), self._max_elems, self.rule127, 1 if observe else 0, stream())
@@ -614,7 +621,7 @@ class Engine:
         if getattr(self, "trace", None) is not None:
             self.trace.append((l.name, y))
         if hsw is not None:                       # ConvBNHswish: the conv emitted linearly at its own record; the hard-swish is a table pass
-            y = self.hswish_converted(y, hsw[1], hsw[2])
+            y = self.hswish_converted(y, hsw[1], hsw[2], owner=l)
             if getattr(self, "trace", None) is not None:
                 self.trace.append((l.name + ".act", y))
         return y
@@ -632,7 +639,7 @@ class Engine:
         call("frost_stem_converted", ptr(x), n, h, w, *x.stride(), ptr(q_in), ptr(l.wq_pack), ptr(l.wsum), ptr(l.coef), ptr(l.qy), l.cout, 3 if fb else 2,
              ptr(y.buf), stream())
         if getattr(l, "hswish", None) is not None:
-            y = self.hswish_converted(y, l.hswish[1], l.hswish[2])
+            y = self.hswish_converted(y, l.hswish[1], l.hswish[2], owner=l)
         return y
 
     def _converted_coef(self, l, qx, fb):

@@ -659,7 +659,8 @@ int frost_hswish_fwd(const int8_t* x, const float* qrec_x, int64_t n, uint32_t* 
 int frost_hswish_bwd(const uint16_t* gout, const int8_t* x, int64_t n, const uint8_t* lut, uint16_t* dx, int accumulate, void* stream);
 /* replaces: the same `_Hswish` after torch.quantization.convert (Classification/evaluate.py:130-134 on a hard-swish network): QFunctional.add_scalar(x, 3) ->
  * nnq.ReLU6 -> QFunctional.mul(x, .) at quant_mul1's frozen record (qrec_site) -> mul_scalar(1/6), integer arithmetic on quint8 indices restated as a 256-entry
- * table of the input index (lut: >= 256 bytes).  qrec_out is written: qrec_site's indices at scale double(s) * (1/6).  n % 4 == 0. */
+ * table of the input index (lut: >= 256 bytes).  qrec_out is written: qrec_site's indices at scale double(s) * (1/6).  n % 4 == 0.
+ * qrec_site == NULL: `lut` and qrec_out were built by an earlier call on the same (frozen) records -- the table pass alone. */
 int frost_hswish_converted(const int8_t* x, const float* qrec_x, int64_t n, const float* qrec_site, float* qrec_out, uint8_t* lut, int8_t* y, void* stream);
 
 /* ---- SSD MultiBoxLoss (Object_Detection/layers/modules/multibox_loss.py:48-117 + layers/box_utils.py:71-139) ------------------------------------------------
