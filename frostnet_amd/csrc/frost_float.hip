@@ -628,7 +628,7 @@ static void launch_f_dw(int mode, int64_t grid, size_t lds, hipStream_t s, const
 // window slots); per output pixel S*k loads of 4 bytes, k*k packed FMAs in the same (ky, kx) order as k_f_dw -- the conv output is bit-identical --, one store.
 // SRC: x holds the KEPT CONV OUTPUT of the layer in front (conv1 of the bottleneck) instead of its activation: y1 = [relu](c1 * scale + bias) is applied as the
 // window is loaded (padding stays zero), so conv1's element-wise emit pass -- one read of c1 and one write of y1 -- never runs in training.
-template <int MODE, int K, int S, int GW, bool SRC, typename ET>
+template <int MODE, int K, int S, int GW, int SRC, typename ET>
 __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET* __restrict__ x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu,
                                                   ET* __restrict__ y, const FrostFDesc* dsrc, int relu_src) {
   constexpr int PAD = (K - 1) / 2, RPW = 64 / GW;
@@ -648,8 +648,8 @@ __global__ __launch_bounds__(256) void k_f_dw_row(const FrostFDesc* dp, const ET
       for (int kx = 0; kx < K; ++kx) wt[ky][kx] = *(const v2f*)(wf + (ky * K + kx) * cpad + ch);
     v2f sc = (v2f){1.0f, 1.0f}, bi = (v2f){0.0f, 0.0f};
     if (MODE == F_EMIT) { sc = *(const v2f*)(dp->coef + FC_SCALE * cpad + ch); bi = *(const v2f*)(dp->coef + FC_BIAS * cpad + ch); }
-    v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; bool shs = false;
-    if (SRC) { ssc = *(const v2f*)(dsrc->coef + FC_SCALE * cpad + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * cpad + ch); slo = relu_src ? 0.0f : -INFINITY; shs = relu_src == F_ACT_HSWISH; }
+    v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; constexpr bool shs = SRC == 2;          // (the source's activation is a template value: a per-element select costs the stencil kernels 20 - 60 %)
+    if (SRC) { ssc = *(const v2f*)(dsrc->coef + FC_SCALE * cpad + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * cpad + ch); slo = relu_src ? 0.0f : -INFINITY; }
     auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){f_act(fmaf(v[0], ssc[0], sbi[0]), slo, shs), f_act(fmaf(v[1], ssc[1], sbi[1]), slo, shs)} : v; };
     const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
     const int rows = n * ho;
@@ -735,8 +735,9 @@ static void launch_f_dw_row2(const FrostFDesc* desc, const ET* x, int n, int h, 
   constexpr int RPW = 64 / GW;
   const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
   int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
-  if (dsrc) hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, true, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
-  else hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, false, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
+  if (dsrc && relu_src == F_ACT_HSWISH) hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, 2, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
+  else if (dsrc) hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, 1, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
+  else hipLaunchKernelGGL((k_f_dw_row<MODE, K, S, GW, 0, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, desc, x, n, h, w, c, cpad, ho, wo, relu, out, dsrc, relu_src);
 }
 template <int MODE, int K, int S, typename ET>
 static void launch_f_dw_row(const FrostFDesc* desc, const ET* x, int n, int h, int w, int c, int cpad, int ho, int wo, int relu, ET* out, hipStream_t s,
@@ -805,7 +806,7 @@ extern "C" int frost_float_dw_src_f32(const FrostFDesc* desc, const float* conv_
 // A training forward keeps every layer's convolution output c (the statistics pass stores it), so the passes that only need c per element do not
 // recompute it:  F_EMIT: y = [relu](c*scale + bias)     F_BRED: S1 += g*m, S2 += g*m*xhat     F_BDC: dc = g*m*K1 + c*E + F     (m = z > 0 for ReLU layers)
 // c: dense [npix][ch]; gy / out rows of ldg / ldy elements.  Thread = 8 channels (fixed: coefficients and partial sums in registers) x strided pixels.
-template <int MODE, typename ET>
+template <int MODE, typename ET, bool HS = false>          // HS: a hard-swish layer (its own instances: a run-time test costs the ReLU instances 7 - 15 %)
 __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __restrict__ cv, int64_t npix, int c, int cpad, int relu,
                                               const ET* __restrict__ gy, int ldg, ET* __restrict__ y, int ldy) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(256) void k_f_ew(const FrostFDesc* dp, const ET* __
   SA s[8], q[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s[e] = (SA)0; q[e] = (SA)0; }
-  const float lo = relu ? 0.0f : -INFINITY; const bool hs = relu == F_ACT_HSWISH;
+  const float lo = relu ? 0.0f : -INFINITY; constexpr bool hs = HS;
   if (slot < PP) {
     for (int64_t p0 = slot; p0 < npix; p0 += 4 * PP) {          // four pixels per trip: their loads are in flight together
       typename FEl<ET>::R8 ra[4], rg[4];
@@ -897,9 +898,10 @@ static int float_ew_any(const FrostFDesc* desc, const ET* cv, int64_t npix, int 
   int64_t grid = (tot + 255) / 256; const int64_t cap = (mode == F_BRED) ? rcap : 8192; if (grid > cap) grid = cap;
   const int64_t gmin = (c8n + 255) / 256; if (grid < gmin) grid = gmin;
   const size_t lds = (mode == F_BRED) ? (size_t)2 * cpad * (sizeof(ET) == 4 ? 8 : 4) : 0;
-  if (mode == F_EMIT) hipLaunchKernelGGL((k_f_ew<F_EMIT, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
-  else if (mode == F_BRED) hipLaunchKernelGGL((k_f_ew<F_BRED, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
-  else hipLaunchKernelGGL((k_f_ew<F_BDC, ET>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy);
+#define FEW_GO(M) { if (relu == F_ACT_HSWISH) hipLaunchKernelGGL((k_f_ew<M, ET, true>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy); \
+                    else hipLaunchKernelGGL((k_f_ew<M, ET, false>), dim3((unsigned)grid), dim3(256), lds, s, desc, cv, npix, c, cpad, relu, gy, ldg, out, ldy); }
+  if (mode == F_EMIT) FEW_GO(F_EMIT) else if (mode == F_BRED) FEW_GO(F_BRED) else FEW_GO(F_BDC)
+#undef FEW_GO
   return frost_check_launch("float_ew");
 }
 extern "C" int frost_float_ew(const FrostFDesc* desc, const uint16_t* conv, int64_t npix, int c, int relu, int mode, const uint16_t* gy, int ldg,
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad(const ET* __restrict__ dc, c
 // along output rows with the k x k input window in registers -- per output pixel it loads the S new window columns (k loads of 4 bytes) and one dc value and
 // runs k*k packed FMAs, so dc and x are read ONCE (the form above reads both once per kernel row, in 64-byte segments).  The window's column slots rotate
 // with the output column ((ox*S + kx) mod k; the ox loop is unrolled k times so that every slot index is a compile-time constant: no register moves).
-template <int K, int S, int GW, bool SRC, typename ET>
+template <int K, int S, int GW, int SRC, typename ET>
 __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ dc, const ET* __restrict__ x, int n, int h, int w, int c, int ho, int wo,
                                                         float* __restrict__ dw, const FrostFDesc* dsrc, int relu_src) {
   // GW lanes (2 * GW channels) per output row, 64 / GW rows per wave: narrow layers (the biggest maps) keep every lane busy
@@ -1130,8 +1132,8 @@ __global__ __launch_bounds__(256) void k_f_dw_wgrad_row(const ET* __restrict__ d
   for (int ky = 0; ky < K; ++ky)
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) acc[ky][kx] = (v2f){0.0f, 0.0f};
-  v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; bool shs = false;          // SRC: x is the kept conv output of the layer in front (see k_f_dw_row<SRC>)
-  if (SRC && live) { const int scp = dsrc->cpad; ssc = *(const v2f*)(dsrc->coef + FC_SCALE * scp + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * scp + ch); slo = relu_src ? 0.0f : -INFINITY; shs = relu_src == F_ACT_HSWISH; }
+  v2f ssc = (v2f){1.0f, 1.0f}, sbi = (v2f){0.0f, 0.0f}; float slo = -INFINITY; constexpr bool shs = SRC == 2;          // SRC: x is the kept conv output of the layer in front (see k_f_dw_row<SRC>)
+  if (SRC && live) { const int scp = dsrc->cpad; ssc = *(const v2f*)(dsrc->coef + FC_SCALE * scp + ch); sbi = *(const v2f*)(dsrc->coef + FC_BIAS * scp + ch); slo = relu_src ? 0.0f : -INFINITY; }
   auto xf = [&](v2f v) __attribute__((always_inline)) { return SRC ? (v2f){f_act(fmaf(v[0], ssc[0], sbi[0]), slo, shs), f_act(fmaf(v[1], ssc[1], sbi[1]), slo, shs)} : v; };
   const int rows = n * ho;
   if (live) {
@@ -1212,8 +1214,9 @@ static void launch_f_dw_wgrad_row2(const ET* dc, const ET* x, int n, int h, int 
   constexpr int RPW = 64 / GW;
   const int groups = (c + 2 * GW - 1) / (2 * GW); const int rows = n * ho;
   int gx = (rows + 4 * RPW - 1) / (4 * RPW); int cap = wgs / groups; if (cap < 1) cap = 1; if (gx > cap) gx = cap;
-  if (dsrc) hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, true, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
-  else hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, false, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
+  if (dsrc && relu_src == F_ACT_HSWISH) hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, 2, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
+  else if (dsrc) hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, 1, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
+  else hipLaunchKernelGGL((k_f_dw_wgrad_row<K, S, GW, 0, ET>), dim3((unsigned)gx, groups), dim3(256), 0, s, dc, x, n, h, w, c, ho, wo, dw, dsrc, relu_src);
 }
 template <int K, int S, typename ET>
 static void launch_f_dw_wgrad_row(const ET* dc, const ET* x, int n, int h, int w, int c, int ho, int wo, float* dw, hipStream_t s, const FrostFDesc* dsrc, int relu_src) {

@@ -64,7 +64,10 @@ struct PwP {
 #ifndef PW_MI2
 #define PW_MI2 2
 #endif
-#define PW_MI(MODE, WP) (((WP) == 2) ? (((MODE) == M_DGRAD) ? PW_MI_DGRAD2 : PW_MI2) : 4)
+#ifndef PW_MI2_FWD
+#define PW_MI2_FWD 2      // ... the forward passes (statistics / emit) of the same split; 3 = one channel group for 9 .. 12 tiles (144 / 168 channels): measured, see DESIGN "Round 6"
+#endif
+#define PW_MI(MODE, WP) (((WP) == 2) ? (((MODE) == M_DGRAD) ? PW_MI_DGRAD2 : (((MODE) == M_STATS || (MODE) == M_EMIT) ? PW_MI2_FWD : PW_MI2)) : 4)
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v, int identity) {
   return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false);
