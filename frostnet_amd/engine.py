@@ -83,7 +83,7 @@ _SQ_BWD_CAT = os.environ.get("FROST_SQ_BWD_CAT", "0") != "0"
 
 class Act:
     """An NHWC activation held as offset-binary int8 indices plus its qrecord (scale / zero-point on device)."""
-    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done", "add_bwd", "bred_done")
+    __slots__ = ("buf", "n", "h", "w", "c", "q", "grad", "needs_grad", "cint", "sum_observed", "cat_observed", "kept_next", "cat_done", "add_bwd", "bred_done", "is_col")
 
     def __init__(self, buf, n, h, w, c, q):
         self.buf, self.n, self.h, self.w, self.c, self.q = buf, n, h, w, c, q
@@ -350,6 +350,17 @@ class Engine:
         else:
             raise ValueError(l.kind)
 
+
+    def stem_im2col(self, x):
+        """The stem's 3 x 3 / stride-2 patches of the quantised NHWC image as rows of 40 bytes (k = tap * 4 + channel): the input of the stem's pointwise
+        kernels, kept for its weight gradient.  Needs no weights, so the runner issues it BEFORE joining the weight-preparation stream."""
+        ho, wo = (x.h + 2 - 3) // 2 + 1, (x.w + 2 - 3) // 2 + 1
+        xc = self.new_act(x.n, ho, wo, 40, x.q)
+        call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream(), prof=("stem_im2col", x.numel + xc.numel))
+        xc.needs_grad = False
+        xc.is_col = True
+        return xc
+
     def conv(self, l, x, training=True, observe=True, residual=None, cat=None):
         """ConvBn(ReLU)2d QAT forward + activation fake-quant: stats pass -> finalize -> emit pass (recompute).
         residual = (a, q_sum): this layer is a bottleneck's reduce_conv whose output goes straight into skip_add.add(a, .) with FakeQuantize record
@@ -359,18 +370,16 @@ class Engine:
         q_cat: that record is updated in this layer's finalize tail (`cat_observed = True` on the result; Engine.cat skips frost_cat_observe)."""
         pad = (l.k - 1) // 2
         ho, wo = (x.h + 2 * pad - l.k) // l.stride + 1, (x.w + 2 * pad - l.k) // l.stride + 1
+        if getattr(x, "is_col", False):          # the stem's im2col ran already (Engine.stem_im2col: in front of the join with the weight-preparation stream)
+            ho, wo = x.h, x.w
         # frozen BatchNorm (`_freeze_stages`, frostnet_features.py:354-359: bn.eval() inside a training forward): this layer normalises with its running
         # statistics (finalize in eval form, nothing updated); its backward is the batch-statistics one minus the S1 / S2 terms (Engine._frozen_after_reduce)
         net_training = training
         l.frozen = bool(training and l.bn_mod is not None and not l.bn_mod.training)
         if l.frozen:
             training = False
-        if l.kind == "stem":      # im2col once (kept for the backward wgrad), then the pointwise int8-MFMA kernels
-            xc = self.new_act(x.n, ho, wo, 40, x.q)
-            call("frost_stem_im2col", ptr(x.buf), ptr(x.q), x.n, x.h, x.w, ptr(xc.buf), stream(),
-                 prof=("stem_im2col", x.numel + xc.numel))
-            xc.needs_grad = False
-            x = xc
+        if l.kind == "stem" and not getattr(x, "is_col", False):      # im2col once (kept for the backward wgrad), then the pointwise int8-MFMA kernels
+            x = self.stem_im2col(x)
         y = self.new_act(x.n, ho, wo, l.cout, l.qy)
         need_stats = training or observe
         if need_stats and _FIN_FOLD:

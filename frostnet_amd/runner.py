@@ -15,6 +15,7 @@ from .engine import ConvLayer, Engine, QArena
 
 
 _PREP_SPLIT = os.environ.get("FROST_PREP_SPLIT", "0") != "0"    # ... in two parts: the high-resolution stages' layers first, the rest joined in front of layer3 (A/B switch; measured +-0 inside the captured step, profiles/r06_prologue_ab.txt: off)
+_STEM_COL_EARLY = os.environ.get("FROST_STEM_COL_EARLY", "1") != "0"      # the stem's im2col in front of the join with the weight-preparation stream (A/B)
 _PREP_SIDE = os.environ.get("FROST_PREP_SIDE", "1") != "0"      # training: the per-step weight preparation on a second stream beside the QuantStub passes
 
 class _QATFunction(torch.autograd.Function):
@@ -587,6 +588,8 @@ class FrostRunner:
                     early.record()
                     E.begin_step(observe=obs, part=(split[0], len(E.layers)))
             a = E.quantize_input(x, self.q_in, observe=obs)
+            if _STEM_COL_EARLY and self.stem.kind == "stem" and getattr(E, "trace", None) is None:
+                a = E.stem_im2col(a)          # needs no weights: in front of the join (the join used to hold it back by the tail of the weight preparation)
             if split is None:
                 cur.wait_stream(E._prep_stream)
             else:
